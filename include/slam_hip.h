@@ -1,0 +1,135 @@
+/* libslamhip.so -- C ABI of the MI355X (gfx950) hot path behind SLAM-LLM's model plugin surface.
+ *
+ * The reference (X-LANCE/SLAM-LLM) has NO native code and NO FFI: every operator below replaces a
+ * PyTorch / HF-transformers / peft / openai-whisper library call made from the reference's Python glue.
+ * Each entry point cites the reference call site (file:line relative to the reference root) it serves.
+ * The ctypes binding a maintainer adds on the reference side is shown in INTEGRATION.md
+ * (slam_llm_amd/lib.py is that binding).
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers owned by the caller (torch tensors kept alive by the caller);
+ *    the library never allocates, never frees, never synchronises the stream or the device;
+ *  - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream), calls are thread-agnostic;
+ *  - bf16 tensors are raw uint16 bit patterns; leading dimensions (ld*) are in ELEMENTS;
+ *  - return 0 on success, < 0 on error; slam_last_error() returns a thread-local message;
+ *  - the binding must raise (RuntimeError) on non-zero -- there is no CPU fallback anywhere.
+ */
+#ifndef SLAM_HIP_H
+#define SLAM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM_BF16 0
+#define SLAM_F32 1
+#define SLAM_ACT_NONE 0
+#define SLAM_ACT_GELU 1 /* exact erf GELU (F.gelu, src/slam_llm/models/encoder.py:18-19) */
+#define SLAM_ACT_RELU 2 /* nn.ReLU, src/slam_llm/models/projector.py:25 */
+
+const char* slam_last_error(void);
+int slam_abi_version(void);
+const char* slam_target_arch(void); /* "gfx950" */
+
+/* ---- a1: log-mel front end ------------------------------------------------------------------
+ * whisper.pad_or_trim + whisper.log_mel_spectrogram, src/slam_llm/datasets/speech_dataset.py:101-103,
+ * src/slam_llm/datasets/speech_dataset_large.py:102-104.
+ * audio [B, ld_audio] f32; n_valid[b] (nullable) = samples of clip b that are real (rest treated as the
+ * zero padding of pad_or_trim); n_samples = padded length (480000); window400 = periodic Hann;
+ * twiddle_400x416 = [n][0..207]=cos(2*pi*n*k/400), [n][208..415]=sin; mel_filters_T [201, n_mels];
+ * out_mel [B, n_samples/160, n_mels] f32; workspace: slam_logmel_workspace_bytes(B) bytes. */
+int slam_logmel_workspace_bytes(int64_t B);
+int slam_logmel_fwd(const float* audio, int64_t ld_audio, const int32_t* n_valid, int64_t n_samples,
+                    const float* window400, const float* twiddle_400x416, const float* mel_filters_T,
+                    int64_t n_mels, float* out_mel, int32_t* workspace, int64_t B, void* stream);
+
+/* ---- GEMM: every Linear / Conv1d-as-GEMM / lm_head on the path ---------------------------------
+ * C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): +bias[N] (f32), act, +residual[(m % res_row_mod), n] (bf16),
+ * optional accumulate into C, C bf16 or f32.  K % 64 == 0, N % 4 == 0, 16-byte aligned operands.
+ * Sites: Whisper linears/convs (src/slam_llm/models/encoder.py:18-29), projector (projector.py:24-26),
+ * Llama linears + lm_head (slam_model.py:400), and all their backward products (via stored W^T). */
+int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                      int64_t M, int64_t N, int64_t K, const float* bias, const void* residual,
+                      int64_t ldr, int64_t res_row_mod, int act, float alpha, int out_dtype,
+                      int accumulate, void* stream);
+/* tile configuration override: 0 auto, 1 128x128/4 waves, 2 256x128/8 waves, 3 128x64, 4 256x256/8 waves */
+int slam_gemm_set_config(int cfg);
+
+/* ---- conv front end (src/slam_llm/models/encoder.py:18-19): k=3, pad=1 im2col, stride 1|2 ---------
+ * in [B, Tin, C] (f32 or bf16) -> out [B*Tout, Kp] bf16, column j*C + c = in[b, t*stride + j - 1, c]. */
+int slam_conv1d_k3_im2col(const void* in, int in_dtype, void* out, int64_t B, int64_t Tin, int64_t C,
+                          int64_t stride, int64_t Kp, void* stream);
+
+/* ---- norms -------------------------------------------------------------------------------------
+ * LayerNorm (Whisper blocks + ln_post, encoder.py:26-29; fp32 statistics), RMSNorm fwd/bwd (Llama). */
+int slam_layernorm_fwd(const void* x, int64_t ldx, const float* weight, const float* bias, void* y,
+                       int64_t ldy, int64_t M, int64_t d, float eps, void* stream);
+int slam_rmsnorm_fwd(const void* x, int64_t ldx, const float* weight, void* y, int64_t ldy, float* rstd,
+                     int64_t M, int64_t d, float eps, void* stream);
+/* dx = rmsnorm'(dy) * (*grad_scale or 1) + dres (nullable) */
+int slam_rmsnorm_bwd(const void* x, int64_t ldx, const float* rstd, const float* weight, const void* dy,
+                     int64_t lddy, const void* dres, int64_t lddres, void* dx, int64_t lddx,
+                     const float* grad_scale, int64_t M, int64_t d, void* stream);
+
+/* ---- RoPE + head transposes (HF apply_rotary_pos_emb; positions = arange(T)) -------------
+ * src rows (b*T+t), columns col0 + h*D + d, rotated IN PLACE when cos/sin tables [T, D/2] are given
+ * (inverse != 0 applies the transposed rotation = RoPE backward); dstT (nullable) [B,H,D,Tp] gets the
+ * (rotated) values transposed, zero padded to Tp (multiple of 64). */
+int slam_head_rope_transpose(void* src, int64_t ld, int64_t col0, const float* cos_table,
+                             const float* sin_table, int inverse, void* dstT, int64_t B, int64_t T,
+                             int64_t Tp, int64_t H, int64_t D, void* stream);
+int slam_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t R, int64_t C,
+                        int64_t Rp, void* stream);
+
+/* ---- attention (Whisper blocks: bidirectional, no mask; Llama: causal ^ key padding, GQA) -----------
+ * Q/K/V/O/dO row-major [B*T, ld] with head h at column h*D; Vt/Kt/Qt/dOt = [B,H,D,Tp] transposed copies;
+ * LSE/Delta [B,Hq,Tp] f32; key_mask [B,Tp] uint8 (1 = attend, zero padded) or NULL; D in {64,128}. */
+int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, void* O,
+                  int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B, int64_t T, int64_t Tp,
+                  int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale, void* stream);
+int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                  const void* Qt, const void* Kt, const void* O, int64_t ldo, const void* dO,
+                  int64_t lddo, const void* dOt, const float* LSE, float* Delta, const uint8_t* key_mask,
+                  void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv, int64_t B,
+                  int64_t T, int64_t Tp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
+                  void* stream);
+
+/* ---- SwiGLU (LlamaMLP) : gate_up [M, 2F] = [gate | up] ---------------------------------------------- */
+int slam_swiglu_fwd(const void* gate_up, int64_t ldgu, void* h, int64_t ldh, int64_t M, int64_t F,
+                    void* stream);
+int slam_swiglu_bwd(const void* gate_up, int64_t ldgu, const void* dh, int64_t lddh, void* dgate_up,
+                    int64_t lddgu, int64_t M, int64_t F, void* stream);
+
+/* ---- embed + audio splice (src/slam_llm/models/slam_model.py:370-392) and its backward --------------
+ * input_ids int64 [B,T] (-1 -> 0 in place), modality_mask uint8 [B,T], enc = projector output [B,Ta,ldenc],
+ * out [B*T, ldo]; spans int32 [B,2] (start,len) is produced by fwd and consumed by bwd. No host sync. */
+int slam_embed_splice_fwd(int64_t* input_ids, const uint8_t* modality_mask, const void* embed_table,
+                          int64_t vocab, const void* enc, int64_t ldenc, void* out, int64_t ldo,
+                          int32_t* spans, int64_t B, int64_t T, int64_t Ta, int64_t d, void* stream);
+int slam_embed_splice_bwd(const int32_t* spans, const void* dX, int64_t lddx, void* denc, int64_t ldde,
+                          int64_t B, int64_t T, int64_t Ta, int64_t d, void* stream);
+
+/* ---- loss + accuracy (HF ForCausalLMLoss; slam_model.py:402-405; utils/metric.py:3-19) --------------
+ * targets[b*T+t] = labels[b,t+1] (or -1 when ignored / t = T-1); n_valid = #valid targets (device int). */
+int slam_ce_targets(const int64_t* labels, int32_t* targets, int32_t* n_valid, int64_t B, int64_t T,
+                    int64_t ignore_index, void* stream);
+/* per row: loss, argmax==target; when write_grad, logits are overwritten by dlogits = (softmax-onehot)/n_valid */
+int slam_ce_fwd_bwd(void* logits, int64_t ld, const int32_t* targets, const int32_t* n_valid,
+                    float* row_loss, int32_t* row_correct, int64_t rows, int64_t V, int write_grad,
+                    void* stream);
+/* out2[0] = mean loss over valid targets, out2[1] = accuracy */
+int slam_ce_finalize(const float* row_loss, const int32_t* row_correct, const int32_t* n_valid,
+                     int64_t rows, float* out2, void* stream);
+
+/* ---- optimizer (torch.optim.AdamW, src/slam_llm/pipeline/finetune.py:247-251) ------------------------
+ * one fused pass over the flat trainable buffer; also refreshes the bf16 compute copy (nullable). */
+int slam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
+                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    int64_t step, float grad_scale, void* stream);
+int slam_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM_HIP_H */

@@ -1,0 +1,12 @@
+"""Golden-fixture case table shared by oracle/make_golden.py and the tests -- TEST INFRASTRUCTURE."""
+from oracle import slam_oracle as O
+
+CASES = {
+    # MHA-ish GQA(2q/1kv), hd 64, left-padded ragged answers (exercises g3/g4 padding semantics)
+    "step_tiny": dict(cfg=O.make_config(), clip_seconds=2.0, answer_lens=(5, 9), left_pad=True),
+    # hd 128, GQA 4q/2kv, 128 mel bins, LoRA r16 on q,k,v,o, right-pad collator (aispeech_asr layout)
+    "step_hd128": dict(cfg=O.make_config(n_mels=128, enc_dim=128, enc_heads=2, llm_dim=256, llm_heads=4, llm_kv_heads=2,
+                                         llm_head_dim=128, llm_ffn=512, vocab=1024, rope_theta=500000.0, lora_r=16,
+                                         lora_alpha=32, lora_targets=("q_proj", "k_proj", "v_proj", "o_proj")),
+                       clip_seconds=3.0, answer_lens=(7, 3, 11), left_pad=False),
+}

@@ -1,0 +1,454 @@
+"""CPU oracle for the SLAM-LLM hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch fp32 restatement of the reference's algorithm for the path
+speech-encoder -> projector -> (frozen LLM + LoRA) training step.  It is the checker for the HIP kernels:
+only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it; the product
+(`slam_llm_amd/`) never does and has no CPU fallback.
+
+PARITY PINNING.  The reference's own test-suite pins nothing on this path ("parity
+unpinned" by the reference).  The oracle is therefore pinned against outputs of the reference ITSELF run in the
+authoring container: `oracle/make_golden.py` imports the reference's `slam_model.forward`
+(src/slam_llm/models/slam_model.py:283-407) and `EncoderProjectorConcat` (models/projector.py:5-27) unmodified,
+drives HF `WhisperEncoder` submodules with the reference's variable-length forward (models/encoder.py:13-30),
+HF `LlamaForCausalLM`, a peft-0.6.0-equivalent LoRA wrapper and `torch.optim.AdamW`, and stores the results
+under `tests/golden/*.npz`; `tests/test_oracle_golden.py` checks this file against those fixtures.
+
+Third-party arithmetic that is NOT under /root/reference and is restated here from its published algorithm:
+  openai-whisper (unpinned)   audio.py log_mel_spectrogram / model.py AudioEncoder
+  transformers  (v4.35.2)     LlamaForCausalLM, loss
+  peft          (v0.6.0)      LoRA Linear
+  torch         (2.0.1)       AdamW, LambdaLR
+Weights are a flat {name: fp32 tensor} dict using the reference's state_dict names.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SAMPLE_RATE, N_FFT, HOP, N_SAMPLES = 16000, 400, 160, 480000
+
+
+# ---------------------------------------------------------------------------------------------- a1: log-mel
+def mel_filters(n_mels: int) -> torch.Tensor:
+    """librosa slaney mel filterbank [n_mels, 201] (openai-whisper assets/mel_filters.npz; HF twin:
+    transformers/audio_utils.py mel_filter_bank(norm='slaney', mel_scale='slaney'))."""
+    def hz2mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-10) / 1000.0) * (27.0 / np.log(6.4)), 3.0 * f / 200.0)
+
+    def mel2hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), 200.0 * m / 3.0)
+
+    freqs = np.linspace(0, SAMPLE_RATE / 2, N_FFT // 2 + 1)
+    pts = mel2hz(np.linspace(hz2mel(0.0), hz2mel(SAMPLE_RATE / 2), n_mels + 2))
+    fdiff = np.diff(pts)
+    ramps = pts[:, None] - freqs[None, :]
+    w = np.maximum(0, np.minimum(-ramps[:-2] / fdiff[:-1, None], ramps[2:] / fdiff[1:, None]))
+    w *= (2.0 / (pts[2:] - pts[:-2]))[:, None]
+    return torch.from_numpy(w.astype(np.float32))
+
+
+def pad_or_trim(audio: torch.Tensor, length: int = N_SAMPLES) -> torch.Tensor:
+    """whisper.pad_or_trim (called at src/slam_llm/datasets/speech_dataset.py:101)."""
+    n = audio.shape[-1]
+    if n > length:
+        return audio[..., :length]
+    if n < length:
+        return F.pad(audio, (0, length - n))
+    return audio
+
+
+def log_mel_spectrogram(audio: torch.Tensor, n_mels: int) -> torch.Tensor:
+    """whisper.log_mel_spectrogram (speech_dataset.py:103); returns [n_mels, n_frames].  The per-clip
+    `max - 8` floor is taken over all frames incl. the zero-padded tail."""
+    window = torch.hann_window(N_FFT)
+    stft = torch.stft(audio.float(), N_FFT, HOP, window=window, return_complex=True)
+    mag = stft[..., :-1].abs() ** 2
+    mel = mel_filters(n_mels) @ mag
+    log_spec = torch.clamp(mel, min=1e-10).log10()
+    if log_spec.dim() == 2:
+        log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
+    else:
+        log_spec = torch.maximum(log_spec, log_spec.amax(dim=(-2, -1), keepdim=True) - 8.0)
+    return (log_spec + 4.0) / 4.0
+
+
+# ---------------------------------------------------------------------------------------------- a2: whisper encoder
+def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> torch.Tensor:
+    """openai-whisper model.py sinusoids(): the encoder's fixed positional embedding."""
+    inc = math.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2))
+    t = torch.arange(length)[:, None] * inv[None, :]
+    return torch.cat([t.sin(), t.cos()], dim=1)
+
+
+def _ln(x, w, b, eps=1e-5):
+    return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps).type(x.dtype)
+
+
+def whisper_encoder(W: Dict[str, torch.Tensor], cfg: dict, mel_bct: torch.Tensor, prefix="encoder.") -> torch.Tensor:
+    """extract_variable_length_features, src/slam_llm/models/encoder.py:13-30, on openai-whisper's
+    AudioEncoder (pre-LN blocks; key projection has no bias; q,k each scaled by hd^-0.25; no mask).
+    mel_bct: [B, n_mels, T] -> [B, ceil(T/2), d]."""
+    H = cfg["enc_heads"]
+    x = F.gelu(F.conv1d(mel_bct, W[prefix + "conv1.weight"], W[prefix + "conv1.bias"], padding=1))
+    x = F.gelu(F.conv1d(x, W[prefix + "conv2.weight"], W[prefix + "conv2.bias"], stride=2, padding=1))
+    x = x.permute(0, 2, 1)
+    x = (x + W[prefix + "positional_embedding"][: x.shape[1]]).to(x.dtype)
+    B, T, d = x.shape
+    hd = d // H
+    for i in range(cfg["enc_layers"]):
+        p = f"{prefix}blocks.{i}."
+        h = _ln(x, W[p + "attn_ln.weight"], W[p + "attn_ln.bias"])
+        q = F.linear(h, W[p + "attn.query.weight"], W[p + "attn.query.bias"])
+        k = F.linear(h, W[p + "attn.key.weight"])
+        v = F.linear(h, W[p + "attn.value.weight"], W[p + "attn.value.bias"])
+        scale = hd ** -0.25
+        q = q.view(B, T, H, hd).permute(0, 2, 1, 3) * scale
+        k = k.view(B, T, H, hd).permute(0, 2, 3, 1) * scale
+        v = v.view(B, T, H, hd).permute(0, 2, 1, 3)
+        w = F.softmax((q @ k).float(), dim=-1).to(q.dtype)
+        a = (w @ v).permute(0, 2, 1, 3).flatten(start_dim=2)
+        x = x + F.linear(a, W[p + "attn.out.weight"], W[p + "attn.out.bias"])
+        h = _ln(x, W[p + "mlp_ln.weight"], W[p + "mlp_ln.bias"])
+        h = F.linear(F.gelu(F.linear(h, W[p + "mlp.0.weight"], W[p + "mlp.0.bias"])), W[p + "mlp.2.weight"], W[p + "mlp.2.bias"])
+        x = x + h
+    return _ln(x, W[prefix + "ln_post.weight"], W[prefix + "ln_post.bias"])
+
+
+# ---------------------------------------------------------------------------------------------- a3: projector
+def projector_concat(W, x: torch.Tensor, k: int, prefix="encoder_projector.") -> torch.Tensor:
+    """EncoderProjectorConcat.forward, src/slam_llm/models/projector.py:15-27."""
+    B, T, d = x.shape
+    drop = T % k
+    if drop > 0:
+        x = x[:, :-drop, :]
+    x = x.contiguous().view(B, x.shape[1] // k, d * k)
+    x = F.relu(F.linear(x, W[prefix + "linear1.weight"], W[prefix + "linear1.bias"]))
+    return F.linear(x, W[prefix + "linear2.weight"], W[prefix + "linear2.bias"])
+
+
+# ---------------------------------------------------------------------------------------------- a4: embed + splice
+def embed_splice(embed_weight, input_ids, modality_mask, encoder_outs):
+    """src/slam_llm/models/slam_model.py:370-392 (input_ids is mutated in place like the reference)."""
+    input_ids[input_ids == -1] = 0
+    inputs_embeds = F.embedding(input_ids, embed_weight)
+    start = (modality_mask == True).float().argmax(dim=1)  # noqa: E712
+    lengths = torch.clamp(modality_mask.sum(dim=1), max=encoder_outs.shape[1]).tolist()
+    pad = torch.zeros_like(inputs_embeds)
+    for i in range(encoder_outs.shape[0]):
+        pad[i, start[i]: start[i] + lengths[i]] = encoder_outs[i][: lengths[i]]
+    return pad + inputs_embeds * (~modality_mask[:, :, None])
+
+
+# ---------------------------------------------------------------------------------------------- a5/a6: llama + LoRA
+def _rmsnorm(x, w, eps):
+    dt = x.dtype
+    v = x.float().pow(2).mean(-1, keepdim=True)
+    return w * (x.float() * torch.rsqrt(v + eps)).to(dt)
+
+
+def rope_tables(T: int, D: int, theta: float):
+    inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    freqs = torch.arange(T, dtype=torch.float32)[:, None] * inv[None, :]
+    emb = torch.cat([freqs, freqs], dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def _rot_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat([-x[..., h:], x[..., :h]], dim=-1)
+
+
+def lora_linear(W, name: str, x: torch.Tensor, cfg: dict) -> torch.Tensor:
+    """peft 0.6.0 LoRA Linear: F.linear(x, W) + lora_B(lora_A(dropout(x))) * (alpha / r); dropout = 0 for parity."""
+    y = F.linear(x, W[name + ".weight"])
+    a = W.get(name + ".lora_A.default.weight")
+    if a is not None:
+        b = W[name + ".lora_B.default.weight"]
+        y = y + F.linear(F.linear(x, a), b) * (cfg["lora_alpha"] / cfg["lora_r"])
+    return y
+
+
+def llama_forward(W, cfg, inputs_embeds, attention_mask, labels=None, prefix="llm.base_model.model."):
+    """HF LlamaForCausalLM(inputs_embeds, attention_mask, labels) as called at slam_model.py:400
+    (transformers/models/llama/modeling_llama.py; loss transformers/loss/loss_utils.py:32-70).
+    positions = arange(T) for every row; mask = causal ^ key padding, additive finfo.min."""
+    B, T, d = inputs_embeds.shape
+    Hq, Hkv, D = cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"]
+    eps = cfg["rms_eps"]
+    cos, sin = rope_tables(T, D, cfg["rope_theta"])
+    minv = torch.finfo(torch.float32).min
+    causal = torch.tril(torch.ones(T, T, dtype=torch.bool))
+    allowed = causal[None, None] & attention_mask.bool()[:, None, None, :]
+    add_mask = torch.zeros(B, 1, T, T).masked_fill(~allowed, minv)
+    h = inputs_embeds
+    for i in range(cfg["llm_layers"]):
+        p = f"{prefix}model.layers.{i}."
+        res = h
+        x = _rmsnorm(h, W[p + "input_layernorm.weight"], eps)
+        q = lora_linear(W, p + "self_attn.q_proj", x, cfg).view(B, T, Hq, D).transpose(1, 2)
+        k = lora_linear(W, p + "self_attn.k_proj", x, cfg).view(B, T, Hkv, D).transpose(1, 2)
+        v = lora_linear(W, p + "self_attn.v_proj", x, cfg).view(B, T, Hkv, D).transpose(1, 2)
+        q = q * cos + _rot_half(q) * sin
+        k = k * cos + _rot_half(k) * sin
+        rep = Hq // Hkv
+        k = k[:, :, None].expand(B, Hkv, rep, T, D).reshape(B, Hq, T, D)
+        v = v[:, :, None].expand(B, Hkv, rep, T, D).reshape(B, Hq, T, D)
+        att = (q @ k.transpose(2, 3)) * (D ** -0.5) + add_mask
+        att = F.softmax(att, dim=-1, dtype=torch.float32)
+        o = (att @ v).transpose(1, 2).reshape(B, T, Hq * D)
+        h = res + lora_linear(W, p + "self_attn.o_proj", o, cfg)
+        res = h
+        x = _rmsnorm(h, W[p + "post_attention_layernorm.weight"], eps)
+        g = lora_linear(W, p + "mlp.gate_proj", x, cfg)
+        u = lora_linear(W, p + "mlp.up_proj", x, cfg)
+        h = res + lora_linear(W, p + "mlp.down_proj", F.silu(g) * u, cfg)
+    h = _rmsnorm(h, W[prefix + "model.norm.weight"], eps)
+    logits = F.linear(h, W[prefix + "lm_head.weight"])
+    loss = None
+    if labels is not None:
+        lg = logits.float()
+        sl = F.pad(labels, (0, 1), value=-100)[..., 1:].contiguous()
+        loss = F.cross_entropy(lg.view(-1, lg.shape[-1]), sl.view(-1), ignore_index=-100, reduction="mean")
+    return loss, logits
+
+
+def compute_accuracy(pad_outputs, pad_targets, ignore_label=-100):
+    """src/slam_llm/utils/metric.py:3-19."""
+    mask = pad_targets != ignore_label
+    num = torch.sum(pad_outputs.masked_select(mask) == pad_targets.masked_select(mask))
+    return num.float() / torch.sum(mask).float()
+
+
+def slam_forward(W, cfg, batch: dict):
+    """slam_model.forward, src/slam_llm/models/slam_model.py:283-407, whisper + linear projector branch.
+    Returns (loss, logits, acc, aux dict of intermediates)."""
+    mel = batch["audio_mel"]
+    enc = whisper_encoder(W, cfg, mel.permute(0, 2, 1))
+    proj = projector_concat(W, enc, cfg["ds_rate"])
+    ids = batch["input_ids"].clone()
+    emb_w = W["llm.base_model.model.model.embed_tokens.weight"]
+    embeds = embed_splice(emb_w, ids, batch["modality_mask"].bool(), proj)
+    loss, logits = llama_forward(W, cfg, embeds, batch["attention_mask"], batch.get("labels"))
+    acc = None
+    if batch.get("labels") is not None:
+        preds = torch.argmax(logits, -1)
+        acc = compute_accuracy(preds[:, :-1], batch["labels"][:, 1:], -100)
+    return loss, logits, acc, {"encoder_out": enc, "projector_out": proj, "inputs_embeds": embeds}
+
+
+TRAINABLE_MARKERS = ("encoder_projector.", "lora_A", "lora_B")
+
+
+def trainable_names(W) -> List[str]:
+    return [n for n in W if any(m in n for m in TRAINABLE_MARKERS)]
+
+
+def lr_lambda(step: int, warmup: int, total: int) -> float:
+    """src/slam_llm/pipeline/finetune.py:253-260."""
+    if step < warmup:
+        return min(step / warmup, 1)
+    return max(0.0, 1 - (step - warmup) / (total - warmup))
+
+
+def train_steps(W, cfg, batches: List[dict], lr=1e-4, weight_decay=0.0, warmup=1000, total=100000):
+    """Loop body of src/slam_llm/utils/train_utils.py:112-169 (fp32, no autocast, grad-accum 1) with
+    torch.optim.AdamW + LambdaLR as built at pipeline/finetune.py:247-260.  Mutates W in place."""
+    names = trainable_names(W)
+    for n in W:
+        W[n].requires_grad_(n in names)
+    params = [W[n] for n in names]
+    opt = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: lr_lambda(s, warmup, total))
+    out = []
+    for batch in batches:
+        loss, logits, acc, _ = slam_forward(W, cfg, batch)
+        loss.backward()
+        grads = {n: W[n].grad.detach().clone() for n in names}
+        opt.step()
+        sched.step()
+        opt.zero_grad()
+        out.append({"loss": loss.detach(), "acc": acc, "grads": grads})
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- a9: batcher + collators
+def window_class(elem_len: int, buffer_lens: List[int], max_frame_length: int) -> bool:
+    """src/slam_llm/datasets/speech_dataset_large.py:259-263 on sequence lengths."""
+    if len(buffer_lens) == 0:
+        return True
+    return (len(buffer_lens) + 1) * max(elem_len, max(buffer_lens)) > max_frame_length
+
+
+def dynamic_batches(lengths: List[int], max_frame_length: int) -> List[List[int]]:
+    """MultiTaskDynamicBatchDataset.__iter__, speech_dataset_large.py:244-256: returns index groups."""
+    out, buf = [], []
+    for i, n in enumerate(lengths):
+        if not window_class(n, [lengths[j] for j in buf], max_frame_length):
+            buf.append(i)
+        else:
+            if buf:
+                out.append(buf)
+            buf = [i]
+    if buf:
+        out.append(buf)
+    return out
+
+
+def make_sample(audio_length: int, prompt_ids: List[int], answer_ids: List[int], eos: int):
+    """token layout of SpeechDatasetJsonl.__getitem__, src/slam_llm/datasets/speech_dataset.py:109-161."""
+    ids = torch.tensor([-1] * audio_length + list(prompt_ids) + list(answer_ids) + [eos], dtype=torch.int64)
+    labels = ids.clone()
+    labels[: audio_length + len(prompt_ids)] = -1
+    mask = ids.ge(-1)
+    label_mask = labels.ge(0)
+    ids[~mask] = 0
+    labels[~label_mask] = -100
+    return {"input_ids": ids, "labels": labels, "attention_mask": mask, "audio_length": audio_length,
+            "prompt_length": len(prompt_ids)}
+
+
+def collate_left_pad(samples: List[dict], pad_id: int, mels: Optional[List[torch.Tensor]] = None) -> dict:
+    """SpeechDatasetJsonl.collator, speech_dataset.py:216-291: [audio,prompt] left-padded, answer right-padded."""
+    pl = [s["audio_length"] + s["prompt_length"] for s in samples]
+    al = [len(s["input_ids"]) - p for s, p in zip(samples, pl)]
+    pm, am = max(pl), max(al)
+
+    def pad(t, left, right, v):
+        return torch.cat([torch.full((left,), v, dtype=t.dtype), t, torch.full((right,), v, dtype=t.dtype)])
+
+    out = {
+        "input_ids": torch.stack([pad(s["input_ids"], pm - p, am - a, pad_id) for s, p, a in zip(samples, pl, al)]),
+        "labels": torch.stack([pad(s["labels"], pm - p, am - a, -100) for s, p, a in zip(samples, pl, al)]),
+        "attention_mask": torch.stack([pad(s["attention_mask"], pm - p, am - a, False) for s, p, a in zip(samples, pl, al)]),
+    }
+    mm = torch.zeros_like(out["attention_mask"])
+    for i, (s, p) in enumerate(zip(samples, pl)):
+        mm[i, pm - p: pm - p + s["audio_length"]] = True
+    out["modality_mask"] = mm
+    if mels is not None:
+        tm = max(m.shape[0] for m in mels)
+        out["audio_mel"] = torch.stack([F.pad(m, (0, 0, 0, tm - m.shape[0])) for m in mels])
+        pm_ = torch.zeros(len(mels), (tm + 1) // 2)
+        for i, m in enumerate(mels):
+            pm_[i, : (m.shape[0] + 1) // 2] = 1
+        out["audio_mel_post_mask"] = pm_
+    return out
+
+
+def collate_right_pad(samples: List[dict], pad_id: int, mels: Optional[List[torch.Tensor]] = None) -> dict:
+    """MultiTaskDataset.collator, speech_dataset_large.py:180-233: right padding only, audio at [0, audio_length)."""
+    tm = max(len(s["input_ids"]) for s in samples)
+
+    def pad(t, v):
+        return torch.cat([t, torch.full((tm - len(t),), v, dtype=t.dtype)])
+
+    out = {
+        "input_ids": torch.stack([pad(s["input_ids"], pad_id) for s in samples]),
+        "labels": torch.stack([pad(s["labels"], -100) for s in samples]),
+        "attention_mask": torch.stack([pad(s["attention_mask"], False) for s in samples]),
+    }
+    mm = torch.zeros_like(out["attention_mask"])
+    for i, s in enumerate(samples):
+        mm[i, : s["audio_length"]] = True
+    out["modality_mask"] = mm
+    if mels is not None:
+        t2 = max(m.shape[0] for m in mels)
+        out["audio_mel"] = torch.stack([F.pad(m, (0, 0, 0, t2 - m.shape[0])) for m in mels])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- synthetic weights / batches
+def make_config(**kw) -> dict:
+    cfg = dict(n_mels=80, enc_dim=64, enc_heads=2, enc_layers=2, enc_ctx=1500, ds_rate=5, proj_hidden=2048,
+               llm_dim=128, llm_layers=2, llm_heads=2, llm_kv_heads=1, llm_head_dim=64, llm_ffn=256, vocab=512,
+               rope_theta=10000.0, rms_eps=1e-5, lora_r=8, lora_alpha=32, lora_targets=("q_proj", "v_proj"))
+    cfg.update(kw)
+    return cfg
+
+
+def init_weights(cfg: dict, seed: int = 42, lora_b_std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """Seeded random weights at the reference's state_dict names (LoRA B non-zero so adapters contribute)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, std=0.02):
+        return torch.randn(*shape, generator=g) * std
+
+    W = {}
+    d, nm = cfg["enc_dim"], cfg["n_mels"]
+    W["encoder.conv1.weight"] = rn(d, nm, 3, std=(1.0 / (3 * nm)) ** 0.5)
+    W["encoder.conv1.bias"] = rn(d)
+    W["encoder.conv2.weight"] = rn(d, d, 3, std=(1.0 / (3 * d)) ** 0.5)
+    W["encoder.conv2.bias"] = rn(d)
+    W["encoder.positional_embedding"] = sinusoids(cfg["enc_ctx"], d)
+    for i in range(cfg["enc_layers"]):
+        p = f"encoder.blocks.{i}."
+        s = d ** -0.5
+        for nme in ("query", "key", "value", "out"):
+            W[p + f"attn.{nme}.weight"] = rn(d, d, std=s)
+            if nme != "key":
+                W[p + f"attn.{nme}.bias"] = rn(d)
+        W[p + "attn_ln.weight"] = 1 + rn(d, std=0.1)
+        W[p + "attn_ln.bias"] = rn(d, std=0.1)
+        W[p + "mlp.0.weight"] = rn(4 * d, d, std=s)
+        W[p + "mlp.0.bias"] = rn(4 * d)
+        W[p + "mlp.2.weight"] = rn(d, 4 * d, std=(4 * d) ** -0.5)
+        W[p + "mlp.2.bias"] = rn(d)
+        W[p + "mlp_ln.weight"] = 1 + rn(d, std=0.1)
+        W[p + "mlp_ln.bias"] = rn(d, std=0.1)
+    W["encoder.ln_post.weight"] = 1 + rn(d, std=0.1)
+    W["encoder.ln_post.bias"] = rn(d, std=0.1)
+    k, ph, dl = cfg["ds_rate"], cfg["proj_hidden"], cfg["llm_dim"]
+    W["encoder_projector.linear1.weight"] = rn(ph, d * k, std=(d * k) ** -0.5)
+    W["encoder_projector.linear1.bias"] = rn(ph)
+    W["encoder_projector.linear2.weight"] = rn(dl, ph, std=ph ** -0.5)
+    W["encoder_projector.linear2.bias"] = rn(dl)
+    Hq, Hkv, D, Fd, V = cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"], cfg["llm_ffn"], cfg["vocab"]
+    P = "llm.base_model.model."
+    W[P + "model.embed_tokens.weight"] = rn(V, dl, std=1.0)
+    shapes = {"q_proj": (Hq * D, dl), "k_proj": (Hkv * D, dl), "v_proj": (Hkv * D, dl), "o_proj": (dl, Hq * D),
+              "gate_proj": (Fd, dl), "up_proj": (Fd, dl), "down_proj": (dl, Fd)}
+    for i in range(cfg["llm_layers"]):
+        p = f"{P}model.layers.{i}."
+        for nme, (o, ii) in shapes.items():
+            mod = "self_attn." if nme in ("q_proj", "k_proj", "v_proj", "o_proj") else "mlp."
+            W[p + mod + nme + ".weight"] = rn(o, ii, std=ii ** -0.5)
+            if nme in cfg["lora_targets"]:
+                W[p + mod + nme + ".lora_A.default.weight"] = rn(cfg["lora_r"], ii, std=ii ** -0.5)
+                W[p + mod + nme + ".lora_B.default.weight"] = rn(o, cfg["lora_r"], std=lora_b_std)
+        W[p + "input_layernorm.weight"] = 1 + rn(dl, std=0.1)
+        W[p + "post_attention_layernorm.weight"] = 1 + rn(dl, std=0.1)
+    W[P + "model.norm.weight"] = 1 + rn(dl, std=0.1)
+    W[P + "lm_head.weight"] = rn(V, dl, std=dl ** -0.5)
+    return W
+
+
+def synth_audio(n_clips: int, seconds: float, seed: int = 1234) -> torch.Tensor:
+    """SURVEY 8d synthetic audio: N(0, 0.1^2) clamped to [-1, 1], fp32, 16 kHz."""
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(n_clips, int(seconds * SAMPLE_RATE), generator=g) * 0.1).clamp(-1, 1)
+
+
+def synth_batch(cfg, audio: torch.Tensor, prompt_len=16, answer_lens=(64,), seed=1236, left_pad=True,
+                pad_to_30s=True) -> dict:
+    """One synthetic batch in the reference's dict layout."""
+    g = torch.Generator().manual_seed(seed)
+    V = cfg["vocab"]
+    samples, mels = [], []
+    for i in range(audio.shape[0]):
+        a = pad_or_trim(audio[i]) if pad_to_30s else audio[i][: audio.shape[1] // HOP * HOP]
+        mel = log_mel_spectrogram(a, cfg["n_mels"]).permute(1, 0)
+        mels.append(mel)
+        alen = ((mel.shape[0] + 1) // 2) // cfg["ds_rate"]
+        al = answer_lens[i % len(answer_lens)]
+        pids = torch.randint(3, V, (prompt_len,), generator=g).tolist()
+        aids = torch.randint(3, V, (al - 1,), generator=g).tolist()
+        samples.append(make_sample(alen, pids, aids, eos=2))
+    coll = collate_left_pad if left_pad else collate_right_pad
+    return coll(samples, pad_id=2, mels=mels)

@@ -1,0 +1,556 @@
+// Flash-style attention on MFMA for gfx950: encoder (bidirectional, Whisper blocks reached from
+// src/slam_llm/models/encoder.py:26-27) and LLM (causal + key-padding, GQA; HF LlamaAttention with the
+// 4-D causal^padding mask, transformers/models/llama/modeling_llama.py:217-282, called through
+// src/slam_llm/models/slam_model.py:400), forward and backward.
+//
+// Layout trick (no P transposes, no LDS round trip for P):
+//   v_mfma_f32_16x16x32_bf16 computes D[i][j] = sum_k A[i][k] * B[k][j]; lane l supplies A[l&15][8*(l>>4)+e]
+//   and B[8*(l>>4)+e][l&15] (e = 0..7) and receives D[4*(l>>4)+r][l&15] (r = 0..3).  The k index only has
+//   to be enumerated identically for A and B, so:
+//     S^T = K . Q^T          (A = K rows, B = Q rows)        -> lane owns query (l&15), 4 consecutive keys
+//     O^T = V^T . P^T        (A = V^T rows = head-dim, B = P) -> lane owns the same query, 4 consecutive d
+//   Two S^T fragments (32 keys) already ARE a B operand for the second product, provided the V^T operand
+//   enumerates keys in the same order: k-slot (g, e) = key 16*(2a + e/4) + 4g + e%4.  V (and, for the
+//   backward, K, Q and dO) are therefore also kept transposed ([B,H,D,Tp], written by
+//   slam_head_rope_transpose) so that those operands are contiguous 8-byte reads.
+//   All per-query softmax state (m, l, LSE, Delta) is lane-local; row reductions are two xor-shuffles.
+//
+// Masking follows HF: key j is visible to query i iff j <= i (causal) and key_mask[b][j]; query rows are
+// never masked.  A row with no visible key yields O = 0, LSE = +inf (P = 0 in the backward)
+// so pad rows stay finite.  Positions/rows beyond T are handled by clamped/zero loads and guarded stores.
+#include "common.h"
+
+namespace {
+
+typedef u16x8_t frag_t;
+
+struct AttnParams {
+  const bf16_t* Q; int64_t ldq;     // [B*T, ldq], head h at column h*D
+  const bf16_t* K; int64_t ldk;     // [B*T, ldk], kv head at column hk*D
+  const bf16_t* V; int64_t ldv;     // row-major V (backward only)
+  const bf16_t* Vt;                 // [B, Hkv, D, Tp]
+  const bf16_t* Kt;                 // [B, Hkv, D, Tp] (backward dQ)
+  const bf16_t* Qt;                 // [B, Hq, D, Tp]  (backward dK/dV)
+  const bf16_t* dOt;                // [B, Hq, D, Tp]  (backward dK/dV)
+  bf16_t* O; int64_t ldo;           // [B*T, ldo]
+  const bf16_t* dO; int64_t lddo;   // [B*T, lddo]
+  bf16_t* dQ; int64_t lddq;
+  bf16_t* dK; int64_t lddk;
+  bf16_t* dV; int64_t lddv;
+  float* LSE;                       // [B, Hq, Tp] natural-log units
+  float* Delta;                     // [B, Hq, Tp]
+  const uint8_t* kmask;             // [B, Tp] 1 = attend (zero padded) or null
+  int T, Tp, Hq, Hkv;
+  float scale;                      // softmax scale (1/sqrt(D))
+};
+
+__device__ __forceinline__ f32x4_t mfma16(frag_t a, frag_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                 __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ frag_t zero_frag() {
+  frag_t z;
+#pragma unroll
+  for (int e = 0; e < 8; e++) z[e] = 0;
+  return z;
+}
+__device__ __forceinline__ frag_t pack_frag(f32x4_t x, f32x4_t y) {
+  frag_t f;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    f[e] = f2bf(x[e]);
+    f[4 + e] = f2bf(y[e]);
+  }
+  return f;
+}
+__device__ __forceinline__ frag_t join_frag(u16x4_t lo, u16x4_t hi) {
+  frag_t f;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    f[e] = lo[e];
+    f[4 + e] = hi[e];
+  }
+  return f;
+}
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// ------------------------------------------------------------------------------------------
+// forward: 4 waves x 32 query rows per workgroup, 64-key K / V^T tiles staged through LDS
+// ------------------------------------------------------------------------------------------
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  constexpr int KD = D / 32;
+  constexpr int DF = D / 16;
+  constexpr int KROWB = D * 2;
+  constexpr int KCH = D / 8;       // 16-byte chunks per K row
+  constexpr int KCM = KCH - 1;
+  constexpr int KI = 64 * KCH / 256;
+  constexpr int VI = D * 8 / 256;
+  __shared__ __attribute__((aligned(16))) char lds[64 * KROWB + D * 128];
+  char* ldsK = lds;
+  char* ldsV = lds + 64 * KROWB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int hk = h / (p.Hq / p.Hkv);
+  const int T = p.T, Tp = p.Tp;
+  const int qb0 = blockIdx.x * 128, qw0 = qb0 + wave * 32;
+
+  frag_t qf[2][KD];
+#pragma unroll
+  for (int f = 0; f < 2; f++) {
+    const int q = qw0 + f * 16 + li;
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) {
+      qf[f][kd] = (q < T) ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * T + q) * p.ldq + h * D + kd * 32 + g * 8)
+                          : zero_frag();
+    }
+  }
+  f32x4_t o[2][DF];
+#pragma unroll
+  for (int f = 0; f < 2; f++)
+#pragma unroll
+    for (int df = 0; df < DF; df++) o[f][df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float mrow[2] = {-INFINITY, -INFINITY};
+  float lrow[2] = {0.f, 0.f};
+
+  const int kend = CAUSAL ? min(T, qb0 + 128) : T;
+  const int ntiles = (kend + 63) / 64;
+  const float sl2 = p.scale * LOG2E;
+
+  frag_t kreg[KI], vreg[VI];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < KI; i++) {
+      const int item = tid + i * 256;
+      const int row = item / KCH, c = item % KCH;
+      const int key = k0 + row;
+      kreg[i] = (key < T) ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * T + key) * p.ldk + hk * D + c * 8)
+                          : zero_frag();
+    }
+#pragma unroll
+    for (int i = 0; i < VI; i++) {
+      const int item = tid + i * 256;
+      const int d = item >> 3, c = item & 7;
+      vreg[i] = *reinterpret_cast<const frag_t*>(p.Vt + ((int64_t)(b * p.Hkv + hk) * D + d) * Tp + k0 + c * 8);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < KI; i++) {
+      const int item = tid + i * 256;
+      const int row = item / KCH, c = item % KCH;
+      *reinterpret_cast<frag_t*>(ldsK + row * KROWB + ((c ^ (row & KCM)) << 4)) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VI; i++) {
+      const int item = tid + i * 256;
+      const int d = item >> 3, c = item & 7;
+      *reinterpret_cast<frag_t*>(ldsV + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = vreg[i];
+    }
+  };
+
+  gload(0);
+  for (int it = 0; it < ntiles; it++) {
+    const int k0 = it * 64;
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (it + 1 < ntiles) gload(k0 + 64);
+    if (CAUSAL && k0 > qw0 + 31) continue;  // whole tile is in this wave's future
+
+    // ---- S^T = K . Q^T ----
+    f32x4_t s[2][4];
+#pragma unroll
+    for (int kf = 0; kf < 4; kf++) {
+      frag_t kfr[KD];
+      const int row = kf * 16 + li;
+#pragma unroll
+      for (int kd = 0; kd < KD; kd++)
+        kfr[kd] = *reinterpret_cast<const frag_t*>(ldsK + row * KROWB + (((kd * 4 + g) ^ (row & KCM)) << 4));
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kd = 0; kd < KD; kd++) a = mfma16(kfr[kd], qf[f][kd], a);
+        s[f][kf] = a;
+      }
+    }
+    // ---- key validity for this lane's 16 keys ----
+    bool kv[4][4];
+#pragma unroll
+    for (int kf = 0; kf < 4; kf++) {
+      const int kb = k0 + kf * 16 + 4 * g;
+      unsigned mk = 0x01010101u;
+      if (p.kmask) mk = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tp + kb);
+#pragma unroll
+      for (int r = 0; r < 4; r++) kv[kf][r] = ((mk >> (8 * r)) & 0xffu) != 0 && (kb + r) < T;
+    }
+    // ---- online softmax (per query = lane&15, replicated over the 4 lane groups) ----
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+      const int q = qw0 + f * 16 + li;
+      float mt = -INFINITY;
+#pragma unroll
+      for (int kf = 0; kf < 4; kf++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int key = k0 + kf * 16 + 4 * g + r;
+          const bool ok = kv[kf][r] && (!CAUSAL || key <= q);
+          const float x = ok ? s[f][kf][r] * sl2 : -INFINITY;
+          s[f][kf][r] = x;
+          mt = fmaxf(mt, x);
+        }
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float mnew = fmaxf(mrow[f], mt);
+      const float muse = (mnew == -INFINITY) ? 0.f : mnew;
+      const float alpha = exp2f(mrow[f] - muse);
+      mrow[f] = mnew;
+      float rs = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < 4; kf++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float pv = exp2f(s[f][kf][r] - muse);
+          s[f][kf][r] = pv;
+          rs += pv;
+        }
+      lrow[f] = lrow[f] * alpha + rs;
+#pragma unroll
+      for (int df = 0; df < DF; df++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[f][df][r] *= alpha;
+    }
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      frag_t pb[2];
+#pragma unroll
+      for (int f = 0; f < 2; f++) pb[f] = pack_frag(s[f][2 * a], s[f][2 * a + 1]);
+#pragma unroll
+      for (int df = 0; df < DF; df++) {
+        const int d = df * 16 + li;
+        const int sw = (d >> 1) & 7;
+        const int c0 = a * 4 + (g >> 1);
+        const u16x4_t lo = *reinterpret_cast<const u16x4_t*>(ldsV + d * 128 + ((c0 ^ sw) << 4) + (g & 1) * 8);
+        const u16x4_t hi = *reinterpret_cast<const u16x4_t*>(ldsV + d * 128 + (((c0 + 2) ^ sw) << 4) + (g & 1) * 8);
+        const frag_t vf = join_frag(lo, hi);
+#pragma unroll
+        for (int f = 0; f < 2; f++) o[f][df] = mfma16(vf, pb[f], o[f][df]);
+      }
+    }
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int f = 0; f < 2; f++) {
+    float lt = lrow[f];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+    const int q = qw0 + f * 16 + li;
+    if (q >= T) continue;
+    bf16_t* orow = p.O + ((int64_t)b * T + q) * p.ldo + h * D;
+#pragma unroll
+    for (int df = 0; df < DF; df++) {
+      uint2 w;
+      w.x = pack2bf(o[f][df][0] * inv, o[f][df][1] * inv);
+      w.y = pack2bf(o[f][df][2] * inv, o[f][df][3] * inv);
+      *reinterpret_cast<uint2*>(orow + df * 16 + 4 * g) = w;
+    }
+    if (p.LSE && g == 0)
+      p.LSE[((int64_t)b * p.Hq + h) * Tp + q] = lt > 0.f ? (mrow[f] * LN2 + __logf(lt)) : INFINITY;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Delta[b,h,t] = sum_d dO[b,t,h,d] * O[b,t,h,d]      (one wave per (row, head))
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
+  const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.z;
+  if (idx >= (int64_t)p.T * p.Hq) return;
+  const int t = (int)(idx / p.Hq), h = (int)(idx % p.Hq);
+  const bf16_t* orow = p.O + ((int64_t)b * p.T + t) * p.ldo + h * D;
+  const bf16_t* drow = p.dO + ((int64_t)b * p.T + t) * p.lddo + h * D;
+  float acc = 0.f;
+  if (lane < D / 2) {
+    const u16x2_t a = *reinterpret_cast<const u16x2_t*>(orow + lane * 2);
+    const u16x2_t c = *reinterpret_cast<const u16x2_t*>(drow + lane * 2);
+    acc = bf2f(a[0]) * bf2f(c[0]) + bf2f(a[1]) * bf2f(c[1]);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) p.Delta[((int64_t)b * p.Hq + h) * p.Tp + t] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward dQ: one wave = 16 queries, loop over 32-key tiles, operands straight from L1/L2
+//   S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - Delta) * scale, dQ^T += K^T(as [d x keys]) . dS^T
+// ------------------------------------------------------------------------------------------
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+  constexpr int KD = D / 32;
+  constexpr int DF = D / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int hk = h / (p.Hq / p.Hkv);
+  const int T = p.T, Tp = p.Tp;
+  const int qw0 = blockIdx.x * 64 + wave * 16;
+  if (qw0 >= T) return;
+  const int q = qw0 + li;
+  const bool qok = q < T;
+
+  frag_t qf[KD], dof[KD];
+#pragma unroll
+  for (int kd = 0; kd < KD; kd++) {
+    qf[kd] = qok ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * T + q) * p.ldq + h * D + kd * 32 + g * 8) : zero_frag();
+    dof[kd] = qok ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * T + q) * p.lddo + h * D + kd * 32 + g * 8) : zero_frag();
+  }
+  const float lse2 = qok ? p.LSE[((int64_t)b * p.Hq + h) * Tp + q] * LOG2E : INFINITY;
+  const float delta = qok ? p.Delta[((int64_t)b * p.Hq + h) * Tp + q] : 0.f;
+  const float sl2 = p.scale * LOG2E;
+
+  f32x4_t dq[DF];
+#pragma unroll
+  for (int df = 0; df < DF; df++) dq[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int kend = CAUSAL ? min(T, qw0 + 16) : T;
+  const bf16_t* ktb = p.Kt + ((int64_t)(b * p.Hkv + hk) * D) * Tp;
+  for (int k0 = 0; k0 < kend; k0 += 32) {
+    f32x4_t st[2], dpt[2];
+#pragma unroll
+    for (int kf = 0; kf < 2; kf++) {
+      const int key = k0 + kf * 16 + li;
+      const bool kok = key < T;
+      f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f}, c = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kd = 0; kd < KD; kd++) {
+        const frag_t kfr = kok ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * T + key) * p.ldk + hk * D + kd * 32 + g * 8) : zero_frag();
+        const frag_t vfr = kok ? *reinterpret_cast<const frag_t*>(p.V + ((int64_t)b * T + key) * p.ldv + hk * D + kd * 32 + g * 8) : zero_frag();
+        a = mfma16(kfr, qf[kd], a);
+        c = mfma16(vfr, dof[kd], c);
+      }
+      st[kf] = a;
+      dpt[kf] = c;
+    }
+#pragma unroll
+    for (int kf = 0; kf < 2; kf++) {
+      const int kb = k0 + kf * 16 + 4 * g;
+      unsigned mk = 0x01010101u;
+      if (p.kmask) mk = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tp + kb);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int key = kb + r;
+        const bool ok = ((mk >> (8 * r)) & 0xffu) != 0 && key < T && (!CAUSAL || key <= q) && qok;
+        const float pv = ok ? exp2f(st[kf][r] * sl2 - lse2) : 0.f;
+        st[kf][r] = pv * (dpt[kf][r] - delta) * p.scale;
+      }
+    }
+    const frag_t dsb = pack_frag(st[0], st[1]);
+#pragma unroll
+    for (int df = 0; df < DF; df++) {
+      const bf16_t* kr = ktb + (int64_t)(df * 16 + li) * Tp + k0 + 4 * g;
+      const u16x4_t lo = *reinterpret_cast<const u16x4_t*>(kr);
+      const u16x4_t hi = *reinterpret_cast<const u16x4_t*>(kr + 16);
+      dq[df] = mfma16(join_frag(lo, hi), dsb, dq[df]);
+    }
+  }
+  if (!qok) return;
+  bf16_t* orow = p.dQ + ((int64_t)b * T + q) * p.lddq + h * D;
+#pragma unroll
+  for (int df = 0; df < DF; df++) {
+    uint2 w;
+    w.x = pack2bf(dq[df][0], dq[df][1]);
+    w.y = pack2bf(dq[df][2], dq[df][3]);
+    *reinterpret_cast<uint2*>(orow + df * 16 + 4 * g) = w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward dK/dV: one wave = 16 keys, loops over the GQA group's query heads and 32-query tiles
+//   S = Q K^T, dP = dO V^T (lane owns key (l&15), 4 consecutive queries),
+//   dV^T += dO^T(as [d x q]) . P,   dK^T += Q^T(as [d x q]) . dS
+// ------------------------------------------------------------------------------------------
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
+  constexpr int KD = D / 32;
+  constexpr int DF = D / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.z, hk = blockIdx.y;
+  const int G = p.Hq / p.Hkv;
+  const int T = p.T, Tp = p.Tp;
+  const int kw0 = blockIdx.x * 64 + wave * 16;
+  if (kw0 >= T) return;
+  const int key = kw0 + li;
+  const bool kok = key < T && (!p.kmask || p.kmask[(int64_t)b * Tp + key] != 0);
+
+  frag_t kf[KD], vf[KD];
+#pragma unroll
+  for (int kd = 0; kd < KD; kd++) {
+    const bool inb = key < T;
+    kf[kd] = inb ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * T + key) * p.ldk + hk * D + kd * 32 + g * 8) : zero_frag();
+    vf[kd] = inb ? *reinterpret_cast<const frag_t*>(p.V + ((int64_t)b * T + key) * p.ldv + hk * D + kd * 32 + g * 8) : zero_frag();
+  }
+  f32x4_t dk[DF], dv[DF];
+#pragma unroll
+  for (int df = 0; df < DF; df++) {
+    dk[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    dv[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const float sl2 = p.scale * LOG2E;
+  const int qstart = CAUSAL ? (kw0 / 32) * 32 : 0;
+
+  for (int hh = 0; hh < G; hh++) {
+    const int h = hk * G + hh;
+    const float* lsep = p.LSE + ((int64_t)b * p.Hq + h) * Tp;
+    const float* delp = p.Delta + ((int64_t)b * p.Hq + h) * Tp;
+    const bf16_t* qtb = p.Qt + ((int64_t)(b * p.Hq + h) * D) * Tp;
+    const bf16_t* dotb = p.dOt + ((int64_t)(b * p.Hq + h) * D) * Tp;
+    for (int q0 = qstart; q0 < T; q0 += 32) {
+      f32x4_t s[2], dp[2];
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const int q = q0 + f * 16 + li;
+        const bool qin = q < T;
+        f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f}, c = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kd = 0; kd < KD; kd++) {
+          const frag_t qfr = qin ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * T + q) * p.ldq + h * D + kd * 32 + g * 8) : zero_frag();
+          const frag_t dfr = qin ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * T + q) * p.lddo + h * D + kd * 32 + g * 8) : zero_frag();
+          a = mfma16(qfr, kf[kd], a);
+          c = mfma16(dfr, vf[kd], c);
+        }
+        s[f] = a;
+        dp[f] = c;
+      }
+      f32x4_t pm[2], ds[2];
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const int qb = q0 + f * 16 + 4 * g;
+        const float4 l4 = *reinterpret_cast<const float4*>(lsep + qb);
+        const float4 d4 = *reinterpret_cast<const float4*>(delp + qb);
+        const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+        const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int q = qb + r;
+          const bool ok = kok && q < T && (!CAUSAL || key <= q);
+          const float pv = ok ? exp2f(s[f][r] * sl2 - ls[r] * LOG2E) : 0.f;
+          pm[f][r] = pv;
+          ds[f][r] = ok ? pv * (dp[f][r] - dl[r]) * p.scale : 0.f;
+        }
+      }
+      const frag_t pb = pack_frag(pm[0], pm[1]);
+      const frag_t dsb = pack_frag(ds[0], ds[1]);
+#pragma unroll
+      for (int df = 0; df < DF; df++) {
+        const int64_t off = (int64_t)(df * 16 + li) * Tp + q0 + 4 * g;
+        const u16x4_t dlo = *reinterpret_cast<const u16x4_t*>(dotb + off);
+        const u16x4_t dhi = *reinterpret_cast<const u16x4_t*>(dotb + off + 16);
+        dv[df] = mfma16(join_frag(dlo, dhi), pb, dv[df]);
+        const u16x4_t qlo = *reinterpret_cast<const u16x4_t*>(qtb + off);
+        const u16x4_t qhi = *reinterpret_cast<const u16x4_t*>(qtb + off + 16);
+        dk[df] = mfma16(join_frag(qlo, qhi), dsb, dk[df]);
+      }
+    }
+  }
+  if (key >= T) return;
+  bf16_t* krow = p.dK + ((int64_t)b * T + key) * p.lddk + hk * D;
+  bf16_t* vrow = p.dV + ((int64_t)b * T + key) * p.lddv + hk * D;
+#pragma unroll
+  for (int df = 0; df < DF; df++) {
+    uint2 w;
+    w.x = pack2bf(dk[df][0], dk[df][1]);
+    w.y = pack2bf(dk[df][2], dk[df][3]);
+    *reinterpret_cast<uint2*>(krow + df * 16 + 4 * g) = w;
+    w.x = pack2bf(dv[df][0], dv[df][1]);
+    w.y = pack2bf(dv[df][2], dv[df][3]);
+    *reinterpret_cast<uint2*>(vrow + df * 16 + 4 * g) = w;
+  }
+}
+
+int check_common(const char* name, int64_t B, int64_t T, int64_t Tp, int64_t Hq, int64_t Hkv, int64_t D) {
+  SLAM_CHECK_ARG(D == 64 || D == 128, "%s: head_dim %ld unsupported (64|128)", name, (long)D);
+  SLAM_CHECK_ARG(B > 0 && T > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "%s: bad shape B=%ld T=%ld Hq=%ld Hkv=%ld", name, (long)B, (long)T, (long)Hq, (long)Hkv);
+  SLAM_CHECK_ARG(Tp % 64 == 0 && Tp >= T, "%s: Tp=%ld must be a multiple of 64 and >= T=%ld", name, (long)Tp, (long)T);
+  SLAM_CHECK_ARG(B < 65536 && Hq < 65536, "%s: grid dims exceed 65535", name);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt,
+                             void* O, int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B,
+                             int64_t T, int64_t Tp, int64_t Hq, int64_t Hkv, int64_t D, int causal,
+                             float scale, void* stream) {
+  SLAM_CHECK_ARG(Q && K && Vt && O, "slam_attn_fwd: null pointer");
+  if (int rc = check_common("slam_attn_fwd", B, T, Tp, Hq, Hkv, D)) return rc;
+  SLAM_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "slam_attn_fwd: leading dims must be multiples of 8");
+  AttnParams p = {};
+  p.Q = (const bf16_t*)Q; p.ldq = ldq; p.K = (const bf16_t*)K; p.ldk = ldk; p.Vt = (const bf16_t*)Vt;
+  p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = LSE; p.kmask = key_mask;
+  p.T = (int)T; p.Tp = (int)Tp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
+  dim3 grid((unsigned)cdiv64(T, 128), (unsigned)Hq, (unsigned)B);
+  hipStream_t s = (hipStream_t)stream;
+  if (D == 64) {
+    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), 0, s, p);
+  } else {
+    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), 0, s, p);
+  }
+  SLAM_CHECK_LAUNCH("slam_attn_fwd");
+  return 0;
+}
+
+extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V,
+                             int64_t ldv, const void* Qt, const void* Kt, const void* O, int64_t ldo,
+                             const void* dO, int64_t lddo, const void* dOt, const float* LSE,
+                             float* Delta, const uint8_t* key_mask, void* dQ, int64_t lddq, void* dK,
+                             int64_t lddk, void* dV, int64_t lddv, int64_t B, int64_t T, int64_t Tp,
+                             int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale, void* stream) {
+  SLAM_CHECK_ARG(Q && K && V && Qt && Kt && O && dO && dOt && LSE && Delta && dQ && dK && dV, "slam_attn_bwd: null pointer");
+  if (int rc = check_common("slam_attn_bwd", B, T, Tp, Hq, Hkv, D)) return rc;
+  SLAM_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && ldo % 2 == 0 &&
+                     lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0,
+                 "slam_attn_bwd: leading dims misaligned");
+  AttnParams p = {};
+  p.Q = (const bf16_t*)Q; p.ldq = ldq; p.K = (const bf16_t*)K; p.ldk = ldk; p.V = (const bf16_t*)V; p.ldv = ldv;
+  p.Qt = (const bf16_t*)Qt; p.Kt = (const bf16_t*)Kt; p.dOt = (const bf16_t*)dOt;
+  p.O = (bf16_t*)O; p.ldo = ldo; p.dO = (const bf16_t*)dO; p.lddo = lddo;
+  p.dQ = (bf16_t*)dQ; p.lddq = lddq; p.dK = (bf16_t*)dK; p.lddk = lddk; p.dV = (bf16_t*)dV; p.lddv = lddv;
+  p.LSE = (float*)LSE; p.Delta = Delta; p.kmask = key_mask;
+  p.T = (int)T; p.Tp = (int)Tp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 gdel((unsigned)cdiv64(T * Hq, 4), 1, (unsigned)B);
+  dim3 gq((unsigned)cdiv64(T, 64), (unsigned)Hq, (unsigned)B);
+  dim3 gk((unsigned)cdiv64(T, 64), (unsigned)Hkv, (unsigned)B);
+  if (D == 64) {
+    hipLaunchKernelGGL((attn_delta_kernel<64>), gdel, dim3(256), 0, s, p);
+    if (causal) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true>), gk, dim3(256), 0, s, p);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), gq, dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false>), gk, dim3(256), 0, s, p);
+    }
+  } else {
+    hipLaunchKernelGGL((attn_delta_kernel<128>), gdel, dim3(256), 0, s, p);
+    if (causal) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, true>), gk, dim3(256), 0, s, p);
+    } else {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, false>), gq, dim3(256), 0, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false>), gk, dim3(256), 0, s, p);
+    }
+  }
+  SLAM_CHECK_LAUNCH("slam_attn_bwd");
+  return 0;
+}

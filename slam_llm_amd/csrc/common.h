@@ -1,0 +1,89 @@
+// Shared device/host helpers for the slam_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SLAM_BF16 0
+#define SLAM_F32 1
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---- error plumbing (host) -------------------------------------------------
+extern "C" const char* slam_last_error();
+void slam_set_error(const char* fmt, ...);
+#define SLAM_CHECK_ARG(cond, ...)      \
+  do {                                 \
+    if (!(cond)) {                     \
+      slam_set_error(__VA_ARGS__);     \
+      return -1;                       \
+    }                                  \
+  } while (0)
+#define SLAM_CHECK_LAUNCH(name)                                             \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      slam_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return -2;                                                            \
+    }                                                                       \
+  } while (0)
+
+// ---- bf16 <-> f32 (device) -------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  return __uint_as_float(((unsigned)v) << 16);
+}
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+// ---- wave / block reductions (wave = 64 lanes) -------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum for blockDim.x == NT (multiple of 64); red must hold NT/64 floats
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  if constexpr (NT == 64) return v;
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; i++) t += red[i];
+  return t;
+}
+template <int NT>
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  if constexpr (NT == 64) return v;
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; i++) t = fmaxf(t, red[i]);
+  return t;
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

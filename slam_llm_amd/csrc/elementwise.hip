@@ -1,0 +1,401 @@
+// HBM-bound data-movement / elementwise kernels of the SLAM hot path (gfx950).
+//   * head transpose (+ RoPE) : Llama rotary embedding (HF apply_rotary_pos_emb / rotate_half,
+//     transformers/models/llama/modeling_llama.py:130-160, positions = arange(T) per row as the
+//     reference never passes position_ids, src/slam_llm/models/slam_model.py:400) fused with the
+//     [B,T,H,D] -> [B,H,D,Tp] transposes the MFMA attention kernels consume.
+//   * SwiGLU fwd/bwd          : LlamaMLP act_fn(gate)*up (modeling_llama.py:163-177).
+//   * conv im2col             : Whisper conv1 (k3,p1) / conv2 (k3,s2,p1) -> implicit-GEMM operand
+//     (src/slam_llm/models/encoder.py:18-19).
+//   * embed + audio splice    : src/slam_llm/models/slam_model.py:370-392 without the .tolist() host
+//     sync or the per-sample python loop; plus its backward (a row gather into the projector grad).
+//   * generic bf16 transpose, fp32->bf16 cast.
+// All kernels move 16 bytes per lane per access and never synchronise with the host.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// head transpose with optional in-place rotary embedding
+// src: rows (b*T + t), columns col0 + h*D + d.  dstT: [B, H, D, Tp] (t contiguous), zero padded.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void head_rope_transpose_kernel(
+    bf16_t* __restrict__ src, int64_t ld, int col0, const float* __restrict__ cosT,
+    const float* __restrict__ sinT, float sin_sign, bf16_t* __restrict__ dstT, int T, int Tp, int H) {
+  constexpr int LDT = D + 8;  // LDS row stride (elements)
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * LDT];
+  const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  constexpr int HC = D / 16;  // 16-byte chunks in half a head
+  for (int item = tid; item < 64 * HC; item += 256) {
+    const int tt = item / HC, c = item % HC;
+    const int t = t0 + tt;
+    u16x8_t y1, y2;
+    if (t < T) {
+      bf16_t* p = src + (int64_t)(b * (int64_t)T + t) * ld + col0 + h * D;
+      const u16x8_t x1 = *reinterpret_cast<const u16x8_t*>(p + c * 8);
+      const u16x8_t x2 = *reinterpret_cast<const u16x8_t*>(p + D / 2 + c * 8);
+      if (cosT) {
+        const float* cp = cosT + (int64_t)t * (D / 2) + c * 8;
+        const float* sp = sinT + (int64_t)t * (D / 2) + c * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float cs = cp[e], sn = sp[e] * sin_sign;
+          const float a = bf2f(x1[e]), bb = bf2f(x2[e]);
+          y1[e] = f2bf(a * cs - bb * sn);
+          y2[e] = f2bf(bb * cs + a * sn);
+        }
+        *reinterpret_cast<u16x8_t*>(p + c * 8) = y1;
+        *reinterpret_cast<u16x8_t*>(p + D / 2 + c * 8) = y2;
+      } else {
+        y1 = x1;
+        y2 = x2;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { y1[e] = 0; y2[e] = 0; }
+    }
+    if (dstT) {
+      *reinterpret_cast<u16x8_t*>(&tile[tt * LDT + c * 8]) = y1;
+      *reinterpret_cast<u16x8_t*>(&tile[tt * LDT + D / 2 + c * 8]) = y2;
+    }
+  }
+  if (!dstT) return;
+  __syncthreads();
+  bf16_t* out = dstT + ((int64_t)(b * (int64_t)H + h) * D) * Tp + t0;
+  for (int item = tid; item < D * 8; item += 256) {
+    const int d = item >> 3, tc = item & 7;
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = tile[(tc * 8 + e) * LDT + d];
+    *reinterpret_cast<u16x8_t*>(out + (int64_t)d * Tp + tc * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic transpose: in [R, C] (ld) -> out [C, Rp] (ldo), rows R..Rp-1 written as zeros
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, int64_t ldi,
+                                                        bf16_t* __restrict__ out, int64_t ldo, int R,
+                                                        int C) {
+  constexpr int LDT = 64 + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * LDT];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  for (int item = tid; item < 512; item += 256) {
+    const int r = item >> 3, cc = item & 7;
+    u16x8_t v;
+    if (r0 + r < R && c0 + cc * 8 < C) {
+      v = *reinterpret_cast<const u16x8_t*>(in + (int64_t)(r0 + r) * ldi + c0 + cc * 8);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = 0;
+    }
+    *reinterpret_cast<u16x8_t*>(&tile[r * LDT + cc * 8]) = v;
+  }
+  __syncthreads();
+  for (int item = tid; item < 512; item += 256) {
+    const int c = item >> 3, rc = item & 7;
+    if (c0 + c >= C) continue;
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = tile[(rc * 8 + e) * LDT + c];
+    *reinterpret_cast<u16x8_t*>(out + (int64_t)(c0 + c) * ldo + r0 + rc * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// SwiGLU
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, int64_t ldgu,
+                                                         bf16_t* __restrict__ h, int64_t ldh,
+                                                         int64_t M, int F) {
+  const int nch = F >> 3;
+  const int64_t total = M * nch;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / nch;
+    const int c = (int)(i % nch);
+    const u16x8_t g = *reinterpret_cast<const u16x8_t*>(gu + m * ldgu + c * 8);
+    const u16x8_t u = *reinterpret_cast<const u16x8_t*>(gu + m * ldgu + F + c * 8);
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float gf = bf2f(g[e]);
+      const float s = gf / (1.0f + __expf(-gf));
+      o[e] = f2bf(s * bf2f(u[e]));
+    }
+    *reinterpret_cast<u16x8_t*>(h + m * ldh + c * 8) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, int64_t ldgu,
+                                                         const bf16_t* __restrict__ dh, int64_t lddh,
+                                                         bf16_t* __restrict__ dgu, int64_t lddgu,
+                                                         int64_t M, int F) {
+  const int nch = F >> 3;
+  const int64_t total = M * nch;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / nch;
+    const int c = (int)(i % nch);
+    const u16x8_t g = *reinterpret_cast<const u16x8_t*>(gu + m * ldgu + c * 8);
+    const u16x8_t u = *reinterpret_cast<const u16x8_t*>(gu + m * ldgu + F + c * 8);
+    const u16x8_t d = *reinterpret_cast<const u16x8_t*>(dh + m * lddh + c * 8);
+    u16x8_t og, ou;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float gf = bf2f(g[e]), uf = bf2f(u[e]), df = bf2f(d[e]);
+      const float sg = 1.0f / (1.0f + __expf(-gf));
+      const float silu = gf * sg;
+      og[e] = f2bf(df * uf * sg * (1.0f + gf * (1.0f - sg)));
+      ou[e] = f2bf(df * silu);
+    }
+    *reinterpret_cast<u16x8_t*>(dgu + m * lddgu + c * 8) = og;
+    *reinterpret_cast<u16x8_t*>(dgu + m * lddgu + F + c * 8) = ou;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1d(k=3, pad=1, stride s) im2col: in [B, Tin, C] -> out [B*Tout, Kp], col = j*C + c
+// ------------------------------------------------------------------------------------------
+template <typename TIN>
+__global__ __launch_bounds__(256) void im2col_k3_kernel(const TIN* __restrict__ in, bf16_t* __restrict__ out,
+                                                        int B, int Tin, int Tout, int C, int Kp,
+                                                        int stride) {
+  const int64_t total = (int64_t)B * Tout * Kp;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int col = (int)(i % Kp);
+    const int64_t row = i / Kp;
+    const int t = (int)(row % Tout);
+    const int b = (int)(row / Tout);
+    float v = 0.f;
+    if (col < 3 * C) {
+      const int j = col / C, c = col % C;
+      const int ti = t * stride + j - 1;
+      if (ti >= 0 && ti < Tin) {
+        if constexpr (sizeof(TIN) == 4)
+          v = in[((int64_t)b * Tin + ti) * C + c];
+        else
+          v = bf2f(in[((int64_t)b * Tin + ti) * C + c]);
+      }
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 -> bf16 cast
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in,
+                                                            bf16_t* __restrict__ out, int64_t n) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = f2bf(in[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// modality spans + embed/splice
+// ------------------------------------------------------------------------------------------
+// spans[b] = (start, len): start = first True of modality_mask[b,:] (0 if none),
+// len = min(sum(mask), Ta)   (slam_model.py:383-384)
+__global__ __launch_bounds__(64) void modality_spans_kernel(const uint8_t* __restrict__ mask, int T,
+                                                            int Ta, int* __restrict__ spans) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int first = T, cnt = 0;
+  for (int t = lane; t < T; t += 64) {
+    if (mask[(int64_t)b * T + t]) {
+      cnt++;
+      first = min(first, t);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+    first = min(first, __shfl_xor(first, o, 64));
+  }
+  if (lane == 0) {
+    spans[2 * b] = (first == T) ? 0 : first;
+    spans[2 * b + 1] = min(cnt, Ta);
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_splice_kernel(
+    int64_t* __restrict__ ids, const uint8_t* __restrict__ mask, const int* __restrict__ spans,
+    const bf16_t* __restrict__ E, const bf16_t* __restrict__ enc, int64_t ldenc, bf16_t* __restrict__ out,
+    int64_t ldo, int T, int Ta, int d, int64_t vocab) {
+  const int64_t row = blockIdx.x;  // b*T + t
+  const int b = (int)(row / T), t = (int)(row % T);
+  const int start = spans[2 * b], len = spans[2 * b + 1];
+  const bool in_span = (t >= start) && (t < start + len);
+  const bool m = mask[row] != 0;
+  int64_t id = ids[row];
+  if (id == -1) {
+    id = 0;
+    if (threadIdx.x == 0) ids[row] = 0;  // the reference mutates input_ids in place (slam_model.py:371)
+  }
+  if (id < 0) id = 0;
+  if (id >= vocab) id = vocab - 1;
+  const bf16_t* er = E + id * (int64_t)d;
+  const bf16_t* ar = enc + ((int64_t)b * Ta + (t - start)) * ldenc;
+  bf16_t* orow = out + row * ldo;
+  for (int c = threadIdx.x; c < (d >> 3); c += 256) {
+    u16x8_t o;
+    if (in_span && m) {
+      o = *reinterpret_cast<const u16x8_t*>(ar + c * 8);
+    } else if (!in_span && !m) {
+      o = *reinterpret_cast<const u16x8_t*>(er + c * 8);
+    } else if (in_span && !m) {  // encoder_outs_pad + embeds * 1  (never happens for contiguous masks)
+      const u16x8_t a = *reinterpret_cast<const u16x8_t*>(ar + c * 8);
+      const u16x8_t e8 = *reinterpret_cast<const u16x8_t*>(er + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = f2bf(bf2f(a[e]) + bf2f(e8[e]));
+    } else {  // masked but beyond the (clamped) span: zero embedding
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = 0;
+    }
+    *reinterpret_cast<u16x8_t*>(orow + c * 8) = o;
+  }
+}
+
+// d_enc[b, j, :] = j < len_b ? dX[b, start_b + j, :] : 0
+__global__ __launch_bounds__(256) void embed_splice_bwd_kernel(const int* __restrict__ spans,
+                                                               const bf16_t* __restrict__ dX, int64_t lddx,
+                                                               bf16_t* __restrict__ denc, int64_t ldde,
+                                                               int T, int Ta, int d) {
+  const int64_t row = blockIdx.x;  // b*Ta + j
+  const int b = (int)(row / Ta), j = (int)(row % Ta);
+  const int start = spans[2 * b], len = spans[2 * b + 1];
+  bf16_t* orow = denc + row * ldde;
+  const bf16_t* irow = dX + ((int64_t)b * T + start + j) * lddx;
+  for (int c = threadIdx.x; c < (d >> 3); c += 256) {
+    u16x8_t o;
+    if (j < len) {
+      o = *reinterpret_cast<const u16x8_t*>(irow + c * 8);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = 0;
+    }
+    *reinterpret_cast<u16x8_t*>(orow + c * 8) = o;
+  }
+}
+
+inline unsigned ew_grid(int64_t total_items) {
+  int64_t g = cdiv64(total_items, 256);
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int slam_head_rope_transpose(void* src, int64_t ld, int64_t col0, const float* cos_table,
+                                        const float* sin_table, int inverse, void* dstT, int64_t B,
+                                        int64_t T, int64_t Tp, int64_t H, int64_t D, void* stream) {
+  SLAM_CHECK_ARG(src, "slam_head_rope_transpose: null src");
+  SLAM_CHECK_ARG(D == 64 || D == 128, "slam_head_rope_transpose: head_dim %ld unsupported (64|128)", (long)D);
+  SLAM_CHECK_ARG((cos_table == nullptr) == (sin_table == nullptr), "slam_head_rope_transpose: cos/sin must both be set or both null");
+  SLAM_CHECK_ARG(ld % 8 == 0 && col0 % 8 == 0, "slam_head_rope_transpose: ld/col0 must be multiples of 8");
+  SLAM_CHECK_ARG(B > 0 && T > 0 && H > 0, "slam_head_rope_transpose: bad shape");
+  SLAM_CHECK_ARG(!dstT || (Tp % 64 == 0 && Tp >= T), "slam_head_rope_transpose: Tp must be a multiple of 64 and >= T");
+  if (!dstT && !cos_table) return 0;
+  const int64_t tt = dstT ? Tp : ((T + 63) / 64) * 64;
+  dim3 grid((unsigned)(tt / 64), (unsigned)H, (unsigned)B);
+  const float sgn = inverse ? -1.f : 1.f;
+  if (D == 64)
+    hipLaunchKernelGGL(head_rope_transpose_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)src, ld, (int)col0, cos_table, sin_table, sgn, (bf16_t*)dstT, (int)T, (int)Tp, (int)H);
+  else
+    hipLaunchKernelGGL(head_rope_transpose_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)src, ld, (int)col0, cos_table, sin_table, sgn, (bf16_t*)dstT, (int)T, (int)Tp, (int)H);
+  SLAM_CHECK_LAUNCH("slam_head_rope_transpose");
+  return 0;
+}
+
+extern "C" int slam_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t R,
+                                   int64_t C, int64_t Rp, void* stream) {
+  SLAM_CHECK_ARG(in && out, "slam_transpose_bf16: null pointer");
+  SLAM_CHECK_ARG(R > 0 && C > 0 && C % 8 == 0 && ldi % 8 == 0, "slam_transpose_bf16: C and ldi must be multiples of 8");
+  SLAM_CHECK_ARG(Rp % 64 == 0 && Rp >= R && ldo >= Rp && ldo % 8 == 0, "slam_transpose_bf16: Rp must be a multiple of 64, >= R, <= ldo");
+  dim3 grid((unsigned)(Rp / 64), (unsigned)cdiv64(C, 64));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, ldi,
+                     (bf16_t*)out, ldo, (int)R, (int)C);
+  SLAM_CHECK_LAUNCH("slam_transpose_bf16");
+  return 0;
+}
+
+extern "C" int slam_swiglu_fwd(const void* gate_up, int64_t ldgu, void* h, int64_t ldh, int64_t M,
+                               int64_t F, void* stream) {
+  SLAM_CHECK_ARG(gate_up && h, "slam_swiglu_fwd: null pointer");
+  SLAM_CHECK_ARG(M > 0 && F > 0 && F % 8 == 0 && ldgu % 8 == 0 && ldh % 8 == 0, "slam_swiglu_fwd: F/ld must be multiples of 8");
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(ew_grid(M * (F / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)gate_up, ldgu, (bf16_t*)h, ldh, M, (int)F);
+  SLAM_CHECK_LAUNCH("slam_swiglu_fwd");
+  return 0;
+}
+
+extern "C" int slam_swiglu_bwd(const void* gate_up, int64_t ldgu, const void* dh, int64_t lddh,
+                               void* dgate_up, int64_t lddgu, int64_t M, int64_t F, void* stream) {
+  SLAM_CHECK_ARG(gate_up && dh && dgate_up, "slam_swiglu_bwd: null pointer");
+  SLAM_CHECK_ARG(M > 0 && F > 0 && F % 8 == 0 && ldgu % 8 == 0 && lddh % 8 == 0 && lddgu % 8 == 0,
+                 "slam_swiglu_bwd: F/ld must be multiples of 8");
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(ew_grid(M * (F / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)gate_up, ldgu, (const bf16_t*)dh, lddh, (bf16_t*)dgate_up, lddgu, M, (int)F);
+  SLAM_CHECK_LAUNCH("slam_swiglu_bwd");
+  return 0;
+}
+
+extern "C" int slam_conv1d_k3_im2col(const void* in, int in_dtype, void* out, int64_t B, int64_t Tin,
+                                     int64_t C, int64_t stride, int64_t Kp, void* stream) {
+  SLAM_CHECK_ARG(in && out, "slam_conv1d_k3_im2col: null pointer");
+  SLAM_CHECK_ARG(stride == 1 || stride == 2, "slam_conv1d_k3_im2col: stride %ld unsupported", (long)stride);
+  SLAM_CHECK_ARG(Kp >= 3 * C, "slam_conv1d_k3_im2col: Kp=%ld < 3*C=%ld", (long)Kp, (long)(3 * C));
+  SLAM_CHECK_ARG(B > 0 && Tin > 0 && C > 0, "slam_conv1d_k3_im2col: bad shape");
+  const int64_t Tout = (Tin + 2 - 3) / stride + 1;
+  const int64_t total = B * Tout * Kp;
+  if (in_dtype == SLAM_F32)
+    hipLaunchKernelGGL(im2col_k3_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)in, (bf16_t*)out, (int)B, (int)Tin, (int)Tout, (int)C, (int)Kp, (int)stride);
+  else if (in_dtype == SLAM_BF16)
+    hipLaunchKernelGGL(im2col_k3_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, (bf16_t*)out, (int)B, (int)Tin, (int)Tout, (int)C, (int)Kp, (int)stride);
+  else {
+    slam_set_error("slam_conv1d_k3_im2col: in_dtype %d unknown", in_dtype);
+    return -1;
+  }
+  SLAM_CHECK_LAUNCH("slam_conv1d_k3_im2col");
+  return 0;
+}
+
+extern "C" int slam_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
+  SLAM_CHECK_ARG(in && out && n > 0, "slam_cast_f32_to_bf16: bad arguments");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, in,
+                     (bf16_t*)out, n);
+  SLAM_CHECK_LAUNCH("slam_cast_f32_to_bf16");
+  return 0;
+}
+
+extern "C" int slam_embed_splice_fwd(int64_t* input_ids, const uint8_t* modality_mask,
+                                     const void* embed_table, int64_t vocab, const void* enc,
+                                     int64_t ldenc, void* out, int64_t ldo, int32_t* spans, int64_t B,
+                                     int64_t T, int64_t Ta, int64_t d, void* stream) {
+  SLAM_CHECK_ARG(input_ids && modality_mask && embed_table && enc && out && spans, "slam_embed_splice_fwd: null pointer");
+  SLAM_CHECK_ARG(B > 0 && T > 0 && Ta > 0 && d > 0 && d % 8 == 0 && ldenc % 8 == 0 && ldo % 8 == 0,
+                 "slam_embed_splice_fwd: bad shape (d, ld multiples of 8)");
+  hipLaunchKernelGGL(modality_spans_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream,
+                     modality_mask, (int)T, (int)Ta, spans);
+  hipLaunchKernelGGL(embed_splice_kernel, dim3((unsigned)(B * T)), dim3(256), 0, (hipStream_t)stream,
+                     input_ids, modality_mask, spans, (const bf16_t*)embed_table, (const bf16_t*)enc, ldenc,
+                     (bf16_t*)out, ldo, (int)T, (int)Ta, (int)d, vocab);
+  SLAM_CHECK_LAUNCH("slam_embed_splice_fwd");
+  return 0;
+}
+
+extern "C" int slam_embed_splice_bwd(const int32_t* spans, const void* dX, int64_t lddx, void* denc,
+                                     int64_t ldde, int64_t B, int64_t T, int64_t Ta, int64_t d,
+                                     void* stream) {
+  SLAM_CHECK_ARG(spans && dX && denc, "slam_embed_splice_bwd: null pointer");
+  SLAM_CHECK_ARG(B > 0 && T > 0 && Ta > 0 && d % 8 == 0 && lddx % 8 == 0 && ldde % 8 == 0,
+                 "slam_embed_splice_bwd: bad shape");
+  hipLaunchKernelGGL(embed_splice_bwd_kernel, dim3((unsigned)(B * Ta)), dim3(256), 0, (hipStream_t)stream,
+                     spans, (const bf16_t*)dX, lddx, (bf16_t*)denc, ldde, (int)T, (int)Ta, (int)d);
+  SLAM_CHECK_LAUNCH("slam_embed_splice_bwd");
+  return 0;
+}

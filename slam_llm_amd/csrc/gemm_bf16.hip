@@ -1,0 +1,286 @@
+// bf16 "NT" GEMM on MFMA for gfx950:  C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T)
+//
+// Every dense contraction on the SLAM hot path is routed through this one kernel
+// (reference sites: openai-whisper Linear/Conv1d called from
+// src/slam_llm/models/encoder.py:18-29, projector Linear src/slam_llm/models/projector.py:24-26,
+// HF LlamaDecoderLayer linears + lm_head via src/slam_llm/models/slam_model.py:400).
+// Frozen weights are kept in HBM in BOTH orientations (W and W^T; 288 GB makes that free), so the
+// backward dX = dY.W is again an NT product against W^T and no NN/TN variants exist.
+//
+// Structure (MI355X-first, see /opt/skills/guides/cdna_hip_programming.md section 5):
+//   * BMxBN output tile per workgroup, BK = 64, waves arranged WM x WN, each wave owns a
+//     (BM/WM)x(BN/WN) sub-tile of 16x16 MFMA fragments (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//   * A/B K-tiles are DMA'd HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS
+//     stages, one barrier per K-tile; the next tile's DMA is in flight during the MFMA phase.
+//   * LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-swizzled with (row & 7).  The DMA
+//     destination must stay lane-linear, so the swizzle is applied to the per-lane *source* address
+//     and again on the ds_read_b128 side (same involution) -> conflict-free fragment reads.
+//   * operands are swapped in the MFMA (B-fragment as the "A" operand) so each lane ends up with
+//     4 consecutive output columns -> 8-byte bf16 / 16-byte fp32 stores, float4 bias loads.
+//   * workgroup ids are remapped XCD-aware (block b runs on XCD b%8): each XCD gets a contiguous
+//     run of tiles, ordered in groups of 8 M-tiles, so A/B panels are re-used out of that XCD's L2.
+#include "common.h"
+
+namespace {
+
+struct GemmParams {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  const float* bias;
+  const bf16_t* res;
+  int64_t ldr;
+  int res_mod;
+  int act;  // 0 none, 1 gelu(erf), 2 relu
+  float alpha;
+  int out_f32;
+  int accumulate;
+  int tiles_m, tiles_n;
+};
+
+constexpr int BK = 64;           // bf16 elements per K-tile
+constexpr int ROWB = BK * 2;     // 128 bytes per LDS row
+
+__device__ __forceinline__ void glds16(const bf16_t* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int FM = WTM / 16, FN = WTN / 16;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int NIA = BM / 8 / NW;  // DMA instructions per wave per K-tile for A
+  constexpr int NIB = BN / 8 / NW;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- XCD-aware tile remap (bijective for any grid size) ----
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    bid = base + (bid >> 3);
+  }
+  constexpr int GM = 8;
+  const int per_group = GM * p.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GM;
+  const int gsz = min(GM, p.tiles_m - first_m);
+  const int within = bid - group * per_group;
+  const int tm = first_m + within % gsz;
+  const int tn = within / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- per-lane DMA source pointers (row clamp handles the M/N edges) ----
+  const int srow = lane >> 3;                // row within the 8-row DMA group
+  const int schunk = (lane & 7) ^ srow;      // swizzled source chunk
+  const bf16_t* a_src[NIA];
+  const bf16_t* b_src[NIB];
+#pragma unroll
+  for (int j = 0; j < NIA; j++) {
+    int r = m0 + (j * NW + wave) * 8 + srow;
+    r = min(r, p.M - 1);
+    a_src[j] = p.A + (int64_t)r * p.lda + schunk * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < NIB; j++) {
+    int r = n0 + (j * NW + wave) * 8 + srow;
+    r = min(r, p.N - 1);
+    b_src[j] = p.B + (int64_t)r * p.ldb + schunk * 8;
+  }
+
+  auto stage = [&](int kt, int s) {
+    char* sa = smem + s * STAGE;
+    char* sb = sa + BM * ROWB;
+    const int koff = kt * BK;
+#pragma unroll
+    for (int j = 0; j < NIA; j++) glds16(a_src[j] + koff, sa + (j * NW + wave) * 1024);
+#pragma unroll
+    for (int j = 0; j < NIB; j++) glds16(b_src[j] + koff, sb + (j * NW + wave) * 1024);
+  };
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; i++)
+#pragma unroll
+    for (int j = 0; j < FN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row = base + lane&15, chunk = ks*4 + lane>>4, swizzled by row&7
+  const int frow = lane & 15;
+  const int fg = lane >> 4;
+
+  const int nt = p.K / BK;
+  stage(0, 0);
+  for (int t = 0; t < nt; t++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+    const char* sa = smem + (t & 1) * STAGE;
+    const char* sb = sa + BM * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ks++) {
+      bf16x8_t af[FM], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < FM; i++) {
+        const int row = wm * WTM + i * 16 + frow;
+        const int ch = (ks * 4 + fg) ^ (row & 7);
+        af[i] = *reinterpret_cast<const bf16x8_t*>(sa + row * ROWB + ch * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < FN; j++) {
+        const int row = wn * WTN + j * 16 + frow;
+        const int ch = (ks * 4 + fg) ^ (row & 7);
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(sb + row * ROWB + ch * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; i++)
+#pragma unroll
+        for (int j = 0; j < FN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds C[m = ..+lane&15][n = ..+(lane>>4)*4 + 0..3] ----
+#pragma unroll
+  for (int i = 0; i < FM; i++) {
+    const int m = m0 + wm * WTM + i * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      const int n = n0 + wn * WTN + j * 16 + fg * 4;
+      if (n >= p.N) continue;  // N % 4 == 0 is enforced by the launcher
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = acc[i][j][e] * p.alpha;
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.res) {
+        const int rr = p.res_mod > 0 ? (m % p.res_mod) : m;
+        const u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.res + (int64_t)rr * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] += bf2f(r4[e]);
+      }
+      if (p.out_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+        if (p.accumulate) {
+          const float4 o = *reinterpret_cast<const float4*>(c);
+          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+        }
+        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n;
+        if (p.accumulate) {
+          const u16x4_t o = *reinterpret_cast<const u16x4_t*>(c);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += bf2f(o[e]);
+        }
+        uint2 o2;
+        o2.x = pack2bf(v[0], v[1]);
+        o2.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(c) = o2;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_gemm(GemmParams& p, hipStream_t stream) {
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  constexpr int lds = 2 * (BM + BN) * ROWB;
+  static bool attr_set = false;
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN>;
+  if (!attr_set && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      slam_set_error("gemm: cannot raise LDS limit to %d: %s", lds, hipGetErrorString(e));
+      return -2;
+    }
+    attr_set = true;
+  }
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), lds, stream, p);
+  SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt");
+  return 0;
+}
+
+int g_gemm_cfg = 0;  // 0 = auto
+
+}  // namespace
+
+extern "C" int slam_gemm_set_config(int cfg) {
+  SLAM_CHECK_ARG(cfg >= 0 && cfg <= 4, "slam_gemm_set_config: cfg %d out of range [0,4]", cfg);
+  g_gemm_cfg = cfg;
+  return 0;
+}
+
+extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                                 int64_t ldc, int64_t M, int64_t N, int64_t K, const float* bias,
+                                 const void* residual, int64_t ldr, int64_t res_row_mod, int act,
+                                 float alpha, int out_dtype, int accumulate, void* stream) {
+  SLAM_CHECK_ARG(A && B && C, "slam_gemm_bf16_nt: null operand");
+  SLAM_CHECK_ARG(M > 0 && N > 0 && K > 0, "slam_gemm_bf16_nt: bad shape M=%ld N=%ld K=%ld", (long)M,
+                 (long)N, (long)K);
+  SLAM_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "slam_gemm_bf16_nt: dim >= 2^31");
+  SLAM_CHECK_ARG(K % 64 == 0, "slam_gemm_bf16_nt: K=%ld must be a multiple of 64 (pad the operands)", (long)K);
+  SLAM_CHECK_ARG(N % 4 == 0, "slam_gemm_bf16_nt: N=%ld must be a multiple of 4", (long)N);
+  SLAM_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, "slam_gemm_bf16_nt: lda/ldb must be multiples of 8 elements");
+  SLAM_CHECK_ARG(ldc % 4 == 0, "slam_gemm_bf16_nt: ldc must be a multiple of 4 elements");
+  SLAM_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
+                 "slam_gemm_bf16_nt: operands must be 16-byte aligned");
+  SLAM_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "slam_gemm_bf16_nt: leading dimension too small");
+  SLAM_CHECK_ARG(act >= 0 && act <= 2, "slam_gemm_bf16_nt: act %d unknown", act);
+  SLAM_CHECK_ARG(out_dtype == SLAM_BF16 || out_dtype == SLAM_F32, "slam_gemm_bf16_nt: out_dtype %d unknown", out_dtype);
+  if (residual) {
+    SLAM_CHECK_ARG(ldr % 4 == 0 && ldr >= N && ((uintptr_t)residual % 8) == 0,
+                   "slam_gemm_bf16_nt: bad residual layout");
+  }
+  GemmParams p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.bias = bias; p.res = (const bf16_t*)residual; p.ldr = ldr; p.res_mod = (int)res_row_mod;
+  p.act = act; p.alpha = alpha; p.out_f32 = (out_dtype == SLAM_F32); p.accumulate = accumulate;
+  hipStream_t s = (hipStream_t)stream;
+  int cfg = g_gemm_cfg;
+  if (cfg == 0) {
+    // auto: big square-ish problems take the 256x128 tile (8 waves); narrow N takes 128x64.
+    if (N <= 64) cfg = 3;
+    else if (M >= 2048 && N >= 1024) cfg = 2;
+    else cfg = 1;
+  }
+  switch (cfg) {
+    case 1: return launch_gemm<128, 128, 2, 2>(p, s);
+    case 2: return launch_gemm<256, 128, 4, 2>(p, s);
+    case 3: return launch_gemm<128, 64, 2, 2>(p, s);
+    case 4: return launch_gemm<256, 256, 2, 4>(p, s);
+  }
+  slam_set_error("slam_gemm_bf16_nt: bad config %d", cfg);
+  return -1;
+}

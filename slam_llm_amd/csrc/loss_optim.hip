@@ -1,0 +1,235 @@
+// Shifted masked cross-entropy + argmax accuracy over bf16 logits, and fused flat AdamW.
+//
+// Reference semantics:
+//  * HF ForCausalLMLoss (transformers/loss/loss_utils.py:32-70): logits upcast to fp32, labels shifted by
+//    one, mean CE over labels != -100 (ignore_index), per local batch.
+//  * accuracy: argmax(logits)[:, :-1] == labels[:, 1:] over labels != -100
+//    (src/slam_llm/models/slam_model.py:402-405, src/slam_llm/utils/metric.py:3-19).
+//  * AdamW: torch.optim.AdamW as constructed at src/slam_llm/pipeline/finetune.py:247-251
+//    (decoupled weight decay, bias correction, eps added after sqrt(v_hat)).
+// The CE kernel never materialises fp32 logits; rows whose shifted label is ignored only get their gradient
+// row zeroed.  Row losses are reduced by a single-block kernel in a fixed order -> bit-reproducible loss.
+#include "common.h"
+
+namespace {
+
+// tgt[row=b*T+t] = t+1<T ? labels[b,t+1] : -100 ; n_valid = #(tgt != ignore)
+__global__ __launch_bounds__(1024) void ce_targets_kernel(const int64_t* __restrict__ labels,
+                                                          int32_t* __restrict__ tgt,
+                                                          int32_t* __restrict__ n_valid, int64_t M, int T,
+                                                          int ignore_index) {
+  __shared__ int red[16];
+  int cnt = 0;
+  for (int64_t r = threadIdx.x; r < M; r += 1024) {
+    const int t = (int)(r % T);
+    int64_t l = (t + 1 < T) ? labels[r + 1] : (int64_t)ignore_index;
+    if (l != ignore_index) cnt++;
+    tgt[r] = (l == ignore_index) ? -1 : (int32_t)l;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int i = 0; i < 16; i++) s += red[i];
+    *n_valid = s;
+  }
+}
+
+struct MaxSum {
+  float m, s;
+  int idx;
+};
+__device__ __forceinline__ MaxSum ms_combine(MaxSum a, MaxSum b) {
+  MaxSum r;
+  if (b.m > a.m || (b.m == a.m && b.idx < a.idx)) {
+    r.m = b.m; r.idx = b.idx;
+  } else {
+    r.m = a.m; r.idx = a.idx;
+  }
+  // (-inf, 0) is the identity element (lanes that saw no chunk); avoid exp(-inf - -inf) = NaN
+  const float ea = (a.m == -INFINITY) ? 0.f : __expf(a.m - r.m);
+  const float eb = (b.m == -INFINITY) ? 0.f : __expf(b.m - r.m);
+  r.s = a.s * ea + b.s * eb;
+  return r;
+}
+
+// one workgroup per logits row; logits are overwritten with dlogits when write_grad != 0
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(bf16_t* __restrict__ logits, int64_t ld,
+                                                         const int32_t* __restrict__ tgt,
+                                                         const int32_t* __restrict__ n_valid,
+                                                         float* __restrict__ row_loss,
+                                                         int32_t* __restrict__ row_correct, int V,
+                                                         int write_grad) {
+  __shared__ float sm[4], ss[4];
+  __shared__ int si[4];
+  const int64_t row = blockIdx.x;
+  const int target = tgt[row];
+  bf16_t* lr = logits + row * ld;
+  const int nch = V >> 3;
+  const int tid = threadIdx.x;
+  if (target < 0) {
+    if (tid == 0) {
+      row_loss[row] = 0.f;
+      row_correct[row] = 0;
+    }
+    if (write_grad) {
+      u16x8_t z;
+#pragma unroll
+      for (int e = 0; e < 8; e++) z[e] = 0;
+      for (int c = tid; c < nch; c += 256) *reinterpret_cast<u16x8_t*>(lr + c * 8) = z;
+    }
+    return;
+  }
+  MaxSum a;
+  a.m = -INFINITY; a.s = 0.f; a.idx = 0x7fffffff;
+  for (int c = tid; c < nch; c += 256) {
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(lr + c * 8);
+    float f[8];
+    float cm = -INFINITY;
+    int ci = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      f[e] = bf2f(v[e]);
+      if (f[e] > cm) { cm = f[e]; ci = e; }
+    }
+    float cs = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) cs += __expf(f[e] - cm);
+    MaxSum b;
+    b.m = cm; b.s = cs; b.idx = c * 8 + ci;
+    a = ms_combine(a, b);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MaxSum b;
+    b.m = __shfl_xor(a.m, o, 64);
+    b.s = __shfl_xor(a.s, o, 64);
+    b.idx = __shfl_xor(a.idx, o, 64);
+    a = ms_combine(a, b);
+  }
+  if ((tid & 63) == 0) { sm[tid >> 6] = a.m; ss[tid >> 6] = a.s; si[tid >> 6] = a.idx; }
+  __syncthreads();
+  MaxSum t;
+  t.m = sm[0]; t.s = ss[0]; t.idx = si[0];
+#pragma unroll
+  for (int i = 1; i < 4; i++) {
+    MaxSum b;
+    b.m = sm[i]; b.s = ss[i]; b.idx = si[i];
+    t = ms_combine(t, b);
+  }
+  const float lse = t.m + __logf(t.s);
+  if (tid == 0) {
+    row_loss[row] = lse - bf2f(lr[target]);
+    row_correct[row] = (t.idx == target) ? 1 : 0;
+  }
+  if (write_grad) {
+    __syncthreads();  // the target logit has been read by thread 0 before it is overwritten
+    const float inv_n = 1.0f / (float)max(*n_valid, 1);
+    for (int c = tid; c < nch; c += 256) {
+      const u16x8_t v = *reinterpret_cast<const u16x8_t*>(lr + c * 8);
+      u16x8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float p = __expf(bf2f(v[e]) - lse);
+        if (c * 8 + e == target) p -= 1.0f;
+        o[e] = f2bf(p * inv_n);
+      }
+      *reinterpret_cast<u16x8_t*>(lr + c * 8) = o;
+    }
+  }
+}
+
+// out[0] = mean loss, out[1] = accuracy, fixed summation order
+__global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* __restrict__ row_loss,
+                                                           const int32_t* __restrict__ row_correct,
+                                                           const int32_t* __restrict__ n_valid, int64_t M,
+                                                           float* __restrict__ out) {
+  __shared__ float rl[16];
+  __shared__ int rc[16];
+  float l = 0.f;
+  int c = 0;
+  for (int64_t r = threadIdx.x; r < M; r += 1024) {
+    l += row_loss[r];
+    c += row_correct[r];
+  }
+  l = wave_sum(l);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) { rl[threadIdx.x >> 6] = l; rc[threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float L = 0.f;
+    int C = 0;
+    for (int i = 0; i < 16; i++) { L += rl[i]; C += rc[i]; }
+    const float n = (float)(*n_valid);
+    out[0] = L / n;   // n == 0 -> NaN, same as torch's mean over an empty selection
+    out[1] = (float)C / n;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ p_bf16, int64_t n, float lr,
+                                                    float beta1, float beta2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt, float gscale) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * gscale;
+    float pi = p[i];
+    pi *= (1.0f - lr * wd);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (p_bf16) p_bf16[i] = f2bf(pi);
+  }
+}
+
+}  // namespace
+
+extern "C" int slam_ce_targets(const int64_t* labels, int32_t* targets, int32_t* n_valid, int64_t B,
+                               int64_t T, int64_t ignore_index, void* stream) {
+  SLAM_CHECK_ARG(labels && targets && n_valid && B > 0 && T > 0, "slam_ce_targets: bad arguments");
+  hipLaunchKernelGGL(ce_targets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, targets,
+                     n_valid, B * T, (int)T, (int)ignore_index);
+  SLAM_CHECK_LAUNCH("slam_ce_targets");
+  return 0;
+}
+
+extern "C" int slam_ce_fwd_bwd(void* logits, int64_t ld, const int32_t* targets, const int32_t* n_valid,
+                               float* row_loss, int32_t* row_correct, int64_t rows, int64_t V,
+                               int write_grad, void* stream) {
+  SLAM_CHECK_ARG(logits && targets && n_valid && row_loss && row_correct, "slam_ce_fwd_bwd: null pointer");
+  SLAM_CHECK_ARG(rows > 0 && V > 0 && V % 8 == 0 && ld % 8 == 0 && ld >= V, "slam_ce_fwd_bwd: V and ld must be multiples of 8");
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)logits, ld, targets, n_valid, row_loss, row_correct, (int)V, write_grad);
+  SLAM_CHECK_LAUNCH("slam_ce_fwd_bwd");
+  return 0;
+}
+
+extern "C" int slam_ce_finalize(const float* row_loss, const int32_t* row_correct, const int32_t* n_valid,
+                                int64_t rows, float* out2, void* stream) {
+  SLAM_CHECK_ARG(row_loss && row_correct && n_valid && out2 && rows > 0, "slam_ce_finalize: bad arguments");
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss,
+                     row_correct, n_valid, rows, out2);
+  SLAM_CHECK_LAUNCH("slam_ce_finalize");
+  return 0;
+}
+
+extern "C" int slam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                               void* param_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int64_t step, float grad_scale, void* stream) {
+  SLAM_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0, "slam_adamw_step: bad arguments");
+  SLAM_CHECK_ARG(step >= 1, "slam_adamw_step: step must be >= 1 (got %ld)", (long)step);
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = 1.0f - powf(beta2, (float)step);
+  int64_t g = cdiv64(n, 256);
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, param, grad,
+                     exp_avg, exp_avg_sq, (bf16_t*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1,
+                     sqrtf(bc2), grad_scale);
+  SLAM_CHECK_LAUNCH("slam_adamw_step");
+  return 0;
+}

@@ -1,0 +1,182 @@
+// HBM-bound row normalisations: LayerNorm (Whisper encoder) and RMSNorm fwd/bwd (Llama).
+//
+// Reference semantics:
+//  * openai-whisper LayerNorm computes in fp32 and casts back (called from
+//    src/slam_llm/models/encoder.py:26-29 via the blocks and ln_post).
+//  * HF LlamaRMSNorm: variance in fp32, x*rsqrt(var+eps) cast back to the input dtype, THEN multiplied
+//    by the weight (transformers/models/llama/modeling_llama.py:62-67) -> two roundings, reproduced here.
+// One wave (64 lanes) per row, 16-byte (8 x bf16) accesses, 4 rows per 256-thread workgroup; rows are
+// re-read from L1/L2 for the second/third pass, so HBM traffic is one read + one write per element.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ b,
+                                                        bf16_t* __restrict__ y, int64_t ldy, int M,
+                                                        int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const bf16_t* xr = x + (int64_t)row * ldx;
+  const int nch = d >> 3;
+  float s = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; e++) s += bf2f(v[e]);
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float t = bf2f(v[e]) - mean;
+      q += t * t;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  bf16_t* yr = y + (int64_t)row * ldy;
+  for (int c = lane; c < nch; c += 64) {
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+    const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + c * 8);
+    const float4 b1 = *reinterpret_cast<const float4*>(b + c * 8 + 4);
+    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf((bf2f(v[e]) - mean) * rstd * ww[e] + bb[e]);
+    *reinterpret_cast<u16x8_t*>(yr + c * 8) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ w,
+                                                          bf16_t* __restrict__ y, int64_t ldy,
+                                                          float* __restrict__ rstd_out, int M, int d,
+                                                          float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const bf16_t* xr = x + (int64_t)row * ldx;
+  const int nch = d >> 3;
+  float q = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float t = bf2f(v[e]);
+      q += t * t;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+  bf16_t* yr = y + (int64_t)row * ldy;
+  for (int c = lane; c < nch; c += 64) {
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+    const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
+    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float xn = bf2f(f2bf(bf2f(v[e]) * rstd));  // cast back to the input dtype first
+      o[e] = f2bf(ww[e] * xn);
+    }
+    *reinterpret_cast<u16x8_t*>(yr + c * 8) = o;
+  }
+}
+
+// dx = rstd * (g - xhat * mean(g * xhat)) [* gscale] + dres ,  g = dy * w, xhat = x * rstd
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(
+    const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ rstd_in,
+    const float* __restrict__ w, const bf16_t* __restrict__ dy, int64_t lddy,
+    const bf16_t* __restrict__ dres, int64_t lddres, bf16_t* __restrict__ dx, int64_t lddx,
+    const float* __restrict__ gscale, int M, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const bf16_t* xr = x + (int64_t)row * ldx;
+  const bf16_t* dyr = dy + (int64_t)row * lddy;
+  const float rstd = rstd_in[row];
+  const float gs = gscale ? *gscale : 1.0f;
+  const int nch = d >> 3;
+  float dot = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+    const u16x8_t g = *reinterpret_cast<const u16x8_t*>(dyr + c * 8);
+    const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
+    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+    for (int e = 0; e < 8; e++) dot += bf2f(g[e]) * ww[e] * bf2f(v[e]) * rstd;
+  }
+  const float mdot = wave_sum(dot) / (float)d;
+  bf16_t* dxr = dx + (int64_t)row * lddx;
+  for (int c = lane; c < nch; c += 64) {
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+    const u16x8_t g = *reinterpret_cast<const u16x8_t*>(dyr + c * 8);
+    const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
+    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    u16x8_t r;
+    if (dres) r = *reinterpret_cast<const u16x8_t*>(dres + (int64_t)row * lddres + c * 8);
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float xh = bf2f(v[e]) * rstd;
+      float t = rstd * (bf2f(g[e]) * ww[e] - xh * mdot) * gs;
+      if (dres) t += bf2f(r[e]);
+      o[e] = f2bf(t);
+    }
+    *reinterpret_cast<u16x8_t*>(dxr + c * 8) = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int slam_layernorm_fwd(const void* x, int64_t ldx, const float* weight, const float* bias,
+                                  void* y, int64_t ldy, int64_t M, int64_t d, float eps, void* stream) {
+  SLAM_CHECK_ARG(x && weight && bias && y, "slam_layernorm_fwd: null pointer");
+  SLAM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0, "slam_layernorm_fwd: bad shape M=%ld d=%ld (d%%8 must be 0)", (long)M, (long)d);
+  SLAM_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= d && ldy >= d, "slam_layernorm_fwd: bad leading dims");
+  const unsigned grid = (unsigned)cdiv64(M, ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(layernorm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     ldx, weight, bias, (bf16_t*)y, ldy, (int)M, (int)d, eps);
+  SLAM_CHECK_LAUNCH("slam_layernorm_fwd");
+  return 0;
+}
+
+extern "C" int slam_rmsnorm_fwd(const void* x, int64_t ldx, const float* weight, void* y, int64_t ldy,
+                                float* rstd, int64_t M, int64_t d, float eps, void* stream) {
+  SLAM_CHECK_ARG(x && weight && y, "slam_rmsnorm_fwd: null pointer");
+  SLAM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0, "slam_rmsnorm_fwd: bad shape M=%ld d=%ld (d%%8 must be 0)", (long)M, (long)d);
+  SLAM_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= d && ldy >= d, "slam_rmsnorm_fwd: bad leading dims");
+  const unsigned grid = (unsigned)cdiv64(M, ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, weight, (bf16_t*)y, ldy, rstd, (int)M, (int)d, eps);
+  SLAM_CHECK_LAUNCH("slam_rmsnorm_fwd");
+  return 0;
+}
+
+extern "C" int slam_rmsnorm_bwd(const void* x, int64_t ldx, const float* rstd, const float* weight,
+                                const void* dy, int64_t lddy, const void* dres, int64_t lddres,
+                                void* dx, int64_t lddx, const float* grad_scale, int64_t M, int64_t d,
+                                void* stream) {
+  SLAM_CHECK_ARG(x && rstd && weight && dy && dx, "slam_rmsnorm_bwd: null pointer");
+  SLAM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0, "slam_rmsnorm_bwd: bad shape M=%ld d=%ld", (long)M, (long)d);
+  SLAM_CHECK_ARG(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && (!dres || lddres % 8 == 0),
+                 "slam_rmsnorm_bwd: leading dims must be multiples of 8");
+  const unsigned grid = (unsigned)cdiv64(M, ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, rstd, weight, (const bf16_t*)dy, lddy, (const bf16_t*)dres,
+                     lddres, (bf16_t*)dx, lddx, grad_scale, (int)M, (int)d);
+  SLAM_CHECK_LAUNCH("slam_rmsnorm_bwd");
+  return 0;
+}

@@ -1,0 +1,90 @@
+"""ctypes binding of libslamhip.so (C ABI declared in include/slam_hip.h).
+
+This is the reference-side stub a SLAM-LLM maintainer would add: plain pointers and
+sizes in, an int return code out, ``RuntimeError(slam_last_error())`` on failure -- mirroring the reference's
+"raise a Python exception" convention (src/slam_llm/utils/model_utils.py:17-23).  There is NO CPU fallback:
+if the shared library is missing or a symbol is absent, importing this module fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslamhip.so")
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+P, I64, I32, F = c_void_p, c_int64, c_int, c_float
+
+# name -> argtypes; every symbol of include/slam_hip.h (tests/test_capi_symbols.py checks the two agree)
+SIGNATURES = {
+    "slam_logmel_workspace_bytes": [I64],
+    "slam_logmel_fwd": [P, I64, P, I64, P, P, P, I64, P, P, I64, P],
+    "slam_gemm_bf16_nt": [P, I64, P, I64, P, I64, I64, I64, I64, P, P, I64, I64, I32, F, I32, I32, P],
+    "slam_gemm_set_config": [I32],
+    "slam_conv1d_k3_im2col": [P, I32, P, I64, I64, I64, I64, I64, P],
+    "slam_layernorm_fwd": [P, I64, P, P, P, I64, I64, I64, F, P],
+    "slam_rmsnorm_fwd": [P, I64, P, P, I64, P, I64, I64, F, P],
+    "slam_rmsnorm_bwd": [P, I64, P, P, P, I64, P, I64, P, I64, P, I64, I64, P],
+    "slam_head_rope_transpose": [P, I64, I64, P, P, I32, P, I64, I64, I64, I64, I64, P],
+    "slam_transpose_bf16": [P, I64, P, I64, I64, I64, I64, P],
+    "slam_attn_fwd": [P, I64, P, I64, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, I32, F, P],
+    "slam_attn_bwd": [P, I64, P, I64, P, I64, P, P, P, I64, P, I64, P, P, P, P, P, I64, P, I64, P, I64,
+                      I64, I64, I64, I64, I64, I64, I32, F, P],
+    "slam_swiglu_fwd": [P, I64, P, I64, I64, I64, P],
+    "slam_swiglu_bwd": [P, I64, P, I64, P, I64, I64, I64, P],
+    "slam_embed_splice_fwd": [P, P, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P],
+    "slam_embed_splice_bwd": [P, P, I64, P, I64, I64, I64, I64, I64, P],
+    "slam_ce_targets": [P, P, P, I64, I64, I64, P],
+    "slam_ce_fwd_bwd": [P, I64, P, P, P, P, I64, I64, I32, P],
+    "slam_ce_finalize": [P, P, P, I64, P, P],
+    "slam_adamw_step": [P, P, P, P, P, I64, F, F, F, F, F, I64, F, P],
+    "slam_cast_f32_to_bf16": [P, P, I64, P],
+}
+
+
+class SlamHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the SLAM hot path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.slam_last_error.restype = c_char_p
+    lib.slam_last_error.argtypes = []
+    lib.slam_abi_version.restype = c_int
+    lib.slam_target_arch.restype = c_char_p
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so and the header ever diverge
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    return lib
+
+
+_lib = _load()
+
+
+def raw():
+    """The ctypes CDLL handle (for symbol checks)."""
+    return _lib
+
+
+def last_error() -> str:
+    return (_lib.slam_last_error() or b"").decode()
+
+
+def call(name: str, *args) -> int:
+    """Invoke a C-ABI entry point; raise SlamHipError on a non-zero return code."""
+    rc = getattr(_lib, name)(*args)
+    if name == "slam_logmel_workspace_bytes":
+        return rc
+    if rc != 0:
+        raise SlamHipError(f"{name} failed (rc={rc}): {last_error()}")
+    return rc

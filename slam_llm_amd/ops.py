@@ -1,0 +1,273 @@
+"""Tensor-level wrappers over the C ABI (device memory + stream plumbing only).
+
+torch supplies HBM allocations (`torch.empty`) and the current HIP stream; every arithmetic step is a
+hand-written gfx950 kernel in libslamhip.so.  Nothing here falls back to a PyTorch op: tensors that are not
+on a HIP device are rejected.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import torch
+
+from . import lib
+from .lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, call  # noqa: F401
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise lib.SlamHipError("slam_llm_amd ops need tensors resident in HBM (cuda/HIP device); got a CPU tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _ld(t: torch.Tensor) -> int:
+    """leading dimension (elements) of a 2-D row-major view"""
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a 2-D tensor with unit column stride"
+    return t.stride(0)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None,
+            residual=None, res_row_mod: int = 0, act: int = ACT_NONE, alpha: float = 1.0,
+            out_dtype=torch.bfloat16, accumulate: bool = False) -> torch.Tensor:
+    """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T).  a, b bf16 (row views with arbitrary ld)."""
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    M, K = a.shape
+    N, K2 = b.shape
+    assert K == K2, f"K mismatch {K} vs {K2}"
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    od = F32 if out.dtype == torch.float32 else BF16
+    call("slam_gemm_bf16_nt", _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, N, K, _p(bias),
+         _p(residual), _ld(residual) if residual is not None else 0, res_row_mod, act, alpha, od,
+         1 if accumulate else 0, _s())
+    return out
+
+
+def gemm_set_config(cfg: int):
+    call("slam_gemm_set_config", cfg)
+
+
+# ------------------------------------------------------------------------------------------------ mel
+_MEL_TABLES = {}
+
+
+def _hz_to_mel_slaney(f):
+    import numpy as np
+    f = np.asarray(f, dtype=np.float64)
+    mels = 3.0 * f / 200.0
+    min_log_hz, min_log_mel, logstep = 1000.0, 15.0, 27.0 / math.log(6.4)
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) * logstep, mels)
+
+
+def _mel_to_hz_slaney(m):
+    import numpy as np
+    m = np.asarray(m, dtype=np.float64)
+    f = 200.0 * m / 3.0
+    min_log_hz, min_log_mel, logstep = 1000.0, 15.0, math.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f)
+
+
+def mel_filterbank(n_mels: int, n_fft: int = 400, sr: int = 16000):
+    """librosa-slaney mel filters [n_mels, 201] (what openai-whisper ships in assets/mel_filters.npz)."""
+    import numpy as np
+    fft_freqs = np.linspace(0, sr / 2, n_fft // 2 + 1)
+    mel_pts = np.linspace(_hz_to_mel_slaney(0.0), _hz_to_mel_slaney(sr / 2.0), n_mels + 2)
+    hz_pts = _mel_to_hz_slaney(mel_pts)
+    fdiff = np.diff(hz_pts)
+    ramps = hz_pts[:, None] - fft_freqs[None, :]
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    w = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (hz_pts[2:n_mels + 2] - hz_pts[:n_mels])
+    return (w * enorm[:, None]).astype(np.float32)
+
+
+def _mel_tables(n_mels: int, device):
+    key = (n_mels, str(device))
+    if key not in _MEL_TABLES:
+        import numpy as np
+        n = np.arange(400, dtype=np.float64)
+        window = (0.5 - 0.5 * np.cos(2 * np.pi * n / 400)).astype(np.float32)
+        k = np.arange(208, dtype=np.float64)
+        ang = 2 * np.pi * np.outer(n, k) / 400.0
+        tw = np.zeros((400, 416), dtype=np.float32)
+        tw[:, :201] = np.cos(ang[:, :201])
+        tw[:, 208:208 + 201] = np.sin(ang[:, :201])
+        melT = np.ascontiguousarray(mel_filterbank(n_mels).T)  # [201, n_mels]
+        _MEL_TABLES[key] = tuple(torch.from_numpy(x).to(device) for x in (window, tw, melT))
+    return _MEL_TABLES[key]
+
+
+def logmel(audio: torch.Tensor, n_mels: int, n_samples: int = 480000,
+           n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """audio [B, >=?] f32 on device -> [B, n_samples/160, n_mels] f32 (pad_or_trim + log_mel_spectrogram)."""
+    assert audio.dtype == torch.float32 and audio.dim() == 2
+    B = audio.shape[0]
+    if n_valid is None and audio.shape[1] < n_samples:
+        n_valid = torch.full((B,), audio.shape[1], dtype=torch.int32, device=audio.device)
+    window, tw, melT = _mel_tables(n_mels, audio.device)
+    out = torch.empty((B, n_samples // 160, n_mels), dtype=torch.float32, device=audio.device)
+    ws = torch.empty((B,), dtype=torch.int32, device=audio.device)
+    call("slam_logmel_fwd", _p(audio), audio.stride(0), _p(n_valid), n_samples, _p(window), _p(tw), _p(melT),
+         n_mels, _p(out), _p(ws), B, _s())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ conv/norm
+def conv1d_k3_im2col(x: torch.Tensor, stride: int, Kp: int) -> torch.Tensor:
+    """x [B, Tin, C] (f32|bf16) -> [B*Tout, Kp] bf16"""
+    B, Tin, C = x.shape
+    assert x.is_contiguous()
+    Tout = (Tin + 2 - 3) // stride + 1
+    out = torch.empty((B * Tout, Kp), dtype=torch.bfloat16, device=x.device)
+    call("slam_conv1d_k3_im2col", _p(x), F32 if x.dtype == torch.float32 else BF16, _p(out), B, Tin, C, stride,
+         Kp, _s())
+    return out
+
+
+def layernorm(x, weight, bias, eps=1e-5, out=None):
+    M, d = x.shape
+    if out is None:
+        out = torch.empty((M, d), dtype=torch.bfloat16, device=x.device)
+    call("slam_layernorm_fwd", _p(x), _ld(x), _p(weight), _p(bias), _p(out), _ld(out), M, d, eps, _s())
+    return out
+
+
+def rmsnorm_fwd(x, weight, eps, out=None, rstd=None):
+    M, d = x.shape
+    if out is None:
+        out = torch.empty((M, d), dtype=torch.bfloat16, device=x.device)
+    if rstd is None:
+        rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+    call("slam_rmsnorm_fwd", _p(x), _ld(x), _p(weight), _p(out), _ld(out), _p(rstd), M, d, eps, _s())
+    return out, rstd
+
+
+def rmsnorm_bwd(x, rstd, weight, dy, dres=None, grad_scale=None, out=None):
+    M, d = x.shape
+    if out is None:
+        out = torch.empty((M, d), dtype=torch.bfloat16, device=x.device)
+    call("slam_rmsnorm_bwd", _p(x), _ld(x), _p(rstd), _p(weight), _p(dy), _ld(dy), _p(dres),
+         _ld(dres) if dres is not None else 0, _p(out), _ld(out), _p(grad_scale), M, d, _s())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ rope / transposes
+def head_rope_transpose(src2d, col0, B, T, H, D, cos=None, sin=None, inverse=False, want_t=True, Tp=None):
+    """In-place RoPE on columns [col0, col0+H*D) of src2d [B*T, ld]; returns [B,H,D,Tp] transposed copy."""
+    Tp = Tp or round_up(T, 64)
+    dst = torch.empty((B, H, D, Tp), dtype=torch.bfloat16, device=src2d.device) if want_t else None
+    call("slam_head_rope_transpose", _p(src2d), _ld(src2d), col0, _p(cos), _p(sin), 1 if inverse else 0,
+         _p(dst), B, T, Tp, H, D, _s())
+    return dst
+
+
+def transpose(x2d, Rp=None, out=None):
+    R, C = x2d.shape
+    Rp = Rp or round_up(R, 64)
+    if out is None:
+        out = torch.empty((C, Rp), dtype=torch.bfloat16, device=x2d.device)
+    call("slam_transpose_bf16", _p(x2d), _ld(x2d), _p(out), _ld(out), R, C, Rp, _s())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_lse=True, out=None):
+    Tp = vt.shape[-1]
+    if out is None:
+        out = torch.empty((B * T, Hq * D), dtype=torch.bfloat16, device=q2d.device)
+    lse = torch.empty((B, Hq, Tp), dtype=torch.float32, device=q2d.device) if want_lse else None
+    call("slam_attn_fwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(vt), _p(out), _ld(out), _p(lse),
+         _p(key_mask), B, T, Tp, Hq, Hkv, D, 1 if causal else 0, scale, _s())
+    return out, lse
+
+
+def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T, Hq, Hkv, D, causal, scale,
+             key_mask=None):
+    Tp = qt.shape[-1]
+    delta = torch.empty((B, Hq, Tp), dtype=torch.float32, device=q2d.device)
+    call("slam_attn_bwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(v2d), _ld(v2d), _p(qt), _p(kt), _p(o2d),
+         _ld(o2d), _p(do2d), _ld(do2d), _p(dot), _p(lse), _p(delta), _p(key_mask), _p(dq2d), _ld(dq2d),
+         _p(dk2d), _ld(dk2d), _p(dv2d), _ld(dv2d), B, T, Tp, Hq, Hkv, D, 1 if causal else 0, scale, _s())
+    return delta
+
+
+# ------------------------------------------------------------------------------------------------ mlp
+def swiglu_fwd(gu, out=None):
+    M, F2 = gu.shape
+    Fd = F2 // 2
+    if out is None:
+        out = torch.empty((M, Fd), dtype=torch.bfloat16, device=gu.device)
+    call("slam_swiglu_fwd", _p(gu), _ld(gu), _p(out), _ld(out), M, Fd, _s())
+    return out
+
+
+def swiglu_bwd(gu, dh, out=None):
+    M, F2 = gu.shape
+    if out is None:
+        out = torch.empty((M, F2), dtype=torch.bfloat16, device=gu.device)
+    call("slam_swiglu_bwd", _p(gu), _ld(gu), _p(dh), _ld(dh), _p(out), _ld(out), M, F2 // 2, _s())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ embed / loss / optim
+def embed_splice_fwd(input_ids, modality_mask_u8, embed_table, enc3d):
+    B, T = input_ids.shape
+    Ta, d = enc3d.shape[1], enc3d.shape[2]
+    assert enc3d.stride(2) == 1 and enc3d.stride(0) == Ta * enc3d.stride(1)
+    out = torch.empty((B * T, d), dtype=torch.bfloat16, device=enc3d.device)
+    spans = torch.empty((B, 2), dtype=torch.int32, device=enc3d.device)
+    call("slam_embed_splice_fwd", _p(input_ids), _p(modality_mask_u8), _p(embed_table), embed_table.shape[0],
+         _p(enc3d), enc3d.stride(1), _p(out), _ld(out), _p(spans), B, T, Ta, d, _s())
+    return out, spans
+
+
+def embed_splice_bwd(spans, dx2d, B, T, Ta, d):
+    out = torch.empty((B * Ta, d), dtype=torch.bfloat16, device=dx2d.device)
+    call("slam_embed_splice_bwd", _p(spans), _p(dx2d), _ld(dx2d), _p(out), _ld(out), B, T, Ta, d, _s())
+    return out
+
+
+def ce_targets(labels, ignore_index=-100):
+    B, T = labels.shape
+    tgt = torch.empty((B * T,), dtype=torch.int32, device=labels.device)
+    nv = torch.empty((1,), dtype=torch.int32, device=labels.device)
+    call("slam_ce_targets", _p(labels), _p(tgt), _p(nv), B, T, ignore_index, _s())
+    return tgt, nv
+
+
+def ce_fwd_bwd(logits2d, targets, n_valid, row_loss, row_correct, write_grad=True):
+    rows, V = logits2d.shape
+    call("slam_ce_fwd_bwd", _p(logits2d), _ld(logits2d), _p(targets), _p(n_valid), _p(row_loss),
+         _p(row_correct), rows, V, 1 if write_grad else 0, _s())
+
+
+def ce_finalize(row_loss, row_correct, n_valid):
+    out = torch.empty((2,), dtype=torch.float32, device=row_loss.device)
+    call("slam_ce_finalize", _p(row_loss), _p(row_correct), _p(n_valid), row_loss.numel(), _p(out), _s())
+    return out
+
+
+def adamw_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    call("slam_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), lr, beta1, beta2, eps, wd, step,
+         grad_scale, _s())
+
+
+def cast_bf16(src_f32, dst_bf16=None):
+    if dst_bf16 is None:
+        dst_bf16 = torch.empty(src_f32.shape, dtype=torch.bfloat16, device=src_f32.device)
+    call("slam_cast_f32_to_bf16", _p(src_f32), _p(dst_bf16), src_f32.numel(), _s())
+    return dst_bf16

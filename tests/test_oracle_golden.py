@@ -1,0 +1,68 @@
+"""CPU: pins oracle/slam_oracle.py against fixtures produced by the reference itself (oracle/make_golden.py).
+
+fp32 vs fp32, different op order only -> tight tolerances (stated per check)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import slam_oracle as O
+from oracle.make_golden_cases import CASES
+from tests import golden_util as G
+
+
+def test_logmel_matches_reference_feature_extractor():
+    fx = G.load("logmel")
+    audio = torch.from_numpy(fx["audio"])
+    for nm in (80, 128):
+        mel = torch.stack([O.log_mel_spectrogram(O.pad_or_trim(a), nm) for a in audio]).numpy()  # [2, nm, 3000]
+        idx = fx[f"mel{nm}_frames"]
+        # tolerance: SURVEY 8c "mel fp32 abs <= 1e-4"
+        np.testing.assert_allclose(mel[:, :, idx], fx[f"mel{nm}_values"], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(mel.reshape(2, -1).max(axis=1), fx[f"mel{nm}_max"], atol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_backward_and_optimizer_match_reference(name):
+    fx = G.load(name)
+    cfg = CASES[name]["cfg"]
+    W = O.init_weights(cfg, seed=42)
+    batch = {k[len("batch."):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("batch.")}
+    # the batch itself is rebuilt by the oracle's collator restatement and must equal the stored one
+    audio = torch.from_numpy(fx["audio"])
+    rb = O.synth_batch(cfg, audio, prompt_len=6, answer_lens=CASES[name]["answer_lens"], seed=1236,
+                       left_pad=CASES[name]["left_pad"], pad_to_30s=False)
+    for k in ("input_ids", "labels", "attention_mask", "modality_mask"):
+        assert torch.equal(rb[k], batch[k]), k
+    outs = O.train_steps(W, cfg, [dict(batch) for _ in range(3)], lr=1e-2, weight_decay=0.01, warmup=2, total=10)
+    for s in range(3):
+        assert abs(float(outs[s]["loss"]) - float(fx[f"loss.{s}"])) < 2e-5, (s, float(outs[s]["loss"]), float(fx[f"loss.{s}"]))
+        assert abs(float(outs[s]["acc"]) - float(fx[f"acc.{s}"])) < 1e-6
+    # first step at lr = 0 leaves the parameters untouched: loss.0 == loss.1
+    assert float(fx["loss.0"]) == float(fx["loss.1"])
+    W0 = O.init_weights(cfg, seed=42)
+    with torch.no_grad():
+        loss, logits, acc, aux = O.slam_forward(W0, cfg, dict(batch))
+    G.check_packed(fx, "encoder_out", aux["encoder_out"].numpy(), atol=2e-5, rtol=1e-4)
+    G.check_packed(fx, "projector_out", aux["projector_out"].numpy(), atol=2e-5, rtol=1e-4)
+    # logits of pad query rows are garbage-by-design in the reference but deterministic in fp32
+    G.check_packed(fx, "logits", logits.numpy(), atol=5e-5, rtol=1e-4)
+    for n, g in outs[0]["grads"].items():
+        G.check_packed(fx, "grad." + n, g.numpy(), atol=1e-6, rtol=1e-3, norm_rtol=1e-4)
+    for n in O.trainable_names(W):
+        # Adam normalises the update (lr * m / sqrt(v)): elements with a near-zero gradient move by O(lr) on
+        # rounding-level gradient differences, so the bound is a fraction of lr = 1e-2, not of the value
+        G.check_packed(fx, "final." + n, W[n].detach().numpy(), atol=2e-4, rtol=1e-4)
+
+
+def test_dynamic_batcher_matches_reference_window_class():
+    # fixtures come from the reference's own MultiTaskDynamicBatchDataset/window_class (speech_dataset_large.py:235-263)
+    fx = G.load("batcher")
+    ci = 0
+    while f"lens.{ci}" in fx.files:
+        groups = O.dynamic_batches([int(x) for x in fx[f"lens.{ci}"]], int(fx[f"mfl.{ci}"]))
+        assert [len(g) for g in groups] == [int(x) for x in fx[f"group_sizes.{ci}"]], ci
+        assert sum(groups, []) == list(range(len(fx[f"lens.{ci}"])))
+        ci += 1
+    assert ci == 4
+    # 31 samples of T=380 fit under 12000 and the 32nd does not
+    assert [int(x) for x in fx["group_sizes.1"]] == [31, 31, 2]
