@@ -101,6 +101,13 @@ int slam_swiglu_fwd(const void* gate_up, int64_t ldgu, void* h, int64_t ldh, int
 int slam_swiglu_bwd(const void* gate_up, int64_t ldgu, const void* dh, int64_t lddh, void* dgate_up,
                     int64_t lddgu, int64_t M, int64_t F, void* stream);
 
+/* ---- projector ReLU backward (projector.py:25) and LoRA weight packing (peft Linear: scaling = alpha/r) ---
+ * relu_bwd: dh *= (h > 0) in place.  lora_pack_b: dst[row,j] = dstT[j,row] = bf16(scale*B[row,j]), B f32 [rows,r]:
+ * writes the adapter into the K-extension columns of the fused weight [W | s*B] and of its transpose. */
+int slam_relu_bwd(void* dh, int64_t lddh, const void* h, int64_t ldh, int64_t M, int64_t N, void* stream);
+int slam_lora_pack_b(const float* B, float scale, void* dst, int64_t ld_dst, void* dstT, int64_t ld_dstT,
+                     int64_t rows, int64_t r, void* stream);
+
 /* ---- embed + audio splice (src/slam_llm/models/slam_model.py:370-392) and its backward --------------
  * input_ids int64 [B,T] (-1 -> 0 in place), modality_mask uint8 [B,T], enc = projector output [B,Ta,ldenc],
  * out [B*T, ldo]; spans int32 [B,2] (start,len) is produced by fwd and consumed by bwd. No host sync. */

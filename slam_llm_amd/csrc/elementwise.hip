@@ -277,6 +277,43 @@ __global__ __launch_bounds__(256) void embed_splice_bwd_kernel(const int* __rest
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// ReLU backward (projector, src/slam_llm/models/projector.py:25): dh *= (h > 0), in place
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relu_bwd_kernel(bf16_t* __restrict__ dh, int64_t lddh,
+                                                       const bf16_t* __restrict__ h, int64_t ldh,
+                                                       int64_t M, int N) {
+  const int nch = N >> 3;
+  const int64_t total = M * nch;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / nch;
+    const int c = (int)(i % nch);
+    u16x8_t d = *reinterpret_cast<const u16x8_t*>(dh + m * lddh + c * 8);
+    const u16x8_t a = *reinterpret_cast<const u16x8_t*>(h + m * ldh + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; e++) d[e] = (bf2f(a[e]) > 0.f) ? d[e] : (bf16_t)0;
+    *reinterpret_cast<u16x8_t*>(dh + m * lddh + c * 8) = d;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LoRA B packing: dst[row, j] = bf16(scale * B[row, j]) and dstT[j, row] = same (peft scaling = alpha / r)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lora_pack_b_kernel(const float* __restrict__ B, float scale,
+                                                          bf16_t* __restrict__ dst, int64_t ld_dst,
+                                                          bf16_t* __restrict__ dstT, int64_t ld_dstT,
+                                                          int64_t rows, int r) {
+  const int64_t total = rows * r;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / r;
+    const int j = (int)(i % r);
+    const bf16_t v = f2bf(B[i] * scale);
+    dst[row * ld_dst + j] = v;
+    dstT[(int64_t)j * ld_dstT + row] = v;
+  }
+}
+
 inline unsigned ew_grid(int64_t total_items) {
   int64_t g = cdiv64(total_items, 256);
   if (g > 16384) g = 16384;
@@ -397,5 +434,24 @@ extern "C" int slam_embed_splice_bwd(const int32_t* spans, const void* dX, int64
   hipLaunchKernelGGL(embed_splice_bwd_kernel, dim3((unsigned)(B * Ta)), dim3(256), 0, (hipStream_t)stream,
                      spans, (const bf16_t*)dX, lddx, (bf16_t*)denc, ldde, (int)T, (int)Ta, (int)d);
   SLAM_CHECK_LAUNCH("slam_embed_splice_bwd");
+  return 0;
+}
+
+extern "C" int slam_relu_bwd(void* dh, int64_t lddh, const void* h, int64_t ldh, int64_t M, int64_t N,
+                             void* stream) {
+  SLAM_CHECK_ARG(dh && h, "slam_relu_bwd: null pointer");
+  SLAM_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && lddh % 8 == 0 && ldh % 8 == 0, "slam_relu_bwd: N/ld must be multiples of 8");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(M * (N / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)dh, lddh, (const bf16_t*)h, ldh, M, (int)N);
+  SLAM_CHECK_LAUNCH("slam_relu_bwd");
+  return 0;
+}
+
+extern "C" int slam_lora_pack_b(const float* B, float scale, void* dst, int64_t ld_dst, void* dstT,
+                                int64_t ld_dstT, int64_t rows, int64_t r, void* stream) {
+  SLAM_CHECK_ARG(B && dst && dstT && rows > 0 && r > 0, "slam_lora_pack_b: bad arguments");
+  hipLaunchKernelGGL(lora_pack_b_kernel, dim3(ew_grid(rows * r)), dim3(256), 0, (hipStream_t)stream, B,
+                     scale, (bf16_t*)dst, ld_dst, (bf16_t*)dstT, ld_dstT, rows, (int)r);
+  SLAM_CHECK_LAUNCH("slam_lora_pack_b");
   return 0;
 }

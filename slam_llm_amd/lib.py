@@ -36,6 +36,8 @@ SIGNATURES = {
                       I64, I64, I64, I64, I64, I64, I32, F, P],
     "slam_swiglu_fwd": [P, I64, P, I64, I64, I64, P],
     "slam_swiglu_bwd": [P, I64, P, I64, P, I64, I64, I64, P],
+    "slam_relu_bwd": [P, I64, P, I64, I64, I64, P],
+    "slam_lora_pack_b": [P, F, P, I64, P, I64, I64, I64, P],
     "slam_embed_splice_fwd": [P, P, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P],
     "slam_embed_splice_bwd": [P, P, I64, P, I64, I64, I64, I64, I64, P],
     "slam_ce_targets": [P, P, P, I64, I64, I64, P],

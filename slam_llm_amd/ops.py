@@ -271,3 +271,16 @@ def cast_bf16(src_f32, dst_bf16=None):
         dst_bf16 = torch.empty(src_f32.shape, dtype=torch.bfloat16, device=src_f32.device)
     call("slam_cast_f32_to_bf16", _p(src_f32), _p(dst_bf16), src_f32.numel(), _s())
     return dst_bf16
+
+
+def relu_bwd_(dh, h):
+    M, N = dh.shape
+    call("slam_relu_bwd", _p(dh), _ld(dh), _p(h), _ld(h), M, N, _s())
+    return dh
+
+
+def lora_pack_b(b_f32, scale, dst2d, dstT2d):
+    """dst2d [rows, r] view (any ld) and dstT2d [r, rows] view of the fused weight / its transpose"""
+    rows, r = b_f32.shape
+    assert b_f32.is_contiguous()
+    call("slam_lora_pack_b", _p(b_f32), scale, _p(dst2d), _ld(dst2d), _p(dstT2d), _ld(dstT2d), rows, r, _s())

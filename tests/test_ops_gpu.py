@@ -1,0 +1,380 @@
+"""GPU: every HIP kernel against a plain PyTorch fp32 reference of the same op (through the C ABI).
+
+Tolerances: bf16 outputs carry ~2^-8 relative rounding; accumulations are fp32.  Each check states its bound."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from slam_llm_amd import ops
+    return ops
+
+
+def rnd(shape, dev, std=1.0, seed=0, dtype=torch.bfloat16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * std).to(dtype).to(dev)
+
+
+def assert_close(got, ref, atol, rtol, what=""):
+    got = got.float().cpu()
+    ref = ref.float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; max err "
+                           f"{float(err.max()):.4e} at {int(err.argmax())}, ref there {float(ref.flatten()[err.argmax()]):.4e}")
+
+
+# ----------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 64), (1000, 388, 192), (77, 64, 4160)])
+def test_gemm_plain(dev, cfg, M, N, K):
+    ops = _ops()
+    a, b = rnd((M, K), dev, seed=1), rnd((N, K), dev, seed=2)
+    ops.gemm_set_config(cfg)
+    try:
+        c = ops.gemm_nt(a, b)
+    finally:
+        ops.gemm_set_config(0)
+    ref = a.float() @ b.float().T
+    # fp32 accumulate, one bf16 rounding at the output: |err| <= 2^-8 |ref| + accumulation noise
+    assert_close(c, ref, atol=2e-2 * math.sqrt(K / 64), rtol=1e-2, what=f"gemm cfg{cfg} {M}x{N}x{K}")
+
+
+def test_gemm_asymmetric_identity(dev):
+    """A = I with an asymmetric B catches row/col swaps in the MFMA output mapping."""
+    ops = _ops()
+    K = 128
+    a = torch.eye(K, dtype=torch.bfloat16, device=dev)
+    b = (torch.arange(192 * K, dtype=torch.float32).reshape(192, K) % 251 - 125).to(torch.bfloat16).to(dev)
+    c = ops.gemm_nt(a, b, out_dtype=torch.float32)
+    assert torch.equal(c.cpu(), b.float().T.cpu())
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_epilogues(dev, act):
+    ops = _ops()
+    M, N, K = 333, 260, 128
+    a, b = rnd((M, K), dev, seed=3), rnd((N, K), dev, seed=4, std=0.1)
+    bias = rnd((N,), dev, seed=5, dtype=torch.float32)
+    res = rnd((50, N), dev, seed=6)
+    c = ops.gemm_nt(a, b, bias=bias, residual=res, res_row_mod=50, act=act, alpha=0.5)
+    ref = 0.5 * (a.float() @ b.float().T) + bias
+    ref = F.gelu(ref) if act == 1 else (F.relu(ref) if act == 2 else ref)
+    ref = ref + res.float()[torch.arange(M) % 50]
+    assert_close(c, ref, atol=2e-2, rtol=1e-2, what=f"epilogue act{act}")
+    # fp32 output + accumulate, strided operands (lda/ldb/ldc > logical width)
+    big_a = rnd((M, K + 64), dev, seed=7)
+    big_c = torch.ones((M, N + 8), dtype=torch.float32, device=dev)
+    ops.gemm_nt(big_a[:, :K], b, out=big_c[:, :N], accumulate=True)
+    ref2 = 1.0 + big_a[:, :K].float() @ b.float().T
+    assert_close(big_c[:, :N], ref2, atol=1e-3, rtol=1e-4, what="f32 accumulate")
+    assert torch.all(big_c[:, N:] == 1.0)
+
+
+def test_gemm_rejects_bad_shapes(dev):
+    ops = _ops()
+    from slam_llm_amd.lib import SlamHipError
+    with pytest.raises(SlamHipError, match="multiple of 64"):
+        ops.gemm_nt(rnd((8, 40), dev), rnd((8, 40), dev))
+    with pytest.raises(SlamHipError, match="HBM"):
+        ops.gemm_nt(torch.zeros(8, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16))
+
+
+# ----------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("M,d", [(37, 64), (1000, 1280), (5, 4096)])
+def test_layernorm(dev, M, d):
+    ops = _ops()
+    x = rnd((M, d), dev, seed=1, std=2.0)
+    w, b = rnd((d,), dev, seed=2, dtype=torch.float32), rnd((d,), dev, seed=3, dtype=torch.float32)
+    y = ops.layernorm(x, w, b, 1e-5)
+    ref = F.layer_norm(x.float(), (d,), w, b, 1e-5)
+    assert_close(y, ref, atol=1e-2, rtol=1e-2, what="layernorm")
+
+
+@pytest.mark.parametrize("M,d", [(37, 128), (300, 4096)])
+def test_rmsnorm_fwd_bwd(dev, M, d):
+    ops = _ops()
+    x = rnd((M, d), dev, seed=1, std=1.5)
+    w = (1 + 0.1 * torch.randn(d)).to(dev)
+    dy = rnd((M, d), dev, seed=2)
+    dres = rnd((M, d), dev, seed=3)
+    y, rstd = ops.rmsnorm_fwd(x, w, 1e-5)
+    xf = x.float().requires_grad_(True)
+    ref = w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))
+    assert_close(y, ref.detach(), atol=1e-2, rtol=1.2e-2, what="rmsnorm fwd")
+    ref.backward(dy.float())
+    scale = torch.tensor([0.5], device=dev)
+    dx = ops.rmsnorm_bwd(x, rstd, w, dy, dres=dres, grad_scale=scale)
+    assert_close(dx, 0.5 * xf.grad + dres.float(), atol=2e-2, rtol=1.5e-2, what="rmsnorm bwd")
+
+
+# ----------------------------------------------------------------------------------------- rope / transposes
+def _rope_ref(x, theta):  # x [B,T,H,D]
+    B, T, H, D = x.shape
+    inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    fr = torch.arange(T, dtype=torch.float32)[:, None] * inv[None]
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos()[None, :, None, :], emb.sin()[None, :, None, :]
+    rot = torch.cat([-x[..., D // 2:], x[..., : D // 2]], -1)
+    return x * cos + rot * sin
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_head_rope_transpose(dev, D):
+    ops = _ops()
+    B, T, H = 2, 75, 3
+    ld = H * D + 2 * D + 64
+    buf = rnd((B * T, ld), dev, seed=1)
+    orig = buf.clone()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    fr = torch.arange(T, dtype=torch.float32)[:, None] * inv[None]
+    cos, sin = fr.cos().contiguous().to(dev), fr.sin().contiguous().to(dev)
+    xt = ops.head_rope_transpose(buf, 64, B, T, H, D, cos=cos, sin=sin)
+    x = orig[:, 64:64 + H * D].float().cpu().view(B, T, H, D)
+    ref = _rope_ref(x, 10000.0)
+    got = buf[:, 64:64 + H * D].float().cpu().view(B, T, H, D)
+    assert_close(got, ref, atol=2e-2, rtol=1e-2, what="rope in place")
+    assert torch.equal(buf[:, :64], orig[:, :64]) and torch.equal(buf[:, 64 + H * D:], orig[:, 64 + H * D:])
+    Tp = xt.shape[-1]
+    assert Tp == 128
+    assert torch.equal(xt[..., :T].cpu(), buf[:, 64:64 + H * D].cpu().view(B, T, H, D).permute(0, 2, 3, 1))
+    assert torch.all(xt[..., T:] == 0)
+    # inverse rotation restores the input (RoPE backward = transposed rotation)
+    ops.head_rope_transpose(buf, 64, B, T, H, D, cos=cos, sin=sin, inverse=True, want_t=False)
+    assert_close(buf[:, 64:64 + H * D], orig[:, 64:64 + H * D], atol=3e-2, rtol=2e-2, what="rope inverse")
+
+
+def test_transpose(dev):
+    ops = _ops()
+    x = rnd((333, 200), dev, seed=1)
+    t = ops.transpose(x)
+    assert t.shape == (200, 384)
+    assert torch.equal(t[:, :333].cpu(), x.cpu().T)
+    assert torch.all(t[:, 333:] == 0)
+
+
+# ----------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, causal, kmask, scale):
+    """q [B,T,Hq,D], k/v [B,T,Hkv,D] fp32 -> o [B,T,Hq,D]; rows with no visible key give 0."""
+    B, T, Hq, D = q.shape
+    Hkv = k.shape[2]
+    rep = Hq // Hkv
+    qh = q.permute(0, 2, 1, 3)
+    kh = k.permute(0, 2, 1, 3).repeat_interleave(rep, dim=1)
+    vh = v.permute(0, 2, 1, 3).repeat_interleave(rep, dim=1)
+    s = qh @ kh.transpose(2, 3) * scale
+    allowed = torch.ones(B, 1, T, T, dtype=torch.bool, device=q.device)
+    if causal:
+        allowed = allowed & torch.tril(torch.ones(T, T, dtype=torch.bool, device=q.device))[None, None]
+    if kmask is not None:
+        allowed = allowed & kmask.bool()[:, None, None, :]
+    s = s.masked_fill(~allowed, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    p = torch.nan_to_num(p, nan=0.0)
+    return (p @ vh).permute(0, 2, 1, 3)
+
+
+def _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed):
+    ld = (Hq + 2 * Hkv) * D
+    qkv = rnd((B * T, ld), dev, seed=seed, std=1.0)
+    qt = ops.head_rope_transpose(qkv, 0, B, T, Hq, D)
+    kt = ops.head_rope_transpose(qkv, Hq * D, B, T, Hkv, D)
+    vt = ops.head_rope_transpose(qkv, (Hq + Hkv) * D, B, T, Hkv, D)
+    q2, k2, v2 = qkv[:, : Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
+    return qkv, q2, k2, v2, qt, kt, vt
+
+
+@pytest.mark.parametrize("B,T,Hq,Hkv,D,causal,masked", [
+    (2, 150, 2, 2, 64, False, False),     # encoder-like, T not a multiple of the tile
+    (1, 1500, 1, 1, 64, False, False),    # Whisper context length
+    (2, 100, 4, 2, 64, True, True),       # causal GQA + left padding
+    (2, 380, 4, 1, 128, True, True),      # Llama-3 head_dim, T of the C3 workload
+    (1, 64, 2, 2, 128, True, False),
+])
+def test_attention_fwd(dev, B, T, Hq, Hkv, D, causal, masked):
+    ops = _ops()
+    qkv, q2, k2, v2, qt, kt, vt = _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed=11)
+    Tp = vt.shape[-1]
+    km = None
+    km_ref = None
+    if masked:
+        km = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
+        km[:, :T] = 1
+        km[0, :7] = 0  # left padding on sample 0
+        km_ref = km[:, :T]
+    scale = D ** -0.5
+    o, lse = ops.attn_fwd(q2, k2, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=km)
+    ref = _attn_ref(q2.float().view(B, T, Hq, D), k2.float().view(B, T, Hkv, D), v2.float().view(B, T, Hkv, D),
+                    causal, km_ref, scale)
+    # P is rounded to bf16 before the PV product and O to bf16: ~1e-2 relative on O(1) values
+    assert_close(o.view(B, T, Hq, D), ref, atol=2e-2, rtol=2e-2, what="attn fwd")
+    assert torch.isfinite(o.float()).all()
+
+
+@pytest.mark.parametrize("B,T,Hq,Hkv,D,masked", [
+    (2, 100, 4, 2, 64, True),
+    (2, 380, 4, 1, 128, True),
+    (1, 70, 2, 2, 128, False),
+])
+def test_attention_bwd(dev, B, T, Hq, Hkv, D, masked):
+    ops = _ops()
+    qkv, q2, k2, v2, qt, kt, vt = _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed=12)
+    Tp = vt.shape[-1]
+    km = None
+    if masked:
+        km = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
+        km[:, :T] = 1
+        km[0, :9] = 0
+    scale = D ** -0.5
+    o, lse = ops.attn_fwd(q2, k2, vt, B, T, Hq, Hkv, D, True, scale, key_mask=km)
+    do = rnd((B * T, Hq * D), dev, seed=13)
+    if masked:
+        do.view(B, T, Hq * D)[0, :9] = 0  # pad query rows never receive gradient (labels = -100, never attended)
+    dot = ops.head_rope_transpose(do, 0, B, T, Hq, D)
+    dqkv = torch.zeros_like(qkv)
+    dq2, dk2, dv2 = dqkv[:, : Hq * D], dqkv[:, Hq * D:(Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:]
+    ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, dq2, dk2, dv2, B, T, Hq, Hkv, D, True, scale, key_mask=km)
+    qf = q2.float().view(B, T, Hq, D).clone().requires_grad_(True)
+    kf = k2.float().view(B, T, Hkv, D).clone().requires_grad_(True)
+    vf = v2.float().view(B, T, Hkv, D).clone().requires_grad_(True)
+    ref = _attn_ref(qf, kf, vf, True, km[:, :T] if masked else None, scale)
+    ref.backward(do.float().view(B, T, Hq, D))
+    for nme, got, r in (("dq", dq2, qf.grad), ("dk", dk2, kf.grad), ("dv", dv2, vf.grad)):
+        got = got.float().reshape(r.shape)
+        # cosine over the whole tensor + elementwise bound scaled to the tensor's magnitude
+        cs = F.cosine_similarity(got.flatten(), r.flatten(), dim=0)
+        assert cs > 0.999, f"{nme} cosine {float(cs)}"
+        assert_close(got, r, atol=3e-2 * float(r.abs().max()), rtol=3e-2, what=nme)
+
+
+# ----------------------------------------------------------------------------------------- mlp / conv
+def test_swiglu(dev):
+    ops = _ops()
+    M, Fd = 123, 256
+    gu = rnd((M, 2 * Fd), dev, seed=1, std=2.0)
+    dh = rnd((M, Fd), dev, seed=2)
+    h = ops.swiglu_fwd(gu)
+    g = gu[:, :Fd].float().requires_grad_(True)
+    u = gu[:, Fd:].float().requires_grad_(True)
+    ref = F.silu(g) * u
+    assert_close(h, ref.detach(), atol=1e-2, rtol=1e-2, what="swiglu fwd")
+    ref.backward(dh.float())
+    dgu = ops.swiglu_bwd(gu, dh)
+    assert_close(dgu[:, :Fd], g.grad, atol=2e-2, rtol=1.5e-2, what="swiglu dgate")
+    assert_close(dgu[:, Fd:], u.grad, atol=2e-2, rtol=1.5e-2, what="swiglu dup")
+
+
+@pytest.mark.parametrize("stride,C,dt", [(1, 80, torch.float32), (2, 64, torch.bfloat16)])
+def test_conv1d_as_gemm(dev, stride, C, dt):
+    ops = _ops()
+    B, Tin, Cout = 2, 101, 128
+    x = rnd((B, Tin, C), dev, seed=1, dtype=dt)
+    w = rnd((Cout, C, 3), dev, seed=2, std=0.1, dtype=torch.float32)
+    bias = rnd((Cout,), dev, seed=3, dtype=torch.float32)
+    Kp = ops.round_up(3 * C, 64)
+    cols = ops.conv1d_k3_im2col(x, stride, Kp)
+    w2 = torch.zeros((Cout, Kp), dtype=torch.bfloat16, device=dev)
+    w2[:, : 3 * C] = w.permute(0, 2, 1).reshape(Cout, 3 * C).to(torch.bfloat16)
+    y = ops.gemm_nt(cols, w2, bias=bias, act=ops.ACT_GELU)
+    ref = F.gelu(F.conv1d(x.float().permute(0, 2, 1), w.to(torch.bfloat16).float(), bias, stride=stride, padding=1))
+    ref = ref.permute(0, 2, 1).reshape(-1, Cout)
+    assert y.shape == ref.shape
+    assert_close(y, ref, atol=2e-2, rtol=1e-2, what="conv")
+
+
+# ----------------------------------------------------------------------------------------- embed / loss / optim
+def test_embed_splice(dev):
+    ops = _ops()
+    B, T, Ta, d, V = 3, 40, 12, 128, 200
+    E = rnd((V, d), dev, seed=1)
+    enc = rnd((B, Ta, d), dev, seed=2)
+    ids = torch.randint(1, V, (B, T), dtype=torch.int64)
+    mask = torch.zeros((B, T), dtype=torch.bool)
+    mask[0, 5:17] = True          # exactly Ta
+    mask[1, 0:14] = True          # longer than Ta -> clamp, slots 12,13 get zeros
+    mask[2, 20:25] = True         # shorter
+    ids[mask] = -1
+    ids_d = ids.clone().to(dev)
+    out, spans = ops.embed_splice_fwd(ids_d, mask.to(torch.uint8).to(dev), E, enc)
+    # reference (slam_model.py:370-392)
+    from oracle.slam_oracle import embed_splice
+    ref = embed_splice(E.float().cpu(), ids.clone(), mask, enc.float().cpu())
+    assert torch.equal(out.view(B, T, d).float().cpu(), ref)
+    assert (ids_d >= 0).all()
+    dx = rnd((B * T, d), dev, seed=3)
+    de = ops.embed_splice_bwd(spans, dx, B, T, Ta, d).view(B, Ta, d).cpu()
+    dxc = dx.view(B, T, d).cpu()
+    assert torch.equal(de[0], dxc[0, 5:17])
+    assert torch.equal(de[1], dxc[1, 0:12])
+    assert torch.equal(de[2, :5], dxc[2, 20:25]) and torch.all(de[2, 5:] == 0)
+
+
+@pytest.mark.parametrize("V", [512, 32000])
+def test_cross_entropy(dev, V):
+    ops = _ops()
+    B, T = 3, 17
+    logits = rnd((B * T, V), dev, seed=1, std=2.0)
+    labels = torch.randint(0, V, (B, T), dtype=torch.int64)
+    labels[:, :6] = -100
+    labels[1, 12:] = -100
+    labels_d = labels.to(dev)
+    tgt, nv = ops.ce_targets(labels_d)
+    row_loss = torch.empty(B * T, dtype=torch.float32, device=dev)
+    row_ok = torch.empty(B * T, dtype=torch.int32, device=dev)
+    lg = logits.clone()
+    ops.ce_fwd_bwd(lg, tgt, nv, row_loss, row_ok, write_grad=True)
+    out = ops.ce_finalize(row_loss, row_ok, nv).cpu()
+    lf = logits.float().cpu().view(B, T, V).requires_grad_(True)
+    sl = F.pad(labels, (0, 1), value=-100)[:, 1:]
+    ref = F.cross_entropy(lf.view(-1, V), sl.reshape(-1), ignore_index=-100)
+    ref.backward()
+    assert int(nv.item()) == int((sl != -100).sum())
+    assert abs(float(out[0]) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+    preds = lf.detach().argmax(-1)
+    m = sl != -100
+    acc = (preds[m] == sl[m]).float().mean()
+    assert abs(float(out[1]) - float(acc)) < 1e-6
+    assert_close(lg.view(B, T, V), lf.grad, atol=2e-5, rtol=1.5e-2, what="dlogits")
+
+
+def test_adamw_matches_torch(dev):
+    ops = _ops()
+    n = 10007
+    p0 = torch.randn(n)
+    p = p0.clone().to(dev)
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    pb = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    tp = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([tp], lr=1e-2, weight_decay=0.01)
+    for step in range(1, 4):
+        g = torch.randn(n, generator=torch.Generator().manual_seed(step))
+        tp.grad = g.clone()
+        opt.step()
+        ops.adamw_step(p, g.to(dev), m, v, pb, 1e-2, 0.9, 0.999, 1e-8, 0.01, step)
+    assert_close(p, tp.detach(), atol=1e-6, rtol=1e-5, what="adamw params")
+    assert torch.equal(pb.cpu(), p.cpu().to(torch.bfloat16))
+
+
+# ----------------------------------------------------------------------------------------- log-mel
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_logmel_vs_golden_and_oracle(dev, n_mels):
+    ops = _ops()
+    from oracle import slam_oracle as O
+    from tests import golden_util as G
+    fx = G.load("logmel")
+    audio = torch.from_numpy(fx["audio"]).to(dev)  # 3.7 s clips, padded to 30 s inside the kernel
+    mel = ops.logmel(audio, n_mels).cpu()  # [2, 3000, n_mels]
+    idx = fx[f"mel{n_mels}_frames"]
+    gold = torch.from_numpy(fx[f"mel{n_mels}_values"]).permute(0, 2, 1)  # [2, nidx, n_mels]
+    # SURVEY 8c tolerance: mel fp32 abs <= 1e-4
+    assert_close(mel[:, idx, :], gold, atol=1e-4, rtol=0, what="logmel vs reference fixture")
+    full = torch.stack([O.log_mel_spectrogram(O.pad_or_trim(a), n_mels) for a in audio.cpu()]).permute(0, 2, 1)
+    assert_close(mel, full, atol=1e-4, rtol=0, what="logmel vs oracle")
