@@ -105,6 +105,8 @@ int slam_swiglu_bwd(const void* gate_up, int64_t ldgu, const void* dh, int64_t l
  * relu_bwd: dh *= (h > 0) in place.  lora_pack_b: dst[row,j] = dstT[j,row] = bf16(scale*B[row,j]), B f32 [rows,r]:
  * writes the adapter into the K-extension columns of the fused weight [W | s*B] and of its transpose. */
 int slam_relu_bwd(void* dh, int64_t lddh, const void* h, int64_t ldh, int64_t M, int64_t N, void* stream);
+/* out[n] (+)= sum_m x[m,n] (bias gradient of nn.Linear, projector.py:24-26), fixed summation order */
+int slam_colsum_bf16(const void* x, int64_t ldx, float* out, int64_t M, int64_t N, int accumulate, void* stream);
 int slam_lora_pack_b(const float* B, float scale, void* dst, int64_t ld_dst, void* dstT, int64_t ld_dstT,
                      int64_t rows, int64_t r, void* stream);
 

@@ -366,7 +366,7 @@ def collate_right_pad(samples: List[dict], pad_id: int, mels: Optional[List[torc
 
 # ---------------------------------------------------------------------------------------------- synthetic weights / batches
 def make_config(**kw) -> dict:
-    cfg = dict(n_mels=80, enc_dim=64, enc_heads=2, enc_layers=2, enc_ctx=1500, ds_rate=5, proj_hidden=2048,
+    cfg = dict(n_mels=80, enc_dim=128, enc_heads=2, enc_layers=2, enc_ctx=1500, ds_rate=5, proj_hidden=2048,
                llm_dim=128, llm_layers=2, llm_heads=2, llm_kv_heads=1, llm_head_dim=64, llm_ffn=256, vocab=512,
                rope_theta=10000.0, rms_eps=1e-5, lora_r=8, lora_alpha=32, lora_targets=("q_proj", "v_proj"))
     cfg.update(kw)

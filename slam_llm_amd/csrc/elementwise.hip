@@ -314,6 +314,38 @@ __global__ __launch_bounds__(256) void lora_pack_b_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// column sum (bias gradients of the projector Linears): out[n] (+)= sum_m x[m, n], deterministic order
+// one workgroup = 64 columns; thread (ty = tid/8, tx = tid%8) walks rows ty, ty+32, ... on 8 columns
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                     float* __restrict__ out, int64_t M, int N,
+                                                     int accumulate) {
+  __shared__ float red[32][65];
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64 + tx * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < N) {
+    for (int64_t m = ty; m < M; m += 32) {
+      const u16x8_t v = *reinterpret_cast<const u16x8_t*>(x + m * ldx + c0);
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[e] += bf2f(v[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) red[ty][tx * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < N) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 32; r++) s += red[r][threadIdx.x];
+      out[c] = accumulate ? out[c] + s : s;
+    }
+  }
+}
+
 inline unsigned ew_grid(int64_t total_items) {
   int64_t g = cdiv64(total_items, 256);
   if (g > 16384) g = 16384;
@@ -453,5 +485,14 @@ extern "C" int slam_lora_pack_b(const float* B, float scale, void* dst, int64_t 
   hipLaunchKernelGGL(lora_pack_b_kernel, dim3(ew_grid(rows * r)), dim3(256), 0, (hipStream_t)stream, B,
                      scale, (bf16_t*)dst, ld_dst, (bf16_t*)dstT, ld_dstT, rows, (int)r);
   SLAM_CHECK_LAUNCH("slam_lora_pack_b");
+  return 0;
+}
+
+extern "C" int slam_colsum_bf16(const void* x, int64_t ldx, float* out, int64_t M, int64_t N,
+                                int accumulate, void* stream) {
+  SLAM_CHECK_ARG(x && out && M > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0, "slam_colsum_bf16: bad arguments (N, ld multiples of 8)");
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv64(N, 64)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, out, M, (int)N, accumulate);
+  SLAM_CHECK_LAUNCH("slam_colsum_bf16");
   return 0;
 }

@@ -37,6 +37,7 @@ SIGNATURES = {
     "slam_swiglu_fwd": [P, I64, P, I64, I64, I64, P],
     "slam_swiglu_bwd": [P, I64, P, I64, P, I64, I64, I64, P],
     "slam_relu_bwd": [P, I64, P, I64, I64, I64, P],
+    "slam_colsum_bf16": [P, I64, P, I64, I64, I32, P],
     "slam_lora_pack_b": [P, F, P, I64, P, I64, I64, I64, P],
     "slam_embed_splice_fwd": [P, P, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P],
     "slam_embed_splice_bwd": [P, P, I64, P, I64, I64, I64, I64, I64, P],

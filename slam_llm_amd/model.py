@@ -1,0 +1,779 @@
+"""Host-side mirror of the reference's encoder -> projector -> LLM(+LoRA) composite for the HIP path.
+
+Mirrors `slam_llm.models.slam_model.slam_model` (src/slam_llm/models/slam_model.py:239-456): same constructor
+surface (`.encoder`, `.encoder_projector`, `.llm`, `.tokenizer`), same `forward(**batch) -> (outputs, acc)` with
+`outputs.loss` autograd-connected, `inference_mode=True -> (inputs_embeds, attention_mask)`, same state_dict
+key names for the trainable tensors (`encoder_projector.linear1.weight`, peft's
+`llm.base_model.model.model.layers.N.self_attn.q_proj.lora_A.default.weight`, ...).
+
+Everything numerical is a C-ABI call into libslamhip.so (slam_llm_amd.ops); torch provides HBM buffers, the
+HIP stream and the autograd hook (`loss.backward()` enters `_SlamStep.backward`, which runs the hand-written
+backward kernels and deposits gradients into one flat fp32 buffer that `.grad` of every trainable parameter
+views).  Data layout in HBM (sized for 288 GB):
+  * frozen weights bf16 in BOTH orientations (W for forward, W^T for dX) -> every product is an NT GEMM;
+  * LoRA is folded into the frozen GEMM by K-extension: y = [x | xA^T] . [W | (alpha/r)B]^T; the same
+    extended W^T yields dx and d(xA^T) in one backward GEMM;
+  * trainable parameters: one flat fp32 master buffer (+ flat fp32 grad, + bf16 compute copies), ordered in
+    backward-production order (last LLM layer first, projector last) so data-parallel all-reduce can start
+    on a prefix while the rest of the backward is still running.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU, round_up
+
+LORA_PAD = 64  # K-extension granule (GEMM K-tile)
+
+
+# ======================================================================================== presets
+PRESETS = {
+    # encoders (openai-whisper dims)
+    "whisper-tiny": dict(n_mels=80, enc_dim=384, enc_heads=6, enc_layers=4),
+    "whisper-base": dict(n_mels=80, enc_dim=512, enc_heads=8, enc_layers=6),
+    "whisper-small": dict(n_mels=80, enc_dim=768, enc_heads=12, enc_layers=12),
+    "whisper-medium": dict(n_mels=80, enc_dim=1024, enc_heads=16, enc_layers=24),
+    "whisper-large-v2": dict(n_mels=80, enc_dim=1280, enc_heads=20, enc_layers=32),
+    "whisper-large-v3": dict(n_mels=128, enc_dim=1280, enc_heads=20, enc_layers=32),
+    # LLMs
+    "llama-3-8b": dict(llm_dim=4096, llm_layers=32, llm_heads=32, llm_kv_heads=8, llm_head_dim=128, llm_ffn=14336,
+                       vocab=128256, rope_theta=500000.0, rms_eps=1e-5),
+    "tinyllama-1.1b": dict(llm_dim=2048, llm_layers=22, llm_heads=32, llm_kv_heads=4, llm_head_dim=64, llm_ffn=5632,
+                           vocab=32000, rope_theta=10000.0, rms_eps=1e-5),
+    "vicuna-7b": dict(llm_dim=4096, llm_layers=32, llm_heads=32, llm_kv_heads=32, llm_head_dim=128, llm_ffn=11008,
+                      vocab=32000, rope_theta=10000.0, rms_eps=1e-5),
+}
+
+
+def make_config(encoder: Optional[str] = None, llm: Optional[str] = None, **kw) -> dict:
+    cfg = dict(n_mels=80, enc_dim=128, enc_heads=2, enc_layers=2, enc_ctx=1500, ds_rate=5, proj_hidden=2048,
+               llm_dim=128, llm_layers=2, llm_heads=2, llm_kv_heads=1, llm_head_dim=64, llm_ffn=256, vocab=512,
+               rope_theta=10000.0, rms_eps=1e-5, lora_r=8, lora_alpha=32, lora_targets=("q_proj", "v_proj"),
+               lora_dropout=0.0)
+    if encoder:
+        cfg.update(PRESETS[encoder])
+    if llm:
+        cfg.update(PRESETS[llm])
+    cfg.update(kw)
+    return cfg
+
+
+# ======================================================================================== trainable store
+class TrainableStore:
+    """One flat fp32 master / grad buffer (+ bf16 copy); parameters are views (64-element aligned)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries: List[Tuple[str, Tuple[int, ...], int]] = []
+        self.size = 0
+        self.flat = self.grad = self.flat_bf16 = None
+        self.params: Dict[str, nn.Parameter] = {}
+
+    def reserve(self, name: str, shape) -> None:
+        assert self.flat is None
+        n = int(math.prod(shape))
+        self.entries.append((name, tuple(shape), self.size))
+        self.size += round_up(n, 64)
+
+    def allocate(self):
+        self.flat = torch.zeros(self.size, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(self.size, dtype=torch.float32, device=self.device)
+        self.flat_bf16 = torch.zeros(self.size, dtype=torch.bfloat16, device=self.device)
+        self.offsets = {}
+        for name, shape, off in self.entries:
+            n = int(math.prod(shape))
+            self.params[name] = nn.Parameter(self.flat[off:off + n].view(shape), requires_grad=True)
+            self.offsets[name] = (off, n, shape)
+
+    def grad_view(self, name):
+        off, n, shape = self.offsets[name]
+        return self.grad[off:off + n].view(shape)
+
+    def bf16_view(self, name):
+        off, n, shape = self.offsets[name]
+        return self.flat_bf16[off:off + n].view(shape)
+
+    def master_view(self, name):
+        off, n, shape = self.offsets[name]
+        return self.flat[off:off + n].view(shape)
+
+    def refresh_bf16(self):
+        ops.cast_bf16(self.flat, self.flat_bf16)
+
+
+# ======================================================================================== fused (LoRA) linear
+class FusedLinear:
+    """Frozen y = x W^T for a group of projections sharing the input (q|k|v, gate|up, ...), with optional
+    peft-style LoRA adapters on any member folded in by K-extension (see module docstring)."""
+
+    def __init__(self, K: int, parts: List[Tuple[str, int]], device):
+        self.K = K
+        self.parts = parts
+        self.N = sum(r for _, r in parts)
+        self.row0 = {}
+        o = 0
+        for n, r in parts:
+            self.row0[n] = o
+            o += r
+        self.device = device
+        self.adapters = []  # dicts: part, row0, rows, r, j0, scale, A(name), B(name)
+        self.Rp = 0
+        self.Wext = self.WextT = None
+        self._base = {}
+
+    def set_base(self, part: str, w: torch.Tensor):
+        self._base[part] = w
+
+    def add_lora(self, part: str, r: int, alpha: float, a_name: str, b_name: str):
+        rows = dict(self.parts)[part]
+        j0 = sum(a["r"] for a in self.adapters)
+        self.adapters.append(dict(part=part, row0=self.row0[part], rows=rows, r=r, j0=j0, scale=alpha / r,
+                                  A=a_name, B=b_name))
+        self.Rp = round_up(j0 + r, LORA_PAD)
+
+    @property
+    def sum_r(self):
+        return sum(a["r"] for a in self.adapters)
+
+    def finalize(self):
+        """materialise [W | 0] and its transpose from the parts' base weights (bf16, device)."""
+        Kx = self.K + self.Rp
+        assert self.N % 64 == 0 and self.K % 64 == 0, f"fused linear dims must be multiples of 64 (N={self.N}, K={self.K})"
+        self.Wext = torch.zeros((self.N, Kx), dtype=torch.bfloat16, device=self.device)
+        for n, rows in self.parts:
+            w = self._base.pop(n)
+            self.Wext[self.row0[n]: self.row0[n] + rows, : self.K].copy_(w)
+        self.WextT = torch.zeros((Kx, self.N), dtype=torch.bfloat16, device=self.device)
+        ops.transpose(self.Wext[:, : self.K], Rp=self.N, out=self.WextT[: self.K])
+
+    def refresh(self, store: TrainableStore):
+        """re-pack the adapters from the fp32 masters (after an optimizer step)."""
+        if not self.adapters:
+            return
+        K = self.K
+        for a in self.adapters:
+            ops.lora_pack_b(store.master_view(a["B"]), a["scale"],
+                            self.Wext[a["row0"]: a["row0"] + a["rows"], K + a["j0"]: K + a["j0"] + a["r"]],
+                            self.WextT[K + a["j0"]: K + a["j0"] + a["r"], a["row0"]: a["row0"] + a["rows"]])
+        # A's bf16 copies live in the store's flat bf16 buffer (contiguous block of all adapters of this group);
+        # their transpose [K, Rp] serves the second hop of the backward: dx += d(xA^T) . A
+        self.AcatT = ops.transpose(self.a_cat(store), Rp=self.Rp)
+
+    def a_cat(self, store: TrainableStore) -> torch.Tensor:
+        first = self.adapters[0]
+        off, _, _ = store.offsets[first["A"]]
+        return store.flat_bf16[off: off + self.sum_r * self.K].view(self.sum_r, self.K)
+
+    def a_cat_grad(self, store: TrainableStore) -> torch.Tensor:
+        first = self.adapters[0]
+        off, _, _ = store.offsets[first["A"]]
+        return store.grad[off: off + self.sum_r * self.K].view(self.sum_r, self.K)
+
+    def new_input(self, M: int) -> torch.Tensor:
+        """[M, K + Rp] activation buffer; the caller fills [:, :K]."""
+        buf = torch.empty((M, self.K + self.Rp), dtype=torch.bfloat16, device=self.device)
+        if self.Rp:
+            buf[:, self.K + self.sum_r:].zero_()  # padding columns of the K-extension
+        return buf
+
+    def forward(self, x_ext: torch.Tensor, store: Optional[TrainableStore], out=None, residual=None, bias=None,
+                act=ACT_NONE):
+        if self.adapters:
+            sr = self.sum_r
+            ops.gemm_nt(x_ext[:, : self.K], self.a_cat(store), out=x_ext[:, self.K: self.K + sr])
+        return ops.gemm_nt(x_ext, self.Wext, out=out, residual=residual, bias=bias, act=act,
+                           k_alg=self.K + self.sum_r)
+
+    def backward(self, dy: torch.Tensor, x_ext: Optional[torch.Tensor], store: Optional[TrainableStore],
+                 accumulate: bool, out=None) -> torch.Tensor:
+        """returns dx_ext [M, K+Rp] (columns [:K] are dL/dx); deposits adapter gradients into the store."""
+        dx_ext = ops.gemm_nt(dy, self.WextT, out=out)
+        if self.adapters:
+            # x_ext = [x | u] with u = x A^T: the columns [K:] of dx_ext are dL/du, and dL/dx gets the second hop
+            ops.gemm_nt(dx_ext[:, self.K:], self.AcatT, out=dx_ext[:, : self.K], accumulate=True)
+            M = dy.shape[0]
+            Mp = round_up(M, 64)
+            K, sr = self.K, self.sum_r
+            xT = ops.transpose(x_ext[:, :K], Rp=Mp)
+            duT = ops.transpose(dx_ext[:, K: K + self.Rp], Rp=Mp)
+            uT = ops.transpose(x_ext[:, K: K + self.Rp], Rp=Mp)
+            ops.gemm_nt(duT[:sr], xT, out=self.a_cat_grad(store), accumulate=accumulate)
+            for a in self.adapters:
+                dyT = ops.transpose(dy[:, a["row0"]: a["row0"] + a["rows"]], Rp=Mp)
+                ops.gemm_nt(dyT, uT[a["j0"]: a["j0"] + a["r"]], out=store.grad_view(a["B"]), alpha=a["scale"],
+                            accumulate=accumulate)
+        return dx_ext
+
+
+# ======================================================================================== whisper encoder
+class HipWhisperEncoder(nn.Module):
+    """Frozen Whisper audio encoder, inference-only (src/slam_llm/models/encoder.py:13-30).
+    bf16 weights/activations, LayerNorm statistics in fp32 (deviation from the fp32 reference: stated in DESIGN.md)."""
+
+    def __init__(self, cfg: dict, device):
+        super().__init__()
+        self.cfg = cfg
+        self.device_ = device
+        self.w = {}
+
+    def load(self, W: Dict[str, torch.Tensor], prefix="encoder."):
+        cfg, dev = self.cfg, self.device_
+        d, nm = cfg["enc_dim"], cfg["n_mels"]
+        assert d % 64 == 0 and d // cfg["enc_heads"] == 64, "whisper head_dim must be 64"
+        bf = lambda t: t.to(device=dev, dtype=torch.bfloat16).contiguous()  # noqa: E731
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        w = self.w
+        self.kp1 = round_up(3 * nm, 64)
+        c1 = torch.zeros((d, self.kp1), dtype=torch.bfloat16, device=dev)
+        c1[:, : 3 * nm] = bf(W[prefix + "conv1.weight"].permute(0, 2, 1).reshape(d, 3 * nm))
+        w["conv1"], w["conv1_b"] = c1, f32(W[prefix + "conv1.bias"])
+        w["conv2"] = bf(W[prefix + "conv2.weight"].permute(0, 2, 1).reshape(d, 3 * d))
+        w["conv2_b"] = f32(W[prefix + "conv2.bias"])
+        w["pos"] = bf(W[prefix + "positional_embedding"])
+        for i in range(cfg["enc_layers"]):
+            p = f"{prefix}blocks.{i}."
+            w[f"{i}.qkv"] = bf(torch.cat([W[p + "attn.query.weight"], W[p + "attn.key.weight"], W[p + "attn.value.weight"]], 0))
+            w[f"{i}.qkv_b"] = f32(torch.cat([W[p + "attn.query.bias"], torch.zeros(d), W[p + "attn.value.bias"]], 0))
+            w[f"{i}.out"], w[f"{i}.out_b"] = bf(W[p + "attn.out.weight"]), f32(W[p + "attn.out.bias"])
+            w[f"{i}.ln1_w"], w[f"{i}.ln1_b"] = f32(W[p + "attn_ln.weight"]), f32(W[p + "attn_ln.bias"])
+            w[f"{i}.fc1"], w[f"{i}.fc1_b"] = bf(W[p + "mlp.0.weight"]), f32(W[p + "mlp.0.bias"])
+            w[f"{i}.fc2"], w[f"{i}.fc2_b"] = bf(W[p + "mlp.2.weight"]), f32(W[p + "mlp.2.bias"])
+            w[f"{i}.ln2_w"], w[f"{i}.ln2_b"] = f32(W[p + "mlp_ln.weight"]), f32(W[p + "mlp_ln.bias"])
+        w["lnp_w"], w["lnp_b"] = f32(W[prefix + "ln_post.weight"]), f32(W[prefix + "ln_post.bias"])
+        return self
+
+    def init_random(self, seed: int = 42):
+        """seeded random weights generated directly in HBM at the true dimensions (benchmarks: no checkpoints offline)."""
+        cfg, dev = self.cfg, self.device_
+        d, nm = cfg["enc_dim"], cfg["n_mels"]
+        g = torch.Generator(device=dev).manual_seed(seed)
+        rn = lambda *s, std=0.02: (torch.randn(*s, generator=g, device=dev) * std)  # noqa: E731
+        w = self.w
+        self.kp1 = round_up(3 * nm, 64)
+        c1 = torch.zeros((d, self.kp1), dtype=torch.bfloat16, device=dev)
+        c1[:, : 3 * nm] = rn(d, 3 * nm, std=(3 * nm) ** -0.5).to(torch.bfloat16)
+        w["conv1"], w["conv1_b"] = c1, rn(d)
+        w["conv2"], w["conv2_b"] = rn(d, 3 * d, std=(3 * d) ** -0.5).to(torch.bfloat16), rn(d)
+        from .host_tables import sinusoids
+        w["pos"] = sinusoids(cfg["enc_ctx"], d).to(device=dev, dtype=torch.bfloat16)
+        for i in range(cfg["enc_layers"]):
+            w[f"{i}.qkv"] = rn(3 * d, d, std=d ** -0.5).to(torch.bfloat16)
+            qb = rn(3 * d)
+            qb[d: 2 * d] = 0
+            w[f"{i}.qkv_b"] = qb
+            w[f"{i}.out"], w[f"{i}.out_b"] = rn(d, d, std=d ** -0.5).to(torch.bfloat16), rn(d)
+            w[f"{i}.ln1_w"], w[f"{i}.ln1_b"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+            w[f"{i}.fc1"], w[f"{i}.fc1_b"] = rn(4 * d, d, std=d ** -0.5).to(torch.bfloat16), rn(4 * d)
+            w[f"{i}.fc2"], w[f"{i}.fc2_b"] = rn(d, 4 * d, std=(4 * d) ** -0.5).to(torch.bfloat16), rn(d)
+            w[f"{i}.ln2_w"], w[f"{i}.ln2_b"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+        w["lnp_w"], w["lnp_b"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+        return self
+
+    @torch.no_grad()
+    def extract_variable_length_features(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [B, n_mels, T] (the reference passes audio_mel.permute(0, 2, 1)) -> [B, ceil(T/2), d] bf16."""
+        mel = x.permute(0, 2, 1).contiguous()  # [B, T, n_mels]; a no-op copy for the reference's permuted view
+        return self.forward_btc(mel)
+
+    @torch.no_grad()
+    def forward_btc(self, mel: torch.Tensor) -> torch.Tensor:
+        cfg, w = self.cfg, self.w
+        B, T, nm = mel.shape
+        d, H = cfg["enc_dim"], cfg["enc_heads"]
+        cols = ops.conv1d_k3_im2col(mel, 1, self.kp1)
+        h1 = ops.gemm_nt(cols, w["conv1"], bias=w["conv1_b"], act=ACT_GELU)
+        del cols
+        cols2 = ops.conv1d_k3_im2col(h1.view(B, T, d), 2, 3 * d)
+        T2 = (T + 1) // 2
+        assert T2 <= w["pos"].shape[0], "audio longer than the encoder's positional table"
+        x = ops.gemm_nt(cols2, w["conv2"], bias=w["conv2_b"], act=ACT_GELU, residual=w["pos"], res_row_mod=T2)
+        del cols2, h1
+        M = B * T2
+        scale = 64 ** -0.5
+        hbuf = torch.empty((M, d), dtype=torch.bfloat16, device=mel.device)
+        qkv = torch.empty((M, 3 * d), dtype=torch.bfloat16, device=mel.device)
+        obuf = torch.empty((M, d), dtype=torch.bfloat16, device=mel.device)
+        fbuf = torch.empty((M, 4 * d), dtype=torch.bfloat16, device=mel.device)
+        for i in range(cfg["enc_layers"]):
+            ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], out=hbuf)
+            ops.gemm_nt(hbuf, w[f"{i}.qkv"], out=qkv, bias=w[f"{i}.qkv_b"])
+            vt = ops.head_rope_transpose(qkv, 2 * d, B, T2, H, 64)
+            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T2, H, H, 64, False, scale, want_lse=False, out=obuf)
+            ops.gemm_nt(obuf, w[f"{i}.out"], out=x, bias=w[f"{i}.out_b"], residual=x)
+            ops.layernorm(x, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], out=hbuf)
+            ops.gemm_nt(hbuf, w[f"{i}.fc1"], out=fbuf, bias=w[f"{i}.fc1_b"], act=ACT_GELU)
+            ops.gemm_nt(fbuf, w[f"{i}.fc2"], out=x, bias=w[f"{i}.fc2_b"], residual=x)
+        out = ops.layernorm(x, w["lnp_w"], w["lnp_b"])
+        return out.view(B, T2, d)
+
+    def forward(self, x):
+        return self.extract_variable_length_features(x)
+
+
+# ======================================================================================== projector
+class HipProjectorConcat(nn.Module):
+    """EncoderProjectorConcat (src/slam_llm/models/projector.py:5-27): k-frame stack, Linear-ReLU-Linear."""
+
+    def __init__(self, cfg: dict, store: TrainableStore, prefix="encoder_projector."):
+        super().__init__()
+        self.k, self.d, self.hid, self.dl = cfg["ds_rate"], cfg["enc_dim"], cfg["proj_hidden"], cfg["llm_dim"]
+        self.store, self.prefix = store, prefix
+        assert (self.k * self.d) % 64 == 0 and self.hid % 64 == 0 and self.dl % 64 == 0
+        store.reserve(prefix + "linear1.weight", (self.hid, self.k * self.d))
+        store.reserve(prefix + "linear1.bias", (self.hid,))
+        store.reserve(prefix + "linear2.weight", (self.dl, self.hid))
+        store.reserve(prefix + "linear2.bias", (self.dl,))
+        self.linear1 = nn.Module()
+        self.linear2 = nn.Module()
+
+    def bind(self):
+        s, p = self.store, self.prefix
+        self.linear1.weight, self.linear1.bias = s.params[p + "linear1.weight"], s.params[p + "linear1.bias"]
+        self.linear2.weight, self.linear2.bias = s.params[p + "linear2.weight"], s.params[p + "linear2.bias"]
+
+    def refresh(self):
+        s, p = self.store, self.prefix
+        # linear1's transpose would only serve dL/d(encoder output): the encoder is frozen, never needed
+        self.w2T = ops.transpose(s.bf16_view(p + "linear2.weight"), Rp=self.dl)  # [hid, dl]
+
+    def forward_hip(self, enc: torch.Tensor, stash: Optional[dict]):
+        """enc [B, T2, d] bf16 -> [B, Ta, dl] bf16"""
+        s, p = self.store, self.prefix
+        B, T2, d = enc.shape
+        Ta = T2 // self.k
+        xp = enc[:, : Ta * self.k, :]
+        if T2 % self.k:
+            xp = xp.contiguous()
+        xp = xp.reshape(B * Ta, self.k * d)
+        h = ops.gemm_nt(xp, s.bf16_view(p + "linear1.weight"), bias=s.master_view(p + "linear1.bias"), act=ACT_RELU)
+        y = ops.gemm_nt(h, s.bf16_view(p + "linear2.weight"), bias=s.master_view(p + "linear2.bias"))
+        if stash is not None:
+            stash["proj"] = (xp, h)
+        return y.view(B, Ta, self.dl)
+
+    def backward_hip(self, dy: torch.Tensor, stash: dict, accumulate: bool):
+        s, p = self.store, self.prefix
+        xp, h = stash.pop("proj")
+        M = dy.shape[0]
+        Mp = round_up(M, 64)
+        dyT = ops.transpose(dy, Rp=Mp)
+        hT = ops.transpose(h, Rp=Mp)
+        ops.gemm_nt(dyT, hT, out=s.grad_view(p + "linear2.weight"), accumulate=accumulate)
+        ops.colsum(dy, s.grad_view(p + "linear2.bias"), accumulate=accumulate)
+        dh = ops.gemm_nt(dy, self.w2T)
+        ops.relu_bwd_(dh, h)
+        dhT = ops.transpose(dh, Rp=Mp)
+        xT = ops.transpose(xp, Rp=Mp)
+        ops.gemm_nt(dhT, xT, out=s.grad_view(p + "linear1.weight"), accumulate=accumulate)
+        ops.colsum(dh, s.grad_view(p + "linear1.bias"), accumulate=accumulate)
+
+    def forward(self, x):
+        return self.forward_hip(x, None)
+
+
+# ======================================================================================== llama + LoRA
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
+    """register `param` under a dotted path, creating plain container modules on the way."""
+    parts = dotted.split(".")
+    m = root
+    for seg in parts[:-1]:
+        if seg not in m._modules:
+            m.add_module(seg, nn.Module())
+        m = m._modules[seg]
+    m.register_parameter(parts[-1], param)
+
+
+class HipLlamaLora(nn.Module):
+    """Frozen Llama decoder + peft-style LoRA adapters (HF LlamaForCausalLM under peft's LoraModel as built at
+    src/slam_llm/models/slam_model.py:118-221); parameter names follow peft 0.6.0."""
+
+    ATTN = ("q_proj", "k_proj", "v_proj", "o_proj")
+
+    def __init__(self, cfg: dict, store: TrainableStore, device, prefix="llm."):
+        super().__init__()
+        self.cfg, self.store, self.device_, self.prefix = cfg, store, device, prefix
+        d, Hq, Hkv, D, Fd = cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"], cfg["llm_ffn"]
+        if cfg.get("lora_dropout", 0.0) not in (0, 0.0):
+            raise NotImplementedError("lora_dropout > 0 is not implemented by the HIP path yet; pass "
+                                      "++train_config.peft_config.lora_dropout=0 (SURVEY g10)")
+        self.layers = []
+        targets = tuple(cfg.get("lora_targets") or ())
+        r, alpha = cfg["lora_r"], cfg["lora_alpha"]
+        P = prefix + "base_model.model."
+        # reserve in backward-production order: last layer first
+        for i in reversed(range(cfg["llm_layers"])):
+            L = SimpleNamespace()
+            L.qkv = FusedLinear(d, [("q_proj", Hq * D), ("k_proj", Hkv * D), ("v_proj", Hkv * D)], device)
+            L.o = FusedLinear(Hq * D, [("o_proj", d)], device)
+            L.gu = FusedLinear(d, [("gate_proj", Fd), ("up_proj", Fd)], device)
+            L.down = FusedLinear(Fd, [("down_proj", d)], device)
+            for fl in (L.down, L.gu, L.o, L.qkv):
+                mine = [(n, rows) for n, rows in fl.parts if n in targets]
+                for n, rows in mine:  # all A of a group first (contiguous A_cat), then the B's
+                    mod = "self_attn." if n in self.ATTN else "mlp."
+                    store.reserve(f"{P}model.layers.{i}.{mod}{n}.lora_A.default.weight", (r, fl.K))
+                for n, rows in mine:
+                    mod = "self_attn." if n in self.ATTN else "mlp."
+                    base = f"{P}model.layers.{i}.{mod}{n}."
+                    store.reserve(base + "lora_B.default.weight", (rows, r))
+                    fl.add_lora(n, r, alpha, base + "lora_A.default.weight", base + "lora_B.default.weight")
+            self.layers.insert(0, L)
+        self._rope = {}
+
+    # ---- weights -------------------------------------------------------------------------------------
+    def bind(self):
+        for name, p in self.store.params.items():
+            if name.startswith(self.prefix):
+                _attach(self, name[len(self.prefix):], p)
+
+    def load(self, W: Dict[str, torch.Tensor]):
+        cfg, dev = self.cfg, self.device_
+        P = self.prefix + "base_model.model."
+        bf = lambda t: t.to(device=dev, dtype=torch.bfloat16)  # noqa: E731
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        self.embed = bf(W[P + "model.embed_tokens.weight"]).contiguous()
+        for i, L in enumerate(self.layers):
+            p = f"{P}model.layers.{i}."
+            for fl in (L.qkv, L.o, L.gu, L.down):
+                for n, _ in fl.parts:
+                    mod = "self_attn." if n in self.ATTN else "mlp."
+                    fl.set_base(n, bf(W[p + mod + n + ".weight"]))
+                fl.finalize()
+            L.ln1, L.ln2 = f32(W[p + "input_layernorm.weight"]), f32(W[p + "post_attention_layernorm.weight"])
+        self.norm_w = f32(W[P + "model.norm.weight"])
+        self.lm_head = bf(W[P + "lm_head.weight"]).contiguous()
+        self.lm_headT = ops.transpose(self.lm_head, Rp=self.lm_head.shape[0])
+        return self
+
+    def init_random(self, seed: int = 42):
+        cfg, dev = self.cfg, self.device_
+        d, Fd, V = cfg["llm_dim"], cfg["llm_ffn"], cfg["vocab"]
+        g = torch.Generator(device=dev).manual_seed(seed)
+        rn = lambda *s, std=0.02: (torch.randn(*s, generator=g, device=dev) * std)  # noqa: E731
+        self.embed = rn(V, d, std=1.0).to(torch.bfloat16)
+        for L in self.layers:
+            for fl in (L.qkv, L.o, L.gu, L.down):
+                for n, rows in fl.parts:
+                    fl.set_base(n, rn(rows, fl.K, std=fl.K ** -0.5).to(torch.bfloat16))
+                fl.finalize()
+            L.ln1, L.ln2 = 1 + rn(d, std=0.1), 1 + rn(d, std=0.1)
+        self.norm_w = 1 + rn(d, std=0.1)
+        self.lm_head = rn(V, d, std=d ** -0.5).to(torch.bfloat16)
+        self.lm_headT = ops.transpose(self.lm_head, Rp=V)
+        return self
+
+    def refresh(self):
+        for L in self.layers:
+            for fl in (L.qkv, L.o, L.gu, L.down):
+                fl.refresh(self.store)
+
+    def rope(self, T: int):
+        if T not in self._rope:
+            from .host_tables import rope_tables
+            cos, sin = rope_tables(T, self.cfg["llm_head_dim"], self.cfg["rope_theta"])
+            self._rope[T] = (cos.to(self.device_), sin.to(self.device_))
+        return self._rope[T]
+
+    # ---- forward -------------------------------------------------------------------------------------
+    def forward_hip(self, h: torch.Tensor, B: int, T: int, key_mask: torch.Tensor, targets, n_valid,
+                    train: bool, return_logits: bool):
+        """h [B*T, d] bf16 (consumed).  Returns (out2 = [loss, acc] device tensor or None, logits or None, stash)."""
+        cfg, st = self.cfg, self.store
+        d, Hq, Hkv, D, Fd, V = (cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"],
+                                cfg["llm_ffn"], cfg["vocab"])
+        M = B * T
+        eps = cfg["rms_eps"]
+        cos, sin = self.rope(T)
+        scale = D ** -0.5
+        stash = {"layers": [], "B": B, "T": T, "key_mask": key_mask} if train else None
+        for L in self.layers:
+            x1 = L.qkv.new_input(M)
+            _, rstd1 = ops.rmsnorm_fwd(h, L.ln1, eps, out=x1[:, :d])
+            qkv = L.qkv.forward(x1, st)
+            qt = ops.head_rope_transpose(qkv, 0, B, T, Hq, D, cos=cos, sin=sin, want_t=train)
+            kt = ops.head_rope_transpose(qkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, want_t=train)
+            vt = ops.head_rope_transpose(qkv, (Hq + Hkv) * D, B, T, Hkv, D)
+            o_ext = L.o.new_input(M)
+            _, lse = ops.attn_fwd(qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], vt, B, T, Hq, Hkv, D, True, scale,
+                                  key_mask=key_mask, want_lse=train, out=o_ext[:, : Hq * D])
+            h_mid = L.o.forward(o_ext, st, residual=h)
+            x2 = L.gu.new_input(M)
+            _, rstd2 = ops.rmsnorm_fwd(h_mid, L.ln2, eps, out=x2[:, :d])
+            gu = L.gu.forward(x2, st)
+            hh = L.down.new_input(M)
+            ops.swiglu_fwd(gu, out=hh[:, :Fd])
+            h_out = L.down.forward(hh, st, residual=h_mid)
+            if train:
+                stash["layers"].append(dict(h=h, rstd1=rstd1, x1=x1 if L.qkv.adapters else None, qkv=qkv, qt=qt, kt=kt,
+                                            o=o_ext, lse=lse, h_mid=h_mid, rstd2=rstd2,
+                                            x2=x2 if L.gu.adapters else None, gu=gu,
+                                            hh=hh if L.down.adapters else None))
+            h = h_out
+        hN, rstdN = ops.rmsnorm_fwd(h, self.norm_w, eps)
+        logits_full = torch.empty((M, V), dtype=torch.bfloat16, device=h.device) if return_logits else None
+        out2 = None
+        if targets is not None:
+            row_loss = torch.empty((M,), dtype=torch.float32, device=h.device)
+            row_ok = torch.empty((M,), dtype=torch.int32, device=h.device)
+            dhN = torch.empty((M, d), dtype=torch.bfloat16, device=h.device) if train else None
+            Rc = max(256, min(M, ((1 << 29) // V) // 256 * 256))
+            chunk = torch.empty((min(Rc, M), V), dtype=torch.bfloat16, device=h.device)
+            for r0 in range(0, M, Rc):
+                r1 = min(M, r0 + Rc)
+                lg = chunk[: r1 - r0]
+                ops.gemm_nt(hN[r0:r1], self.lm_head, out=lg)
+                if return_logits:
+                    logits_full[r0:r1].copy_(lg)
+                ops.ce_fwd_bwd(lg, targets[r0:r1], n_valid, row_loss[r0:r1], row_ok[r0:r1], write_grad=train)
+                if train:
+                    ops.gemm_nt(lg, self.lm_headT, out=dhN[r0:r1])
+            out2 = ops.ce_finalize(row_loss, row_ok, n_valid)
+            if train:
+                stash["final"] = dict(h=h, rstdN=rstdN, dhN=dhN)
+        elif return_logits:
+            Rc = 4096
+            for r0 in range(0, M, Rc):
+                r1 = min(M, r0 + Rc)
+                ops.gemm_nt(hN[r0:r1], self.lm_head, out=logits_full[r0:r1])
+        return out2, logits_full, stash
+
+    # ---- backward ------------------------------------------------------------------------------------
+    def backward_hip(self, stash: dict, grad_scale: Optional[torch.Tensor], accumulate: bool, on_layer_done=None):
+        cfg, st = self.cfg, self.store
+        d, Hq, Hkv, D, Fd = cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"], cfg["llm_ffn"]
+        B, T, key_mask = stash["B"], stash["T"], stash["key_mask"]
+        cos, sin = self.rope(T)
+        scale = D ** -0.5
+        f = stash.pop("final")
+        dh = ops.rmsnorm_bwd(f["h"], f["rstdN"], self.norm_w, f["dhN"], grad_scale=grad_scale)
+        del f
+        for li in reversed(range(len(self.layers))):
+            L, S = self.layers[li], stash["layers"][li]
+            d_hh = L.down.backward(dh, S["hh"], st, accumulate)
+            dgu = ops.swiglu_bwd(S["gu"], d_hh[:, :Fd])
+            del d_hh
+            dx2 = L.gu.backward(dgu, S["x2"], st, accumulate)
+            del dgu
+            dh_mid = ops.rmsnorm_bwd(S["h_mid"], S["rstd2"], L.ln2, dx2[:, :d], dres=dh)
+            del dx2
+            do_ext = L.o.backward(dh_mid, S["o"], st, accumulate)
+            dO = do_ext[:, : Hq * D]
+            dOt = ops.head_rope_transpose(dO, 0, B, T, Hq, D)
+            qkv = S["qkv"]
+            q2, k2, v2 = qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd(q2, k2, v2, S["qt"], S["kt"], S["o"][:, : Hq * D], dO, dOt, S["lse"],
+                         dqkv[:, : Hq * D], dqkv[:, Hq * D: (Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:],
+                         B, T, Hq, Hkv, D, True, scale, key_mask=key_mask)
+            ops.head_rope_transpose(dqkv, 0, B, T, Hq, D, cos=cos, sin=sin, inverse=True, want_t=False)
+            ops.head_rope_transpose(dqkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, inverse=True, want_t=False)
+            del do_ext, dO, dOt
+            dx1 = L.qkv.backward(dqkv, S["x1"], st, accumulate)
+            del dqkv
+            dh = ops.rmsnorm_bwd(S["h"], S["rstd1"], L.ln1, dx1[:, :d], dres=dh_mid)
+            del dx1, dh_mid
+            stash["layers"][li] = None
+            if on_layer_done is not None:
+                on_layer_done(li)
+        return dh
+
+
+# ======================================================================================== composite
+class _SlamStep(torch.autograd.Function):
+    """autograd entry: forward returned the loss computed by the HIP path; backward runs the HIP backward and
+    deposits gradients directly into the flat grad buffer (`.grad` of every trainable parameter views it)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, stash, loss_value):
+        ctx.model, ctx.stash = model, stash
+        return loss_value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model, stash = ctx.model, ctx.stash
+        ctx.stash = None
+        model._run_backward(stash, grad_out)
+        return None, None, None, None
+
+
+class SlamHipModel(nn.Module):
+    def __init__(self, cfg: dict, device, tokenizer=None, train_config=None, model_config=None, **kwargs):
+        super().__init__()
+        self.cfg = cfg
+        self.device_ = torch.device(device)
+        self.tokenizer = tokenizer
+        self.train_config, self.model_config = train_config, model_config
+        self.metric = kwargs.get("metric", "acc")
+        self.store = TrainableStore(self.device_)
+        self.encoder = HipWhisperEncoder(cfg, self.device_)
+        self.llm = HipLlamaLora(cfg, self.store, self.device_)          # reserves LoRA (last layer first)
+        self.encoder_projector = HipProjectorConcat(cfg, self.store)    # projector last = produced last in backward
+        self.store.allocate()
+        self.llm.bind()
+        self.encoder_projector.bind()
+        self._anchor = torch.zeros(1, device=self.device_, requires_grad=True)
+        self._stale = True
+        self.return_logits = None  # None: logits only in eval mode
+        self.grad_hooks = []       # callables(prefix_end_offset) for data-parallel bucket launches
+        self._always_refresh = True
+
+    # ---- weights -------------------------------------------------------------------------------------
+    def load_weights(self, W: Dict[str, torch.Tensor]):
+        """W: {name: tensor} with the reference's state_dict names (fp32 or bf16, any device)."""
+        self.encoder.load(W)
+        self.llm.load(W)
+        with torch.no_grad():
+            for name, p in self.store.params.items():
+                if name in W:
+                    p.copy_(W[name].to(self.device_, torch.float32))
+        self._stale = True
+        return self
+
+    def init_random(self, seed: int = 42, lora_b_std: float = 0.02):
+        self.encoder.init_random(seed)
+        self.llm.init_random(seed + 1)
+        g = torch.Generator(device=self.device_).manual_seed(seed + 2)
+        with torch.no_grad():
+            for name, p in self.store.params.items():
+                if name.endswith("bias"):
+                    p.normal_(0, 0.02, generator=g)
+                elif "lora_B" in name:
+                    p.normal_(0, lora_b_std, generator=g)
+                else:
+                    p.normal_(0, p.shape[-1] ** -0.5, generator=g)
+        self._stale = True
+        return self
+
+    def mark_params_updated(self):
+        """call after an optimizer step that bypassed SlamAdamW (e.g. torch.optim.AdamW on .parameters())."""
+        self._stale = True
+
+    def _refresh(self):
+        self.store.refresh_bf16()
+        self.llm.refresh()
+        self.encoder_projector.refresh()
+        self._stale = False
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        return self
+
+    # ---- forward -------------------------------------------------------------------------------------
+    def forward(self, input_ids=None, attention_mask=None, labels=None, **kwargs):
+        """same contract as slam_model.forward (src/slam_llm/models/slam_model.py:283-407)."""
+        dev = self.device_
+        audio_mel = kwargs.get("audio_mel", None)
+        audio = kwargs.get("audio", None)
+        modality_mask = kwargs.get("modality_mask", None)
+        if input_ids is None or input_ids.device.type != "cuda":
+            raise RuntimeError("SlamHipModel.forward needs the batch resident in HBM (move it with .to(device) as the "
+                               "reference's train loop does, utils/train_utils.py:101-111)")
+        if self._stale or (self._always_refresh and self.training):
+            # params may have been updated by a foreign optimizer (torch.optim.AdamW on .parameters());
+            # refreshing is one cheap pass over the ~30 M trainable parameters.  SlamAdamW refreshes itself.
+            self._refresh()
+        B, T = input_ids.shape
+        train = torch.is_grad_enabled() and labels is not None
+        stash = {} if train else None
+
+        if audio_mel is None:
+            if audio is None:
+                raise RuntimeError("batch carries neither audio_mel nor audio")
+            # GPU log-mel front end (replaces the CPU DataLoader mel of speech_dataset.py:101-103)
+            audio_mel = ops.logmel(audio.float(), self.cfg["n_mels"])
+        enc = self.encoder.forward_btc(audio_mel.float().contiguous())
+        proj = self.encoder_projector.forward_hip(enc, stash)  # [B, Ta, dl]
+        Ta = proj.shape[1]
+        if modality_mask is None:
+            raise RuntimeError("modality_mask is required (speech recipes always provide it)")
+        mm = modality_mask.to(torch.uint8).contiguous()
+        embeds, spans = ops.embed_splice_fwd(input_ids, mm, self.llm.embed, proj)
+        if kwargs.get("inference_mode", False):
+            return embeds.view(B, T, -1), attention_mask
+        Tp = round_up(T, 64)
+        key_mask = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
+        key_mask[:, :T] = attention_mask.to(torch.uint8)
+        targets = n_valid = None
+        if labels is not None:
+            targets, n_valid = ops.ce_targets(labels.contiguous())
+        want_logits = self.return_logits if self.return_logits is not None else (not train)
+        out2, logits, lstash = self.llm.forward_hip(embeds, B, T, key_mask, targets, n_valid, train, want_logits)
+        loss = acc = None
+        if out2 is not None:
+            loss_val, acc = out2[0], out2[1]
+            if train:
+                stash.update(lstash)
+                stash.update(spans=spans, Ta=Ta, B=B, T=T)
+                loss = _SlamStep.apply(self._anchor, self, stash, loss_val)
+            else:
+                loss = loss_val
+        if not self.metric:
+            acc = -1
+        outputs = SimpleNamespace(loss=loss, logits=logits.view(B, T, -1) if logits is not None else None)
+        return outputs, acc
+
+    def _run_backward(self, stash: dict, grad_out: torch.Tensor):
+        st = self.store
+        accumulate = any(p.grad is not None for p in st.params.values())
+        gs = grad_out.reshape(1).to(torch.float32).contiguous()
+        dh0 = self.llm.backward_hip(stash, gs, accumulate, on_layer_done=self._on_layer_done)
+        dproj = ops.embed_splice_bwd(stash["spans"], dh0, stash["B"], stash["T"], stash["Ta"], self.cfg["llm_dim"])
+        self.encoder_projector.backward_hip(dproj, stash, accumulate)
+        for name, p in st.params.items():
+            if p.grad is None:
+                p.grad = st.grad_view(name)
+        for hk in self.grad_hooks:
+            hk(st.size)
+
+    def _on_layer_done(self, li: int):
+        if not self.grad_hooks:
+            return
+        # LoRA grads of layers >= li are final: they occupy the prefix of the flat buffer (reserved last layer first)
+        names = [n for n in self.store.offsets if f".layers.{li}." in n]
+        if not names:
+            return
+        end = max(self.store.offsets[n][0] + round_up(self.store.offsets[n][1], 64) for n in names)
+        for hk in self.grad_hooks:
+            hk(end)
+
+    # ---- generate (greedy; beam search is a next-round row) ------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, **kwargs):
+        raise NotImplementedError("batch decode (model.generate) is SURVEY 8(f) rank 1: not part of round 1")
+
+
+# ======================================================================================== optimizer
+class SlamAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (src/slam_llm/pipeline/finetune.py:247-251) as ONE fused kernel over the
+    flat master/grad buffers; also refreshes the bf16 compute copies.  Works with LambdaLR (reads group['lr'])."""
+
+    def __init__(self, model: SlamHipModel, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        params = list(model.store.params.values())
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.model = model
+        st = model.store
+        self.exp_avg = torch.zeros_like(st.flat)
+        self.exp_avg_sq = torch.zeros_like(st.flat)
+        self._step = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        st = self.model.store
+        self._step += 1
+        ops.adamw_step(st.flat, st.grad, self.exp_avg, self.exp_avg_sq, st.flat_bf16, float(g["lr"]), g["betas"][0],
+                       g["betas"][1], g["eps"], g["weight_decay"], self._step)
+        self.model.llm.refresh()
+        self.model.encoder_projector.refresh()
+        self.model._stale = False
+        self.model._always_refresh = False
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.model.store.params.values():
+            p.grad = None

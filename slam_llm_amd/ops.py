@@ -16,6 +16,39 @@ from . import lib
 from .lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, call  # noqa: F401
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the stream the kernels are launched on (torch's
+    current stream).  Enabled by bench.py over the timed region: `ops.TIMER = KernelTimer()`."""
+
+    def __init__(self):
+        self.rec = {}
+
+    def run(self, name, work, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn()
+        e.record()
+        self.rec.setdefault(name, []).append((s, e, work))
+        return out
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, lst in self.rec.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in lst)
+            out[name] = dict(launches=len(lst), total_ms=ms, avg_ms=ms / len(lst), work=sum(w for _, _, w in lst))
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def _timed(name, work, fn):
+    if TIMER is None:
+        return fn()
+    return TIMER.run(name, work, fn)
+
+
 def _p(t: Optional[torch.Tensor]):
     if t is None:
         return None
@@ -41,8 +74,9 @@ def _ld(t: torch.Tensor) -> int:
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None,
             residual=None, res_row_mod: int = 0, act: int = ACT_NONE, alpha: float = 1.0,
-            out_dtype=torch.bfloat16, accumulate: bool = False) -> torch.Tensor:
-    """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T).  a, b bf16 (row views with arbitrary ld)."""
+            out_dtype=torch.bfloat16, accumulate: bool = False, k_alg: Optional[int] = None) -> torch.Tensor:
+    """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T).  a, b bf16 (row views with arbitrary ld).
+    k_alg: algorithmic K (excludes zero padding) for FLOP accounting only."""
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
     M, K = a.shape
     N, K2 = b.shape
@@ -50,9 +84,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     od = F32 if out.dtype == torch.float32 else BF16
-    call("slam_gemm_bf16_nt", _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, N, K, _p(bias),
-         _p(residual), _ld(residual) if residual is not None else 0, res_row_mod, act, alpha, od,
-         1 if accumulate else 0, _s())
+    _timed("gemm_bf16_nt", 2.0 * M * N * (k_alg or K),
+           lambda: call("slam_gemm_bf16_nt", _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, N, K, _p(bias),
+                        _p(residual), _ld(residual) if residual is not None else 0, res_row_mod, act, alpha, od,
+                        1 if accumulate else 0, _s()))
     return out
 
 
@@ -190,8 +225,9 @@ def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_
     if out is None:
         out = torch.empty((B * T, Hq * D), dtype=torch.bfloat16, device=q2d.device)
     lse = torch.empty((B, Hq, Tp), dtype=torch.float32, device=q2d.device) if want_lse else None
-    call("slam_attn_fwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(vt), _p(out), _ld(out), _p(lse),
-         _p(key_mask), B, T, Tp, Hq, Hkv, D, 1 if causal else 0, scale, _s())
+    _timed("attn_fwd", 4.0 * B * Hq * T * T * D * (0.5 if causal else 1.0),
+           lambda: call("slam_attn_fwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(vt), _p(out), _ld(out), _p(lse),
+                        _p(key_mask), B, T, Tp, Hq, Hkv, D, 1 if causal else 0, scale, _s()))
     return out, lse
 
 
@@ -199,9 +235,11 @@ def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T,
              key_mask=None):
     Tp = qt.shape[-1]
     delta = torch.empty((B, Hq, Tp), dtype=torch.float32, device=q2d.device)
-    call("slam_attn_bwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(v2d), _ld(v2d), _p(qt), _p(kt), _p(o2d),
-         _ld(o2d), _p(do2d), _ld(do2d), _p(dot), _p(lse), _p(delta), _p(key_mask), _p(dq2d), _ld(dq2d),
-         _p(dk2d), _ld(dk2d), _p(dv2d), _ld(dv2d), B, T, Tp, Hq, Hkv, D, 1 if causal else 0, scale, _s())
+    _timed("attn_bwd", 10.0 * B * Hq * T * T * D * (0.5 if causal else 1.0),
+           lambda: call("slam_attn_bwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(v2d), _ld(v2d), _p(qt), _p(kt),
+                        _p(o2d), _ld(o2d), _p(do2d), _ld(do2d), _p(dot), _p(lse), _p(delta), _p(key_mask), _p(dq2d),
+                        _ld(dq2d), _p(dk2d), _ld(dk2d), _p(dv2d), _ld(dv2d), B, T, Tp, Hq, Hkv, D,
+                        1 if causal else 0, scale, _s()))
     return delta
 
 
@@ -284,3 +322,9 @@ def lora_pack_b(b_f32, scale, dst2d, dstT2d):
     rows, r = b_f32.shape
     assert b_f32.is_contiguous()
     call("slam_lora_pack_b", _p(b_f32), scale, _p(dst2d), _ld(dst2d), _p(dstT2d), _ld(dstT2d), rows, r, _s())
+
+
+def colsum(x2d, out_f32, accumulate=False):
+    M, N = x2d.shape
+    call("slam_colsum_bf16", _p(x2d), _ld(x2d), _p(out_f32), M, N, 1 if accumulate else 0, _s())
+    return out_f32

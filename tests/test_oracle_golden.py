@@ -50,8 +50,13 @@ def test_forward_backward_and_optimizer_match_reference(name):
         G.check_packed(fx, "grad." + n, g.numpy(), atol=1e-6, rtol=1e-3, norm_rtol=1e-4)
     for n in O.trainable_names(W):
         # Adam normalises the update (lr * m / sqrt(v)): elements with a near-zero gradient move by O(lr) on
-        # rounding-level gradient differences, so the bound is a fraction of lr = 1e-2, not of the value
-        G.check_packed(fx, "final." + n, W[n].detach().numpy(), atol=2e-4, rtol=1e-4)
+        # rounding-level gradient differences, so elementwise bounds are a fraction of the total movement
+        # (2 real steps x lr 1e-2) and the direction of the whole update is checked by cosine.
+        gold, mine = G.sub(fx, "final." + n, W[n].detach().numpy())
+        _, init = G.sub(fx, "final." + n, W0[n].detach().numpy())
+        assert np.abs(gold - mine).max() < 2e-3, n
+        if np.abs(gold - init).max() > 0:
+            assert G.cosine(gold - init, mine - init) > 0.999, n
 
 
 def test_dynamic_batcher_matches_reference_window_class():
