@@ -270,9 +270,11 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
   hipStream_t s = (hipStream_t)stream;
   int cfg = g_gemm_cfg;
   if (cfg == 0) {
-    // auto: big square-ish problems take the 256x128 tile (8 waves); narrow N takes 128x64.
+    // auto (measured on MI355X, profiles/r01_perf_ops_first.json): the 256x256 tile wins whenever it still gives
+    // >= 2 full waves of workgroups over the 256 CUs; otherwise 128x128 (4 waves, 2 WG/CU); skinny N takes 128x64.
+    const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
     if (N <= 64) cfg = 3;
-    else if (M >= 2048 && N >= 1024) cfg = 2;
+    else if (tiles256 >= 512) cfg = 4;
     else cfg = 1;
   }
   switch (cfg) {

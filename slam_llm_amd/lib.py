@@ -11,6 +11,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
+# torch must be loaded first: it brings the process-wide HIP runtime (libamdhip64) that owns the device context,
+# the allocator and the streams this library launches on; loading libslamhip.so before torch would bind it to a
+# second, separate runtime copy ("no ROCm-capable device is detected" at the first launch).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslamhip.so")
 

@@ -84,14 +84,30 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     od = F32 if out.dtype == torch.float32 else BF16
-    _timed("gemm_bf16_nt", 2.0 * M * N * (k_alg or K),
+    _timed(gemm_kernel_name(M, N), 2.0 * M * N * (k_alg or K),
            lambda: call("slam_gemm_bf16_nt", _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, N, K, _p(bias),
                         _p(residual), _ld(residual) if residual is not None else 0, res_row_mod, act, alpha, od,
                         1 if accumulate else 0, _s()))
     return out
 
 
+_GEMM_CFG = 0
+_GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
+               4: "gemm_nt_kernel<256,256,2,4>"}
+
+
+def gemm_kernel_name(M: int, N: int) -> str:
+    """which template instance slam_gemm_bf16_nt's auto rule launches for this shape (mirrors gemm_bf16.hip)"""
+    cfg = _GEMM_CFG
+    if cfg == 0:
+        tiles256 = ((M + 255) // 256) * ((N + 255) // 256)
+        cfg = 3 if N <= 64 else (4 if tiles256 >= 512 else 1)
+    return _GEMM_NAMES[cfg]
+
+
 def gemm_set_config(cfg: int):
+    global _GEMM_CFG
+    _GEMM_CFG = cfg
     call("slam_gemm_set_config", cfg)
 
 
