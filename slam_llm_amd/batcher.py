@@ -1,0 +1,98 @@
+"""Dynamic-frame batcher and collators of the speech recipes (host logic, no audio I/O dependencies).
+
+Same batch MEMBERSHIP as the reference: `window_class` / `MultiTaskDynamicBatchDataset.__iter__`
+(src/slam_llm/datasets/speech_dataset_large.py:244-263: greedy in-order grouping, a batch closes when
+(n+1) * max_len would exceed max_frame_length; "frames" = padded LLM positions) and the two collators
+(speech_dataset.py:216-291 left/right padding; speech_dataset_large.py:180-233 right padding).  Audio is NOT
+converted to log-mel on the host: batches carry raw waveforms (`audio`, `audio_len`) and the GPU front end
+(slam_logmel_fwd) produces `audio_mel` inside the step.  `max_frame_length` keeps its meaning; on a 288 GB part it
+can be raised ~6x -- `frames_for_hbm()` gives the budget-derived cap.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Iterator, List, Optional
+
+import torch
+
+IGNORE_INDEX = -100
+
+
+def window_class(elem_len: int, buffer_lens: List[int], max_frame_length: int) -> bool:
+    """True -> close the current batch before adding `elem` (speech_dataset_large.py:259-263)."""
+    if len(buffer_lens) == 0:
+        return True
+    return (len(buffer_lens) + 1) * max(elem_len, max(buffer_lens)) > max_frame_length
+
+
+def dynamic_batches(samples: Iterable[dict], max_frame_length: int) -> Iterator[List[dict]]:
+    """MultiTaskDynamicBatchDataset.__iter__ (speech_dataset_large.py:244-256)."""
+    buf: List[dict] = []
+    for elem in samples:
+        n = len(elem["input_ids"])
+        if not window_class(n, [len(e["input_ids"]) for e in buf], max_frame_length):
+            buf.append(elem)
+        else:
+            if buf:
+                yield buf
+            buf = [elem]
+    if buf:
+        yield buf
+
+
+def frames_for_hbm(hbm_bytes: int = 288 << 30, weights_bytes: int = 36 << 30, bytes_per_frame: int = 3_400_000) -> int:
+    """largest max_frame_length whose backward stash fits (≈3.3 MB/token over 32 Llama-3-8B layers)."""
+    return int((hbm_bytes * 0.85 - weights_bytes) // bytes_per_frame)
+
+
+def make_sample(audio: torch.Tensor, prompt_ids: List[int], answer_ids: Optional[List[int]], eos_id: int,
+                audio_length: int) -> dict:
+    """token layout [audio(-1)*audio_length, prompt, answer, eos] (speech_dataset.py:109-161)."""
+    if answer_ids is None:  # inference_mode
+        ids = torch.tensor([-1] * audio_length + list(prompt_ids), dtype=torch.int64)
+        return {"input_ids": ids.clamp(min=-1), "attention_mask": ids.ge(-1), "audio": audio,
+                "audio_length": audio_length, "prompt_length": len(prompt_ids)}
+    ids = torch.tensor([-1] * audio_length + list(prompt_ids) + list(answer_ids) + [eos_id], dtype=torch.int64)
+    labels = ids.clone()
+    labels[: audio_length + len(prompt_ids)] = IGNORE_INDEX
+    return {"input_ids": ids, "labels": labels, "attention_mask": ids.ge(-1), "audio": audio,
+            "audio_length": audio_length, "prompt_length": len(prompt_ids)}
+
+
+def whisper_audio_length(n_samples: int, ds_rate: int = 5, pad_to_30s: bool = True) -> int:
+    """((n_mel_frames + 1) // 2) // k  (speech_dataset.py:104-105); 300 for a padded 30 s clip."""
+    n = 480000 if pad_to_30s else n_samples
+    frames = n // 160
+    return ((frames + 1) // 2) // ds_rate
+
+
+def _pad1(t: torch.Tensor, left: int, right: int, value) -> torch.Tensor:
+    return torch.cat([torch.full((left,), value, dtype=t.dtype), t, torch.full((right,), value, dtype=t.dtype)])
+
+
+def collate(samples: List[dict], pad_token_id: int, left_pad_prompt: bool, n_samples: int = 480000) -> dict:
+    """left_pad_prompt=True: SpeechDatasetJsonl.collator; False: MultiTaskDataset.collator (right padding only)."""
+    if left_pad_prompt:
+        pl = [s["audio_length"] + s["prompt_length"] for s in samples]
+        al = [len(s["input_ids"]) - p for s, p in zip(samples, pl)]
+        pm, am = max(pl), max(al)
+        lr = [(pm - p, am - a) for p, a in zip(pl, al)]
+    else:
+        tm = max(len(s["input_ids"]) for s in samples)
+        lr = [(0, tm - len(s["input_ids"])) for s in samples]
+    out = {
+        "input_ids": torch.stack([_pad1(s["input_ids"], l, r, pad_token_id) for s, (l, r) in zip(samples, lr)]),
+        "attention_mask": torch.stack([_pad1(s["attention_mask"], l, r, False) for s, (l, r) in zip(samples, lr)]),
+    }
+    if "labels" in samples[0]:
+        out["labels"] = torch.stack([_pad1(s["labels"], l, r, IGNORE_INDEX) for s, (l, r) in zip(samples, lr)])
+    mm = torch.zeros_like(out["attention_mask"])
+    for i, (s, (l, _)) in enumerate(zip(samples, lr)):
+        mm[i, l: l + s["audio_length"]] = True
+    out["modality_mask"] = mm
+    # raw waveforms, zero padded to a common length; audio_len = true sample counts (GPU log-mel pads/trims to n_samples)
+    alen = torch.tensor([min(len(s["audio"]), n_samples) for s in samples], dtype=torch.int32)
+    amax = int(alen.max())
+    out["audio"] = torch.stack([torch.nn.functional.pad(s["audio"][:amax].float(), (0, amax - min(len(s["audio"]), amax)))
+                                for s in samples])
+    out["audio_len"] = alen
+    return out

@@ -686,7 +686,7 @@ class SlamHipModel(nn.Module):
             if audio is None:
                 raise RuntimeError("batch carries neither audio_mel nor audio")
             # GPU log-mel front end (replaces the CPU DataLoader mel of speech_dataset.py:101-103)
-            audio_mel = ops.logmel(audio.float(), self.cfg["n_mels"])
+            audio_mel = ops.logmel(audio.float(), self.cfg["n_mels"], n_valid=kwargs.get("audio_len", None))
         enc = self.encoder.forward_btc(audio_mel.float().contiguous())
         proj = self.encoder_projector.forward_hip(enc, stash)  # [B, Ta, dl]
         Ta = proj.shape[1]

@@ -1,0 +1,111 @@
+"""Plugin file for the reference's loaders: use with
+
+    ++model_config.file=<repo>/slam_llm_amd/slam_model_hip.py:model_factory
+    ++dataset_config.file=<repo>/slam_llm_amd/slam_model_hip.py:get_speech_dataset
+
+`model_factory(train_config, model_config, **kwargs) -> (model, tokenizer)` has the signature of
+src/slam_llm/models/slam_model.py:21-51 and is resolved by src/slam_llm/utils/model_utils.py:4-29 (path.py:func).
+Configuration is read with `.get()` so both the asr_librispeech and the aispeech_asr config dataclasses work
+(SURVEY g14).  Weights: `model_config.encoder_path` / `llm_path` may point at *.pt / *.safetensors state dicts in
+the reference's key names; with `model_config.random_init=true` (benchmarks, tests) seeded random weights at the
+true dimensions are generated directly in HBM.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import sys
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if os.path.dirname(_HERE) not in sys.path:
+    sys.path.insert(0, os.path.dirname(_HERE))
+
+from slam_llm_amd.model import PRESETS, SlamHipModel, make_config  # noqa: E402
+
+logger = logging.getLogger(__name__)
+
+
+def _get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    if hasattr(cfg, "get"):
+        v = cfg.get(key, default)
+        return default if v is None else v
+    return getattr(cfg, key, default)
+
+
+def _guess_preset(name: str, table) -> str:
+    n = (name or "").lower().replace("_", "-")
+    for k in sorted(table, key=len, reverse=True):
+        if k in n or k.replace("-", "") in n.replace("-", ""):
+            return k
+    raise ValueError(f"cannot map '{name}' to a known architecture preset {sorted(table)}; pass model_config.arch_*")
+
+
+def build_config(train_config, model_config) -> dict:
+    enc_name = _get(model_config, "encoder_name", "whisper")
+    if enc_name != "whisper":
+        raise NotImplementedError(f"encoder_name={enc_name}: only the Whisper branch (src/slam_llm/models/slam_model.py:320-321) "
+                                  "is on the HIP path this round; HuBERT/WavLM are SURVEY 8(f) rows")
+    if _get(model_config, "encoder_projector", "linear") != "linear":
+        raise NotImplementedError("only encoder_projector=linear (EncoderProjectorConcat) is on the HIP path this round")
+    enc_presets = {k: v for k, v in PRESETS.items() if k.startswith("whisper")}
+    llm_presets = {k: v for k, v in PRESETS.items() if not k.startswith("whisper")}
+    enc = _get(model_config, "arch_encoder") or _guess_preset("whisper-" + str(_get(model_config, "encoder_path", "")).split("/")[-1].replace(".pt", ""), enc_presets)
+    llm = _get(model_config, "arch_llm") or _guess_preset(str(_get(model_config, "llm_name", "")), llm_presets)
+    peft = _get(train_config, "peft_config", None)
+    use_peft = bool(_get(train_config, "use_peft", False))
+    cfg = make_config(enc, llm,
+                      ds_rate=int(_get(model_config, "encoder_projector_ds_rate", 5)),
+                      lora_r=int(_get(peft, "r", 8)), lora_alpha=float(_get(peft, "lora_alpha", 32)),
+                      lora_targets=tuple(_get(peft, "target_modules", ("q_proj", "v_proj"))) if use_peft else (),
+                      lora_dropout=float(_get(peft, "lora_dropout", 0.05)) if use_peft else 0.0)
+    if int(_get(model_config, "encoder_dim", cfg["enc_dim"])) != cfg["enc_dim"] or int(_get(model_config, "llm_dim", cfg["llm_dim"])) != cfg["llm_dim"]:
+        raise ValueError("model_config.encoder_dim / llm_dim do not match the selected architecture presets")
+    return cfg
+
+
+def _load_state(path):
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    return torch.load(path, map_location="cpu")
+
+
+def model_factory(train_config, model_config, **kwargs):
+    """returns (model, tokenizer) like src/slam_llm/models/slam_model.py:21-51"""
+    cfg = build_config(train_config, model_config)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    tokenizer = None
+    llm_path = _get(model_config, "llm_path", None)
+    if llm_path and os.path.isdir(str(llm_path)):
+        from transformers import AutoTokenizer
+        tokenizer = AutoTokenizer.from_pretrained(llm_path)
+        tokenizer.pad_token_id = tokenizer.eos_token_id  # slam_model.py:63-64
+    model = SlamHipModel(cfg, dev, tokenizer=tokenizer, train_config=train_config, model_config=model_config, **kwargs)
+    if _get(model_config, "random_init", False):
+        model.init_random(int(_get(train_config, "seed", 42)))
+    else:
+        W = {}
+        for key in ("encoder_state", "llm_state"):
+            p = _get(model_config, key, None)
+            if p:
+                W.update(_load_state(str(p)))
+        if not W:
+            raise FileNotFoundError("no weights given: set model_config.encoder_state / llm_state (state dicts in the "
+                                    "reference's key names) or model_config.random_init=true")
+        model.load_weights(W)
+    ckpt_path = kwargs.get("ckpt_path", None)  # projector/LoRA checkpoint written by save_model_checkpoint_peft
+    if ckpt_path is not None:
+        logger.info("loading other parts from: %s", ckpt_path)
+        model.load_state_dict(torch.load(ckpt_path, map_location="cpu"), strict=False)
+        model.mark_params_updated()
+    return model, tokenizer
+
+
+def get_speech_dataset(dataset_config, tokenizer, split):
+    from slam_llm_amd.dataset import SpeechDatasetJsonlRaw
+    return SpeechDatasetJsonlRaw(dataset_config, tokenizer, split)

@@ -1,0 +1,67 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient exchange (GradSync) and the uneven-input guard."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from slam_llm_amd.train import GradSync, all_ranks_have_data, setup_distributed
+    r, lr, w = setup_distributed("cpu")
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+    n = 100_000
+    flat = torch.full((n,), float(rank + 1))
+    flat[: 10] = torch.arange(10, dtype=torch.float32) * (rank + 1)
+
+    class FakeModel:
+        grad_hooks = []
+
+    gs = GradSync(flat, bucket_bytes=64 * 1024).attach(FakeModel)
+    # backward produces the flat buffer prefix by prefix (last LLM layer first, projector tail last)
+    for end in (10_000, 30_000, 30_001, 70_000):
+        for hk in FakeModel.grad_hooks:
+            hk(end)
+    gs.finish()  # flushes the tail and averages
+    expect = torch.full((n,), 1.5)
+    expect[: 10] = torch.arange(10, dtype=torch.float32) * 1.5
+    ok = torch.allclose(flat, expect)
+    # second step re-uses the object
+    flat.fill_(float(rank))
+    for hk in FakeModel.grad_hooks:
+        hk(n)
+    gs.finish()
+    ok = ok and torch.allclose(flat, torch.full((n,), 0.5))
+    # uneven shards: rank 1 runs dry first -> everybody stops (reference: Join / monitored_barrier)
+    flags = [all_ranks_have_data(step < (3 if rank == 0 else 2), torch.device("cpu")) for step in range(3)]
+    q.put((rank, bool(ok), flags))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gradsync_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, ok, flags in res:
+        assert ok, f"rank {rank}: averaged gradients wrong"
+        assert flags == [True, True, False]

@@ -1,0 +1,86 @@
+"""CPU: host-side logic of the product (batcher, collators, LR schedule, FLOP model) against the oracle / fixtures."""
+import numpy as np
+import torch
+
+from oracle import slam_oracle as O
+from slam_llm_amd import batcher
+from slam_llm_amd.train import lr_lambda
+from tests import golden_util as G
+
+
+def test_dynamic_batcher_membership_matches_reference_fixture():
+    fx = G.load("batcher")  # produced by the reference's own window_class / MultiTaskDynamicBatchDataset
+    ci = 0
+    while f"lens.{ci}" in fx.files:
+        lens = [int(x) for x in fx[f"lens.{ci}"]]
+        samples = [{"input_ids": torch.zeros(n, dtype=torch.int64), "idx": i} for i, n in enumerate(lens)]
+        groups = list(batcher.dynamic_batches(samples, int(fx[f"mfl.{ci}"])))
+        assert [len(g) for g in groups] == [int(x) for x in fx[f"group_sizes.{ci}"]]
+        assert [s["idx"] for g in groups for s in g] == list(range(len(lens)))
+        ci += 1
+    assert ci == 4
+
+
+def _samples():
+    g = torch.Generator().manual_seed(0)
+    out_b, out_o = [], []
+    for alen, pl, al in [(20, 6, 5), (20, 6, 9), (12, 4, 1)]:
+        pids = torch.randint(3, 100, (pl,), generator=g).tolist()
+        aids = torch.randint(3, 100, (al,), generator=g).tolist()
+        audio = torch.randn(1600 * (alen // 4), generator=g)
+        out_b.append(batcher.make_sample(audio, pids, aids, 2, alen))
+        out_o.append(O.make_sample(alen, pids, aids, 2))
+    return out_b, out_o
+
+
+def test_collators_match_oracle_restatement_of_reference():
+    sb, so = _samples()
+    for left in (True, False):
+        got = batcher.collate(sb, pad_token_id=2, left_pad_prompt=left)
+        ref = (O.collate_left_pad if left else O.collate_right_pad)(so, pad_id=2)
+        for k in ("input_ids", "labels", "attention_mask", "modality_mask"):
+            assert torch.equal(got[k], ref[k]), (left, k)
+        assert got["audio"].shape[0] == 3 and got["audio_len"].tolist() == [len(s["audio"]) for s in sb]
+
+
+def test_golden_batches_are_reproduced_by_product_collator():
+    """the batch stored in the step fixtures (built through the oracle, equal to the reference layout) is
+    reproduced by the product's make_sample + collate"""
+    from oracle.make_golden_cases import CASES
+    for name, case in CASES.items():
+        fx = G.load(name)
+        cfg = case["cfg"]
+        g = torch.Generator().manual_seed(1236)
+        audio = torch.from_numpy(fx["audio"])
+        samples = []
+        for i in range(audio.shape[0]):
+            al = case["answer_lens"][i % len(case["answer_lens"])]
+            pids = torch.randint(3, cfg["vocab"], (6,), generator=g).tolist()
+            aids = torch.randint(3, cfg["vocab"], (al - 1,), generator=g).tolist()
+            alen = batcher.whisper_audio_length(audio.shape[1], cfg["ds_rate"], pad_to_30s=False)
+            samples.append(batcher.make_sample(audio[i], pids, aids, 2, alen))
+        got = batcher.collate(samples, pad_token_id=2, left_pad_prompt=case["left_pad"])
+        for k in ("input_ids", "labels", "attention_mask", "modality_mask"):
+            assert np.array_equal(got[k].numpy(), fx["batch." + k]), (name, k)
+
+
+def test_whisper_audio_length():
+    assert batcher.whisper_audio_length(16000 * 10) == 300  # padded to 30 s by the recipe (speech_dataset.py:101-105)
+    assert batcher.whisper_audio_length(32000, pad_to_30s=False) == 20
+
+
+def test_lr_schedule_matches_reference_lambda():
+    for s in (0, 1, 999, 1000, 1001, 50000, 100000, 100001):
+        assert lr_lambda(s, 1000, 100000) == O.lr_lambda(s, 1000, 100000)
+    assert lr_lambda(0, 1000, 100000) == 0  # first optimizer step is a no-op on the parameters
+
+
+def test_flop_model_matches_survey_worked_example():
+    import bench
+    from slam_llm_amd.model import make_config
+    cfg = make_config("whisper-large-v3", "llama-3-8b", lora_r=16, lora_alpha=32)
+    fl = bench.algorithmic_flops_per_clip(cfg, T=380, Ta=300, n_frames=3000)
+    # enc 2.27e12, proj 3.9e10, llm 1.15e13, lora 1.6e10, mel 1.1e9 -> 1.38e13 per 30 s clip
+    assert abs(fl["enc"] / 2.27e12 - 1) < 0.02 and abs(fl["proj"] / 3.9e10 - 1) < 0.03
+    assert abs(fl["llm"] / 1.15e13 - 1) < 0.02 and abs(fl["total"] / 1.38e13 - 1) < 0.02
+    assert batcher.frames_for_hbm() > 60000
