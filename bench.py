@@ -157,10 +157,10 @@ def main():
     fl = algorithmic_flops_per_clip(cfg, T, Ta, 3000)
     step_flops = fl["total"] * N_CLIPS
     ksum = timer.summary()
-    gemm_all = [v for k, v in ksum.items() if k.startswith("gemm_nt_kernel")]
+    gemm_all = [v for k, v in ksum.items() if k.startswith("gemm_nt")]
     gemm_ms = sum(v["total_ms"] for v in gemm_all)
     gemm_tf_all = sum(v["work"] for v in gemm_all) / (gemm_ms * 1e-3) / 1e12
-    dom = max((k for k in ksum if k.startswith("gemm_nt_kernel")), key=lambda k: ksum[k]["total_ms"])
+    dom = max((k for k in ksum if k.startswith("gemm_nt")), key=lambda k: ksum[k]["total_ms"])
     g = ksum[dom]  # the dominant kernel (largest share of the step): one template instance of the bf16 GEMM
     gemm_tf = g["work"] / (g["total_ms"] * 1e-3) / 1e12
     kern = {k: dict(launches_per_step=v["launches"] / args.steps, ms_per_step=v["total_ms"] / args.steps,

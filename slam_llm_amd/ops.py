@@ -93,7 +93,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
 
 _GEMM_CFG = 0
 _GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
-               4: "gemm_nt_kernel<256,256,2,4>"}
+               4: "gemm_nt_kernel<256,256,2,4>", 5: "gemm_nt_pipe_kernel<256,256,2,4>",
+               6: "gemm_nt_pipe_kernel<256,256,2,4,v1>", 7: "gemm_nt_pipe_kernel<256,256,4,2>"}
 
 
 def gemm_kernel_name(M: int, N: int) -> str:
@@ -101,7 +102,7 @@ def gemm_kernel_name(M: int, N: int) -> str:
     cfg = _GEMM_CFG
     if cfg == 0:
         tiles256 = ((M + 255) // 256) * ((N + 255) // 256)
-        cfg = 3 if N <= 64 else (4 if tiles256 >= 512 else 1)
+        cfg = 3 if N <= 64 else (6 if tiles256 >= 512 else 1)
     return _GEMM_NAMES[cfg]
 
 

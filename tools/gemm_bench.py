@@ -1,0 +1,47 @@
+"""A/B GEMM tile/pipeline configs on the GPU box (interleaved rounds, correctness checked vs torch)."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from slam_llm_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfgs = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "4,5".split(","))]
+shapes = [(11780, 4096, 4096), (11780, 28672, 4096), (11780, 4096, 14336), (11780, 6144, 4160), (46500, 5120, 1280),
+          (46500, 1280, 5120), (4096, 128256, 4096), (8192, 8192, 8192)]
+res = []
+for (M, N, K) in shapes:
+    a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    b = torch.randn(N, K, device=dev).to(torch.bfloat16)
+    c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ref = None
+    if M * N <= 11780 * 6144:
+        ref = (a.float() @ b.float().T)
+    best = {cfg: 1e9 for cfg in cfgs}
+    for cfg in cfgs:
+        ops.gemm_set_config(cfg)
+        ops.gemm_nt(a, b, out=c)
+        if ref is not None:
+            err = (c.float() - ref).abs().max().item() / ref.abs().max().item()
+            assert err < 2e-2, f"cfg {cfg} wrong result: rel err {err}"
+    for rnd in range(4):
+        for cfg in cfgs:
+            ops.gemm_set_config(cfg)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(5):
+                ops.gemm_nt(a, b, out=c)
+            e.record()
+            torch.cuda.synchronize()
+            best[cfg] = min(best[cfg], s.elapsed_time(e) / 5)
+    ops.gemm_set_config(0)
+    line = {"M": M, "N": N, "K": K, **{f"cfg{cfg}_TF": round(2.0 * M * N * K / (best[cfg] * 1e-3) / 1e12, 1) for cfg in cfgs}}
+    res.append(line)
+    print(line, flush=True)
+    del a, b, c, ref
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/gemm_bench.json", "w"), indent=1)
