@@ -55,14 +55,16 @@ __device__ __forceinline__ frag_t zero_frag() {
   return z;
 }
 __device__ __forceinline__ frag_t pack_frag(f32x4_t x, f32x4_t y) {
-  frag_t f;
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    f[e] = f2bf(x[e]);
-    f[4 + e] = f2bf(y[e]);
-  }
-  return f;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  u32x4_t w;
+  w[0] = pack2bf(x[0], x[1]);
+  w[1] = pack2bf(x[2], x[3]);
+  w[2] = pack2bf(y[0], y[1]);
+  w[3] = pack2bf(y[2], y[3]);
+  return __builtin_bit_cast(frag_t, w);
 }
+// v_exp_f32 directly: arguments here are <= 0 (or -inf), no denormal-range fix-up needed
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ frag_t join_frag(u16x4_t lo, u16x4_t hi) {
   frag_t f;
 #pragma unroll
@@ -207,14 +209,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
       const float mnew = fmaxf(mrow[f], mt);
       const float muse = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = exp2f(mrow[f] - muse);
+      const float alpha = fast_exp2(mrow[f] - muse);
       mrow[f] = mnew;
       float rs = 0.f;
 #pragma unroll
       for (int kf = 0; kf < 4; kf++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const float pv = exp2f(s[f][kf][r] - muse);
+          const float pv = fast_exp2(s[f][kf][r] - muse);
           s[f][kf][r] = pv;
           rs += pv;
         }
@@ -289,20 +291,30 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// backward dQ: one wave = 16 queries, loop over 32-key tiles, operands straight from L1/L2
+// backward dQ: workgroup = 4 waves x 16 queries; 32-key K / V / K^T tiles are staged through LDS (shared by the
+// four waves, next tile prefetched into registers during the MFMA phase)
 //   S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - Delta) * scale, dQ^T += K^T(as [d x keys]) . dS^T
 // ------------------------------------------------------------------------------------------
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
+  constexpr int ROWB = D * 2;
+  constexpr int KCH = D / 8;
+  constexpr int KCM = KCH - 1;
+  constexpr int NKV = 32 * KCH / 256;  // 16-byte chunks per thread of a [32][D] tile
+  constexpr int NKT = D * 4 / 256;     // 16-byte chunks per thread of the [D][32] transposed tile
+  __shared__ __attribute__((aligned(16))) char lds[2 * 32 * ROWB + D * 64];
+  char* ldsK = lds;
+  char* ldsV = lds + 32 * ROWB;
+  char* ldsKt = lds + 64 * ROWB;
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.Hq / p.Hkv);
   const int T = p.T, Tp = p.Tp;
-  const int qw0 = blockIdx.x * 64 + wave * 16;
-  if (qw0 >= T) return;
+  const int qb0 = blockIdx.x * 64, qw0 = qb0 + wave * 16;
   const int q = qw0 + li;
   const bool qok = q < T;
 
@@ -320,19 +332,64 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
   for (int df = 0; df < DF; df++) dq[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int kend = CAUSAL ? min(T, qw0 + 16) : T;
+  const int kend = CAUSAL ? min(T, qb0 + 64) : T;
+  const int ntiles = (kend + 31) / 32;
   const bf16_t* ktb = p.Kt + ((int64_t)(b * p.Hkv + hk) * D) * Tp;
-  for (int k0 = 0; k0 < kend; k0 += 32) {
+
+  frag_t kreg[NKV], vreg[NKV], ktreg[NKT];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NKV; i++) {
+      const int item = tid + i * 256;
+      const int row = item / KCH, c = item % KCH;
+      const int key = k0 + row;
+      const bool ok = key < T;
+      kreg[i] = ok ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * T + key) * p.ldk + hk * D + c * 8) : zero_frag();
+      vreg[i] = ok ? *reinterpret_cast<const frag_t*>(p.V + ((int64_t)b * T + key) * p.ldv + hk * D + c * 8) : zero_frag();
+    }
+#pragma unroll
+    for (int i = 0; i < NKT; i++) {
+      const int item = tid + i * 256;
+      const int d = item >> 2, c = item & 3;
+      ktreg[i] = *reinterpret_cast<const frag_t*>(ktb + (int64_t)d * Tp + k0 + c * 8);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NKV; i++) {
+      const int item = tid + i * 256;
+      const int row = item / KCH, c = item % KCH;
+      const int off = row * ROWB + ((c ^ (row & KCM)) << 4);
+      *reinterpret_cast<frag_t*>(ldsK + off) = kreg[i];
+      *reinterpret_cast<frag_t*>(ldsV + off) = vreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NKT; i++) {
+      const int item = tid + i * 256;
+      const int d = item >> 2, c = item & 3;
+      *reinterpret_cast<frag_t*>(ldsKt + d * 64 + ((c ^ ((d >> 2) & 3)) << 4)) = ktreg[i];
+    }
+  };
+
+  if (ntiles > 0) gload(0);
+  for (int it = 0; it < ntiles; it++) {
+    const int k0 = it * 32;
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (it + 1 < ntiles) gload(k0 + 32);
+    if (qw0 >= T || (CAUSAL && k0 > qw0 + 15)) continue;
+
     f32x4_t st[2], dpt[2];
 #pragma unroll
     for (int kf = 0; kf < 2; kf++) {
-      const int key = k0 + kf * 16 + li;
-      const bool kok = key < T;
+      const int row = kf * 16 + li;
       f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f}, c = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kd = 0; kd < KD; kd++) {
-        const frag_t kfr = kok ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * T + key) * p.ldk + hk * D + kd * 32 + g * 8) : zero_frag();
-        const frag_t vfr = kok ? *reinterpret_cast<const frag_t*>(p.V + ((int64_t)b * T + key) * p.ldv + hk * D + kd * 32 + g * 8) : zero_frag();
+        const int off = row * ROWB + (((kd * 4 + g) ^ (row & KCM)) << 4);
+        const frag_t kfr = *reinterpret_cast<const frag_t*>(ldsK + off);
+        const frag_t vfr = *reinterpret_cast<const frag_t*>(ldsV + off);
         a = mfma16(kfr, qf[kd], a);
         c = mfma16(vfr, dof[kd], c);
       }
@@ -348,16 +405,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
       for (int r = 0; r < 4; r++) {
         const int key = kb + r;
         const bool ok = ((mk >> (8 * r)) & 0xffu) != 0 && key < T && (!CAUSAL || key <= q) && qok;
-        const float pv = ok ? exp2f(st[kf][r] * sl2 - lse2) : 0.f;
+        const float pv = ok ? fast_exp2(st[kf][r] * sl2 - lse2) : 0.f;
         st[kf][r] = pv * (dpt[kf][r] - delta) * p.scale;
       }
     }
     const frag_t dsb = pack_frag(st[0], st[1]);
 #pragma unroll
     for (int df = 0; df < DF; df++) {
-      const bf16_t* kr = ktb + (int64_t)(df * 16 + li) * Tp + k0 + 4 * g;
-      const u16x4_t lo = *reinterpret_cast<const u16x4_t*>(kr);
-      const u16x4_t hi = *reinterpret_cast<const u16x4_t*>(kr + 16);
+      const int d = df * 16 + li;
+      const int sw = (d >> 2) & 3;
+      const u16x4_t lo = *reinterpret_cast<const u16x4_t*>(ldsKt + d * 64 + (((g >> 1) ^ sw) << 4) + (g & 1) * 8);
+      const u16x4_t hi = *reinterpret_cast<const u16x4_t*>(ldsKt + d * 64 + (((2 + (g >> 1)) ^ sw) << 4) + (g & 1) * 8);
       dq[df] = mfma16(join_frag(lo, hi), dsb, dq[df]);
     }
   }
@@ -373,23 +431,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// backward dK/dV: one wave = 16 keys, loops over the GQA group's query heads and 32-query tiles
-//   S = Q K^T, dP = dO V^T (lane owns key (l&15), 4 consecutive queries),
+// backward dK/dV: workgroup = 4 waves x 16 keys; for every query head of the GQA group and every 32-query tile the
+// Q / dO tiles (row-major, for S and dP) and Q^T / dO^T tiles (for the reductions over queries) are staged through
+// LDS and shared by the four waves;  S = Q K^T, dP = dO V^T (lane owns key (l&15), 4 consecutive queries),
 //   dV^T += dO^T(as [d x q]) . P,   dK^T += Q^T(as [d x q]) . dS
 // ------------------------------------------------------------------------------------------
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
+  constexpr int ROWB = D * 2;
+  constexpr int KCH = D / 8;
+  constexpr int KCM = KCH - 1;
+  constexpr int NQ = 32 * KCH / 256;
+  constexpr int NQT = D * 4 / 256;
+  __shared__ __attribute__((aligned(16))) char lds[2 * 32 * ROWB + 2 * D * 64];
+  char* ldsQ = lds;
+  char* ldsDO = lds + 32 * ROWB;
+  char* ldsQt = lds + 64 * ROWB;
+  char* ldsDOt = lds + 64 * ROWB + D * 64;
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int b = blockIdx.z, hk = blockIdx.y;
   const int G = p.Hq / p.Hkv;
   const int T = p.T, Tp = p.Tp;
-  const int kw0 = blockIdx.x * 64 + wave * 16;
-  if (kw0 >= T) return;
+  const int kb0 = blockIdx.x * 64, kw0 = kb0 + wave * 16;
   const int key = kw0 + li;
-  const bool kok = key < T && (!p.kmask || p.kmask[(int64_t)b * Tp + key] != 0);
+  const bool kok = key < T && (!p.kmask || p.kmask[(int64_t)b * Tp + min(key, Tp - 1)] != 0);
 
   frag_t kf[KD], vf[KD];
 #pragma unroll
@@ -405,60 +474,110 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
     dv[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
   const float sl2 = p.scale * LOG2E;
-  const int qstart = CAUSAL ? (kw0 / 32) * 32 : 0;
+  const int qstart = CAUSAL ? (kb0 / 32) * 32 : 0;
+  const int nq = (T - qstart + 31) / 32;  // kb0 < T always holds for launched blocks
+  const int ntiles = G * nq;
 
-  for (int hh = 0; hh < G; hh++) {
+  frag_t qreg[NQ], doreg[NQ], qtreg[NQT], dotreg[NQT];
+  auto gload = [&](int it) {
+    const int hh = it / nq, q0 = qstart + (it - hh * nq) * 32;
     const int h = hk * G + hh;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+      const int item = tid + i * 256;
+      const int row = item / KCH, c = item % KCH;
+      const int q = q0 + row;
+      const bool ok = q < T;
+      qreg[i] = ok ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * T + q) * p.ldq + h * D + c * 8) : zero_frag();
+      doreg[i] = ok ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * T + q) * p.lddo + h * D + c * 8) : zero_frag();
+    }
+    const int64_t tb = ((int64_t)(b * p.Hq + h) * D) * Tp + q0;
+#pragma unroll
+    for (int i = 0; i < NQT; i++) {
+      const int item = tid + i * 256;
+      const int d = item >> 2, c = item & 3;
+      qtreg[i] = *reinterpret_cast<const frag_t*>(p.Qt + tb + (int64_t)d * Tp + c * 8);
+      dotreg[i] = *reinterpret_cast<const frag_t*>(p.dOt + tb + (int64_t)d * Tp + c * 8);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+      const int item = tid + i * 256;
+      const int row = item / KCH, c = item % KCH;
+      const int off = row * ROWB + ((c ^ (row & KCM)) << 4);
+      *reinterpret_cast<frag_t*>(ldsQ + off) = qreg[i];
+      *reinterpret_cast<frag_t*>(ldsDO + off) = doreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NQT; i++) {
+      const int item = tid + i * 256;
+      const int d = item >> 2, c = item & 3;
+      const int off = d * 64 + ((c ^ ((d >> 2) & 3)) << 4);
+      *reinterpret_cast<frag_t*>(ldsQt + off) = qtreg[i];
+      *reinterpret_cast<frag_t*>(ldsDOt + off) = dotreg[i];
+    }
+  };
+
+  if (ntiles > 0) gload(0);
+  for (int it = 0; it < ntiles; it++) {
+    const int hh = it / nq, q0 = qstart + (it - hh * nq) * 32;
+    const int h = hk * G + hh;
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (it + 1 < ntiles) gload(it + 1);
+    if (kw0 >= T || (CAUSAL && q0 + 31 < kw0)) continue;
+
     const float* lsep = p.LSE + ((int64_t)b * p.Hq + h) * Tp;
     const float* delp = p.Delta + ((int64_t)b * p.Hq + h) * Tp;
-    const bf16_t* qtb = p.Qt + ((int64_t)(b * p.Hq + h) * D) * Tp;
-    const bf16_t* dotb = p.dOt + ((int64_t)(b * p.Hq + h) * D) * Tp;
-    for (int q0 = qstart; q0 < T; q0 += 32) {
-      f32x4_t s[2], dp[2];
+    f32x4_t s[2], dp[2];
 #pragma unroll
-      for (int f = 0; f < 2; f++) {
-        const int q = q0 + f * 16 + li;
-        const bool qin = q < T;
-        f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f}, c = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < 2; f++) {
+      const int row = f * 16 + li;
+      f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f}, c = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kd = 0; kd < KD; kd++) {
-          const frag_t qfr = qin ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * T + q) * p.ldq + h * D + kd * 32 + g * 8) : zero_frag();
-          const frag_t dfr = qin ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * T + q) * p.lddo + h * D + kd * 32 + g * 8) : zero_frag();
-          a = mfma16(qfr, kf[kd], a);
-          c = mfma16(dfr, vf[kd], c);
-        }
-        s[f] = a;
-        dp[f] = c;
+      for (int kd = 0; kd < KD; kd++) {
+        const int off = row * ROWB + (((kd * 4 + g) ^ (row & KCM)) << 4);
+        const frag_t qfr = *reinterpret_cast<const frag_t*>(ldsQ + off);
+        const frag_t dfr = *reinterpret_cast<const frag_t*>(ldsDO + off);
+        a = mfma16(qfr, kf[kd], a);
+        c = mfma16(dfr, vf[kd], c);
       }
-      f32x4_t pm[2], ds[2];
+      s[f] = a;
+      dp[f] = c;
+    }
+    f32x4_t pm[2], ds[2];
 #pragma unroll
-      for (int f = 0; f < 2; f++) {
-        const int qb = q0 + f * 16 + 4 * g;
-        const float4 l4 = *reinterpret_cast<const float4*>(lsep + qb);
-        const float4 d4 = *reinterpret_cast<const float4*>(delp + qb);
-        const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
-        const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
+    for (int f = 0; f < 2; f++) {
+      const int qb = q0 + f * 16 + 4 * g;
+      const float4 l4 = *reinterpret_cast<const float4*>(lsep + qb);
+      const float4 d4 = *reinterpret_cast<const float4*>(delp + qb);
+      const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+      const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int q = qb + r;
-          const bool ok = kok && q < T && (!CAUSAL || key <= q);
-          const float pv = ok ? exp2f(s[f][r] * sl2 - ls[r] * LOG2E) : 0.f;
-          pm[f][r] = pv;
-          ds[f][r] = ok ? pv * (dp[f][r] - dl[r]) * p.scale : 0.f;
-        }
+      for (int r = 0; r < 4; r++) {
+        const int q = qb + r;
+        const bool ok = kok && q < T && (!CAUSAL || key <= q);
+        const float pv = ok ? fast_exp2(s[f][r] * sl2 - ls[r] * LOG2E) : 0.f;
+        pm[f][r] = pv;
+        ds[f][r] = ok ? pv * (dp[f][r] - dl[r]) * p.scale : 0.f;
       }
-      const frag_t pb = pack_frag(pm[0], pm[1]);
-      const frag_t dsb = pack_frag(ds[0], ds[1]);
+    }
+    const frag_t pb = pack_frag(pm[0], pm[1]);
+    const frag_t dsb = pack_frag(ds[0], ds[1]);
 #pragma unroll
-      for (int df = 0; df < DF; df++) {
-        const int64_t off = (int64_t)(df * 16 + li) * Tp + q0 + 4 * g;
-        const u16x4_t dlo = *reinterpret_cast<const u16x4_t*>(dotb + off);
-        const u16x4_t dhi = *reinterpret_cast<const u16x4_t*>(dotb + off + 16);
-        dv[df] = mfma16(join_frag(dlo, dhi), pb, dv[df]);
-        const u16x4_t qlo = *reinterpret_cast<const u16x4_t*>(qtb + off);
-        const u16x4_t qhi = *reinterpret_cast<const u16x4_t*>(qtb + off + 16);
-        dk[df] = mfma16(join_frag(qlo, qhi), dsb, dk[df]);
-      }
+    for (int df = 0; df < DF; df++) {
+      const int d = df * 16 + li;
+      const int sw = (d >> 2) & 3;
+      const int olo = d * 64 + (((g >> 1) ^ sw) << 4) + (g & 1) * 8;
+      const int ohi = d * 64 + (((2 + (g >> 1)) ^ sw) << 4) + (g & 1) * 8;
+      const u16x4_t dlo = *reinterpret_cast<const u16x4_t*>(ldsDOt + olo);
+      const u16x4_t dhi = *reinterpret_cast<const u16x4_t*>(ldsDOt + ohi);
+      dv[df] = mfma16(join_frag(dlo, dhi), pb, dv[df]);
+      const u16x4_t qlo = *reinterpret_cast<const u16x4_t*>(ldsQt + olo);
+      const u16x4_t qhi = *reinterpret_cast<const u16x4_t*>(ldsQt + ohi);
+      dk[df] = mfma16(join_frag(qlo, qhi), dsb, dk[df]);
     }
   }
   if (key >= T) return;

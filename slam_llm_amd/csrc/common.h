@@ -43,8 +43,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+// two floats -> packed bf16x2 with the hardware converter (v_cvt_pk_bf16_f32 on gfx950, round-to-nearest-even)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  bf16x2_t v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
 }
 
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------

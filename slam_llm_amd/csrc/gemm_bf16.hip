@@ -48,8 +48,17 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// exact-erf GELU.  erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16 output rounding):
+// one v_exp + one v_rcp + a 5-term Horner instead of libm's branchy erff in the epilogue of every fc1 tile.
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = 1.0f - poly * t * __expf(-z * z);  // erf(|x|/sqrt2)
+  return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
 template <int FM, int FN, int WTM, int WTN>
