@@ -110,6 +110,13 @@ int slam_colsum_bf16(const void* x, int64_t ldx, float* out, int64_t M, int64_t 
 int slam_lora_pack_b(const float* B, float scale, void* dst, int64_t ld_dst, void* dstT, int64_t ld_dstT,
                      int64_t rows, int64_t r, void* stream);
 
+/* LoRA gradients (peft Linear backward): out[r*ld_r + c*ld_c] (+)= alpha * sum_m S[m,r] * X[m,c];
+ * S [M,R] bf16 (R in 8|16|32|64), X [M,C] bf16, out fp32; workspace: slam_skinny_gram_workspace_bytes(M,R,C). */
+int64_t slam_skinny_gram_workspace_bytes(int64_t M, int64_t R, int64_t C);
+int slam_skinny_gram(const void* S, int64_t lds, const void* X, int64_t ldx, float* out, int64_t out_ld_r,
+                     int64_t out_ld_c, int64_t M, int64_t R, int64_t C, float alpha, int accumulate,
+                     float* workspace, void* stream);
+
 /* ---- embed + audio splice (src/slam_llm/models/slam_model.py:370-392) and its backward --------------
  * input_ids int64 [B,T] (-1 -> 0 in place), modality_mask uint8 [B,T], enc = projector output [B,Ta,ldenc],
  * out [B*T, ldo]; spans int32 [B,2] (start,len) is produced by fwd and consumed by bwd. No host sync. */

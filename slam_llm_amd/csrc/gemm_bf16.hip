@@ -283,7 +283,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
   auto stage = [&](int kt, int s) {
     char* sa = smem + s * STAGE;
     char* sb = sa + BM * ROWB;
-    const int koff = kt * BK;
+    const int koff = (VAR == 9) ? 0 : kt * BK;
 #pragma unroll
     for (int j = 0; j < NIA; j++) glds16(a_src[j] + koff, sa + (j * NW + wave) * 1024);
 #pragma unroll
@@ -398,7 +398,7 @@ int g_gemm_cfg = 0;  // 0 = auto
 }  // namespace
 
 extern "C" int slam_gemm_set_config(int cfg) {
-  SLAM_CHECK_ARG(cfg >= 0 && cfg <= 7, "slam_gemm_set_config: cfg %d out of range [0,7]", cfg);
+  SLAM_CHECK_ARG(cfg >= 0 && cfg <= 8, "slam_gemm_set_config: cfg %d out of range [0,8]", cfg);
   g_gemm_cfg = cfg;
   return 0;
 }
@@ -448,6 +448,7 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     case 5: return launch_gemm<256, 256, 2, 4, 0>(p, s);
     case 6: return launch_gemm<256, 256, 2, 4, 1>(p, s);
     case 7: return launch_gemm<256, 256, 4, 2, 0>(p, s);
+    case 8: return launch_gemm<256, 256, 2, 4, 9>(p, s);  // timing experiment only (wrong results by design)
   }
   slam_set_error("slam_gemm_bf16_nt: bad config %d", cfg);
   return -1;

@@ -233,3 +233,118 @@ extern "C" int slam_adamw_step(float* param, const float* grad, float* exp_avg, 
   SLAM_CHECK_LAUNCH("slam_adamw_step");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Tall-skinny gram product for the LoRA gradients (peft Linear backward: dA = (dy.sB)^T x, dB = s dy^T (xA^T)):
+//   out[r, c] (+)= alpha * sum_m S[m, r] * X[m, c]       S: [M, R] bf16 with R in {8,16,32,64},  X: [M, C] bf16
+// The reduction runs over the token dimension M (~12 k) while R is tiny, so this is an HBM-bound stream over X,
+// not an MFMA problem: lane = 8 consecutive columns of X (16-byte loads), wave w = R/4 rows of the output, fp32
+// FMA accumulation; M is split over gridDim.y and the partials are reduced in a fixed order by a second kernel
+// (bit-reproducible gradients).  Replaces three bf16 transposes + three starved-grid GEMMs per adapted projection.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <int RW>
+__global__ __launch_bounds__(256) void skinny_gram_kernel(const bf16_t* __restrict__ S, int64_t lds_,
+                                                          const bf16_t* __restrict__ X, int64_t ldx,
+                                                          float* __restrict__ ws, int M, int R, int C,
+                                                          int rows_per_split) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 512 + lane * 8;
+  const int r0 = wave * RW;
+  const int m0 = blockIdx.y * rows_per_split;
+  const int m1 = min(M, m0 + rows_per_split);
+  float acc[RW][8];
+#pragma unroll
+  for (int i = 0; i < RW; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[i][e] = 0.f;
+  if (c0 < C) {
+    typedef __attribute__((ext_vector_type(RW))) unsigned short svec_t;  // RW bf16 of S in one load
+    constexpr int U = 4;                                                 // rows in flight per iteration
+    int m = m0;
+    for (; m + U <= m1; m += U) {
+      u16x8_t xv[U];
+      svec_t sv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        xv[u] = *reinterpret_cast<const u16x8_t*>(X + (int64_t)(m + u) * ldx + c0);
+        sv[u] = *reinterpret_cast<const svec_t*>(S + (int64_t)(m + u) * lds_ + r0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        float xf[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) xf[e] = bf2f(xv[u][e]);
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+          const float sf = bf2f(sv[u][i]);
+#pragma unroll
+          for (int e = 0; e < 8; e++) acc[i][e] = fmaf(sf, xf[e], acc[i][e]);
+        }
+      }
+    }
+    for (; m < m1; m++) {
+      const u16x8_t xv = *reinterpret_cast<const u16x8_t*>(X + (int64_t)m * ldx + c0);
+      const svec_t sv = *reinterpret_cast<const svec_t*>(S + (int64_t)m * lds_ + r0);
+#pragma unroll
+      for (int i = 0; i < RW; i++) {
+        const float sf = bf2f(sv[i]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[i][e] = fmaf(sf, bf2f(xv[e]), acc[i][e]);
+      }
+    }
+    float* w = ws + ((int64_t)blockIdx.y * R + r0) * C + c0;
+#pragma unroll
+    for (int i = 0; i < RW; i++) {
+      *reinterpret_cast<float4*>(w + (int64_t)i * C) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+      *reinterpret_cast<float4*>(w + (int64_t)i * C + 4) = make_float4(acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void skinny_gram_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                                 int64_t ld_r, int64_t ld_c, int R, int C, int nsplit,
+                                                                 float alpha, int accumulate) {
+  const int64_t total = (int64_t)R * C;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; k++) s += ws[(int64_t)k * total + i];
+    const int r = (int)(i / C), c = (int)(i % C);
+    float* o = out + r * ld_r + c * ld_c;
+    *o = accumulate ? (*o + alpha * s) : alpha * s;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t slam_skinny_gram_workspace_bytes(int64_t M, int64_t R, int64_t C) {
+  const int64_t nsplit = (M + 127) / 128;
+  return nsplit * R * C * (int64_t)sizeof(float);
+}
+
+extern "C" int slam_skinny_gram(const void* S, int64_t lds_, const void* X, int64_t ldx, float* out,
+                                int64_t out_ld_r, int64_t out_ld_c, int64_t M, int64_t R, int64_t C, float alpha,
+                                int accumulate, float* workspace, void* stream) {
+  SLAM_CHECK_ARG(S && X && out && workspace, "slam_skinny_gram: null pointer");
+  SLAM_CHECK_ARG(R == 8 || R == 16 || R == 32 || R == 64, "slam_skinny_gram: R=%ld must be 8, 16, 32 or 64", (long)R);
+  SLAM_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0, "slam_skinny_gram: C and ldx must be multiples of 8");
+  SLAM_CHECK_ARG(lds_ % (R / 4) == 0 && ((uintptr_t)S % (R / 2)) == 0, "slam_skinny_gram: S must be aligned to R/4 elements (vector loads)");
+  SLAM_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)workspace % 16) == 0, "slam_skinny_gram: X/workspace must be 16-byte aligned");
+  const int rows_per_split = 128;
+  const int nsplit = (int)((M + rows_per_split - 1) / rows_per_split);
+  dim3 grid((unsigned)cdiv64(C, 512), (unsigned)nsplit);
+  hipStream_t s = (hipStream_t)stream;
+  switch (R) {
+    case 8: hipLaunchKernelGGL(skinny_gram_kernel<2>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split); break;
+    case 16: hipLaunchKernelGGL(skinny_gram_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split); break;
+    case 32: hipLaunchKernelGGL(skinny_gram_kernel<8>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split); break;
+    default: hipLaunchKernelGGL(skinny_gram_kernel<16>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split); break;
+  }
+  int64_t g = cdiv64(R * C, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(skinny_gram_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, workspace, out, out_ld_r, out_ld_c,
+                     (int)R, (int)C, nsplit, alpha, accumulate);
+  SLAM_CHECK_LAUNCH("slam_skinny_gram");
+  return 0;
+}

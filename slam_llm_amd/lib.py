@@ -43,6 +43,8 @@ SIGNATURES = {
     "slam_swiglu_bwd": [P, I64, P, I64, P, I64, I64, I64, P],
     "slam_relu_bwd": [P, I64, P, I64, I64, I64, P],
     "slam_colsum_bf16": [P, I64, P, I64, I64, I32, P],
+    "slam_skinny_gram_workspace_bytes": [I64, I64, I64],
+    "slam_skinny_gram": [P, I64, P, I64, P, I64, I64, I64, I64, I64, F, I32, P, P],
     "slam_lora_pack_b": [P, F, P, I64, P, I64, I64, I64, P],
     "slam_embed_splice_fwd": [P, P, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P],
     "slam_embed_splice_bwd": [P, P, I64, P, I64, I64, I64, I64, I64, P],
@@ -72,7 +74,7 @@ def _load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so and the header ever diverge
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_int64 if name.endswith("_workspace_bytes") else c_int
     return lib
 
 
@@ -91,7 +93,7 @@ def last_error() -> str:
 def call(name: str, *args) -> int:
     """Invoke a C-ABI entry point; raise SlamHipError on a non-zero return code."""
     rc = getattr(_lib, name)(*args)
-    if name == "slam_logmel_workspace_bytes":
+    if name in ("slam_logmel_workspace_bytes", "slam_skinny_gram_workspace_bytes"):
         return rc
     if rc != 0:
         raise SlamHipError(f"{name} failed (rc={rc}): {last_error()}")

@@ -197,17 +197,15 @@ class FusedLinear:
         if self.adapters:
             # x_ext = [x | u] with u = x A^T: the columns [K:] of dx_ext are dL/du, and dL/dx gets the second hop
             ops.gemm_nt(dx_ext[:, self.K:], self.AcatT, out=dx_ext[:, : self.K], accumulate=True)
-            M = dy.shape[0]
-            Mp = round_up(M, 64)
-            K, sr = self.K, self.sum_r
-            xT = ops.transpose(x_ext[:, :K], Rp=Mp)
-            duT = ops.transpose(dx_ext[:, K: K + self.Rp], Rp=Mp)
-            uT = ops.transpose(x_ext[:, K: K + self.Rp], Rp=Mp)
-            ops.gemm_nt(duT[:sr], xT, out=self.a_cat_grad(store), accumulate=accumulate)
+            K = self.K
             for a in self.adapters:
-                dyT = ops.transpose(dy[:, a["row0"]: a["row0"] + a["rows"]], Rp=Mp)
-                ops.gemm_nt(dyT, uT[a["j0"]: a["j0"] + a["r"]], out=store.grad_view(a["B"]), alpha=a["scale"],
-                            accumulate=accumulate)
+                r = a["r"]
+                du = dx_ext[:, K + a["j0"]: K + a["j0"] + r]          # dL/d(xA^T)  [M, r]
+                u = x_ext[:, K + a["j0"]: K + a["j0"] + r]            # xA^T        [M, r]
+                # dA[r, K] = du^T x ;  dB[rows, r] = (alpha/r) * dy[:, rows]^T u   (HBM-bound tall-skinny products)
+                ops.skinny_gram(du, x_ext[:, :K], store.grad_view(a["A"]), K, 1, accumulate=accumulate)
+                ops.skinny_gram(u, dy[:, a["row0"]: a["row0"] + a["rows"]], store.grad_view(a["B"]), 1, r,
+                                alpha=a["scale"], accumulate=accumulate)
         return dx_ext
 
 

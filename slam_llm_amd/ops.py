@@ -94,7 +94,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
 _GEMM_CFG = 0
 _GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
                4: "gemm_nt_kernel<256,256,2,4>", 5: "gemm_nt_pipe_kernel<256,256,2,4>",
-               6: "gemm_nt_pipe_kernel<256,256,2,4,v1>", 7: "gemm_nt_pipe_kernel<256,256,4,2>"}
+               6: "gemm_nt_pipe_kernel<256,256,2,4,v1>", 7: "gemm_nt_pipe_kernel<256,256,4,2>", 8: "gemm_nt_pipe_kernel<debug>"}
 
 
 def gemm_kernel_name(M: int, N: int) -> str:
@@ -345,3 +345,21 @@ def colsum(x2d, out_f32, accumulate=False):
     M, N = x2d.shape
     call("slam_colsum_bf16", _p(x2d), _ld(x2d), _p(out_f32), M, N, 1 if accumulate else 0, _s())
     return out_f32
+
+
+_GRAM_WS = {}
+
+
+def skinny_gram(S2d, X2d, out, out_ld_r, out_ld_c, alpha=1.0, accumulate=False):
+    """out[r*ld_r + c*ld_c] (+)= alpha * sum_m S[m,r] X[m,c]   (LoRA dA / dB); out is an fp32 tensor (any view)"""
+    M, R = S2d.shape
+    M2, C = X2d.shape
+    assert M == M2
+    nbytes = call("slam_skinny_gram_workspace_bytes", M, R, C)
+    key = (str(S2d.device), nbytes)
+    if key not in _GRAM_WS:
+        _GRAM_WS.clear()
+        _GRAM_WS[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=S2d.device)
+    call("slam_skinny_gram", _p(S2d), _ld(S2d), _p(X2d), _ld(X2d), _p(out), out_ld_r, out_ld_c, M, R, C, alpha,
+         1 if accumulate else 0, _p(_GRAM_WS[key]), _s())
+    return out
