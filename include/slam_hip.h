@@ -61,10 +61,17 @@ int slam_gemm_set_config(int cfg);
 int slam_conv1d_k3_im2col(const void* in, int in_dtype, void* out, int64_t B, int64_t Tin, int64_t C,
                           int64_t stride, int64_t Kp, void* stream);
 
+/* general conv1d im2col (HuBERT/WavLM feature encoder and grouped positional conv, models/slam_model.py:335-341):
+ * rows (b*Tin+t) with stride ld_in, channel slice [c0, c0+C) -> out [B*Tout, Kp] bf16, col = j*C + c. */
+int slam_conv1d_im2col(const void* in, int in_dtype, int64_t ld_in, int64_t c0, int64_t C, void* out, int64_t B,
+                       int64_t Tin, int64_t k, int64_t stride, int64_t pad, int64_t Kp, int64_t Tout_limit,
+                       void* stream);
+
 /* ---- norms -------------------------------------------------------------------------------------
  * LayerNorm (Whisper blocks + ln_post, encoder.py:26-29; fp32 statistics), RMSNorm fwd/bwd (Llama). */
+/* act: 0 none, 1 exact GELU fused after the affine (HuBERT feature-encoder LayerNorm+GELU) */
 int slam_layernorm_fwd(const void* x, int64_t ldx, const float* weight, const float* bias, void* y,
-                       int64_t ldy, int64_t M, int64_t d, float eps, void* stream);
+                       int64_t ldy, int64_t M, int64_t d, float eps, int act, void* stream);
 int slam_rmsnorm_fwd(const void* x, int64_t ldx, const float* weight, void* y, int64_t ldy, float* rstd,
                      int64_t M, int64_t d, float eps, void* stream);
 /* dx = rmsnorm'(dy) * (*grad_scale or 1) + dres (nullable) */

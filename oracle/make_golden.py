@@ -249,7 +249,7 @@ def gen_step(name, cfg, clip_seconds, answer_lens, n_steps=3, left_pad=True):
     print(name + ".npz written")
 
 
-from oracle.make_golden_cases import CASES  # noqa: E402
+from oracle.make_golden_cases import CASES, HUBERT_TINY  # noqa: E402
 
 def gen_batcher():
     """Run the reference's own window_class + MultiTaskDynamicBatchDataset (speech_dataset_large.py:235-263).
@@ -291,9 +291,45 @@ def gen_batcher():
     print("batcher.npz written")
 
 
+def gen_hubert():
+    """HF HubertModel (the runnable twin of fairseq's HuBERT, which is not installed) on a tiny config."""
+    from transformers import HubertConfig, HubertModel
+    cfg = HUBERT_TINY
+    hc = HubertConfig(hidden_size=cfg["hub_dim"], num_hidden_layers=cfg["hub_layers"], num_attention_heads=cfg["hub_heads"],
+                      intermediate_size=cfg["hub_ffn"], conv_dim=list(cfg["hub_conv_dim"]), conv_kernel=list(cfg["hub_conv_kernel"]),
+                      conv_stride=list(cfg["hub_conv_stride"]), conv_bias=True, feat_extract_norm="layer",
+                      do_stable_layer_norm=True, feat_proj_layer_norm=True, num_conv_pos_embeddings=cfg["hub_pos_k"],
+                      num_conv_pos_embedding_groups=cfg["hub_pos_groups"], hidden_dropout=0.0, attention_dropout=0.0,
+                      activation_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0, mask_time_prob=0.0, mask_feature_prob=0.0,
+                      layer_norm_eps=cfg["hub_eps"], hidden_act="gelu", feat_extract_activation="gelu")
+    hc._attn_implementation = "eager"
+    m = HubertModel(hc).eval()
+    W = O.init_hubert_weights(cfg, seed=7)
+    sd = m.state_dict()
+    with torch.no_grad():
+        for k in sd:
+            if "pos_conv_embed.conv.parametrizations" in k or k == "masked_spec_embed":
+                continue
+            sd[k].copy_(W["encoder." + k])
+        # weight-norm parametrisation (dim=2): set v = w and g = ||w|| so that the effective weight equals ours
+        w = W["encoder.encoder.pos_conv_embed.conv.weight"]
+        sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"].copy_(w)
+        sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"].copy_(w.norm(dim=(0, 1), keepdim=True))
+    m.load_state_dict(sd)
+    wav = O.synth_audio(2, 1.0, seed=4321)
+    wav = torch.nn.functional.layer_norm(wav, (wav.shape[1],))  # dataset `normalize` (speech_dataset.py:96-97)
+    with torch.no_grad():
+        out = m(wav).last_hidden_state
+    fx = {"wav": wav.numpy(), "weights_sha256": np.array(wsum(W)), "out_shape": np.array(out.shape)}
+    pack(fx, "out", out.numpy(), limit=65536)
+    np.savez_compressed(os.path.join(GOLD, "hubert_tiny.npz"), **fx)
+    print("hubert_tiny.npz written", tuple(out.shape))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     gen_mel()
     gen_batcher()
+    gen_hubert()
     for nme, c in CASES.items():
         gen_step(nme, **c)

@@ -10,3 +10,7 @@ CASES = {
                                          lora_alpha=32, lora_targets=("q_proj", "k_proj", "v_proj", "o_proj")),
                        clip_seconds=3.0, answer_lens=(7, 3, 11), left_pad=False),
 }
+
+# HuBERT-style encoder (a11): same structure as hubert-large, narrow widths (conv 64 ch, d 128, pos-conv k 16 / 4 groups)
+HUBERT_TINY = O.hubert_config(hub_conv_dim=(64,) * 7, hub_dim=128, hub_heads=2, hub_layers=2, hub_ffn=256, hub_pos_k=16,
+                              hub_pos_groups=4)

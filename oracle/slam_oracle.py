@@ -121,6 +121,95 @@ def whisper_encoder(W: Dict[str, torch.Tensor], cfg: dict, mel_bct: torch.Tensor
     return _ln(x, W[prefix + "ln_post.weight"], W[prefix + "ln_post.bias"])
 
 
+
+# ---------------------------------------------------------------------------------------------- a11: HuBERT encoder
+def hubert_config(**kw) -> dict:
+    """HuBERT-large geometry (fairseq hubert_large / HF HubertConfig: feat_extract_norm="layer",
+    do_stable_layer_norm=True, conv_bias=True); tests shrink the widths, not the structure."""
+    c = dict(hub_conv_dim=(512,) * 7, hub_conv_kernel=(10, 3, 3, 3, 3, 2, 2), hub_conv_stride=(5, 2, 2, 2, 2, 2, 2),
+             hub_dim=1024, hub_heads=16, hub_layers=24, hub_ffn=4096, hub_pos_k=128, hub_pos_groups=16, hub_eps=1e-5)
+    c.update(kw)
+    return c
+
+
+def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, prefix="encoder.") -> torch.Tensor:
+    """The HuBERT branch of slam_model.forward (src/slam_llm/models/slam_model.py:335-341: fairseq
+    `self.encoder(source=audio, padding_mask=...)["encoder_out"]`), restated from the HF twin of fairseq's model
+    (transformers/models/hubert/modeling_hubert.py: HubertFeatureEncoder with LayerNorm conv layers :127-151,
+    HubertFeatureProjection :216-233, HubertPositionalConvEmbedding :45-93 (weight-norm folded into the weight),
+    HubertEncoderStableLayerNorm :550-625).  Equal-length, unpadded batches only (mask = None).
+    wav [B, N] (already layer-normed by the dataset, speech_dataset.py:96-97) -> [B, T', hub_dim]."""
+    x = wav[:, None, :]
+    for i, (k, st) in enumerate(zip(cfg["hub_conv_kernel"], cfg["hub_conv_stride"])):
+        p = f"{prefix}feature_extractor.conv_layers.{i}."
+        x = F.conv1d(x, W[p + "conv.weight"], W[p + "conv.bias"], stride=st)
+        x = F.layer_norm(x.transpose(-2, -1), (x.shape[1],), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5)
+        x = F.gelu(x.transpose(-2, -1))
+    x = x.transpose(1, 2)  # [B, T', C]
+    eps = cfg["hub_eps"]
+    p = prefix + "feature_projection."
+    x = F.layer_norm(x, (x.shape[-1],), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], eps)
+    x = F.linear(x, W[p + "projection.weight"], W[p + "projection.bias"])
+    p = prefix + "encoder."
+    kpos = cfg["hub_pos_k"]
+    pos = F.conv1d(x.transpose(1, 2), W[p + "pos_conv_embed.conv.weight"], W[p + "pos_conv_embed.conv.bias"],
+                   padding=kpos // 2, groups=cfg["hub_pos_groups"])
+    if kpos % 2 == 0:
+        pos = pos[:, :, :-1]
+    x = x + F.gelu(pos).transpose(1, 2)
+    B, T, d = x.shape
+    H = cfg["hub_heads"]
+    hd = d // H
+    for i in range(cfg["hub_layers"]):
+        q_ = f"{p}layers.{i}."
+        h = F.layer_norm(x, (d,), W[q_ + "layer_norm.weight"], W[q_ + "layer_norm.bias"], eps)
+        q = F.linear(h, W[q_ + "attention.q_proj.weight"], W[q_ + "attention.q_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
+        k = F.linear(h, W[q_ + "attention.k_proj.weight"], W[q_ + "attention.k_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
+        v = F.linear(h, W[q_ + "attention.v_proj.weight"], W[q_ + "attention.v_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
+        a = F.softmax((q @ k.transpose(2, 3)) * hd ** -0.5, dim=-1) @ v
+        a = a.transpose(1, 2).reshape(B, T, d)
+        x = x + F.linear(a, W[q_ + "attention.out_proj.weight"], W[q_ + "attention.out_proj.bias"])
+        h = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], eps)
+        h = F.linear(F.gelu(F.linear(h, W[q_ + "feed_forward.intermediate_dense.weight"], W[q_ + "feed_forward.intermediate_dense.bias"])),
+                     W[q_ + "feed_forward.output_dense.weight"], W[q_ + "feed_forward.output_dense.bias"])
+        x = x + h
+    return F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], eps)
+
+
+def init_hubert_weights(cfg: dict, seed: int = 7, prefix="encoder.") -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, std=0.02):
+        return torch.randn(*shape, generator=g) * std
+
+    W = {}
+    cin = 1
+    for i, (co, k) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"])):
+        p = f"{prefix}feature_extractor.conv_layers.{i}."
+        W[p + "conv.weight"] = rn(co, cin, k, std=(1.0 / (cin * k)) ** 0.5)
+        W[p + "conv.bias"] = rn(co)
+        W[p + "layer_norm.weight"] = 1 + rn(co, std=0.1)
+        W[p + "layer_norm.bias"] = rn(co, std=0.1)
+        cin = co
+    d, ffn = cfg["hub_dim"], cfg["hub_ffn"]
+    p = prefix + "feature_projection."
+    W[p + "layer_norm.weight"], W[p + "layer_norm.bias"] = 1 + rn(cin, std=0.1), rn(cin, std=0.1)
+    W[p + "projection.weight"], W[p + "projection.bias"] = rn(d, cin, std=cin ** -0.5), rn(d)
+    p = prefix + "encoder."
+    gch = d // cfg["hub_pos_groups"]
+    W[p + "pos_conv_embed.conv.weight"] = rn(d, gch, cfg["hub_pos_k"], std=(1.0 / (gch * cfg["hub_pos_k"])) ** 0.5)
+    W[p + "pos_conv_embed.conv.bias"] = rn(d)
+    for i in range(cfg["hub_layers"]):
+        q_ = f"{p}layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            W[q_ + f"attention.{n}.weight"], W[q_ + f"attention.{n}.bias"] = rn(d, d, std=d ** -0.5), rn(d)
+        W[q_ + "layer_norm.weight"], W[q_ + "layer_norm.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+        W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+        W[q_ + "feed_forward.intermediate_dense.weight"], W[q_ + "feed_forward.intermediate_dense.bias"] = rn(ffn, d, std=d ** -0.5), rn(ffn)
+        W[q_ + "feed_forward.output_dense.weight"], W[q_ + "feed_forward.output_dense.bias"] = rn(d, ffn, std=ffn ** -0.5), rn(d)
+    W[p + "layer_norm.weight"], W[p + "layer_norm.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+    return W
+
 # ---------------------------------------------------------------------------------------------- a3: projector
 def projector_concat(W, x: torch.Tensor, k: int, prefix="encoder_projector.") -> torch.Tensor:
     """EncoderProjectorConcat.forward, src/slam_llm/models/projector.py:15-27."""

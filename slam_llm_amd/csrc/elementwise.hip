@@ -183,6 +183,59 @@ __global__ __launch_bounds__(256) void im2col_k3_kernel(const TIN* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// general conv1d im2col (HuBERT feature encoder k=10/3/2, stride 5/2, no padding; positional conv k=128, groups=16:
+// fairseq/HF HubertModel reached from src/slam_llm/models/slam_model.py:335-341; conv spec in-repo at
+// src/slam_llm/models/wavlm/WavLM.py:173,378-505).
+// in: rows (b*Tin + t) with row stride ld_in, channels [c0, c0+C) -> out [B*Tout, Kp], col = j*C + c, zero padded.
+// 16-byte path when the input is bf16 and C, c0, ld_in are multiples of 8.
+// ------------------------------------------------------------------------------------------
+template <typename TIN>
+__global__ __launch_bounds__(256) void im2col_gen_kernel(const TIN* __restrict__ in, int64_t ld_in, int c0,
+                                                         bf16_t* __restrict__ out, int B, int Tin, int Tout,
+                                                         int C, int Kp, int k, int stride, int pad) {
+  const int64_t total = (int64_t)B * Tout * Kp;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int col = (int)(i % Kp);
+    const int64_t row = i / Kp;
+    const int t = (int)(row % Tout);
+    const int b = (int)(row / Tout);
+    float v = 0.f;
+    if (col < k * C) {
+      const int j = col / C, c = col % C;
+      const int ti = t * stride + j - pad;
+      if (ti >= 0 && ti < Tin) {
+        const TIN x = in[((int64_t)b * Tin + ti) * ld_in + c0 + c];
+        if constexpr (sizeof(TIN) == 4) v = x; else v = bf2f(x);
+      }
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void im2col_vec_kernel(const bf16_t* __restrict__ in, int64_t ld_in, int c0,
+                                                         bf16_t* __restrict__ out, int B, int Tin, int Tout,
+                                                         int C, int Kp, int k, int stride, int pad) {
+  const int kpc = Kp >> 3, cc = C >> 3;
+  const int64_t total = (int64_t)B * Tout * kpc;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % kpc);
+    const int64_t row = i / kpc;
+    const int t = (int)(row % Tout);
+    const int b = (int)(row / Tout);
+    u16x8_t v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = 0;
+    if (ch < k * cc) {
+      const int j = ch / cc, c8 = ch % cc;
+      const int ti = t * stride + j - pad;
+      if (ti >= 0 && ti < Tin)
+        v = *reinterpret_cast<const u16x8_t*>(in + ((int64_t)b * Tin + ti) * ld_in + c0 + c8 * 8);
+    }
+    *reinterpret_cast<u16x8_t*>(out + row * Kp + ch * 8) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // fp32 -> bf16 cast
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in,
@@ -494,5 +547,32 @@ extern "C" int slam_colsum_bf16(const void* x, int64_t ldx, float* out, int64_t 
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv64(N, 64)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, ldx, out, M, (int)N, accumulate);
   SLAM_CHECK_LAUNCH("slam_colsum_bf16");
+  return 0;
+}
+
+extern "C" int slam_conv1d_im2col(const void* in, int in_dtype, int64_t ld_in, int64_t c0, int64_t C, void* out,
+                                  int64_t B, int64_t Tin, int64_t k, int64_t stride, int64_t pad, int64_t Kp,
+                                  int64_t Tout_limit, void* stream) {
+  SLAM_CHECK_ARG(in && out, "slam_conv1d_im2col: null pointer");
+  SLAM_CHECK_ARG(B > 0 && Tin > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && c0 >= 0, "slam_conv1d_im2col: bad shape");
+  SLAM_CHECK_ARG(Kp >= k * C && Kp % 8 == 0, "slam_conv1d_im2col: Kp=%ld must be >= k*C=%ld and a multiple of 8", (long)Kp, (long)(k * C));
+  SLAM_CHECK_ARG(Tin + 2 * pad >= k, "slam_conv1d_im2col: input shorter than the kernel");
+  int64_t Tout = (Tin + 2 * pad - k) / stride + 1;
+  if (Tout_limit > 0 && Tout_limit < Tout) Tout = Tout_limit;  // e.g. even-kernel "same" padding drops the last frame
+  hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == SLAM_BF16 && C % 8 == 0 && c0 % 8 == 0 && ld_in % 8 == 0) {
+    hipLaunchKernelGGL(im2col_vec_kernel, dim3(ew_grid(B * Tout * (Kp / 8))), dim3(256), 0, s, (const bf16_t*)in, ld_in,
+                       (int)c0, (bf16_t*)out, (int)B, (int)Tin, (int)Tout, (int)C, (int)Kp, (int)k, (int)stride, (int)pad);
+  } else if (in_dtype == SLAM_BF16) {
+    hipLaunchKernelGGL(im2col_gen_kernel<bf16_t>, dim3(ew_grid(B * Tout * Kp)), dim3(256), 0, s, (const bf16_t*)in, ld_in,
+                       (int)c0, (bf16_t*)out, (int)B, (int)Tin, (int)Tout, (int)C, (int)Kp, (int)k, (int)stride, (int)pad);
+  } else if (in_dtype == SLAM_F32) {
+    hipLaunchKernelGGL(im2col_gen_kernel<float>, dim3(ew_grid(B * Tout * Kp)), dim3(256), 0, s, (const float*)in, ld_in,
+                       (int)c0, (bf16_t*)out, (int)B, (int)Tin, (int)Tout, (int)C, (int)Kp, (int)k, (int)stride, (int)pad);
+  } else {
+    slam_set_error("slam_conv1d_im2col: in_dtype %d unknown", in_dtype);
+    return -1;
+  }
+  SLAM_CHECK_LAUNCH("slam_conv1d_im2col");
   return 0;
 }

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b,
                                                         bf16_t* __restrict__ y, int64_t ldy, int M,
-                                                        int d, float eps) {
+                                                        int d, float eps, int act) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -51,7 +51,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
     u16x8_t o;
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = f2bf((bf2f(v[e]) - mean) * rstd * ww[e] + bb[e]);
+    for (int e = 0; e < 8; e++) {
+      float t = (bf2f(v[e]) - mean) * rstd * ww[e] + bb[e];
+      if (act == 1) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));  // exact GELU (HuBERT conv layers)
+      o[e] = f2bf(t);
+    }
     *reinterpret_cast<u16x8_t*>(yr + c * 8) = o;
   }
 }
@@ -142,13 +146,14 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(
 }  // namespace
 
 extern "C" int slam_layernorm_fwd(const void* x, int64_t ldx, const float* weight, const float* bias,
-                                  void* y, int64_t ldy, int64_t M, int64_t d, float eps, void* stream) {
+                                  void* y, int64_t ldy, int64_t M, int64_t d, float eps, int act, void* stream) {
+  SLAM_CHECK_ARG(act == 0 || act == 1, "slam_layernorm_fwd: act %d unknown (0 none, 1 gelu)", act);
   SLAM_CHECK_ARG(x && weight && bias && y, "slam_layernorm_fwd: null pointer");
   SLAM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0, "slam_layernorm_fwd: bad shape M=%ld d=%ld (d%%8 must be 0)", (long)M, (long)d);
   SLAM_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= d && ldy >= d, "slam_layernorm_fwd: bad leading dims");
   const unsigned grid = (unsigned)cdiv64(M, ROWS_PER_BLOCK);
   hipLaunchKernelGGL(layernorm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                     ldx, weight, bias, (bf16_t*)y, ldy, (int)M, (int)d, eps);
+                     ldx, weight, bias, (bf16_t*)y, ldy, (int)M, (int)d, eps, act);
   SLAM_CHECK_LAUNCH("slam_layernorm_fwd");
   return 0;
 }

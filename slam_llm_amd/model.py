@@ -314,6 +314,113 @@ class HipWhisperEncoder(nn.Module):
         return self.extract_variable_length_features(x)
 
 
+
+# ======================================================================================== hubert encoder
+class HipHubertEncoder(nn.Module):
+    """Frozen HuBERT encoder (fairseq HubertModel as called at src/slam_llm/models/slam_model.py:335-341;
+    architecture per its HF twin, transformers/models/hubert/modeling_hubert.py): 7 LayerNorm conv layers
+    (im2col + MFMA GEMM + fused LayerNorm-GELU), feature projection, grouped positional conv (one GEMM per group with
+    the GELU and the residual add fused in the epilogue), pre-LN transformer, final LayerNorm.  Inference-only.
+    Weights use the HF state-dict names under `encoder.` (fairseq -> HF renaming is HF's conversion script)."""
+
+    def __init__(self, cfg: dict, device):
+        super().__init__()
+        self.cfg, self.device_, self.w = cfg, device, {}
+
+    def load(self, W: Dict[str, torch.Tensor], prefix="encoder."):
+        cfg, dev, w = self.cfg, self.device_, self.w
+        bf = lambda t: t.to(device=dev, dtype=torch.bfloat16).contiguous()  # noqa: E731
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        cin = 1
+        for i, (co, k) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"])):
+            p = f"{prefix}feature_extractor.conv_layers.{i}."
+            kp = round_up(k * cin, 64)
+            wc = torch.zeros((co, kp), dtype=torch.bfloat16, device=dev)
+            wc[:, : k * cin] = bf(W[p + "conv.weight"].permute(0, 2, 1).reshape(co, k * cin))
+            w[f"c{i}"], w[f"c{i}_b"] = wc, f32(W[p + "conv.bias"])
+            w[f"c{i}_lw"], w[f"c{i}_lb"] = f32(W[p + "layer_norm.weight"]), f32(W[p + "layer_norm.bias"])
+            cin = co
+        d = cfg["hub_dim"]
+        assert d % 64 == 0 and d // cfg["hub_heads"] == 64 and cin % 64 == 0
+        p = prefix + "feature_projection."
+        w["fp_lw"], w["fp_lb"] = f32(W[p + "layer_norm.weight"]), f32(W[p + "layer_norm.bias"])
+        w["fp"], w["fp_b"] = bf(W[p + "projection.weight"]), f32(W[p + "projection.bias"])
+        p = prefix + "encoder."
+        key = p + "pos_conv_embed.conv.weight"
+        if key in W:
+            pw = W[key].float()
+        else:  # HF checkpoints keep the weight-norm parametrisation (dim=2): w = g * v / ||v||
+            g_, v_ = W[p + "pos_conv_embed.conv.parametrizations.weight.original0"].float(), W[p + "pos_conv_embed.conv.parametrizations.weight.original1"].float()
+            pw = g_ * v_ / v_.norm(dim=(0, 1), keepdim=True)
+        G, kpos = cfg["hub_pos_groups"], cfg["hub_pos_k"]
+        gch = d // G
+        self.pos_kp = round_up(kpos * gch, 64)
+        pg = torch.zeros((G, gch, self.pos_kp), dtype=torch.bfloat16, device=dev)
+        for g in range(G):
+            pg[g, :, : kpos * gch] = bf(pw[g * gch:(g + 1) * gch].permute(0, 2, 1).reshape(gch, kpos * gch))
+        w["pos"], w["pos_b"] = pg, f32(W[p + "pos_conv_embed.conv.bias"])
+        for i in range(cfg["hub_layers"]):
+            q = f"{p}layers.{i}."
+            w[f"{i}.qkv"] = bf(torch.cat([W[q + "attention.q_proj.weight"], W[q + "attention.k_proj.weight"], W[q + "attention.v_proj.weight"]], 0))
+            w[f"{i}.qkv_b"] = f32(torch.cat([W[q + "attention.q_proj.bias"], W[q + "attention.k_proj.bias"], W[q + "attention.v_proj.bias"]], 0))
+            w[f"{i}.out"], w[f"{i}.out_b"] = bf(W[q + "attention.out_proj.weight"]), f32(W[q + "attention.out_proj.bias"])
+            w[f"{i}.ln1_w"], w[f"{i}.ln1_b"] = f32(W[q + "layer_norm.weight"]), f32(W[q + "layer_norm.bias"])
+            w[f"{i}.fc1"], w[f"{i}.fc1_b"] = bf(W[q + "feed_forward.intermediate_dense.weight"]), f32(W[q + "feed_forward.intermediate_dense.bias"])
+            w[f"{i}.fc2"], w[f"{i}.fc2_b"] = bf(W[q + "feed_forward.output_dense.weight"]), f32(W[q + "feed_forward.output_dense.bias"])
+            w[f"{i}.ln2_w"], w[f"{i}.ln2_b"] = f32(W[q + "final_layer_norm.weight"]), f32(W[q + "final_layer_norm.bias"])
+        w["lnp_w"], w["lnp_b"] = f32(W[p + "layer_norm.weight"]), f32(W[p + "layer_norm.bias"])
+        return self
+
+    def out_frames(self, n: int) -> int:
+        for k, s_ in zip(self.cfg["hub_conv_kernel"], self.cfg["hub_conv_stride"]):
+            n = (n - k) // s_ + 1
+        return n
+
+    @torch.no_grad()
+    def forward_wav(self, wav: torch.Tensor) -> torch.Tensor:
+        """wav [B, N] f32 (already normalised by the dataset) -> [B, T', hub_dim] bf16"""
+        cfg, w = self.cfg, self.w
+        B, N = wav.shape
+        x2d, Tin, cin = wav.contiguous().view(B * N, 1), N, 1
+        for i, (co, k, st) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"], cfg["hub_conv_stride"])):
+            cols, Tout = ops.conv1d_im2col(x2d, B, Tin, 0, cin, k, st, 0, Kp=w[f"c{i}"].shape[1])
+            y = ops.gemm_nt(cols, w[f"c{i}"], bias=w[f"c{i}_b"])
+            del cols
+            x2d = ops.layernorm(y, w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5, out=y, gelu=True)
+            Tin, cin = Tout, co
+        T, d, H, eps = Tin, cfg["hub_dim"], cfg["hub_heads"], cfg["hub_eps"]
+        M = B * T
+        h = ops.layernorm(x2d, w["fp_lw"], w["fp_lb"], eps)
+        h = ops.gemm_nt(h, w["fp"], bias=w["fp_b"])
+        G, kpos = cfg["hub_pos_groups"], cfg["hub_pos_k"]
+        gch = d // G
+        x = torch.empty((M, d), dtype=torch.bfloat16, device=wav.device)
+        cols = torch.empty((M, self.pos_kp), dtype=torch.bfloat16, device=wav.device)
+        for g in range(G):  # grouped conv: x[:, grp] = h[:, grp] + gelu(conv_g(h[:, grp]) + b_g)
+            ops.conv1d_im2col(h, B, T, g * gch, gch, kpos, 1, kpos // 2, Kp=self.pos_kp, Tout_limit=T, out=cols)
+            ops.gemm_nt(cols, w["pos"][g], out=x[:, g * gch:(g + 1) * gch], bias=w["pos_b"][g * gch:(g + 1) * gch],
+                        act=ACT_GELU, residual=h[:, g * gch:(g + 1) * gch])
+        del cols, h
+        scale = 64 ** -0.5
+        hbuf = torch.empty((M, d), dtype=torch.bfloat16, device=wav.device)
+        qkv = torch.empty((M, 3 * d), dtype=torch.bfloat16, device=wav.device)
+        obuf = torch.empty((M, d), dtype=torch.bfloat16, device=wav.device)
+        fbuf = torch.empty((M, cfg["hub_ffn"]), dtype=torch.bfloat16, device=wav.device)
+        for i in range(cfg["hub_layers"]):
+            ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, out=hbuf)
+            ops.gemm_nt(hbuf, w[f"{i}.qkv"], out=qkv, bias=w[f"{i}.qkv_b"])
+            vt = ops.head_rope_transpose(qkv, 2 * d, B, T, H, 64)
+            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, want_lse=False, out=obuf)
+            ops.gemm_nt(obuf, w[f"{i}.out"], out=x, bias=w[f"{i}.out_b"], residual=x)
+            ops.layernorm(x, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], eps, out=hbuf)
+            ops.gemm_nt(hbuf, w[f"{i}.fc1"], out=fbuf, bias=w[f"{i}.fc1_b"], act=ACT_GELU)
+            ops.gemm_nt(fbuf, w[f"{i}.fc2"], out=x, bias=w[f"{i}.fc2_b"], residual=x)
+        out = ops.layernorm(x, w["lnp_w"], w["lnp_b"], eps)
+        return out.view(B, T, d)
+
+    def forward(self, source=None, padding_mask=None, **kw):
+        return {"encoder_out": self.forward_wav(source).transpose(0, 1), "padding_mask": None}
+
 # ======================================================================================== projector
 class HipProjectorConcat(nn.Module):
     """EncoderProjectorConcat (src/slam_llm/models/projector.py:5-27): k-frame stack, Linear-ReLU-Linear."""
@@ -609,7 +716,12 @@ class SlamHipModel(nn.Module):
         self.train_config, self.model_config = train_config, model_config
         self.metric = kwargs.get("metric", "acc")
         self.store = TrainableStore(self.device_)
-        self.encoder = HipWhisperEncoder(cfg, self.device_)
+        self.encoder_name = cfg.get("encoder_name", "whisper")
+        if self.encoder_name == "hubert":
+            self.encoder = HipHubertEncoder(cfg, self.device_)
+            cfg["enc_dim"] = cfg["hub_dim"]
+        else:
+            self.encoder = HipWhisperEncoder(cfg, self.device_)
         self.llm = HipLlamaLora(cfg, self.store, self.device_)          # reserves LoRA (last layer first)
         self.encoder_projector = HipProjectorConcat(cfg, self.store)    # projector last = produced last in backward
         self.store.allocate()
@@ -680,12 +792,21 @@ class SlamHipModel(nn.Module):
         train = torch.is_grad_enabled() and labels is not None
         stash = {} if train else None
 
-        if audio_mel is None:
+        if self.encoder_name == "hubert":
+            # raw-waveform encoder (slam_model.py:335-341); equal-length unpadded clips only this round
             if audio is None:
-                raise RuntimeError("batch carries neither audio_mel nor audio")
-            # GPU log-mel front end (replaces the CPU DataLoader mel of speech_dataset.py:101-103)
-            audio_mel = ops.logmel(audio.float(), self.cfg["n_mels"], n_valid=kwargs.get("audio_len", None))
-        enc = self.encoder.forward_btc(audio_mel.float().contiguous())
+                raise RuntimeError("hubert encoder needs the raw `audio` batch key")
+            am = kwargs.get("audio_mask", None)
+            if am is not None and not bool((am > 0).all()):
+                raise NotImplementedError("ragged raw-audio batches for the HuBERT branch are not supported yet")
+            enc = self.encoder.forward_wav(audio.float())
+        else:
+            if audio_mel is None:
+                if audio is None:
+                    raise RuntimeError("batch carries neither audio_mel nor audio")
+                # GPU log-mel front end (replaces the CPU DataLoader mel of speech_dataset.py:101-103)
+                audio_mel = ops.logmel(audio.float(), self.cfg["n_mels"], n_valid=kwargs.get("audio_len", None))
+            enc = self.encoder.forward_btc(audio_mel.float().contiguous())
         proj = self.encoder_projector.forward_hip(enc, stash)  # [B, Ta, dl]
         Ta = proj.shape[1]
         if modality_mask is None:

@@ -190,12 +190,25 @@ def conv1d_k3_im2col(x: torch.Tensor, stride: int, Kp: int) -> torch.Tensor:
     return out
 
 
-def layernorm(x, weight, bias, eps=1e-5, out=None):
+def layernorm(x, weight, bias, eps=1e-5, out=None, gelu=False):
     M, d = x.shape
     if out is None:
         out = torch.empty((M, d), dtype=torch.bfloat16, device=x.device)
-    call("slam_layernorm_fwd", _p(x), _ld(x), _p(weight), _p(bias), _p(out), _ld(out), M, d, eps, _s())
+    call("slam_layernorm_fwd", _p(x), _ld(x), _p(weight), _p(bias), _p(out), _ld(out), M, d, eps, 1 if gelu else 0, _s())
     return out
+
+
+def conv1d_im2col(x2d, B, Tin, c0, C, k, stride, pad, Kp=None, Tout_limit=0, out=None):
+    """x2d rows (b*Tin + t) [B*Tin, >= c0+C] (bf16|f32) -> ([B*Tout, Kp] bf16, Tout); column j*C + c"""
+    Kp = Kp or round_up(k * C, 64)
+    Tout = (Tin + 2 * pad - k) // stride + 1
+    if Tout_limit:
+        Tout = min(Tout, Tout_limit)
+    if out is None:
+        out = torch.empty((B * Tout, Kp), dtype=torch.bfloat16, device=x2d.device)
+    call("slam_conv1d_im2col", _p(x2d), F32 if x2d.dtype == torch.float32 else BF16, _ld(x2d), c0, C, _p(out), B, Tin, k,
+         stride, pad, Kp, Tout_limit, _s())
+    return out, Tout
 
 
 def rmsnorm_fwd(x, weight, eps, out=None, rstd=None):

@@ -129,3 +129,52 @@ def test_grad_accumulation_and_foreign_optimizer(dev):
     opt.zero_grad()
     out3, _ = model(**{k: v.clone() for k, v in b.items()})
     assert float(out3.loss) < float(out1.loss)
+
+
+def test_hubert_encoder_matches_reference_twin_fixture(dev):
+    """a11: HuBERT encoder forward vs the HF-HubertModel fixture and the oracle (bf16 path: <= 3e-2 of tensor scale)"""
+    from oracle.make_golden_cases import HUBERT_TINY
+    from slam_llm_amd.model import HipHubertEncoder
+    fx = G.load("hubert_tiny")
+    W = O.init_hubert_weights(HUBERT_TINY, seed=7)
+    enc = HipHubertEncoder(dict(HUBERT_TINY), dev).load(W)
+    wav = torch.from_numpy(fx["wav"]).to(dev)
+    out = enc.forward_wav(wav)
+    assert list(out.shape) == [int(x) for x in fx["out_shape"]]
+    assert enc.out_frames(wav.shape[1]) == out.shape[1]
+    g, a = G.sub(fx, "out", out.float().cpu().numpy())
+    assert rel_err(a, g) < 3e-2, f"hubert out rel err {rel_err(a, g)}"
+    assert G.cosine(g, a) > 0.9995
+    assert HUBERT_TINY["hub_conv_kernel"] == (10, 3, 3, 3, 3, 2, 2)
+    # 30 s of 16 kHz audio -> 1499 frames (SURVEY g12: one fewer than the 300*5 slots the dataset reserves)
+    assert enc.out_frames(480000) == 1499
+
+
+def test_hubert_linear_llm_step_matches_oracle(dev):
+    """alt-encoder path end to end (HuBERT -> linear projector -> LLM+LoRA): loss vs the CPU oracle"""
+    from oracle.make_golden_cases import HUBERT_TINY
+    from slam_llm_amd.model import SlamHipModel
+    cfg = dict(O.make_config(), **HUBERT_TINY)
+    cfg.update(encoder_name="hubert", enc_dim=HUBERT_TINY["hub_dim"])
+    W = O.init_weights(cfg, seed=42)
+    W = {k: v for k, v in W.items() if not k.startswith("encoder.")}
+    W.update(O.init_hubert_weights(HUBERT_TINY, seed=7))
+    model = SlamHipModel(dict(cfg, lora_dropout=0.0), dev).load_weights(W)
+    model.train()
+    wav = torch.nn.functional.layer_norm(O.synth_audio(2, 1.0, seed=9), (16000,))
+    with torch.no_grad():
+        enc = O.hubert_encoder(W, cfg, wav)
+        proj = O.projector_concat(W, enc, cfg["ds_rate"])
+    Ta = proj.shape[1]
+    samples = [O.make_sample(Ta + 1, [5, 6, 7], [9, 10, 11, 12], 2), O.make_sample(Ta + 1, [5, 6], [9, 10], 2)]
+    ob = O.collate_left_pad(samples, pad_id=2)
+    with torch.no_grad():
+        emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+        loss_ref, _ = O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
+    gb = {k: v.to(dev) for k, v in ob.items()}
+    gb["audio"] = wav.to(dev)
+    gb["audio_mask"] = torch.ones_like(gb["audio"])
+    outputs, acc = model(**gb)
+    assert abs(float(outputs.loss.detach()) - float(loss_ref)) < 1e-2
+    outputs.loss.backward()
+    assert torch.isfinite(model.store.grad).all() and float(model.store.grad.abs().sum()) > 0

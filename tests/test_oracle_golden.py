@@ -71,3 +71,13 @@ def test_dynamic_batcher_matches_reference_window_class():
     assert ci == 4
     # 31 samples of T=380 fit under 12000 and the 32nd does not
     assert [int(x) for x in fx["group_sizes.1"]] == [31, 31, 2]
+
+
+def test_hubert_encoder_matches_hf_twin_of_reference():
+    from oracle.make_golden_cases import HUBERT_TINY
+    fx = G.load("hubert_tiny")
+    W = O.init_hubert_weights(HUBERT_TINY, seed=7)
+    with torch.no_grad():
+        out = O.hubert_encoder(W, HUBERT_TINY, torch.from_numpy(fx["wav"]))
+    assert list(out.shape) == [int(x) for x in fx["out_shape"]]
+    G.check_packed(fx, "out", out.numpy(), atol=3e-5, rtol=1e-4)
