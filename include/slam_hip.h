@@ -91,16 +91,19 @@ int slam_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int
 
 /* ---- attention (Whisper blocks: bidirectional, no mask; Llama: causal ^ key padding, GQA) -----------
  * Q/K/V/O/dO row-major [B*T, ld] with head h at column h*D; Vt/Kt/Qt/dOt = [B,H,D,Tp] transposed copies;
- * LSE/Delta [B,Hq,Tp] f32; key_mask [B,Tp] uint8 (1 = attend, zero padded) or NULL; D in {64,128}. */
+ * LSE/Delta [B,Hq,Tqp] f32; key_mask [B,Tkp] uint8 (1 = attend, zero padded) or NULL; D in {64,128}.
+ * Query rows are (b*Tq + t), key/value rows (b*Tk + t): Tq != Tk is cross-attention (Q-Former, projector.py:69-80);
+ * Tqp/Tkp are the 64-padded lengths used by the transposed copies, LSE/Delta and the mask. */
 int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, void* O,
-                  int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B, int64_t T, int64_t Tp,
-                  int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale, void* stream);
+                  int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B, int64_t Tq, int64_t Tk,
+                  int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
+                  void* stream);
 int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                   const void* Qt, const void* Kt, const void* O, int64_t ldo, const void* dO,
                   int64_t lddo, const void* dOt, const float* LSE, float* Delta, const uint8_t* key_mask,
                   void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv, int64_t B,
-                  int64_t T, int64_t Tp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
-                  void* stream);
+                  int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D,
+                  int causal, float scale, void* stream);
 
 /* ---- SwiGLU (LlamaMLP) : gate_up [M, 2F] = [gate | up] ---------------------------------------------- */
 int slam_swiglu_fwd(const void* gate_up, int64_t ldgu, void* h, int64_t ldh, int64_t M, int64_t F,

@@ -40,7 +40,7 @@ struct AttnParams {
   float* LSE;                       // [B, Hq, Tp] natural-log units
   float* Delta;                     // [B, Hq, Tp]
   const uint8_t* kmask;             // [B, Tp] 1 = attend (zero padded) or null
-  int T, Tp, Hq, Hkv;
+  int Tq, Tk, Tqp, Tkp, Hq, Hkv;  // query / key lengths and their 64-padded strides (Tq == Tk for self-attention)
   float scale;                      // softmax scale (1/sqrt(D))
 };
 
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int g = lane >> 4, li = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.Hq / p.Hkv);
-  const int T = p.T, Tp = p.Tp;
+  const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
   const int qb0 = blockIdx.x * 128, qw0 = qb0 + wave * 32;
 
   frag_t qf[2][KD];
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     const int q = qw0 + f * 16 + li;
 #pragma unroll
     for (int kd = 0; kd < KD; kd++) {
-      qf[f][kd] = (q < T) ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * T + q) * p.ldq + h * D + kd * 32 + g * 8)
+      qf[f][kd] = (q < Tq) ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * Tq + q) * p.ldq + h * D + kd * 32 + g * 8)
                           : zero_frag();
     }
   }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   float mrow[2] = {-INFINITY, -INFINITY};
   float lrow[2] = {0.f, 0.f};
 
-  const int kend = CAUSAL ? min(T, qb0 + 128) : T;
+  const int kend = CAUSAL ? min(Tk, qb0 + 128) : Tk;
   const int ntiles = (kend + 63) / 64;
   const float sl2 = p.scale * LOG2E;
 
@@ -129,14 +129,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       const int item = tid + i * 256;
       const int row = item / KCH, c = item % KCH;
       const int key = k0 + row;
-      kreg[i] = (key < T) ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * T + key) * p.ldk + hk * D + c * 8)
+      kreg[i] = (key < Tk) ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * Tk + key) * p.ldk + hk * D + c * 8)
                           : zero_frag();
     }
 #pragma unroll
     for (int i = 0; i < VI; i++) {
       const int item = tid + i * 256;
       const int d = item >> 3, c = item & 7;
-      vreg[i] = *reinterpret_cast<const frag_t*>(p.Vt + ((int64_t)(b * p.Hkv + hk) * D + d) * Tp + k0 + c * 8);
+      vreg[i] = *reinterpret_cast<const frag_t*>(p.Vt + ((int64_t)(b * p.Hkv + hk) * D + d) * Tkp + k0 + c * 8);
     }
   };
   auto lstore = [&]() {
@@ -186,9 +186,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int kf = 0; kf < 4; kf++) {
       const int kb = k0 + kf * 16 + 4 * g;
       unsigned mk = 0x01010101u;
-      if (p.kmask) mk = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tp + kb);
+      if (p.kmask) mk = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tkp + kb);
 #pragma unroll
-      for (int r = 0; r < 4; r++) kv[kf][r] = ((mk >> (8 * r)) & 0xffu) != 0 && (kb + r) < T;
+      for (int r = 0; r < 4; r++) kv[kf][r] = ((mk >> (8 * r)) & 0xffu) != 0 && (kb + r) < Tk;
     }
     // ---- online softmax (per query = lane&15, replicated over the 4 lane groups) ----
 #pragma unroll
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     lt += __shfl_xor(lt, 32, 64);
     const float inv = lt > 0.f ? 1.0f / lt : 0.f;
     const int q = qw0 + f * 16 + li;
-    if (q >= T) continue;
-    bf16_t* orow = p.O + ((int64_t)b * T + q) * p.ldo + h * D;
+    if (q >= Tq) continue;
+    bf16_t* orow = p.O + ((int64_t)b * Tq + q) * p.ldo + h * D;
 #pragma unroll
     for (int df = 0; df < DF; df++) {
       uint2 w;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       *reinterpret_cast<uint2*>(orow + df * 16 + 4 * g) = w;
     }
     if (p.LSE && g == 0)
-      p.LSE[((int64_t)b * p.Hq + h) * Tp + q] = lt > 0.f ? (mrow[f] * LN2 + __logf(lt)) : INFINITY;
+      p.LSE[((int64_t)b * p.Hq + h) * Tqp + q] = lt > 0.f ? (mrow[f] * LN2 + __logf(lt)) : INFINITY;
   }
 }
 
@@ -276,10 +276,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
   const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.z;
-  if (idx >= (int64_t)p.T * p.Hq) return;
+  if (idx >= (int64_t)p.Tq * p.Hq) return;
   const int t = (int)(idx / p.Hq), h = (int)(idx % p.Hq);
-  const bf16_t* orow = p.O + ((int64_t)b * p.T + t) * p.ldo + h * D;
-  const bf16_t* drow = p.dO + ((int64_t)b * p.T + t) * p.lddo + h * D;
+  const bf16_t* orow = p.O + ((int64_t)b * p.Tq + t) * p.ldo + h * D;
+  const bf16_t* drow = p.dO + ((int64_t)b * p.Tq + t) * p.lddo + h * D;
   float acc = 0.f;
   if (lane < D / 2) {
     const u16x2_t a = *reinterpret_cast<const u16x2_t*>(orow + lane * 2);
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
     acc = bf2f(a[0]) * bf2f(c[0]) + bf2f(a[1]) * bf2f(c[1]);
   }
   acc = wave_sum(acc);
-  if (lane == 0) p.Delta[((int64_t)b * p.Hq + h) * p.Tp + t] = acc;
+  if (lane == 0) p.Delta[((int64_t)b * p.Hq + h) * p.Tqp + t] = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -313,28 +313,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const int g = lane >> 4, li = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.Hq / p.Hkv);
-  const int T = p.T, Tp = p.Tp;
+  const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
   const int qb0 = blockIdx.x * 64, qw0 = qb0 + wave * 16;
   const int q = qw0 + li;
-  const bool qok = q < T;
+  const bool qok = q < Tq;
 
   frag_t qf[KD], dof[KD];
 #pragma unroll
   for (int kd = 0; kd < KD; kd++) {
-    qf[kd] = qok ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * T + q) * p.ldq + h * D + kd * 32 + g * 8) : zero_frag();
-    dof[kd] = qok ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * T + q) * p.lddo + h * D + kd * 32 + g * 8) : zero_frag();
+    qf[kd] = qok ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * Tq + q) * p.ldq + h * D + kd * 32 + g * 8) : zero_frag();
+    dof[kd] = qok ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * Tq + q) * p.lddo + h * D + kd * 32 + g * 8) : zero_frag();
   }
-  const float lse2 = qok ? p.LSE[((int64_t)b * p.Hq + h) * Tp + q] * LOG2E : INFINITY;
-  const float delta = qok ? p.Delta[((int64_t)b * p.Hq + h) * Tp + q] : 0.f;
+  const float lse2 = qok ? p.LSE[((int64_t)b * p.Hq + h) * Tqp + q] * LOG2E : INFINITY;
+  const float delta = qok ? p.Delta[((int64_t)b * p.Hq + h) * Tqp + q] : 0.f;
   const float sl2 = p.scale * LOG2E;
 
   f32x4_t dq[DF];
 #pragma unroll
   for (int df = 0; df < DF; df++) dq[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int kend = CAUSAL ? min(T, qb0 + 64) : T;
+  const int kend = CAUSAL ? min(Tk, qb0 + 64) : Tk;
   const int ntiles = (kend + 31) / 32;
-  const bf16_t* ktb = p.Kt + ((int64_t)(b * p.Hkv + hk) * D) * Tp;
+  const bf16_t* ktb = p.Kt + ((int64_t)(b * p.Hkv + hk) * D) * Tkp;
 
   frag_t kreg[NKV], vreg[NKV], ktreg[NKT];
   auto gload = [&](int k0) {
@@ -343,15 +343,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
       const int item = tid + i * 256;
       const int row = item / KCH, c = item % KCH;
       const int key = k0 + row;
-      const bool ok = key < T;
-      kreg[i] = ok ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * T + key) * p.ldk + hk * D + c * 8) : zero_frag();
-      vreg[i] = ok ? *reinterpret_cast<const frag_t*>(p.V + ((int64_t)b * T + key) * p.ldv + hk * D + c * 8) : zero_frag();
+      const bool ok = key < Tk;
+      kreg[i] = ok ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * Tk + key) * p.ldk + hk * D + c * 8) : zero_frag();
+      vreg[i] = ok ? *reinterpret_cast<const frag_t*>(p.V + ((int64_t)b * Tk + key) * p.ldv + hk * D + c * 8) : zero_frag();
     }
 #pragma unroll
     for (int i = 0; i < NKT; i++) {
       const int item = tid + i * 256;
       const int d = item >> 2, c = item & 3;
-      ktreg[i] = *reinterpret_cast<const frag_t*>(ktb + (int64_t)d * Tp + k0 + c * 8);
+      ktreg[i] = *reinterpret_cast<const frag_t*>(ktb + (int64_t)d * Tkp + k0 + c * 8);
     }
   };
   auto lstore = [&]() {
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     lstore();
     __syncthreads();
     if (it + 1 < ntiles) gload(k0 + 32);
-    if (qw0 >= T || (CAUSAL && k0 > qw0 + 15)) continue;
+    if (qw0 >= Tq || (CAUSAL && k0 > qw0 + 15)) continue;
 
     f32x4_t st[2], dpt[2];
 #pragma unroll
@@ -400,11 +400,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     for (int kf = 0; kf < 2; kf++) {
       const int kb = k0 + kf * 16 + 4 * g;
       unsigned mk = 0x01010101u;
-      if (p.kmask) mk = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tp + kb);
+      if (p.kmask) mk = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tkp + kb);
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int key = kb + r;
-        const bool ok = ((mk >> (8 * r)) & 0xffu) != 0 && key < T && (!CAUSAL || key <= q) && qok;
+        const bool ok = ((mk >> (8 * r)) & 0xffu) != 0 && key < Tk && (!CAUSAL || key <= q) && qok;
         const float pv = ok ? fast_exp2(st[kf][r] * sl2 - lse2) : 0.f;
         st[kf][r] = pv * (dpt[kf][r] - delta) * p.scale;
       }
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     }
   }
   if (!qok) return;
-  bf16_t* orow = p.dQ + ((int64_t)b * T + q) * p.lddq + h * D;
+  bf16_t* orow = p.dQ + ((int64_t)b * Tq + q) * p.lddq + h * D;
 #pragma unroll
   for (int df = 0; df < DF; df++) {
     uint2 w;
@@ -455,17 +455,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   const int g = lane >> 4, li = lane & 15;
   const int b = blockIdx.z, hk = blockIdx.y;
   const int G = p.Hq / p.Hkv;
-  const int T = p.T, Tp = p.Tp;
+  const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
   const int kb0 = blockIdx.x * 64, kw0 = kb0 + wave * 16;
   const int key = kw0 + li;
-  const bool kok = key < T && (!p.kmask || p.kmask[(int64_t)b * Tp + min(key, Tp - 1)] != 0);
+  const bool kok = key < Tk && (!p.kmask || p.kmask[(int64_t)b * Tkp + min(key, Tkp - 1)] != 0);
 
   frag_t kf[KD], vf[KD];
 #pragma unroll
   for (int kd = 0; kd < KD; kd++) {
-    const bool inb = key < T;
-    kf[kd] = inb ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * T + key) * p.ldk + hk * D + kd * 32 + g * 8) : zero_frag();
-    vf[kd] = inb ? *reinterpret_cast<const frag_t*>(p.V + ((int64_t)b * T + key) * p.ldv + hk * D + kd * 32 + g * 8) : zero_frag();
+    const bool inb = key < Tk;
+    kf[kd] = inb ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * Tk + key) * p.ldk + hk * D + kd * 32 + g * 8) : zero_frag();
+    vf[kd] = inb ? *reinterpret_cast<const frag_t*>(p.V + ((int64_t)b * Tk + key) * p.ldv + hk * D + kd * 32 + g * 8) : zero_frag();
   }
   f32x4_t dk[DF], dv[DF];
 #pragma unroll
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   }
   const float sl2 = p.scale * LOG2E;
   const int qstart = CAUSAL ? (kb0 / 32) * 32 : 0;
-  const int nq = (T - qstart + 31) / 32;  // kb0 < T always holds for launched blocks
+  const int nq = (Tq - qstart + 31) / 32;
   const int ntiles = G * nq;
 
   frag_t qreg[NQ], doreg[NQ], qtreg[NQT], dotreg[NQT];
@@ -487,17 +487,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
       const int item = tid + i * 256;
       const int row = item / KCH, c = item % KCH;
       const int q = q0 + row;
-      const bool ok = q < T;
-      qreg[i] = ok ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * T + q) * p.ldq + h * D + c * 8) : zero_frag();
-      doreg[i] = ok ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * T + q) * p.lddo + h * D + c * 8) : zero_frag();
+      const bool ok = q < Tq;
+      qreg[i] = ok ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * Tq + q) * p.ldq + h * D + c * 8) : zero_frag();
+      doreg[i] = ok ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * Tq + q) * p.lddo + h * D + c * 8) : zero_frag();
     }
-    const int64_t tb = ((int64_t)(b * p.Hq + h) * D) * Tp + q0;
+    const int64_t tb = ((int64_t)(b * p.Hq + h) * D) * Tqp + q0;
 #pragma unroll
     for (int i = 0; i < NQT; i++) {
       const int item = tid + i * 256;
       const int d = item >> 2, c = item & 3;
-      qtreg[i] = *reinterpret_cast<const frag_t*>(p.Qt + tb + (int64_t)d * Tp + c * 8);
-      dotreg[i] = *reinterpret_cast<const frag_t*>(p.dOt + tb + (int64_t)d * Tp + c * 8);
+      qtreg[i] = *reinterpret_cast<const frag_t*>(p.Qt + tb + (int64_t)d * Tqp + c * 8);
+      dotreg[i] = *reinterpret_cast<const frag_t*>(p.dOt + tb + (int64_t)d * Tqp + c * 8);
     }
   };
   auto lstore = [&]() {
@@ -527,10 +527,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
     lstore();
     __syncthreads();
     if (it + 1 < ntiles) gload(it + 1);
-    if (kw0 >= T || (CAUSAL && q0 + 31 < kw0)) continue;
+    if (kw0 >= Tk || (CAUSAL && q0 + 31 < kw0)) continue;
 
-    const float* lsep = p.LSE + ((int64_t)b * p.Hq + h) * Tp;
-    const float* delp = p.Delta + ((int64_t)b * p.Hq + h) * Tp;
+    const float* lsep = p.LSE + ((int64_t)b * p.Hq + h) * Tqp;
+    const float* delp = p.Delta + ((int64_t)b * p.Hq + h) * Tqp;
     f32x4_t s[2], dp[2];
 #pragma unroll
     for (int f = 0; f < 2; f++) {
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int q = qb + r;
-        const bool ok = kok && q < T && (!CAUSAL || key <= q);
+        const bool ok = kok && q < Tq && (!CAUSAL || key <= q);
         const float pv = ok ? fast_exp2(s[f][r] * sl2 - ls[r] * LOG2E) : 0.f;
         pm[f][r] = pv;
         ds[f][r] = ok ? pv * (dp[f][r] - dl[r]) * p.scale : 0.f;
@@ -580,9 +580,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
       dk[df] = mfma16(join_frag(qlo, qhi), dsb, dk[df]);
     }
   }
-  if (key >= T) return;
-  bf16_t* krow = p.dK + ((int64_t)b * T + key) * p.lddk + hk * D;
-  bf16_t* vrow = p.dV + ((int64_t)b * T + key) * p.lddv + hk * D;
+  if (key >= Tk) return;
+  bf16_t* krow = p.dK + ((int64_t)b * Tk + key) * p.lddk + hk * D;
+  bf16_t* vrow = p.dV + ((int64_t)b * Tk + key) * p.lddv + hk * D;
 #pragma unroll
   for (int df = 0; df < DF; df++) {
     uint2 w;
@@ -595,10 +595,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   }
 }
 
-int check_common(const char* name, int64_t B, int64_t T, int64_t Tp, int64_t Hq, int64_t Hkv, int64_t D) {
+int check_common(const char* name, int64_t B, int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv,
+                 int64_t D, int causal) {
   SLAM_CHECK_ARG(D == 64 || D == 128, "%s: head_dim %ld unsupported (64|128)", name, (long)D);
-  SLAM_CHECK_ARG(B > 0 && T > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "%s: bad shape B=%ld T=%ld Hq=%ld Hkv=%ld", name, (long)B, (long)T, (long)Hq, (long)Hkv);
-  SLAM_CHECK_ARG(Tp % 64 == 0 && Tp >= T, "%s: Tp=%ld must be a multiple of 64 and >= T=%ld", name, (long)Tp, (long)T);
+  SLAM_CHECK_ARG(B > 0 && Tq > 0 && Tk > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "%s: bad shape B=%ld Tq=%ld Tk=%ld Hq=%ld Hkv=%ld",
+                 name, (long)B, (long)Tq, (long)Tk, (long)Hq, (long)Hkv);
+  SLAM_CHECK_ARG(Tqp % 64 == 0 && Tqp >= Tq && Tkp % 64 == 0 && Tkp >= Tk, "%s: padded lengths must be multiples of 64 and >= T", name);
+  SLAM_CHECK_ARG(!causal || Tq == Tk, "%s: causal attention needs Tq == Tk", name);
   SLAM_CHECK_ARG(B < 65536 && Hq < 65536, "%s: grid dims exceed 65535", name);
   return 0;
 }
@@ -607,16 +610,16 @@ int check_common(const char* name, int64_t B, int64_t T, int64_t Tp, int64_t Hq,
 
 extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt,
                              void* O, int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B,
-                             int64_t T, int64_t Tp, int64_t Hq, int64_t Hkv, int64_t D, int causal,
-                             float scale, void* stream) {
+                             int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D,
+                             int causal, float scale, void* stream) {
   SLAM_CHECK_ARG(Q && K && Vt && O, "slam_attn_fwd: null pointer");
-  if (int rc = check_common("slam_attn_fwd", B, T, Tp, Hq, Hkv, D)) return rc;
+  if (int rc = check_common("slam_attn_fwd", B, Tq, Tk, Tqp, Tkp, Hq, Hkv, D, causal)) return rc;
   SLAM_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "slam_attn_fwd: leading dims must be multiples of 8");
   AttnParams p = {};
   p.Q = (const bf16_t*)Q; p.ldq = ldq; p.K = (const bf16_t*)K; p.ldk = ldk; p.Vt = (const bf16_t*)Vt;
   p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = LSE; p.kmask = key_mask;
-  p.T = (int)T; p.Tp = (int)Tp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
-  dim3 grid((unsigned)cdiv64(T, 128), (unsigned)Hq, (unsigned)B);
+  p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
+  dim3 grid((unsigned)cdiv64(Tq, 128), (unsigned)Hq, (unsigned)B);
   hipStream_t s = (hipStream_t)stream;
   if (D == 64) {
     if (causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, s, p);
@@ -633,10 +636,10 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
                              int64_t ldv, const void* Qt, const void* Kt, const void* O, int64_t ldo,
                              const void* dO, int64_t lddo, const void* dOt, const float* LSE,
                              float* Delta, const uint8_t* key_mask, void* dQ, int64_t lddq, void* dK,
-                             int64_t lddk, void* dV, int64_t lddv, int64_t B, int64_t T, int64_t Tp,
-                             int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale, void* stream) {
+                             int64_t lddk, void* dV, int64_t lddv, int64_t B, int64_t Tq, int64_t Tk, int64_t Tqp,
+                             int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale, void* stream) {
   SLAM_CHECK_ARG(Q && K && V && Qt && Kt && O && dO && dOt && LSE && Delta && dQ && dK && dV, "slam_attn_bwd: null pointer");
-  if (int rc = check_common("slam_attn_bwd", B, T, Tp, Hq, Hkv, D)) return rc;
+  if (int rc = check_common("slam_attn_bwd", B, Tq, Tk, Tqp, Tkp, Hq, Hkv, D, causal)) return rc;
   SLAM_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && ldo % 2 == 0 &&
                      lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0,
                  "slam_attn_bwd: leading dims misaligned");
@@ -646,11 +649,11 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.O = (bf16_t*)O; p.ldo = ldo; p.dO = (const bf16_t*)dO; p.lddo = lddo;
   p.dQ = (bf16_t*)dQ; p.lddq = lddq; p.dK = (bf16_t*)dK; p.lddk = lddk; p.dV = (bf16_t*)dV; p.lddv = lddv;
   p.LSE = (float*)LSE; p.Delta = Delta; p.kmask = key_mask;
-  p.T = (int)T; p.Tp = (int)Tp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
+  p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
   hipStream_t s = (hipStream_t)stream;
-  dim3 gdel((unsigned)cdiv64(T * Hq, 4), 1, (unsigned)B);
-  dim3 gq((unsigned)cdiv64(T, 64), (unsigned)Hq, (unsigned)B);
-  dim3 gk((unsigned)cdiv64(T, 64), (unsigned)Hkv, (unsigned)B);
+  dim3 gdel((unsigned)cdiv64(Tq * Hq, 4), 1, (unsigned)B);
+  dim3 gq((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B);
+  dim3 gk((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);
   if (D == 64) {
     hipLaunchKernelGGL((attn_delta_kernel<64>), gdel, dim3(256), 0, s, p);
     if (causal) {

@@ -250,25 +250,28 @@ def transpose(x2d, Rp=None, out=None):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_lse=True, out=None):
-    Tp = vt.shape[-1]
+def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_lse=True, out=None, Tk=None):
+    """self-attention: q/k rows (b*T + t).  Cross-attention: pass Tk (key rows b*Tk + t); vt is [B,Hkv,D,Tkp]."""
+    Tk = Tk or T
+    Tkp, Tqp = vt.shape[-1], round_up(T, 64)
     if out is None:
         out = torch.empty((B * T, Hq * D), dtype=torch.bfloat16, device=q2d.device)
-    lse = torch.empty((B, Hq, Tp), dtype=torch.float32, device=q2d.device) if want_lse else None
-    _timed("attn_fwd", 4.0 * B * Hq * T * T * D * (0.5 if causal else 1.0),
+    lse = torch.empty((B, Hq, Tqp), dtype=torch.float32, device=q2d.device) if want_lse else None
+    _timed("attn_fwd", 4.0 * B * Hq * T * Tk * D * (0.5 if causal else 1.0),
            lambda: call("slam_attn_fwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(vt), _p(out), _ld(out), _p(lse),
-                        _p(key_mask), B, T, Tp, Hq, Hkv, D, 1 if causal else 0, scale, _s()))
+                        _p(key_mask), B, T, Tk, Tqp, Tkp, Hq, Hkv, D, 1 if causal else 0, scale, _s()))
     return out, lse
 
 
 def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T, Hq, Hkv, D, causal, scale,
-             key_mask=None):
-    Tp = qt.shape[-1]
-    delta = torch.empty((B, Hq, Tp), dtype=torch.float32, device=q2d.device)
-    _timed("attn_bwd", 10.0 * B * Hq * T * T * D * (0.5 if causal else 1.0),
+             key_mask=None, Tk=None):
+    Tk = Tk or T
+    Tqp, Tkp = qt.shape[-1], kt.shape[-1]
+    delta = torch.empty((B, Hq, Tqp), dtype=torch.float32, device=q2d.device)
+    _timed("attn_bwd", 10.0 * B * Hq * T * Tk * D * (0.5 if causal else 1.0),
            lambda: call("slam_attn_bwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(v2d), _ld(v2d), _p(qt), _p(kt),
                         _p(o2d), _ld(o2d), _p(do2d), _ld(do2d), _p(dot), _p(lse), _p(delta), _p(key_mask), _p(dq2d),
-                        _ld(dq2d), _p(dk2d), _ld(dk2d), _p(dv2d), _ld(dv2d), B, T, Tp, Hq, Hkv, D,
+                        _ld(dq2d), _p(dk2d), _ld(dk2d), _p(dv2d), _ld(dv2d), B, T, Tk, Tqp, Tkp, Hq, Hkv, D,
                         1 if causal else 0, scale, _s()))
     return delta
 

@@ -254,6 +254,42 @@ def test_attention_bwd(dev, B, T, Hq, Hkv, D, masked):
         assert_close(got, r, atol=3e-2 * float(r.abs().max()), rtol=3e-2, what=nme)
 
 
+def test_cross_attention_fwd_bwd(dev):
+    """Tq != Tk (Q-Former cross-attention: 32 queries over 150 encoder frames, key padding mask), D = 64"""
+    ops = _ops()
+    B, Tq, Tk, H, D = 2, 32, 150, 3, 64
+    q2 = rnd((B * Tq, H * D), dev, seed=21)
+    kv = rnd((B * Tk, 2 * H * D), dev, seed=22)
+    k2, v2 = kv[:, : H * D], kv[:, H * D:]
+    qt = ops.head_rope_transpose(q2, 0, B, Tq, H, D)
+    kt = ops.head_rope_transpose(kv, 0, B, Tk, H, D)
+    vt = ops.head_rope_transpose(kv, H * D, B, Tk, H, D)
+    km = torch.zeros((B, vt.shape[-1]), dtype=torch.uint8, device=dev)
+    km[0, :Tk] = 1
+    km[1, :100] = 1
+    scale = D ** -0.5
+    o, lse = ops.attn_fwd(q2, k2, vt, B, Tq, H, H, D, False, scale, key_mask=km, Tk=Tk)
+    qf = q2.float().view(B, Tq, H, D).clone().requires_grad_(True)
+    kf = k2.float().reshape(B, Tk, H, D).clone().requires_grad_(True)
+    vf = v2.float().reshape(B, Tk, H, D).clone().requires_grad_(True)
+    s = (qf.permute(0, 2, 1, 3) @ kf.permute(0, 2, 3, 1)) * scale
+    s = s.masked_fill(~km[:, None, None, :Tk].bool(), float("-inf"))
+    ref = (torch.softmax(s, -1) @ vf.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+    assert_close(o.view(B, Tq, H, D), ref.detach(), atol=2e-2, rtol=2e-2, what="cross attn fwd")
+    do = rnd((B * Tq, H * D), dev, seed=23)
+    dot = ops.head_rope_transpose(do, 0, B, Tq, H, D)
+    dq2 = torch.zeros_like(q2)
+    dkv = torch.zeros_like(kv)
+    ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, dq2, dkv[:, : H * D], dkv[:, H * D:], B, Tq, H, H, D, False, scale,
+                 key_mask=km, Tk=Tk)
+    ref.backward(do.float().view(B, Tq, H, D))
+    for nme, got, r in (("dq", dq2, qf.grad), ("dk", dkv[:, : H * D], kf.grad), ("dv", dkv[:, H * D:], vf.grad)):
+        got = got.float().reshape(r.shape)
+        cs = F.cosine_similarity(got.flatten(), r.flatten(), dim=0)
+        assert cs > 0.9995, f"{nme} cosine {float(cs)}"
+        assert_close(got, r, atol=3e-2 * float(r.abs().max()), rtol=3e-2, what=nme)
+
+
 # ----------------------------------------------------------------------------------------- mlp / conv
 def test_swiglu(dev):
     ops = _ops()
