@@ -71,7 +71,16 @@ int slam_conv1d_im2col(const void* in, int in_dtype, int64_t ld_in, int64_t c0, 
  * LayerNorm (Whisper blocks + ln_post, encoder.py:26-29; fp32 statistics), RMSNorm fwd/bwd (Llama). */
 /* act: 0 none, 1 exact GELU fused after the affine (HuBERT feature-encoder LayerNorm+GELU) */
 int slam_layernorm_fwd(const void* x, int64_t ldx, const float* weight, const float* bias, void* y,
-                       int64_t ldy, int64_t M, int64_t d, float eps, int act, void* stream);
+                       int64_t ldy, int64_t M, int64_t d, float eps, int act, float* mean_out, float* rstd_out,
+                       void* stream);
+/* LayerNorm backward (trainable Q-Former projector, projector.py:51-80): dx (nullable) and dgamma/dbeta (nullable, f32) */
+int slam_layernorm_bwd(const void* x, int64_t ldx, const float* mean, const float* rstd, const float* weight,
+                       const void* dy, int64_t lddy, void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t M,
+                       int64_t d, int accumulate, void* stream);
+/* exact GELU forward/backward on the pre-activation z (Q-Former feed-forward) */
+int slam_gelu_fwd(const void* z, int64_t ldz, void* y, int64_t ldy, int64_t M, int64_t N, void* stream);
+int slam_gelu_bwd(const void* z, int64_t ldz, const void* dy, int64_t lddy, void* dz, int64_t lddz, int64_t M,
+                  int64_t N, void* stream);
 int slam_rmsnorm_fwd(const void* x, int64_t ldx, const float* weight, void* y, int64_t ldy, float* rstd,
                      int64_t M, int64_t d, float eps, void* stream);
 /* dx = rmsnorm'(dy) * (*grad_scale or 1) + dres (nullable) */
@@ -154,6 +163,9 @@ int slam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                     int64_t step, float grad_scale, void* stream);
 int slam_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+/* a += b (bf16 residual-gradient merge of the post-LN Q-Former blocks) */
+int slam_add_bf16(void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N, void* stream);
+int slam_cast_bf16_to_f32(const void* in, float* out, int64_t n, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

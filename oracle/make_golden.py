@@ -249,7 +249,7 @@ def gen_step(name, cfg, clip_seconds, answer_lens, n_steps=3, left_pad=True):
     print(name + ".npz written")
 
 
-from oracle.make_golden_cases import CASES, HUBERT_TINY  # noqa: E402
+from oracle.make_golden_cases import CASES, HUBERT_TINY, QFORMER_CASE  # noqa: E402
 
 def gen_batcher():
     """Run the reference's own window_class + MultiTaskDynamicBatchDataset (speech_dataset_large.py:235-263).
@@ -326,10 +326,39 @@ def gen_hubert():
     print("hubert_tiny.npz written", tuple(out.shape))
 
 
+def gen_qformer():
+    """The reference's EncoderProjectorQFormer (projector.py:51-80), imported unmodified, in eval mode (dropout off):
+    output and gradients of every parameter for a fixed random cotangent."""
+    from slam_llm.models.projector import EncoderProjectorQFormer
+    c = QFORMER_CASE
+    cfg = c["cfg"]
+    mc = Cfg(encoder_dim=c["enc_dim"], llm_dim=c["llm_dim"], qformer_layers=cfg["qf_layers"], query_len=cfg["qf_queries"])
+    torch.manual_seed(0)
+    m = EncoderProjectorQFormer(mc).eval()
+    W = O.init_qformer_weights(cfg, c["enc_dim"], c["llm_dim"], seed=11)
+    sd = m.state_dict()
+    assert set("encoder_projector." + k for k in sd) == set(W), set("encoder_projector." + k for k in sd) ^ set(W)
+    m.load_state_dict({k: W["encoder_projector." + k] for k in sd})
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(c["B"], c["Tk"], c["enc_dim"], generator=g)
+    atts = torch.ones(c["B"], c["Tk"])
+    atts[1, -c["masked_tail"]:] = 0
+    cot = torch.randn(c["B"], cfg["qf_queries"], c["llm_dim"], generator=g)
+    out = m(x, atts)
+    (out * cot).sum().backward()
+    fx = {"x": x.numpy(), "atts": atts.numpy(), "cot": cot.numpy(), "weights_sha256": np.array(wsum(W))}
+    pack(fx, "out", out.detach().numpy(), limit=65536)
+    for n, p_ in m.named_parameters():
+        pack(fx, "grad.encoder_projector." + n, p_.grad.numpy(), limit=4096)
+    np.savez_compressed(os.path.join(GOLD, "qformer.npz"), **fx)
+    print("qformer.npz written", tuple(out.shape))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     gen_mel()
     gen_batcher()
     gen_hubert()
+    gen_qformer()
     for nme, c in CASES.items():
         gen_step(nme, **c)

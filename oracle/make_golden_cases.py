@@ -14,3 +14,7 @@ CASES = {
 # HuBERT-style encoder (a11): same structure as hubert-large, narrow widths (conv 64 ch, d 128, pos-conv k 16 / 4 groups)
 HUBERT_TINY = O.hubert_config(hub_conv_dim=(64,) * 7, hub_dim=128, hub_heads=2, hub_layers=2, hub_ffn=256, hub_pos_k=16,
                               hub_pos_groups=4)
+
+# Q-Former projector (a3'): the reference module hard-codes Blip2QFormerConfig() widths (768/12/3072); layers, queries,
+# encoder_dim and llm_dim come from the recipe -> keep those small
+QFORMER_CASE = dict(cfg=O.qformer_config(qf_layers=2, qf_queries=8), enc_dim=128, llm_dim=128, B=2, Tk=37, masked_tail=7)

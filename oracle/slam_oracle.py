@@ -222,6 +222,83 @@ def projector_concat(W, x: torch.Tensor, k: int, prefix="encoder_projector.") ->
     return F.linear(x, W[prefix + "linear2.weight"], W[prefix + "linear2.bias"])
 
 
+
+# ---------------------------------------------------------------------------------------------- a3': Q-Former projector
+def qformer_config(**kw) -> dict:
+    """Blip2QFormerConfig defaults as used by EncoderProjectorQFormer (src/slam_llm/models/projector.py:52-67):
+    hidden 768, 12 heads, ffn 3072, cross-attention every 2nd layer, LayerNorm eps 1e-12; layers/queries from the recipe."""
+    c = dict(qf_dim=768, qf_heads=12, qf_ffn=3072, qf_layers=8, qf_queries=64, qf_eps=1e-12, qf_cross_freq=2)
+    c.update(kw)
+    return c
+
+
+def _mha(W, p, hq, hkv, H, key_mask=None):
+    B, Tq, d = hq.shape
+    Tk = hkv.shape[1]
+    hd = d // H
+    q = F.linear(hq, W[p + "query.weight"], W[p + "query.bias"]).view(B, Tq, H, hd).transpose(1, 2)
+    k = F.linear(hkv, W[p + "key.weight"], W[p + "key.bias"]).view(B, Tk, H, hd).transpose(1, 2)
+    v = F.linear(hkv, W[p + "value.weight"], W[p + "value.bias"]).view(B, Tk, H, hd).transpose(1, 2)
+    s = (q @ k.transpose(2, 3)) * hd ** -0.5
+    if key_mask is not None:
+        s = s.masked_fill(~key_mask.bool()[:, None, None, :], torch.finfo(torch.float32).min)
+    return (F.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, Tq, d)
+
+
+def projector_qformer(W, cfg, x: torch.Tensor, atts: Optional[torch.Tensor], prefix="encoder_projector.") -> torch.Tensor:
+    """EncoderProjectorQFormer.forward (src/slam_llm/models/projector.py:69-80) over HF Blip2QFormerModel
+    (transformers/models/blip_2/modeling_blip_2.py:536-760, 849-940), dropout = 0 (eval-mode parity; the HIP path
+    implements no dropout).  x [B, Tk, d_enc], atts [B, Tk] (1 = attend) -> [B, Q, llm_dim]."""
+    eps, H = cfg["qf_eps"], cfg["qf_heads"]
+    B = x.shape[0]
+    d = cfg["qf_dim"]
+    P = prefix + "qformer."
+    h = F.layer_norm(W[prefix + "query"].expand(B, -1, -1), (d,), W[P + "layernorm.weight"], W[P + "layernorm.bias"], eps)
+    for l in range(cfg["qf_layers"]):
+        L = f"{P}encoder.layer.{l}."
+        a = _mha(W, L + "attention.attention.", h, h, H)
+        h = F.layer_norm(F.linear(a, W[L + "attention.output.dense.weight"], W[L + "attention.output.dense.bias"]) + h, (d,),
+                         W[L + "attention.output.LayerNorm.weight"], W[L + "attention.output.LayerNorm.bias"], eps)
+        if l % cfg["qf_cross_freq"] == 0:
+            c = _mha(W, L + "crossattention.attention.", h, x, H, atts)
+            h = F.layer_norm(F.linear(c, W[L + "crossattention.output.dense.weight"], W[L + "crossattention.output.dense.bias"]) + h,
+                             (d,), W[L + "crossattention.output.LayerNorm.weight"], W[L + "crossattention.output.LayerNorm.bias"], eps)
+        f = F.gelu(F.linear(h, W[L + "intermediate_query.dense.weight"], W[L + "intermediate_query.dense.bias"]))
+        h = F.layer_norm(F.linear(f, W[L + "output_query.dense.weight"], W[L + "output_query.dense.bias"]) + h, (d,),
+                         W[L + "output_query.LayerNorm.weight"], W[L + "output_query.LayerNorm.bias"], eps)
+    y = F.linear(h, W[prefix + "linear.weight"], W[prefix + "linear.bias"])
+    return F.layer_norm(y, (y.shape[-1],), W[prefix + "norm.weight"], W[prefix + "norm.bias"], 1e-5)
+
+
+def init_qformer_weights(cfg: dict, enc_dim: int, llm_dim: int, seed: int = 11, prefix="encoder_projector.") -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, std=0.02):
+        return torch.randn(*shape, generator=g) * std
+
+    d, ffn = cfg["qf_dim"], cfg["qf_ffn"]
+    W = {prefix + "query": rn(1, cfg["qf_queries"], d, std=1.0)}
+    P = prefix + "qformer."
+    W[P + "layernorm.weight"], W[P + "layernorm.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+
+    def attn(p, kv_dim):
+        for n, kin in (("query", d), ("key", kv_dim), ("value", kv_dim)):
+            W[p + f"attention.{n}.weight"], W[p + f"attention.{n}.bias"] = rn(d, kin, std=kin ** -0.5), rn(d)
+        W[p + "output.dense.weight"], W[p + "output.dense.bias"] = rn(d, d, std=d ** -0.5), rn(d)
+        W[p + "output.LayerNorm.weight"], W[p + "output.LayerNorm.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+
+    for l in range(cfg["qf_layers"]):
+        L = f"{P}encoder.layer.{l}."
+        attn(L + "attention.", d)
+        if l % cfg["qf_cross_freq"] == 0:
+            attn(L + "crossattention.", enc_dim)
+        W[L + "intermediate_query.dense.weight"], W[L + "intermediate_query.dense.bias"] = rn(ffn, d, std=d ** -0.5), rn(ffn)
+        W[L + "output_query.dense.weight"], W[L + "output_query.dense.bias"] = rn(d, ffn, std=ffn ** -0.5), rn(d)
+        W[L + "output_query.LayerNorm.weight"], W[L + "output_query.LayerNorm.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+    W[prefix + "linear.weight"], W[prefix + "linear.bias"] = rn(llm_dim, d, std=d ** -0.5), rn(llm_dim)
+    W[prefix + "norm.weight"], W[prefix + "norm.bias"] = 1 + rn(llm_dim, std=0.1), rn(llm_dim, std=0.1)
+    return W
+
 # ---------------------------------------------------------------------------------------------- a4: embed + splice
 def embed_splice(embed_weight, input_ids, modality_mask, encoder_outs):
     """src/slam_llm/models/slam_model.py:370-392 (input_ids is mutated in place like the reference)."""

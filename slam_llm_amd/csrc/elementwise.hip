@@ -244,6 +244,27 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     out[i] = f2bf(in[i]);
 }
 
+__global__ __launch_bounds__(256) void add_bf16_kernel(bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b,
+                                                       int64_t ldb, int64_t M, int N) {
+  const int nch = N >> 3;
+  const int64_t total = M * nch;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / nch;
+    const int c = (int)(i % nch);
+    u16x8_t x = *reinterpret_cast<const u16x8_t*>(a + m * lda + c * 8);
+    const u16x8_t y = *reinterpret_cast<const u16x8_t*>(b + m * ldb + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; e++) x[e] = f2bf(bf2f(x[e]) + bf2f(y[e]));
+    *reinterpret_cast<u16x8_t*>(a + m * lda + c * 8) = x;
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out,
+                                                            int64_t n, int accumulate) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = accumulate ? out[i] + bf2f(in[i]) : bf2f(in[i]);
+}
+
 // ------------------------------------------------------------------------------------------
 // modality spans + embed/splice
 // ------------------------------------------------------------------------------------------
@@ -396,6 +417,49 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
       for (int r = 0; r < 32; r++) s += red[r][threadIdx.x];
       out[c] = accumulate ? out[c] + s : s;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// exact GELU forward / backward (Q-Former feed-forward, HF Blip2QFormerIntermediate): y = x * Phi(x)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ z, int64_t ldz, bf16_t* __restrict__ y,
+                                                       int64_t ldy, int64_t M, int N) {
+  const int nch = N >> 3;
+  const int64_t total = M * nch;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / nch;
+    const int c = (int)(i % nch);
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(z + m * ldz + c * 8);
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float x = bf2f(v[e]);
+      o[e] = f2bf(0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)));
+    }
+    *reinterpret_cast<u16x8_t*>(y + m * ldy + c * 8) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ z, int64_t ldz,
+                                                       const bf16_t* __restrict__ dy, int64_t lddy,
+                                                       bf16_t* __restrict__ dz, int64_t lddz, int64_t M, int N) {
+  const int nch = N >> 3;
+  const int64_t total = M * nch;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / nch;
+    const int c = (int)(i % nch);
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(z + m * ldz + c * 8);
+    const u16x8_t g = *reinterpret_cast<const u16x8_t*>(dy + m * lddy + c * 8);
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float x = bf2f(v[e]);
+      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+      o[e] = f2bf(bf2f(g[e]) * (cdf + x * pdf));
+    }
+    *reinterpret_cast<u16x8_t*>(dz + m * lddz + c * 8) = o;
   }
 }
 
@@ -574,5 +638,39 @@ extern "C" int slam_conv1d_im2col(const void* in, int in_dtype, int64_t ld_in, i
     return -1;
   }
   SLAM_CHECK_LAUNCH("slam_conv1d_im2col");
+  return 0;
+}
+
+extern "C" int slam_gelu_fwd(const void* z, int64_t ldz, void* y, int64_t ldy, int64_t M, int64_t N, void* stream) {
+  SLAM_CHECK_ARG(z && y && M > 0 && N > 0 && N % 8 == 0 && ldz % 8 == 0 && ldy % 8 == 0, "slam_gelu_fwd: bad arguments");
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(ew_grid(M * (N / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, ldz,
+                     (bf16_t*)y, ldy, M, (int)N);
+  SLAM_CHECK_LAUNCH("slam_gelu_fwd");
+  return 0;
+}
+
+extern "C" int slam_gelu_bwd(const void* z, int64_t ldz, const void* dy, int64_t lddy, void* dz, int64_t lddz,
+                             int64_t M, int64_t N, void* stream) {
+  SLAM_CHECK_ARG(z && dy && dz && M > 0 && N > 0 && N % 8 == 0 && ldz % 8 == 0 && lddy % 8 == 0 && lddz % 8 == 0,
+                 "slam_gelu_bwd: bad arguments");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(M * (N / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, ldz,
+                     (const bf16_t*)dy, lddy, (bf16_t*)dz, lddz, M, (int)N);
+  SLAM_CHECK_LAUNCH("slam_gelu_bwd");
+  return 0;
+}
+
+extern "C" int slam_cast_bf16_to_f32(const void* in, float* out, int64_t n, int accumulate, void* stream) {
+  SLAM_CHECK_ARG(in && out && n > 0, "slam_cast_bf16_to_f32: bad arguments");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, out, n,
+                     accumulate);
+  SLAM_CHECK_LAUNCH("slam_cast_bf16_to_f32");
+  return 0;
+}
+
+extern "C" int slam_add_bf16(void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N, void* stream) {
+  SLAM_CHECK_ARG(a && b && M > 0 && N > 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "slam_add_bf16: bad arguments");
+  hipLaunchKernelGGL(add_bf16_kernel, dim3(ew_grid(M * (N / 8))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)a, lda,
+                     (const bf16_t*)b, ldb, M, (int)N);
+  SLAM_CHECK_LAUNCH("slam_add_bf16");
   return 0;
 }

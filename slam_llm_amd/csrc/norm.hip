@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b,
                                                         bf16_t* __restrict__ y, int64_t ldy, int M,
-                                                        int d, float eps, int act) {
+                                                        int d, float eps, int act, float* __restrict__ mean_out,
+                                                        float* __restrict__ rstd_out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -40,6 +41,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  if (lane == 0 && mean_out) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
   bf16_t* yr = y + (int64_t)row * ldy;
   for (int c = lane; c < nch; c += 64) {
     const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
@@ -143,17 +148,107 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(
   }
 }
 
+// LayerNorm backward (Q-Former projector, src/slam_llm/models/projector.py:51-80 -> HF Blip2QFormer LayerNorms):
+//   g = dy * w ; dx = rstd * (g - mean(g) - xhat * mean(g * xhat))        (one wave per row)
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                               const float* __restrict__ mean_in,
+                                                               const float* __restrict__ rstd_in,
+                                                               const float* __restrict__ w,
+                                                               const bf16_t* __restrict__ dy, int64_t lddy,
+                                                               bf16_t* __restrict__ dx, int64_t lddx, int M, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const bf16_t* xr = x + (int64_t)row * ldx;
+  const bf16_t* dyr = dy + (int64_t)row * lddy;
+  const float mean = mean_in[row], rstd = rstd_in[row];
+  const int nch = d >> 3;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+    const u16x8_t g = *reinterpret_cast<const u16x8_t*>(dyr + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float gw = bf2f(g[e]) * w[c * 8 + e];
+      s1 += gw;
+      s2 += gw * (bf2f(v[e]) - mean) * rstd;
+    }
+  }
+  s1 = wave_sum(s1) / (float)d;
+  s2 = wave_sum(s2) / (float)d;
+  bf16_t* dxr = dx + (int64_t)row * lddx;
+  for (int c = lane; c < nch; c += 64) {
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+    const u16x8_t g = *reinterpret_cast<const u16x8_t*>(dyr + c * 8);
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float xh = (bf2f(v[e]) - mean) * rstd;
+      o[e] = f2bf(rstd * (bf2f(g[e]) * w[c * 8 + e] - s1 - xh * s2));
+    }
+    *reinterpret_cast<u16x8_t*>(dxr + c * 8) = o;
+  }
+}
+
+// dgamma[c] (+)= sum_r dy[r,c] * xhat[r,c] ; dbeta[c] (+)= sum_r dy[r,c]   (64 columns per workgroup, fixed order)
+__global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                                   const float* __restrict__ mean_in,
+                                                                   const float* __restrict__ rstd_in,
+                                                                   const bf16_t* __restrict__ dy, int64_t lddy,
+                                                                   float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, int64_t M, int d,
+                                                                   int accumulate) {
+  __shared__ float rg[32][65], rb[32][65];
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64 + tx * 8;
+  float ag[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ab[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < d) {
+    for (int64_t m = ty; m < M; m += 32) {
+      const u16x8_t v = *reinterpret_cast<const u16x8_t*>(x + m * ldx + c0);
+      const u16x8_t g = *reinterpret_cast<const u16x8_t*>(dy + m * lddy + c0);
+      const float mean = mean_in[m], rstd = rstd_in[m];
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float gf = bf2f(g[e]);
+        ag[e] += gf * (bf2f(v[e]) - mean) * rstd;
+        ab[e] += gf;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    rg[ty][tx * 8 + e] = ag[e];
+    rb[ty][tx * 8 + e] = ab[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < d) {
+      float sg = 0.f, sb = 0.f;
+#pragma unroll
+      for (int r = 0; r < 32; r++) {
+        sg += rg[r][threadIdx.x];
+        sb += rb[r][threadIdx.x];
+      }
+      dgamma[c] = accumulate ? dgamma[c] + sg : sg;
+      dbeta[c] = accumulate ? dbeta[c] + sb : sb;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int slam_layernorm_fwd(const void* x, int64_t ldx, const float* weight, const float* bias,
-                                  void* y, int64_t ldy, int64_t M, int64_t d, float eps, int act, void* stream) {
+                                  void* y, int64_t ldy, int64_t M, int64_t d, float eps, int act, float* mean_out,
+                                  float* rstd_out, void* stream) {
+  SLAM_CHECK_ARG((mean_out == nullptr) == (rstd_out == nullptr), "slam_layernorm_fwd: mean/rstd outputs must both be set or both null");
   SLAM_CHECK_ARG(act == 0 || act == 1, "slam_layernorm_fwd: act %d unknown (0 none, 1 gelu)", act);
   SLAM_CHECK_ARG(x && weight && bias && y, "slam_layernorm_fwd: null pointer");
   SLAM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0, "slam_layernorm_fwd: bad shape M=%ld d=%ld (d%%8 must be 0)", (long)M, (long)d);
   SLAM_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= d && ldy >= d, "slam_layernorm_fwd: bad leading dims");
   const unsigned grid = (unsigned)cdiv64(M, ROWS_PER_BLOCK);
   hipLaunchKernelGGL(layernorm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                     ldx, weight, bias, (bf16_t*)y, ldy, (int)M, (int)d, eps, act);
+                     ldx, weight, bias, (bf16_t*)y, ldy, (int)M, (int)d, eps, act, mean_out, rstd_out);
   SLAM_CHECK_LAUNCH("slam_layernorm_fwd");
   return 0;
 }
@@ -183,5 +278,22 @@ extern "C" int slam_rmsnorm_bwd(const void* x, int64_t ldx, const float* rstd, c
                      (const bf16_t*)x, ldx, rstd, weight, (const bf16_t*)dy, lddy, (const bf16_t*)dres,
                      lddres, (bf16_t*)dx, lddx, grad_scale, (int)M, (int)d);
   SLAM_CHECK_LAUNCH("slam_rmsnorm_bwd");
+  return 0;
+}
+
+extern "C" int slam_layernorm_bwd(const void* x, int64_t ldx, const float* mean, const float* rstd, const float* weight,
+                                  const void* dy, int64_t lddy, void* dx, int64_t lddx, float* dgamma, float* dbeta,
+                                  int64_t M, int64_t d, int accumulate, void* stream) {
+  SLAM_CHECK_ARG(x && mean && rstd && weight && dy, "slam_layernorm_bwd: null pointer");
+  SLAM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && (!dx || lddx % 8 == 0), "slam_layernorm_bwd: bad shape");
+  SLAM_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "slam_layernorm_bwd: dgamma/dbeta must both be set or both null");
+  hipStream_t s = (hipStream_t)stream;
+  if (dx)
+    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((unsigned)cdiv64(M, ROWS_PER_BLOCK)), dim3(256), 0, s, (const bf16_t*)x, ldx,
+                       mean, rstd, weight, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (int)M, (int)d);
+  if (dgamma)
+    hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3((unsigned)cdiv64(d, 64)), dim3(256), 0, s, (const bf16_t*)x, ldx, mean,
+                       rstd, (const bf16_t*)dy, lddy, dgamma, dbeta, M, (int)d, accumulate);
+  SLAM_CHECK_LAUNCH("slam_layernorm_bwd");
   return 0;
 }

@@ -32,7 +32,10 @@ SIGNATURES = {
     "slam_gemm_set_config": [I32],
     "slam_conv1d_k3_im2col": [P, I32, P, I64, I64, I64, I64, I64, P],
     "slam_conv1d_im2col": [P, I32, I64, I64, I64, P, I64, I64, I64, I64, I64, I64, I64, P],
-    "slam_layernorm_fwd": [P, I64, P, P, P, I64, I64, I64, F, I32, P],
+    "slam_layernorm_fwd": [P, I64, P, P, P, I64, I64, I64, F, I32, P, P, P],
+    "slam_layernorm_bwd": [P, I64, P, P, P, P, I64, P, I64, P, P, I64, I64, I32, P],
+    "slam_gelu_fwd": [P, I64, P, I64, I64, I64, P],
+    "slam_gelu_bwd": [P, I64, P, I64, P, I64, I64, I64, P],
     "slam_rmsnorm_fwd": [P, I64, P, P, I64, P, I64, I64, F, P],
     "slam_rmsnorm_bwd": [P, I64, P, P, P, I64, P, I64, P, I64, P, I64, I64, P],
     "slam_head_rope_transpose": [P, I64, I64, P, P, I32, P, I64, I64, I64, I64, I64, P],
@@ -54,6 +57,8 @@ SIGNATURES = {
     "slam_ce_finalize": [P, P, P, I64, P, P],
     "slam_adamw_step": [P, P, P, P, P, I64, F, F, F, F, F, I64, F, P],
     "slam_cast_f32_to_bf16": [P, P, I64, P],
+    "slam_cast_bf16_to_f32": [P, P, I64, I32, P],
+    "slam_add_bf16": [P, I64, P, I64, I64, I64, P],
 }
 
 

@@ -723,7 +723,12 @@ class SlamHipModel(nn.Module):
         else:
             self.encoder = HipWhisperEncoder(cfg, self.device_)
         self.llm = HipLlamaLora(cfg, self.store, self.device_)          # reserves LoRA (last layer first)
-        self.encoder_projector = HipProjectorConcat(cfg, self.store)    # projector last = produced last in backward
+        self.projector_name = cfg.get("projector", "linear")
+        if self.projector_name == "q-former":
+            from .qformer import HipProjectorQFormer
+            self.encoder_projector = HipProjectorQFormer(cfg, self.store)
+        else:
+            self.encoder_projector = HipProjectorConcat(cfg, self.store)  # projector last = produced last in backward
         self.store.allocate()
         self.llm.bind()
         self.encoder_projector.bind()
@@ -807,7 +812,12 @@ class SlamHipModel(nn.Module):
                 # GPU log-mel front end (replaces the CPU DataLoader mel of speech_dataset.py:101-103)
                 audio_mel = ops.logmel(audio.float(), self.cfg["n_mels"], n_valid=kwargs.get("audio_len", None))
             enc = self.encoder.forward_btc(audio_mel.float().contiguous())
-        proj = self.encoder_projector.forward_hip(enc, stash)  # [B, Ta, dl]
+        if self.projector_name == "q-former":
+            # audio_mel_post_mask is consumed only by this branch (slam_model.py:354-355); None = attend to all
+            pmask = kwargs.get("audio_mel_post_mask", None) if self.encoder_name == "whisper" else None
+            proj = self.encoder_projector.forward_hip(enc, pmask, stash)
+        else:
+            proj = self.encoder_projector.forward_hip(enc, stash)  # [B, Ta, dl]
         Ta = proj.shape[1]
         if modality_mask is None:
             raise RuntimeError("modality_mask is required (speech recipes always provide it)")

@@ -190,11 +190,41 @@ def conv1d_k3_im2col(x: torch.Tensor, stride: int, Kp: int) -> torch.Tensor:
     return out
 
 
-def layernorm(x, weight, bias, eps=1e-5, out=None, gelu=False):
+def layernorm(x, weight, bias, eps=1e-5, out=None, gelu=False, stats=False):
+    """stats=True additionally returns (mean, rstd) fp32 [M] for slam_layernorm_bwd"""
     M, d = x.shape
     if out is None:
         out = torch.empty((M, d), dtype=torch.bfloat16, device=x.device)
-    call("slam_layernorm_fwd", _p(x), _ld(x), _p(weight), _p(bias), _p(out), _ld(out), M, d, eps, 1 if gelu else 0, _s())
+    mean = rstd = None
+    if stats:
+        mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+    call("slam_layernorm_fwd", _p(x), _ld(x), _p(weight), _p(bias), _p(out), _ld(out), M, d, eps, 1 if gelu else 0,
+         _p(mean), _p(rstd), _s())
+    return (out, mean, rstd) if stats else out
+
+
+def layernorm_bwd(x, mean, rstd, weight, dy, dgamma=None, dbeta=None, want_dx=True, accumulate=False):
+    M, d = x.shape
+    dx = torch.empty((M, d), dtype=torch.bfloat16, device=x.device) if want_dx else None
+    call("slam_layernorm_bwd", _p(x), _ld(x), _p(mean), _p(rstd), _p(weight), _p(dy), _ld(dy), _p(dx),
+         _ld(dx) if dx is not None else 0, _p(dgamma), _p(dbeta), M, d, 1 if accumulate else 0, _s())
+    return dx
+
+
+def gelu_fwd(z, out=None):
+    M, N = z.shape
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=z.device)
+    call("slam_gelu_fwd", _p(z), _ld(z), _p(out), _ld(out), M, N, _s())
+    return out
+
+
+def gelu_bwd(z, dy, out=None):
+    M, N = z.shape
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=z.device)
+    call("slam_gelu_bwd", _p(z), _ld(z), _p(dy), _ld(dy), _p(out), _ld(out), M, N, _s())
     return out
 
 
@@ -379,3 +409,14 @@ def skinny_gram(S2d, X2d, out, out_ld_r, out_ld_c, alpha=1.0, accumulate=False):
     call("slam_skinny_gram", _p(S2d), _ld(S2d), _p(X2d), _ld(X2d), _p(out), out_ld_r, out_ld_c, M, R, C, alpha,
          1 if accumulate else 0, _p(_GRAM_WS[key]), _s())
     return out
+
+
+def cast_f32_(src_bf16, dst_f32, accumulate=False):
+    call("slam_cast_bf16_to_f32", _p(src_bf16), _p(dst_f32), src_bf16.numel(), 1 if accumulate else 0, _s())
+    return dst_f32
+
+
+def add_(a2d, b2d):
+    M, N = a2d.shape
+    call("slam_add_bf16", _p(a2d), _ld(a2d), _p(b2d), _ld(b2d), M, N, _s())
+    return a2d

@@ -178,3 +178,45 @@ def test_hubert_linear_llm_step_matches_oracle(dev):
     assert abs(float(outputs.loss.detach()) - float(loss_ref)) < 1e-2
     outputs.loss.backward()
     assert torch.isfinite(model.store.grad).all() and float(model.store.grad.abs().sum()) > 0
+
+
+def test_qformer_projector_matches_reference_fixture(dev):
+    """a3': Q-Former projector forward + every parameter gradient vs the reference module's fixture"""
+    from oracle.make_golden_cases import QFORMER_CASE as C
+    from slam_llm_amd.model import TrainableStore
+    from slam_llm_amd.qformer import HipProjectorQFormer
+    fx = G.load("qformer")
+    cfg = dict(C["cfg"], enc_dim=C["enc_dim"], llm_dim=C["llm_dim"])
+    W = O.init_qformer_weights(C["cfg"], C["enc_dim"], C["llm_dim"], seed=11)
+    store = TrainableStore(dev)
+    qf = HipProjectorQFormer(cfg, store)
+    store.allocate()
+    qf.bind()
+    with torch.no_grad():
+        for n, p in store.params.items():
+            p.copy_(W[n].to(dev))
+    assert set(store.params) == set(W)
+    store.refresh_bf16()
+    qf.refresh()
+    x = torch.from_numpy(fx["x"]).to(dev).to(torch.bfloat16)
+    atts = torch.from_numpy(fx["atts"]).to(dev)
+    stash = {}
+    out = qf.forward_hip(x, atts, stash)
+    g, a = G.sub(fx, "out", out.float().cpu().numpy())
+    assert rel_err(a, g) < 3e-2 and G.cosine(g, a) > 0.9995, (rel_err(a, g), G.cosine(g, a))
+    cot = torch.from_numpy(fx["cot"]).to(dev).to(torch.bfloat16).reshape(-1, C["llm_dim"]).contiguous()
+    qf.backward_hip(cot, stash, acc=False)
+    worst = 1.0
+    for n in W:
+        gold, mine = G.sub(fx, "grad." + n, store.grad_view(n).float().cpu().numpy())
+        gn = float(fx["grad." + n + ".__norm"])
+        if gn < 1e-4:  # key biases: mathematically zero gradient
+            assert np.abs(mine).max() < 3e-2, n  # bf16 rounding noise of the dK column sum
+            continue
+        cs = G.cosine(gold, mine)
+        worst = min(worst, cs)
+        assert cs > 0.998, f"grad {n}: cosine {cs}"
+        mn = float(np.sqrt((store.grad_view(n).float().cpu().numpy().astype(np.float64) ** 2).sum()))
+        assert abs(mn - gn) < 4e-2 * gn, f"grad {n}: norm {mn} vs {gn}"
+    # state-dict keys equal the reference module's
+    assert {k for k in qf.state_dict()} == {k[len("encoder_projector."):] for k in W}

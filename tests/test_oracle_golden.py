@@ -81,3 +81,19 @@ def test_hubert_encoder_matches_hf_twin_of_reference():
         out = O.hubert_encoder(W, HUBERT_TINY, torch.from_numpy(fx["wav"]))
     assert list(out.shape) == [int(x) for x in fx["out_shape"]]
     G.check_packed(fx, "out", out.numpy(), atol=3e-5, rtol=1e-4)
+
+
+def test_qformer_projector_matches_reference_module():
+    from oracle.make_golden_cases import QFORMER_CASE as C
+    fx = G.load("qformer")
+    W = O.init_qformer_weights(C["cfg"], C["enc_dim"], C["llm_dim"], seed=11)
+    for v in W.values():
+        v.requires_grad_(True)
+    out = O.projector_qformer(W, C["cfg"], torch.from_numpy(fx["x"]), torch.from_numpy(fx["atts"]))
+    G.check_packed(fx, "out", out.detach().numpy(), atol=3e-5, rtol=1e-4)
+    (out * torch.from_numpy(fx["cot"])).sum().backward()
+    for n, v in W.items():
+        # key biases have a mathematically zero gradient (softmax is invariant to a per-query constant): pure
+        # rounding noise, compared in absolute terms only
+        tiny = float(fx["grad." + n + ".__norm"]) < 1e-4
+        G.check_packed(fx, "grad." + n, v.grad.numpy(), atol=2e-5, rtol=2e-3, norm_rtol=None if tiny else 1e-3)
