@@ -44,24 +44,45 @@ def _guess_preset(name: str, table) -> str:
     raise ValueError(f"cannot map '{name}' to a known architecture preset {sorted(table)}; pass model_config.arch_*")
 
 
+HUBERT_PRESETS = {
+    # fairseq / HF HubertConfig geometry
+    "hubert-large": dict(hub_conv_dim=(512,) * 7, hub_conv_kernel=(10, 3, 3, 3, 3, 2, 2), hub_conv_stride=(5, 2, 2, 2, 2, 2, 2),
+                         hub_dim=1024, hub_heads=16, hub_layers=24, hub_ffn=4096, hub_pos_k=128, hub_pos_groups=16, hub_eps=1e-5),
+    "hubert-xlarge": dict(hub_conv_dim=(512,) * 7, hub_conv_kernel=(10, 3, 3, 3, 3, 2, 2), hub_conv_stride=(5, 2, 2, 2, 2, 2, 2),
+                          hub_dim=1280, hub_heads=20, hub_layers=48, hub_ffn=5120, hub_pos_k=128, hub_pos_groups=16, hub_eps=1e-5),
+}
+
+
 def build_config(train_config, model_config) -> dict:
     enc_name = _get(model_config, "encoder_name", "whisper")
-    if enc_name != "whisper":
-        raise NotImplementedError(f"encoder_name={enc_name}: only the Whisper branch (src/slam_llm/models/slam_model.py:320-321) "
-                                  "is on the HIP path this round; HuBERT/WavLM are SURVEY 8(f) rows")
-    if _get(model_config, "encoder_projector", "linear") != "linear":
-        raise NotImplementedError("only encoder_projector=linear (EncoderProjectorConcat) is on the HIP path this round")
+    if enc_name not in ("whisper", "hubert"):
+        raise NotImplementedError(f"encoder_name={enc_name}: the HIP path covers the Whisper (slam_model.py:320-321) and HuBERT "
+                                  "(:335-341) branches; WavLM & co. are SURVEY 8(f) rows")
+    projector = _get(model_config, "encoder_projector", "linear")
+    if projector not in ("linear", "q-former"):
+        raise NotImplementedError("encoder_projector must be `linear` (EncoderProjectorConcat) or `q-former` "
+                                  "(EncoderProjectorQFormer); cov1d-linear is a SURVEY 8(f) row")
     enc_presets = {k: v for k, v in PRESETS.items() if k.startswith("whisper")}
     llm_presets = {k: v for k, v in PRESETS.items() if not k.startswith("whisper")}
-    enc = _get(model_config, "arch_encoder") or _guess_preset("whisper-" + str(_get(model_config, "encoder_path", "")).split("/")[-1].replace(".pt", ""), enc_presets)
     llm = _get(model_config, "arch_llm") or _guess_preset(str(_get(model_config, "llm_name", "")), llm_presets)
     peft = _get(train_config, "peft_config", None)
     use_peft = bool(_get(train_config, "use_peft", False))
+    extra = dict(encoder_name=enc_name, projector=projector)
+    if enc_name == "hubert":
+        hp = _get(model_config, "arch_encoder") or _guess_preset(str(_get(model_config, "encoder_path", "hubert-large")).replace("_", "-"), HUBERT_PRESETS)
+        extra.update(HUBERT_PRESETS[hp])
+        extra["enc_dim"] = extra["hub_dim"]
+        enc = None
+    else:
+        enc = _get(model_config, "arch_encoder") or _guess_preset("whisper-" + str(_get(model_config, "encoder_path", "")).split("/")[-1].replace(".pt", ""), enc_presets)
+    if projector == "q-former":
+        extra.update(qf_dim=768, qf_heads=12, qf_ffn=3072, qf_eps=1e-12, qf_cross_freq=2,
+                     qf_layers=int(_get(model_config, "qformer_layers", 8)), qf_queries=int(_get(model_config, "query_len", 64)))
     cfg = make_config(enc, llm,
                       ds_rate=int(_get(model_config, "encoder_projector_ds_rate", 5)),
                       lora_r=int(_get(peft, "r", 8)), lora_alpha=float(_get(peft, "lora_alpha", 32)),
                       lora_targets=tuple(_get(peft, "target_modules", ("q_proj", "v_proj"))) if use_peft else (),
-                      lora_dropout=float(_get(peft, "lora_dropout", 0.05)) if use_peft else 0.0)
+                      lora_dropout=float(_get(peft, "lora_dropout", 0.05)) if use_peft else 0.0, **extra)
     if int(_get(model_config, "encoder_dim", cfg["enc_dim"])) != cfg["enc_dim"] or int(_get(model_config, "llm_dim", cfg["llm_dim"])) != cfg["llm_dim"]:
         raise ValueError("model_config.encoder_dim / llm_dim do not match the selected architecture presets")
     return cfg

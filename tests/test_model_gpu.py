@@ -220,3 +220,38 @@ def test_qformer_projector_matches_reference_fixture(dev):
         assert abs(mn - gn) < 4e-2 * gn, f"grad {n}: norm {mn} vs {gn}"
     # state-dict keys equal the reference module's
     assert {k for k in qf.state_dict()} == {k[len("encoder_projector."):] for k in W}
+
+
+def test_c4_hubert_qformer_llm_step_matches_oracle(dev):
+    """BASELINE config 4 shape (HuBERT -> Q-Former -> LLM+LoRA), tiny widths: loss vs oracle, then 2 optimizer steps"""
+    from oracle.make_golden_cases import HUBERT_TINY
+    from slam_llm_amd.model import SlamAdamW, SlamHipModel
+    qcfg = O.qformer_config(qf_layers=2, qf_queries=8)
+    cfg = dict(O.make_config(), **HUBERT_TINY, **qcfg)
+    cfg.update(encoder_name="hubert", projector="q-former", enc_dim=HUBERT_TINY["hub_dim"])
+    W = {k: v for k, v in O.init_weights(cfg, seed=42).items() if not k.startswith(("encoder.", "encoder_projector."))}
+    W.update(O.init_hubert_weights(HUBERT_TINY, seed=7))
+    W.update(O.init_qformer_weights(qcfg, cfg["enc_dim"], cfg["llm_dim"], seed=11))
+    model = SlamHipModel(dict(cfg, lora_dropout=0.0), dev).load_weights(W)
+    model.train()
+    wav = torch.nn.functional.layer_norm(O.synth_audio(2, 1.0, seed=9), (16000,))
+    Q = qcfg["qf_queries"]
+    samples = [O.make_sample(Q, [5, 6, 7], [9, 10, 11, 12], 2), O.make_sample(Q, [5, 6], [9, 10], 2)]
+    ob = O.collate_left_pad(samples, pad_id=2)
+    with torch.no_grad():
+        enc = O.hubert_encoder(W, cfg, wav)
+        proj = O.projector_qformer(W, qcfg, enc, None)
+        emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+        loss_ref, _ = O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
+    gb = {k: v.to(dev) for k, v in ob.items()}
+    gb["audio"] = wav.to(dev)
+    opt = SlamAdamW(model, lr=1e-3)
+    losses = []
+    for _ in range(3):
+        outputs, acc = model(**{k: v.clone() for k, v in gb.items()})
+        outputs.loss.backward()
+        opt.step(); opt.zero_grad()
+        losses.append(float(outputs.loss.detach()))
+    assert abs(losses[0] - float(loss_ref)) < 1.5e-2, (losses[0], float(loss_ref))
+    assert losses[2] < losses[0]  # it trains
+    assert torch.isfinite(model.store.flat).all()
