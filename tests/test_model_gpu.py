@@ -255,3 +255,37 @@ def test_c4_hubert_qformer_llm_step_matches_oracle(dev):
     assert abs(losses[0] - float(loss_ref)) < 1.5e-2, (losses[0], float(loss_ref))
     assert losses[2] < losses[0]  # it trains
     assert torch.isfinite(model.store.flat).all()
+
+
+def test_checkpoint_wire_format_round_trip(dev, tmp_path):
+    """the trainable-only checkpoint of save_model_checkpoint_peft (utils/checkpoint_handler.py:185-201:
+    {name: state_dict[name] for requires_grad params} -> model.pt) reloads through ckpt_path/load_state_dict(strict=False)
+    (models/slam_model.py:44-48) and reproduces the loss bit-for-bit."""
+    cfg = CASES["step_tiny"]["cfg"]
+    fx = G.load("step_tiny")
+    model, W = build(cfg, dev)
+    model.train()
+    b = batch_from_fixture(fx, dev)
+    from slam_llm_amd.model import SlamAdamW
+    opt = SlamAdamW(model, lr=1e-2)
+    for _ in range(2):
+        out, _ = model(**{k: v.clone() for k, v in b.items()})
+        out.loss.backward(); opt.step(); opt.zero_grad()
+    sd = model.state_dict()
+    cpu_state = {}
+    for name, p in model.named_parameters():      # what save_model_checkpoint_peft does
+        if p.requires_grad:
+            cpu_state[name] = sd[name].cpu()
+    assert set(cpu_state) == set(O.trainable_names(W))
+    path = tmp_path / "model.pt"
+    torch.save(cpu_state, path)
+    with torch.no_grad():
+        ref_loss = float(model(**{k: v.clone() for k, v in b.items()})[0].loss)
+    fresh, _ = build(cfg, dev)
+    missing = fresh.load_state_dict(torch.load(path, map_location="cpu"), strict=False)
+    assert not missing.unexpected_keys
+    fresh.mark_params_updated()
+    fresh.train()
+    with torch.no_grad():
+        got = float(fresh(**{k: v.clone() for k, v in b.items()})[0].loss)
+    assert got == ref_loss
