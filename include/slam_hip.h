@@ -38,11 +38,13 @@ const char* slam_target_arch(void); /* "gfx950" */
  * audio [B, ld_audio] f32; n_valid[b] (nullable) = samples of clip b that are real (rest treated as the
  * zero padding of pad_or_trim); n_samples = padded length (480000); window400 = periodic Hann;
  * twiddle_400x416 = [n][0..207]=cos(2*pi*n*k/400), [n][208..415]=sin; mel_filters_T [201, n_mels];
- * out_mel [B, n_samples/160, n_mels] f32; workspace: slam_logmel_workspace_bytes(B) bytes. */
+ * out_mel [B, n_samples/160, n_mels] f32; workspace: slam_logmel_workspace_bytes(B) bytes.
+ * per_clip != 0: pad_or_trim OFF (speech_dataset_large.py:102-104 with pad_or_trim=false): each clip's STFT runs over its own
+ * n_valid[b] samples, it owns n_valid[b]/160 frames, the remaining rows are the collator's mel-space zeros. */
 int slam_logmel_workspace_bytes(int64_t B);
 int slam_logmel_fwd(const float* audio, int64_t ld_audio, const int32_t* n_valid, int64_t n_samples,
                     const float* window400, const float* twiddle_400x416, const float* mel_filters_T,
-                    int64_t n_mels, float* out_mel, int32_t* workspace, int64_t B, void* stream);
+                    int64_t n_mels, float* out_mel, int32_t* workspace, int64_t B, int per_clip, void* stream);
 
 /* ---- GEMM: every Linear / Conv1d-as-GEMM / lm_head on the path ---------------------------------
  * C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): +bias[N] (f32), act, +residual[(m % res_row_mod), n] (bf16),
@@ -53,7 +55,8 @@ int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, vo
                       int64_t M, int64_t N, int64_t K, const float* bias, const void* residual,
                       int64_t ldr, int64_t res_row_mod, int act, float alpha, int out_dtype,
                       int accumulate, void* stream);
-/* tile configuration override: 0 auto, 1 128x128/4 waves, 2 256x128/8 waves, 3 128x64, 4 256x256/8 waves */
+/* tile configuration override: 0 auto, 1 128x128/4 waves, 2 256x128/8 waves, 3 128x64, 4 256x256/8 waves (2-stage loop),
+ * 5/6 256x256 register-double-buffered pipeline (6 = shipped schedule) */
 int slam_gemm_set_config(int cfg);
 
 /* ---- conv front end (src/slam_llm/models/encoder.py:18-19): k=3, pad=1 im2col, stride 1|2 ---------

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
   auto stage = [&](int kt, int s) {
     char* sa = smem + s * STAGE;
     char* sb = sa + BM * ROWB;
-    const int koff = (VAR == 9) ? 0 : kt * BK;
+    const int koff = kt * BK;
 #pragma unroll
     for (int j = 0; j < NIA; j++) glds16(a_src[j] + koff, sa + (j * NW + wave) * 1024);
 #pragma unroll
@@ -357,6 +357,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
 #pragma unroll
       for (int j = 0; j < FN; j++)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+    // measured on MI355X: DMA issue first, fragment prefetch second beats the reverse order by 3-5 %, and s_setprio
+    // around the MFMA runs is a loss on this schedule (profiles/r01_gemm_pmc.md)
 #pragma unroll
     for (int g = 0; g < NIA + NIB; g++) {  // DMA issue spread over the first MFMAs
       __builtin_amdgcn_sched_group_barrier(0x010, 1, 1);
@@ -398,7 +400,7 @@ int g_gemm_cfg = 0;  // 0 = auto
 }  // namespace
 
 extern "C" int slam_gemm_set_config(int cfg) {
-  SLAM_CHECK_ARG(cfg >= 0 && cfg <= 8, "slam_gemm_set_config: cfg %d out of range [0,8]", cfg);
+  SLAM_CHECK_ARG(cfg >= 0 && cfg <= 6, "slam_gemm_set_config: cfg %d out of range [0,6]", cfg);
   g_gemm_cfg = cfg;
   return 0;
 }
@@ -445,10 +447,8 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     case 2: return launch_gemm<256, 128, 4, 2>(p, s);
     case 3: return launch_gemm<128, 64, 2, 2>(p, s);
     case 4: return launch_gemm<256, 256, 2, 4>(p, s);
-    case 5: return launch_gemm<256, 256, 2, 4, 0>(p, s);
-    case 6: return launch_gemm<256, 256, 2, 4, 1>(p, s);
-    case 7: return launch_gemm<256, 256, 4, 2, 0>(p, s);
-    case 8: return launch_gemm<256, 256, 2, 4, 9>(p, s);  // timing experiment only (wrong results by design)
+    case 5: return launch_gemm<256, 256, 2, 4, 0>(p, s);  // pipelined, compiler-placed barrier (A/B reference)
+    case 6: return launch_gemm<256, 256, 2, 4, 1>(p, s);  // pipelined, phase A pinned before the barrier (shipped)
   }
   slam_set_error("slam_gemm_bf16_nt: bad config %d", cfg);
   return -1;

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void logmel_stft_kernel(const float* __restric
                                                           const float* __restrict__ twiddle,
                                                           const float* __restrict__ melT, int n_mels,
                                                           float* __restrict__ out, int n_frames,
-                                                          int* __restrict__ clipmax) {
+                                                          int* __restrict__ clipmax, int per_clip) {
   __shared__ float lds[FR * XLD];  // frames [32][401]; later re-used as power [32][209]
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,16 +47,21 @@ __global__ __launch_bounds__(256) void logmel_stft_kernel(const float* __restric
   const int b = blockIdx.y, f0 = blockIdx.x * FR;
   const float* x = audio + (int64_t)b * ld_audio;
   const int nv = n_valid ? min(n_valid[b], N) : N;
+  // per_clip: the clip is NOT padded to N first (pad_or_trim off, speech_dataset_large.py:102-104): its own length is
+  // the STFT length (reflection about its own end), it owns nv/160 frames and the rest of the row is mel-space zero
+  // padding added by the collator (speech_dataset_large.py:194-197) -- exact zeros, excluded from the clip maximum.
+  const int clipN = per_clip ? nv : N;
+  const int clip_frames = per_clip ? nv / HOP : n_frames;
 
   for (int i = tid; i < FR * NFFT; i += 256) {
     const int r = i / NFFT, n = i % NFFT;
     const int f = f0 + r;
     float v = 0.f;
-    if (f < n_frames) {
+    if (f < clip_frames) {
       int j = f * HOP + n - NFFT / 2;
       if (j < 0) j = -j;
-      if (j >= N) j = 2 * (N - 1) - j;
-      v = (j < nv) ? x[j] * window[n] : 0.f;
+      if (j >= clipN) j = 2 * (clipN - 1) - j;
+      v = (j >= 0 && j < nv) ? x[j] * window[n] : 0.f;
     }
     lds[r * XLD + n] = v;
   }
@@ -109,6 +114,10 @@ __global__ __launch_bounds__(256) void logmel_stft_kernel(const float* __restric
     const int r = idx / n_mels, m = idx % n_mels;
     const int f = f0 + r;
     if (f >= n_frames) continue;
+    if (f >= clip_frames) {
+      out[((int64_t)b * n_frames + f) * n_mels + m] = 0.f;
+      continue;
+    }
     float acc = 0.f;
     for (int k = 0; k < NBIN; k++) acc = fmaf(lds[r * PLD + k], melT[k * n_mels + m], acc);
     const float lv = log10f(fmaxf(acc, 1e-10f));
@@ -119,12 +128,16 @@ __global__ __launch_bounds__(256) void logmel_stft_kernel(const float* __restric
   if (tid == 0 && lmax > -INFINITY) atomicMax(clipmax + b, f2ord(lmax));
 }
 
-__global__ __launch_bounds__(256) void logmel_finish_kernel(float* __restrict__ out, int64_t per_clip,
-                                                            const int* __restrict__ clipmax) {
+__global__ __launch_bounds__(256) void logmel_finish_kernel(float* __restrict__ out, int64_t elems_per_clip,
+                                                            const int* __restrict__ clipmax,
+                                                            const int* __restrict__ n_valid, int n_mels, int N,
+                                                            int per_clip) {
   const int b = blockIdx.y;
   const float floorv = ord2f(clipmax[b]) - 8.0f;
-  float* o = out + (int64_t)b * per_clip;
-  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < per_clip; i += (int64_t)gridDim.x * 256)
+  float* o = out + (int64_t)b * elems_per_clip;
+  int64_t live = elems_per_clip;  // elements that belong to real frames of this clip
+  if (per_clip) live = (int64_t)(min(n_valid[b], N) / HOP) * n_mels;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < live; i += (int64_t)gridDim.x * 256)
     o[i] = (fmaxf(o[i], floorv) + 4.0f) / 4.0f;
 }
 
@@ -135,7 +148,8 @@ extern "C" int slam_logmel_workspace_bytes(int64_t B) { return (int)(B * sizeof(
 extern "C" int slam_logmel_fwd(const float* audio, int64_t ld_audio, const int32_t* n_valid,
                                int64_t n_samples, const float* window400, const float* twiddle_400x416,
                                const float* mel_filters_T, int64_t n_mels, float* out_mel,
-                               int32_t* workspace, int64_t B, void* stream) {
+                               int32_t* workspace, int64_t B, int per_clip, void* stream) {
+  SLAM_CHECK_ARG(!per_clip || n_valid, "slam_logmel_fwd: per_clip mode needs n_valid");
   SLAM_CHECK_ARG(audio && window400 && twiddle_400x416 && mel_filters_T && out_mel && workspace,
                  "slam_logmel_fwd: null pointer");
   SLAM_CHECK_ARG(B > 0 && B < 65536, "slam_logmel_fwd: bad batch %ld", (long)B);
@@ -148,10 +162,11 @@ extern "C" int slam_logmel_fwd(const float* audio, int64_t ld_audio, const int32
   hipLaunchKernelGGL(logmel_init_kernel, dim3((unsigned)cdiv64(B, 256)), dim3(256), 0, s, workspace, (int)B);
   dim3 grid((unsigned)cdiv64(n_frames, FR), (unsigned)B);
   hipLaunchKernelGGL(logmel_stft_kernel, grid, dim3(256), 0, s, audio, ld_audio, n_valid, (int)n_samples,
-                     window400, twiddle_400x416, mel_filters_T, (int)n_mels, out_mel, n_frames, workspace);
-  const int64_t per_clip = (int64_t)n_frames * n_mels;
-  dim3 grid2((unsigned)std::min<int64_t>(cdiv64(per_clip, 256), 1024), (unsigned)B);
-  hipLaunchKernelGGL(logmel_finish_kernel, grid2, dim3(256), 0, s, out_mel, per_clip, workspace);
+                     window400, twiddle_400x416, mel_filters_T, (int)n_mels, out_mel, n_frames, workspace, per_clip);
+  const int64_t per_clip_elems = (int64_t)n_frames * n_mels;
+  dim3 grid2((unsigned)std::min<int64_t>(cdiv64(per_clip_elems, 256), 1024), (unsigned)B);
+  hipLaunchKernelGGL(logmel_finish_kernel, grid2, dim3(256), 0, s, out_mel, per_clip_elems, workspace, n_valid, (int)n_mels,
+                     (int)n_samples, per_clip);
   SLAM_CHECK_LAUNCH("slam_logmel_fwd");
   return 0;
 }

@@ -27,7 +27,7 @@ P, I64, I32, F = c_void_p, c_int64, c_int, c_float
 # name -> argtypes; every symbol of include/slam_hip.h (tests/test_capi_symbols.py checks the two agree)
 SIGNATURES = {
     "slam_logmel_workspace_bytes": [I64],
-    "slam_logmel_fwd": [P, I64, P, I64, P, P, P, I64, P, P, I64, P],
+    "slam_logmel_fwd": [P, I64, P, I64, P, P, P, I64, P, P, I64, I32, P],
     "slam_gemm_bf16_nt": [P, I64, P, I64, P, I64, I64, I64, I64, P, P, I64, I64, I32, F, I32, I32, P],
     "slam_gemm_set_config": [I32],
     "slam_conv1d_k3_im2col": [P, I32, P, I64, I64, I64, I64, I64, P],

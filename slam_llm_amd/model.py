@@ -810,7 +810,12 @@ class SlamHipModel(nn.Module):
                 if audio is None:
                     raise RuntimeError("batch carries neither audio_mel nor audio")
                 # GPU log-mel front end (replaces the CPU DataLoader mel of speech_dataset.py:101-103)
-                audio_mel = ops.logmel(audio.float(), self.cfg["n_mels"], n_valid=kwargs.get("audio_len", None))
+                if self.cfg.get("pad_or_trim", True):   # reference default (aispeech_asr_config.py:106; unconditional in speech_dataset.py:101)
+                    audio_mel = ops.logmel(audio.float(), self.cfg["n_mels"], n_valid=kwargs.get("audio_len", None))
+                else:                                   # ragged clips: mel over each clip's own length, zero padded to the batch max
+                    alen = kwargs.get("audio_len", None)
+                    nmax = min(480000, round_up(int(audio.shape[1]), 160))
+                    audio_mel = ops.logmel(audio.float(), self.cfg["n_mels"], n_samples=nmax, n_valid=alen, per_clip=True)
             enc = self.encoder.forward_btc(audio_mel.float().contiguous())
         if self.projector_name == "q-former":
             # audio_mel_post_mask is consumed only by this branch (slam_model.py:354-355); None = attend to all

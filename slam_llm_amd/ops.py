@@ -93,8 +93,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
 
 _GEMM_CFG = 0
 _GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
-               4: "gemm_nt_kernel<256,256,2,4>", 5: "gemm_nt_pipe_kernel<256,256,2,4>",
-               6: "gemm_nt_pipe_kernel<256,256,2,4,v1>", 7: "gemm_nt_pipe_kernel<256,256,4,2>", 8: "gemm_nt_pipe_kernel<debug>"}
+               4: "gemm_nt_kernel<256,256,2,4>", 5: "gemm_nt_pipe_kernel<256,256,2,4,0>",
+               6: "gemm_nt_pipe_kernel<256,256,2,4,1>"}
 
 
 def gemm_kernel_name(M: int, N: int) -> str:
@@ -163,18 +163,22 @@ def _mel_tables(n_mels: int, device):
     return _MEL_TABLES[key]
 
 
-def logmel(audio: torch.Tensor, n_mels: int, n_samples: int = 480000,
-           n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """audio [B, >=?] f32 on device -> [B, n_samples/160, n_mels] f32 (pad_or_trim + log_mel_spectrogram)."""
+def logmel(audio: torch.Tensor, n_mels: int, n_samples: int = 480000, n_valid: Optional[torch.Tensor] = None,
+           per_clip: bool = False) -> torch.Tensor:
+    """audio [B, N'] f32 on device -> [B, n_samples/160, n_mels] f32.
+    per_clip=False: whisper.pad_or_trim(n_samples) + log_mel_spectrogram (speech_dataset.py:101-103).
+    per_clip=True : pad_or_trim off -- each clip over its own n_valid samples, mel-space zero padding to n_samples/160."""
     assert audio.dtype == torch.float32 and audio.dim() == 2
     B = audio.shape[0]
-    if n_valid is None and audio.shape[1] < n_samples:
-        n_valid = torch.full((B,), audio.shape[1], dtype=torch.int32, device=audio.device)
+    if n_valid is None and (audio.shape[1] < n_samples or per_clip):
+        n_valid = torch.full((B,), min(audio.shape[1], n_samples), dtype=torch.int32, device=audio.device)
+    if n_valid is not None:
+        n_valid = n_valid.to(device=audio.device, dtype=torch.int32)
     window, tw, melT = _mel_tables(n_mels, audio.device)
     out = torch.empty((B, n_samples // 160, n_mels), dtype=torch.float32, device=audio.device)
     ws = torch.empty((B,), dtype=torch.int32, device=audio.device)
     call("slam_logmel_fwd", _p(audio), audio.stride(0), _p(n_valid), n_samples, _p(window), _p(tw), _p(melT),
-         n_mels, _p(out), _p(ws), B, _s())
+         n_mels, _p(out), _p(ws), B, 1 if per_clip else 0, _s())
     return out
 
 

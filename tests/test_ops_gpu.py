@@ -32,7 +32,7 @@ def assert_close(got, ref, atol, rtol, what=""):
 
 
 # ----------------------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 64), (1000, 388, 192), (77, 64, 4160)])
 def test_gemm_plain(dev, cfg, M, N, K):
     ops = _ops()
@@ -414,3 +414,22 @@ def test_logmel_vs_golden_and_oracle(dev, n_mels):
     assert_close(mel[:, idx, :], gold, atol=1e-4, rtol=0, what="logmel vs reference fixture")
     full = torch.stack([O.log_mel_spectrogram(O.pad_or_trim(a), n_mels) for a in audio.cpu()]).permute(0, 2, 1)
     assert_close(mel, full, atol=1e-4, rtol=0, what="logmel vs oracle")
+
+
+def test_logmel_per_clip_ragged(dev):
+    """pad_or_trim off: each clip's own STFT/floor, mel-space zero padding to the batch maximum (speech_dataset_large.py)"""
+    ops = _ops()
+    from oracle import slam_oracle as O
+    lens = [16000 * 2 + 37, 16000 * 3, 9000]
+    g = torch.Generator().manual_seed(3)
+    clips = [(torch.randn(n, generator=g) * 0.1).clamp(-1, 1) for n in lens]
+    nmax = max(lens)
+    audio = torch.stack([torch.nn.functional.pad(c, (0, nmax - len(c))) for c in clips]).to(dev)
+    nv = torch.tensor(lens, dtype=torch.int32, device=dev)
+    mel = ops.logmel(audio, 80, n_samples=ops.round_up(nmax, 160), n_valid=nv, per_clip=True).cpu()
+    for i, c in enumerate(clips):
+        ref = O.log_mel_spectrogram(c, 80).permute(1, 0)  # [frames_i, 80] over the clip's own length
+        fi = ref.shape[0]
+        assert fi == lens[i] // 160
+        assert_close(mel[i, :fi], ref, atol=1e-4, rtol=0, what=f"ragged clip {i}")
+        assert torch.all(mel[i, fi:] == 0)
