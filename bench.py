@@ -116,7 +116,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    cfg = make_config(args.encoder, args.llm, lora_r=16, lora_alpha=32, lora_targets=("q_proj", "v_proj"))
+    # recipe defaults (examples/asr_librispeech/asr_config.py:29-37): LoRA on q_proj,v_proj with lora_dropout 0.05 live in
+    # train mode ("dropout 0 for parity, 0.05 for throughput"); r = 16 per BASELINE.json configs[2]
+    cfg = make_config(args.encoder, args.llm, lora_r=16, lora_alpha=32, lora_targets=("q_proj", "v_proj"), lora_dropout=0.05)
     model = SlamHipModel(cfg, dev).init_random(42)
     model.train()
     opt = SlamAdamW(model, lr=1e-4, weight_decay=0.0)
@@ -170,7 +172,7 @@ def main():
         "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (seeded N(0,0.1^2) audio, random token ids, random-init weights at true dims)",
-        "config": {"workload": f"C3: {args.encoder} -> {args.llm}, linear projector k=5, LoRA r16 (q_proj,v_proj), dynamic-frame "
+        "config": {"workload": f"C3: {args.encoder} -> {args.llm}, linear projector k=5, LoRA r16 (q_proj,v_proj, dropout 0.05), dynamic-frame "
                                f"batch {N_CLIPS} x 30 s clips per GPU (T={T}, {N_CLIPS * T} frames <= 12000), GPU log-mel in the step, "
                                "fwd+bwd+grad all-reduce+fused AdamW",
                    "global_batch_clips": world * N_CLIPS, "seq_len": T, "parallelism": f"dp{world}",

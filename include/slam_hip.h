@@ -166,6 +166,10 @@ int slam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                     int64_t step, float grad_scale, void* stream);
 int slam_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+/* counter-based dropout (peft lora_dropout): out (+)= keep(seed, offset + m*N + n) ? x/(1-p) : 0.
+ * The mask is a pure function of (seed, offset, index): backward recomputes it (same call on the incoming gradient). */
+int slam_dropout_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t M, int64_t N, float p, uint64_t seed,
+                      uint64_t offset, int accumulate, void* stream);
 /* a += b (bf16 residual-gradient merge of the post-LN Q-Former blocks) */
 int slam_add_bf16(void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N, void* stream);
 int slam_cast_bf16_to_f32(const void* in, float* out, int64_t n, int accumulate, void* stream);

@@ -463,6 +463,41 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// counter-based dropout (peft LoRA `lora_dropout`, active in train mode: SURVEY g10):
+//   out (+)= keep(seed, offset + m*N + n) ? x / (1 - p) : 0      keep = hash >= p * 2^32
+// The mask is a pure function of (seed, offset, element index), so the backward recomputes it instead of storing it.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mix64to32(unsigned long long z) {  // splitmix64 finaliser, top 32 bits
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (unsigned)(z >> 32);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out,
+                                                      int64_t ldo, int64_t M, int N, float inv_keep, unsigned thresh,
+                                                      unsigned long long seed, unsigned long long offset, int accumulate) {
+  const int nch = N >> 3;
+  const int64_t total = M * nch;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / nch;
+    const int c = (int)(i % nch);
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(x + m * ldx + c * 8);
+    u16x8_t o;
+    if (accumulate) o = *reinterpret_cast<const u16x8_t*>(out + m * ldo + c * 8);
+    const unsigned long long base = offset + (unsigned long long)m * (unsigned long long)N + (unsigned long long)c * 8ull;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const bool keep = mix64to32(seed ^ ((base + e) * 0xD1342543DE82EF95ull)) >= thresh;
+      const float val = keep ? bf2f(v[e]) * inv_keep : 0.f;
+      o[e] = f2bf(accumulate ? bf2f(o[e]) + val : val);
+    }
+    *reinterpret_cast<u16x8_t*>(out + m * ldo + c * 8) = o;
+  }
+}
+
 inline unsigned ew_grid(int64_t total_items) {
   int64_t g = cdiv64(total_items, 256);
   if (g > 16384) g = 16384;
@@ -672,5 +707,18 @@ extern "C" int slam_add_bf16(void* a, int64_t lda, const void* b, int64_t ldb, i
   hipLaunchKernelGGL(add_bf16_kernel, dim3(ew_grid(M * (N / 8))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)a, lda,
                      (const bf16_t*)b, ldb, M, (int)N);
   SLAM_CHECK_LAUNCH("slam_add_bf16");
+  return 0;
+}
+
+extern "C" int slam_dropout_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t M, int64_t N, float p,
+                                 uint64_t seed, uint64_t offset, int accumulate, void* stream) {
+  SLAM_CHECK_ARG(x && out && M > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "slam_dropout_bf16: bad arguments");
+  SLAM_CHECK_ARG(p >= 0.f && p < 1.f, "slam_dropout_bf16: p=%f must be in [0, 1)", (double)p);
+  const double t = (double)p * 4294967296.0;
+  const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(M * (N / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                     (bf16_t*)out, ldo, M, (int)N, 1.0f / (1.0f - p), thresh, (unsigned long long)seed,
+                     (unsigned long long)offset, accumulate);
+  SLAM_CHECK_LAUNCH("slam_dropout_bf16");
   return 0;
 }

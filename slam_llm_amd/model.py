@@ -183,27 +183,39 @@ class FusedLinear:
         return buf
 
     def forward(self, x_ext: torch.Tensor, store: Optional[TrainableStore], out=None, residual=None, bias=None,
-                act=ACT_NONE):
+                act=ACT_NONE, drop=None):
+        """drop = (p, seed, offset) applies peft's lora_dropout to the adapters' input (one mask per fused group:
+        peft samples one mask per adapted Linear -- sharing it between e.g. q_proj and v_proj of a layer is a stated
+        deviation); None = no dropout (eval mode / p = 0)."""
         if self.adapters:
             sr = self.sum_r
-            ops.gemm_nt(x_ext[:, : self.K], self.a_cat(store), out=x_ext[:, self.K: self.K + sr])
+            xin = x_ext[:, : self.K]
+            if drop is not None:
+                xin = ops.dropout(xin, *drop)
+            ops.gemm_nt(xin, self.a_cat(store), out=x_ext[:, self.K: self.K + sr])
         return ops.gemm_nt(x_ext, self.Wext, out=out, residual=residual, bias=bias, act=act,
                            k_alg=self.K + self.sum_r)
 
     def backward(self, dy: torch.Tensor, x_ext: Optional[torch.Tensor], store: Optional[TrainableStore],
-                 accumulate: bool, out=None) -> torch.Tensor:
+                 accumulate: bool, out=None, drop=None) -> torch.Tensor:
         """returns dx_ext [M, K+Rp] (columns [:K] are dL/dx); deposits adapter gradients into the store."""
         dx_ext = ops.gemm_nt(dy, self.WextT, out=out)
         if self.adapters:
-            # x_ext = [x | u] with u = x A^T: the columns [K:] of dx_ext are dL/du, and dL/dx gets the second hop
-            ops.gemm_nt(dx_ext[:, self.K:], self.AcatT, out=dx_ext[:, : self.K], accumulate=True)
+            # x_ext = [x | u] with u = dropout(x) A^T: the columns [K:] of dx_ext are dL/du, and dL/dx gets the second hop
+            xin = x_ext[:, : self.K]
+            if drop is None:
+                ops.gemm_nt(dx_ext[:, self.K:], self.AcatT, out=dx_ext[:, : self.K], accumulate=True)
+            else:
+                hop = ops.gemm_nt(dx_ext[:, self.K:], self.AcatT)           # dL/d(dropout(x))
+                ops.dropout(hop, *drop, out=dx_ext[:, : self.K], accumulate=True)  # same mask, recomputed
+                xin = ops.dropout(xin, *drop)                                 # recomputed for dA
             K = self.K
             for a in self.adapters:
                 r = a["r"]
                 du = dx_ext[:, K + a["j0"]: K + a["j0"] + r]          # dL/d(xA^T)  [M, r]
                 u = x_ext[:, K + a["j0"]: K + a["j0"] + r]            # xA^T        [M, r]
                 # dA[r, K] = du^T x ;  dB[rows, r] = (alpha/r) * dy[:, rows]^T u   (HBM-bound tall-skinny products)
-                ops.skinny_gram(du, x_ext[:, :K], store.grad_view(a["A"]), K, 1, accumulate=accumulate)
+                ops.skinny_gram(du, xin, store.grad_view(a["A"]), K, 1, accumulate=accumulate)
                 ops.skinny_gram(u, dy[:, a["row0"]: a["row0"] + a["rows"]], store.grad_view(a["B"]), 1, r,
                                 alpha=a["scale"], accumulate=accumulate)
         return dx_ext
@@ -504,9 +516,8 @@ class HipLlamaLora(nn.Module):
         super().__init__()
         self.cfg, self.store, self.device_, self.prefix = cfg, store, device, prefix
         d, Hq, Hkv, D, Fd = cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"], cfg["llm_ffn"]
-        if cfg.get("lora_dropout", 0.0) not in (0, 0.0):
-            raise NotImplementedError("lora_dropout > 0 is not implemented by the HIP path yet; pass "
-                                      "++train_config.peft_config.lora_dropout=0 (SURVEY g10)")
+        self.lora_p = float(cfg.get("lora_dropout", 0.0) or 0.0)
+        self._drop_calls = 0
         self.layers = []
         targets = tuple(cfg.get("lora_targets") or ())
         r, alpha = cfg["lora_r"], cfg["lora_alpha"]
@@ -597,28 +608,39 @@ class HipLlamaLora(nn.Module):
         cos, sin = self.rope(T)
         scale = D ** -0.5
         stash = {"layers": [], "B": B, "T": T, "key_mask": key_mask} if train else None
+        use_drop = self.training and self.lora_p > 0.0
+        seed = torch.initial_seed() if use_drop else 0
+
+        def drop_for(fl):
+            """fresh (p, seed, offset) per adapted group and forward call; offsets never overlap (stride 2^40)"""
+            if not (use_drop and fl.adapters):
+                return None
+            self._drop_calls += 1
+            return (self.lora_p, seed, self._drop_calls << 40)
+
         for L in self.layers:
             x1 = L.qkv.new_input(M)
             _, rstd1 = ops.rmsnorm_fwd(h, L.ln1, eps, out=x1[:, :d])
-            qkv = L.qkv.forward(x1, st)
+            dq_, do_, dg_, dd_ = drop_for(L.qkv), drop_for(L.o), drop_for(L.gu), drop_for(L.down)
+            qkv = L.qkv.forward(x1, st, drop=dq_)
             qt = ops.head_rope_transpose(qkv, 0, B, T, Hq, D, cos=cos, sin=sin, want_t=train)
             kt = ops.head_rope_transpose(qkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, want_t=train)
             vt = ops.head_rope_transpose(qkv, (Hq + Hkv) * D, B, T, Hkv, D)
             o_ext = L.o.new_input(M)
             _, lse = ops.attn_fwd(qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], vt, B, T, Hq, Hkv, D, True, scale,
                                   key_mask=key_mask, want_lse=train, out=o_ext[:, : Hq * D])
-            h_mid = L.o.forward(o_ext, st, residual=h)
+            h_mid = L.o.forward(o_ext, st, residual=h, drop=do_)
             x2 = L.gu.new_input(M)
             _, rstd2 = ops.rmsnorm_fwd(h_mid, L.ln2, eps, out=x2[:, :d])
-            gu = L.gu.forward(x2, st)
+            gu = L.gu.forward(x2, st, drop=dg_)
             hh = L.down.new_input(M)
             ops.swiglu_fwd(gu, out=hh[:, :Fd])
-            h_out = L.down.forward(hh, st, residual=h_mid)
+            h_out = L.down.forward(hh, st, residual=h_mid, drop=dd_)
             if train:
                 stash["layers"].append(dict(h=h, rstd1=rstd1, x1=x1 if L.qkv.adapters else None, qkv=qkv, qt=qt, kt=kt,
                                             o=o_ext, lse=lse, h_mid=h_mid, rstd2=rstd2,
                                             x2=x2 if L.gu.adapters else None, gu=gu,
-                                            hh=hh if L.down.adapters else None))
+                                            hh=hh if L.down.adapters else None, drops=(dq_, do_, dg_, dd_)))
             h = h_out
         hN, rstdN = ops.rmsnorm_fwd(h, self.norm_w, eps)
         logits_full = torch.empty((M, V), dtype=torch.bfloat16, device=h.device) if return_logits else None
@@ -660,14 +682,15 @@ class HipLlamaLora(nn.Module):
         del f
         for li in reversed(range(len(self.layers))):
             L, S = self.layers[li], stash["layers"][li]
-            d_hh = L.down.backward(dh, S["hh"], st, accumulate)
+            dq_, do_, dg_, dd_ = S["drops"]
+            d_hh = L.down.backward(dh, S["hh"], st, accumulate, drop=dd_)
             dgu = ops.swiglu_bwd(S["gu"], d_hh[:, :Fd])
             del d_hh
-            dx2 = L.gu.backward(dgu, S["x2"], st, accumulate)
+            dx2 = L.gu.backward(dgu, S["x2"], st, accumulate, drop=dg_)
             del dgu
             dh_mid = ops.rmsnorm_bwd(S["h_mid"], S["rstd2"], L.ln2, dx2[:, :d], dres=dh)
             del dx2
-            do_ext = L.o.backward(dh_mid, S["o"], st, accumulate)
+            do_ext = L.o.backward(dh_mid, S["o"], st, accumulate, drop=do_)
             dO = do_ext[:, : Hq * D]
             dOt = ops.head_rope_transpose(dO, 0, B, T, Hq, D)
             qkv = S["qkv"]
@@ -679,7 +702,7 @@ class HipLlamaLora(nn.Module):
             ops.head_rope_transpose(dqkv, 0, B, T, Hq, D, cos=cos, sin=sin, inverse=True, want_t=False)
             ops.head_rope_transpose(dqkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, inverse=True, want_t=False)
             del do_ext, dO, dOt
-            dx1 = L.qkv.backward(dqkv, S["x1"], st, accumulate)
+            dx1 = L.qkv.backward(dqkv, S["x1"], st, accumulate, drop=dq_)
             del dqkv
             dh = ops.rmsnorm_bwd(S["h"], S["rstd1"], L.ln1, dx1[:, :d], dres=dh_mid)
             del dx1, dh_mid

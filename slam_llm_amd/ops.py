@@ -424,3 +424,13 @@ def add_(a2d, b2d):
     M, N = a2d.shape
     call("slam_add_bf16", _p(a2d), _ld(a2d), _p(b2d), _ld(b2d), M, N, _s())
     return a2d
+
+
+def dropout(x2d, p, seed, offset, out=None, accumulate=False):
+    """out (+)= mask(seed, offset) * x / (1 - p); the mask depends only on (seed, offset, element index)"""
+    M, N = x2d.shape
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=x2d.device)
+    call("slam_dropout_bf16", _p(x2d), _ld(x2d), _p(out), _ld(out), M, N, float(p), int(seed) & (2 ** 64 - 1),
+         int(offset) & (2 ** 64 - 1), 1 if accumulate else 0, _s())
+    return out

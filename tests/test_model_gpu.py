@@ -289,3 +289,24 @@ def test_checkpoint_wire_format_round_trip(dev, tmp_path):
     with torch.no_grad():
         got = float(fresh(**{k: v.clone() for k, v in b.items()})[0].loss)
     assert got == ref_loss
+
+
+def test_lora_dropout_trains_and_is_off_in_eval(dev):
+    """recipe default lora_dropout = 0.05 (asr_config.py:29-37) is live in train mode and off in eval"""
+    from slam_llm_amd.model import SlamHipModel
+    cfg = CASES["step_tiny"]["cfg"]
+    fx = G.load("step_tiny")
+    W = O.init_weights(cfg, seed=42)
+    model = SlamHipModel(dict(cfg, lora_dropout=0.3), dev).load_weights(W)
+    b = batch_from_fixture(fx, dev)
+    model.train()
+    l1 = float(model(**{k: v.clone() for k, v in b.items()})[0].loss.detach())
+    out2, _ = model(**{k: v.clone() for k, v in b.items()})
+    l2 = float(out2.loss.detach())
+    out2.loss.backward()
+    assert l1 != l2 and abs(l1 - float(fx["loss.0"])) < 0.2          # fresh mask per call, same ballpark
+    assert torch.isfinite(model.store.grad).all() and float(model.store.grad.abs().sum()) > 0
+    model.eval()
+    with torch.no_grad():
+        le = float(model(**{k: v.clone() for k, v in b.items()})[0].loss)
+    assert abs(le - float(fx["loss.0"])) < 1e-2                      # dropout disabled -> reference loss

@@ -433,3 +433,73 @@ def test_logmel_per_clip_ragged(dev):
         assert fi == lens[i] // 160
         assert_close(mel[i, :fi], ref, atol=1e-4, rtol=0, what=f"ragged clip {i}")
         assert torch.all(mel[i, fi:] == 0)
+
+
+def test_dropout_mask_properties(dev):
+    ops = _ops()
+    M, N, p = 500, 256, 0.25
+    x = rnd((M, N), dev, seed=1)
+    y1 = ops.dropout(x, p, seed=123, offset=1 << 40)
+    y2 = ops.dropout(x, p, seed=123, offset=1 << 40)
+    y3 = ops.dropout(x, p, seed=123, offset=2 << 40)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)          # pure function of (seed, offset, index)
+    ones = torch.ones((M, N), dtype=torch.bfloat16, device=dev)
+    mask = ops.dropout(ones, p, seed=123, offset=1 << 40).float()
+    keep = (mask > 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 0.01, keep
+    assert torch.allclose(mask[mask > 0], torch.tensor(1 / (1 - p)), rtol=1e-2)
+    assert_close(y1, x.float() * mask, atol=1e-2, rtol=1e-2, what="dropout scaling")
+    acc = x.clone()
+    ops.dropout(x, p, seed=123, offset=1 << 40, out=acc, accumulate=True)
+    assert_close(acc, x.float() + x.float() * mask, atol=2e-2, rtol=1e-2, what="dropout accumulate")
+    assert torch.equal(ops.dropout(x, 0.0, seed=5, offset=0), x)
+
+
+def test_lora_fused_linear_with_dropout_matches_autograd(dev):
+    """peft semantics y = x W^T + s * (dropout(x) A^T) B^T, forward and every gradient, with the kernel's own mask"""
+    ops = _ops()
+    from slam_llm_amd.model import FusedLinear, TrainableStore
+    M, K, r, alpha, p = 200, 128, 8, 32.0, 0.3
+    store = TrainableStore(dev)
+    fl = FusedLinear(K, [("q_proj", 128), ("k_proj", 64), ("v_proj", 64)], dev)
+    for n, rows in (("q_proj", 128), ("v_proj", 64)):
+        store.reserve(f"{n}.A", (r, K))
+    for n, rows in (("q_proj", 128), ("v_proj", 64)):
+        store.reserve(f"{n}.B", (rows, r))
+        fl.add_lora(n, r, alpha, f"{n}.A", f"{n}.B")
+    store.allocate()
+    g = torch.Generator().manual_seed(0)
+    Wb = {n: (torch.randn(rows, K, generator=g) * K ** -0.5) for n, rows in fl.parts}
+    for n, rows in fl.parts:
+        fl.set_base(n, Wb[n].to(dev).to(torch.bfloat16))
+    fl.finalize()
+    with torch.no_grad():
+        for n, prm in store.params.items():
+            prm.copy_((torch.randn(prm.shape, generator=g) * 0.1).to(dev))
+    store.refresh_bf16()
+    fl.refresh(store)
+    x_ext = fl.new_input(M)
+    x = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    x_ext[:, :K] = x.to(dev)
+    drop = (p, 77, 5 << 40)
+    y = fl.forward(x_ext, store, drop=drop)
+    mask = ops.dropout(torch.ones((M, K), dtype=torch.bfloat16, device=dev), *drop).float().cpu()
+    # torch reference (bf16-rounded operands, fp32 math)
+    xf = x.float().requires_grad_(True)
+    Wcat = torch.cat([Wb[n].to(torch.bfloat16).float() for n, _ in fl.parts], 0)
+    P = {n: store.params[n].detach().cpu().to(torch.bfloat16).float().requires_grad_(True) for n in store.params}
+    xd = xf * mask
+    yq = xf @ Wcat[:128].T + (alpha / r) * (xd @ P["q_proj.A"].T) @ P["q_proj.B"].T
+    yk = xf @ Wcat[128:192].T
+    yv = xf @ Wcat[192:].T + (alpha / r) * (xd @ P["v_proj.A"].T) @ P["v_proj.B"].T
+    ref = torch.cat([yq, yk, yv], 1)
+    assert_close(y, ref.detach(), atol=3e-2, rtol=2e-2, what="lora+dropout fwd")
+    dy = rnd((M, 256), dev, seed=9)
+    ref.backward(dy.float().cpu())
+    dx_ext = fl.backward(dy, x_ext, store, accumulate=False, drop=drop)
+    assert F.cosine_similarity(dx_ext[:, :K].float().cpu().flatten(), xf.grad.flatten(), dim=0) > 0.9995
+    assert_close(dx_ext[:, :K], xf.grad, atol=3e-2 * float(xf.grad.abs().max()), rtol=3e-2, what="dx")
+    for n in store.params:
+        gr = store.grad_view(n).float().cpu()
+        cs = F.cosine_similarity(gr.flatten(), P[n].grad.flatten(), dim=0)
+        assert cs > 0.999, f"{n}: cosine {float(cs)}"
