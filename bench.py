@@ -113,6 +113,7 @@ def main():
 
     rank, local_rank, world = setup_distributed("cuda")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -28,9 +28,10 @@ def setup_distributed(device_type: str = "cuda"):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if device_type == "cuda" else "gloo"  # "nccl" IS RCCL on ROCm
+        # "nccl" IS RCCL on ROCm; SLAM_DIST_BACKEND=gloo lets two ranks share one GPU for functional tests
+        backend = os.environ.get("SLAM_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
