@@ -180,51 +180,82 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         s[f][kf] = a;
       }
     }
-    // ---- key validity for this lane's 16 keys ----
-    bool kv[4][4];
-#pragma unroll
-    for (int kf = 0; kf < 4; kf++) {
-      const int kb = k0 + kf * 16 + 4 * g;
-      unsigned mk = 0x01010101u;
-      if (p.kmask) mk = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tkp + kb);
-#pragma unroll
-      for (int r = 0; r < 4; r++) kv[kf][r] = ((mk >> (8 * r)) & 0xffu) != 0 && (kb + r) < Tk;
-    }
     // ---- online softmax (per query = lane&15, replicated over the 4 lane groups) ----
+    // interior tiles (no key mask, fully inside [0, Tk), fully below the causal diagonal of this wave) skip all masking
+    const bool tile_full = (p.kmask == nullptr) && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0);
+    if (tile_full) {
 #pragma unroll
-    for (int f = 0; f < 2; f++) {
-      const int q = qw0 + f * 16 + li;
-      float mt = -INFINITY;
+      for (int f = 0; f < 2; f++) {
+        float mt = s[f][0][0];
 #pragma unroll
-      for (int kf = 0; kf < 4; kf++)
+        for (int kf = 0; kf < 4; kf++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int key = k0 + kf * 16 + 4 * g + r;
-          const bool ok = kv[kf][r] && (!CAUSAL || key <= q);
-          const float x = ok ? s[f][kf][r] * sl2 : -INFINITY;
-          s[f][kf][r] = x;
-          mt = fmaxf(mt, x);
-        }
-      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float mnew = fmaxf(mrow[f], mt);
-      const float muse = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = fast_exp2(mrow[f] - muse);
-      mrow[f] = mnew;
-      float rs = 0.f;
+          for (int r = 0; r < 4; r++) mt = fmaxf(mt, s[f][kf][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mnew = fmaxf(mrow[f], mt * sl2);
+        const float alpha = fast_exp2(mrow[f] - mnew);
+        mrow[f] = mnew;
+        float rs = 0.f;
 #pragma unroll
-      for (int kf = 0; kf < 4; kf++)
+        for (int kf = 0; kf < 4; kf++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float pv = fast_exp2(s[f][kf][r] - muse);
-          s[f][kf][r] = pv;
-          rs += pv;
-        }
-      lrow[f] = lrow[f] * alpha + rs;
+          for (int r = 0; r < 4; r++) {
+            const float pv = fast_exp2(fmaf(s[f][kf][r], sl2, -mnew));
+            s[f][kf][r] = pv;
+            rs += pv;
+          }
+        lrow[f] = lrow[f] * alpha + rs;
 #pragma unroll
-      for (int df = 0; df < DF; df++)
+        for (int df = 0; df < DF; df++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) o[f][df][r] *= alpha;
+          for (int r = 0; r < 4; r++) o[f][df][r] *= alpha;
+      }
+    } else {
+      bool kv[4][4];
+#pragma unroll
+      for (int kf = 0; kf < 4; kf++) {
+        const int kb = k0 + kf * 16 + 4 * g;
+        unsigned mk = 0x01010101u;
+        if (p.kmask) mk = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tkp + kb);
+#pragma unroll
+        for (int r = 0; r < 4; r++) kv[kf][r] = ((mk >> (8 * r)) & 0xffu) != 0 && (kb + r) < Tk;
+      }
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        const int q = qw0 + f * 16 + li;
+        float mt = -INFINITY;
+#pragma unroll
+        for (int kf = 0; kf < 4; kf++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int key = k0 + kf * 16 + 4 * g + r;
+            const bool ok = kv[kf][r] && (!CAUSAL || key <= q);
+            const float x = ok ? s[f][kf][r] * sl2 : -INFINITY;
+            s[f][kf][r] = x;
+            mt = fmaxf(mt, x);
+          }
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mnew = fmaxf(mrow[f], mt);
+        const float muse = (mnew == -INFINITY) ? 0.f : mnew;
+        const float alpha = fast_exp2(mrow[f] - muse);
+        mrow[f] = mnew;
+        float rs = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < 4; kf++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float pv = fast_exp2(s[f][kf][r] - muse);
+            s[f][kf][r] = pv;
+            rs += pv;
+          }
+        lrow[f] = lrow[f] * alpha + rs;
+#pragma unroll
+        for (int df = 0; df < DF; df++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) o[f][df][r] *= alpha;
+      }
     }
     // ---- O^T += V^T . P^T ----
 #pragma unroll
