@@ -94,10 +94,11 @@ int slam_rmsnorm_bwd(const void* x, int64_t ldx, const float* rstd, const float*
 /* ---- RoPE + head transposes (HF apply_rotary_pos_emb; positions = arange(T)) -------------
  * src rows (b*T+t), columns col0 + h*D + d, rotated IN PLACE when cos/sin tables [T, D/2] are given
  * (inverse != 0 applies the transposed rotation = RoPE backward); dstT (nullable) [B,H,D,Tp] gets the
- * (rotated) values transposed, zero padded to Tp (multiple of 64). */
+ * (rotated) values transposed, zero padded to Tp (multiple of 64).
+ * positions (nullable, int32 [B*T]): explicit RoPE positions (HF generate derives them from the attention mask). */
 int slam_head_rope_transpose(void* src, int64_t ld, int64_t col0, const float* cos_table,
                              const float* sin_table, int inverse, void* dstT, int64_t B, int64_t T,
-                             int64_t Tp, int64_t H, int64_t D, void* stream);
+                             int64_t Tp, int64_t H, int64_t D, const int32_t* positions, void* stream);
 int slam_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t R, int64_t C,
                         int64_t Rp, void* stream);
 

@@ -249,7 +249,47 @@ def gen_step(name, cfg, clip_seconds, answer_lens, n_steps=3, left_pad=True):
     print(name + ".npz written")
 
 
-from oracle.make_golden_cases import CASES, HUBERT_TINY, QFORMER_CASE  # noqa: E402
+from oracle.make_golden_cases import CASES, GENERATE_CASE, HUBERT_TINY, QFORMER_CASE  # noqa: E402
+
+def gen_generate():
+    """slam_model.generate (slam_model.py:409-456) UNMODIFIED -> HF LlamaForCausalLM.generate (fp32, transformers
+    5.15 here), greedy and beam-4, on a ragged left-padded inference batch."""
+    case = GENERATE_CASE
+    cfg = case["cfg"]
+    audio = O.synth_audio(len(case["clip_samples"]), 2.0, seed=1234)
+    batch = O.synth_infer_batch(cfg, audio, case["clip_samples"], case["prompt_lens"])
+    fx = {"audio": audio.numpy()}
+    for k, v in batch.items():
+        fx["batch." + k] = v.numpy()
+    for scale in case["lm_head_scales"]:
+        W = O.init_weights(cfg, seed=42)
+        W["llm.base_model.model.lm_head.weight"] = W["llm.base_model.model.lm_head.weight"] * scale
+        model = build_reference(cfg, W)
+        model.eval()
+        fx[f"s{scale}.weights_sha256"] = np.array(wsum(W))
+
+        def run(eos, nb, **kw):
+            model.tokenizer = types.SimpleNamespace(bos_token_id=case["bos"], eos_token_id=eos, pad_token_id=kw.pop("pad"))
+            b = {k: v.clone() for k, v in batch.items()}
+            with torch.no_grad():
+                return model.generate(**b, max_new_tokens=case["max_new_tokens"], num_beams=nb, **kw)
+
+        # pick eos: a token some greedy row emits mid-sequence, so rows (and beams) finish at different lengths
+        free = run(cfg["vocab"] - 1, 1, pad=case["pad"])
+        eos = int(free[0, 4])
+        fx[f"s{scale}.eos"] = np.int64(eos)
+        for nb, lp, pad in ((1, 1.0, case["pad"]), (4, 1.0, case["pad"]), (4, 2.0, 1), (3, 0.0, 1)):
+            out = run(eos, nb, length_penalty=lp, pad=pad)
+            mine = O.slam_generate(W, cfg, {k: v.clone() for k, v in batch.items()}, max_new_tokens=case["max_new_tokens"],
+                                   num_beams=nb, length_penalty=lp, eos=eos, pad=pad)
+            ok = out.shape == mine.shape and bool((out == mine).all())
+            print(f"generate scale={scale} beams={nb} lp={lp} pad={pad}: oracle match {ok}\n{out.numpy()}")
+            if not ok:
+                print("oracle:\n", mine.numpy())
+            fx[f"s{scale}.tokens.b{nb}.lp{lp}.pad{pad}"] = out.numpy()
+    np.savez_compressed(os.path.join(GOLD, "generate.npz"), **fx)
+    print("generate.npz written")
+
 
 def gen_batcher():
     """Run the reference's own window_class + MultiTaskDynamicBatchDataset (speech_dataset_large.py:235-263).
@@ -356,6 +396,11 @@ def gen_qformer():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1:  # regenerate selected fixtures only: python oracle/make_golden.py generate qformer
+        for nme in sys.argv[1:]:
+            globals()["gen_" + nme]()
+        sys.exit(0)
+    gen_generate()
     gen_mel()
     gen_batcher()
     gen_hubert()

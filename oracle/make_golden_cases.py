@@ -18,3 +18,9 @@ HUBERT_TINY = O.hubert_config(hub_conv_dim=(64,) * 7, hub_dim=128, hub_heads=2, 
 # Q-Former projector (a3'): the reference module hard-codes Blip2QFormerConfig() widths (768/12/3072); layers, queries,
 # encoder_dim and llm_dim come from the recipe -> keep those small
 QFORMER_CASE = dict(cfg=O.qformer_config(qf_layers=2, qf_queries=8), enc_dim=128, llm_dim=128, B=2, Tk=37, masked_tail=7)
+
+# generate (f1): step_tiny architecture with a sharpened lm_head: x24 gives clear ranking margins (end-to-end GPU
+# parity), x5 a flatter distribution where beam search departs from greedy (host-logic parity); ragged clips and
+# prompts -> left padding; eos id is chosen by make_golden so that hypotheses finish at different lengths
+GENERATE_CASE = dict(cfg=O.make_config(), lm_head_scales=(24.0, 5.0), clip_samples=(32000, 22400, 28800), prompt_lens=(6, 4, 7),
+                     max_new_tokens=12, pad=0, bos=1)

@@ -341,14 +341,18 @@ def lora_linear(W, name: str, x: torch.Tensor, cfg: dict) -> torch.Tensor:
     return y
 
 
-def llama_forward(W, cfg, inputs_embeds, attention_mask, labels=None, prefix="llm.base_model.model."):
+def llama_forward(W, cfg, inputs_embeds, attention_mask, labels=None, prefix="llm.base_model.model.",
+                  position_ids=None):
     """HF LlamaForCausalLM(inputs_embeds, attention_mask, labels) as called at slam_model.py:400
     (transformers/models/llama/modeling_llama.py; loss transformers/loss/loss_utils.py:32-70).
-    positions = arange(T) for every row; mask = causal ^ key padding, additive finfo.min."""
+    positions = arange(T) for every row unless position_ids [B,T] is given (the generate() path:
+    HF derives them from the mask); mask = causal ^ key padding, additive finfo.min."""
     B, T, d = inputs_embeds.shape
     Hq, Hkv, D = cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"]
     eps = cfg["rms_eps"]
     cos, sin = rope_tables(T, D, cfg["rope_theta"])
+    if position_ids is not None:
+        cos, sin = cos[position_ids][:, None], sin[position_ids][:, None]  # [B,1,T,D]
     minv = torch.finfo(torch.float32).min
     causal = torch.tril(torch.ones(T, T, dtype=torch.bool))
     allowed = causal[None, None] & attention_mask.bool()[:, None, None, :]
@@ -442,6 +446,129 @@ def train_steps(W, cfg, batches: List[dict], lr=1e-4, weight_decay=0.0, warmup=1
         opt.zero_grad()
         out.append({"loss": loss.detach(), "acc": acc, "grads": grads})
     return out
+
+
+# ---------------------------------------------------------------------------------------------- f1: generate (beam / greedy)
+def greedy_search(step_fn, batch_size: int, max_new_tokens: int, eos: int, pad: int, min_length: int = 1):
+    """HF `GenerationMixin._sample` with do_sample=False (transformers/generation/utils.py), the num_beams=1 branch of
+    `self.llm.generate(...)` at slam_model.py:438-452.  The prompt is inputs_embeds only, so the token history starts
+    empty: MinLengthLogitsProcessor(min_length) therefore masks eos while fewer than `min_length` tokens exist.
+    step_fn(tokens [R, t] int64, src_rows [R]) -> next-token logits [R, V] fp32."""
+    toks = torch.zeros((batch_size, 0), dtype=torch.int64)
+    alive = torch.ones(batch_size, dtype=torch.bool)
+    rows = torch.arange(batch_size)
+    while True:
+        logits = step_fn(toks, rows).float().clone()
+        if toks.shape[1] < min_length:
+            logits[:, eos] = -float("inf")
+        nxt = logits.argmax(-1)
+        nxt = torch.where(alive, nxt, torch.full_like(nxt, pad))
+        toks = torch.cat([toks, nxt[:, None]], dim=1)
+        alive = alive & (nxt != eos) & (toks.shape[1] < max_new_tokens)
+        if not bool(alive.any()):
+            return toks
+
+
+def beam_search(step_fn, batch_size: int, num_beams: int, max_new_tokens: int, eos: int, pad: int,
+                min_length: int = 1, length_penalty: float = 1.0):
+    """HF `GenerationMixin._beam_search` (transformers 5.x vectorised form; early_stopping=False, one eos id,
+    num_return_sequences=1), restated per batch item.  Each item keeps `num_beams` running hypotheses and
+    `num_beams` finished ones; every step the best 2*num_beams continuations are ranked, the non-terminated ones
+    refill the running set, and a terminated one enters the finished set only if it ranks inside the top
+    `num_beams` continuations.  Finished scores are sum-logprob / length**length_penalty.  An item is closed once its
+    best running score / cur_len**length_penalty cannot beat its worst finished score; the loop ends when every item
+    is closed or max_new_tokens is reached.  Returns [batch, max generated length] padded with `pad or eos`.
+    step_fn(tokens [R, t] int64, src_rows [R] = row of the previous call each hypothesis extends) -> logits [R, V]."""
+    nb, L, K = num_beams, max_new_tokens, 2 * num_beams
+    NEG = -1.0e9
+    pad = pad or eos  # HF: `output_fill_value = pad_token_id or eos_token_id[0]` -- pad id 0 falls through to eos
+    run_seq = [torch.full((nb, L), pad, dtype=torch.int64) for _ in range(batch_size)]
+    run_score = [torch.tensor([0.0] + [NEG] * (nb - 1)) for _ in range(batch_size)]
+    fin_seq = [torch.full((nb, L), pad, dtype=torch.int64) for _ in range(batch_size)]
+    fin_score = [torch.full((nb,), NEG) for _ in range(batch_size)]
+    fin_flag = [torch.zeros(nb, dtype=torch.bool) for _ in range(batch_size)]
+    fin_len = [torch.zeros(nb, dtype=torch.int64) for _ in range(batch_size)]
+    open_ = [True] * batch_size
+    src_rows = torch.arange(batch_size * nb)
+    t = 0
+    while True:
+        flat = torch.cat([r[:, :t] for r in run_seq], dim=0)
+        logits = step_fn(flat, src_rows).float()
+        lp_all = F.log_softmax(logits, dim=-1)
+        if t < min_length:
+            lp_all[:, eos] = -float("inf")
+        V = lp_all.shape[-1]
+        all_hit = True
+        new_src = []
+        for b in range(batch_size):
+            acc = (lp_all[b * nb:(b + 1) * nb] + run_score[b][:, None]).reshape(-1)
+            top_lp, top_idx = torch.topk(acc, K)
+            src, tok = top_idx // V, top_idx % V
+            cand = run_seq[b][src].clone()
+            cand[:, t] = tok
+            hits = (tok == eos) | (t + 1 >= L)
+            all_hit = all_hit and bool(hits.all())
+            # running set: best non-terminated continuations
+            run_lp = top_lp + hits.float() * NEG
+            sel = torch.topk(run_lp, nb)[1]
+            run_seq[b], run_score[b] = cand[sel], run_lp[sel]
+            new_src.append(src[sel] + b * nb)
+            # finished set
+            just = hits & (torch.arange(K) < nb)
+            sc = top_lp / ((t + 1) ** length_penalty)
+            sc = sc + (0.0 if open_[b] else 1.0) * NEG
+            sc = sc + (~just).float() * NEG
+            m_score = torch.cat([fin_score[b], sc])
+            idx = torch.topk(m_score, nb)[1]
+            fin_seq[b] = torch.cat([fin_seq[b], cand])[idx]
+            fin_score[b] = m_score[idx]
+            fin_flag[b] = torch.cat([fin_flag[b], just])[idx]
+            fin_len[b] = torch.cat([fin_len[b], torch.full((K,), t + 1, dtype=torch.int64)])[idx]
+        src_rows = torch.cat(new_src)
+        t += 1
+        for b in range(batch_size):
+            best = run_score[b][:1] / (t ** length_penalty)
+            worst = torch.where(fin_flag[b], fin_score[b].min(), torch.tensor(NEG))
+            open_[b] = open_[b] and bool((best > worst).any())
+        if not any(open_) or all_hit:
+            break
+    out_len = int(max(int(fl[0]) for fl in fin_len))
+    return torch.stack([fs[0, :out_len] for fs in fin_seq])
+
+
+def generate_position_ids(attention_mask: torch.Tensor) -> torch.Tensor:
+    """HF prepare_inputs_for_generation: position_ids = cumsum(attention_mask) - 1, pad slots set to 1."""
+    pos = attention_mask.long().cumsum(-1) - 1
+    return pos.masked_fill(attention_mask == 0, 1)
+
+
+def slam_generate(W, cfg, batch: dict, max_new_tokens=200, num_beams=4, min_length=1, length_penalty=1.0,
+                  eos=2, pad=0):
+    """slam_model.generate (src/slam_llm/models/slam_model.py:409-456): forward(..., inference_mode=True) returns
+    (inputs_embeds, attention_mask) [slam_model.py:394-395], then `self.llm.generate(inputs_embeds=...,
+    attention_mask=..., num_beams, max_new_tokens, min_length, length_penalty, eos/pad ids)`.  do_sample=False,
+    top_p = temperature = repetition_penalty = 1.0 are no-ops.  The oracle re-runs the full sequence every step
+    (no KV cache) in fp32."""
+    mel = batch["audio_mel"]
+    enc = whisper_encoder(W, cfg, mel.permute(0, 2, 1))
+    proj = projector_concat(W, enc, cfg["ds_rate"])
+    emb_w = W["llm.base_model.model.model.embed_tokens.weight"]
+    embeds = embed_splice(emb_w, batch["input_ids"].clone(), batch["modality_mask"].bool(), proj)
+    mask = batch["attention_mask"].long()
+    B = embeds.shape[0]
+
+    def step_fn(tokens, src_rows):
+        # row r of this call extends row src_rows[r] of the previous call; prompts only depend on the batch item
+        R = tokens.shape[0]
+        item = torch.arange(R) // (R // B)
+        x = torch.cat([embeds[item], F.embedding(tokens, emb_w)], dim=1)
+        m = torch.cat([mask[item], torch.ones_like(tokens)], dim=1)
+        _, logits = llama_forward(W, cfg, x, m, None, position_ids=generate_position_ids(m))
+        return logits[:, -1, :]
+
+    if num_beams == 1:
+        return greedy_search(step_fn, B, max_new_tokens, eos, pad, min_length)
+    return beam_search(step_fn, B, num_beams, max_new_tokens, eos, pad, min_length, length_penalty)
 
 
 # ---------------------------------------------------------------------------------------------- a9: batcher + collators
@@ -618,3 +745,22 @@ def synth_batch(cfg, audio: torch.Tensor, prompt_len=16, answer_lens=(64,), seed
         samples.append(make_sample(alen, pids, aids, eos=2))
     coll = collate_left_pad if left_pad else collate_right_pad
     return coll(samples, pad_id=2, mels=mels)
+
+
+def synth_infer_batch(cfg, audio: torch.Tensor, clip_samples=(32000,), prompt_lens=(6,), seed=1237) -> dict:
+    """Inference-mode batch (speech_dataset.py:120-134 + collator :259-273): [audio, prompt] only, left padded,
+    no labels.  Row i uses the first clip_samples[i] samples of audio[i] (ragged clips -> ragged audio_length)."""
+    g = torch.Generator().manual_seed(seed)
+    samples, mels = [], []
+    for i in range(audio.shape[0]):
+        n = clip_samples[i % len(clip_samples)] // HOP * HOP
+        mel = log_mel_spectrogram(audio[i][:n], cfg["n_mels"]).permute(1, 0)
+        mels.append(mel)
+        alen = ((mel.shape[0] + 1) // 2) // cfg["ds_rate"]
+        pids = torch.randint(3, cfg["vocab"], (prompt_lens[i % len(prompt_lens)],), generator=g)
+        ids = torch.cat([torch.zeros(alen, dtype=torch.int64), pids])
+        samples.append({"input_ids": ids, "labels": torch.full_like(ids, -100), "attention_mask": torch.ones_like(ids).bool(),
+                        "audio_length": alen, "prompt_length": len(pids)})
+    out = collate_left_pad(samples, pad_id=2, mels=mels)
+    del out["labels"]
+    return out

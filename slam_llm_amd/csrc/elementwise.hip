@@ -21,7 +21,8 @@ namespace {
 template <int D>
 __global__ __launch_bounds__(256) void head_rope_transpose_kernel(
     bf16_t* __restrict__ src, int64_t ld, int col0, const float* __restrict__ cosT,
-    const float* __restrict__ sinT, float sin_sign, bf16_t* __restrict__ dstT, int T, int Tp, int H) {
+    const float* __restrict__ sinT, float sin_sign, bf16_t* __restrict__ dstT, int T, int Tp, int H,
+    const int* __restrict__ positions) {
   constexpr int LDT = D + 8;  // LDS row stride (elements)
   __shared__ __attribute__((aligned(16))) bf16_t tile[64 * LDT];
   const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
@@ -36,8 +37,11 @@ __global__ __launch_bounds__(256) void head_rope_transpose_kernel(
       const u16x8_t x1 = *reinterpret_cast<const u16x8_t*>(p + c * 8);
       const u16x8_t x2 = *reinterpret_cast<const u16x8_t*>(p + D / 2 + c * 8);
       if (cosT) {
-        const float* cp = cosT + (int64_t)t * (D / 2) + c * 8;
-        const float* sp = sinT + (int64_t)t * (D / 2) + c * 8;
+        // training: position = t (the reference never passes position_ids); generate(): HF derives
+        // position_ids from the attention mask, the caller passes them explicitly
+        const int pp = positions ? positions[(int64_t)b * T + t] : t;
+        const float* cp = cosT + (int64_t)pp * (D / 2) + c * 8;
+        const float* sp = sinT + (int64_t)pp * (D / 2) + c * 8;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
           const float cs = cp[e], sn = sp[e] * sin_sign;
@@ -509,7 +513,8 @@ inline unsigned ew_grid(int64_t total_items) {
 
 extern "C" int slam_head_rope_transpose(void* src, int64_t ld, int64_t col0, const float* cos_table,
                                         const float* sin_table, int inverse, void* dstT, int64_t B,
-                                        int64_t T, int64_t Tp, int64_t H, int64_t D, void* stream) {
+                                        int64_t T, int64_t Tp, int64_t H, int64_t D, const int32_t* positions,
+                                        void* stream) {
   SLAM_CHECK_ARG(src, "slam_head_rope_transpose: null src");
   SLAM_CHECK_ARG(D == 64 || D == 128, "slam_head_rope_transpose: head_dim %ld unsupported (64|128)", (long)D);
   SLAM_CHECK_ARG((cos_table == nullptr) == (sin_table == nullptr), "slam_head_rope_transpose: cos/sin must both be set or both null");
@@ -522,10 +527,10 @@ extern "C" int slam_head_rope_transpose(void* src, int64_t ld, int64_t col0, con
   const float sgn = inverse ? -1.f : 1.f;
   if (D == 64)
     hipLaunchKernelGGL(head_rope_transpose_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream,
-                       (bf16_t*)src, ld, (int)col0, cos_table, sin_table, sgn, (bf16_t*)dstT, (int)T, (int)Tp, (int)H);
+                       (bf16_t*)src, ld, (int)col0, cos_table, sin_table, sgn, (bf16_t*)dstT, (int)T, (int)Tp, (int)H, positions);
   else
     hipLaunchKernelGGL(head_rope_transpose_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream,
-                       (bf16_t*)src, ld, (int)col0, cos_table, sin_table, sgn, (bf16_t*)dstT, (int)T, (int)Tp, (int)H);
+                       (bf16_t*)src, ld, (int)col0, cos_table, sin_table, sgn, (bf16_t*)dstT, (int)T, (int)Tp, (int)H, positions);
   SLAM_CHECK_LAUNCH("slam_head_rope_transpose");
   return 0;
 }

@@ -670,6 +670,93 @@ class HipLlamaLora(nn.Module):
                 ops.gemm_nt(hN[r0:r1], self.lm_head, out=logits_full[r0:r1])
         return out2, logits_full, stash
 
+    # ---- decode (generate) ---------------------------------------------------------------------------
+    def _infer_block(self, L, h, B, T, positions, cos, sin, cache_k, cache_vt, slot0, key_mask, causal):
+        """one decoder layer over T new tokens per row: K (post-RoPE) goes to cache_k[:, slot0:slot0+T], V to
+        cache_vt[..., slot0:slot0+T]; attention runs over the whole cache under key_mask."""
+        cfg, st = self.cfg, self.store
+        d, Hq, Hkv, D, Fd = cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"], cfg["llm_ffn"]
+        M, eps, Tcp = B * T, cfg["rms_eps"], cache_vt.shape[-1]
+        x1 = L.qkv.new_input(M)
+        ops.rmsnorm_fwd(h, L.ln1, eps, out=x1[:, :d])
+        qkv = L.qkv.forward(x1, st)
+        ops.head_rope_transpose(qkv, 0, B, T, Hq, D, cos=cos, sin=sin, want_t=False, positions=positions)
+        ops.head_rope_transpose(qkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, want_t=False, positions=positions)
+        cache_k[:, slot0:slot0 + T].copy_(qkv[:, Hq * D:(Hq + Hkv) * D].view(B, T, Hkv * D))
+        if T == 1:
+            cache_vt[..., slot0].copy_(qkv[:, (Hq + Hkv) * D:].view(B, Hkv, D))
+        else:
+            vt = ops.head_rope_transpose(qkv, (Hq + Hkv) * D, B, T, Hkv, D)
+            cache_vt[..., slot0:slot0 + T].copy_(vt[..., :T])
+        o_ext = L.o.new_input(M)
+        if causal:   # prefill: the T new tokens are the whole history -> plain causal self-attention on the local K
+            ops.attn_fwd(qkv[:, : Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], cache_vt, B, T, Hq, Hkv, D, True, D ** -0.5,
+                         key_mask=key_mask, want_lse=False, out=o_ext[:, : Hq * D])
+        else:        # decode: one query per row against the cache; key_mask marks the live slots
+            ops.attn_fwd(qkv[:, : Hq * D], cache_k.view(B * Tcp, Hkv * D), cache_vt, B, T, Hq, Hkv, D, False, D ** -0.5,
+                         key_mask=key_mask, want_lse=False, out=o_ext[:, : Hq * D], Tk=Tcp)
+        h_mid = L.o.forward(o_ext, st, residual=h)
+        x2 = L.gu.new_input(M)
+        ops.rmsnorm_fwd(h_mid, L.ln2, eps, out=x2[:, :d])
+        gu = L.gu.forward(x2, st)
+        hh = L.down.new_input(M)
+        ops.swiglu_fwd(gu, out=hh[:, :Fd])
+        return L.down.forward(hh, st, residual=h_mid)
+
+    def _next_logits(self, h_last: torch.Tensor) -> torch.Tensor:
+        hN, _ = ops.rmsnorm_fwd(h_last, self.norm_w, self.cfg["rms_eps"])
+        return ops.gemm_nt(hN, self.lm_head, out_dtype=torch.float32)
+
+    @torch.no_grad()
+    def prefill(self, h: torch.Tensor, B: int, T: int, attention_mask: torch.Tensor, max_new_tokens: int):
+        """Run the prompt (h [B*T, d] bf16, left padded) and build the KV cache.  Rotary positions follow HF
+        generate(): cumsum(attention_mask) - 1 per row, NOT arange (which the training forward uses).
+        Returns (next-token logits [B, V] fp32, cache)."""
+        cfg, dev = self.cfg, h.device
+        Hkv, D = cfg["llm_kv_heads"], cfg["llm_head_dim"]
+        Tcp = round_up(T + max_new_tokens, 64)
+        am = attention_mask.to(device=dev, dtype=torch.int32)
+        positions = (am.cumsum(-1) - 1).clamp_(min=0).to(torch.int32).contiguous()
+        cos, sin = self.rope(Tcp)
+        cache = SimpleNamespace(k=[], vt=[], slot=T, B=B, Tcp=Tcp,
+                                mask=torch.zeros((B, Tcp), dtype=torch.uint8, device=dev),
+                                next_pos=am.sum(-1).to(torch.int32).contiguous())
+        cache.mask[:, :T] = am.to(torch.uint8)
+        for L in self.layers:
+            ck = torch.zeros((B, Tcp, Hkv * D), dtype=torch.bfloat16, device=dev)
+            cvt = torch.zeros((B, Hkv, D, Tcp), dtype=torch.bfloat16, device=dev)
+            h = self._infer_block(L, h, B, T, positions, cos, sin, ck, cvt, 0, cache.mask, True)
+            cache.k.append(ck)
+            cache.vt.append(cvt)
+        last = h.view(B, T, -1)[:, T - 1].contiguous()
+        return self._next_logits(last), cache
+
+    @torch.no_grad()
+    def reorder_cache(self, cache, rows: torch.Tensor):
+        """cache row r <- old row rows[r] (beam bookkeeping; also expands B prompt rows to B*num_beams)"""
+        cache.k = [t.index_select(0, rows) for t in cache.k]
+        cache.vt = [t.index_select(0, rows) for t in cache.vt]
+        cache.mask = cache.mask.index_select(0, rows)
+        cache.next_pos = cache.next_pos.index_select(0, rows)
+        cache.B = int(rows.shape[0])
+        return cache
+
+    @torch.no_grad()
+    def decode_step(self, tokens: torch.Tensor, cache):
+        """append one token per cache row; returns next-token logits [rows, V] fp32."""
+        R, slot = cache.B, cache.slot
+        if slot >= cache.Tcp:
+            raise RuntimeError("KV cache capacity exhausted")
+        h = self.embed.index_select(0, tokens.to(torch.int64))
+        cos, sin = self.rope(cache.Tcp)
+        cache.mask[:, slot] = 1
+        positions = cache.next_pos.contiguous()
+        for L, ck, cvt in zip(self.layers, cache.k, cache.vt):
+            h = self._infer_block(L, h, R, 1, positions, cos, sin, ck, cvt, slot, cache.mask, False)
+        cache.slot += 1
+        cache.next_pos = cache.next_pos + 1
+        return self._next_logits(h)
+
     # ---- backward ------------------------------------------------------------------------------------
     def backward_hip(self, stash: dict, grad_scale: Optional[torch.Tensor], accumulate: bool, on_layer_done=None):
         cfg, st = self.cfg, self.store
@@ -899,10 +986,52 @@ class SlamHipModel(nn.Module):
         for hk in self.grad_hooks:
             hk(end)
 
-    # ---- generate (greedy; beam search is a next-round row) ------------------------------------
+    # ---- generate ------------------------------------------------------------------------------------
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, **kwargs):
-        raise NotImplementedError("batch decode (model.generate) is SURVEY 8(f) rank 1: not part of round 1")
+        """slam_model.generate (src/slam_llm/models/slam_model.py:409-456): forward(..., inference_mode=True) for
+        the spliced prompt embeddings, then HF `llm.generate(inputs_embeds=..., attention_mask=..., num_beams=4,
+        max_new_tokens=200, min_length=1, length_penalty=1.0, eos/pad from the tokenizer)`.  Here: one prefill
+        pass + KV-cache decode steps on the HIP path; beam / greedy bookkeeping in slam_llm_amd/decode.py.
+        Returns the NEW tokens only [B, <=max_new_tokens] (HF's behaviour for inputs_embeds prompts)."""
+        from . import decode
+        if kwargs.get("do_sample", False):
+            raise NotImplementedError("sampling decode is not implemented (the reference recipes decode with do_sample=False)")
+        for k_, neutral in (("repetition_penalty", 1.0), ("top_p", 1.0), ("temperature", 1.0)):
+            if float(kwargs.get(k_, neutral)) != neutral:
+                raise NotImplementedError(f"{k_} != {neutral} is not implemented")
+        tok = self.tokenizer
+        eos = kwargs.get("eos_token_id", getattr(tok, "eos_token_id", None))
+        pad = kwargs.get("pad_token_id", getattr(tok, "pad_token_id", None))
+        if eos is None or pad is None:
+            raise RuntimeError("generate() needs eos/pad token ids (tokenizer or eos_token_id= / pad_token_id=)")
+        max_new = int(kwargs.get("max_new_tokens", 200))
+        num_beams = int(kwargs.get("num_beams", 4))
+        fwd_kwargs = {k_: v for k_, v in kwargs.items() if k_ not in decode.GENERATE_KEYS}
+        fwd_kwargs["inference_mode"] = True
+        embeds, attention_mask = self.forward(input_ids=input_ids, attention_mask=attention_mask, **fwd_kwargs)
+        B, T, d = embeds.shape
+        logits0, cache = self.llm.prefill(embeds.reshape(B * T, d), B, T, attention_mask, max_new)
+        state = {"first": True}
+
+        def step_fn(tokens, src_rows):
+            if state["first"]:       # prompt logits; expand the cache to one row per hypothesis
+                state["first"] = False
+                R = int(tokens.shape[0])
+                if R == B:
+                    return logits0
+                rows = torch.arange(B, device=self.device_).repeat_interleave(R // B)
+                self.llm.reorder_cache(cache, rows)
+                return logits0.index_select(0, rows)
+            if src_rows is not None:  # beam search: hypothesis r continues old row src_rows[r]
+                self.llm.reorder_cache(cache, src_rows)
+            return self.llm.decode_step(tokens[:, -1], cache)
+
+        if num_beams == 1:
+            return decode.greedy_search(step_fn, B, max_new, int(eos), int(pad), int(kwargs.get("min_length", 1)),
+                                        self.device_)
+        return decode.beam_search(step_fn, B, num_beams, max_new, int(eos), int(pad), int(kwargs.get("min_length", 1)),
+                                  float(kwargs.get("length_penalty", 1.0)), self.device_)
 
 
 # ======================================================================================== optimizer

@@ -265,12 +265,14 @@ def rmsnorm_bwd(x, rstd, weight, dy, dres=None, grad_scale=None, out=None):
 
 
 # ------------------------------------------------------------------------------------------------ rope / transposes
-def head_rope_transpose(src2d, col0, B, T, H, D, cos=None, sin=None, inverse=False, want_t=True, Tp=None):
-    """In-place RoPE on columns [col0, col0+H*D) of src2d [B*T, ld]; returns [B,H,D,Tp] transposed copy."""
+def head_rope_transpose(src2d, col0, B, T, H, D, cos=None, sin=None, inverse=False, want_t=True, Tp=None,
+                        positions=None):
+    """In-place RoPE on columns [col0, col0+H*D) of src2d [B*T, ld]; returns [B,H,D,Tp] transposed copy.
+    positions: optional int32 [B*T] explicit rotary positions (decode / mask-derived positions of generate())."""
     Tp = Tp or round_up(T, 64)
     dst = torch.empty((B, H, D, Tp), dtype=torch.bfloat16, device=src2d.device) if want_t else None
     call("slam_head_rope_transpose", _p(src2d), _ld(src2d), col0, _p(cos), _p(sin), 1 if inverse else 0,
-         _p(dst), B, T, Tp, H, D, _s())
+         _p(dst), B, T, Tp, H, D, _p(positions), _s())
     return dst
 
 

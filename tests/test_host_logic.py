@@ -1,5 +1,6 @@
 """CPU: host-side logic of the product (batcher, collators, LR schedule, FLOP model) against the oracle / fixtures."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import slam_oracle as O
@@ -84,3 +85,38 @@ def test_flop_model_matches_survey_worked_example():
     assert abs(fl["enc"] / 2.27e12 - 1) < 0.02 and abs(fl["proj"] / 3.9e10 - 1) < 0.03
     assert abs(fl["llm"] / 1.15e13 - 1) < 0.02 and abs(fl["total"] / 1.38e13 - 1) < 0.02
     assert batcher.frames_for_hbm() > 60000
+
+
+@pytest.mark.parametrize("scale", [24.0, 5.0])
+def test_decode_bookkeeping_matches_reference_generate(scale):
+    """the product's beam / greedy bookkeeping (slam_llm_amd/decode.py), driven on CPU by the oracle's fp32 model
+    step, reproduces the token ids the reference's generate() produced (tests/golden/generate.npz)."""
+    import torch.nn.functional as F
+    from oracle import slam_oracle as O
+    from oracle.make_golden_cases import GENERATE_CASE as C
+    from slam_llm_amd import decode
+    from tests.test_oracle_golden import GEN_RUNS, generate_case_weights
+    fx = G.load("generate")
+    cfg, W = C["cfg"], generate_case_weights(scale)
+    batch = {k[len("batch."):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("batch.")}
+    enc = O.whisper_encoder(W, cfg, batch["audio_mel"].permute(0, 2, 1))
+    proj = O.projector_concat(W, enc, cfg["ds_rate"])
+    emb_w = W["llm.base_model.model.model.embed_tokens.weight"]
+    embeds = O.embed_splice(emb_w, batch["input_ids"].clone(), batch["modality_mask"].bool(), proj)
+    mask = batch["attention_mask"].long()
+    B = embeds.shape[0]
+
+    def step_fn(tokens, src_rows):
+        item = torch.arange(tokens.shape[0]) // (tokens.shape[0] // B)
+        x = torch.cat([embeds[item], F.embedding(tokens, emb_w)], dim=1)
+        m = torch.cat([mask[item], torch.ones_like(tokens)], dim=1)
+        return O.llama_forward(W, cfg, x, m, None, position_ids=O.generate_position_ids(m))[1][:, -1, :]
+
+    eos = int(fx[f"s{scale}.eos"])
+    for nb, lp, pad in GEN_RUNS:
+        if nb == 1:
+            got = decode.greedy_search(step_fn, B, C["max_new_tokens"], eos, pad, 1, "cpu")
+        else:
+            got = decode.beam_search(step_fn, B, nb, C["max_new_tokens"], eos, pad, 1, lp, "cpu")
+        want = fx[f"s{scale}.tokens.b{nb}.lp{lp}.pad{pad}"]
+        assert tuple(got.shape) == want.shape and (got.numpy() == want).all(), (nb, lp, pad, got, want)

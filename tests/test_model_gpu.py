@@ -310,3 +310,68 @@ def test_lora_dropout_trains_and_is_off_in_eval(dev):
     with torch.no_grad():
         le = float(model(**{k: v.clone() for k, v in b.items()})[0].loss)
     assert abs(le - float(fx["loss.0"])) < 1e-2                      # dropout disabled -> reference loss
+
+
+# ------------------------------------------------------------------------------------------------ generate (f1)
+def _generate_setup(dev, scale):
+    from oracle.make_golden_cases import GENERATE_CASE as C
+    from slam_llm_amd.model import SlamHipModel
+    from tests.test_oracle_golden import generate_case_weights
+    fx = G.load("generate")
+    W = generate_case_weights(scale)
+    model = SlamHipModel(dict(C["cfg"], lora_dropout=0.0), dev).load_weights(W)
+    model.eval()
+    b = batch_from_fixture(fx, dev)
+    return C, fx, W, model, b
+
+
+@pytest.mark.parametrize("scale", [24.0, 5.0])
+def test_generate_matches_reference_tokens(dev, scale):
+    """SlamHipModel.generate (prefill + KV-cache decode on the HIP path, bf16) == the token ids the reference's
+    slam_model.generate -> HF generate produced in fp32.  Bit-exact integer comparison; covers greedy, beam 4 / 3
+    (x5 lm_head: beam search departs from greedy), eos + pad fill, length_penalty 0/1/2, left padding."""
+    from tests.test_oracle_golden import GEN_RUNS
+    C, fx, W, model, b = _generate_setup(dev, scale)
+    eos = int(fx[f"s{scale}.eos"])
+    for nb, lp, pad in GEN_RUNS:
+        got = model.generate(**{k: v.clone() for k, v in b.items()}, max_new_tokens=C["max_new_tokens"], num_beams=nb,
+                             length_penalty=lp, eos_token_id=eos, pad_token_id=pad)
+        want = fx[f"s{scale}.tokens.b{nb}.lp{lp}.pad{pad}"]
+        assert tuple(got.shape) == want.shape and (got.cpu().numpy() == want).all(), (nb, lp, pad, got, want)
+
+
+def test_kv_cache_decode_logits_match_oracle_teacher_forced(dev):
+    """prefill + decode_step logits along the reference's greedy token sequence vs the fp32 oracle re-running the
+    full sequence (no cache): bf16 bound 6e-2 + 2e-2*max|logit| (same bound as the training-forward logits test)."""
+    import torch.nn.functional as F
+    C, fx, W, model, b = _generate_setup(dev, 5.0)
+    cfg = C["cfg"]
+    toks = torch.from_numpy(fx["s5.0.tokens.b4.lp1.0.pad0"])  # [B, 12], row 0 ends with eos fill: still valid input ids
+    cpu = {k: v.cpu() for k, v in b.items()}
+    enc = O.whisper_encoder(W, cfg, cpu["audio_mel"].permute(0, 2, 1))
+    proj = O.projector_concat(W, enc, cfg["ds_rate"])
+    emb_w = W["llm.base_model.model.model.embed_tokens.weight"]
+    embeds_ref = O.embed_splice(emb_w, cpu["input_ids"].clone(), cpu["modality_mask"].bool(), proj)
+    mask = cpu["attention_mask"].long()
+    embeds, am = model(**{k: v.clone() for k, v in b.items()}, inference_mode=True)
+    B, T, d = embeds.shape
+    logits, cache = model.llm.prefill(embeds.reshape(B * T, d), B, T, am, toks.shape[1])
+    worst = 0.0
+    for t in range(toks.shape[1]):
+        x = torch.cat([embeds_ref, F.embedding(toks[:, :t], emb_w)], dim=1)
+        m = torch.cat([mask, torch.ones_like(toks[:, :t])], dim=1)
+        ref = O.llama_forward(W, cfg, x, m, None, position_ids=O.generate_position_ids(m))[1][:, -1, :]
+        err = (logits.float().cpu() - ref).abs().max().item()
+        bound = 6e-2 + 2e-2 * ref.abs().max().item()
+        worst = max(worst, err / bound)
+        assert err < bound, f"step {t}: logits err {err} > {bound}"
+        logits = model.llm.decode_step(toks[:, t].to(dev), cache)
+    print("teacher-forced decode: worst err/bound", worst)
+
+
+def test_generate_rejects_unimplemented_modes(dev):
+    C, fx, W, model, b = _generate_setup(dev, 24.0)
+    with pytest.raises(NotImplementedError):
+        model.generate(**b, do_sample=True, eos_token_id=2, pad_token_id=0)
+    with pytest.raises(NotImplementedError):
+        model.generate(**b, repetition_penalty=1.2, eos_token_id=2, pad_token_id=0)

@@ -97,3 +97,28 @@ def test_qformer_projector_matches_reference_module():
         # rounding noise, compared in absolute terms only
         tiny = float(fx["grad." + n + ".__norm"]) < 1e-4
         G.check_packed(fx, "grad." + n, v.grad.numpy(), atol=2e-5, rtol=2e-3, norm_rtol=None if tiny else 1e-3)
+
+
+GEN_RUNS = ((1, 1.0, 0), (4, 1.0, 0), (4, 2.0, 1), (3, 0.0, 1))
+
+
+def generate_case_weights(scale):
+    from oracle.make_golden_cases import GENERATE_CASE
+    W = O.init_weights(GENERATE_CASE["cfg"], seed=42)
+    W["llm.base_model.model.lm_head.weight"] = W["llm.base_model.model.lm_head.weight"] * scale
+    return W
+
+
+@pytest.mark.parametrize("scale", [24.0, 5.0])
+def test_generate_matches_reference_generate(scale):
+    """oracle greedy/beam restatement == slam_model.generate -> HF generate (fixture written by the reference)"""
+    from oracle.make_golden_cases import GENERATE_CASE as C
+    fx = G.load("generate")
+    W = generate_case_weights(scale)
+    batch = {k[len("batch."):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("batch.")}
+    eos = int(fx[f"s{scale}.eos"])
+    for nb, lp, pad in GEN_RUNS:
+        got = O.slam_generate(W, C["cfg"], {k: v.clone() for k, v in batch.items()}, max_new_tokens=C["max_new_tokens"],
+                              num_beams=nb, length_penalty=lp, eos=eos, pad=pad)
+        want = fx[f"s{scale}.tokens.b{nb}.lp{lp}.pad{pad}"]
+        assert got.shape == want.shape and (got.numpy() == want).all(), (nb, lp, pad, got, want)
