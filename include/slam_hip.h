@@ -175,6 +175,38 @@ int slam_dropout_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int64_
 int slam_add_bf16(void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N, void* stream);
 int slam_cast_bf16_to_f32(const void* in, float* out, int64_t n, int accumulate, void* stream);
 
+/* ---- decode (generate) --------------------------------------------------------------------------------------
+ * Replaces, for `slam_model.generate` (src/slam_llm/models/slam_model.py:409-456), what HF runs per generated token:
+ * LlamaDecoderLayer with a DynamicCache (transformers/models/llama/modeling_llama.py), nn.Linear on a few rows, and
+ * the per-step `_reorder_cache` / `reorder_cache(beam_idx)` of beam search (transformers/generation/utils.py). */
+
+/* y[M<=64, N+N2] = x[M,K] . [W (N rows, ldb); W2 (N2 rows, ldb2)]^T (+ residual), HBM-bound weight streaming (every weight
+ * byte read once, K split over waves / workgroups, fixed-order reduction -> bit-reproducible).  W2 (nullable) stacks a
+ * second row block under W -- the decode path appends the LoRA A matrices so that u = x A^T comes out of the same
+ * launch.  swiglu != 0: W = [gate (N/2 rows); up (N/2 rows)] and the output is [M, N/2] = silu(gate) * up (HF LlamaMLP).
+ * splits: 0 automatic, > 0 forced cross-workgroup split, < 0 forced in-workgroup split (M <= 16).
+ * workspace: slam_gemm_skinny_workspace_bytes(M, N+N2, K, splits, swiglu) bytes (0 for the in-workgroup path). */
+int64_t slam_gemm_skinny_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t splits, int swiglu);
+int slam_gemm_skinny_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, const void* B2, int64_t ldb2,
+                             int64_t N2, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, const void* residual,
+                             int64_t ldr, int out_dtype, int swiglu, void* workspace, int64_t workspace_bytes,
+                             int64_t splits, void* stream);
+
+/* One decode step of self-attention for R = B*beams hypotheses, one launch per layer:
+ *   new token: q|k|v = qkv[r, :(Hq+2Hkv)*D] (+ LoRA delta u . lora_b^T with u = qkv[r, (Hq+2Hkv)*D : +lora_r], peft's
+ *   `base(x) + scale*B(A(x))`), RoPE (HF apply_rotary_pos_emb, position = positions[r]) on q and k, then
+ *   k -> k_gen[r, j], v -> v_gen[r, j], ancestors[r, j] = r with j = generated tokens cached so far (*gen_count_dev if
+ *   non-null -- graph-capturable -- else gen_count);
+ *   attention of the new q over [prompt KV of item r / beams, slots prompt_start[item] .. Tp) | generated slots 0 .. j],
+ *   slot i of hypothesis r being read from physical row ancestors[r, i].
+ * k/v_prompt [B, Tp, Hkv*D], k/v_gen [R, G, Hkv*D] (G <= 1024), O [R, Hq*D] bf16.  Replaces HF's eager attention
+ * over a cache that beam search re-orders with index_select every step. */
+int slam_attn_decode(const void* qkv, int64_t ld, const void* lora_b, int64_t ldlb, int64_t lora_r,
+                     const float* cos_table, const float* sin_table, const int32_t* positions, const void* k_prompt,
+                     const void* v_prompt, const int32_t* prompt_start, void* k_gen, void* v_gen, int32_t* ancestors,
+                     const int32_t* gen_count_dev, int64_t gen_count, void* O, int64_t ldo, int64_t R, int64_t beams,
+                     int64_t Tp, int64_t G, int64_t Hq, int64_t Hkv, int64_t D, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

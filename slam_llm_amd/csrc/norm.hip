@@ -102,6 +102,52 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
   }
 }
 
+// few rows (decode: batch x beams): one workgroup per row so the row is read with one load per thread and kept in
+// registers between the two passes (the one-wave-per-row kernel above serialises 8 dependent loads per pass here)
+__global__ __launch_bounds__(256) void rmsnorm_fwd_small_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                                const float* __restrict__ w,
+                                                                bf16_t* __restrict__ y, int64_t ldy,
+                                                                float* __restrict__ rstd_out, int d, float eps) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const bf16_t* xr = x + (int64_t)row * ldx;
+  const int nch = d >> 3;
+  constexpr int MAXC = 4;  // d <= 8192
+  u16x8_t v[MAXC];
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; i++) {
+    const int c = tid + i * 256;
+    if (c < nch) {
+      v[i] = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float t = bf2f(v[i][e]);
+        q += t * t;
+      }
+    }
+  }
+  const float rstd = rsqrtf(block_sum<256>(q, red) / (float)d + eps);
+  if (tid == 0 && rstd_out) rstd_out[row] = rstd;
+  bf16_t* yr = y + (int64_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < MAXC; i++) {
+    const int c = tid + i * 256;
+    if (c < nch) {
+      const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8);
+      const float4 w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
+      const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      u16x8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float xn = bf2f(f2bf(bf2f(v[i][e]) * rstd));  // cast back to the input dtype first
+        o[e] = f2bf(ww[e] * xn);
+      }
+      *reinterpret_cast<u16x8_t*>(yr + c * 8) = o;
+    }
+  }
+}
+
 // dx = rstd * (g - xhat * mean(g * xhat)) [* gscale] + dres ,  g = dy * w, xhat = x * rstd
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(
     const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ rstd_in,
@@ -259,8 +305,12 @@ extern "C" int slam_rmsnorm_fwd(const void* x, int64_t ldx, const float* weight,
   SLAM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0, "slam_rmsnorm_fwd: bad shape M=%ld d=%ld (d%%8 must be 0)", (long)M, (long)d);
   SLAM_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= d && ldy >= d, "slam_rmsnorm_fwd: bad leading dims");
   const unsigned grid = (unsigned)cdiv64(M, ROWS_PER_BLOCK);
-  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, ldx, weight, (bf16_t*)y, ldy, rstd, (int)M, (int)d, eps);
+  if (M <= 128 && d <= 8192)
+    hipLaunchKernelGGL(rmsnorm_fwd_small_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, ldx, weight, (bf16_t*)y, ldy, rstd, (int)d, eps);
+  else
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, ldx, weight, (bf16_t*)y, ldy, rstd, (int)M, (int)d, eps);
   SLAM_CHECK_LAUNCH("slam_rmsnorm_fwd");
   return 0;
 }

@@ -50,6 +50,10 @@ SIGNATURES = {
     "slam_skinny_gram_workspace_bytes": [I64, I64, I64],
     "slam_skinny_gram": [P, I64, P, I64, P, I64, I64, I64, I64, I64, F, I32, P, P],
     "slam_lora_pack_b": [P, F, P, I64, P, I64, I64, I64, P],
+    "slam_gemm_skinny_workspace_bytes": [I64, I64, I64, I64, I32],
+    "slam_gemm_skinny_bf16_nt": [P, I64, P, I64, P, I64, I64, P, I64, I64, I64, I64, P, I64, I32, I32, P, I64, I64, P],
+    "slam_attn_decode": [P, I64, P, I64, I64, P, P, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, I64,
+                         I64, F, P],
     "slam_embed_splice_fwd": [P, P, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P],
     "slam_embed_splice_bwd": [P, P, I64, P, I64, I64, I64, I64, I64, P],
     "slam_ce_targets": [P, P, P, I64, I64, I64, P],
@@ -100,7 +104,7 @@ def last_error() -> str:
 def call(name: str, *args) -> int:
     """Invoke a C-ABI entry point; raise SlamHipError on a non-zero return code."""
     rc = getattr(_lib, name)(*args)
-    if name in ("slam_logmel_workspace_bytes", "slam_skinny_gram_workspace_bytes"):
+    if name.endswith("_workspace_bytes"):
         return rc
     if rc != 0:
         raise SlamHipError(f"{name} failed (rc={rc}): {last_error()}")

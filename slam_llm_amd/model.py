@@ -196,6 +196,12 @@ class FusedLinear:
         return ops.gemm_nt(x_ext, self.Wext, out=out, residual=residual, bias=bias, act=act,
                            k_alg=self.K + self.sum_r)
 
+    def forward_swiglu(self, x_ext: torch.Tensor, store: Optional[TrainableStore], out: torch.Tensor):
+        """decode (<= 64 rows): this group is [gate | up]; out = silu(gate) * up from one weight-streaming launch."""
+        if self.adapters:
+            ops.gemm_nt(x_ext[:, : self.K], self.a_cat(store), out=x_ext[:, self.K: self.K + self.sum_r])
+        return ops.gemm_skinny(x_ext, self.Wext, out, swiglu=True)
+
     def backward(self, dy: torch.Tensor, x_ext: Optional[torch.Tensor], store: Optional[TrainableStore],
                  accumulate: bool, out=None, drop=None) -> torch.Tensor:
         """returns dx_ext [M, K+Rp] (columns [:K] are dL/dx); deposits adapter gradients into the store."""
@@ -671,33 +677,18 @@ class HipLlamaLora(nn.Module):
         return out2, logits_full, stash
 
     # ---- decode (generate) ---------------------------------------------------------------------------
-    def _infer_block(self, L, h, B, T, positions, cos, sin, cache_k, cache_vt, slot0, key_mask, causal):
-        """one decoder layer over T new tokens per row: K (post-RoPE) goes to cache_k[:, slot0:slot0+T], V to
-        cache_vt[..., slot0:slot0+T]; attention runs over the whole cache under key_mask."""
+    # KV layout (all bf16, row-major [.., Hkv*D]):
+    #   prompt     Kp/Vp [layers, B, T, Hkv*D]   written once by prefill, SHARED by the beams of a batch item
+    #   generated  Kg/Vg [layers, R, G, Hkv*D]   R = B*beams rows, G = max_new_tokens slots, append-only
+    #   anc        [R, G] int32                  physical row holding slot j of hypothesis r's history
+    # Beam search re-ranks hypotheses every step; instead of re-ordering the cache (HF: index_select over every
+    # layer's K and V), only `anc` is gathered -- a [R, G] int table shared by all layers.
+    def _mlp_block(self, L, h_mid):
         cfg, st = self.cfg, self.store
-        d, Hq, Hkv, D, Fd = cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"], cfg["llm_ffn"]
-        M, eps, Tcp = B * T, cfg["rms_eps"], cache_vt.shape[-1]
-        x1 = L.qkv.new_input(M)
-        ops.rmsnorm_fwd(h, L.ln1, eps, out=x1[:, :d])
-        qkv = L.qkv.forward(x1, st)
-        ops.head_rope_transpose(qkv, 0, B, T, Hq, D, cos=cos, sin=sin, want_t=False, positions=positions)
-        ops.head_rope_transpose(qkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, want_t=False, positions=positions)
-        cache_k[:, slot0:slot0 + T].copy_(qkv[:, Hq * D:(Hq + Hkv) * D].view(B, T, Hkv * D))
-        if T == 1:
-            cache_vt[..., slot0].copy_(qkv[:, (Hq + Hkv) * D:].view(B, Hkv, D))
-        else:
-            vt = ops.head_rope_transpose(qkv, (Hq + Hkv) * D, B, T, Hkv, D)
-            cache_vt[..., slot0:slot0 + T].copy_(vt[..., :T])
-        o_ext = L.o.new_input(M)
-        if causal:   # prefill: the T new tokens are the whole history -> plain causal self-attention on the local K
-            ops.attn_fwd(qkv[:, : Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], cache_vt, B, T, Hq, Hkv, D, True, D ** -0.5,
-                         key_mask=key_mask, want_lse=False, out=o_ext[:, : Hq * D])
-        else:        # decode: one query per row against the cache; key_mask marks the live slots
-            ops.attn_fwd(qkv[:, : Hq * D], cache_k.view(B * Tcp, Hkv * D), cache_vt, B, T, Hq, Hkv, D, False, D ** -0.5,
-                         key_mask=key_mask, want_lse=False, out=o_ext[:, : Hq * D], Tk=Tcp)
-        h_mid = L.o.forward(o_ext, st, residual=h)
+        d, Fd = cfg["llm_dim"], cfg["llm_ffn"]
+        M = h_mid.shape[0]
         x2 = L.gu.new_input(M)
-        ops.rmsnorm_fwd(h_mid, L.ln2, eps, out=x2[:, :d])
+        ops.rmsnorm_fwd(h_mid, L.ln2, cfg["rms_eps"], out=x2[:, :d])
         gu = L.gu.forward(x2, st)
         hh = L.down.new_input(M)
         ops.swiglu_fwd(gu, out=hh[:, :Fd])
@@ -708,54 +699,116 @@ class HipLlamaLora(nn.Module):
         return ops.gemm_nt(hN, self.lm_head, out_dtype=torch.float32)
 
     @torch.no_grad()
-    def prefill(self, h: torch.Tensor, B: int, T: int, attention_mask: torch.Tensor, max_new_tokens: int):
-        """Run the prompt (h [B*T, d] bf16, left padded) and build the KV cache.  Rotary positions follow HF
-        generate(): cumsum(attention_mask) - 1 per row, NOT arange (which the training forward uses).
-        Returns (next-token logits [B, V] fp32, cache)."""
-        cfg, dev = self.cfg, h.device
-        Hkv, D = cfg["llm_kv_heads"], cfg["llm_head_dim"]
-        Tcp = round_up(T + max_new_tokens, 64)
+    def prefill(self, h: torch.Tensor, B: int, T: int, attention_mask: torch.Tensor, max_new_tokens: int, beams: int = 1):
+        """Run the prompt (h [B*T, d] bf16, LEFT padded) and build the KV cache for B*beams hypotheses.  Rotary
+        positions follow HF generate(): cumsum(attention_mask) - 1 per row, NOT arange (which the training forward
+        uses).  Returns (next-token logits [B, V] fp32, cache)."""
+        cfg, st, dev = self.cfg, self.store, h.device
+        d, Hq, Hkv, D = cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"]
+        M, R, G, Ln, eps = B * T, B * beams, max_new_tokens, len(self.layers), cfg["rms_eps"]
         am = attention_mask.to(device=dev, dtype=torch.int32)
+        if not bool((am[:, 1:] >= am[:, :-1]).all()) or not bool(am[:, -1].all()):
+            raise ValueError("generate(): the prompt batch must be left padded (speech_dataset.py:216-273 inference collator)")
         positions = (am.cumsum(-1) - 1).clamp_(min=0).to(torch.int32).contiguous()
-        cos, sin = self.rope(Tcp)
-        cache = SimpleNamespace(k=[], vt=[], slot=T, B=B, Tcp=Tcp,
-                                mask=torch.zeros((B, Tcp), dtype=torch.uint8, device=dev),
-                                next_pos=am.sum(-1).to(torch.int32).contiguous())
-        cache.mask[:, :T] = am.to(torch.uint8)
-        for L in self.layers:
-            ck = torch.zeros((B, Tcp, Hkv * D), dtype=torch.bfloat16, device=dev)
-            cvt = torch.zeros((B, Hkv, D, Tcp), dtype=torch.bfloat16, device=dev)
-            h = self._infer_block(L, h, B, T, positions, cos, sin, ck, cvt, 0, cache.mask, True)
-            cache.k.append(ck)
-            cache.vt.append(cvt)
+        n_real = am.sum(-1).to(torch.int32)
+        cos, sin = self.rope(T + G)
+        Tp64 = round_up(T, 64)
+        key_mask = torch.zeros((B, Tp64), dtype=torch.uint8, device=dev)
+        key_mask[:, :T] = am.to(torch.uint8)
+        kv = dict(dtype=torch.bfloat16, device=dev)
+        cache = SimpleNamespace(
+            B=B, R=R, beams=beams, T=T, G=G, n=0,
+            Kp=torch.empty((Ln, B, T, Hkv * D), **kv), Vp=torch.empty((Ln, B, T, Hkv * D), **kv),
+            Kg=torch.zeros((Ln, R, G, Hkv * D), **kv), Vg=torch.zeros((Ln, R, G, Hkv * D), **kv),
+            anc=torch.arange(R, dtype=torch.int32, device=dev)[:, None].repeat(1, G).contiguous(),
+            start=(T - n_real).to(torch.int32).contiguous(),
+            next_pos=n_real.repeat_interleave(beams).contiguous(),
+            n_dev=torch.zeros(1, dtype=torch.int32, device=dev), tok=torch.zeros(R, dtype=torch.int64, device=dev),
+            graph=None, logits=None)
+        for li, L in enumerate(self.layers):
+            x1 = L.qkv.new_input(M)
+            ops.rmsnorm_fwd(h, L.ln1, eps, out=x1[:, :d])
+            qkv = L.qkv.forward(x1, st)
+            ops.head_rope_transpose(qkv, 0, B, T, Hq, D, cos=cos, sin=sin, want_t=False, positions=positions)
+            ops.head_rope_transpose(qkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, want_t=False, positions=positions)
+            vt = ops.head_rope_transpose(qkv, (Hq + Hkv) * D, B, T, Hkv, D)
+            cache.Kp[li].copy_(qkv[:, Hq * D:(Hq + Hkv) * D].view(B, T, Hkv * D))
+            cache.Vp[li].copy_(qkv[:, (Hq + Hkv) * D:].view(B, T, Hkv * D))
+            o_ext = L.o.new_input(M)
+            ops.attn_fwd(qkv[:, : Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], vt, B, T, Hq, Hkv, D, True, D ** -0.5,
+                         key_mask=key_mask, want_lse=False, out=o_ext[:, : Hq * D])
+            h = self._mlp_block(L, L.o.forward(o_ext, st, residual=h))
         last = h.view(B, T, -1)[:, T - 1].contiguous()
         return self._next_logits(last), cache
 
     @torch.no_grad()
     def reorder_cache(self, cache, rows: torch.Tensor):
-        """cache row r <- old row rows[r] (beam bookkeeping; also expands B prompt rows to B*num_beams)"""
-        cache.k = [t.index_select(0, rows) for t in cache.k]
-        cache.vt = [t.index_select(0, rows) for t in cache.vt]
-        cache.mask = cache.mask.index_select(0, rows)
-        cache.next_pos = cache.next_pos.index_select(0, rows)
-        cache.B = int(rows.shape[0])
+        """hypothesis r continues old hypothesis rows[r] (same batch item): gather the ancestor table only."""
+        cache.anc.copy_(cache.anc.index_select(0, rows))
         return cache
+
+    def _decode_body(self, cache) -> torch.Tensor:
+        """one decode step over static buffers (cache.tok, cache.next_pos, cache.n_dev, cache.anc): every launch
+        reads the step index from device memory, so the sequence can be captured once in a HIP graph and replayed.
+        7 launches per layer for <= 64 hypotheses: rmsnorm, qkv (+ LoRA A rows), attention (LoRA delta + RoPE + KV
+        append fused), o_proj (+ residual), rmsnorm, gate_up (+ SwiGLU), down_proj (+ residual)."""
+        cfg, st = self.cfg, self.store
+        d, Hq, Hkv, D, Fd = cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"], cfg["llm_ffn"]
+        R, eps = cache.R, cfg["rms_eps"]
+        skinny = R <= ops.SKINNY_MAX_M
+        h = self.embed.index_select(0, cache.tok)
+        cos, sin = self.rope(cache.T + cache.G)
+        for li, L in enumerate(self.layers):
+            fq = L.qkv
+            if skinny and fq.adapters:
+                # u = x A^T comes out of the same launch as q|k|v (A stacked under W); the attention kernel adds
+                # u . (scale B)^T to the new token's q/k/v (peft: base(x) + scale * B(A(x)))
+                x1, _ = ops.rmsnorm_fwd(h, L.ln1, eps)
+                qkv = torch.empty((R, fq.N + fq.sum_r), dtype=torch.bfloat16, device=h.device)
+                ops.gemm_skinny(x1, fq.Wext[:, : fq.K], qkv, b2=fq.a_cat(st))
+                lora_b, lora_r = fq.Wext[:, fq.K:], fq.sum_r
+            else:
+                x1 = fq.new_input(R)
+                ops.rmsnorm_fwd(h, L.ln1, eps, out=x1[:, :d])
+                qkv, lora_b, lora_r = fq.forward(x1, st), None, 0
+            o_ext = L.o.new_input(R)
+            ops.attn_decode(qkv, lora_b, lora_r, cos, sin, cache.next_pos, cache.Kp[li], cache.Vp[li], cache.start,
+                            cache.Kg[li], cache.Vg[li], cache.anc, cache.n_dev, cache.n, cache.beams, Hq, Hkv, D,
+                            D ** -0.5, o_ext)
+            h_mid = L.o.forward(o_ext, st, residual=h)
+            x2 = L.gu.new_input(R)
+            ops.rmsnorm_fwd(h_mid, L.ln2, eps, out=x2[:, :d])
+            hh = L.down.new_input(R)
+            if skinny:
+                L.gu.forward_swiglu(x2, st, hh[:, :Fd])
+            else:
+                ops.swiglu_fwd(L.gu.forward(x2, st), out=hh[:, :Fd])
+            h = L.down.forward(hh, st, residual=h_mid)
+        logits = self._next_logits(h)
+        cache.n_dev += 1
+        cache.next_pos += 1
+        return logits
 
     @torch.no_grad()
     def decode_step(self, tokens: torch.Tensor, cache):
-        """append one token per cache row; returns next-token logits [rows, V] fp32."""
-        R, slot = cache.B, cache.slot
-        if slot >= cache.Tcp:
-            raise RuntimeError("KV cache capacity exhausted")
-        h = self.embed.index_select(0, tokens.to(torch.int64))
-        cos, sin = self.rope(cache.Tcp)
-        cache.mask[:, slot] = 1
-        positions = cache.next_pos.contiguous()
-        for L, ck, cvt in zip(self.layers, cache.k, cache.vt):
-            h = self._infer_block(L, h, R, 1, positions, cos, sin, ck, cvt, slot, cache.mask, False)
-        cache.slot += 1
-        cache.next_pos = cache.next_pos + 1
-        return self._next_logits(h)
+        """append one token per hypothesis; returns next-token logits [R, V] fp32 (a buffer re-used by the next step).
+        ~330 short launches per step: captured into a HIP graph on the first step and replayed afterwards
+        (cfg['decode_graph'], default on; per-kernel timing via ops.TIMER runs eagerly)."""
+        if cache.n >= cache.G:
+            raise RuntimeError("KV cache capacity exhausted (max_new_tokens)")
+        cache.tok.copy_(tokens)
+        if not self.cfg.get("decode_graph", True) or ops.TIMER is not None:
+            logits = self._decode_body(cache)
+        else:
+            if cache.graph is None:
+                self.rope(cache.T + cache.G)   # tables must exist before capture (host -> device copy)
+                cache.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cache.graph):
+                    cache.logits = self._decode_body(cache)
+            cache.graph.replay()
+            logits = cache.logits
+        cache.n += 1
+        return logits
 
     # ---- backward ------------------------------------------------------------------------------------
     def backward_hip(self, stash: dict, grad_scale: Optional[torch.Tensor], accumulate: bool, on_layer_done=None):
@@ -1011,19 +1064,14 @@ class SlamHipModel(nn.Module):
         fwd_kwargs["inference_mode"] = True
         embeds, attention_mask = self.forward(input_ids=input_ids, attention_mask=attention_mask, **fwd_kwargs)
         B, T, d = embeds.shape
-        logits0, cache = self.llm.prefill(embeds.reshape(B * T, d), B, T, attention_mask, max_new)
+        logits0, cache = self.llm.prefill(embeds.reshape(B * T, d), B, T, attention_mask, max_new, beams=num_beams)
         state = {"first": True}
 
         def step_fn(tokens, src_rows):
-            if state["first"]:       # prompt logits; expand the cache to one row per hypothesis
+            if state["first"]:       # prompt logits, one row per hypothesis (the prompt KV itself is shared)
                 state["first"] = False
-                R = int(tokens.shape[0])
-                if R == B:
-                    return logits0
-                rows = torch.arange(B, device=self.device_).repeat_interleave(R // B)
-                self.llm.reorder_cache(cache, rows)
-                return logits0.index_select(0, rows)
-            if src_rows is not None:  # beam search: hypothesis r continues old row src_rows[r]
+                return logits0 if num_beams == 1 else logits0.repeat_interleave(num_beams, dim=0)
+            if src_rows is not None:  # beam search: hypothesis r continues old hypothesis src_rows[r]
                 self.llm.reorder_cache(cache, src_rows)
             return self.llm.decode_step(tokens[:, -1], cache)
 

@@ -84,10 +84,32 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     od = F32 if out.dtype == torch.float32 else BF16
+    if (M <= SKINNY_MAX_M and bias is None and act == ACT_NONE and alpha == 1.0 and not accumulate and res_row_mod == 0
+            and _GEMM_CFG == 0):
+        return gemm_skinny(a, b, out, residual=residual)  # a few rows (decode): HBM-bound weight-streaming kernel
     _timed(gemm_kernel_name(M, N), 2.0 * M * N * (k_alg or K),
            lambda: call("slam_gemm_bf16_nt", _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, N, K, _p(bias),
                         _p(residual), _ld(residual) if residual is not None else 0, res_row_mod, act, alpha, od,
                         1 if accumulate else 0, _s()))
+    return out
+
+
+SKINNY_MAX_M = 64
+SKINNY_SPLITS = 0  # 0 = automatic split-K plan (tools/decode_bench.py overrides it for sweeps)
+
+
+def gemm_skinny(a, b, out, residual=None, b2=None, swiglu=False):
+    """out[M<=64, :] = a[M,K] @ [b; b2]^T (+ residual), or silu(gate)*up with b = [gate; up] (swiglu): every weight byte is
+    read once; work = weight bytes streamed."""
+    M, K = a.shape
+    N, N2 = b.shape[0], (b2.shape[0] if b2 is not None else 0)
+    wsb = call("slam_gemm_skinny_workspace_bytes", M, N + N2, K, SKINNY_SPLITS, 1 if swiglu else 0)
+    ws = torch.empty((wsb // 4,), dtype=torch.float32, device=a.device) if wsb else None
+    od = F32 if out.dtype == torch.float32 else BF16
+    _timed("gemm_skinny", 2.0 * (N + N2) * K,
+           lambda: call("slam_gemm_skinny_bf16_nt", _p(a), _ld(a), _p(b), _ld(b), _p(b2), _ld(b2) if b2 is not None else 0, N2,
+                        _p(out), _ld(out), M, N, K, _p(residual), _ld(residual) if residual is not None else 0, od,
+                        1 if swiglu else 0, _p(ws), wsb, SKINNY_SPLITS, _s()))
     return out
 
 
@@ -310,6 +332,20 @@ def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T,
                         _ld(dq2d), _p(dk2d), _ld(dk2d), _p(dv2d), _ld(dv2d), B, T, Tk, Tqp, Tkp, Hq, Hkv, D,
                         1 if causal else 0, scale, _s()))
     return delta
+
+
+def attn_decode(qkv, lora_b, lora_r, cos, sin, positions, k_prompt, v_prompt, prompt_start, k_gen, v_gen, ancestors,
+                gen_count_dev, gen_count, beams, Hq, Hkv, D, scale, out):
+    """one decode step of attention per hypothesis: LoRA delta + RoPE + KV append of the new token, then one query per
+    row against [prompt KV of its batch item | generated KV via the ancestor table]."""
+    R, G = k_gen.shape[0], k_gen.shape[1]
+    Tp = k_prompt.shape[1]
+    _timed("attn_decode", 4.0 * R * Hkv * D * (Tp + gen_count + 1),
+           lambda: call("slam_attn_decode", _p(qkv), _ld(qkv), _p(lora_b), _ld(lora_b) if lora_b is not None else 0, lora_r,
+                        _p(cos), _p(sin), _p(positions), _p(k_prompt), _p(v_prompt), _p(prompt_start), _p(k_gen), _p(v_gen),
+                        _p(ancestors), _p(gen_count_dev), gen_count, _p(out), _ld(out), R, beams, Tp, G, Hq, Hkv, D, scale,
+                        _s()))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ mlp

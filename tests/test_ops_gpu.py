@@ -98,7 +98,7 @@ def test_layernorm(dev, M, d):
     assert_close(y, ref, atol=1e-2, rtol=1e-2, what="layernorm")
 
 
-@pytest.mark.parametrize("M,d", [(37, 128), (300, 4096)])
+@pytest.mark.parametrize("M,d", [(37, 128), (300, 4096), (16, 4096)])
 def test_rmsnorm_fwd_bwd(dev, M, d):
     ops = _ops()
     x = rnd((M, d), dev, seed=1, std=1.5)
@@ -503,3 +503,117 @@ def test_lora_fused_linear_with_dropout_matches_autograd(dev):
         gr = store.grad_view(n).float().cpu()
         cs = F.cosine_similarity(gr.flatten(), P[n].grad.flatten(), dim=0)
         assert cs > 0.999, f"{n}: cosine {float(cs)}"
+
+
+# ----------------------------------------------------------------------------------------- decode kernels
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 40, 64])
+@pytest.mark.parametrize("N,K,splits", [(96, 64, 0), (4128, 4160, 0), (1000, 512, 1), (256, 1024, 3), (50176, 256, 0)])
+def test_gemm_skinny_matches_fp32_matmul(dev, M, N, K, splits):
+    ops = _ops()
+    a, b = rnd((M, K), dev, seed=3), rnd((N, K), dev, seed=4)
+    res = rnd((M, N), dev, seed=5)
+    ref = a.float() @ b.float().T
+    ops.SKINNY_SPLITS = splits
+    try:
+        c32 = ops.gemm_nt(a, b, out_dtype=torch.float32)
+        cbf = ops.gemm_nt(a, b, residual=res)
+        again = ops.gemm_nt(a, b, out_dtype=torch.float32)
+    finally:
+        ops.SKINNY_SPLITS = 0
+    # fp32 products and accumulation: only the summation order differs from torch's
+    assert_close(c32, ref, atol=2e-4 * math.sqrt(K), rtol=1e-5, what=f"skinny f32 {M}x{N}x{K}")
+    assert_close(cbf, ref + res.float(), atol=2e-2 * math.sqrt(K / 64), rtol=1e-2, what=f"skinny bf16+res {M}x{N}x{K}")
+    assert torch.equal(c32, again), "split-K reduction must be bit-reproducible"
+
+
+def test_gemm_skinny_asymmetric_identity(dev):
+    """x = rows of I with an asymmetric W catches row/col or k-permutation mistakes in the MFMA mapping."""
+    ops = _ops()
+    K = 256
+    a = torch.eye(K, dtype=torch.bfloat16, device=dev)[200:248]
+    b = (torch.arange(200 * K, dtype=torch.float32).reshape(200, K) % 251 - 125).to(torch.bfloat16).to(dev)
+    c = ops.gemm_nt(a, b, out_dtype=torch.float32)
+    assert torch.equal(c.cpu(), b.float().T[200:248].cpu())
+    c16 = ops.gemm_nt(a[:13], b, out_dtype=torch.float32)   # M <= 16 kernel (in-workgroup split-K)
+    assert torch.equal(c16.cpu(), b.float().T[200:213].cpu())
+
+
+def test_gemm_skinny_stacked_weights_and_swiglu(dev):
+    """two-block weight rows (LoRA A stacked under W) and the fused SwiGLU epilogue, both kernels (M <= 16 / <= 64)"""
+    ops = _ops()
+    K, N1, N2, Fd = 512, 200, 24, 1088
+    w, w2, wg = rnd((N1, K + 64), dev, seed=21), rnd((N2, K), dev, seed=22), rnd((2 * Fd, K), dev, seed=23, std=0.05)
+    for M in (3, 16, 40):
+        x = rnd((M, K), dev, seed=24)
+        out = torch.empty((M, N1 + N2), dtype=torch.bfloat16, device=dev)
+        ops.gemm_skinny(x, w[:, :K], out, b2=w2)
+        ref = torch.cat([x.float() @ w[:, :K].float().T, x.float() @ w2.float().T], dim=1)
+        assert_close(out, ref, atol=2e-2 * math.sqrt(K / 64), rtol=1e-2, what=f"stacked rows M={M}")
+        for splits in (0, 2):
+            ops.SKINNY_SPLITS = splits
+            try:
+                hh = torch.empty((M, Fd), dtype=torch.bfloat16, device=dev)
+                ops.gemm_skinny(x, wg, hh, swiglu=True)
+            finally:
+                ops.SKINNY_SPLITS = 0
+            gu = (x.float() @ wg.float().T).to(torch.bfloat16)
+            assert torch.equal(hh, ops.swiglu_fwd(gu)) or (hh.float() - ops.swiglu_fwd(gu).float()).abs().max() < 2e-2, \
+                f"fused swiglu M={M} splits={splits}"
+
+
+@pytest.mark.parametrize("D,Hq,Hkv,lora", [(128, 8, 2, 16), (64, 4, 4, 0), (64, 8, 1, 12), (128, 4, 2, 0)])
+def test_decode_attention_fused(dev, D, Hq, Hkv, lora):
+    """one decode step (LoRA delta + RoPE + KV append + attention in one launch) against a torch fp32 reference that
+    materialises each hypothesis' history from the ancestor table; prompt KV shared by the beams of an item, ragged
+    left padding."""
+    ops = _ops()
+    from slam_llm_amd.host_tables import rope_tables
+    B, beams, T, G, n = 2, 3, 37, 9, 5   # n generated tokens already cached
+    R, HD, NQ = B * beams, Hkv * D, (Hq + 2 * Hkv) * D
+    g = torch.Generator().manual_seed(11)
+    ld = NQ + (lora + 7) // 8 * 8
+    qkv = rnd((R, ld), dev, seed=6)
+    lora_b = rnd((NQ, 16), dev, seed=12, std=0.3) if lora else None
+    Kp, Vp = rnd((B, T, HD), dev, seed=7), rnd((B, T, HD), dev, seed=8)
+    Kg, Vg = rnd((R, G, HD), dev, seed=9), rnd((R, G, HD), dev, seed=10)
+    start = torch.tensor([0, 6], dtype=torch.int32, device=dev)
+    anc = torch.stack([torch.randint(0, beams, (G,), generator=g) + (r // beams) * beams for r in range(R)]).to(torch.int32).to(dev)
+    positions = torch.tensor([T - int(start[r // beams]) + n for r in range(R)], dtype=torch.int32, device=dev)
+    cos, sin = rope_tables(T + G, D, 10000.0)
+    cos, sin = cos.to(dev), sin.to(dev)
+    Kg0, Vg0 = Kg.clone(), Vg.clone()
+    out = torch.empty((R, Hq * D), dtype=torch.bfloat16, device=dev)
+    ops.attn_decode(qkv, lora_b, lora, cos, sin, positions, Kp, Vp, start, Kg, Vg, anc, None, n, beams, Hq, Hkv, D,
+                    D ** -0.5, out)
+
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    y = qkv[:, :NQ].float()
+    if lora:
+        y = bf(y + bf(qkv[:, NQ:NQ + lora].float() @ lora_b[:, :lora].float().T))
+
+    def rope(x, pos):   # x [R, H, D] fp32, HF rotate_half convention; rounded to bf16 like the kernel's stores
+        c = torch.cat([cos[pos.long()], cos[pos.long()]], -1)[:, None, :].float()
+        s = torch.cat([sin[pos.long()], sin[pos.long()]], -1)[:, None, :].float()
+        rot = torch.cat([-x[..., D // 2:], x[..., : D // 2]], -1)
+        return bf(x * c + rot * s)
+
+    qf = rope(y[:, : Hq * D].view(R, Hq, D), positions)
+    kf = rope(y[:, Hq * D:(Hq + Hkv) * D].view(R, Hkv, D), positions)
+    vf = y[:, (Hq + Hkv) * D:].view(R, Hkv, D)
+    assert_close(Kg[:, n].view(R, Hkv, D), kf, atol=1e-6, rtol=2 ** -7, what="K append (<= 1 bf16 ulp: fma order)")
+    assert_close(Vg[:, n].view(R, Hkv, D), vf, atol=1e-6, rtol=2 ** -7, what="V append")
+    keep = torch.ones(G, dtype=torch.bool)
+    keep[n] = False
+    assert torch.equal(Kg[:, keep], Kg0[:, keep]) and torch.equal(Vg[:, keep], Vg0[:, keep]), "other slots untouched"
+    assert torch.equal(anc[:, n].cpu(), torch.arange(R, dtype=torch.int32))
+    ref = torch.empty(R, Hq, D)
+    rep = Hq // Hkv
+    for r in range(R):
+        it, s0 = r // beams, int(start[r // beams])
+        rows = anc[r, : n + 1].long()
+        Kh = torch.cat([Kp[it, s0:].float(), Kg[rows, torch.arange(n + 1, device=dev)].float()]).view(-1, Hkv, D).cpu()
+        Vh = torch.cat([Vp[it, s0:].float(), Vg[rows, torch.arange(n + 1, device=dev)].float()]).view(-1, Hkv, D).cpu()
+        for hq in range(Hq):
+            sc = (Kh[:, hq // rep] @ qf[r, hq].cpu()) * D ** -0.5
+            ref[r, hq] = torch.softmax(sc, 0) @ Vh[:, hq // rep]
+    assert_close(out.view(R, Hq, D), ref, atol=2e-2, rtol=1e-2, what="decode attention")

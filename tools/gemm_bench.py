@@ -39,7 +39,20 @@ for (M, N, K) in shapes:
             torch.cuda.synchronize()
             best[cfg] = min(best[cfg], s.elapsed_time(e) / 5)
     ops.gemm_set_config(0)
-    line = {"M": M, "N": N, "K": K, **{f"cfg{cfg}_TF": round(2.0 * M * N * K / (best[cfg] * 1e-3) / 1e12, 1) for cfg in cfgs}}
+    # library yardstick (hipBLASLt behind torch): NOT used by the product, printed to know the headroom
+    lib_ms = 1e9
+    bt = b.T
+    for rnd in range(4):
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(5):
+            torch.matmul(a, bt, out=c)
+        e.record()
+        torch.cuda.synchronize()
+        lib_ms = min(lib_ms, s.elapsed_time(e) / 5)
+    line = {"M": M, "N": N, "K": K, **{f"cfg{cfg}_TF": round(2.0 * M * N * K / (best[cfg] * 1e-3) / 1e12, 1) for cfg in cfgs},
+            "hipblaslt_TF": round(2.0 * M * N * K / (lib_ms * 1e-3) / 1e12, 1)}
     res.append(line)
     print(line, flush=True)
     del a, b, c, ref
