@@ -20,11 +20,13 @@ def main():
     ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--encoder", default="whisper-large-v3")
     ap.add_argument("--llm", default="llama-3-8b")
+    ap.add_argument("--splits", type=int, default=0, help="override the skinny-GEMM cross-workgroup split plan")
     ap.add_argument("--kernels", action="store_true", help="per-kernel HIP-event timing (adds launch gaps)")
     args = ap.parse_args()
     from slam_llm_amd import ops
     from slam_llm_amd.model import SlamHipModel, make_config
     dev = torch.device("cuda:0")
+    ops.SKINNY_SPLITS = args.splits
     cfg = make_config(args.encoder, args.llm, lora_r=16, lora_alpha=32, lora_targets=("q_proj", "v_proj"))
     model = SlamHipModel(cfg, dev).init_random(42)
     model.eval()
