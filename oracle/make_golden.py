@@ -249,7 +249,27 @@ def gen_step(name, cfg, clip_seconds, answer_lens, n_steps=3, left_pad=True):
     print(name + ".npz written")
 
 
-from oracle.make_golden_cases import CASES, GENERATE_CASE, HUBERT_TINY, QFORMER_CASE  # noqa: E402
+from oracle.make_golden_cases import CASES, COV1D_CASE, GENERATE_CASE, HUBERT_TINY, QFORMER_CASE  # noqa: E402
+
+def gen_cov1d():
+    """EncoderProjectorCov1d (models/projector.py:29-49) imported UNMODIFIED: forward + every parameter gradient."""
+    from slam_llm.models.projector import EncoderProjectorCov1d
+    c = COV1D_CASE
+    W = O.init_cov1d_weights(c["enc_dim"], c["llm_dim"], c["k"])
+    m = EncoderProjectorCov1d(Cfg(encoder_projector_ds_rate=c["k"], encoder_dim=c["enc_dim"], llm_dim=c["llm_dim"]))
+    m.load_state_dict({k[len("encoder_projector."):]: v for k, v in W.items()})
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(c["B"], c["T"], c["enc_dim"], generator=g)
+    cot = torch.randn(c["B"], c["T"] // c["k"], c["llm_dim"], generator=g)
+    out = m(x)
+    (out * cot).sum().backward()
+    fx = {"x": x.numpy(), "cot": cot.numpy(), "weights_sha256": np.array(wsum(W))}
+    pack(fx, "out", out.detach().numpy(), limit=65536)
+    for n, p_ in m.named_parameters():
+        pack(fx, "grad.encoder_projector." + n, p_.grad.numpy(), limit=8192)
+    np.savez_compressed(os.path.join(GOLD, "cov1d.npz"), **fx)
+    print("cov1d.npz written", tuple(out.shape))
+
 
 def gen_generate():
     """slam_model.generate (slam_model.py:409-456) UNMODIFIED -> HF LlamaForCausalLM.generate (fp32, transformers
@@ -401,6 +421,7 @@ if __name__ == "__main__":
             globals()["gen_" + nme]()
         sys.exit(0)
     gen_generate()
+    gen_cov1d()
     gen_mel()
     gen_batcher()
     gen_hubert()

@@ -24,3 +24,6 @@ QFORMER_CASE = dict(cfg=O.qformer_config(qf_layers=2, qf_queries=8), enc_dim=128
 # prompts -> left padding; eos id is chosen by make_golden so that hypotheses finish at different lengths
 GENERATE_CASE = dict(cfg=O.make_config(), lm_head_scales=(24.0, 5.0), clip_samples=(32000, 22400, 28800), prompt_lens=(6, 4, 7),
                      max_new_tokens=12, pad=0, bos=1)
+
+# cov1d-linear projector (f4, models/projector.py:29-49): T not a multiple of k (tail frames dropped by the strided conv)
+COV1D_CASE = dict(enc_dim=128, llm_dim=192, k=5, B=2, T=43)

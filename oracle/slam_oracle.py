@@ -223,6 +223,30 @@ def projector_concat(W, x: torch.Tensor, k: int, prefix="encoder_projector.") ->
 
 
 
+def projector_cov1d(W, x: torch.Tensor, k: int, prefix="encoder_projector.") -> torch.Tensor:
+    """EncoderProjectorCov1d.forward, src/slam_llm/models/projector.py:29-49: Conv1d(d, d, kernel=k, stride=k) over
+    time, ReLU, Linear(d, 2048), ReLU, Linear(2048, llm_dim).  kernel = stride and no padding, so the conv is a
+    linear map of each k-frame stack: out[t] = sum_j W[:, :, j] x[t*k + j] + b (tail frames beyond k*(T//k) dropped)."""
+    B, T, d = x.shape
+    Ta = T // k
+    frames = x[:, : Ta * k].reshape(B, Ta, k, d)
+    c = torch.einsum("btjc,ocj->bto", frames, W[prefix + "conv1d.weight"]) + W[prefix + "conv1d.bias"]
+    h = F.relu(F.linear(F.relu(c), W[prefix + "linear1.weight"], W[prefix + "linear1.bias"]))
+    return F.linear(h, W[prefix + "linear2.weight"], W[prefix + "linear2.bias"])
+
+
+def init_cov1d_weights(enc_dim: int, llm_dim: int, k: int, hidden: int = 2048, seed: int = 13,
+                       prefix="encoder_projector.") -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s, std: torch.randn(*s, generator=g) * std  # noqa: E731
+    return {prefix + "conv1d.weight": rn(enc_dim, enc_dim, k, std=(enc_dim * k) ** -0.5),
+            prefix + "conv1d.bias": rn(enc_dim, std=0.05),
+            prefix + "linear1.weight": rn(hidden, enc_dim, std=enc_dim ** -0.5),
+            prefix + "linear1.bias": rn(hidden, std=0.05),
+            prefix + "linear2.weight": rn(llm_dim, hidden, std=hidden ** -0.5),
+            prefix + "linear2.bias": rn(llm_dim, std=0.05)}
+
+
 # ---------------------------------------------------------------------------------------------- a3': Q-Former projector
 def qformer_config(**kw) -> dict:
     """Blip2QFormerConfig defaults as used by EncoderProjectorQFormer (src/slam_llm/models/projector.py:52-67):

@@ -95,4 +95,7 @@ def collate(samples: List[dict], pad_token_id: int, left_pad_prompt: bool, n_sam
     out["audio"] = torch.stack([torch.nn.functional.pad(s["audio"][:amax].float(), (0, amax - min(len(s["audio"]), amax)))
                                 for s in samples])
     out["audio_len"] = alen
+    if "key" in samples[0]:  # inference-mode batches carry the utterance ids / references (speech_dataset.py:259-273)
+        out["keys"] = [s.get("key") for s in samples]
+        out["targets"] = [s.get("target") for s in samples]
     return out

@@ -500,6 +500,82 @@ class HipProjectorConcat(nn.Module):
         return self.forward_hip(x, None)
 
 
+class HipProjectorCov1d(nn.Module):
+    """EncoderProjectorCov1d (src/slam_llm/models/projector.py:29-49): Conv1d(d, d, kernel = stride = k) over time, ReLU,
+    Linear(d, 2048), ReLU, Linear(2048, llm_dim).  kernel == stride with no padding makes the conv a Linear over the
+    k-frame stack, so it runs on the same GEMM as the concat projector: Wc[co, j*d + ci] = conv.weight[co, ci, j]
+    (re-packed from the fp32 master at refresh; its gradient is un-packed into the reference's [co, ci, j] layout)."""
+
+    def __init__(self, cfg: dict, store: TrainableStore, prefix="encoder_projector."):
+        super().__init__()
+        self.k, self.d, self.hid, self.dl = cfg["ds_rate"], cfg["enc_dim"], cfg["proj_hidden"], cfg["llm_dim"]
+        self.store, self.prefix = store, prefix
+        assert self.d % 64 == 0 and self.hid % 64 == 0 and self.dl % 64 == 0
+        store.reserve(prefix + "conv1d.weight", (self.d, self.d, self.k))
+        store.reserve(prefix + "conv1d.bias", (self.d,))
+        store.reserve(prefix + "linear1.weight", (self.hid, self.d))
+        store.reserve(prefix + "linear1.bias", (self.hid,))
+        store.reserve(prefix + "linear2.weight", (self.dl, self.hid))
+        store.reserve(prefix + "linear2.bias", (self.dl,))
+        self.conv1d, self.linear1, self.linear2 = nn.Module(), nn.Module(), nn.Module()
+
+    def bind(self):
+        s, p = self.store, self.prefix
+        for m, n in ((self.conv1d, "conv1d"), (self.linear1, "linear1"), (self.linear2, "linear2")):
+            m.weight, m.bias = s.params[p + n + ".weight"], s.params[p + n + ".bias"]
+
+    def refresh(self):
+        s, p = self.store, self.prefix
+        d, k = self.d, self.k
+        # frame-major packing of the conv taps: [co, ci, j] -> [co, j*d + ci] (one strided copy of 5*d^2 elements)
+        self.wc = s.bf16_view(p + "conv1d.weight").permute(0, 2, 1).reshape(d, k * d).contiguous()
+        self.w1T = ops.transpose(s.bf16_view(p + "linear1.weight"), Rp=self.hid)  # [d, hid]
+        self.w2T = ops.transpose(s.bf16_view(p + "linear2.weight"), Rp=self.dl)   # [hid, dl]
+
+    def forward_hip(self, enc: torch.Tensor, stash: Optional[dict]):
+        """enc [B, T2, d] bf16 -> [B, T2 // k, dl] bf16"""
+        s, p = self.store, self.prefix
+        B, T2, d = enc.shape
+        Ta = T2 // self.k
+        xp = enc[:, : Ta * self.k, :]
+        if T2 % self.k:
+            xp = xp.contiguous()
+        xp = xp.reshape(B * Ta, self.k * d)
+        c = ops.gemm_nt(xp, self.wc, bias=s.master_view(p + "conv1d.bias"), act=ACT_RELU)
+        h = ops.gemm_nt(c, s.bf16_view(p + "linear1.weight"), bias=s.master_view(p + "linear1.bias"), act=ACT_RELU)
+        y = ops.gemm_nt(h, s.bf16_view(p + "linear2.weight"), bias=s.master_view(p + "linear2.bias"))
+        if stash is not None:
+            stash["proj"] = (xp, c, h)
+        return y.view(B, Ta, self.dl)
+
+    def backward_hip(self, dy: torch.Tensor, stash: dict, accumulate: bool):
+        s, p = self.store, self.prefix
+        xp, c, h = stash.pop("proj")
+        M = dy.shape[0]
+        Mp = round_up(M, 64)
+        ops.gemm_nt(ops.transpose(dy, Rp=Mp), ops.transpose(h, Rp=Mp), out=s.grad_view(p + "linear2.weight"),
+                    accumulate=accumulate)
+        ops.colsum(dy, s.grad_view(p + "linear2.bias"), accumulate=accumulate)
+        dh = ops.gemm_nt(dy, self.w2T)
+        ops.relu_bwd_(dh, h)
+        ops.gemm_nt(ops.transpose(dh, Rp=Mp), ops.transpose(c, Rp=Mp), out=s.grad_view(p + "linear1.weight"),
+                    accumulate=accumulate)
+        ops.colsum(dh, s.grad_view(p + "linear1.bias"), accumulate=accumulate)
+        dc = ops.gemm_nt(dh, self.w1T)
+        ops.relu_bwd_(dc, c)
+        dwc = ops.gemm_nt(ops.transpose(dc, Rp=Mp), ops.transpose(xp, Rp=Mp), out_dtype=torch.float32)  # [d, k*d]
+        g = s.grad_view(p + "conv1d.weight")                                  # reference layout [co, ci, j]
+        dwc = dwc.view(self.d, self.k, self.d).permute(0, 2, 1)
+        if accumulate:
+            g.add_(dwc)
+        else:
+            g.copy_(dwc)
+        ops.colsum(dc, s.grad_view(p + "conv1d.bias"), accumulate=accumulate)
+
+    def forward(self, x):
+        return self.forward_hip(x, None)
+
+
 # ======================================================================================== llama + LoRA
 def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
     """register `param` under a dotted path, creating plain container modules on the way."""
@@ -890,6 +966,10 @@ class SlamHipModel(nn.Module):
         if self.projector_name == "q-former":
             from .qformer import HipProjectorQFormer
             self.encoder_projector = HipProjectorQFormer(cfg, self.store)
+        elif self.projector_name == "cov1d-linear":
+            self.encoder_projector = HipProjectorCov1d(cfg, self.store)
+        elif self.projector_name != "linear":
+            raise ValueError(f"unknown encoder_projector {self.projector_name!r} (linear | cov1d-linear | q-former)")
         else:
             self.encoder_projector = HipProjectorConcat(cfg, self.store)  # projector last = produced last in backward
         self.store.allocate()

@@ -59,9 +59,9 @@ def build_config(train_config, model_config) -> dict:
         raise NotImplementedError(f"encoder_name={enc_name}: the HIP path covers the Whisper (slam_model.py:320-321) and HuBERT "
                                   "(:335-341) branches; WavLM & co. are SURVEY 8(f) rows")
     projector = _get(model_config, "encoder_projector", "linear")
-    if projector not in ("linear", "q-former"):
-        raise NotImplementedError("encoder_projector must be `linear` (EncoderProjectorConcat) or `q-former` "
-                                  "(EncoderProjectorQFormer); cov1d-linear is a SURVEY 8(f) row")
+    if projector not in ("linear", "cov1d-linear", "q-former"):
+        raise NotImplementedError("encoder_projector must be `linear` (EncoderProjectorConcat), `cov1d-linear` "
+                                  "(EncoderProjectorCov1d) or `q-former` (EncoderProjectorQFormer)")
     enc_presets = {k: v for k, v in PRESETS.items() if k.startswith("whisper")}
     llm_presets = {k: v for k, v in PRESETS.items() if not k.startswith("whisper")}
     llm = _get(model_config, "arch_llm") or _guess_preset(str(_get(model_config, "llm_name", "")), llm_presets)
@@ -130,3 +130,21 @@ def model_factory(train_config, model_config, **kwargs):
 def get_speech_dataset(dataset_config, tokenizer, split):
     from slam_llm_amd.dataset import SpeechDatasetJsonlRaw
     return SpeechDatasetJsonlRaw(dataset_config, tokenizer, split)
+
+
+def inference_batch(model, tokenizer, dataloader, decode_log: str, device="cuda", **generate_kwargs):
+    """Loop body of the reference's batch decoder (src/slam_llm/pipeline/inference_batch.py:118-137): move the batch,
+    `model.generate(**batch)`, `tokenizer.batch_decode(..., skip_special_tokens=True)`, write `<decode_log>_pred` /
+    `<decode_log>_gt` as "key\ttext" lines.  Returns the number of utterances written."""
+    import torch
+    n = 0
+    with open(decode_log + "_pred", "w") as pred, open(decode_log + "_gt", "w") as gt:
+        for batch in dataloader:
+            batch = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+            tokens = model.generate(**batch, **generate_kwargs)
+            texts = tokenizer.batch_decode(tokens, add_special_tokens=False, skip_special_tokens=True)
+            for key, text, target in zip(batch["keys"], texts, batch["targets"]):
+                pred.write(f"{key}\t{text.replace(chr(10), ' ')}\n")
+                gt.write(f"{key}\t{target}\n")
+                n += 1
+    return n

@@ -120,3 +120,21 @@ def test_decode_bookkeeping_matches_reference_generate(scale):
             got = decode.beam_search(step_fn, B, nb, C["max_new_tokens"], eos, pad, 1, lp, "cpu")
         want = fx[f"s{scale}.tokens.b{nb}.lp{lp}.pad{pad}"]
         assert tuple(got.shape) == want.shape and (got.numpy() == want).all(), (nb, lp, pad, got, want)
+
+
+def test_inference_collator_reproduces_reference_layout():
+    """inference-mode samples ([audio, prompt], no labels) through the product collator == the batch of
+    tests/golden/generate.npz (built by the oracle's restatement of speech_dataset.py:120-134 + :216-273)."""
+    fx = G.load("generate")
+    ids, am, mm = (torch.from_numpy(fx["batch." + k]) for k in ("input_ids", "attention_mask", "modality_mask"))
+    samples = []
+    for b in range(ids.shape[0]):
+        row = ids[b][am[b].bool()]
+        alen = int(mm[b].sum())
+        s = batcher.make_sample(torch.zeros(1600), row[alen:].tolist(), None, 2, alen)
+        s.update(key=f"utt{b}", target=f"ref {b}")
+        samples.append(s)
+    out = batcher.collate(samples, pad_token_id=2, left_pad_prompt=True)
+    assert torch.equal(out["attention_mask"], am.bool()) and torch.equal(out["modality_mask"], mm.bool())
+    assert torch.equal(out["input_ids"].masked_fill(mm.bool(), 0), ids.masked_fill(mm.bool(), 0))
+    assert "labels" not in out and out["keys"] == ["utt0", "utt1", "utt2"] and out["targets"][2] == "ref 2"

@@ -99,6 +99,19 @@ def test_qformer_projector_matches_reference_module():
         G.check_packed(fx, "grad." + n, v.grad.numpy(), atol=2e-5, rtol=2e-3, norm_rtol=None if tiny else 1e-3)
 
 
+def test_cov1d_projector_matches_reference_module():
+    from oracle.make_golden_cases import COV1D_CASE as C
+    fx = G.load("cov1d")
+    W = O.init_cov1d_weights(C["enc_dim"], C["llm_dim"], C["k"])
+    for v in W.values():
+        v.requires_grad_(True)
+    out = O.projector_cov1d(W, torch.from_numpy(fx["x"]), C["k"])
+    G.check_packed(fx, "out", out.detach().numpy(), atol=2e-5, rtol=1e-4)
+    (out * torch.from_numpy(fx["cot"])).sum().backward()
+    for n, v in W.items():
+        G.check_packed(fx, "grad." + n, v.grad.numpy(), atol=2e-5, rtol=1e-3, norm_rtol=1e-4)
+
+
 GEN_RUNS = ((1, 1.0, 0), (4, 1.0, 0), (4, 2.0, 1), (3, 0.0, 1))
 
 
