@@ -435,11 +435,17 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
   hipStream_t s = (hipStream_t)stream;
   int cfg = g_gemm_cfg;
   if (cfg == 0) {
-    // auto (measured on MI355X, profiles/r01_perf_ops_first.json): the 256x256 tile wins whenever it still gives
-    // >= 2 full waves of workgroups over the 256 CUs; otherwise 128x128 (4 waves, 2 WG/CU); skinny N takes 128x64.
+    // auto (measured on MI355X, profiles/r01_perf_ops_first.json, tools/gemm_bench.py): the pipelined 256x256 tile
+    // runs 1.25-1.4x the 128x128 one per CU; pick whichever loses less to wave quantisation over the 256 CUs
+    // (256x256: 1 WG/CU -> 256 slots per round; 128x128: 2 WG/CU -> 512 slots).  E.g. the lm_head^T product of the
+    // CE backward (4096 x 4096 x 128256) is exactly 256 big tiles = one full round.  Skinny N takes 128x64.
     const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+    const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+    // time in units of "one CU doing one 128x128 tile": a 256x256 round = 4 tiles of work at ~1.3-1.4x speed (ties go to the big tile)
+    const double t256 = (double)((tiles256 + 255) / 256) * (4.0 / 1.4);
+    const double t128 = (double)((tiles128 + 511) / 512) * 2.0;
     if (N <= 64) cfg = 3;
-    else if (tiles256 >= 512) cfg = 6;  // register-double-buffered pipeline: +10-12 % over the plain 2-stage loop
+    else if (t256 < t128) cfg = 6;
     else cfg = 1;
   }
   switch (cfg) {

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void skinny_gram_reduce_kernel(const float* __
 }  // namespace
 
 extern "C" int64_t slam_skinny_gram_workspace_bytes(int64_t M, int64_t R, int64_t C) {
-  const int64_t nsplit = (M + 127) / 128;
+  const int64_t nsplit = (M + 255) / 256;
   return nsplit * R * C * (int64_t)sizeof(float);
 }
 
@@ -331,7 +331,7 @@ extern "C" int slam_skinny_gram(const void* S, int64_t lds_, const void* X, int6
   SLAM_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0, "slam_skinny_gram: C and ldx must be multiples of 8");
   SLAM_CHECK_ARG(lds_ % (R / 4) == 0 && ((uintptr_t)S % (R / 2)) == 0, "slam_skinny_gram: S must be aligned to R/4 elements (vector loads)");
   SLAM_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)workspace % 16) == 0, "slam_skinny_gram: X/workspace must be 16-byte aligned");
-  const int rows_per_split = 128;
+  const int rows_per_split = 256;
   const int nsplit = (int)((M + rows_per_split - 1) / rows_per_split);
   dim3 grid((unsigned)cdiv64(C, 512), (unsigned)nsplit);
   hipStream_t s = (hipStream_t)stream;

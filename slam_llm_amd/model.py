@@ -215,13 +215,17 @@ class FusedLinear:
                 hop = ops.gemm_nt(dx_ext[:, self.K:], self.AcatT)           # dL/d(dropout(x))
                 ops.dropout(hop, *drop, out=dx_ext[:, : self.K], accumulate=True)  # same mask, recomputed
                 xin = ops.dropout(xin, *drop)                                 # recomputed for dA
-            K = self.K
+            K, sr = self.K, self.sum_r
+            # dA[r, K] = du^T x ;  dB[rows, r] = (alpha/r) * dy[:, rows]^T u   (HBM-bound tall-skinny products).
+            # All adapters of the group share x and their A's (and A gradients) are contiguous: one pass over x.
+            if sr in (8, 16, 32, 64):
+                ops.skinny_gram(dx_ext[:, K: K + sr], xin, self.a_cat_grad(store), K, 1, accumulate=accumulate)
             for a in self.adapters:
                 r = a["r"]
-                du = dx_ext[:, K + a["j0"]: K + a["j0"] + r]          # dL/d(xA^T)  [M, r]
+                if sr not in (8, 16, 32, 64):
+                    ops.skinny_gram(dx_ext[:, K + a["j0"]: K + a["j0"] + r], xin, store.grad_view(a["A"]), K, 1,
+                                    accumulate=accumulate)
                 u = x_ext[:, K + a["j0"]: K + a["j0"] + r]            # xA^T        [M, r]
-                # dA[r, K] = du^T x ;  dB[rows, r] = (alpha/r) * dy[:, rows]^T u   (HBM-bound tall-skinny products)
-                ops.skinny_gram(du, xin, store.grad_view(a["A"]), K, 1, accumulate=accumulate)
                 ops.skinny_gram(u, dy[:, a["row0"]: a["row0"] + a["rows"]], store.grad_view(a["B"]), 1, r,
                                 alpha=a["scale"], accumulate=accumulate)
         return dx_ext

@@ -124,7 +124,10 @@ def gemm_kernel_name(M: int, N: int) -> str:
     cfg = _GEMM_CFG
     if cfg == 0:
         tiles256 = ((M + 255) // 256) * ((N + 255) // 256)
-        cfg = 3 if N <= 64 else (6 if tiles256 >= 512 else 1)
+        tiles128 = ((M + 127) // 128) * ((N + 127) // 128)
+        t256 = ((tiles256 + 255) // 256) * (4.0 / 1.4)
+        t128 = ((tiles128 + 511) // 512) * 2.0
+        cfg = 3 if N <= 64 else (6 if t256 < t128 else 1)
     return _GEMM_NAMES[cfg]
 
 
@@ -444,9 +447,8 @@ def skinny_gram(S2d, X2d, out, out_ld_r, out_ld_c, alpha=1.0, accumulate=False):
     M2, C = X2d.shape
     assert M == M2
     nbytes = call("slam_skinny_gram_workspace_bytes", M, R, C)
-    key = (str(S2d.device), nbytes)
-    if key not in _GRAM_WS:
-        _GRAM_WS.clear()
+    key = str(S2d.device)
+    if key not in _GRAM_WS or _GRAM_WS[key].numel() * 4 < nbytes:   # one workspace per device, grown to the largest need
         _GRAM_WS[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=S2d.device)
     call("slam_skinny_gram", _p(S2d), _ld(S2d), _p(X2d), _ld(X2d), _p(out), out_ld_r, out_ld_c, M, R, C, alpha,
          1 if accumulate else 0, _p(_GRAM_WS[key]), _s())
