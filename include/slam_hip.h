@@ -106,7 +106,9 @@ int slam_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int
  * Q/K/V/O/dO row-major [B*T, ld] with head h at column h*D; Vt/Kt/Qt/dOt = [B,H,D,Tp] transposed copies;
  * LSE/Delta [B,Hq,Tqp] f32; key_mask [B,Tkp] uint8 (1 = attend, zero padded) or NULL; D in {64,128}.
  * Query rows are (b*Tq + t), key/value rows (b*Tk + t): Tq != Tk is cross-attention (Q-Former, projector.py:69-80);
- * Tqp/Tkp are the 64-padded lengths used by the transposed copies, LSE/Delta and the mask. */
+ * Tqp/Tkp are the 64-padded lengths used by the transposed copies, LSE/Delta and the mask.
+ * slam_attn_bwd rope_cos/rope_sin (nullable, [T, D/2] f32): when set, dQ and dK are the gradients w.r.t. the
+ * PRE-RoPE q/k (the backward of HF apply_rotary_pos_emb with position = row index is applied in the epilogue). */
 int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, void* O,
                   int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B, int64_t Tq, int64_t Tk,
                   int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
@@ -116,7 +118,8 @@ int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
                   int64_t lddo, const void* dOt, const float* LSE, float* Delta, const uint8_t* key_mask,
                   void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv, int64_t B,
                   int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D,
-                  int causal, float scale, void* stream);
+                  int causal, float scale,
+                  const float* rope_cos, const float* rope_sin, void* stream);
 
 /* ---- SwiGLU (LlamaMLP) : gate_up [M, 2F] = [gate | up] ---------------------------------------------- */
 int slam_swiglu_fwd(const void* gate_up, int64_t ldgu, void* h, int64_t ldh, int64_t M, int64_t F,
@@ -137,8 +140,14 @@ int slam_lora_pack_b(const float* B, float scale, void* dst, int64_t ld_dst, voi
  * S [M,R] bf16 (R in 8|16|32|64), X [M,C] bf16, out fp32; workspace: slam_skinny_gram_workspace_bytes(M,R,C). */
 int64_t slam_skinny_gram_workspace_bytes(int64_t M, int64_t R, int64_t C);
 int slam_skinny_gram(const void* S, int64_t lds, const void* X, int64_t ldx, float* out, int64_t out_ld_r,
-                     int64_t out_ld_c, int64_t M, int64_t R, int64_t C, float alpha, int accumulate,
-                     float* workspace, void* stream);
+                     int64_t out_ld_c, int64_t M, int64_t R, int64_t C, float alpha, int accumulate, float drop_p,
+                     uint64_t seed, uint64_t offset, float* workspace, void* stream);
+
+/* LoRA first hop u[M, R] = lora_dropout(x)[M, K] . A[R, K]^T (peft 0.6.0 Linear.forward: lora_A(lora_dropout(x))), R <= 64
+ * = all adapters sharing x stacked.  drop_p > 0 applies the counter-based mask of slam_dropout_bf16 (same seed / offset /
+ * element index -> same mask) in registers; slam_skinny_gram's drop_p does the same to X for dA = du^T dropout(x). */
+int slam_lora_a_fwd(const void* X, int64_t ldx, const void* A, int64_t lda, void* U, int64_t ldu, int64_t M, int64_t R,
+                    int64_t K, float drop_p, uint64_t seed, uint64_t offset, void* stream);
 
 /* ---- embed + audio splice (src/slam_llm/models/slam_model.py:370-392) and its backward --------------
  * input_ids int64 [B,T] (-1 -> 0 in place), modality_mask uint8 [B,T], enc = projector output [B,Ta,ldenc],

@@ -42,7 +42,28 @@ struct AttnParams {
   const uint8_t* kmask;             // [B, Tp] 1 = attend (zero padded) or null
   int Tq, Tk, Tqp, Tkp, Hq, Hkv;  // query / key lengths and their 64-padded strides (Tq == Tk for self-attention)
   float scale;                      // softmax scale (1/sqrt(D))
+  const float* rope_cos;            // backward only, nullable: [T, D/2] RoPE tables; when set dQ and dK are rotated back
+  const float* rope_sin;            //   (d/dx of the forward rotation, position = row index) before they are stored
 };
+
+// gradient of HF's rotate_half RoPE for one row held as DF fragments of 4 consecutive head-dim elements per lane:
+// dx1 = dy1 cos + dy2 sin, dx2 = dy2 cos - dy1 sin with (1, 2) = (d, d + D/2) -> fragments (df, df + DF/2) of the same lane
+template <int DF>
+__device__ __forceinline__ void rope_grad_inplace(f32x4_t (&v)[DF], const float* cosT, const float* sinT, int pos, int D,
+                                                  int g) {
+#pragma unroll
+  for (int df = 0; df < DF / 2; df++) {
+    const float4 c4 = *reinterpret_cast<const float4*>(cosT + (int64_t)pos * (D / 2) + df * 16 + 4 * g);
+    const float4 s4 = *reinterpret_cast<const float4*>(sinT + (int64_t)pos * (D / 2) + df * 16 + 4 * g);
+    const float cs[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float a = v[df][r], b = v[df + DF / 2][r];
+      v[df][r] = a * cs[r] + b * sn[r];
+      v[df + DF / 2][r] = b * cs[r] - a * sn[r];
+    }
+  }
+}
 
 __device__ __forceinline__ f32x4_t mfma16(frag_t a, frag_t b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
@@ -451,6 +472,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     }
   }
   if (!qok) return;
+  if (p.rope_cos) rope_grad_inplace<DF>(dq, p.rope_cos, p.rope_sin, q, D, g);
   bf16_t* orow = p.dQ + ((int64_t)b * Tq + q) * p.lddq + h * D;
 #pragma unroll
   for (int df = 0; df < DF; df++) {
@@ -612,6 +634,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
     }
   }
   if (key >= Tk) return;
+  if (p.rope_cos) rope_grad_inplace<DF>(dk, p.rope_cos, p.rope_sin, key, D, g);
   bf16_t* krow = p.dK + ((int64_t)b * Tk + key) * p.lddk + hk * D;
   bf16_t* vrow = p.dV + ((int64_t)b * Tk + key) * p.lddv + hk * D;
 #pragma unroll
@@ -668,8 +691,11 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
                              const void* dO, int64_t lddo, const void* dOt, const float* LSE,
                              float* Delta, const uint8_t* key_mask, void* dQ, int64_t lddq, void* dK,
                              int64_t lddk, void* dV, int64_t lddv, int64_t B, int64_t Tq, int64_t Tk, int64_t Tqp,
-                             int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale, void* stream) {
+                             int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
+                             const float* rope_cos, const float* rope_sin, void* stream) {
   SLAM_CHECK_ARG(Q && K && V && Qt && Kt && O && dO && dOt && LSE && Delta && dQ && dK && dV, "slam_attn_bwd: null pointer");
+  SLAM_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr), "slam_attn_bwd: rope_cos/rope_sin must both be set or both null");
+  SLAM_CHECK_ARG(!rope_cos || Tq == Tk, "slam_attn_bwd: the fused RoPE gradient needs self-attention (Tq == Tk)");
   if (int rc = check_common("slam_attn_bwd", B, Tq, Tk, Tqp, Tkp, Hq, Hkv, D, causal)) return rc;
   SLAM_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && ldo % 2 == 0 &&
                      lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0,
@@ -681,6 +707,7 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.dQ = (bf16_t*)dQ; p.lddq = lddq; p.dK = (bf16_t*)dK; p.lddk = lddk; p.dV = (bf16_t*)dV; p.lddv = lddv;
   p.LSE = (float*)LSE; p.Delta = Delta; p.kmask = key_mask;
   p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
+  p.rope_cos = rope_cos; p.rope_sin = rope_sin;
   hipStream_t s = (hipStream_t)stream;
   dim3 gdel((unsigned)cdiv64(Tq * Hq, 4), 1, (unsigned)B);
   dim3 gq((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B);

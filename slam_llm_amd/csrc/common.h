@@ -91,4 +91,28 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
+// ---- counter-based dropout mask (peft lora_dropout; shared by every kernel that applies or recomputes it) -------
+// One splitmix64 hash serves the 4 consecutive elements of group (index >> 2), 16 random bits each:
+//   keep(index) = bits16(index) >= round(p * 2^16).   `base` must be a multiple of 8; bit e of the result = keep(base+e).
+__device__ __forceinline__ unsigned long long slam_mix64(unsigned long long z) {  // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned slam_keep8(unsigned long long seed, unsigned long long base, unsigned thresh16) {
+  unsigned bits = 0;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const unsigned long long h = slam_mix64(seed ^ (((base >> 2) + q) * 0xD1342543DE82EF95ull));
+#pragma unroll
+    for (int e = 0; e < 4; e++) bits |= ((unsigned)((h >> (16 * e)) & 0xFFFFull) >= thresh16 ? 1u : 0u) << (q * 4 + e);
+  }
+  return bits;
+}
+static inline unsigned slam_drop_thresh16(float p) {
+  const double t = (double)p * 65536.0 + 0.5;
+  return t >= 65535.0 ? 65535u : (unsigned)t;
+}
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

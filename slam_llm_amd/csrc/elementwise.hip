@@ -474,13 +474,6 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
 // One splitmix64 hash serves 4 consecutive elements (16 random bits each, keep = bits >= round(p * 2^16)): the
 // 64-bit multiplies made a hash per element VALU-bound (58 us for 11780 x 4096 instead of the 35 us of its HBM traffic).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {  // splitmix64 finaliser
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out,
                                                       int64_t ldo, int64_t M, int N, float inv_keep, unsigned thresh,
                                                       unsigned long long seed, unsigned long long offset, int accumulate) {
@@ -493,11 +486,10 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__
     u16x8_t o;
     if (accumulate) o = *reinterpret_cast<const u16x8_t*>(out + m * ldo + c * 8);
     const unsigned long long base = offset + (unsigned long long)m * (unsigned long long)N + (unsigned long long)c * 8ull;
-    const unsigned long long h[2] = {mix64(seed ^ ((base >> 2) * 0xD1342543DE82EF95ull)),
-                                     mix64(seed ^ (((base >> 2) + 1ull) * 0xD1342543DE82EF95ull))};
+    const unsigned keep8 = slam_keep8(seed, base, thresh);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      const bool keep = (unsigned)((h[e >> 2] >> (16 * (e & 3))) & 0xFFFFull) >= thresh;
+      const bool keep = (keep8 >> e) & 1u;
       const float val = keep ? bf2f(v[e]) * inv_keep : 0.f;
       o[e] = f2bf(accumulate ? bf2f(o[e]) + val : val);
     }
@@ -723,8 +715,7 @@ extern "C" int slam_dropout_bf16(const void* x, int64_t ldx, void* out, int64_t 
   SLAM_CHECK_ARG(x && out && M > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "slam_dropout_bf16: bad arguments");
   SLAM_CHECK_ARG(p >= 0.f && p < 1.f, "slam_dropout_bf16: p=%f must be in [0, 1)", (double)p);
   SLAM_CHECK_ARG(offset % 8 == 0, "slam_dropout_bf16: offset must be a multiple of 8");
-  const double t = (double)p * 65536.0 + 0.5;
-  const unsigned thresh = t >= 65535.0 ? 65535u : (unsigned)t;
+  const unsigned thresh = slam_drop_thresh16(p);
   hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(M * (N / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
                      (bf16_t*)out, ldo, M, (int)N, 1.0f / (1.0f - p), thresh, (unsigned long long)seed,
                      (unsigned long long)offset, accumulate);

@@ -248,7 +248,8 @@ template <int RW>
 __global__ __launch_bounds__(256) void skinny_gram_kernel(const bf16_t* __restrict__ S, int64_t lds_,
                                                           const bf16_t* __restrict__ X, int64_t ldx,
                                                           float* __restrict__ ws, int M, int R, int C,
-                                                          int rows_per_split) {
+                                                          int rows_per_split, unsigned thresh16,
+                                                          unsigned long long seed, unsigned long long offset) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = blockIdx.x * 512 + lane * 8;
   const int r0 = wave * RW;
@@ -274,8 +275,10 @@ __global__ __launch_bounds__(256) void skinny_gram_kernel(const bf16_t* __restri
 #pragma unroll
       for (int u = 0; u < U; u++) {
         float xf[8];
+        // X = dropout(x) recomputed from the counter-based mask (the 1/(1-p) scale is folded into alpha by the host)
+        const unsigned keep = thresh16 ? slam_keep8(seed, offset + (unsigned long long)(m + u) * (unsigned long long)C + c0, thresh16) : 0xFFu;
 #pragma unroll
-        for (int e = 0; e < 8; e++) xf[e] = bf2f(xv[u][e]);
+        for (int e = 0; e < 8; e++) xf[e] = ((keep >> e) & 1u) ? bf2f(xv[u][e]) : 0.f;
 #pragma unroll
         for (int i = 0; i < RW; i++) {
           const float sf = bf2f(sv[u][i]);
@@ -287,11 +290,12 @@ __global__ __launch_bounds__(256) void skinny_gram_kernel(const bf16_t* __restri
     for (; m < m1; m++) {
       const u16x8_t xv = *reinterpret_cast<const u16x8_t*>(X + (int64_t)m * ldx + c0);
       const svec_t sv = *reinterpret_cast<const svec_t*>(S + (int64_t)m * lds_ + r0);
+      const unsigned keep = thresh16 ? slam_keep8(seed, offset + (unsigned long long)m * (unsigned long long)C + c0, thresh16) : 0xFFu;
 #pragma unroll
       for (int i = 0; i < RW; i++) {
         const float sf = bf2f(sv[i]);
 #pragma unroll
-        for (int e = 0; e < 8; e++) acc[i][e] = fmaf(sf, bf2f(xv[e]), acc[i][e]);
+        for (int e = 0; e < 8; e++) acc[i][e] = fmaf(sf, ((keep >> e) & 1u) ? bf2f(xv[e]) : 0.f, acc[i][e]);
       }
     }
     float* w = ws + ((int64_t)blockIdx.y * R + r0) * C + c0;
@@ -316,7 +320,122 @@ __global__ __launch_bounds__(256) void skinny_gram_reduce_kernel(const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// LoRA first hop  u[M, R] = dropout(x)[M, K] . A[R, K]^T   (peft: lora_A(lora_dropout(x)), R = sum of the ranks of the
+// adapters sharing x, <= 64).  HBM-bound on x: a 128-row MFMA GEMM tile gives only M/128 workgroups (93 for the C3
+// batch) -- here a workgroup owns 32 rows and its 4 waves split K (fixed-order LDS reduction), the dropout mask is
+// recomputed in registers, so x is read once and no dropout(x) copy is ever written.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void lora_a_fwd_kernel(const bf16_t* __restrict__ X, int64_t ldx,
+                                                         const bf16_t* __restrict__ A, int64_t lda,
+                                                         bf16_t* __restrict__ U, int64_t ldu, int M, int R, int K,
+                                                         unsigned thresh16, float inv_keep, unsigned long long seed,
+                                                         unsigned long long offset) {
+  __shared__ float red[4][2 * NT][256 + 4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * 32;
+  const int kw = (int)(((K / 64 + 3) / 4) * 64);
+  const int k_begin = wave * kw, k_end = min(K, k_begin + kw);
+  int mrow[2];
+  const bf16_t* xp[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++) {
+    mrow[mt] = min(m0 + mt * 16 + r, M - 1);
+    xp[mt] = X + (int64_t)mrow[mt] * ldx + g * 16;
+  }
+  const bf16_t* ap[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) ap[nt] = A + (int64_t)min(nt * 16 + r, R - 1) * lda + g * 16;
+  f32x4_t acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = k_begin; k0 < k_end; k0 += 64) {
+    u16x8_t xf[2][2], af[NT][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+      xf[mt][0] = *reinterpret_cast<const u16x8_t*>(xp[mt] + k0);
+      xf[mt][1] = *reinterpret_cast<const u16x8_t*>(xp[mt] + k0 + 8);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      af[nt][0] = *reinterpret_cast<const u16x8_t*>(ap[nt] + k0);
+      af[nt][1] = *reinterpret_cast<const u16x8_t*>(ap[nt] + k0 + 8);
+    }
+    if (thresh16) {
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+          const unsigned keep = slam_keep8(seed, offset + (unsigned long long)mrow[mt] * (unsigned long long)K +
+                                                     (unsigned long long)(k0 + g * 16 + hf * 8), thresh16);
+#pragma unroll
+          for (int e = 0; e < 8; e++)
+            if (!((keep >> e) & 1u)) xf[mt][hf][e] = 0;
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[nt][0]),
+                                                             __builtin_bit_cast(bf16x8_t, xf[mt][0]), acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[nt][1]),
+                                                             __builtin_bit_cast(bf16x8_t, xf[mt][1]), acc[mt][nt], 0, 0, 0);
+      }
+  }
+  // acc[mt][nt][i] = u[m0 + mt*16 + r][nt*16 + 4g + i]
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) *reinterpret_cast<f32x4_t*>(&red[wave][mt * NT + nt][lane * 4]) = acc[mt][nt];
+  __syncthreads();
+  for (int idx = tid; idx < 32 * NT * 4; idx += 256) {   // (row, 4 consecutive ranks)
+    const int row = idx / (NT * 4), jq = idx % (NT * 4);
+    const int mt = row >> 4, rr = row & 15, nt = jq >> 2, gg = jq & 3;
+    const int m = m0 + row, j = nt * 16 + gg * 4;
+    if (m >= M || j >= R) continue;
+    const int src = (gg * 16 + rr) * 4;
+    f32x4_t v = *reinterpret_cast<const f32x4_t*>(&red[0][mt * NT + nt][src]);
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+      const f32x4_t t = *reinterpret_cast<const f32x4_t*>(&red[w][mt * NT + nt][src]);
+#pragma unroll
+      for (int i = 0; i < 4; i++) v[i] += t[i];
+    }
+    uint2 o;
+    o.x = pack2bf(v[0] * inv_keep, v[1] * inv_keep);
+    o.y = pack2bf(v[2] * inv_keep, v[3] * inv_keep);
+    *reinterpret_cast<uint2*>(U + (int64_t)m * ldu + j) = o;
+  }
+}
+
 }  // namespace
+
+extern "C" int slam_lora_a_fwd(const void* X, int64_t ldx, const void* A, int64_t lda, void* U, int64_t ldu, int64_t M,
+                               int64_t R, int64_t K, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
+  SLAM_CHECK_ARG(X && A && U, "slam_lora_a_fwd: null pointer");
+  SLAM_CHECK_ARG(M > 0 && R > 0 && R <= 64 && R % 4 == 0 && K > 0 && K % 64 == 0, "slam_lora_a_fwd: need R %% 4 == 0, R <= 64, K %% 64 == 0");
+  SLAM_CHECK_ARG(ldx % 8 == 0 && lda % 8 == 0 && ldu % 4 == 0 && ((uintptr_t)U % 8) == 0, "slam_lora_a_fwd: misaligned operands");
+  SLAM_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && offset % 8 == 0, "slam_lora_a_fwd: bad dropout arguments");
+  const unsigned th = drop_p > 0.f ? slam_drop_thresh16(drop_p) : 0u;
+  const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  dim3 grid((unsigned)cdiv64(M, 32));
+  hipStream_t s = (hipStream_t)stream;
+  const int nt = (int)cdiv64(R, 16);
+#define SLAM_LAUNCH_LA(NT_) hipLaunchKernelGGL(lora_a_fwd_kernel<NT_>, grid, dim3(256), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)A, lda, \
+                                              (bf16_t*)U, ldu, (int)M, (int)R, (int)K, th, inv_keep, (unsigned long long)seed, (unsigned long long)offset)
+  if (nt == 1) SLAM_LAUNCH_LA(1);
+  else if (nt == 2) SLAM_LAUNCH_LA(2);
+  else if (nt == 3) SLAM_LAUNCH_LA(3);
+  else SLAM_LAUNCH_LA(4);
+#undef SLAM_LAUNCH_LA
+  SLAM_CHECK_LAUNCH("slam_lora_a_fwd");
+  return 0;
+}
 
 extern "C" int64_t slam_skinny_gram_workspace_bytes(int64_t M, int64_t R, int64_t C) {
   const int64_t nsplit = (M + 255) / 256;
@@ -325,8 +444,12 @@ extern "C" int64_t slam_skinny_gram_workspace_bytes(int64_t M, int64_t R, int64_
 
 extern "C" int slam_skinny_gram(const void* S, int64_t lds_, const void* X, int64_t ldx, float* out,
                                 int64_t out_ld_r, int64_t out_ld_c, int64_t M, int64_t R, int64_t C, float alpha,
-                                int accumulate, float* workspace, void* stream) {
+                                int accumulate, float drop_p, uint64_t seed, uint64_t offset, float* workspace,
+                                void* stream) {
   SLAM_CHECK_ARG(S && X && out && workspace, "slam_skinny_gram: null pointer");
+  SLAM_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && offset % 8 == 0, "slam_skinny_gram: bad dropout arguments");
+  const unsigned th = drop_p > 0.f ? slam_drop_thresh16(drop_p) : 0u;
+  if (drop_p > 0.f) alpha *= 1.0f / (1.0f - drop_p);
   SLAM_CHECK_ARG(R == 8 || R == 16 || R == 32 || R == 64, "slam_skinny_gram: R=%ld must be 8, 16, 32 or 64", (long)R);
   SLAM_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0, "slam_skinny_gram: C and ldx must be multiples of 8");
   SLAM_CHECK_ARG(lds_ % (R / 4) == 0 && ((uintptr_t)S % (R / 2)) == 0, "slam_skinny_gram: S must be aligned to R/4 elements (vector loads)");
@@ -336,10 +459,10 @@ extern "C" int slam_skinny_gram(const void* S, int64_t lds_, const void* X, int6
   dim3 grid((unsigned)cdiv64(C, 512), (unsigned)nsplit);
   hipStream_t s = (hipStream_t)stream;
   switch (R) {
-    case 8: hipLaunchKernelGGL(skinny_gram_kernel<2>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split); break;
-    case 16: hipLaunchKernelGGL(skinny_gram_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split); break;
-    case 32: hipLaunchKernelGGL(skinny_gram_kernel<8>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split); break;
-    default: hipLaunchKernelGGL(skinny_gram_kernel<16>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split); break;
+    case 8: hipLaunchKernelGGL(skinny_gram_kernel<2>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split, th, (unsigned long long)seed, (unsigned long long)offset); break;
+    case 16: hipLaunchKernelGGL(skinny_gram_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split, th, (unsigned long long)seed, (unsigned long long)offset); break;
+    case 32: hipLaunchKernelGGL(skinny_gram_kernel<8>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split, th, (unsigned long long)seed, (unsigned long long)offset); break;
+    default: hipLaunchKernelGGL(skinny_gram_kernel<16>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split, th, (unsigned long long)seed, (unsigned long long)offset); break;
   }
   int64_t g = cdiv64(R * C, 256);
   if (g > 4096) g = 4096;

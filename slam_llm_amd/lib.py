@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libslamhip.so")
 BF16, F32 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
-P, I64, I32, F = c_void_p, c_int64, c_int, c_float
+P, I64, I32, F, U64 = c_void_p, c_int64, c_int, c_float, ctypes.c_uint64
 
 # name -> argtypes; every symbol of include/slam_hip.h (tests/test_capi_symbols.py checks the two agree)
 SIGNATURES = {
@@ -42,13 +42,14 @@ SIGNATURES = {
     "slam_transpose_bf16": [P, I64, P, I64, I64, I64, I64, P],
     "slam_attn_fwd": [P, I64, P, I64, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P],
     "slam_attn_bwd": [P, I64, P, I64, P, I64, P, P, P, I64, P, I64, P, P, P, P, P, I64, P, I64, P, I64,
-                      I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P],
+                      I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P],
     "slam_swiglu_fwd": [P, I64, P, I64, I64, I64, P],
     "slam_swiglu_bwd": [P, I64, P, I64, P, I64, I64, I64, P],
     "slam_relu_bwd": [P, I64, P, I64, I64, I64, P],
     "slam_colsum_bf16": [P, I64, P, I64, I64, I32, P],
     "slam_skinny_gram_workspace_bytes": [I64, I64, I64],
-    "slam_skinny_gram": [P, I64, P, I64, P, I64, I64, I64, I64, I64, F, I32, P, P],
+    "slam_skinny_gram": [P, I64, P, I64, P, I64, I64, I64, I64, I64, F, I32, F, U64, U64, P, P],
+    "slam_lora_a_fwd": [P, I64, P, I64, P, I64, I64, I64, I64, F, U64, U64, P],
     "slam_lora_pack_b": [P, F, P, I64, P, I64, I64, I64, P],
     "slam_gemm_skinny_workspace_bytes": [I64, I64, I64, I64, I32],
     "slam_gemm_skinny_bf16_nt": [P, I64, P, I64, P, I64, I64, P, I64, I64, I64, I64, P, I64, I32, I32, P, I64, I64, P],

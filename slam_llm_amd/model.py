@@ -189,10 +189,13 @@ class FusedLinear:
         deviation); None = no dropout (eval mode / p = 0)."""
         if self.adapters:
             sr = self.sum_r
-            xin = x_ext[:, : self.K]
-            if drop is not None:
-                xin = ops.dropout(xin, *drop)
-            ops.gemm_nt(xin, self.a_cat(store), out=x_ext[:, self.K: self.K + sr])
+            if sr <= 64 and sr % 4 == 0:   # one pass over x, dropout mask applied in registers
+                ops.lora_a_fwd(x_ext[:, : self.K], self.a_cat(store), x_ext[:, self.K: self.K + sr], drop)
+            else:
+                xin = x_ext[:, : self.K]
+                if drop is not None:
+                    xin = ops.dropout(xin, *drop)
+                ops.gemm_nt(xin, self.a_cat(store), out=x_ext[:, self.K: self.K + sr])
         return ops.gemm_nt(x_ext, self.Wext, out=out, residual=residual, bias=bias, act=act,
                            k_alg=self.K + self.sum_r)
 
@@ -214,17 +217,17 @@ class FusedLinear:
             else:
                 hop = ops.gemm_nt(dx_ext[:, self.K:], self.AcatT)           # dL/d(dropout(x))
                 ops.dropout(hop, *drop, out=dx_ext[:, : self.K], accumulate=True)  # same mask, recomputed
-                xin = ops.dropout(xin, *drop)                                 # recomputed for dA
             K, sr = self.K, self.sum_r
             # dA[r, K] = du^T x ;  dB[rows, r] = (alpha/r) * dy[:, rows]^T u   (HBM-bound tall-skinny products).
             # All adapters of the group share x and their A's (and A gradients) are contiguous: one pass over x.
+            # (dropout(x) is never materialised: the gram kernel recomputes the mask)
             if sr in (8, 16, 32, 64):
-                ops.skinny_gram(dx_ext[:, K: K + sr], xin, self.a_cat_grad(store), K, 1, accumulate=accumulate)
+                ops.skinny_gram(dx_ext[:, K: K + sr], xin, self.a_cat_grad(store), K, 1, accumulate=accumulate, drop=drop)
             for a in self.adapters:
                 r = a["r"]
                 if sr not in (8, 16, 32, 64):
                     ops.skinny_gram(dx_ext[:, K + a["j0"]: K + a["j0"] + r], xin, store.grad_view(a["A"]), K, 1,
-                                    accumulate=accumulate)
+                                    accumulate=accumulate, drop=drop)
                 u = x_ext[:, K + a["j0"]: K + a["j0"] + r]            # xA^T        [M, r]
                 ops.skinny_gram(u, dy[:, a["row0"]: a["row0"] + a["rows"]], store.grad_view(a["B"]), 1, r,
                                 alpha=a["scale"], accumulate=accumulate)
@@ -918,9 +921,7 @@ class HipLlamaLora(nn.Module):
             dqkv = torch.empty_like(qkv)
             ops.attn_bwd(q2, k2, v2, S["qt"], S["kt"], S["o"][:, : Hq * D], dO, dOt, S["lse"],
                          dqkv[:, : Hq * D], dqkv[:, Hq * D: (Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:],
-                         B, T, Hq, Hkv, D, True, scale, key_mask=key_mask)
-            ops.head_rope_transpose(dqkv, 0, B, T, Hq, D, cos=cos, sin=sin, inverse=True, want_t=False)
-            ops.head_rope_transpose(dqkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, inverse=True, want_t=False)
+                         B, T, Hq, Hkv, D, True, scale, key_mask=key_mask, rope=(cos, sin))  # RoPE backward fused
             del do_ext, dO, dOt
             dx1 = L.qkv.backward(dqkv, S["x1"], st, accumulate, drop=dq_)
             del dqkv

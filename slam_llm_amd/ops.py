@@ -325,7 +325,8 @@ def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_
 
 
 def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T, Hq, Hkv, D, causal, scale,
-             key_mask=None, Tk=None):
+             key_mask=None, Tk=None, rope=None):
+    """rope = (cos, sin) tables: dq/dk come out as gradients w.r.t. the pre-RoPE projections (fused epilogue)."""
     Tk = Tk or T
     Tqp, Tkp = qt.shape[-1], kt.shape[-1]
     delta = torch.empty((B, Hq, Tqp), dtype=torch.float32, device=q2d.device)
@@ -333,7 +334,7 @@ def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T,
            lambda: call("slam_attn_bwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(v2d), _ld(v2d), _p(qt), _p(kt),
                         _p(o2d), _ld(o2d), _p(do2d), _ld(do2d), _p(dot), _p(lse), _p(delta), _p(key_mask), _p(dq2d),
                         _ld(dq2d), _p(dk2d), _ld(dk2d), _p(dv2d), _ld(dv2d), B, T, Tk, Tqp, Tkp, Hq, Hkv, D,
-                        1 if causal else 0, scale, _s()))
+                        1 if causal else 0, scale, _p(rope[0]) if rope else None, _p(rope[1]) if rope else None, _s()))
     return delta
 
 
@@ -441,8 +442,20 @@ def colsum(x2d, out_f32, accumulate=False):
 _GRAM_WS = {}
 
 
-def skinny_gram(S2d, X2d, out, out_ld_r, out_ld_c, alpha=1.0, accumulate=False):
-    """out[r*ld_r + c*ld_c] (+)= alpha * sum_m S[m,r] X[m,c]   (LoRA dA / dB); out is an fp32 tensor (any view)"""
+def lora_a_fwd(x2d, a_cat, out, drop=None):
+    """out[M, R] = dropout(x)[M, K] @ a_cat[R, K]^T; drop = (p, seed, offset) or None (x is read once, mask in registers)"""
+    M, K = x2d.shape
+    R = a_cat.shape[0]
+    p_, seed, off = drop if drop is not None else (0.0, 0, 0)
+    _timed("lora_a_fwd", 2.0 * M * K,
+           lambda: call("slam_lora_a_fwd", _p(x2d), _ld(x2d), _p(a_cat), _ld(a_cat), _p(out), _ld(out), M, R, K, float(p_),
+                        int(seed) & (2 ** 64 - 1), int(off) & (2 ** 64 - 1), _s()))
+    return out
+
+
+def skinny_gram(S2d, X2d, out, out_ld_r, out_ld_c, alpha=1.0, accumulate=False, drop=None):
+    """out[r*ld_r + c*ld_c] (+)= alpha * sum_m S[m,r] X'[m,c]   (LoRA dA / dB); out is an fp32 tensor (any view);
+    drop = (p, seed, offset): X' = dropout(X) recomputed from the counter-based mask, else X' = X"""
     M, R = S2d.shape
     M2, C = X2d.shape
     assert M == M2
@@ -450,8 +463,9 @@ def skinny_gram(S2d, X2d, out, out_ld_r, out_ld_c, alpha=1.0, accumulate=False):
     key = str(S2d.device)
     if key not in _GRAM_WS or _GRAM_WS[key].numel() * 4 < nbytes:   # one workspace per device, grown to the largest need
         _GRAM_WS[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=S2d.device)
+    p_, seed, off = drop if drop is not None else (0.0, 0, 0)
     call("slam_skinny_gram", _p(S2d), _ld(S2d), _p(X2d), _ld(X2d), _p(out), out_ld_r, out_ld_c, M, R, C, alpha,
-         1 if accumulate else 0, _p(_GRAM_WS[key]), _s())
+         1 if accumulate else 0, float(p_), int(seed) & (2 ** 64 - 1), int(off) & (2 ** 64 - 1), _p(_GRAM_WS[key]), _s())
     return out
 
 

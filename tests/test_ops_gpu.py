@@ -252,6 +252,16 @@ def test_attention_bwd(dev, B, T, Hq, Hkv, D, masked):
         cs = F.cosine_similarity(got.flatten(), r.flatten(), dim=0)
         assert cs > 0.999, f"{nme} cosine {float(cs)}"
         assert_close(got, r, atol=3e-2 * float(r.abs().max()), rtol=3e-2, what=nme)
+    # fused RoPE backward in the dQ/dK epilogues == the separate inverse-rotation pass (one rounding less)
+    from slam_llm_amd.host_tables import rope_tables
+    cos, sin = (t.to(dev) for t in rope_tables(T, D, 10000.0))
+    fused = torch.zeros_like(qkv)
+    ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, fused[:, : Hq * D], fused[:, Hq * D:(Hq + Hkv) * D],
+                 fused[:, (Hq + Hkv) * D:], B, T, Hq, Hkv, D, True, scale, key_mask=km, rope=(cos, sin))
+    ops.head_rope_transpose(dqkv, 0, B, T, Hq, D, cos=cos, sin=sin, inverse=True, want_t=False)
+    ops.head_rope_transpose(dqkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, inverse=True, want_t=False)
+    assert_close(fused, dqkv.float(), atol=2e-2 * float(dqkv.float().abs().max()), rtol=2e-2, what="fused rope grad")
+    assert torch.equal(fused[:, (Hq + Hkv) * D:], dqkv[:, (Hq + Hkv) * D:])  # dV untouched by RoPE
 
 
 def test_cross_attention_fwd_bwd(dev):
@@ -453,6 +463,25 @@ def test_dropout_mask_properties(dev):
     ops.dropout(x, p, seed=123, offset=1 << 40, out=acc, accumulate=True)
     assert_close(acc, x.float() + x.float() * mask, atol=2e-2, rtol=1e-2, what="dropout accumulate")
     assert torch.equal(ops.dropout(x, 0.0, seed=5, offset=0), x)
+
+
+@pytest.mark.parametrize("M,K,R,p", [(200, 128, 16, 0.3), (1000, 4096, 32, 0.05), (77, 256, 24, 0.0), (33, 64, 64, 0.5)])
+def test_lora_first_hop_and_gram_recompute_the_dropout_mask(dev, M, K, R, p):
+    """u = dropout(x) A^T and dA = du^T dropout(x) with the mask recomputed in registers == the same products on the
+    materialised ops.dropout(x) (same seed / offset / element index)"""
+    ops = _ops()
+    x, A = rnd((M, K), dev, seed=31), rnd((R, K), dev, seed=32, std=K ** -0.5)
+    drop = (p, 987654321, 3 << 40) if p > 0 else None
+    xd = ops.dropout(x, *drop) if drop else x
+    u = torch.empty((M, R + 8), dtype=torch.bfloat16, device=dev)
+    ops.lora_a_fwd(x, A, u[:, :R], drop)
+    assert_close(u[:, :R], xd.float() @ A.float().T, atol=2e-2, rtol=2e-2, what="lora first hop")
+    if R in (8, 16, 32, 64):
+        du = rnd((M, R), dev, seed=33)
+        g1 = torch.zeros((R, K), dtype=torch.float32, device=dev)
+        ops.skinny_gram(du, x, g1, K, 1, drop=drop)
+        ref = du.float().T @ xd.float()
+        assert_close(g1, ref, atol=2e-2 * float(ref.abs().max()), rtol=2e-2, what="dA with recomputed mask")
 
 
 def test_lora_fused_linear_with_dropout_matches_autograd(dev):
