@@ -235,76 +235,125 @@ extern "C" int slam_adamw_step(float* param, const float* grad, float* exp_avg, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Tall-skinny gram product for the LoRA gradients (peft Linear backward: dA = (dy.sB)^T x, dB = s dy^T (xA^T)):
-//   out[r, c] (+)= alpha * sum_m S[m, r] * X[m, c]       S: [M, R] bf16 with R in {8,16,32,64},  X: [M, C] bf16
-// The reduction runs over the token dimension M (~12 k) while R is tiny, so this is an HBM-bound stream over X,
-// not an MFMA problem: lane = 8 consecutive columns of X (16-byte loads), wave w = R/4 rows of the output, fp32
-// FMA accumulation; M is split over gridDim.y and the partials are reduced in a fixed order by a second kernel
-// (bit-reproducible gradients).  Replaces three bf16 transposes + three starved-grid GEMMs per adapted projection.
+// Tall-skinny gram product for the LoRA gradients (peft Linear backward: dA = (dy.sB)^T dropout(x), dB = s dy^T (xA^T)):
+//   out[r, c] (+)= alpha * sum_m S[m, r] * X'[m, c]      S: [M, R] bf16, R % 8 == 0, R <= 64;  X: [M, C] bf16
+// The reduction runs over the token dimension M (~12 k): both MFMA operands would need M-contiguous (transposed)
+// layouts.  Instead of writing transposed copies to HBM (the first version of this path) or doing the product on the
+// VALU (1.5 G fp32 FMA for one dA: 160 us), 32-row tiles of X and S are staged ROW-MAJOR in LDS (coalesced 16-byte
+// global loads, lora_dropout mask recomputed once per element on the way) and the MFMA fragments are gathered with
+// 2-byte LDS reads; row strides are padded so that the 4 row groups of a fragment read land in disjoint banks.
+// X is read from HBM exactly once.  M is split over gridDim.y; partials are reduced in a fixed order (bit-reproducible).
 // ------------------------------------------------------------------------------------------------------------
 namespace {
 
-template <int RW>
-__global__ __launch_bounds__(256) void skinny_gram_kernel(const bf16_t* __restrict__ S, int64_t lds_,
-                                                          const bf16_t* __restrict__ X, int64_t ldx,
-                                                          float* __restrict__ ws, int M, int R, int C,
-                                                          int rows_per_split, unsigned thresh16,
-                                                          unsigned long long seed, unsigned long long offset) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c0 = blockIdx.x * 512 + lane * 8;
-  const int r0 = wave * RW;
-  const int m0 = blockIdx.y * rows_per_split;
-  const int m1 = min(M, m0 + rows_per_split);
-  float acc[RW][8];
+constexpr int GM_CB = 256;            // columns of X per workgroup (4 waves x 4 MFMA column tiles)
+constexpr int GM_XLD = GM_CB + 16;    // 544-byte rows: consecutive rows shift by 8 banks -> conflict-free gathers
+
+template <int NT>
+__global__ __launch_bounds__(256) void gram_mfma_kernel(const bf16_t* __restrict__ S, int64_t lds_,
+                                                        const bf16_t* __restrict__ X, int64_t ldx,
+                                                        float* __restrict__ ws, int M, int R, int C, int rows_per_split,
+                                                        unsigned thresh16, unsigned long long seed,
+                                                        unsigned long long offset) {
+  constexpr int SLD = NT == 1 ? 16 : (NT == 2 ? 48 : 80);   // dword strides 8 / 24 / 40: 4 consecutive rows -> disjoint banks
+  constexpr int SCH = NT * 2;                               // 16-byte chunks per S row
+  __shared__ __attribute__((aligned(16))) bf16_t xs[32 * GM_XLD];
+  __shared__ __attribute__((aligned(16))) bf16_t ss[32 * SLD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int c_blk = blockIdx.x * GM_CB;
+  const int m0 = blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
+  f32x4_t acc[NT][4];
 #pragma unroll
-  for (int i = 0; i < RW; i++)
+  for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-    for (int e = 0; e < 8; e++) acc[i][e] = 0.f;
-  if (c0 < C) {
-    typedef __attribute__((ext_vector_type(RW))) unsigned short svec_t;  // RW bf16 of S in one load
-    constexpr int U = 4;                                                 // rows in flight per iteration
-    int m = m0;
-    for (; m + U <= m1; m += U) {
-      u16x8_t xv[U];
-      svec_t sv[U];
+    for (int t = 0; t < 4; t++) acc[nt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  u16x8_t xreg[4], sreg;
+  auto gload = [&](int mb) {
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        xv[u] = *reinterpret_cast<const u16x8_t*>(X + (int64_t)(m + u) * ldx + c0);
-        sv[u] = *reinterpret_cast<const svec_t*>(S + (int64_t)(m + u) * lds_ + r0);
-      }
+    for (int i = 0; i < 4; i++) {
+      const int id = tid + i * 256, row = id >> 5, cc = id & 31;
+      const int m = mb + row, c = c_blk + cc * 8;
+      u16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (m < m1 && c < C) {
+        v = *reinterpret_cast<const u16x8_t*>(X + (int64_t)m * ldx + c);
+        if (thresh16) {
+          const unsigned keep = slam_keep8(seed, offset + (unsigned long long)m * (unsigned long long)C + c, thresh16);
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        float xf[8];
-        // X = dropout(x) recomputed from the counter-based mask (the 1/(1-p) scale is folded into alpha by the host)
-        const unsigned keep = thresh16 ? slam_keep8(seed, offset + (unsigned long long)(m + u) * (unsigned long long)C + c0, thresh16) : 0xFFu;
-#pragma unroll
-        for (int e = 0; e < 8; e++) xf[e] = ((keep >> e) & 1u) ? bf2f(xv[u][e]) : 0.f;
-#pragma unroll
-        for (int i = 0; i < RW; i++) {
-          const float sf = bf2f(sv[u][i]);
-#pragma unroll
-          for (int e = 0; e < 8; e++) acc[i][e] = fmaf(sf, xf[e], acc[i][e]);
+          for (int e = 0; e < 8; e++)
+            if (!((keep >> e) & 1u)) v[e] = 0;
         }
       }
+      xreg[i] = v;
     }
-    for (; m < m1; m++) {
-      const u16x8_t xv = *reinterpret_cast<const u16x8_t*>(X + (int64_t)m * ldx + c0);
-      const svec_t sv = *reinterpret_cast<const svec_t*>(S + (int64_t)m * lds_ + r0);
-      const unsigned keep = thresh16 ? slam_keep8(seed, offset + (unsigned long long)m * (unsigned long long)C + c0, thresh16) : 0xFFu;
+    if (tid < 32 * SCH) {
+      const int row = tid / SCH, jc = tid % SCH;
+      const int m = mb + row;
+      u16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (m < m1 && jc * 8 < R) v = *reinterpret_cast<const u16x8_t*>(S + (int64_t)m * lds_ + jc * 8);
+      sreg = v;
+    }
+  };
+  auto lstore = [&]() {
 #pragma unroll
-      for (int i = 0; i < RW; i++) {
-        const float sf = bf2f(sv[i]);
+    for (int i = 0; i < 4; i++) {
+      const int id = tid + i * 256, row = id >> 5, cc = id & 31;
+      *reinterpret_cast<u16x8_t*>(&xs[row * GM_XLD + cc * 8]) = xreg[i];
+    }
+    if (tid < 32 * SCH) {
+      const int row = tid / SCH, jc = tid % SCH;
+      *reinterpret_cast<u16x8_t*>(&ss[row * SLD + jc * 8]) = sreg;
+    }
+  };
+
+  if (m0 < m1) gload(m0);
+  for (int mb = m0; mb < m1; mb += 32) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (mb + 32 < m1) gload(mb + 32);
+    // MFMA k-slot (g, e) <-> tile row e*4 + g for BOTH operands (any bijection works; this one is bank-friendly)
+    u16x8_t af[NT], bfr[4];
 #pragma unroll
-        for (int e = 0; e < 8; e++) acc[i][e] = fmaf(sf, ((keep >> e) & 1u) ? bf2f(xv[e]) : 0.f, acc[i][e]);
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) af[nt][e] = ss[(e * 4 + g) * SLD + nt * 16 + li];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) bfr[t][e] = xs[(e * 4 + g) * GM_XLD + (wave * 4 + t) * 16 + li];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+        acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[nt]),
+                                                            __builtin_bit_cast(bf16x8_t, bfr[t]), acc[nt][t], 0, 0, 0);
+  }
+  // acc[nt][t][i] = partial out[j = nt*16 + 4g + i][c = c_blk + (wave*4 + t)*16 + li]
+  float* w = ws + (int64_t)blockIdx.y * R * C;
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int c = c_blk + (wave * 4 + t) * 16 + li;
+      if (c >= C) continue;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int j = nt * 16 + 4 * g + i;
+        if (j < R) w[(int64_t)j * C + c] = acc[nt][t][i];
       }
     }
-    float* w = ws + ((int64_t)blockIdx.y * R + r0) * C + c0;
-#pragma unroll
-    for (int i = 0; i < RW; i++) {
-      *reinterpret_cast<float4*>(w + (int64_t)i * C) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
-      *reinterpret_cast<float4*>(w + (int64_t)i * C + 4) = make_float4(acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
-    }
-  }
+}
+
+void gram_plan(int64_t M, int64_t C, int* rows_per_split, int* nsplit) {
+  const int64_t ncb = cdiv64(C, GM_CB);
+  int64_t ns = cdiv64(512, ncb);
+  if (ns > cdiv64(M, 32)) ns = cdiv64(M, 32);
+  if (ns < 1) ns = 1;
+  const int64_t rps = cdiv64(cdiv64(M, ns), 32) * 32;
+  *rows_per_split = (int)rps;
+  *nsplit = (int)cdiv64(M, rps);
 }
 
 __global__ __launch_bounds__(256) void skinny_gram_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
@@ -438,8 +487,9 @@ extern "C" int slam_lora_a_fwd(const void* X, int64_t ldx, const void* A, int64_
 }
 
 extern "C" int64_t slam_skinny_gram_workspace_bytes(int64_t M, int64_t R, int64_t C) {
-  const int64_t nsplit = (M + 255) / 256;
-  return nsplit * R * C * (int64_t)sizeof(float);
+  int rps, nsplit;
+  gram_plan(M, C, &rps, &nsplit);
+  return (int64_t)nsplit * R * C * (int64_t)sizeof(float);
 }
 
 extern "C" int slam_skinny_gram(const void* S, int64_t lds_, const void* X, int64_t ldx, float* out,
@@ -450,20 +500,20 @@ extern "C" int slam_skinny_gram(const void* S, int64_t lds_, const void* X, int6
   SLAM_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && offset % 8 == 0, "slam_skinny_gram: bad dropout arguments");
   const unsigned th = drop_p > 0.f ? slam_drop_thresh16(drop_p) : 0u;
   if (drop_p > 0.f) alpha *= 1.0f / (1.0f - drop_p);
-  SLAM_CHECK_ARG(R == 8 || R == 16 || R == 32 || R == 64, "slam_skinny_gram: R=%ld must be 8, 16, 32 or 64", (long)R);
+  SLAM_CHECK_ARG(R > 0 && R % 8 == 0 && R <= 64, "slam_skinny_gram: R=%ld must be a multiple of 8, <= 64", (long)R);
   SLAM_CHECK_ARG(M > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0, "slam_skinny_gram: C and ldx must be multiples of 8");
-  SLAM_CHECK_ARG(lds_ % (R / 4) == 0 && ((uintptr_t)S % (R / 2)) == 0, "slam_skinny_gram: S must be aligned to R/4 elements (vector loads)");
+  SLAM_CHECK_ARG(lds_ % 8 == 0 && ((uintptr_t)S % 16) == 0, "slam_skinny_gram: S rows must be 16-byte aligned");
   SLAM_CHECK_ARG(((uintptr_t)X % 16) == 0 && ((uintptr_t)workspace % 16) == 0, "slam_skinny_gram: X/workspace must be 16-byte aligned");
-  const int rows_per_split = 256;
-  const int nsplit = (int)((M + rows_per_split - 1) / rows_per_split);
-  dim3 grid((unsigned)cdiv64(C, 512), (unsigned)nsplit);
+  int rows_per_split, nsplit;
+  gram_plan(M, C, &rows_per_split, &nsplit);
+  dim3 grid((unsigned)cdiv64(C, GM_CB), (unsigned)nsplit);
   hipStream_t s = (hipStream_t)stream;
-  switch (R) {
-    case 8: hipLaunchKernelGGL(skinny_gram_kernel<2>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split, th, (unsigned long long)seed, (unsigned long long)offset); break;
-    case 16: hipLaunchKernelGGL(skinny_gram_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split, th, (unsigned long long)seed, (unsigned long long)offset); break;
-    case 32: hipLaunchKernelGGL(skinny_gram_kernel<8>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split, th, (unsigned long long)seed, (unsigned long long)offset); break;
-    default: hipLaunchKernelGGL(skinny_gram_kernel<16>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, workspace, (int)M, (int)R, (int)C, rows_per_split, th, (unsigned long long)seed, (unsigned long long)offset); break;
-  }
+#define SLAM_LAUNCH_GM(NT_) hipLaunchKernelGGL(gram_mfma_kernel<NT_>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, \
+                                              workspace, (int)M, (int)R, (int)C, rows_per_split, th, (unsigned long long)seed, (unsigned long long)offset)
+  if (R <= 16) SLAM_LAUNCH_GM(1);
+  else if (R <= 32) SLAM_LAUNCH_GM(2);
+  else SLAM_LAUNCH_GM(4);
+#undef SLAM_LAUNCH_GM
   int64_t g = cdiv64(R * C, 256);
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(skinny_gram_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, workspace, out, out_ld_r, out_ld_c,

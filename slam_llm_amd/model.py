@@ -221,11 +221,12 @@ class FusedLinear:
             # dA[r, K] = du^T x ;  dB[rows, r] = (alpha/r) * dy[:, rows]^T u   (HBM-bound tall-skinny products).
             # All adapters of the group share x and their A's (and A gradients) are contiguous: one pass over x.
             # (dropout(x) is never materialised: the gram kernel recomputes the mask)
-            if sr in (8, 16, 32, 64):
+            merged = sr % 8 == 0 and sr <= 64
+            if merged:
                 ops.skinny_gram(dx_ext[:, K: K + sr], xin, self.a_cat_grad(store), K, 1, accumulate=accumulate, drop=drop)
             for a in self.adapters:
                 r = a["r"]
-                if sr not in (8, 16, 32, 64):
+                if not merged:
                     ops.skinny_gram(dx_ext[:, K + a["j0"]: K + a["j0"] + r], xin, store.grad_view(a["A"]), K, 1,
                                     accumulate=accumulate, drop=drop)
                 u = x_ext[:, K + a["j0"]: K + a["j0"] + r]            # xA^T        [M, r]
