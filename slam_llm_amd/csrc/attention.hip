@@ -321,28 +321,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Delta[b,h,t] = sum_d dO[b,t,h,d] * O[b,t,h,d]      (one wave per (row, head))
-// ------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
-  const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.z;
-  if (idx >= (int64_t)p.Tq * p.Hq) return;
-  const int t = (int)(idx / p.Hq), h = (int)(idx % p.Hq);
-  const bf16_t* orow = p.O + ((int64_t)b * p.Tq + t) * p.ldo + h * D;
-  const bf16_t* drow = p.dO + ((int64_t)b * p.Tq + t) * p.lddo + h * D;
-  float acc = 0.f;
-  if (lane < D / 2) {
-    const u16x2_t a = *reinterpret_cast<const u16x2_t*>(orow + lane * 2);
-    const u16x2_t c = *reinterpret_cast<const u16x2_t*>(drow + lane * 2);
-    acc = bf2f(a[0]) * bf2f(c[0]) + bf2f(a[1]) * bf2f(c[1]);
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) p.Delta[((int64_t)b * p.Hq + h) * p.Tqp + t] = acc;
-}
-
-// ------------------------------------------------------------------------------------------
 // backward dQ: workgroup = 4 waves x 16 queries; 32-key K / V / K^T tiles are staged through LDS (shared by the
 // four waves, next tile prefetched into registers during the MFMA phase)
 //   S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - Delta) * scale, dQ^T += K^T(as [d x keys]) . dS^T
@@ -357,6 +335,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int NKV = 32 * KCH / 256;  // 16-byte chunks per thread of a [32][D] tile
   constexpr int NKT = D * 4 / 256;     // 16-byte chunks per thread of the [D][32] transposed tile
   __shared__ __attribute__((aligned(16))) char lds[2 * 32 * ROWB + D * 64];
+  __shared__ unsigned ldsMask[8];  // key-padding mask bytes of the current 32-key tile
   char* ldsK = lds;
   char* ldsV = lds + 32 * ROWB;
   char* ldsKt = lds + 64 * ROWB;
@@ -377,7 +356,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     dof[kd] = qok ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * Tq + q) * p.lddo + h * D + kd * 32 + g * 8) : zero_frag();
   }
   const float lse2 = qok ? p.LSE[((int64_t)b * p.Hq + h) * Tqp + q] * LOG2E : INFINITY;
-  const float delta = qok ? p.Delta[((int64_t)b * p.Hq + h) * Tqp + q] : 0.f;
+  // Delta[q] = sum_d dO[q,d] O[q,d]: this lane already holds a quarter of dO's row; the 4 lanes of a row (li + 16 g)
+  // combine theirs.  Written out for the dK/dV kernel that runs next on the stream (no separate delta pass over O, dO).
+  float delta = 0.f;
+  if (qok) {
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) {
+      const frag_t of = *reinterpret_cast<const frag_t*>(p.O + ((int64_t)b * Tq + q) * p.ldo + h * D + kd * 32 + g * 8);
+      const u16x8_t ov = __builtin_bit_cast(u16x8_t, of), dv = __builtin_bit_cast(u16x8_t, dof[kd]);
+#pragma unroll
+      for (int e = 0; e < 8; e++) delta = fmaf(bf2f(ov[e]), bf2f(dv[e]), delta);
+    }
+  }
+  delta += __shfl_xor(delta, 16, 64);
+  delta += __shfl_xor(delta, 32, 64);
+  if (qok && g == 0) p.Delta[((int64_t)b * p.Hq + h) * Tqp + q] = delta;
   const float sl2 = p.scale * LOG2E;
 
   f32x4_t dq[DF];
@@ -389,7 +382,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const bf16_t* ktb = p.Kt + ((int64_t)(b * p.Hkv + hk) * D) * Tkp;
 
   frag_t kreg[NKV], vreg[NKV], ktreg[NKT];
+  unsigned mreg = 0x01010101u;
   auto gload = [&](int k0) {
+    if (p.kmask && tid < 8) mreg = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tkp + k0 + tid * 4);
 #pragma unroll
     for (int i = 0; i < NKV; i++) {
       const int item = tid + i * 256;
@@ -421,6 +416,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
       const int d = item >> 2, c = item & 3;
       *reinterpret_cast<frag_t*>(ldsKt + d * 64 + ((c ^ ((d >> 2) & 3)) << 4)) = ktreg[i];
     }
+    if (tid < 8) ldsMask[tid] = mreg;
   };
 
   if (ntiles > 0) gload(0);
@@ -451,8 +447,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
     for (int kf = 0; kf < 2; kf++) {
       const int kb = k0 + kf * 16 + 4 * g;
-      unsigned mk = 0x01010101u;
-      if (p.kmask) mk = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tkp + kb);
+      const unsigned mk = ldsMask[kf * 4 + g];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int key = kb + r;
@@ -499,6 +494,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   constexpr int NQ = 32 * KCH / 256;
   constexpr int NQT = D * 4 / 256;
   __shared__ __attribute__((aligned(16))) char lds[2 * 32 * ROWB + 2 * D * 64];
+  __shared__ __attribute__((aligned(16))) float ldsLD[64];  // [0,32): LSE of the tile's queries, [32,64): Delta
   char* ldsQ = lds;
   char* ldsDO = lds + 32 * ROWB;
   char* ldsQt = lds + 64 * ROWB;
@@ -532,9 +528,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   const int ntiles = G * nq;
 
   frag_t qreg[NQ], doreg[NQ], qtreg[NQT], dotreg[NQT];
+  float ldreg = 0.f;
   auto gload = [&](int it) {
     const int hh = it / nq, q0 = qstart + (it - hh * nq) * 32;
     const int h = hk * G + hh;
+    // per-query softmax statistics ride along with the tile (a global load inside the MFMA loop sat on the critical
+    // path of every iteration: 2 waves per SIMD cannot hide it)
+    if (tid < 64) {
+      const float* src = (tid < 32 ? p.LSE : p.Delta) + ((int64_t)b * p.Hq + h) * Tqp;
+      const int qq = q0 + (tid & 31);
+      ldreg = qq < Tqp ? src[qq] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
       const int item = tid + i * 256;
@@ -570,6 +574,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
       *reinterpret_cast<frag_t*>(ldsQt + off) = qtreg[i];
       *reinterpret_cast<frag_t*>(ldsDOt + off) = dotreg[i];
     }
+    if (tid < 64) ldsLD[tid] = ldreg;
   };
 
   if (ntiles > 0) gload(0);
@@ -582,8 +587,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
     if (it + 1 < ntiles) gload(it + 1);
     if (kw0 >= Tk || (CAUSAL && q0 + 31 < kw0)) continue;
 
-    const float* lsep = p.LSE + ((int64_t)b * p.Hq + h) * Tqp;
-    const float* delp = p.Delta + ((int64_t)b * p.Hq + h) * Tqp;
     f32x4_t s[2], dp[2];
 #pragma unroll
     for (int f = 0; f < 2; f++) {
@@ -604,8 +607,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
 #pragma unroll
     for (int f = 0; f < 2; f++) {
       const int qb = q0 + f * 16 + 4 * g;
-      const float4 l4 = *reinterpret_cast<const float4*>(lsep + qb);
-      const float4 d4 = *reinterpret_cast<const float4*>(delp + qb);
+      const float4 l4 = *reinterpret_cast<const float4*>(&ldsLD[f * 16 + 4 * g]);
+      const float4 d4 = *reinterpret_cast<const float4*>(&ldsLD[32 + f * 16 + 4 * g]);
       const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
       const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
@@ -709,11 +712,9 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
   p.rope_cos = rope_cos; p.rope_sin = rope_sin;
   hipStream_t s = (hipStream_t)stream;
-  dim3 gdel((unsigned)cdiv64(Tq * Hq, 4), 1, (unsigned)B);
   dim3 gq((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B);
   dim3 gk((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);
   if (D == 64) {
-    hipLaunchKernelGGL((attn_delta_kernel<64>), gdel, dim3(256), 0, s, p);
     if (causal) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, dim3(256), 0, s, p);
       hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true>), gk, dim3(256), 0, s, p);
@@ -722,7 +723,6 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
       hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false>), gk, dim3(256), 0, s, p);
     }
   } else {
-    hipLaunchKernelGGL((attn_delta_kernel<128>), gdel, dim3(256), 0, s, p);
     if (causal) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, dim3(256), 0, s, p);
       hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, true>), gk, dim3(256), 0, s, p);

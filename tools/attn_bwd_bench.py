@@ -1,0 +1,48 @@
+"""GPU: time attention fwd / bwd at the LLM shape of the C3 workload (B=31, T=380, 32 q / 8 kv heads, D=128, causal)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from slam_llm_amd import ops  # noqa: E402
+from slam_llm_amd.host_tables import rope_tables  # noqa: E402
+
+dev = torch.device("cuda:0")
+B, T, Hq, Hkv, D = 31, 380, 32, 8, 128
+qkv = torch.randn(B * T, (Hq + 2 * Hkv) * D, device=dev).to(torch.bfloat16)
+q2, k2, v2 = qkv[:, : Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
+qt = ops.head_rope_transpose(qkv, 0, B, T, Hq, D)
+kt = ops.head_rope_transpose(qkv, Hq * D, B, T, Hkv, D)
+vt = ops.head_rope_transpose(qkv, (Hq + Hkv) * D, B, T, Hkv, D)
+Tp = vt.shape[-1]
+km = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
+km[:, :T] = 1
+cos, sin = (t.to(dev) for t in rope_tables(T, D, 500000.0))
+scale = D ** -0.5
+o, lse = ops.attn_fwd(q2, k2, vt, B, T, Hq, Hkv, D, True, scale, key_mask=km)
+do = torch.randn(B * T, Hq * D, device=dev).to(torch.bfloat16)
+dot = ops.head_rope_transpose(do, 0, B, T, Hq, D)
+dqkv = torch.empty_like(qkv)
+
+
+def bwd():
+    ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, dqkv[:, : Hq * D], dqkv[:, Hq * D:(Hq + Hkv) * D],
+                 dqkv[:, (Hq + Hkv) * D:], B, T, Hq, Hkv, D, True, scale, key_mask=km, rope=(cos, sin))
+
+
+def fwd():
+    ops.attn_fwd(q2, k2, vt, B, T, Hq, Hkv, D, True, scale, key_mask=km, out=o)
+
+
+for name, f, flops in (("fwd", fwd, 4.0 * B * Hq * T * T * D * 0.5), ("bwd", bwd, 10.0 * B * Hq * T * T * D * 0.5)):
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        f()
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / 20
+    print(f"{name}: {us:.1f} us  {flops / us / 1e6:.1f} TF", flush=True)
