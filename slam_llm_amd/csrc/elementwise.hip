@@ -23,7 +23,11 @@ __global__ __launch_bounds__(256) void head_rope_transpose_kernel(
     bf16_t* __restrict__ src, int64_t ld, int col0, const float* __restrict__ cosT,
     const float* __restrict__ sinT, float sin_sign, bf16_t* __restrict__ dstT, int T, int Tp, int H,
     const int* __restrict__ positions) {
-  constexpr int LDT = D + 8;  // LDS row stride (elements)
+  // LDS tile [64 t][D] without padding; the 16-byte chunk index is XOR-swizzled with 2*(t>>3) so that the transposing
+  // 2-byte reads below (8 lanes = 8 different t-groups, same d) land in 8 disjoint bank groups instead of 2
+  // (a padded row stride cannot do that: 8 rows of any 16-byte-aligned stride are 0 or 32 banks apart)
+  constexpr int LDT = D;
+  constexpr int CMASK = D / 8 - 1;
   __shared__ __attribute__((aligned(16))) bf16_t tile[64 * LDT];
   const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x;
@@ -60,8 +64,9 @@ __global__ __launch_bounds__(256) void head_rope_transpose_kernel(
       for (int e = 0; e < 8; e++) { y1[e] = 0; y2[e] = 0; }
     }
     if (dstT) {
-      *reinterpret_cast<u16x8_t*>(&tile[tt * LDT + c * 8]) = y1;
-      *reinterpret_cast<u16x8_t*>(&tile[tt * LDT + D / 2 + c * 8]) = y2;
+      const int sw = ((tt >> 3) * 2) & CMASK;
+      *reinterpret_cast<u16x8_t*>(&tile[tt * LDT + ((c ^ sw) << 3)]) = y1;
+      *reinterpret_cast<u16x8_t*>(&tile[tt * LDT + (((HC + c) ^ sw) << 3)]) = y2;
     }
   }
   if (!dstT) return;
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(256) void head_rope_transpose_kernel(
     const int d = item >> 3, tc = item & 7;
     u16x8_t o;
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = tile[(tc * 8 + e) * LDT + d];
+    for (int e = 0; e < 8; e++) o[e] = tile[(tc * 8 + e) * LDT + (d ^ (((tc * 2) & CMASK) << 3))];
     *reinterpret_cast<u16x8_t*>(out + (int64_t)d * Tp + tc * 8) = o;
   }
 }
