@@ -283,26 +283,68 @@ __device__ __forceinline__ float lane_xor(float v, int lane) {
   }
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
 template <int REP>
 struct AttnState {
-  float m[REP], l[REP], acc[REP][8];
+  float m[REP], l[REP];
+  f32x2_t acc[REP][4];   // 8 head-dim elements per lane as 4 packed pairs (v_pk_fma_f32 / v_pk_mul_f32)
 };
 
-template <int REP, int LPK>
-__device__ __forceinline__ void attn_key(AttnState<REP>& st, const float (&q)[REP][8], const float* kf, const float* vf) {
+// NU keys at once for the REP query heads sharing this K/V stream.  QK^T on packed bf16 pairs (v_dot2c_f32_bf16, no
+// bf16->f32 conversion of q or k), one running-max update and one accumulator rescale per NU keys instead of per key,
+// PV on packed fp32 pairs.  valid[u] = false -> the key contributes nothing (at least one key must be valid).
+template <int REP, int LPK, int NU>
+__device__ __forceinline__ void attn_keys(AttnState<REP>& st, const u16x8_t (&qraw)[REP], const u16x8_t* kk,
+                                          const u16x8_t* vv, const bool* valid, float scale_log2) {
+  float sc[NU][REP];
+#pragma unroll
+  for (int u = 0; u < NU; u++) {
+    const u32x4_t kp = __builtin_bit_cast(u32x4_t, kk[u]);
+#pragma unroll
+    for (int h = 0; h < REP; h++) {
+      const u32x4_t qp = __builtin_bit_cast(u32x4_t, qraw[h]);
+      // s = sum over the lane's 4 packed bf16 pairs of q.lo*k.lo + q.hi*k.hi.  Inline asm on purpose: with hipcc 7.2 the
+      // builtin (__builtin_amdgcn_fdot2_f32_bf16 on bit-cast vector lanes) folds all four pairs onto the first pair's
+      // registers (4 identical v_dot2c in the ISA, wrong scores; tests/test_ops_gpu.py::test_decode_attention_fused
+      // guards it).  The trailing s_nop covers the VALU-write -> DPP-read hazard of group_sum, which the hazard
+      // recogniser cannot see through an asm block.
+      float s = 0.f;
+      asm("v_dot2c_f32_bf16 %0, %1, %5\n\tv_dot2c_f32_bf16 %0, %2, %6\n\tv_dot2c_f32_bf16 %0, %3, %7\n\t"
+          "v_dot2c_f32_bf16 %0, %4, %8\n\ts_nop 1"
+          : "+v"(s)
+          : "v"(qp[0]), "v"(qp[1]), "v"(qp[2]), "v"(qp[3]), "v"(kp[0]), "v"(kp[1]), "v"(kp[2]), "v"(kp[3]));
+      s = group_sum<LPK>(s) * scale_log2;
+      sc[u][h] = valid[u] ? s : -INFINITY;
+    }
+  }
 #pragma unroll
   for (int h = 0; h < REP; h++) {
-    float s = 0.f;
+    float mx = st.m[h];
 #pragma unroll
-    for (int e = 0; e < 8; e++) s = fmaf(q[h][e], kf[e], s);
-    s = group_sum<LPK>(s);
-    const float mn = fmaxf(st.m[h], s);
-    const float corr = __builtin_amdgcn_exp2f(st.m[h] - mn);  // m = -inf on the first key -> 0
-    const float pr = __builtin_amdgcn_exp2f(s - mn);
-    st.l[h] = st.l[h] * corr + pr;
+    for (int u = 0; u < NU; u++) mx = fmaxf(mx, sc[u][h]);
+    const float corr = __builtin_amdgcn_exp2f(st.m[h] - mx);  // m = -inf before the first key -> 0
+    float pr[NU], psum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; e++) st.acc[h][e] = fmaf(pr, vf[e], st.acc[h][e] * corr);
-    st.m[h] = mn;
+    for (int u = 0; u < NU; u++) {
+      pr[u] = __builtin_amdgcn_exp2f(sc[u][h] - mx);
+      psum += pr[u];
+    }
+    st.l[h] = st.l[h] * corr + psum;
+    const f32x2_t c2 = {corr, corr};
+#pragma unroll
+    for (int j = 0; j < 4; j++) st.acc[h][j] = st.acc[h][j] * c2;
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const u32x4_t vp = __builtin_bit_cast(u32x4_t, vv[u]);
+      const f32x2_t p2 = {pr[u], pr[u]};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const f32x2_t v2 = {__uint_as_float(vp[j] << 16), __uint_as_float(vp[j] & 0xFFFF0000u)};
+        st.acc[h][j] = __builtin_elementwise_fma(p2, v2, st.acc[h][j]);
+      }
+    }
+    st.m[h] = mx;
   }
 }
 
@@ -316,7 +358,10 @@ __device__ __forceinline__ void attn_merge(AttnState<REP>& st, int lane) {
     const float b = (mo == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mo - mn);
     st.l[h] = st.l[h] * a + lo * b;
 #pragma unroll
-    for (int e = 0; e < 8; e++) st.acc[h][e] = st.acc[h][e] * a + lane_xor<OFF>(st.acc[h][e], lane) * b;
+    for (int j = 0; j < 4; j++) {
+      const f32x2_t o = {lane_xor<OFF>(st.acc[h][j][0], lane), lane_xor<OFF>(st.acc[h][j][1], lane)};
+      st.acc[h][j] = st.acc[h][j] * f32x2_t{a, a} + o * f32x2_t{b, b};
+    }
     st.m[h] = mn;
   }
 }
@@ -330,7 +375,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(DecodeAttnParams p) {
   constexpr int U = 4;           // keys in flight per group
   constexpr int NH = REP + 2;    // this workgroup's heads of the new token: REP q heads, k, v
   __shared__ int anc_s[MAXG];
-  __shared__ float tok[NH][D];   // new token: q heads (RoPE'd, scaled), k (RoPE'd, bf16-rounded), v (bf16-rounded)
+  __shared__ __attribute__((aligned(16))) bf16_t tok[NH][D];   // new token: q heads and k (RoPE'd), v -- bf16 as stored
   __shared__ float red_m[NW][REP], red_l[NW][REP];
   __shared__ __attribute__((aligned(16))) float red_acc[NW][REP][D];
   const int hk = blockIdx.x, r = blockIdx.y, item = r / p.beams;
@@ -391,44 +436,40 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(DecodeAttnParams p) {
         dst[d] = f2bf(x1);
         dst[D / 2 + d] = f2bf(x2);
       }
-      const float sc = hh < REP ? p.scale_log2 : 1.0f;
-      tok[hh][d] = x1 * sc;
-      tok[hh][D / 2 + d] = x2 * sc;
+      tok[hh][d] = f2bf(x1);
+      tok[hh][D / 2 + d] = f2bf(x2);
     }
   }
   __syncthreads();
 
-  float q[REP][8];
+  u16x8_t q[REP];
 #pragma unroll
-  for (int h = 0; h < REP; h++) {
-#pragma unroll
-    for (int e = 0; e < 8; e++) q[h][e] = tok[h][c * 8 + e];
-  }
+  for (int h = 0; h < REP; h++) q[h] = *reinterpret_cast<const u16x8_t*>(&tok[h][c * 8]);
   AttnState<REP> st;
 #pragma unroll
   for (int h = 0; h < REP; h++) {
     st.m[h] = -INFINITY;
     st.l[h] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; e++) st.acc[h][e] = 0.f;
+    for (int j = 0; j < 4; j++) st.acc[h][j] = f32x2_t{0.f, 0.f};
   }
   if (gid == 0) {  // the new token itself
-    float kf[8], vf[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      kf[e] = tok[REP][c * 8 + e];
-      vf[e] = tok[REP + 1][c * 8 + e];
-    }
-    attn_key<REP, LPK>(st, q, kf, vf);
+    const u16x8_t k1 = *reinterpret_cast<const u16x8_t*>(&tok[REP][c * 8]);
+    const u16x8_t v1 = *reinterpret_cast<const u16x8_t*>(&tok[REP + 1][c * 8]);
+    const bool ok = true;
+    attn_keys<REP, LPK, 1>(st, q, &k1, &v1, &ok, p.scale_log2);
   }
   const bf16_t* kp_base = p.Kp + ((int64_t)item * p.Tp + start) * HD + hk * D + c * 8;
   const bf16_t* vp_base = p.Vp + ((int64_t)item * p.Tp + start) * HD + hk * D + c * 8;
   for (int i0 = gid; i0 < n_keys; i0 += NG * U) {
     u16x8_t kk[U], vv[U];
+    bool valid[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int i = i0 + u * NG;
-      if (i < n_keys) {
+      valid[u] = i < n_keys;
+      kk[u] = vv[u] = u16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      if (valid[u]) {
         int64_t off;
         const bf16_t *kb, *vb;
         if (i < np) {
@@ -445,17 +486,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(DecodeAttnParams p) {
         vv[u] = *reinterpret_cast<const u16x8_t*>(vb + off);
       }
     }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (i0 + u * NG >= n_keys) break;
-      float kf[8], vf[8];
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        kf[e] = bf2f(kk[u][e]);
-        vf[e] = bf2f(vv[u][e]);
-      }
-      attn_key<REP, LPK>(st, q, kf, vf);
-    }
+    attn_keys<REP, LPK, U>(st, q, kk, vv, valid, p.scale_log2);   // valid[0] is always true here
   }
   // merge the key groups of a wave (lanes with equal c) in registers, then the waves through LDS
   if constexpr (LPK == 8) attn_merge<REP, 8>(st, lane);
@@ -469,7 +500,10 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(DecodeAttnParams p) {
         red_l[wave][h] = st.l[h];
       }
 #pragma unroll
-      for (int e = 0; e < 8; e++) red_acc[wave][h][c * 8 + e] = st.acc[h][e];
+      for (int j = 0; j < 4; j++) {
+        red_acc[wave][h][c * 8 + 2 * j] = st.acc[h][j][0];
+        red_acc[wave][h][c * 8 + 2 * j + 1] = st.acc[h][j][1];
+      }
     }
   }
   __syncthreads();

@@ -1168,6 +1168,23 @@ class SlamHipModel(nn.Module):
                                   float(kwargs.get("length_penalty", 1.0)), self.device_)
 
 
+    @torch.no_grad()
+    def inference(self, wav_path=None, prompt=None, **kwargs):
+        """single-utterance decode, examples/asr_librispeech/model/slam_model_asr.py:81-152: load + pad_or_trim the
+        wav, [audio, "USER: {prompt}\n ASSISTANT:"] prompt, generate(**kwargs).  The log-mel runs on the device."""
+        import os
+        from .batcher import collate, make_sample, whisper_audio_length
+        from .dataset import load_wav_16k
+        if not wav_path or not os.path.exists(wav_path):
+            raise NotImplementedError("text-only QA (no audio) is not part of the speech hot path")
+        audio = load_wav_16k(wav_path)
+        ids = self.tokenizer.encode("USER: {}\n ASSISTANT:".format(prompt))
+        alen = whisper_audio_length(len(audio), self.cfg["ds_rate"])
+        batch = collate([make_sample(audio, ids, None, self.tokenizer.eos_token_id, alen)], self.tokenizer.pad_token_id, True)
+        batch = {k: (v.to(self.device_) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        return self.generate(**batch, **kwargs)
+
+
 # ======================================================================================== optimizer
 class SlamAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (src/slam_llm/pipeline/finetune.py:247-251) as ONE fused kernel over the

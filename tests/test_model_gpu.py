@@ -436,3 +436,23 @@ def test_generate_rejects_unimplemented_modes(dev):
         model.generate(**b, do_sample=True, eos_token_id=2, pad_token_id=0)
     with pytest.raises(NotImplementedError):
         model.generate(**b, repetition_penalty=1.2, eos_token_id=2, pad_token_id=0)
+
+
+def test_single_utterance_inference_equals_batch_generate(dev, tmp_path):
+    """model.inference(wav_path, prompt) (slam_model_asr.py:81-152) == generate() on the equivalent 1-clip batch"""
+    import wave
+    from types import SimpleNamespace
+    from slam_llm_amd import batcher
+    C, fx, W, model, b = _generate_setup(dev, 24.0)
+    pcm = (O.synth_audio(1, 1.5, seed=77)[0] * 32767).round().clamp(-32768, 32767).to(torch.int16)
+    path = str(tmp_path / "utt.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.numpy().tobytes())
+    ids = [5, 17, 301, 42, 9]
+    model.tokenizer = SimpleNamespace(encode=lambda text: list(ids), eos_token_id=int(fx["s24.0.eos"]), pad_token_id=0)
+    got = model.inference(path, "transcribe", max_new_tokens=8, num_beams=4)
+    audio = pcm.float() / 32768.0
+    sample = batcher.make_sample(audio, ids, None, model.tokenizer.eos_token_id, batcher.whisper_audio_length(len(audio), 5))
+    batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batcher.collate([sample], 0, True).items()}
+    want = model.generate(**batch, max_new_tokens=8, num_beams=4)
+    assert got.shape[0] == 1 and torch.equal(got, want)
