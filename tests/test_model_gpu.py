@@ -7,6 +7,7 @@ every trainable tensor must pass 0.999)."""
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import slam_oracle as O
 from oracle.make_golden_cases import CASES
@@ -456,3 +457,44 @@ def test_single_utterance_inference_equals_batch_generate(dev, tmp_path):
     batch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batcher.collate([sample], 0, True).items()}
     want = model.generate(**batch, max_new_tokens=8, num_beams=4)
     assert got.shape[0] == 1 and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("case", ["long_sequence_single_clip", "ragged_right_padded_batch"])
+def test_edge_shapes_match_oracle(dev, case):
+    """edge shapes vs the fp32 oracle (loss, accuracy, every trainable gradient):
+      * B = 1, 0.7 s clip (7 audio tokens), T = 1223 tokens: many attention tiles, no padding anywhere;
+      * B = 3 right-padded (aispeech layout) with clips of 0.5 / 2.0 / 1.2 s and answers of 1 / 40 / 9 tokens: ragged audio
+        lengths inside one zero-padded mel batch, a sample whose only label is eos, T not a multiple of 64."""
+    from slam_llm_amd.model import SlamHipModel
+    cfg = O.make_config()
+    W = O.init_weights(cfg, seed=42)
+    if case == "long_sequence_single_clip":
+        audio = O.synth_audio(1, 0.7, seed=21)
+        batch = O.synth_batch(cfg, audio, prompt_len=900, answer_lens=(316,), seed=5, left_pad=True, pad_to_30s=False)
+    else:
+        g = torch.Generator().manual_seed(3)
+        samples, mels = [], []
+        for secs, al in ((0.5, 1), (2.0, 40), (1.2, 9)):
+            a = O.synth_audio(1, secs, seed=int(secs * 100))[0]
+            mel = O.log_mel_spectrogram(a[: len(a) // O.HOP * O.HOP], cfg["n_mels"]).permute(1, 0)
+            mels.append(mel)
+            alen = ((mel.shape[0] + 1) // 2) // cfg["ds_rate"]
+            samples.append(O.make_sample(alen, torch.randint(3, cfg["vocab"], (5,), generator=g).tolist(),
+                                         torch.randint(3, cfg["vocab"], (al - 1,), generator=g).tolist(), eos=2))
+        batch = O.collate_right_pad(samples, pad_id=2, mels=mels)
+    ref = O.train_steps({k: v.clone() for k, v in W.items()}, cfg, [{k: v.clone() for k, v in batch.items()}])[0]
+    model = SlamHipModel(dict(cfg, lora_dropout=0.0), dev).load_weights(W)
+    model.train()
+    outputs, acc = model(**{k: v.to(dev) for k, v in batch.items()})
+    outputs.loss.backward()
+    assert abs(float(outputs.loss.detach()) - float(ref["loss"])) < 1e-2, (float(outputs.loss.detach()), float(ref["loss"]))
+    n_valid = int((batch["labels"][:, 1:] != -100).sum())
+    assert abs(float(acc) - float(ref["acc"])) <= 2.0 / n_valid + 1e-6
+    worst = 1.0
+    for n, gref in ref["grads"].items():
+        mine = model.store.grad_view(n).float().cpu()
+        cs = float(F.cosine_similarity(mine.flatten(), gref.flatten(), dim=0))
+        worst = min(worst, cs)
+        assert cs > 0.998, f"{case}: grad {n} cosine {cs}"
+        assert abs(float(mine.norm()) - float(gref.norm())) < 4e-2 * float(gref.norm()) + 1e-6, n
+    print(case, "T =", batch["input_ids"].shape[1], "worst grad cosine", worst)
