@@ -49,6 +49,8 @@ int slam_logmel_fwd(const float* audio, int64_t ld_audio, const int32_t* n_valid
 /* ---- GEMM: every Linear / Conv1d-as-GEMM / lm_head on the path ---------------------------------
  * C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): +bias[N] (f32), act, +residual[(m % res_row_mod), n] (bf16),
  * optional accumulate into C, C bf16 or f32.  K % 64 == 0, N % 4 == 0, 16-byte aligned operands.
+ * act: 0 none, 1 GELU(erf), 2 ReLU, 3 SwiGLU backward: the product is dL/dh of h = silu(gate) * up (HF LlamaMLP), `residual`
+ * holds the forward's [gate | up] ([M, 2N]); dL/dgate goes to C[:, :N] and dL/dup to C[:, N:2N] (no residual add).
  * Sites: Whisper linears/convs (src/slam_llm/models/encoder.py:18-29), projector (projector.py:24-26),
  * Llama linears + lm_head (slam_model.py:400), and all their backward products (via stored W^T). */
 int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,

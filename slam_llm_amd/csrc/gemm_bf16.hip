@@ -33,7 +33,7 @@ struct GemmParams {
   const bf16_t* res;
   int64_t ldr;
   int res_mod;
-  int act;  // 0 none, 1 gelu(erf), 2 relu
+  int act;  // 0 none, 1 gelu(erf), 2 relu, 3 swiglu backward (res = [gate | up] of the forward, N = F)
   float alpha;
   int out_f32;
   int accumulate;
@@ -87,7 +87,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
       }
-      if (p.res) {
+      if (p.act == 3) {
+        // SwiGLU backward fused into the down_proj dX GEMM: acc = dL/dh for h = silu(gate) * up.  Reads the forward's
+        // gate/up (p.res, columns n and N + n), writes dL/dgate to C[m, n] (below) and dL/dup to C[m, N + n] -- the
+        // [M, F] intermediate dL/dh and its elementwise pass never touch HBM.  Same arithmetic as swiglu_bwd_kernel
+        // (elementwise.hip) applied to the bf16-rounded product.
+        const u16x4_t g4 = *reinterpret_cast<const u16x4_t*>(p.res + (int64_t)m * p.ldr + n);
+        const u16x4_t u4 = *reinterpret_cast<const u16x4_t*>(p.res + (int64_t)m * p.ldr + p.N + n);
+        float du[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float gf = bf2f(g4[e]), uf = bf2f(u4[e]), df = bf2f(f2bf(v[e]));
+          const float sg = 1.0f / (1.0f + __expf(-gf));
+          v[e] = df * uf * sg * (1.0f + gf * (1.0f - sg));
+          du[e] = df * (gf * sg);
+        }
+        uint2 o2;
+        o2.x = pack2bf(du[0], du[1]);
+        o2.y = pack2bf(du[2], du[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + p.N + n) = o2;
+      } else if (p.res) {
         const int rr = p.res_mod > 0 ? (m % p.res_mod) : m;
         const u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.res + (int64_t)rr * p.ldr + n);
 #pragma unroll
@@ -420,7 +439,12 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
   SLAM_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
                  "slam_gemm_bf16_nt: operands must be 16-byte aligned");
   SLAM_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "slam_gemm_bf16_nt: leading dimension too small");
-  SLAM_CHECK_ARG(act >= 0 && act <= 2, "slam_gemm_bf16_nt: act %d unknown", act);
+  SLAM_CHECK_ARG(act >= 0 && act <= 3, "slam_gemm_bf16_nt: act %d unknown", act);
+  if (act == 3) {
+    SLAM_CHECK_ARG(residual && ldr >= 2 * N && ldc >= 2 * N && out_dtype == SLAM_BF16 && !accumulate && !bias,
+                   "slam_gemm_bf16_nt: act 3 (swiglu backward) needs residual = [gate | up] with ldr >= 2N, bf16 C with ldc >= 2N, "
+                   "no bias / accumulate");
+  }
   SLAM_CHECK_ARG(out_dtype == SLAM_BF16 || out_dtype == SLAM_F32, "slam_gemm_bf16_nt: out_dtype %d unknown", out_dtype);
   if (residual) {
     SLAM_CHECK_ARG(ldr % 4 == 0 && ldr >= N && ((uintptr_t)residual % 8) == 0,

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslamhip.so")
 
 BF16, F32 = 0, 1
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SWIGLU_BWD = 0, 1, 2, 3
 
 P, I64, I32, F, U64 = c_void_p, c_int64, c_int, c_float, ctypes.c_uint64
 

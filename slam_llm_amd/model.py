@@ -29,6 +29,11 @@ import torch.nn as nn
 from . import ops
 from .ops import ACT_GELU, ACT_NONE, ACT_RELU, round_up
 
+import os as _os
+# SwiGLU backward inside the down_proj dX GEMM epilogue (act = 3).  Correct and tested, but measured neutral-to-slower
+# on the C3 step (A/B in one process: 444.2-446.4 ms fused vs 443.7-444.6 ms separate pass): with one 256x256 workgroup
+# per CU the exp-heavy epilogue is not overlapped with MFMA work.  Off unless SLAM_FUSED_SWIGLU_BWD=1.
+FUSE_SWIGLU_BWD = _os.environ.get("SLAM_FUSED_SWIGLU_BWD", "0") == "1"
 LORA_PAD = 64  # K-extension granule (GEMM K-tile)
 
 
@@ -907,9 +912,15 @@ class HipLlamaLora(nn.Module):
         for li in reversed(range(len(self.layers))):
             L, S = self.layers[li], stash["layers"][li]
             dq_, do_, dg_, dd_ = S["drops"]
-            d_hh = L.down.backward(dh, S["hh"], st, accumulate, drop=dd_)
-            dgu = ops.swiglu_bwd(S["gu"], d_hh[:, :Fd])
-            del d_hh
+            if L.down.adapters or not FUSE_SWIGLU_BWD:
+                d_hh = L.down.backward(dh, S["hh"], st, accumulate, drop=dd_)
+                dgu = ops.swiglu_bwd(S["gu"], d_hh[:, :Fd])
+                del d_hh
+            else:
+                # frozen down_proj: dL/dh = dy . W_down never leaves the GEMM -- its epilogue applies the SwiGLU backward
+                # against the stashed [gate | up] and writes dL/dgate | dL/dup directly
+                dgu = torch.empty_like(S["gu"])
+                ops.gemm_nt(dh, L.down.WextT, out=dgu[:, :Fd], act=ops.ACT_SWIGLU_BWD, residual=S["gu"])
             dx2 = L.gu.backward(dgu, S["x2"], st, accumulate, drop=dg_)
             del dgu
             dh_mid = ops.rmsnorm_bwd(S["h_mid"], S["rstd2"], L.ln2, dx2[:, :d], dres=dh)

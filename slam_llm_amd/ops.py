@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import lib
-from .lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, call  # noqa: F401
+from .lib import ACT_GELU, ACT_NONE, ACT_RELU, ACT_SWIGLU_BWD, BF16, F32, call  # noqa: F401
 
 
 class KernelTimer:

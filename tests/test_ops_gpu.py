@@ -78,6 +78,20 @@ def test_gemm_epilogues(dev, act):
     assert torch.all(big_c[:, N:] == 1.0)
 
 
+@pytest.mark.parametrize("M,F_,K", [(300, 192, 128), (1000, 1088, 256), (40, 64, 64)])
+def test_gemm_swiglu_backward_epilogue_equals_separate_pass(dev, M, F_, K):
+    """act = 3: dL/dh = dy . W never leaves the GEMM; the epilogue reproduces gemm -> swiglu_bwd (same formula on the
+    bf16-rounded product; the two translation units may contract a*b+c differently: <= 1 bf16 ulp, almost all equal)"""
+    ops = _ops()
+    dy, wt = rnd((M, K), dev, seed=41), rnd((F_, K), dev, seed=42, std=K ** -0.5)
+    gu = rnd((M, 2 * F_), dev, seed=43)
+    want = ops.swiglu_bwd(gu, ops.gemm_nt(dy, wt))
+    got = torch.zeros((M, 2 * F_), dtype=torch.bfloat16, device=dev)
+    ops.gemm_nt(dy, wt, out=got[:, :F_], act=ops.ACT_SWIGLU_BWD, residual=gu)
+    assert_close(got, want, atol=1e-6, rtol=2 ** -7, what="fused swiglu backward")
+    assert float((got != want).float().mean()) < 0.01
+
+
 def test_gemm_rejects_bad_shapes(dev):
     ops = _ops()
     from slam_llm_amd.lib import SlamHipError
