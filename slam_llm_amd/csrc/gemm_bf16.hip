@@ -20,6 +20,7 @@
 //   * workgroup ids are remapped XCD-aware (block b runs on XCD b%8): each XCD gets a contiguous
 //     run of tiles, ordered in groups of 8 M-tiles, so A/B panels are re-used out of that XCD's L2.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -392,6 +393,161 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
   gemm_epilogue<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, frow, fg);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Persistent variant of the pipelined kernel: one workgroup per CU walks a strided list of output tiles and treats
+// (tile, k-tile) as ONE stream -- the DMA of the next tile's first two k-tiles is issued in the last two phase-B
+// slots of the current tile and its first fragments are read before the epilogue, so the pipeline never drains:
+// no exposed prologue (2 dependent HBM/L2 round trips per tile) and the epilogue's stores retire under the next
+// tile's MFMAs.  Pays most on short-K products (Whisper K = 1280: 20 k-tiles per tile).
+// ------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_persist_kernel(GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int FM = WTM / 16, FN = WTN / 16;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int NIA = BM / 8 / NW;
+  constexpr int NIB = BN / 8 / NW;
+  static_assert(BK == 64, "two 32-deep phases per K-tile");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ srow;
+
+  auto tile_origin = [&](int vbid, int& m0, int& n0) {  // same XCD-aware bijection as the one-tile kernels
+    const int xcd = vbid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int bid = base + (vbid >> 3);
+    constexpr int GM = 8;
+    const int per_group = GM * p.tiles_n;
+    const int group = bid / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(GM, p.tiles_m - first_m);
+    const int within = bid - group * per_group;
+    m0 = (first_m + within % gsz) * BM;
+    n0 = (within / gsz) * BN;
+  };
+  // DMA source addresses are recomputed from the (uniform) tile origin at every issue instead of living in 16 VGPRs:
+  // ~4 VALU per 16-byte DMA, hidden under the MFMAs, and the same code serves the current and the next tile
+  // (the choice is a scalar select -> the k-loop stays one basic block).  32-bit element offsets: < 2^31 elements.
+  const int lrow = wave * 8 + srow;          // this lane's row inside an 8-row DMA group sequence (j * NW * 8 apart)
+  const int lcol = schunk * 8;
+  auto stage = [&](int mo, int no, int kt, int s) {
+    char* sa = smem + s * STAGE;
+    char* sb = sa + BM * ROWB;
+    const int koff = kt * BK + lcol;
+#pragma unroll
+    for (int j = 0; j < NIA; j++) {
+      const int r = min(mo + j * NW * 8 + lrow, p.M - 1);
+      glds16(p.A + ((int64_t)r * p.lda + koff), sa + (j * NW + wave) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < NIB; j++) {
+      const int r = min(no + j * NW * 8 + lrow, p.N - 1);
+      glds16(p.B + ((int64_t)r * p.ldb + koff), sb + (j * NW + wave) * 1024);
+    }
+  };
+
+  const int frow = lane & 15;
+  const int fg = lane >> 4;
+  // fragment addresses: row = (wave tile base) + i*16 + frow, so (row & 7) == (frow & 7) for every fragment and the
+  // i / j dependence is a compile-time multiple of 16 rows -> two base registers + immediate offsets (the generic
+  // per-fragment offset/swizzle arrays of the one-tile kernel cost 24 VGPRs the persistent loop cannot afford)
+  static_assert(WTM % 8 == 0 && WTN % 8 == 0, "wave tile bases must keep row & 7 == frow & 7");
+  const int a_base = (wm * WTM + frow) * ROWB;
+  const int b_base = BM * ROWB + (wn * WTN + frow) * ROWB;
+  const int sw = frow & 7;
+  auto load_frags = [&](const char* st, int ks, bf16x8_t (&af)[FM], bf16x8_t (&bfr)[FN]) {
+    const int ch = ((ks * 4 + fg) ^ sw) << 4;
+#pragma unroll
+    for (int i = 0; i < FM; i++) af[i] = *reinterpret_cast<const bf16x8_t*>(st + a_base + ch + i * 16 * ROWB);
+#pragma unroll
+    for (int j = 0; j < FN; j++) bfr[j] = *reinterpret_cast<const bf16x8_t*>(st + b_base + ch + j * 16 * ROWB);
+  };
+
+  f32x4_t acc[FM][FN];
+  bf16x8_t a0[FM], b0[FN], a1[FM], b1[FN];
+  const int nt = p.K / BK;   // >= 2 (launcher)
+  int vbid = blockIdx.x;
+  int m0, n0;
+  tile_origin(vbid, m0, n0);
+  stage(m0, n0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  stage(m0, n0, 1, 1);
+  load_frags(smem, 0, a0, b0);
+  int par = 0;  // LDS stage holding the stream's current k-tile
+
+  while (true) {
+    const int vnext = vbid + gridDim.x;
+    const bool has_next = vnext < nwg;
+    int m1 = m0, n1 = n0;
+    if (has_next) tile_origin(vnext, m1, n1);   // == current tile when there is none: the tail re-fetches harmless data
+#pragma unroll
+    for (int i = 0; i < FM; i++)
+#pragma unroll
+      for (int j = 0; j < FN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // one k-tile of the stream; LAST = the tile's final k-tile: the next tile's first fragments are NOT prefetched into
+    // a0/b0 there (48 VGPRs that would have to survive the epilogue next to the 128 accumulators -> spills); they are
+    // read right after the epilogue instead, from a stage whose DMA completed one barrier earlier.
+    auto ktile = [&](int t, auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      const int cur = par;
+      const char* st = smem + cur * STAGE;
+      load_frags(st, 1, a1, b1);
+#pragma unroll
+      for (int i = 0; i < FM; i++)
+#pragma unroll
+        for (int j = 0; j < FN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < FM + FN; g++) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      // stream position t+2: still this tile, or k-tile 0 / 1 of the next one (scalar selects, no branch)
+      const bool nx = t + 2 >= nt;
+      stage(nx ? m1 : m0, nx ? n1 : n0, nx ? t + 2 - nt : t + 2, cur);
+      if constexpr (!LAST) load_frags(smem + (cur ^ 1) * STAGE, 0, a0, b0);
+#pragma unroll
+      for (int i = 0; i < FM; i++)
+#pragma unroll
+        for (int j = 0; j < FN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < NIA + NIB; g++) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+      }
+      if constexpr (!LAST) {
+#pragma unroll
+        for (int g = 0; g < FM + FN; g++) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        }
+      }
+      par ^= 1;
+    };
+    for (int t = 0; t < nt - 1; t++) ktile(t, std::false_type{});
+    ktile(nt - 1, std::true_type{});
+    gemm_epilogue<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, frow, fg);
+    if (!has_next) break;
+    vbid = vnext;
+    m0 = m1;
+    n0 = n1;
+    load_frags(smem + par * STAGE, 0, a0, b0);   // next tile's k-tile 0 (landed before the last barrier)
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int PIPE = -1>
 int launch_gemm(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -414,12 +570,42 @@ int launch_gemm(GemmParams& p, hipStream_t stream) {
   return 0;
 }
 
+template <int BM, int BN, int WM, int WN>
+int launch_gemm_persist(GemmParams& p, hipStream_t stream) {
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  constexpr int lds = 2 * (BM + BN) * ROWB;
+  static bool attr_set = false;
+  static int n_cu = 0;
+  auto kern = gemm_nt_persist_kernel<BM, BN, WM, WN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      slam_set_error("gemm: cannot raise LDS limit to %d: %s", lds, hipGetErrorString(e));
+      return -2;
+    }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      slam_set_error("gemm: cannot query the device");
+      return -2;
+    }
+    n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  const int64_t grid = nwg < n_cu ? nwg : n_cu;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), lds, stream, p);
+  SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(persistent)");
+  return 0;
+}
+
 int g_gemm_cfg = 0;  // 0 = auto
 
 }  // namespace
 
 extern "C" int slam_gemm_set_config(int cfg) {
-  SLAM_CHECK_ARG(cfg >= 0 && cfg <= 6, "slam_gemm_set_config: cfg %d out of range [0,6]", cfg);
+  SLAM_CHECK_ARG(cfg >= 0 && cfg <= 7, "slam_gemm_set_config: cfg %d out of range [0,7]", cfg);
   g_gemm_cfg = cfg;
   return 0;
 }
@@ -479,6 +665,9 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     case 4: return launch_gemm<256, 256, 2, 4>(p, s);
     case 5: return launch_gemm<256, 256, 2, 4, 0>(p, s);  // pipelined, compiler-placed barrier (A/B reference)
     case 6: return launch_gemm<256, 256, 2, 4, 1>(p, s);  // pipelined, phase A pinned before the barrier (shipped)
+    case 7:                                                // persistent pipelined (needs >= 2 k-tiles)
+      if (p.K < 2 * BK) return launch_gemm<256, 256, 2, 4, 1>(p, s);
+      return launch_gemm_persist<256, 256, 2, 4>(p, s);
   }
   slam_set_error("slam_gemm_bf16_nt: bad config %d", cfg);
   return -1;

@@ -116,7 +116,7 @@ def gemm_skinny(a, b, out, residual=None, b2=None, swiglu=False):
 _GEMM_CFG = 0
 _GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
                4: "gemm_nt_kernel<256,256,2,4>", 5: "gemm_nt_pipe_kernel<256,256,2,4,0>",
-               6: "gemm_nt_pipe_kernel<256,256,2,4,1>"}
+               6: "gemm_nt_pipe_kernel<256,256,2,4,1>", 7: "gemm_nt_persist_kernel<256,256,2,4>"}
 
 
 def gemm_kernel_name(M: int, N: int) -> str:
