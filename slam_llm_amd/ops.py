@@ -41,6 +41,7 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
+TIMER_SHAPES = False   # tools: key GEMM timings by shape as well as by kernel instance
 
 
 def _timed(name, work, fn):
@@ -87,7 +88,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if (M <= SKINNY_MAX_M and bias is None and act == ACT_NONE and alpha == 1.0 and not accumulate and res_row_mod == 0
             and _GEMM_CFG == 0):
         return gemm_skinny(a, b, out, residual=residual)  # a few rows (decode): HBM-bound weight-streaming kernel
-    _timed(gemm_kernel_name(M, N), 2.0 * M * N * (k_alg or K),
+    _timed(gemm_kernel_name(M, N) + (f" [{M}x{N}x{K}]" if TIMER_SHAPES else ""), 2.0 * M * N * (k_alg or K),
            lambda: call("slam_gemm_bf16_nt", _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, N, K, _p(bias),
                         _p(residual), _ld(residual) if residual is not None else 0, res_row_mod, act, alpha, od,
                         1 if accumulate else 0, _s()))
