@@ -1,4 +1,5 @@
-"""Dataset plugin: JSONL speech dataset feeding RAW waveforms to the GPU log-mel front end.
+"""Dataset plugins: JSONL (asr_librispeech) and kaldi-ark multitask (aispeech_asr) speech datasets feeding RAW
+waveforms to the GPU log-mel front end.
 
 Mirrors `SpeechDatasetJsonl` (src/slam_llm/datasets/speech_dataset.py:17-298): same JSONL schema
 ({"key","source","target"}, examples/asr_librispeech/README.md:17-22), same prompt template and token layout, same
@@ -11,6 +12,9 @@ module (16 kHz PCM wav); other containers need the reference's ffmpeg path and a
 from __future__ import annotations
 
 import json
+import os
+import random
+import struct
 import wave
 
 import numpy as np
@@ -77,5 +81,120 @@ class SpeechDatasetJsonlRaw(torch.utils.data.Dataset):
             yield self.collator(group)
 
 
+def load_ark_wav(spec: str):
+    """`path:offset` entry of a kaldi wav.ark / scp line (what `kaldiio.load_mat` resolves at
+    src/slam_llm/datasets/speech_dataset_large.py:90-91): a RIFF/WAVE file embedded at byte `offset`.
+    Returns (sample_rate, int16 ndarray, mono).  A plain path (no offset) is read from byte 0."""
+    path, _, off = spec.rpartition(":")
+    if not path or not off.isdigit():
+        path, off = spec, "0"
+    with open(path, "rb") as f:
+        f.seek(int(off))
+        riff, _size, wave_id = struct.unpack("<4sI4s", f.read(12))
+        if riff != b"RIFF" or wave_id != b"WAVE":
+            raise ValueError(f"{spec}: not a RIFF/WAVE entry (kaldi feature matrices are not audio)")
+        fmt = None
+        while True:
+            hdr = f.read(8)
+            if len(hdr) < 8:
+                raise ValueError(f"{spec}: no data chunk")
+            cid, csize = struct.unpack("<4sI", hdr)
+            if cid == b"fmt ":
+                fmt = struct.unpack("<HHIIHH", f.read(16))
+                f.seek(csize - 16, 1)
+            elif cid == b"data":
+                if fmt is None or fmt[0] != 1 or fmt[5] != 16:
+                    raise ValueError(f"{spec}: expected 16-bit PCM")
+                if csize in (0, 0xFFFFFFFF):        # streamed ark entries leave the size open
+                    raw = f.read()
+                else:
+                    raw = f.read(csize)
+                a = np.frombuffer(raw[: len(raw) // 2 * 2], dtype=np.int16)
+                if fmt[1] > 1:
+                    a = a.reshape(-1, fmt[1]).mean(axis=1).astype(np.int16)
+                return fmt[2], a
+            else:
+                f.seek(csize + (csize & 1), 1)
+
+
+class MultiTaskDatasetRaw(torch.utils.data.IterableDataset):
+    """`MultiTaskDataset` (src/slam_llm/datasets/speech_dataset_large.py:23-233) over raw waveforms: same files
+    (`<split>_scp_file_path/multitask.jsonl` with {"key","task","target","path"}, `multitask_prompt_path` with
+    {"task","prompt"}), same rank x worker line sharding (:80-86), `max_audio_length` filter (:92-93), random prompt
+    per sample (:113), `append_info_tasks` (:115-116), token layout and RIGHT-padding collator (:180-233) -- but the
+    log-mel is not computed here (:102-104): the batch carries `audio` + `audio_len` for slam_logmel_fwd on the device.
+    `audio_length` reproduces the reference's mel-frame arithmetic for `pad_or_trim` on or off."""
+
+    def __init__(self, dataset_config, tokenizer=None, split="train"):
+        super().__init__()
+        g = dataset_config.get
+        self.prompts = {}
+        with open(g("multitask_prompt_path")) as f:
+            for line in f:
+                if line.strip():
+                    item = json.loads(line)
+                    self.prompts.setdefault(item["task"], []).append(item["prompt"])
+        key = {"train": "train_scp_file_path", "val": "dev_scp_file_path", "test": "test_scp_file_path"}.get(split)
+        if key is None:
+            raise ValueError("split must be train val test")
+        self.data_path = g(key)
+        self.append_info_tasks = g("append_info_tasks", None) or []
+        self.prompt_style = g("prompt_style", "{}")
+        self.tokenizer = tokenizer
+        self.pad_or_trim = g("pad_or_trim", False)
+        self.fix_length_audio = g("fix_length_audio", -1)
+        self.inference_mode = g("inference_mode", False)
+        self.max_audio_length = g("max_audio_length", 30)
+        self.audio_sample_rate = g("audio_sample_rate", 16000)
+        self.ds_rate = g("encoder_projector_ds_rate", 5)
+        self.max_frame_length = g("train_max_frame_length" if split == "train" else "eval_max_frame_length", None)
+
+    def _shard(self):
+        info = torch.utils.data.get_worker_info()
+        nw, wid = (info.num_workers, info.id) if info is not None else (1, 0)
+        import torch.distributed as dist
+        ws, rk = (dist.get_world_size(), dist.get_rank()) if dist.is_available() and dist.is_initialized() else (1, 0)
+        return nw * ws, rk * nw + wid
+
+    def __iter__(self):
+        total, mine = self._shard()
+        with open(os.path.join(self.data_path, "multitask.jsonl")) as f:
+            for index, line in enumerate(f):
+                if index % total != mine:
+                    continue
+                item = json.loads(line)
+                rate, pcm = load_ark_wav(item["path"])
+                if rate != self.audio_sample_rate:
+                    raise ValueError(f"{item['path']}: expected {self.audio_sample_rate} Hz audio, got {rate}")
+                audio = torch.from_numpy(pcm.astype(np.float32) / 32768)
+                if len(audio) / self.audio_sample_rate > self.max_audio_length:
+                    continue
+                alen = (self.fix_length_audio if self.fix_length_audio > 0
+                        else whisper_audio_length(len(audio), self.ds_rate, pad_to_30s=bool(self.pad_or_trim)))
+                prompt = self.prompt_style.format(random.choice(self.prompts[item["task"]]))
+                if item["task"] in self.append_info_tasks:
+                    prompt = prompt.format(item[item["task"]])
+                prompt_ids = self.tokenizer.encode(prompt)
+                if self.inference_mode:
+                    s = make_sample(audio, prompt_ids, None, self.tokenizer.eos_token_id, alen)
+                    s.update(key=item["key"], target=item["target"])
+                else:
+                    full = self.tokenizer.encode(prompt + str(item["target"]))
+                    s = make_sample(audio, prompt_ids, full[len(prompt_ids):], self.tokenizer.eos_token_id, alen)
+                yield s
+
+    def collator(self, samples):
+        return collate(samples, self.tokenizer.pad_token_id, left_pad_prompt=False)
+
+    def dynamic_batch_iter(self):
+        """`MultiTaskDynamicBatchDataset` (speech_dataset_large.py:235-263): in-order batches under max_frame_length"""
+        for group in dynamic_batches(iter(self), int(self.max_frame_length)):
+            yield self.collator(group)
+
+
 def get_speech_dataset(dataset_config, tokenizer, split):
+    """plugin entry (dataset_config.file = ".../slam_model_hip.py:get_speech_dataset"): kaldi-ark multitask layout when
+    the config names `multitask_prompt_path` (aispeech_asr recipes), JSONL otherwise (asr_librispeech recipes)."""
+    if dataset_config.get("multitask_prompt_path", None):
+        return MultiTaskDatasetRaw(dataset_config, tokenizer, split)
     return SpeechDatasetJsonlRaw(dataset_config, tokenizer, split)

@@ -138,3 +138,61 @@ def test_inference_collator_reproduces_reference_layout():
     assert torch.equal(out["attention_mask"], am.bool()) and torch.equal(out["modality_mask"], mm.bool())
     assert torch.equal(out["input_ids"].masked_fill(mm.bool(), 0), ids.masked_fill(mm.bool(), 0))
     assert "labels" not in out and out["keys"] == ["utt0", "utt1", "utt2"] and out["targets"][2] == "ref 2"
+
+
+def _riff(pcm: np.ndarray, rate=16000) -> bytes:
+    import struct
+    data = pcm.astype("<i2").tobytes()
+    return (b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, rate, rate * 2, 2, 16)
+            + b"data" + struct.pack("<I", len(data)) + data)
+
+
+def test_kaldi_ark_multitask_dataset_matches_reference_layout(tmp_path):
+    """aispeech_asr input format: wav.ark entries addressed as path:offset, multitask.jsonl +
+    multiprompt.jsonl; samples / right-padding collator == the oracle's restatement of speech_dataset_large.py:62-233;
+    rank x worker sharding and the max_audio_length filter (:80-93)."""
+    import json
+    from types import SimpleNamespace
+    from slam_llm_amd.dataset import MultiTaskDatasetRaw, get_speech_dataset, load_ark_wav
+    g = torch.Generator().manual_seed(0)
+    clips = [(torch.randn(n, generator=g) * 3000).round().clamp(-32768, 32767).numpy().astype(np.int16) for n in (16000, 4000, 24000, 16000 * 31)]
+    ark, lines = tmp_path / "wav.ark", []
+    with open(ark, "wb") as f:
+        for i, pcm in enumerate(clips):
+            f.write(f"utt{i} ".encode())
+            off = f.tell()
+            f.write(_riff(pcm))
+            lines.append({"key": f"utt{i}", "task": "ASR" if i % 2 == 0 else "hotword", "target": f"t{i}", "path": f"{ark}:{off}",
+                          "hotword": "alpha beta"})
+    (tmp_path / "multitask.jsonl").write_text("\n".join(json.dumps(x) for x in lines) + "\n")
+    (tmp_path / "multiprompt.jsonl").write_text(json.dumps({"task": "ASR", "prompt": "Transcribe."}) + "\n" +
+                                                json.dumps({"task": "hotword", "prompt": "Use {} ."}) + "\n")
+    rate, pcm = load_ark_wav(lines[1]["path"])
+    assert rate == 16000 and np.array_equal(pcm, clips[1])
+    tok = SimpleNamespace(encode=lambda text: [3 + (ord(c) % 50) for c in text], eos_token_id=2, pad_token_id=0)
+    cfg = dict(multitask_prompt_path=str(tmp_path / "multiprompt.jsonl"), train_scp_file_path=str(tmp_path), append_info_tasks=["hotword"],
+               prompt_style="USER: {}\n ASSISTANT:", pad_or_trim=False, max_audio_length=30)
+    ds = get_speech_dataset(cfg, tok, "train")
+    assert isinstance(ds, MultiTaskDatasetRaw)
+    samples = list(ds)
+    assert len(samples) == 3          # the 31 s clip is dropped (speech_dataset_large.py:92-93)
+    for s, line, pcm in zip(samples, lines, clips):
+        assert torch.equal(s["audio"], torch.from_numpy(pcm.astype(np.float32) / 32768))
+        prompt = cfg["prompt_style"].format("Transcribe." if line["task"] == "ASR" else "Use {} .")
+        if line["task"] == "hotword":
+            prompt = prompt.format(line["hotword"])
+        alen = ((len(pcm) // 160 + 1) // 2) // 5
+        pids = tok.encode(prompt)
+        ref = O.make_sample(alen, pids, tok.encode(prompt + line["target"])[len(pids):], eos=2)
+        assert torch.equal(s["input_ids"], ref["input_ids"].clamp(min=-1)) or torch.equal(s["input_ids"].clamp(min=0), ref["input_ids"])
+        assert torch.equal(s["labels"], ref["labels"]) and s["audio_length"] == alen
+    batch = ds.collator(samples)
+    refb = O.collate_right_pad([O.make_sample(s["audio_length"], s["input_ids"][s["audio_length"]: s["audio_length"] + s["prompt_length"]].tolist(),
+                                              s["input_ids"][s["audio_length"] + s["prompt_length"]: -1].tolist(), eos=2) for s in samples], pad_id=0)
+    for k in ("labels", "attention_mask", "modality_mask"):
+        assert torch.equal(batch[k].long(), refb[k].long()), k
+    assert torch.equal(batch["input_ids"].clamp(min=0).masked_fill(batch["modality_mask"].bool(), 0), refb["input_ids"].masked_fill(refb["modality_mask"].bool(), 0))
+    assert batch["audio"].shape == (3, 24000) and batch["audio_len"].tolist() == [16000, 4000, 24000]
+    # rank 1 of 2 (one DataLoader worker each) sees the odd lines only
+    ds._shard = lambda: (2, 1)
+    assert [s["audio"].shape[0] for s in ds] == [4000]
