@@ -128,8 +128,9 @@ def model_factory(train_config, model_config, **kwargs):
 
 
 def get_speech_dataset(dataset_config, tokenizer, split):
-    from slam_llm_amd.dataset import SpeechDatasetJsonlRaw
-    return SpeechDatasetJsonlRaw(dataset_config, tokenizer, split)
+    """dataset plugin entry: kaldi-ark multitask layout (aispeech_asr) or JSONL (asr_librispeech), chosen from the config"""
+    from slam_llm_amd.dataset import get_speech_dataset as _get
+    return _get(dataset_config, tokenizer, split)
 
 
 def inference_batch(model, tokenizer, dataloader, decode_log: str, device="cuda", **generate_kwargs):
