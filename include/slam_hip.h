@@ -110,18 +110,23 @@ int slam_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int
  * Query rows are (b*Tq + t), key/value rows (b*Tk + t): Tq != Tk is cross-attention (Q-Former, projector.py:69-80);
  * Tqp/Tkp are the 64-padded lengths used by the transposed copies, LSE/Delta and the mask.
  * slam_attn_bwd rope_cos/rope_sin (nullable, [T, D/2] f32): when set, dQ and dK are the gradients w.r.t. the
- * PRE-RoPE q/k (the backward of HF apply_rotary_pos_emb with position = row index is applied in the epilogue). */
+ * PRE-RoPE q/k (the backward of HF apply_rotary_pos_emb is applied in the epilogue; position = row index, or
+ * rope_pos[row] when given).
+ * Packed ("varlen") batches: B = 1 with several sequences concatenated along T (no pad tokens, SURVEY 8d ragged set);
+ * seg_lo[q] = first row of q's sequence, seg_hi[k] = one past the last row of k's sequence (int32, non-decreasing,
+ * nullable): query q attends keys seg_lo[q] <= k <= q only.  Equals the right-padded batch of the reference's
+ * MultiTaskDataset collator (speech_dataset_large.py:180-233) on every valid token. */
 int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, void* O,
                   int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B, int64_t Tq, int64_t Tk,
                   int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
-                  void* stream);
+                  const int32_t* seg_lo, void* stream);
 int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                   const void* Qt, const void* Kt, const void* O, int64_t ldo, const void* dO,
                   int64_t lddo, const void* dOt, const float* LSE, float* Delta, const uint8_t* key_mask,
                   void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv, int64_t B,
                   int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D,
-                  int causal, float scale,
-                  const float* rope_cos, const float* rope_sin, void* stream);
+                  int causal, float scale, const float* rope_cos, const float* rope_sin, const int32_t* rope_pos,
+                  const int32_t* seg_lo, const int32_t* seg_hi, void* stream);
 
 /* ---- SwiGLU (LlamaMLP) : gate_up [M, 2F] = [gate | up] ---------------------------------------------- */
 int slam_swiglu_fwd(const void* gate_up, int64_t ldgu, void* h, int64_t ldh, int64_t M, int64_t F,

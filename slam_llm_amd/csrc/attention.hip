@@ -44,6 +44,12 @@ struct AttnParams {
   float scale;                      // softmax scale (1/sqrt(D))
   const float* rope_cos;            // backward only, nullable: [T, D/2] RoPE tables; when set dQ and dK are rotated back
   const float* rope_sin;            //   (d/dx of the forward rotation, position = row index) before they are stored
+  const int* rope_pos;              // nullable [B*T]: explicit rotary position per row (packed / varlen batches)
+  // packed ("varlen") self-attention: several sequences concatenated along T (B = 1).  seg_lo[q] = first key row query q
+  // may attend (start of its sequence), seg_hi[k] = one past the last query row that may see key k (end of its
+  // sequence); both non-decreasing, null for ordinary batches.  Causal only.
+  const int* seg_lo;
+  const int* seg_hi;
 };
 
 // gradient of HF's rotate_half RoPE for one row held as DF fragments of 4 consecutive head-dim elements per lane:
@@ -142,6 +148,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int kend = CAUSAL ? min(Tk, qb0 + 128) : Tk;
   const int ntiles = (kend + 63) / 64;
   const float sl2 = p.scale * LOG2E;
+  // packed batches: keys before the start of the tile's first sequence are never visible -> start there
+  const int tbeg = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(qb0, Tq - 1)] / 64 : 0;
+  int qlo[2] = {0, 0};
+  int lo_wave_max = 0;   // largest sequence start among this wave's 32 queries
+  if (p.seg_lo) {
+#pragma unroll
+    for (int f = 0; f < 2; f++) qlo[f] = p.seg_lo[(int64_t)b * Tq + min(qw0 + f * 16 + li, Tq - 1)];
+    lo_wave_max = p.seg_lo[(int64_t)b * Tq + min(qw0 + 31, Tq - 1)];
+  }
 
   frag_t kreg[KI], vreg[VI];
   auto gload = [&](int k0) {
@@ -175,8 +190,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
   };
 
-  gload(0);
-  for (int it = 0; it < ntiles; it++) {
+  gload(tbeg * 64);
+  for (int it = tbeg; it < ntiles; it++) {
     const int k0 = it * 64;
     __syncthreads();
     lstore();
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
     // ---- online softmax (per query = lane&15, replicated over the 4 lane groups) ----
     // interior tiles (no key mask, fully inside [0, Tk), fully below the causal diagonal of this wave) skip all masking
-    const bool tile_full = (p.kmask == nullptr) && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0);
+    const bool tile_full = (p.kmask == nullptr) && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0;
     if (tile_full) {
 #pragma unroll
       for (int f = 0; f < 2; f++) {
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int key = k0 + kf * 16 + 4 * g + r;
-            const bool ok = kv[kf][r] && (!CAUSAL || key <= q);
+            const bool ok = kv[kf][r] && (!CAUSAL || key <= q) && key >= qlo[f];
             const float x = ok ? s[f][kf][r] * sl2 : -INFINITY;
             s[f][kf][r] = x;
             mt = fmaxf(mt, x);
@@ -380,6 +395,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const int kend = CAUSAL ? min(Tk, qb0 + 64) : Tk;
   const int ntiles = (kend + 31) / 32;
   const bf16_t* ktb = p.Kt + ((int64_t)(b * p.Hkv + hk) * D) * Tkp;
+  const int tbeg = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(qb0, Tq - 1)] / 32 : 0;   // packed batches (see AttnParams)
+  const int qlo = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(q, Tq - 1)] : 0;
 
   frag_t kreg[NKV], vreg[NKV], ktreg[NKT];
   unsigned mreg = 0x01010101u;
@@ -419,8 +436,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     if (tid < 8) ldsMask[tid] = mreg;
   };
 
-  if (ntiles > 0) gload(0);
-  for (int it = 0; it < ntiles; it++) {
+  if (ntiles > tbeg) gload(tbeg * 32);
+  for (int it = tbeg; it < ntiles; it++) {
     const int k0 = it * 32;
     __syncthreads();
     lstore();
@@ -451,7 +468,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int key = kb + r;
-        const bool ok = ((mk >> (8 * r)) & 0xffu) != 0 && key < Tk && (!CAUSAL || key <= q) && qok;
+        const bool ok = ((mk >> (8 * r)) & 0xffu) != 0 && key < Tk && (!CAUSAL || key <= q) && qok && key >= qlo;
         const float pv = ok ? fast_exp2(st[kf][r] * sl2 - lse2) : 0.f;
         st[kf][r] = pv * (dpt[kf][r] - delta) * p.scale;
       }
@@ -467,7 +484,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     }
   }
   if (!qok) return;
-  if (p.rope_cos) rope_grad_inplace<DF>(dq, p.rope_cos, p.rope_sin, q, D, g);
+  if (p.rope_cos) rope_grad_inplace<DF>(dq, p.rope_cos, p.rope_sin, p.rope_pos ? p.rope_pos[(int64_t)b * Tq + q] : q, D, g);
   bf16_t* orow = p.dQ + ((int64_t)b * Tq + q) * p.lddq + h * D;
 #pragma unroll
   for (int df = 0; df < DF; df++) {
@@ -524,7 +541,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   }
   const float sl2 = p.scale * LOG2E;
   const int qstart = CAUSAL ? (kb0 / 32) * 32 : 0;
-  const int nq = (Tq - qstart + 31) / 32;
+  // packed batches: queries at or beyond the end of the tile's last sequence never see these keys
+  const int qend = p.seg_hi ? min(Tq, p.seg_hi[(int64_t)b * Tk + min(kb0 + 63, Tk - 1)]) : Tq;
+  const int khi = p.seg_hi ? p.seg_hi[(int64_t)b * Tk + min(key, Tk - 1)] : 0x7fffffff;
+  const int nq = max(0, (qend - qstart + 31) / 32);
   const int ntiles = G * nq;
 
   frag_t qreg[NQ], doreg[NQ], qtreg[NQT], dotreg[NQT];
@@ -614,7 +634,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int q = qb + r;
-        const bool ok = kok && q < Tq && (!CAUSAL || key <= q);
+        const bool ok = kok && q < Tq && (!CAUSAL || key <= q) && q < khi;
         const float pv = ok ? fast_exp2(s[f][r] * sl2 - ls[r] * LOG2E) : 0.f;
         pm[f][r] = pv;
         ds[f][r] = ok ? pv * (dp[f][r] - dl[r]) * p.scale : 0.f;
@@ -637,7 +657,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
     }
   }
   if (key >= Tk) return;
-  if (p.rope_cos) rope_grad_inplace<DF>(dk, p.rope_cos, p.rope_sin, key, D, g);
+  if (p.rope_cos) rope_grad_inplace<DF>(dk, p.rope_cos, p.rope_sin, p.rope_pos ? p.rope_pos[(int64_t)b * Tk + key] : key, D, g);
   bf16_t* krow = p.dK + ((int64_t)b * Tk + key) * p.lddk + hk * D;
   bf16_t* vrow = p.dV + ((int64_t)b * Tk + key) * p.lddv + hk * D;
 #pragma unroll
@@ -668,14 +688,16 @@ int check_common(const char* name, int64_t B, int64_t Tq, int64_t Tk, int64_t Tq
 extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt,
                              void* O, int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B,
                              int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D,
-                             int causal, float scale, void* stream) {
+                             int causal, float scale, const int32_t* seg_lo, void* stream) {
   SLAM_CHECK_ARG(Q && K && Vt && O, "slam_attn_fwd: null pointer");
+  SLAM_CHECK_ARG(!seg_lo || (causal && Tq == Tk), "slam_attn_fwd: packed sequences (seg_lo) need causal self-attention");
   if (int rc = check_common("slam_attn_fwd", B, Tq, Tk, Tqp, Tkp, Hq, Hkv, D, causal)) return rc;
   SLAM_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "slam_attn_fwd: leading dims must be multiples of 8");
   AttnParams p = {};
   p.Q = (const bf16_t*)Q; p.ldq = ldq; p.K = (const bf16_t*)K; p.ldk = ldk; p.Vt = (const bf16_t*)Vt;
   p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = LSE; p.kmask = key_mask;
   p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
+  p.seg_lo = seg_lo;
   dim3 grid((unsigned)cdiv64(Tq, 128), (unsigned)Hq, (unsigned)B);
   hipStream_t s = (hipStream_t)stream;
   if (D == 64) {
@@ -695,10 +717,13 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
                              float* Delta, const uint8_t* key_mask, void* dQ, int64_t lddq, void* dK,
                              int64_t lddk, void* dV, int64_t lddv, int64_t B, int64_t Tq, int64_t Tk, int64_t Tqp,
                              int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
-                             const float* rope_cos, const float* rope_sin, void* stream) {
+                             const float* rope_cos, const float* rope_sin, const int32_t* rope_pos,
+                             const int32_t* seg_lo, const int32_t* seg_hi, void* stream) {
   SLAM_CHECK_ARG(Q && K && V && Qt && Kt && O && dO && dOt && LSE && Delta && dQ && dK && dV, "slam_attn_bwd: null pointer");
   SLAM_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr), "slam_attn_bwd: rope_cos/rope_sin must both be set or both null");
   SLAM_CHECK_ARG(!rope_cos || Tq == Tk, "slam_attn_bwd: the fused RoPE gradient needs self-attention (Tq == Tk)");
+  SLAM_CHECK_ARG((seg_lo == nullptr) == (seg_hi == nullptr), "slam_attn_bwd: seg_lo/seg_hi must both be set or both null");
+  SLAM_CHECK_ARG(!seg_lo || (causal && Tq == Tk), "slam_attn_bwd: packed sequences need causal self-attention");
   if (int rc = check_common("slam_attn_bwd", B, Tq, Tk, Tqp, Tkp, Hq, Hkv, D, causal)) return rc;
   SLAM_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && ldo % 2 == 0 &&
                      lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0,
@@ -710,7 +735,7 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.dQ = (bf16_t*)dQ; p.lddq = lddq; p.dK = (bf16_t*)dK; p.lddk = lddk; p.dV = (bf16_t*)dV; p.lddv = lddv;
   p.LSE = (float*)LSE; p.Delta = Delta; p.kmask = key_mask;
   p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
-  p.rope_cos = rope_cos; p.rope_sin = rope_sin;
+  p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_pos = rope_pos; p.seg_lo = seg_lo; p.seg_hi = seg_hi;
   hipStream_t s = (hipStream_t)stream;
   dim3 gq((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B);
   dim3 gk((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);

@@ -693,16 +693,18 @@ class HipLlamaLora(nn.Module):
 
     # ---- forward -------------------------------------------------------------------------------------
     def forward_hip(self, h: torch.Tensor, B: int, T: int, key_mask: torch.Tensor, targets, n_valid,
-                    train: bool, return_logits: bool):
+                    train: bool, return_logits: bool, packed=None):
         """h [B*T, d] bf16 (consumed).  Returns (out2 = [loss, acc] device tensor or None, logits or None, stash)."""
         cfg, st = self.cfg, self.store
         d, Hq, Hkv, D, Fd, V = (cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"],
                                 cfg["llm_ffn"], cfg["vocab"])
         M = B * T
         eps = cfg["rms_eps"]
-        cos, sin = self.rope(T)
+        # packed = (positions, seg_lo, seg_hi, max_len): B = 1, sequences concatenated along T without pad tokens
+        positions, seg = (packed[0], (packed[1], packed[2])) if packed is not None else (None, None)
+        cos, sin = self.rope(packed[3] if packed is not None else T)
         scale = D ** -0.5
-        stash = {"layers": [], "B": B, "T": T, "key_mask": key_mask} if train else None
+        stash = {"layers": [], "B": B, "T": T, "key_mask": key_mask, "packed": packed} if train else None
         use_drop = self.training and self.lora_p > 0.0
         seed = torch.initial_seed() if use_drop else 0
 
@@ -718,12 +720,12 @@ class HipLlamaLora(nn.Module):
             _, rstd1 = ops.rmsnorm_fwd(h, L.ln1, eps, out=x1[:, :d])
             dq_, do_, dg_, dd_ = drop_for(L.qkv), drop_for(L.o), drop_for(L.gu), drop_for(L.down)
             qkv = L.qkv.forward(x1, st, drop=dq_)
-            qt = ops.head_rope_transpose(qkv, 0, B, T, Hq, D, cos=cos, sin=sin, want_t=train)
-            kt = ops.head_rope_transpose(qkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, want_t=train)
+            qt = ops.head_rope_transpose(qkv, 0, B, T, Hq, D, cos=cos, sin=sin, want_t=train, positions=positions)
+            kt = ops.head_rope_transpose(qkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, want_t=train, positions=positions)
             vt = ops.head_rope_transpose(qkv, (Hq + Hkv) * D, B, T, Hkv, D)
             o_ext = L.o.new_input(M)
             _, lse = ops.attn_fwd(qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], vt, B, T, Hq, Hkv, D, True, scale,
-                                  key_mask=key_mask, want_lse=train, out=o_ext[:, : Hq * D])
+                                  key_mask=key_mask, want_lse=train, out=o_ext[:, : Hq * D], seg=seg)
             h_mid = L.o.forward(o_ext, st, residual=h, drop=do_)
             x2 = L.gu.new_input(M)
             _, rstd2 = ops.rmsnorm_fwd(h_mid, L.ln2, eps, out=x2[:, :d])
@@ -904,7 +906,10 @@ class HipLlamaLora(nn.Module):
         cfg, st = self.cfg, self.store
         d, Hq, Hkv, D, Fd = cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"], cfg["llm_ffn"]
         B, T, key_mask = stash["B"], stash["T"], stash["key_mask"]
-        cos, sin = self.rope(T)
+        packed = stash.get("packed")
+        cos, sin = self.rope(packed[3] if packed is not None else T)
+        rope = (cos, sin, packed[0]) if packed is not None else (cos, sin)
+        seg = (packed[1], packed[2]) if packed is not None else None
         scale = D ** -0.5
         f = stash.pop("final")
         dh = ops.rmsnorm_bwd(f["h"], f["rstdN"], self.norm_w, f["dhN"], grad_scale=grad_scale)
@@ -933,7 +938,7 @@ class HipLlamaLora(nn.Module):
             dqkv = torch.empty_like(qkv)
             ops.attn_bwd(q2, k2, v2, S["qt"], S["kt"], S["o"][:, : Hq * D], dO, dOt, S["lse"],
                          dqkv[:, : Hq * D], dqkv[:, Hq * D: (Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:],
-                         B, T, Hq, Hkv, D, True, scale, key_mask=key_mask, rope=(cos, sin))  # RoPE backward fused
+                         B, T, Hq, Hkv, D, True, scale, key_mask=key_mask, rope=rope, seg=seg)  # RoPE backward fused
             del do_ext, dO, dOt
             dx1 = L.qkv.backward(dqkv, S["x1"], st, accumulate, drop=dq_)
             del dqkv
@@ -1090,20 +1095,45 @@ class SlamHipModel(nn.Module):
         embeds, spans = ops.embed_splice_fwd(input_ids, mm, self.llm.embed, proj)
         if kwargs.get("inference_mode", False):
             return embeds.view(B, T, -1), attention_mask
-        Tp = round_up(T, 64)
-        key_mask = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
-        key_mask[:, :T] = attention_mask.to(torch.uint8)
         targets = n_valid = None
         if labels is not None:
             targets, n_valid = ops.ce_targets(labels.contiguous())
         want_logits = self.return_logits if self.return_logits is not None else (not train)
-        out2, logits, lstash = self.llm.forward_hip(embeds, B, T, key_mask, targets, n_valid, train, want_logits)
+        pack_idx = None
+        if self.cfg.get("varlen", False):
+            am = attention_mask.to(torch.bool)
+            # packing is exact only for RIGHT-padded batches (MultiTaskDataset collator): every sequence then starts at
+            # position 0 exactly like its padded row; left-padded rows keep the padded path (RoPE offset quirk)
+            if bool((am[:, 1:] <= am[:, :-1]).all()) and bool(am[:, 0].all()):
+                pack_idx = am.flatten().nonzero().squeeze(1)
+        if pack_idx is not None:
+            # ragged batch without pad tokens: one packed sequence of sum(len) rows; attention is restricted to each
+            # sequence by seg_lo / seg_hi, rotary positions restart at every sequence
+            lens = am.sum(1)
+            Mp = int(pack_idx.numel())
+            starts = lens.cumsum(0) - lens
+            lo = starts.repeat_interleave(lens, output_size=Mp).to(torch.int32).contiguous()
+            hi = (starts + lens).repeat_interleave(lens, output_size=Mp).to(torch.int32).contiguous()
+            pos = (torch.arange(Mp, device=dev, dtype=torch.int32) - lo).contiguous()
+            h_packed = embeds.index_select(0, pack_idx)
+            t_packed = targets.index_select(0, pack_idx).contiguous() if targets is not None else None
+            out2, logits_p, lstash = self.llm.forward_hip(h_packed, 1, Mp, None, t_packed, n_valid, train, want_logits,
+                                                          packed=(pos, lo, hi, T))
+            logits = None
+            if logits_p is not None:   # back to the padded [B*T, V] layout (pad rows zero)
+                logits = torch.zeros((B * T, logits_p.shape[1]), dtype=logits_p.dtype, device=dev)
+                logits.index_copy_(0, pack_idx, logits_p)
+        else:
+            Tp = round_up(T, 64)
+            key_mask = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
+            key_mask[:, :T] = attention_mask.to(torch.uint8)
+            out2, logits, lstash = self.llm.forward_hip(embeds, B, T, key_mask, targets, n_valid, train, want_logits)
         loss = acc = None
         if out2 is not None:
             loss_val, acc = out2[0], out2[1]
             if train:
                 stash.update(lstash)
-                stash.update(spans=spans, Ta=Ta, B=B, T=T)
+                stash.update(spans=spans, Ta=Ta, batch_B=B, batch_T=T, pack_idx=pack_idx)  # (B, T of the LLM pass itself live in lstash)
                 loss = _SlamStep.apply(self._anchor, self, stash, loss_val)
             else:
                 loss = loss_val
@@ -1117,7 +1147,11 @@ class SlamHipModel(nn.Module):
         accumulate = any(p.grad is not None for p in st.params.values())
         gs = grad_out.reshape(1).to(torch.float32).contiguous()
         dh0 = self.llm.backward_hip(stash, gs, accumulate, on_layer_done=self._on_layer_done)
-        dproj = ops.embed_splice_bwd(stash["spans"], dh0, stash["B"], stash["T"], stash["Ta"], self.cfg["llm_dim"])
+        if stash.get("pack_idx") is not None:   # packed rows -> padded [B*T, d] layout (pad rows carry no gradient)
+            full = torch.zeros((stash["batch_B"] * stash["batch_T"], dh0.shape[1]), dtype=dh0.dtype, device=dh0.device)
+            full.index_copy_(0, stash["pack_idx"], dh0)
+            dh0 = full
+        dproj = ops.embed_splice_bwd(stash["spans"], dh0, stash["batch_B"], stash["batch_T"], stash["Ta"], self.cfg["llm_dim"])
         self.encoder_projector.backward_hip(dproj, stash, accumulate)
         for name, p in st.params.items():
             if p.grad is None:

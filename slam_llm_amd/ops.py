@@ -312,8 +312,9 @@ def transpose(x2d, Rp=None, out=None):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_lse=True, out=None, Tk=None):
-    """self-attention: q/k rows (b*T + t).  Cross-attention: pass Tk (key rows b*Tk + t); vt is [B,Hkv,D,Tkp]."""
+def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_lse=True, out=None, Tk=None, seg=None):
+    """self-attention: q/k rows (b*T + t).  Cross-attention: pass Tk (key rows b*Tk + t); vt is [B,Hkv,D,Tkp].
+    seg = (lo, hi) int32 [B*T]: packed sequences (B = 1), query q sees keys lo[q] <= k <= q."""
     Tk = Tk or T
     Tkp, Tqp = vt.shape[-1], round_up(T, 64)
     if out is None:
@@ -321,13 +322,15 @@ def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_
     lse = torch.empty((B, Hq, Tqp), dtype=torch.float32, device=q2d.device) if want_lse else None
     _timed("attn_fwd", 4.0 * B * Hq * T * Tk * D * (0.5 if causal else 1.0),
            lambda: call("slam_attn_fwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(vt), _p(out), _ld(out), _p(lse),
-                        _p(key_mask), B, T, Tk, Tqp, Tkp, Hq, Hkv, D, 1 if causal else 0, scale, _s()))
+                        _p(key_mask), B, T, Tk, Tqp, Tkp, Hq, Hkv, D, 1 if causal else 0, scale, _p(seg[0]) if seg else None,
+                        _s()))
     return out, lse
 
 
 def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T, Hq, Hkv, D, causal, scale,
-             key_mask=None, Tk=None, rope=None):
-    """rope = (cos, sin) tables: dq/dk come out as gradients w.r.t. the pre-RoPE projections (fused epilogue)."""
+             key_mask=None, Tk=None, rope=None, seg=None):
+    """rope = (cos, sin[, positions]) tables: dq/dk come out as gradients w.r.t. the pre-RoPE projections (fused
+    epilogue; explicit int32 positions for packed batches).  seg = (lo, hi): packed sequences, see attn_fwd."""
     Tk = Tk or T
     Tqp, Tkp = qt.shape[-1], kt.shape[-1]
     delta = torch.empty((B, Hq, Tqp), dtype=torch.float32, device=q2d.device)
@@ -335,7 +338,9 @@ def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T,
            lambda: call("slam_attn_bwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(v2d), _ld(v2d), _p(qt), _p(kt),
                         _p(o2d), _ld(o2d), _p(do2d), _ld(do2d), _p(dot), _p(lse), _p(delta), _p(key_mask), _p(dq2d),
                         _ld(dq2d), _p(dk2d), _ld(dk2d), _p(dv2d), _ld(dv2d), B, T, Tk, Tqp, Tkp, Hq, Hkv, D,
-                        1 if causal else 0, scale, _p(rope[0]) if rope else None, _p(rope[1]) if rope else None, _s()))
+                        1 if causal else 0, scale, _p(rope[0]) if rope else None, _p(rope[1]) if rope else None,
+                        _p(rope[2]) if rope and len(rope) > 2 else None, _p(seg[0]) if seg else None,
+                        _p(seg[1]) if seg else None, _s()))
     return delta
 
 

@@ -67,7 +67,10 @@ def build_config(train_config, model_config) -> dict:
     llm = _get(model_config, "arch_llm") or _guess_preset(str(_get(model_config, "llm_name", "")), llm_presets)
     peft = _get(train_config, "peft_config", None)
     use_peft = bool(_get(train_config, "use_peft", False))
-    extra = dict(encoder_name=enc_name, projector=projector)
+    # ++model_config.pad_or_trim=false: per-clip mel (aispeech recipes); ++model_config.varlen=true: right-padded batches run
+    # the LLM on packed sequences (no pad tokens) -- identical results on every valid token, see DESIGN.md
+    extra = dict(encoder_name=enc_name, projector=projector, pad_or_trim=bool(_get(model_config, "pad_or_trim", True)),
+                 varlen=bool(_get(model_config, "varlen", False)))
     if enc_name == "hubert":
         hp = _get(model_config, "arch_encoder") or _guess_preset(str(_get(model_config, "encoder_path", "hubert-large")).replace("_", "-"), HUBERT_PRESETS)
         extra.update(HUBERT_PRESETS[hp])

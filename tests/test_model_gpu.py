@@ -459,16 +459,18 @@ def test_single_utterance_inference_equals_batch_generate(dev, tmp_path):
     assert got.shape[0] == 1 and torch.equal(got, want)
 
 
-@pytest.mark.parametrize("case", ["long_sequence_single_clip", "ragged_right_padded_batch"])
+@pytest.mark.parametrize("case", ["long_sequence_single_clip", "ragged_right_padded_batch", "ragged_right_padded_batch_packed"])
 def test_edge_shapes_match_oracle(dev, case):
     """edge shapes vs the fp32 oracle (loss, accuracy, every trainable gradient):
       * B = 1, 0.7 s clip (7 audio tokens), T = 1223 tokens: many attention tiles, no padding anywhere;
       * B = 3 right-padded (aispeech layout) with clips of 0.5 / 2.0 / 1.2 s and answers of 1 / 40 / 9 tokens: ragged audio
-        lengths inside one zero-padded mel batch, a sample whose only label is eos, T not a multiple of 64."""
+        lengths inside one zero-padded mel batch (SURVEY g1), a sample whose only label is eos, T not a multiple of 64;
+      * the same batch with cfg["varlen"]: the LLM runs on the 3 sequences PACKED (no pad tokens, seg_lo / seg_hi
+        attention, per-token rotary positions) -- must equal the reference's right-padded result on every valid token."""
     from slam_llm_amd.model import SlamHipModel
     cfg = O.make_config()
     W = O.init_weights(cfg, seed=42)
-    if case == "long_sequence_single_clip":
+    if case == "long_sequence_single_clip":  # noqa: SIM102
         audio = O.synth_audio(1, 0.7, seed=21)
         batch = O.synth_batch(cfg, audio, prompt_len=900, answer_lens=(316,), seed=5, left_pad=True, pad_to_30s=False)
     else:
@@ -483,11 +485,20 @@ def test_edge_shapes_match_oracle(dev, case):
                                          torch.randint(3, cfg["vocab"], (al - 1,), generator=g).tolist(), eos=2))
         batch = O.collate_right_pad(samples, pad_id=2, mels=mels)
     ref = O.train_steps({k: v.clone() for k, v in W.items()}, cfg, [{k: v.clone() for k, v in batch.items()}])[0]
-    model = SlamHipModel(dict(cfg, lora_dropout=0.0), dev).load_weights(W)
+    model = SlamHipModel(dict(cfg, lora_dropout=0.0, varlen=case.endswith("packed")), dev).load_weights(W)
     model.train()
+    model.return_logits = True
     outputs, acc = model(**{k: v.to(dev) for k, v in batch.items()})
     outputs.loss.backward()
     assert abs(float(outputs.loss.detach()) - float(ref["loss"])) < 1e-2, (float(outputs.loss.detach()), float(ref["loss"]))
+    if case.endswith("packed"):   # logits come back in the padded [B, T, V] layout: valid rows vs the oracle's
+        with torch.no_grad():
+            _, ref_logits, _, _ = O.slam_forward(W, cfg, {k: v.clone() for k, v in batch.items()})
+        valid = batch["attention_mask"].bool()
+        got = outputs.logits.float().cpu()[valid]
+        want = ref_logits[valid]
+        assert (got - want).abs().max() < 6e-2 + 2e-2 * want.abs().max(), float((got - want).abs().max())
+        assert float(outputs.logits.float().cpu()[~valid].abs().max()) == 0.0
     n_valid = int((batch["labels"][:, 1:] != -100).sum())
     assert abs(float(acc) - float(ref["acc"])) <= 2.0 / n_valid + 1e-6
     worst = 1.0

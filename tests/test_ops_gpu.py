@@ -278,6 +278,53 @@ def test_attention_bwd(dev, B, T, Hq, Hkv, D, masked):
     assert torch.equal(fused[:, (Hq + Hkv) * D:], dqkv[:, (Hq + Hkv) * D:])  # dV untouched by RoPE
 
 
+@pytest.mark.parametrize("lens,Hq,Hkv,D", [((70, 133, 37), 4, 2, 128), ((5, 64, 1, 200, 63), 2, 2, 64), ((380, 380), 4, 1, 128)])
+def test_packed_sequences_attention_equals_per_sequence(dev, lens, Hq, Hkv, D):
+    """packed ("varlen") causal attention: sequences concatenated along T with seg_lo / seg_hi == attention run on every
+    sequence alone (torch fp32 reference + autograd), forward and all three gradients, incl. the fused RoPE backward
+    with explicit per-token positions"""
+    ops = _ops()
+    from slam_llm_amd.host_tables import rope_tables
+    T = sum(lens)
+    qkv, q2, k2, v2, qt, kt, vt = _prep_attn(ops, dev, 1, T, Hq, Hkv, D, seed=17)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    lo = torch.tensor(np.repeat(starts, lens), dtype=torch.int32, device=dev)
+    hi = torch.tensor(np.repeat(starts + np.array(lens), lens), dtype=torch.int32, device=dev)
+    pos = (torch.arange(T, device=dev, dtype=torch.int32) - lo).contiguous()
+    scale = D ** -0.5
+    o, lse = ops.attn_fwd(q2, k2, vt, 1, T, Hq, Hkv, D, True, scale, seg=(lo, hi))
+    do = rnd((T, Hq * D), dev, seed=18)
+    dot = ops.head_rope_transpose(do, 0, 1, T, Hq, D)
+    dqkv = torch.zeros_like(qkv)
+    ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, dqkv[:, : Hq * D], dqkv[:, Hq * D:(Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:],
+                 1, T, Hq, Hkv, D, True, scale, seg=(lo, hi))
+    ref_o = torch.empty(T, Hq, D, device=dev)
+    ref_g = [torch.empty(T, Hq, D, device=dev), torch.empty(T, Hkv, D, device=dev), torch.empty(T, Hkv, D, device=dev)]
+    for s0, n in zip(starts, lens):
+        sl = slice(int(s0), int(s0) + n)
+        qf = q2[sl].float().view(1, n, Hq, D).clone().requires_grad_(True)
+        kf = k2[sl].float().view(1, n, Hkv, D).clone().requires_grad_(True)
+        vf = v2[sl].float().view(1, n, Hkv, D).clone().requires_grad_(True)
+        r = _attn_ref(qf, kf, vf, True, None, scale)
+        r.backward(do[sl].float().view(1, n, Hq, D))
+        ref_o[sl] = r[0].detach()
+        for dst, src in zip(ref_g, (qf, kf, vf)):
+            dst[sl] = src.grad[0]
+    assert_close(o.view(T, Hq, D), ref_o, atol=2e-2, rtol=2e-2, what="packed attn fwd")
+    for nme, got, r in (("dq", dqkv[:, : Hq * D], ref_g[0]), ("dk", dqkv[:, Hq * D:(Hq + Hkv) * D], ref_g[1]), ("dv", dqkv[:, (Hq + Hkv) * D:], ref_g[2])):
+        got = got.float().reshape(r.shape)
+        assert F.cosine_similarity(got.flatten(), r.flatten(), dim=0) > 0.999, nme
+        assert_close(got, r, atol=3e-2 * float(r.abs().max()), rtol=3e-2, what="packed " + nme)
+    # fused RoPE backward with per-token positions == separate inverse rotation with the same positions
+    cos, sin = (t.to(dev) for t in rope_tables(max(lens), D, 10000.0))
+    fused = torch.zeros_like(qkv)
+    ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, fused[:, : Hq * D], fused[:, Hq * D:(Hq + Hkv) * D], fused[:, (Hq + Hkv) * D:],
+                 1, T, Hq, Hkv, D, True, scale, rope=(cos, sin, pos), seg=(lo, hi))
+    ops.head_rope_transpose(dqkv, 0, 1, T, Hq, D, cos=cos, sin=sin, inverse=True, want_t=False, positions=pos)
+    ops.head_rope_transpose(dqkv, Hq * D, 1, T, Hkv, D, cos=cos, sin=sin, inverse=True, want_t=False, positions=pos)
+    assert_close(fused, dqkv.float(), atol=2e-2 * float(dqkv.float().abs().max()), rtol=2e-2, what="packed fused rope grad")
+
+
 def test_cross_attention_fwd_bwd(dev):
     """Tq != Tk (Q-Former cross-attention: 32 queries over 150 encoder frames, key padding mask), D = 64"""
     ops = _ops()
