@@ -298,15 +298,16 @@ def gen_generate():
         free = run(cfg["vocab"] - 1, 1, pad=case["pad"])
         eos = int(free[0, 4])
         fx[f"s{scale}.eos"] = np.int64(eos)
-        for nb, lp, pad in ((1, 1.0, case["pad"]), (4, 1.0, case["pad"]), (4, 2.0, 1), (3, 0.0, 1)):
-            out = run(eos, nb, length_penalty=lp, pad=pad)
+        for nb, lp, pad, rp in ((1, 1.0, case["pad"], 1.0), (4, 1.0, case["pad"], 1.0), (4, 2.0, 1, 1.0), (3, 0.0, 1, 1.0),
+                                (1, 1.0, 1, 1.3), (4, 1.0, 1, 1.3)):
+            out = run(eos, nb, length_penalty=lp, pad=pad, repetition_penalty=rp)
             mine = O.slam_generate(W, cfg, {k: v.clone() for k, v in batch.items()}, max_new_tokens=case["max_new_tokens"],
-                                   num_beams=nb, length_penalty=lp, eos=eos, pad=pad)
+                                   num_beams=nb, length_penalty=lp, eos=eos, pad=pad, repetition_penalty=rp)
             ok = out.shape == mine.shape and bool((out == mine).all())
-            print(f"generate scale={scale} beams={nb} lp={lp} pad={pad}: oracle match {ok}\n{out.numpy()}")
+            print(f"generate scale={scale} beams={nb} lp={lp} pad={pad} rp={rp}: oracle match {ok}\n{out.numpy()}")
             if not ok:
                 print("oracle:\n", mine.numpy())
-            fx[f"s{scale}.tokens.b{nb}.lp{lp}.pad{pad}"] = out.numpy()
+            fx[f"s{scale}.tokens.b{nb}.lp{lp}.pad{pad}" + (f".rp{rp}" if rp != 1.0 else "")] = out.numpy()
     np.savez_compressed(os.path.join(GOLD, "generate.npz"), **fx)
     print("generate.npz written")
 

@@ -473,7 +473,18 @@ def train_steps(W, cfg, batches: List[dict], lr=1e-4, weight_decay=0.0, warmup=1
 
 
 # ---------------------------------------------------------------------------------------------- f1: generate (beam / greedy)
-def greedy_search(step_fn, batch_size: int, max_new_tokens: int, eos: int, pad: int, min_length: int = 1):
+def _repetition_penalty(scores: torch.Tensor, history: torch.Tensor, penalty: float) -> torch.Tensor:
+    """HF RepetitionPenaltyLogitsProcessor: every token id already in the row's history gets score*p if score < 0 else
+    score/p (applied before the min-length mask; the history of an inputs_embeds prompt is the generated tokens only)."""
+    if penalty == 1.0 or history.shape[1] == 0:
+        return scores
+    sc = torch.gather(scores, 1, history)
+    sc = torch.where(sc < 0, sc * penalty, sc / penalty)
+    return scores.scatter(1, history, sc)
+
+
+def greedy_search(step_fn, batch_size: int, max_new_tokens: int, eos: int, pad: int, min_length: int = 1,
+                  repetition_penalty: float = 1.0):
     """HF `GenerationMixin._sample` with do_sample=False (transformers/generation/utils.py), the num_beams=1 branch of
     `self.llm.generate(...)` at slam_model.py:438-452.  The prompt is inputs_embeds only, so the token history starts
     empty: MinLengthLogitsProcessor(min_length) therefore masks eos while fewer than `min_length` tokens exist.
@@ -482,7 +493,7 @@ def greedy_search(step_fn, batch_size: int, max_new_tokens: int, eos: int, pad: 
     alive = torch.ones(batch_size, dtype=torch.bool)
     rows = torch.arange(batch_size)
     while True:
-        logits = step_fn(toks, rows).float().clone()
+        logits = _repetition_penalty(step_fn(toks, rows).float().clone(), toks, repetition_penalty)
         if toks.shape[1] < min_length:
             logits[:, eos] = -float("inf")
         nxt = logits.argmax(-1)
@@ -494,7 +505,7 @@ def greedy_search(step_fn, batch_size: int, max_new_tokens: int, eos: int, pad: 
 
 
 def beam_search(step_fn, batch_size: int, num_beams: int, max_new_tokens: int, eos: int, pad: int,
-                min_length: int = 1, length_penalty: float = 1.0):
+                min_length: int = 1, length_penalty: float = 1.0, repetition_penalty: float = 1.0):
     """HF `GenerationMixin._beam_search` (transformers 5.x vectorised form; early_stopping=False, one eos id,
     num_return_sequences=1), restated per batch item.  Each item keeps `num_beams` running hypotheses and
     `num_beams` finished ones; every step the best 2*num_beams continuations are ranked, the non-terminated ones
@@ -518,7 +529,7 @@ def beam_search(step_fn, batch_size: int, num_beams: int, max_new_tokens: int, e
     while True:
         flat = torch.cat([r[:, :t] for r in run_seq], dim=0)
         logits = step_fn(flat, src_rows).float()
-        lp_all = F.log_softmax(logits, dim=-1)
+        lp_all = _repetition_penalty(F.log_softmax(logits, dim=-1), flat, repetition_penalty)
         if t < min_length:
             lp_all[:, eos] = -float("inf")
         V = lp_all.shape[-1]
@@ -567,11 +578,11 @@ def generate_position_ids(attention_mask: torch.Tensor) -> torch.Tensor:
 
 
 def slam_generate(W, cfg, batch: dict, max_new_tokens=200, num_beams=4, min_length=1, length_penalty=1.0,
-                  eos=2, pad=0):
+                  eos=2, pad=0, repetition_penalty=1.0):
     """slam_model.generate (src/slam_llm/models/slam_model.py:409-456): forward(..., inference_mode=True) returns
     (inputs_embeds, attention_mask) [slam_model.py:394-395], then `self.llm.generate(inputs_embeds=...,
     attention_mask=..., num_beams, max_new_tokens, min_length, length_penalty, eos/pad ids)`.  do_sample=False,
-    top_p = temperature = repetition_penalty = 1.0 are no-ops.  The oracle re-runs the full sequence every step
+    top_p = temperature = 1.0 are no-ops; repetition_penalty is HF's RepetitionPenaltyLogitsProcessor.  The oracle re-runs the full sequence every step
     (no KV cache) in fp32."""
     mel = batch["audio_mel"]
     enc = whisper_encoder(W, cfg, mel.permute(0, 2, 1))
@@ -591,8 +602,8 @@ def slam_generate(W, cfg, batch: dict, max_new_tokens=200, num_beams=4, min_leng
         return logits[:, -1, :]
 
     if num_beams == 1:
-        return greedy_search(step_fn, B, max_new_tokens, eos, pad, min_length)
-    return beam_search(step_fn, B, num_beams, max_new_tokens, eos, pad, min_length, length_penalty)
+        return greedy_search(step_fn, B, max_new_tokens, eos, pad, min_length, repetition_penalty)
+    return beam_search(step_fn, B, num_beams, max_new_tokens, eos, pad, min_length, length_penalty, repetition_penalty)
 
 
 # ---------------------------------------------------------------------------------------------- a9: batcher + collators

@@ -1181,7 +1181,7 @@ class SlamHipModel(nn.Module):
         from . import decode
         if kwargs.get("do_sample", False):
             raise NotImplementedError("sampling decode is not implemented (the reference recipes decode with do_sample=False)")
-        for k_, neutral in (("repetition_penalty", 1.0), ("top_p", 1.0), ("temperature", 1.0)):
+        for k_, neutral in (("top_p", 1.0), ("temperature", 1.0)):
             if float(kwargs.get(k_, neutral)) != neutral:
                 raise NotImplementedError(f"{k_} != {neutral} is not implemented")
         tok = self.tokenizer
@@ -1208,9 +1208,10 @@ class SlamHipModel(nn.Module):
 
         if num_beams == 1:
             return decode.greedy_search(step_fn, B, max_new, int(eos), int(pad), int(kwargs.get("min_length", 1)),
-                                        self.device_)
+                                        self.device_, float(kwargs.get("repetition_penalty", 1.0)))
         return decode.beam_search(step_fn, B, num_beams, max_new, int(eos), int(pad), int(kwargs.get("min_length", 1)),
-                                  float(kwargs.get("length_penalty", 1.0)), self.device_)
+                                  float(kwargs.get("length_penalty", 1.0)), self.device_,
+                                  float(kwargs.get("repetition_penalty", 1.0)))
 
 
     @torch.no_grad()

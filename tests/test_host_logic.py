@@ -95,7 +95,7 @@ def test_decode_bookkeeping_matches_reference_generate(scale):
     from oracle import slam_oracle as O
     from oracle.make_golden_cases import GENERATE_CASE as C
     from slam_llm_amd import decode
-    from tests.test_oracle_golden import GEN_RUNS, generate_case_weights
+    from tests.test_oracle_golden import GEN_RUNS, gen_key, generate_case_weights
     fx = G.load("generate")
     cfg, W = C["cfg"], generate_case_weights(scale)
     batch = {k[len("batch."):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("batch.")}
@@ -113,12 +113,12 @@ def test_decode_bookkeeping_matches_reference_generate(scale):
         return O.llama_forward(W, cfg, x, m, None, position_ids=O.generate_position_ids(m))[1][:, -1, :]
 
     eos = int(fx[f"s{scale}.eos"])
-    for nb, lp, pad in GEN_RUNS:
+    for nb, lp, pad, rp in GEN_RUNS:
         if nb == 1:
-            got = decode.greedy_search(step_fn, B, C["max_new_tokens"], eos, pad, 1, "cpu")
+            got = decode.greedy_search(step_fn, B, C["max_new_tokens"], eos, pad, 1, "cpu", rp)
         else:
-            got = decode.beam_search(step_fn, B, nb, C["max_new_tokens"], eos, pad, 1, lp, "cpu")
-        want = fx[f"s{scale}.tokens.b{nb}.lp{lp}.pad{pad}"]
+            got = decode.beam_search(step_fn, B, nb, C["max_new_tokens"], eos, pad, 1, lp, "cpu", rp)
+        want = fx[gen_key(scale, nb, lp, pad, rp)]
         assert tuple(got.shape) == want.shape and (got.numpy() == want).all(), (nb, lp, pad, got, want)
 
 

@@ -112,7 +112,11 @@ def test_cov1d_projector_matches_reference_module():
         G.check_packed(fx, "grad." + n, v.grad.numpy(), atol=2e-5, rtol=1e-3, norm_rtol=1e-4)
 
 
-GEN_RUNS = ((1, 1.0, 0), (4, 1.0, 0), (4, 2.0, 1), (3, 0.0, 1))
+GEN_RUNS = ((1, 1.0, 0, 1.0), (4, 1.0, 0, 1.0), (4, 2.0, 1, 1.0), (3, 0.0, 1, 1.0), (1, 1.0, 1, 1.3), (4, 1.0, 1, 1.3))
+
+
+def gen_key(scale, nb, lp, pad, rp):
+    return f"s{scale}.tokens.b{nb}.lp{lp}.pad{pad}" + (f".rp{rp}" if rp != 1.0 else "")
 
 
 def generate_case_weights(scale):
@@ -130,8 +134,8 @@ def test_generate_matches_reference_generate(scale):
     W = generate_case_weights(scale)
     batch = {k[len("batch."):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("batch.")}
     eos = int(fx[f"s{scale}.eos"])
-    for nb, lp, pad in GEN_RUNS:
+    for nb, lp, pad, rp in GEN_RUNS:
         got = O.slam_generate(W, C["cfg"], {k: v.clone() for k, v in batch.items()}, max_new_tokens=C["max_new_tokens"],
-                              num_beams=nb, length_penalty=lp, eos=eos, pad=pad)
-        want = fx[f"s{scale}.tokens.b{nb}.lp{lp}.pad{pad}"]
+                              num_beams=nb, length_penalty=lp, eos=eos, pad=pad, repetition_penalty=rp)
+        want = fx[gen_key(scale, nb, lp, pad, rp)]
         assert got.shape == want.shape and (got.numpy() == want).all(), (nb, lp, pad, got, want)
