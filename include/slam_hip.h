@@ -59,6 +59,7 @@ int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, vo
                       int accumulate, void* stream);
 /* tile configuration override: 0 auto, 1 128x128/4 waves, 2 256x128/8 waves, 3 128x64, 4 256x256/8 waves (2-stage loop),
  * 5/6 256x256 register-double-buffered pipeline (6 = shipped schedule) */
+int slam_gemm_set_group_m(int group_m);   /* tuning knob: M-tiles per raster group of the 256x256 kernel (default 8) */
 int slam_gemm_set_config(int cfg);
 
 /* ---- conv front end (src/slam_llm/models/encoder.py:18-19): k=3, pad=1 im2col, stride 1|2 ---------

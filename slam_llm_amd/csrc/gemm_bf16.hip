@@ -39,6 +39,7 @@ struct GemmParams {
   int out_f32;
   int accumulate;
   int tiles_m, tiles_n;
+  int group_m;   // M-tiles per raster group (L2 reuse of the B panel inside an XCD)
 };
 
 constexpr int BK = 64;           // bf16 elements per K-tile
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     bid = base + (bid >> 3);
   }
-  constexpr int GM = 8;
+  const int GM = p.group_m;
   const int per_group = GM * p.tiles_n;
   const int group = bid / per_group;
   const int first_m = group * GM;
@@ -601,8 +602,15 @@ int launch_gemm_persist(GemmParams& p, hipStream_t stream) {
 }
 
 int g_gemm_cfg = 0;  // 0 = auto
+int g_gemm_group_m = 8;
 
 }  // namespace
+
+extern "C" int slam_gemm_set_group_m(int group_m) {   // tuning knob (tools): raster group height of the pipelined kernel
+  SLAM_CHECK_ARG(group_m >= 1 && group_m <= 64, "slam_gemm_set_group_m: %d out of range [1,64]", group_m);
+  g_gemm_group_m = group_m;
+  return 0;
+}
 
 extern "C" int slam_gemm_set_config(int cfg) {
   SLAM_CHECK_ARG(cfg >= 0 && cfg <= 7, "slam_gemm_set_config: cfg %d out of range [0,7]", cfg);
@@ -642,6 +650,7 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.bias = bias; p.res = (const bf16_t*)residual; p.ldr = ldr; p.res_mod = (int)res_row_mod;
   p.act = act; p.alpha = alpha; p.out_f32 = (out_dtype == SLAM_F32); p.accumulate = accumulate;
+  p.group_m = g_gemm_group_m;
   hipStream_t s = (hipStream_t)stream;
   int cfg = g_gemm_cfg;
   if (cfg == 0) {
