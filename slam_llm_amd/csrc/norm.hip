@@ -12,7 +12,11 @@
 namespace {
 
 constexpr int ROWS_PER_BLOCK = 4;
+template <bool CACHE> struct RowUnroll { static constexpr int N = CACHE ? 8 : 1; };
 
+// CACHE: the row (d <= 4096 -> at most 8 16-byte chunks per lane) stays in registers between the passes instead of being
+// re-read from L1/L2: one global load per element, half the load instructions (rmsnorm bwd 90 -> ~70 us on 11780 x 4096).
+template <bool CACHE>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b,
@@ -24,16 +28,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   if (row >= M) return;
   const bf16_t* xr = x + (int64_t)row * ldx;
   const int nch = d >> 3;
+  u16x8_t xc[CACHE ? 8 : 1];
   float s = 0.f;
-  for (int c = lane; c < nch; c += 64) {
+#pragma unroll RowUnroll<CACHE>::N
+  for (int i = 0; i < (CACHE ? 8 : (nch + 63) / 64); i++) {
+    const int c = lane + i * 64;
+    if (c >= nch) break;
     const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+    if constexpr (CACHE) xc[i] = v;
 #pragma unroll
     for (int e = 0; e < 8; e++) s += bf2f(v[e]);
   }
   const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
-  for (int c = lane; c < nch; c += 64) {
-    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+#pragma unroll RowUnroll<CACHE>::N
+  for (int i = 0; i < (CACHE ? 8 : (nch + 63) / 64); i++) {
+    const int c = lane + i * 64;
+    if (c >= nch) break;
+    const u16x8_t v = CACHE ? xc[CACHE ? i : 0] : *reinterpret_cast<const u16x8_t*>(xr + c * 8);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const float t = bf2f(v[e]) - mean;
@@ -46,8 +58,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     rstd_out[row] = rstd;
   }
   bf16_t* yr = y + (int64_t)row * ldy;
-  for (int c = lane; c < nch; c += 64) {
-    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+#pragma unroll RowUnroll<CACHE>::N
+  for (int i = 0; i < (CACHE ? 8 : (nch + 63) / 64); i++) {
+    const int c = lane + i * 64;
+    if (c >= nch) break;
+    const u16x8_t v = CACHE ? xc[CACHE ? i : 0] : *reinterpret_cast<const u16x8_t*>(xr + c * 8);
     const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8);
     const float4 w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
     const float4 b0 = *reinterpret_cast<const float4*>(b + c * 8);
@@ -65,6 +80,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   }
 }
 
+template <bool CACHE>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, int64_t ldx,
                                                           const float* __restrict__ w,
                                                           bf16_t* __restrict__ y, int64_t ldy,
@@ -75,9 +91,14 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
   if (row >= M) return;
   const bf16_t* xr = x + (int64_t)row * ldx;
   const int nch = d >> 3;
+  u16x8_t xc[CACHE ? 8 : 1];
   float q = 0.f;
-  for (int c = lane; c < nch; c += 64) {
+#pragma unroll RowUnroll<CACHE>::N
+  for (int i = 0; i < (CACHE ? 8 : (nch + 63) / 64); i++) {
+    const int c = lane + i * 64;
+    if (c >= nch) break;
     const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+    if constexpr (CACHE) xc[i] = v;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const float t = bf2f(v[e]);
@@ -87,8 +108,11 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
   const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
   if (lane == 0 && rstd_out) rstd_out[row] = rstd;
   bf16_t* yr = y + (int64_t)row * ldy;
-  for (int c = lane; c < nch; c += 64) {
-    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+#pragma unroll RowUnroll<CACHE>::N
+  for (int i = 0; i < (CACHE ? 8 : (nch + 63) / 64); i++) {
+    const int c = lane + i * 64;
+    if (c >= nch) break;
+    const u16x8_t v = CACHE ? xc[CACHE ? i : 0] : *reinterpret_cast<const u16x8_t*>(xr + c * 8);
     const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8);
     const float4 w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
     const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
@@ -149,6 +173,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_small_kernel(const bf16_t* __
 }
 
 // dx = rstd * (g - xhat * mean(g * xhat)) [* gscale] + dres ,  g = dy * w, xhat = x * rstd
+template <bool CACHE>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(
     const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ rstd_in,
     const float* __restrict__ w, const bf16_t* __restrict__ dy, int64_t lddy,
@@ -163,9 +188,17 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(
   const float gs = gscale ? *gscale : 1.0f;
   const int nch = d >> 3;
   float dot = 0.f;
-  for (int c = lane; c < nch; c += 64) {
+  u16x8_t xc[CACHE ? 8 : 1], gc[CACHE ? 8 : 1];
+#pragma unroll RowUnroll<CACHE>::N
+  for (int i = 0; i < (CACHE ? 8 : (nch + 63) / 64); i++) {
+    const int c = lane + i * 64;
+    if (c >= nch) break;
     const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
     const u16x8_t g = *reinterpret_cast<const u16x8_t*>(dyr + c * 8);
+    if constexpr (CACHE) {
+      xc[i] = v;
+      gc[i] = g;
+    }
     const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8);
     const float4 w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
     const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
@@ -174,9 +207,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(
   }
   const float mdot = wave_sum(dot) / (float)d;
   bf16_t* dxr = dx + (int64_t)row * lddx;
-  for (int c = lane; c < nch; c += 64) {
-    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
-    const u16x8_t g = *reinterpret_cast<const u16x8_t*>(dyr + c * 8);
+#pragma unroll RowUnroll<CACHE>::N
+  for (int i = 0; i < (CACHE ? 8 : (nch + 63) / 64); i++) {
+    const int c = lane + i * 64;
+    if (c >= nch) break;
+    const u16x8_t v = CACHE ? xc[CACHE ? i : 0] : *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+    const u16x8_t g = CACHE ? gc[CACHE ? i : 0] : *reinterpret_cast<const u16x8_t*>(dyr + c * 8);
     const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8);
     const float4 w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
     const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
@@ -293,8 +329,12 @@ extern "C" int slam_layernorm_fwd(const void* x, int64_t ldx, const float* weigh
   SLAM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0, "slam_layernorm_fwd: bad shape M=%ld d=%ld (d%%8 must be 0)", (long)M, (long)d);
   SLAM_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= d && ldy >= d, "slam_layernorm_fwd: bad leading dims");
   const unsigned grid = (unsigned)cdiv64(M, ROWS_PER_BLOCK);
-  hipLaunchKernelGGL(layernorm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                     ldx, weight, bias, (bf16_t*)y, ldy, (int)M, (int)d, eps, act, mean_out, rstd_out);
+  if (d <= 4096)
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       ldx, weight, bias, (bf16_t*)y, ldy, (int)M, (int)d, eps, act, mean_out, rstd_out);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       ldx, weight, bias, (bf16_t*)y, ldy, (int)M, (int)d, eps, act, mean_out, rstd_out);
   SLAM_CHECK_LAUNCH("slam_layernorm_fwd");
   return 0;
 }
@@ -309,8 +349,8 @@ extern "C" int slam_rmsnorm_fwd(const void* x, int64_t ldx, const float* weight,
     hipLaunchKernelGGL(rmsnorm_fwd_small_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x, ldx, weight, (bf16_t*)y, ldy, rstd, (int)d, eps);
   else
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, ldx, weight, (bf16_t*)y, ldy, rstd, (int)M, (int)d, eps);
+    hipLaunchKernelGGL(d <= 4096 ? rmsnorm_fwd_kernel<true> : rmsnorm_fwd_kernel<false>, dim3(grid), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)x, ldx, weight, (bf16_t*)y, ldy, rstd, (int)M, (int)d, eps);
   SLAM_CHECK_LAUNCH("slam_rmsnorm_fwd");
   return 0;
 }
@@ -324,7 +364,7 @@ extern "C" int slam_rmsnorm_bwd(const void* x, int64_t ldx, const float* rstd, c
   SLAM_CHECK_ARG(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && (!dres || lddres % 8 == 0),
                  "slam_rmsnorm_bwd: leading dims must be multiples of 8");
   const unsigned grid = (unsigned)cdiv64(M, ROWS_PER_BLOCK);
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(d <= 4096 ? rmsnorm_bwd_kernel<true> : rmsnorm_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, ldx, rstd, weight, (const bf16_t*)dy, lddy, (const bf16_t*)dres,
                      lddres, (bf16_t*)dx, lddx, grad_scale, (int)M, (int)d);
   SLAM_CHECK_LAUNCH("slam_rmsnorm_bwd");
