@@ -46,13 +46,28 @@ __global__ __launch_bounds__(256) void head_rope_transpose_kernel(
         const int pp = positions ? positions[(int64_t)b * T + t] : t;
         const float* cp = cosT + (int64_t)pp * (D / 2) + c * 8;
         const float* sp = sinT + (int64_t)pp * (D / 2) + c * 8;
+        // 4 x 16-byte table loads (rows are 256-byte aligned): scalar cp[e] / sp[e] reads made this kernel load-issue bound
+        const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+        const float cs8[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const float sn8[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        float r1[8], r2[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          const float cs = cp[e], sn = sp[e] * sin_sign;
+          const float cs = cs8[e], sn = sn8[e] * sin_sign;
           const float a = bf2f(x1[e]), bb = bf2f(x2[e]);
-          y1[e] = f2bf(a * cs - bb * sn);
-          y2[e] = f2bf(bb * cs + a * sn);
+          r1[e] = a * cs - bb * sn;
+          r2[e] = bb * cs + a * sn;
         }
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        u32x4_t w1, w2;   // hardware round-to-nearest-even packs (v_cvt_pk_bf16_f32)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          w1[e] = pack2bf(r1[2 * e], r1[2 * e + 1]);
+          w2[e] = pack2bf(r2[2 * e], r2[2 * e + 1]);
+        }
+        y1 = __builtin_bit_cast(u16x8_t, w1);
+        y2 = __builtin_bit_cast(u16x8_t, w2);
         *reinterpret_cast<u16x8_t*>(p + c * 8) = y1;
         *reinterpret_cast<u16x8_t*>(p + D / 2 + c * 8) = y2;
       } else {
