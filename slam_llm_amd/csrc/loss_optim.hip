@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void skinny_gram_reduce_kernel(const float* __
   const int64_t total = (int64_t)R * C;
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     float s = 0.f;
+#pragma unroll 8   // the partial loads are independent: keep 8 in flight (the adds stay in fixed order)
     for (int k = 0; k < nsplit; k++) s += ws[(int64_t)k * total + i];
     const int r = (int)(i / C), c = (int)(i % C);
     float* o = out + r * ld_r + c * ld_c;
@@ -376,16 +377,17 @@ __global__ __launch_bounds__(256) void skinny_gram_reduce_kernel(const float* __
 // recomputed in registers, so x is read once and no dropout(x) copy is ever written.
 // ------------------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(256) void lora_a_fwd_kernel(const bf16_t* __restrict__ X, int64_t ldx,
+__global__ __launch_bounds__((NT <= 2 ? 8 : 4) * 64) void lora_a_fwd_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                          const bf16_t* __restrict__ A, int64_t lda,
                                                          bf16_t* __restrict__ U, int64_t ldu, int M, int R, int K,
                                                          unsigned thresh16, float inv_keep, unsigned long long seed,
                                                          unsigned long long offset) {
-  __shared__ float red[4][2 * NT][256 + 4];
+  constexpr int NWV = NT <= 2 ? 8 : 4;   // waves splitting K (8 when the LDS reduction buffer allows: more loads in flight)
+  __shared__ float red[NWV][2 * NT][256 + 4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * 32;
-  const int kw = (int)(((K / 64 + 3) / 4) * 64);
+  const int kw = (int)(((K / 64 + NWV - 1) / NWV) * 64);
   const int k_begin = wave * kw, k_end = min(K, k_begin + kw);
   int mrow[2];
   const bf16_t* xp[2];
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256) void lora_a_fwd_kernel(const bf16_t* __restric
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) *reinterpret_cast<f32x4_t*>(&red[wave][mt * NT + nt][lane * 4]) = acc[mt][nt];
   __syncthreads();
-  for (int idx = tid; idx < 32 * NT * 4; idx += 256) {   // (row, 4 consecutive ranks)
+  for (int idx = tid; idx < 32 * NT * 4; idx += NWV * 64) {   // (row, 4 consecutive ranks)
     const int row = idx / (NT * 4), jq = idx % (NT * 4);
     const int mt = row >> 4, rr = row & 15, nt = jq >> 2, gg = jq & 3;
     const int m = m0 + row, j = nt * 16 + gg * 4;
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256) void lora_a_fwd_kernel(const bf16_t* __restric
     const int src = (gg * 16 + rr) * 4;
     f32x4_t v = *reinterpret_cast<const f32x4_t*>(&red[0][mt * NT + nt][src]);
 #pragma unroll
-    for (int w = 1; w < 4; w++) {
+    for (int w = 1; w < NWV; w++) {
       const f32x4_t t = *reinterpret_cast<const f32x4_t*>(&red[w][mt * NT + nt][src]);
 #pragma unroll
       for (int i = 0; i < 4; i++) v[i] += t[i];
@@ -475,7 +477,7 @@ extern "C" int slam_lora_a_fwd(const void* X, int64_t ldx, const void* A, int64_
   dim3 grid((unsigned)cdiv64(M, 32));
   hipStream_t s = (hipStream_t)stream;
   const int nt = (int)cdiv64(R, 16);
-#define SLAM_LAUNCH_LA(NT_) hipLaunchKernelGGL(lora_a_fwd_kernel<NT_>, grid, dim3(256), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)A, lda, \
+#define SLAM_LAUNCH_LA(NT_) hipLaunchKernelGGL(lora_a_fwd_kernel<NT_>, grid, dim3((NT_ <= 2 ? 8 : 4) * 64), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)A, lda, \
                                               (bf16_t*)U, ldu, (int)M, (int)R, (int)K, th, inv_keep, (unsigned long long)seed, (unsigned long long)offset)
   if (nt == 1) SLAM_LAUNCH_LA(1);
   else if (nt == 2) SLAM_LAUNCH_LA(2);
