@@ -20,3 +20,7 @@ us = t(lambda: ops.rmsnorm_bwd(x, rstd, w, dy, dres=dres, out=dx)); print(f"rmsn
 M2, d2 = 46500, 1280
 x2 = torch.randn(M2, d2, device=dev).to(torch.bfloat16); w2 = torch.randn(d2, device=dev); b2 = torch.randn(d2, device=dev)
 us = t(lambda: ops.layernorm(x2, w2, b2, 1e-5)); print(f"layernorm {us:.1f} us {2 * M2 * d2 * 2 / us / 1e6:.2f} TB/s")
+F_ = 14336
+gu = torch.randn(M, 2 * F_, device=dev).to(torch.bfloat16); hh = torch.empty(M, F_, device=dev, dtype=torch.bfloat16); dgu = torch.empty_like(gu)
+us = t(lambda: ops.swiglu_fwd(gu, out=hh)); print(f"swiglu_fwd {us:.1f} us {3 * M * F_ * 2 / us / 1e6:.2f} TB/s")
+us = t(lambda: ops.swiglu_bwd(gu, hh, out=dgu)); print(f"swiglu_bwd {us:.1f} us {5 * M * F_ * 2 / us / 1e6:.2f} TB/s")
