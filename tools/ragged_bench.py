@@ -41,7 +41,7 @@ def main():
         audio_s = sum(float(b["audio_len"].sum()) / 16000 for b in batches)
         tokens = sum(int(b["attention_mask"].sum()) for b in batches)
         padded = sum(b["attention_mask"].numel() for b in batches)
-        for b in batches[:2]:
+        for b in batches:        # one untimed pass over every batch shape (allocator, RoPE tables, kernel caches warm)
             train_step(model, b, opt)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
