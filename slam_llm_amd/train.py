@@ -46,7 +46,13 @@ class GradSync:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.done = 0
         self.handles = []
-        self.avg_native = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        # ncclAvg needs (R)CCL >= 2.10; otherwise (and on gloo) sum and scale after the wait
+        self.avg_native = False
+        if dist.is_initialized() and dist.get_backend(group) == "nccl":
+            try:
+                self.avg_native = tuple(torch.cuda.nccl.version()[:2]) >= (2, 10)
+            except Exception:  # noqa: BLE001  (version query unavailable: stay on the always-valid SUM path)
+                self.avg_native = False
 
     def attach(self, model):
         model.grad_hooks.append(self.on_prefix)
