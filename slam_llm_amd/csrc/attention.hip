@@ -107,7 +107,8 @@ constexpr float LN2 = 0.6931471805599453f;
 // ------------------------------------------------------------------------------------------
 // forward: 4 waves x 32 query rows per workgroup, 64-key K / V^T tiles staged through LDS
 // ------------------------------------------------------------------------------------------
-template <int D, bool CAUSAL>
+// QF = 16-row query fragments per wave (2: 128-query workgroups; 1: 64-query workgroups, fewer VGPRs -> more waves per SIMD)
+template <int D, bool CAUSAL, int QF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
@@ -125,11 +126,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.Hq / p.Hkv);
   const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
-  const int qb0 = blockIdx.x * 128, qw0 = qb0 + wave * 32;
+  constexpr int QW = 16 * QF;   // query rows per wave
+  const int qb0 = blockIdx.x * (4 * QW), qw0 = qb0 + wave * QW;
 
-  frag_t qf[2][KD];
+  frag_t qf[QF][KD];
 #pragma unroll
-  for (int f = 0; f < 2; f++) {
+  for (int f = 0; f < QF; f++) {
     const int q = qw0 + f * 16 + li;
 #pragma unroll
     for (int kd = 0; kd < KD; kd++) {
@@ -137,25 +139,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                           : zero_frag();
     }
   }
-  f32x4_t o[2][DF];
+  f32x4_t o[QF][DF];
 #pragma unroll
-  for (int f = 0; f < 2; f++)
+  for (int f = 0; f < QF; f++)
 #pragma unroll
     for (int df = 0; df < DF; df++) o[f][df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float mrow[2] = {-INFINITY, -INFINITY};
-  float lrow[2] = {0.f, 0.f};
+  float mrow[QF], lrow[QF];
+#pragma unroll
+  for (int f = 0; f < QF; f++) {
+    mrow[f] = -INFINITY;
+    lrow[f] = 0.f;
+  }
 
-  const int kend = CAUSAL ? min(Tk, qb0 + 128) : Tk;
+  const int kend = CAUSAL ? min(Tk, qb0 + 4 * QW) : Tk;
   const int ntiles = (kend + 63) / 64;
   const float sl2 = p.scale * LOG2E;
   // packed batches: keys before the start of the tile's first sequence are never visible -> start there
   const int tbeg = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(qb0, Tq - 1)] / 64 : 0;
-  int qlo[2] = {0, 0};
+  int qlo[QF];
+#pragma unroll
+  for (int f = 0; f < QF; f++) qlo[f] = 0;
   int lo_wave_max = 0;   // largest sequence start among this wave's 32 queries
   if (p.seg_lo) {
 #pragma unroll
-    for (int f = 0; f < 2; f++) qlo[f] = p.seg_lo[(int64_t)b * Tq + min(qw0 + f * 16 + li, Tq - 1)];
-    lo_wave_max = p.seg_lo[(int64_t)b * Tq + min(qw0 + 31, Tq - 1)];
+    for (int f = 0; f < QF; f++) qlo[f] = p.seg_lo[(int64_t)b * Tq + min(qw0 + f * 16 + li, Tq - 1)];
+    lo_wave_max = p.seg_lo[(int64_t)b * Tq + min(qw0 + QW - 1, Tq - 1)];
   }
 
   frag_t kreg[KI], vreg[VI];
@@ -197,10 +205,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     lstore();
     __syncthreads();
     if (it + 1 < ntiles) gload(k0 + 64);
-    if (CAUSAL && k0 > qw0 + 31) continue;  // whole tile is in this wave's future
+    if (CAUSAL && k0 > qw0 + QW - 1) continue;  // whole tile is in this wave's future
 
     // ---- S^T = K . Q^T ----
-    f32x4_t s[2][4];
+    f32x4_t s[QF][4];
 #pragma unroll
     for (int kf = 0; kf < 4; kf++) {
       frag_t kfr[KD];
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       for (int kd = 0; kd < KD; kd++)
         kfr[kd] = *reinterpret_cast<const frag_t*>(ldsK + row * KROWB + (((kd * 4 + g) ^ (row & KCM)) << 4));
 #pragma unroll
-      for (int f = 0; f < 2; f++) {
+      for (int f = 0; f < QF; f++) {
         f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kd = 0; kd < KD; kd++) a = mfma16(kfr[kd], qf[f][kd], a);
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     const bool tile_full = (p.kmask == nullptr) && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0;
     if (tile_full) {
 #pragma unroll
-      for (int f = 0; f < 2; f++) {
+      for (int f = 0; f < QF; f++) {
         float mt = s[f][0][0];
 #pragma unroll
         for (int kf = 0; kf < 4; kf++)
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         for (int r = 0; r < 4; r++) kv[kf][r] = ((mk >> (8 * r)) & 0xffu) != 0 && (kb + r) < Tk;
       }
 #pragma unroll
-      for (int f = 0; f < 2; f++) {
+      for (int f = 0; f < QF; f++) {
         const int q = qw0 + f * 16 + li;
         float mt = -INFINITY;
 #pragma unroll
@@ -296,9 +304,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     // ---- O^T += V^T . P^T ----
 #pragma unroll
     for (int a = 0; a < 2; a++) {
-      frag_t pb[2];
+      frag_t pb[QF];
 #pragma unroll
-      for (int f = 0; f < 2; f++) pb[f] = pack_frag(s[f][2 * a], s[f][2 * a + 1]);
+      for (int f = 0; f < QF; f++) pb[f] = pack_frag(s[f][2 * a], s[f][2 * a + 1]);
 #pragma unroll
       for (int df = 0; df < DF; df++) {
         const int d = df * 16 + li;
@@ -308,14 +316,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         const u16x4_t hi = *reinterpret_cast<const u16x4_t*>(ldsV + d * 128 + (((c0 + 2) ^ sw) << 4) + (g & 1) * 8);
         const frag_t vf = join_frag(lo, hi);
 #pragma unroll
-        for (int f = 0; f < 2; f++) o[f][df] = mfma16(vf, pb[f], o[f][df]);
+        for (int f = 0; f < QF; f++) o[f][df] = mfma16(vf, pb[f], o[f][df]);
       }
     }
   }
 
   // ---- epilogue ----
 #pragma unroll
-  for (int f = 0; f < 2; f++) {
+  for (int f = 0; f < QF; f++) {
     float lt = lrow[f];
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
@@ -672,6 +680,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   }
 }
 
+int g_attn_fwd_qf = 0;   // 16-row query fragments per wave of the forward kernel: 0 = auto, 1 / 2 forced (tools)
+
 int check_common(const char* name, int64_t B, int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv,
                  int64_t D, int causal) {
   SLAM_CHECK_ARG(D == 64 || D == 128, "%s: head_dim %ld unsupported (64|128)", name, (long)D);
@@ -684,6 +694,12 @@ int check_common(const char* name, int64_t B, int64_t Tq, int64_t Tk, int64_t Tq
 }
 
 }  // namespace
+
+extern "C" int slam_attn_set_fwd_qf(int qf) {
+  SLAM_CHECK_ARG(qf >= 0 && qf <= 2, "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2)", qf);
+  g_attn_fwd_qf = qf;
+  return 0;
+}
 
 extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt,
                              void* O, int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B,
@@ -698,14 +714,17 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = LSE; p.kmask = key_mask;
   p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
   p.seg_lo = seg_lo;
-  dim3 grid((unsigned)cdiv64(Tq, 128), (unsigned)Hq, (unsigned)B);
   hipStream_t s = (hipStream_t)stream;
+  // measured (tools/attn_bwd_bench.py, tools/attn_one.py): D = 128 with two fragments needs 261 VGPRs = one wave per SIMD,
+  // one fragment (171 VGPRs, two waves) is 13 % faster at the Llama shape; D = 64 (182 vs 120 VGPRs) prefers two (+5 %)
+  const int qf = g_attn_fwd_qf ? g_attn_fwd_qf : (D == 128 ? 1 : 2);
+  dim3 grid((unsigned)cdiv64(Tq, 64 * qf), (unsigned)Hq, (unsigned)B);
   if (D == 64) {
-    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), 0, s, p);
+    if (causal) { if (qf == 2) hipLaunchKernelGGL((attn_fwd_kernel<64, true, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_fwd_kernel<64, true, 1>), grid, dim3(256), 0, s, p); }
+    else { if (qf == 2) hipLaunchKernelGGL((attn_fwd_kernel<64, false, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_fwd_kernel<64, false, 1>), grid, dim3(256), 0, s, p); }
   } else {
-    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, dim3(256), 0, s, p);
+    if (causal) { if (qf == 2) hipLaunchKernelGGL((attn_fwd_kernel<128, true, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_fwd_kernel<128, true, 1>), grid, dim3(256), 0, s, p); }
+    else { if (qf == 2) hipLaunchKernelGGL((attn_fwd_kernel<128, false, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_fwd_kernel<128, false, 1>), grid, dim3(256), 0, s, p); }
   }
   SLAM_CHECK_LAUNCH("slam_attn_fwd");
   return 0;

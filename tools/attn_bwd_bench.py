@@ -46,3 +46,18 @@ for name, f, flops in (("fwd", fwd, 4.0 * B * Hq * T * T * D * 0.5), ("bwd", bwd
     torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1e3 / 20
     print(f"{name}: {us:.1f} us  {flops / us / 1e6:.1f} TF", flush=True)
+
+from slam_llm_amd.lib import call  # noqa: E402
+call("slam_attn_set_fwd_qf", 1)
+for _ in range(3):
+    fwd()
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(20):
+    fwd()
+e.record()
+torch.cuda.synchronize()
+us = s.elapsed_time(e) * 1e3 / 20
+print(f"fwd QF=1: {us:.1f} us  {4.0 * B * Hq * T * T * D * 0.5 / us / 1e6:.1f} TF", flush=True)
+call("slam_attn_set_fwd_qf", 0)

@@ -21,3 +21,18 @@ for rnd in range(3):
     torch.cuda.synchronize()
     best = min(best, s.elapsed_time(e) * 100)
 print(f"whisper attn fwd: {best:.1f} us  {4.0 * B * H * T * T * D / best / 1e6:.1f} TF")
+from slam_llm_amd.lib import call
+call("slam_attn_set_fwd_qf", 1)
+for _ in range(3):
+    f()
+torch.cuda.synchronize()
+best = 1e9
+for rnd in range(3):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10):
+        f()
+    e.record()
+    torch.cuda.synchronize()
+    best = min(best, s.elapsed_time(e) * 100)
+print(f"whisper attn fwd QF=1: {best:.1f} us  {4.0 * B * H * T * T * D / best / 1e6:.1f} TF")
