@@ -1,76 +1,151 @@
 #!/usr/bin/env python
 """Headline benchmark: audio-seconds/sec for the Whisper-large-v3 -> Llama-3-8B LoRA training step on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 via torch.distributed.run, one rank per GPU);
-W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize, MAX over ranks, rank 0 prints ONE JSON
-line.  A "step" = one full optimizer step of the hot path on one dynamic-frame batch of synthetic input that is
-already resident in HBM: GPU log-mel -> Whisper encoder -> projector -> embed/splice -> Llama-3-8B (+LoRA) forward
--> CE/accuracy -> backward -> (N>1: RCCL all-reduce of the flat gradient buffer) -> fused AdamW + LR scheduler.
+Contract: `python bench.py --gpus N --steps K --warmup W`; W untimed steps, then EXACTLY K steps bracketed by
+barrier + synchronize, MAX over ranks, rank 0 prints ONE JSON line.  N > 1: one rank per GPU over RCCL; when the
+script is started WITHOUT a torchrun environment it re-launches itself under `python -m torch.distributed.run
+--nproc-per-node N` (rendezvous on 127.0.0.1); when fewer than N GPUs are visible the ranks share devices over gloo
+(functional check of the N > 1 path on a 1-GPU box; the JSON line says so in `backend`).
 
-Workload (BASELINE.json configs[2] / SURVEY.md 8d "C3", which fits one GPU): 31 clips x 30 s per GPU
-(31 x T=380 = 11 780 <= max_frame_length 12 000: the reference's window_class admits 31 and refuses the 32nd),
-prompt 16 + answer 64 tokens, LoRA r=16 alpha=32 on q_proj,v_proj, bf16 frozen weights, fp32 trainable masters.
+A "step" = one full optimizer step of the hot path on one batch of synthetic input already resident in HBM:
+GPU log-mel -> Whisper encoder -> projector -> embed/splice -> Llama-3-8B (+LoRA) forward -> CE/accuracy -> backward ->
+(N>1: all-reduce of the flat gradient buffer, overlapped with the backward) -> fused AdamW + LR scheduler.
+
+Workloads (BASELINE.json `configs`):
+  c3 (default, the headline): configs[2], Whisper-large-v3 -> Llama-3-8B, linear projector, LoRA r16 (q,v), 31 x 30 s clips per
+      GPU (31 x T=380 = 11 780 <= max_frame_length 12 000: the reference's window_class admits 31 and refuses the 32nd);
+  c1: configs[0], Whisper-tiny -> TinyLlama-1.1B, LoRA r8, 1 x 10 s clip (padded to 30 s by the recipe; plumbing-sized);
+  c2: configs[1], Whisper-base -> Llama-3-8B, LoRA r16, batch 8 x 30 s;
+  c4: configs[3], HuBERT-large -> Vicuna-7B, Q-Former (32 queries, 8 layers), LoRA r32, batch 6 x 30 s raw waveforms.
 Weak scaling: per-GPU work is fixed as N grows; no data-path collective except the gradient all-reduce.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
-CLIP_SECONDS, N_CLIPS, PROMPT, ANSWER = 30.0, 31, 16, 64
+CLIP_SECONDS, PROMPT, ANSWER = 30.0, 16, 64
+
+WORKLOADS = {
+    "c1": dict(title="C1", clips=1, clip_seconds=10.0,
+               model=dict(encoder_name="whisper", encoder_path="tiny.pt", llm_name="tinyllama-1.1b", encoder_dim=384, llm_dim=2048,
+                          encoder_projector="linear", encoder_projector_ds_rate=5),
+               peft=dict(r=8, lora_alpha=32, target_modules=["q_proj", "v_proj"], lora_dropout=0.05)),
+    "c3": dict(title="C3", clips=31, model=dict(encoder_name="whisper", encoder_path="large-v3.pt", llm_name="llama-3-8b", encoder_dim=1280,
+                                                 encoder_projector="linear", encoder_projector_ds_rate=5),
+               peft=dict(r=16, lora_alpha=32, target_modules=["q_proj", "v_proj"], lora_dropout=0.05)),
+    "c2": dict(title="C2", clips=8, model=dict(encoder_name="whisper", encoder_path="base.pt", llm_name="llama-3-8b", encoder_dim=512,
+                                                encoder_projector="linear", encoder_projector_ds_rate=5),
+               peft=dict(r=16, lora_alpha=32, target_modules=["q_proj", "v_proj"], lora_dropout=0.05)),
+    "c4": dict(title="C4", clips=6, model=dict(encoder_name="hubert", encoder_path="hubert_large_ll60k.pt", llm_name="vicuna-7b-v1.5",
+                                                encoder_dim=1024, encoder_projector="q-former", qformer_layers=8, query_len=32),
+               peft=dict(r=32, lora_alpha=32, target_modules=["q_proj", "v_proj"], lora_dropout=0.05)),
+}
 
 
 def algorithmic_flops_per_clip(cfg, T, Ta, n_frames):
     """SURVEY.md 8(d) FLOP model (pads and recomputation never count)."""
-    de, Le, nm = cfg["enc_dim"], cfg["enc_layers"], cfg["n_mels"]
     d, L, V = cfg["llm_dim"], cfg["llm_layers"], cfg["vocab"]
     dkv = cfg["llm_kv_heads"] * cfg["llm_head_dim"]
-    Te = (n_frames + 1) // 2
-    f_enc = Le * (24 * Te * de * de + 4 * Te * Te * de) + 2 * 3 * n_frames * nm * de + 2 * 3 * Te * de * de
-    f_proj = 3 * 2 * Ta * (cfg["ds_rate"] * de * cfg["proj_hidden"] + cfg["proj_hidden"] * d)
+    if cfg.get("encoder_name") == "hubert":
+        # same counting rules applied to the HuBERT graph: conv stack, feature projection, grouped positional
+        # conv, L_e pre-LN layers; Q-Former: self-attn over Q queries every layer, cross-attn (K/V projections over the T_e
+        # encoder frames) every 2nd layer, FFN, output Linear -- forward + dX + dW = x3 (trainable)
+        de, Le = cfg["hub_dim"], cfg["hub_layers"]
+        n, cin, f_conv = 480000, 1, 0
+        for co, k, s_ in zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"], cfg["hub_conv_stride"]):
+            n = (n - k) // s_ + 1
+            f_conv += 2 * n * k * cin * co
+            cin = co
+        Te = n
+        f_enc = (f_conv + 2 * Te * cin * de + 2 * Te * de * cfg["hub_pos_k"] * (de // cfg["hub_pos_groups"])
+                 + Le * (2 * Te * (4 * de * de + 2 * de * cfg["hub_ffn"]) + 4 * Te * Te * de))
+        dq, Q, Lq, Fq = cfg["qf_dim"], cfg["qf_queries"], cfg["qf_layers"], cfg["qf_ffn"]
+        n_cross = (Lq + cfg["qf_cross_freq"] - 1) // cfg["qf_cross_freq"]
+        f_q = Lq * (2 * Q * 4 * dq * dq + 4 * Q * Q * dq + 2 * Q * 2 * dq * Fq)
+        f_q += n_cross * (2 * Q * 2 * dq * dq + 2 * Te * 2 * de * dq + 4 * Q * Te * dq)
+        f_proj = 3 * (f_q + 2 * Q * dq * d)
+        f_mel = 0
+    else:
+        de, Le, nm = cfg["enc_dim"], cfg["enc_layers"], cfg["n_mels"]
+        Te = (n_frames + 1) // 2
+        f_enc = Le * (24 * Te * de * de + 4 * Te * Te * de) + 2 * 3 * n_frames * nm * de + 2 * 3 * Te * de * de
+        f_proj = 3 * 2 * Ta * (cfg["ds_rate"] * de * cfg["proj_hidden"] + cfg["proj_hidden"] * d)
+        f_mel = n_frames * (2 * 400 * 402 + 2 * 201 * nm)
     p_mm = L * (d * (d + 2 * dkv + d) + 3 * d * cfg["llm_ffn"]) + V * d
     f_llm = 2 * (2 * T * p_mm + L * 2 * T * T * d)
     tgt = {"q_proj": d + d, "k_proj": d + dkv, "v_proj": d + dkv, "o_proj": d + d}
     f_lora = 3 * 2 * T * cfg["lora_r"] * sum(tgt[t] for t in cfg["lora_targets"]) * L
-    f_mel = n_frames * (2 * 400 * 402 + 2 * 201 * nm)
     return dict(enc=f_enc, proj=f_proj, llm=f_llm, lora=f_lora, mel=f_mel, total=f_enc + f_proj + f_llm + f_lora + f_mel)
 
 
-def make_batch(cfg, dev, seed):
+def audio_tokens(cfg):
+    if cfg.get("projector") == "q-former":
+        return cfg["qf_queries"]          # fix_length_audio == query_len (SURVEY a3')
+    if cfg.get("encoder_name") == "hubert":
+        return 480000 // 320 // 5         # speech_dataset.py:98-99
+    return ((3000 + 1) // 2) // cfg["ds_rate"]
+
+
+def make_batch(cfg, n_clips, dev, seed, clip_seconds=CLIP_SECONDS):
     """synthetic batch in the reference's dict layout (speech_dataset_large.py:180-233 collator)."""
+    import torch
     g = torch.Generator(device=dev).manual_seed(seed)
-    audio = (torch.randn(N_CLIPS, int(CLIP_SECONDS * 16000), generator=g, device=dev) * 0.1).clamp_(-1, 1)
-    Ta = ((3000 + 1) // 2) // cfg["ds_rate"]
+    audio = (torch.randn(n_clips, int(clip_seconds * 16000), generator=g, device=dev) * 0.1).clamp_(-1, 1)
+    if cfg.get("encoder_name") == "hubert":   # dataset_config.normalize (speech_dataset.py:96-97)
+        audio = torch.nn.functional.layer_norm(audio, (audio.shape[1],))
+    Ta = audio_tokens(cfg)
     T = Ta + PROMPT + ANSWER
-    ids = torch.randint(3, cfg["vocab"], (N_CLIPS, T), generator=g, device=dev, dtype=torch.int64)
+    ids = torch.randint(3, cfg["vocab"], (n_clips, T), generator=g, device=dev, dtype=torch.int64)
     ids[:, :Ta] = -1
     ids[:, -1] = 2  # eos
     labels = ids.clone()
     labels[:, : Ta + PROMPT] = -100
-    mm = torch.zeros((N_CLIPS, T), dtype=torch.bool, device=dev)
+    mm = torch.zeros((n_clips, T), dtype=torch.bool, device=dev)
     mm[:, :Ta] = True
-    return dict(input_ids=ids, labels=labels, attention_mask=torch.ones((N_CLIPS, T), dtype=torch.bool, device=dev),
+    return dict(input_ids=ids, labels=labels, attention_mask=torch.ones((n_clips, T), dtype=torch.bool, device=dev),
                 modality_mask=mm, audio=audio), T, Ta
 
 
-def cpu_baseline(cfg):
-    """Oracle (CPU restatement of the reference path, fp32, torch.optim.AdamW) timed on the host cores on a BOUNDED
-    sample of the same workload: 1 clip x 30 s at the true layer dimensions with (1,1) and (2,2) encoder/LLM layers,
-    extrapolated linearly to the full 32 + 32 layers (BASELINE.md 2.1 prescribes exactly this when the full 8B fp32
-    model is too slow/large for the host)."""
+def physical_cores():
+    """(sockets x cores) from /proc/cpuinfo; falls back to os.cpu_count()"""
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or os.cpu_count()
+    except OSError:
+        return os.cpu_count()
+
+
+def cpu_baseline(cfg, n_warm=1, n_meas=3):
+    """The CPU leg: the oracle -- the fp32 restatement of the reference path, pinned to the reference by
+    tests/golden/ (kind "port"; /root/reference itself is not present on the GPU box) -- timed on the host cores on a
+    BOUNDED sample of the same workload: ONE 30 s clip at the true layer dimensions, with the encoder / LLM depth reduced
+    to (2,2), (4,2) and (2,4) layers; each point = median of 3 optimizer steps after 1 warm-up; the per-layer costs are
+    solved from the three points and extrapolated linearly to the full depth."""
+    import torch
     from oracle import slam_oracle as O
-    # pick the host thread count that actually runs torch's CPU GEMM fastest (256 threads on M=380 rows oversubscribe)
+    hub = cfg.get("encoder_name") == "hubert"
+    # pick the host thread count that actually runs torch's CPU GEMM fastest (all hardware threads oversubscribe at M=380 rows)
     a, b = torch.randn(380, 4096), torch.randn(14336, 4096)
-    best, cores = None, os.cpu_count()
-    for nt in sorted({min(os.cpu_count(), n) for n in (16, 32, 64, 128, os.cpu_count())}):
+    best, threads = None, os.cpu_count()
+    for nt in sorted({min(os.cpu_count(), n) for n in (8, 16, 32, 64, 128, os.cpu_count())}):
         torch.set_num_threads(nt)
         torch.nn.functional.linear(a, b)
         t0 = time.perf_counter()
@@ -78,23 +153,99 @@ def cpu_baseline(cfg):
             torch.nn.functional.linear(a, b)
         dt = time.perf_counter() - t0
         if best is None or dt < best:
-            best, cores = dt, nt
-    torch.set_num_threads(cores)
-    times = {}
-    for nl in (1, 2):
-        c = dict(cfg, enc_layers=nl, llm_layers=nl)
-        W = O.init_weights(c, seed=42)
+            best, threads = dt, nt
+    torch.set_num_threads(threads)
+    Le_key = "hub_layers" if hub else "enc_layers"
+    Le_full, Ll_full = cfg[Le_key], cfg["llm_layers"]
+
+    def one_point(le, ll):
+        c = dict(cfg, **{Le_key: le, "llm_layers": ll})
+        W = O.init_weights(dict(c, enc_layers=1) if hub else c, seed=42)   # (the HuBERT case replaces the encoder/projector entries below)
         audio = O.synth_audio(1, CLIP_SECONDS, seed=1234)
-        batch = O.synth_batch(c, audio, prompt_len=PROMPT, answer_lens=(ANSWER,), seed=1236, left_pad=False)
-        t0 = time.perf_counter()
-        O.train_steps(W, c, [batch], lr=1e-4)
-        times[nl] = time.perf_counter() - t0
-        del W
-    per_layer = times[2] - times[1]
-    t_full = (times[1] - per_layer) + cfg["llm_layers"] * per_layer
-    return dict(value=CLIP_SECONDS / t_full, unit="audio-seconds/sec", cores=cores, kind="port",
-                sample=(f"oracle train step (single cold step each) on 1 x 30 s clip, true dims, measured at (enc,llm) layers (1,1)={times[1]:.2f}s and "
-                        f"(2,2)={times[2]:.2f}s, extrapolated linearly to (32,32) = {t_full:.1f} s/clip"))
+        if hub:
+            W = {k: v for k, v in W.items() if not k.startswith(("encoder.", "encoder_projector."))}
+            W.update(O.init_hubert_weights(c, seed=7))
+            W.update(O.init_qformer_weights(c, c["enc_dim"], c["llm_dim"], seed=11))
+            wav = torch.nn.functional.layer_norm(audio, (audio.shape[1],))
+            Q = c["qf_queries"]
+            g = torch.Generator().manual_seed(1236)
+            s = O.make_sample(Q, torch.randint(3, c["vocab"], (PROMPT,), generator=g).tolist(),
+                              torch.randint(3, c["vocab"], (ANSWER - 1,), generator=g).tolist(), 2)
+            batch = O.collate_right_pad([s], pad_id=2)
+            names = O.trainable_names(W)
+            for n in W:
+                W[n].requires_grad_(n in names)
+            opt = torch.optim.AdamW([W[n] for n in names], lr=1e-4, weight_decay=0.0)
+
+            def step():
+                enc = O.hubert_encoder(W, c, wav)
+                proj = O.projector_qformer(W, c, enc, None)
+                emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], batch["input_ids"].clone(),
+                                     batch["modality_mask"].bool(), proj)
+                loss, _ = O.llama_forward(W, c, emb, batch["attention_mask"], batch["labels"])
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+        else:
+            batch = O.synth_batch(c, audio, prompt_len=PROMPT, answer_lens=(ANSWER,), seed=1236, left_pad=False)
+
+            def step():
+                O.train_steps(W, c, [batch], lr=1e-4)
+        ts = []
+        for i in range(n_warm + n_meas):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts[n_warm:]), ts
+
+    t22, r22 = one_point(2, 2)
+    t42, r42 = one_point(4, 2)
+    t24, r24 = one_point(2, 4)
+    b_e, b_l = (t42 - t22) / 2, (t24 - t22) / 2
+    fixed = t22 - 2 * b_e - 2 * b_l
+    t_full = fixed + Le_full * b_e + Ll_full * b_l
+    fmt = lambda r: "[" + ", ".join(f"{x:.2f}" for x in r) + "]"  # noqa: E731
+    return dict(value=CLIP_SECONDS / t_full, unit="audio-seconds/sec", cores=physical_cores(), threads=threads, host_logical_cpus=os.cpu_count(),
+                kind="port", step_seconds_full_depth=t_full,
+                raw_step_seconds={"(2,2)": r22, "(4,2)": r42, "(2,4)": r24},
+                sample=(f"oracle (CPU restatement of the reference path pinned by tests/golden; the reference itself is absent on the GPU "
+                        f"box) fp32 train step on 1 x 30 s clip at true layer dims, {threads} torch threads on {physical_cores()} physical cores; "
+                        f"median of {n_meas} steps after {n_warm} warm-up at (enc,llm) layers (2,2)={t22:.2f}s {fmt(r22)}, (4,2)={t42:.2f}s "
+                        f"{fmt(r42)}, (2,4)={t24:.2f}s {fmt(r24)}; per-layer cost enc {b_e:.3f}s llm {b_l:.3f}s, fixed {fixed:.2f}s -> "
+                        f"({Le_full},{Ll_full}) layers = {t_full:.1f} s/clip"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves."""
+    import torch
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < args.gpus:
+        env.setdefault("SLAM_DIST_BACKEND", "gloo")   # ranks share a device: RCCL cannot, gloo can (functional check)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(cmd[0], cmd, env)
+
+
+def traffic_for(kernel_name):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC summary (separate --pmc passes over this
+    same command, FETCH_SIZE with the gfx950 x2 correction; tools/pmc_traffic.py writes the file)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    table = json.load(open(path))
+    for k, v in table.get("kernels", {}).items():
+        if k in kernel_name or kernel_name.startswith(k):
+            return v, table.get("source")
+    return None, table.get("source")
 
 
 def main():
@@ -103,12 +254,19 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--encoder", default="whisper-large-v3")
-    ap.add_argument("--llm", default="llama-3-8b")
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default: the workload's)")
+    ap.add_argument("--ddp", action="store_true", help="N>1: reduce through torch DistributedDataParallel (autograd_params mode) "
+                                                      "instead of the GradSync fast path")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
+    import torch
+    import torch.distributed as dist
     from slam_llm_amd import ops
-    from slam_llm_amd.model import SlamAdamW, SlamHipModel, make_config
+    from slam_llm_amd.model import SlamAdamW, SlamHipModel
+    from slam_llm_amd.slam_model_hip import build_config
     from slam_llm_amd.train import GradSync, lr_lambda, setup_distributed, train_step
 
     rank, local_rank, world = setup_distributed("cuda")
@@ -116,19 +274,28 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = dist.get_backend() if world > 1 else None
 
     # recipe defaults (examples/asr_librispeech/asr_config.py:29-37): LoRA on q_proj,v_proj with lora_dropout 0.05 live in
-    # train mode ("dropout 0 for parity, 0.05 for throughput"); r = 16 per BASELINE.json configs[2]
-    cfg = make_config(args.encoder, args.llm, lora_r=16, lora_alpha=32, lora_targets=("q_proj", "v_proj"), lora_dropout=0.05)
-    model = SlamHipModel(cfg, dev).init_random(42)
+    # train mode ("dropout 0 for parity, 0.05 for throughput"); r per BASELINE.json
+    wl = WORKLOADS[args.workload]
+    n_clips = args.clips or wl["clips"]
+    cfg = build_config(dict(use_peft=True, peft_config=wl["peft"], seed=42), wl["model"])
+    model = SlamHipModel(cfg, dev, autograd_params=bool(args.ddp and world > 1)).init_random(42)
     model.train()
+    gsync = None
+    step_model = model
+    if world > 1 and args.ddp:
+        step_model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank] if backend == "nccl" else None)
+    elif world > 1:
+        gsync = GradSync(model).attach(model)
     opt = SlamAdamW(model, lr=1e-4, weight_decay=0.0)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: lr_lambda(s, 1000, 100000))
-    gsync = GradSync(model.store.grad).attach(model) if world > 1 else None
-    batch, T, Ta = make_batch(cfg, dev, seed=1234 + rank)
+    clip_s = wl.get("clip_seconds", CLIP_SECONDS)
+    batch, T, Ta = make_batch(cfg, n_clips, dev, seed=1234 + rank, clip_seconds=clip_s)
 
     def step():
-        return train_step(model, batch, opt, sched, gsync)
+        return train_step(step_model, batch, opt, sched, gsync)
 
     for _ in range(args.warmup):
         loss, acc = step()
@@ -155,10 +322,10 @@ def main():
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    audio_s = world * N_CLIPS * CLIP_SECONDS
+    audio_s = world * n_clips * clip_s
     value = audio_s * args.steps / elapsed
     fl = algorithmic_flops_per_clip(cfg, T, Ta, 3000)
-    step_flops = fl["total"] * N_CLIPS
+    step_flops = fl["total"] * n_clips
     ksum = timer.summary()
     gemm_all = [v for k, v in ksum.items() if k.startswith("gemm_nt")]
     gemm_ms = sum(v["total_ms"] for v in gemm_all)
@@ -167,34 +334,53 @@ def main():
     g = ksum[dom]  # the dominant kernel (largest share of the step): one template instance of the bf16 GEMM
     gemm_tf = g["work"] / (g["total_ms"] * 1e-3) / 1e12
     kern = {k: dict(launches_per_step=v["launches"] / args.steps, ms_per_step=v["total_ms"] / args.steps,
-                    avg_ms=v["avg_ms"], TFLOPs=v["work"] / (v["total_ms"] * 1e-3) / 1e12) for k, v in ksum.items()}
+                    avg_ms=v["avg_ms"], TFLOPs=v["work"] / (v["total_ms"] * 1e-3) / 1e12,
+                    **({"algorithmic_GB_per_launch": v["bytes"] / v["launches"] / 1e9} if v.get("bytes") else {}))
+            for k, v in ksum.items()}
+    traffic, traffic_src = (traffic_for(dom) if args.workload == "c3" else (None, None))
+    roof = {"bound": "mfma", "kernel": dom + " (slam_gemm_bf16_nt)", "achieved": gemm_tf,
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS, "traffic": None,
+            "avg_launch_ms": g["avg_ms"], "launches_per_step": g["launches"] / args.steps,
+            "share_of_step": g["total_ms"] / args.steps / ms_per_step,
+            "algorithmic_bytes_per_launch": g["bytes"] / g["launches"] if g.get("bytes") else None,
+            "all_gemm_instances": {"achieved": gemm_tf_all, "share_of_step": gemm_ms / args.steps / ms_per_step}}
+    if traffic is not None:
+        hbm = traffic["fetch_bytes_per_launch"] + traffic["write_bytes_per_launch"]
+        roof["traffic"] = hbm
+        roof["traffic_detail"] = dict(traffic, unit="bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)", source=traffic_src,
+                                      ratio_to_algorithmic=(hbm / roof["algorithmic_bytes_per_launch"]) if roof["algorithmic_bytes_per_launch"] else None)
+    enc_desc = {"c1": "whisper-tiny -> tinyllama-1.1b, linear projector k=5, LoRA r8",
+                "c3": "whisper-large-v3 -> llama-3-8b, linear projector k=5, LoRA r16",
+                "c2": "whisper-base -> llama-3-8b, linear projector k=5, LoRA r16",
+                "c4": "hubert-large -> vicuna-7b, Q-Former (32 queries, 8 layers), LoRA r32"}[args.workload]
     out = {
-        "metric": "audio-seconds/sec/node (Whisper-large-v3->Llama-3-8B LoRA)",
+        "metric": "audio-seconds/sec/node (Whisper-large-v3->Llama-3-8B LoRA)" if args.workload == "c3" else
+                  f"audio-seconds/sec/node ({wl['title']}: not the headline workload)",
         "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (seeded N(0,0.1^2) audio, random token ids, random-init weights at true dims)",
-        "config": {"workload": f"C3: {args.encoder} -> {args.llm}, linear projector k=5, LoRA r16 (q_proj,v_proj, dropout 0.05), dynamic-frame "
-                               f"batch {N_CLIPS} x 30 s clips per GPU (T={T}, {N_CLIPS * T} frames <= 12000), GPU log-mel in the step, "
-                               "fwd+bwd+grad all-reduce+fused AdamW",
-                   "global_batch_clips": world * N_CLIPS, "seq_len": T, "parallelism": f"dp{world}",
+        "config": {"workload": f"{wl['title']}: {enc_desc} (q_proj,v_proj, dropout 0.05), "
+                               f"batch {n_clips} x {clip_s:g} s clips per GPU (T={T}, {n_clips * T} frames"
+                               + (" <= 12000 dynamic-frame budget" if args.workload == "c3" else "") + "), "
+                               + ("GPU log-mel in the step, " if args.workload != "c4" else "raw waveform (layer-normed) in, ")
+                               + "fwd+bwd+grad all-reduce+fused AdamW",
+                   "global_batch_clips": world * n_clips, "seq_len": T, "parallelism": f"dp{world}",
+                   "grad_exchange": None if world == 1 else ("DistributedDataParallel" if args.ddp else "GradSync (flat-buffer prefixes)"),
+                   "backend": backend if backend != "nccl" else "nccl (RCCL)",
                    "logits": "full [B*T, V] lm_head computed (chunked), not materialised in fp32"},
         "loss": float(loss), "acc": float(acc),
         "model_flops_per_step_per_gpu": step_flops,
         "mfu": step_flops / (ms_per_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
-        "roofline": {"bound": "mfma", "kernel": dom + " (slam_gemm_bf16_nt)", "achieved": gemm_tf,
-                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS, "traffic": None,
-                     "avg_launch_ms": g["avg_ms"], "launches_per_step": g["launches"] / args.steps,
-                     "share_of_step": g["total_ms"] / args.steps / ms_per_step,
-                     "all_gemm_instances": {"achieved": gemm_tf_all, "share_of_step": gemm_ms / args.steps / ms_per_step}},
+        "roofline": roof,
         "kernels": kern,
     }
     if world == 1 and not args.no_cpu_baseline:
-        del model, opt, batch
+        del model, opt, batch, step_model
         torch.cuda.empty_cache()
         try:
             out["cpu_baseline"] = cpu_baseline(cfg)
         except Exception as ex:  # noqa: BLE001  (host too small etc.: report, never fake)
-            out["cpu_baseline"] = {"value": None, "unit": "audio-seconds/sec", "cores": os.cpu_count(), "kind": "port",
+            out["cpu_baseline"] = {"value": None, "unit": "audio-seconds/sec", "cores": physical_cores(), "kind": "port",
                                    "sample": f"failed: {ex!r}"}
     print(json.dumps(out), flush=True)
     if world > 1:

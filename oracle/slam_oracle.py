@@ -484,7 +484,7 @@ def _repetition_penalty(scores: torch.Tensor, history: torch.Tensor, penalty: fl
 
 
 def greedy_search(step_fn, batch_size: int, max_new_tokens: int, eos: int, pad: int, min_length: int = 1,
-                  repetition_penalty: float = 1.0):
+                  repetition_penalty: float = 1.0, trace: Optional[list] = None):
     """HF `GenerationMixin._sample` with do_sample=False (transformers/generation/utils.py), the num_beams=1 branch of
     `self.llm.generate(...)` at slam_model.py:438-452.  The prompt is inputs_embeds only, so the token history starts
     empty: MinLengthLogitsProcessor(min_length) therefore masks eos while fewer than `min_length` tokens exist.
@@ -497,6 +497,10 @@ def greedy_search(step_fn, batch_size: int, max_new_tokens: int, eos: int, pad: 
         if toks.shape[1] < min_length:
             logits[:, eos] = -float("inf")
         nxt = logits.argmax(-1)
+        if trace is not None:   # decision margins for margin-aware comparisons of a reduced-precision path (tests)
+            top2 = torch.topk(logits, 2, dim=-1)[0]
+            trace.append({"margin": torch.where(alive, top2[:, 0] - top2[:, 1], torch.full((batch_size,), float("inf"))),
+                          "scale": logits.abs().amax(-1) if not torch.isinf(logits).any() else logits.masked_fill(torch.isinf(logits), 0).abs().amax(-1)})
         nxt = torch.where(alive, nxt, torch.full_like(nxt, pad))
         toks = torch.cat([toks, nxt[:, None]], dim=1)
         alive = alive & (nxt != eos) & (toks.shape[1] < max_new_tokens)
@@ -505,7 +509,8 @@ def greedy_search(step_fn, batch_size: int, max_new_tokens: int, eos: int, pad: 
 
 
 def beam_search(step_fn, batch_size: int, num_beams: int, max_new_tokens: int, eos: int, pad: int,
-                min_length: int = 1, length_penalty: float = 1.0, repetition_penalty: float = 1.0):
+                min_length: int = 1, length_penalty: float = 1.0, repetition_penalty: float = 1.0,
+                trace: Optional[list] = None):
     """HF `GenerationMixin._beam_search` (transformers 5.x vectorised form; early_stopping=False, one eos id,
     num_return_sequences=1), restated per batch item.  Each item keeps `num_beams` running hypotheses and
     `num_beams` finished ones; every step the best 2*num_beams continuations are ranked, the non-terminated ones
@@ -538,6 +543,13 @@ def beam_search(step_fn, batch_size: int, num_beams: int, max_new_tokens: int, e
         for b in range(batch_size):
             acc = (lp_all[b * nb:(b + 1) * nb] + run_score[b][:, None]).reshape(-1)
             top_lp, top_idx = torch.topk(acc, K)
+            if trace is not None and open_[b]:
+                # every ranking decision of the step is a comparison between neighbours of the sorted top K+1 candidates
+                srt = torch.topk(acc, K + 1)[0]
+                live = srt > NEG / 2
+                gaps = (srt[:-1] - srt[1:])[live[:-1] & live[1:]]
+                trace.append({"item": b, "t": t, "margin": float(gaps.min()) if gaps.numel() else float("inf"),
+                              "scale": float(logits[b * nb:(b + 1) * nb].abs().max())})
             src, tok = top_idx // V, top_idx % V
             cand = run_seq[b][src].clone()
             cand[:, t] = tok
@@ -578,7 +590,7 @@ def generate_position_ids(attention_mask: torch.Tensor) -> torch.Tensor:
 
 
 def slam_generate(W, cfg, batch: dict, max_new_tokens=200, num_beams=4, min_length=1, length_penalty=1.0,
-                  eos=2, pad=0, repetition_penalty=1.0):
+                  eos=2, pad=0, repetition_penalty=1.0, trace: Optional[list] = None):
     """slam_model.generate (src/slam_llm/models/slam_model.py:409-456): forward(..., inference_mode=True) returns
     (inputs_embeds, attention_mask) [slam_model.py:394-395], then `self.llm.generate(inputs_embeds=...,
     attention_mask=..., num_beams, max_new_tokens, min_length, length_penalty, eos/pad ids)`.  do_sample=False,
@@ -602,8 +614,8 @@ def slam_generate(W, cfg, batch: dict, max_new_tokens=200, num_beams=4, min_leng
         return logits[:, -1, :]
 
     if num_beams == 1:
-        return greedy_search(step_fn, B, max_new_tokens, eos, pad, min_length, repetition_penalty)
-    return beam_search(step_fn, B, num_beams, max_new_tokens, eos, pad, min_length, length_penalty, repetition_penalty)
+        return greedy_search(step_fn, B, max_new_tokens, eos, pad, min_length, repetition_penalty, trace)
+    return beam_search(step_fn, B, num_beams, max_new_tokens, eos, pad, min_length, length_penalty, repetition_penalty, trace)
 
 
 # ---------------------------------------------------------------------------------------------- a9: batcher + collators

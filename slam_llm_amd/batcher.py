@@ -45,13 +45,17 @@ def frames_for_hbm(hbm_bytes: int = 288 << 30, weights_bytes: int = 36 << 30, by
 
 
 def make_sample(audio: torch.Tensor, prompt_ids: List[int], answer_ids: Optional[List[int]], eos_id: int,
-                audio_length: int) -> dict:
-    """token layout [audio(-1)*audio_length, prompt, answer, eos] (speech_dataset.py:109-161)."""
-    if answer_ids is None:  # inference_mode
+                audio_length: int, example_ids: Optional[List[int]] = None) -> dict:
+    """token layout [audio(-1)*audio_length, prompt, answer, eos] (speech_dataset.py:109-161).
+    example_ids: the reference tokenises prompt + answer as ONE string (`tokenizer.encode(prompt + answer)`,
+    speech_dataset.py:137-139) and masks the first len(prompt_ids) labels; pass that encoding here so a tokenizer that
+    merges across the prompt/answer boundary yields the reference's ids (answer_ids is then ignored)."""
+    if answer_ids is None and example_ids is None:  # inference_mode
         ids = torch.tensor([-1] * audio_length + list(prompt_ids), dtype=torch.int64)
         return {"input_ids": ids.clamp(min=-1), "attention_mask": ids.ge(-1), "audio": audio,
                 "audio_length": audio_length, "prompt_length": len(prompt_ids)}
-    ids = torch.tensor([-1] * audio_length + list(prompt_ids) + list(answer_ids) + [eos_id], dtype=torch.int64)
+    text = list(example_ids) if example_ids is not None else list(prompt_ids) + list(answer_ids)
+    ids = torch.tensor([-1] * audio_length + text + [eos_id], dtype=torch.int64)
     labels = ids.clone()
     labels[: audio_length + len(prompt_ids)] = IGNORE_INDEX
     return {"input_ids": ids, "labels": labels, "attention_mask": ids.ge(-1), "audio": audio,
@@ -59,18 +63,29 @@ def make_sample(audio: torch.Tensor, prompt_ids: List[int], answer_ids: Optional
 
 
 def whisper_audio_length(n_samples: int, ds_rate: int = 5, pad_to_30s: bool = True) -> int:
-    """((n_mel_frames + 1) // 2) // k  (speech_dataset.py:104-105); 300 for a padded 30 s clip."""
+    """((n_mel_frames + 1) // 2) // 5  (speech_dataset.py:104-105; the reference hard-codes the 5x projector rate there,
+    so the dataset plugins call this with ds_rate = 5 whatever the projector's rate); 300 for a padded 30 s clip."""
     n = 480000 if pad_to_30s else n_samples
     frames = n // 160
     return ((frames + 1) // 2) // ds_rate
+
+
+def raw_audio_length(n_samples: int) -> int:
+    """placeholder count for raw-waveform encoders (HuBERT / WavLM): `len // 320 // 5` (speech_dataset.py:98-99,
+    speech_dataset_large.py:97-98: "ad-hoc for fairseq 320x downsample", "ad-hoc for 5x fc downsample")."""
+    return n_samples // 320 // 5
 
 
 def _pad1(t: torch.Tensor, left: int, right: int, value) -> torch.Tensor:
     return torch.cat([torch.full((left,), value, dtype=t.dtype), t, torch.full((right,), value, dtype=t.dtype)])
 
 
-def collate(samples: List[dict], pad_token_id: int, left_pad_prompt: bool, n_samples: int = 480000) -> dict:
-    """left_pad_prompt=True: SpeechDatasetJsonl.collator; False: MultiTaskDataset.collator (right padding only)."""
+def collate(samples: List[dict], pad_token_id: int, left_pad_prompt: bool, n_samples: int = 480000,
+            input_type: str = "mel") -> dict:
+    """left_pad_prompt=True: SpeechDatasetJsonl.collator; False: MultiTaskDataset.collator (right padding only).
+    input_type "mel": Whisper recipes -- the waveform is carried instead of the CPU log-mel (`audio` + `audio_len`, trimmed
+    to n_samples as whisper.pad_or_trim would).  "raw": HuBERT / WavLM recipes -- `audio` zero padded to the longest clip
+    plus the reference's float `audio_mask` (speech_dataset.py:238-244)."""
     if left_pad_prompt:
         pl = [s["audio_length"] + s["prompt_length"] for s in samples]
         al = [len(s["input_ids"]) - p for s, p in zip(samples, pl)]
@@ -89,12 +104,19 @@ def collate(samples: List[dict], pad_token_id: int, left_pad_prompt: bool, n_sam
     for i, (s, (l, _)) in enumerate(zip(samples, lr)):
         mm[i, l: l + s["audio_length"]] = True
     out["modality_mask"] = mm
-    # raw waveforms, zero padded to a common length; audio_len = true sample counts (GPU log-mel pads/trims to n_samples)
-    alen = torch.tensor([min(len(s["audio"]), n_samples) for s in samples], dtype=torch.int32)
-    amax = int(alen.max())
-    out["audio"] = torch.stack([torch.nn.functional.pad(s["audio"][:amax].float(), (0, amax - min(len(s["audio"]), amax)))
-                                for s in samples])
-    out["audio_len"] = alen
+    if input_type == "raw":
+        alen = torch.tensor([len(s["audio"]) for s in samples], dtype=torch.int32)
+        amax = int(alen.max())
+        out["audio"] = torch.stack([torch.nn.functional.pad(s["audio"].float(), (0, amax - len(s["audio"]))) for s in samples])
+        out["audio_mask"] = (torch.arange(amax)[None, :] < alen[:, None]).float()
+        out["audio_len"] = alen
+    else:
+        # raw waveforms, zero padded to a common length; audio_len = true sample counts (GPU log-mel pads/trims to n_samples)
+        alen = torch.tensor([min(len(s["audio"]), n_samples) for s in samples], dtype=torch.int32)
+        amax = int(alen.max())
+        out["audio"] = torch.stack([torch.nn.functional.pad(s["audio"][:amax].float(), (0, amax - min(len(s["audio"]), amax)))
+                                    for s in samples])
+        out["audio_len"] = alen
     if "key" in samples[0]:  # inference-mode batches carry the utterance ids / references (speech_dataset.py:259-273)
         out["keys"] = [s.get("key") for s in samples]
         out["targets"] = [s.get("target") for s in samples]

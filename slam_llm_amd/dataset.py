@@ -20,7 +20,7 @@ import wave
 import numpy as np
 import torch
 
-from .batcher import collate, dynamic_batches, make_sample, whisper_audio_length
+from .batcher import collate, dynamic_batches, make_sample, raw_audio_length, whisper_audio_length
 
 
 def load_wav_16k(path: str) -> torch.Tensor:
@@ -37,17 +37,45 @@ def load_wav_16k(path: str) -> torch.Tensor:
     return torch.from_numpy(a)
 
 
+def _cfg_get(dataset_config):
+    """`.get(key, default)` over the reference's OmegaConf dataset_config, a plain dict, or a dataclass instance"""
+    if hasattr(dataset_config, "get"):
+        return dataset_config.get
+    return lambda k, d=None: getattr(dataset_config, k, d)
+
+
+def _input_type(g):
+    it = g("input_type", None)
+    if it not in ("raw", "mel"):   # speech_dataset.py:53: assert self.input_type in ["raw", "mel"]
+        raise ValueError("dataset_config.input_type must be one of [raw, mel] (raw: HuBERT / WavLM waveforms, mel: Whisper)")
+    return it
+
+
+def _prepare_audio(audio: torch.Tensor, input_type: str, normalize: bool, fix_length_audio: int, pad_to_30s: bool):
+    """(audio, audio_length): the placeholder arithmetic of speech_dataset.py:94-108 / speech_dataset_large.py:94-108."""
+    if input_type == "raw":
+        if normalize:
+            audio = torch.nn.functional.layer_norm(audio, audio.shape)
+        alen = raw_audio_length(len(audio))
+    else:
+        alen = whisper_audio_length(len(audio), 5, pad_to_30s=pad_to_30s)
+    if fix_length_audio > 0:
+        alen = fix_length_audio
+    return audio, alen
+
+
 class SpeechDatasetJsonlRaw(torch.utils.data.Dataset):
     def __init__(self, dataset_config, tokenizer=None, split="train"):
         super().__init__()
-        g = dataset_config.get
+        g = _cfg_get(dataset_config)
         self.tokenizer = tokenizer
         self.prompt = g("prompt", None) or ("Transcribe speech to text. Output the transcription directly without "
                                             "redundant content. Ensure that the output is not duplicated. ")
         self.prompt_template = "USER: {}\n ASSISTANT:"
         self.fix_length_audio = g("fix_length_audio", -1)
         self.inference_mode = g("inference_mode", False)
-        self.ds_rate = g("encoder_projector_ds_rate", 5)
+        self.normalize = bool(g("normalize", False))
+        self.input_type = _input_type(g)
         self.left_pad = g("left_pad_prompt", True)
         self.max_frame_length = g("train_max_frame_length" if split == "train" else "eval_max_frame_length", None)
         path = g("train_data_path") if split == "train" else g("val_data_path")
@@ -62,18 +90,19 @@ class SpeechDatasetJsonlRaw(torch.utils.data.Dataset):
 
     def __getitem__(self, index):
         d = self.data_list[index]
-        audio = load_wav_16k(d["source"])
-        alen = self.fix_length_audio if self.fix_length_audio > 0 else whisper_audio_length(len(audio), self.ds_rate)
-        prompt_ids = self.tokenizer.encode(self.prompt_template.format(self.prompt))
+        audio, alen = _prepare_audio(load_wav_16k(d["source"]), self.input_type, self.normalize, self.fix_length_audio, True)
+        prompt = self.prompt_template.format(self.prompt)
+        prompt_ids = self.tokenizer.encode(prompt)
         if self.inference_mode:
             s = make_sample(audio, prompt_ids, None, self.tokenizer.eos_token_id, alen)
             s.update(key=d.get("key"), target=d.get("target"))
             return s
-        full = self.tokenizer.encode(self.prompt_template.format(self.prompt) + str(d.get("target", "")))
-        return make_sample(audio, prompt_ids, full[len(prompt_ids):], self.tokenizer.eos_token_id, alen)
+        # speech_dataset.py:136-139: prompt + answer tokenised as ONE string, the first len(prompt_ids) labels masked
+        example_ids = self.tokenizer.encode(prompt + "{}".format(d.get("target", None)))
+        return make_sample(audio, prompt_ids, None, self.tokenizer.eos_token_id, alen, example_ids=example_ids)
 
     def collator(self, samples):
-        return collate(samples, self.tokenizer.pad_token_id, self.left_pad)
+        return collate(samples, self.tokenizer.pad_token_id, self.left_pad, input_type=self.input_type)
 
     def dynamic_batch_iter(self):
         """in-order dynamic-frame batches (already collated)"""
@@ -123,11 +152,17 @@ class MultiTaskDatasetRaw(torch.utils.data.IterableDataset):
     {"task","prompt"}), same rank x worker line sharding (:80-86), `max_audio_length` filter (:92-93), random prompt
     per sample (:113), `append_info_tasks` (:115-116), token layout and RIGHT-padding collator (:180-233) -- but the
     log-mel is not computed here (:102-104): the batch carries `audio` + `audio_len` for slam_logmel_fwd on the device.
-    `audio_length` reproduces the reference's mel-frame arithmetic for `pad_or_trim` on or off."""
+    `audio_length` reproduces the reference's mel-frame arithmetic for `pad_or_trim` on or off.
+
+    Sharding quirk, reproduced by default because index work must match the reference bit for bit: the reference's
+    `continue` for a clip longer than max_audio_length skips its `data_index += 1` (:92-93 vs :156), so the worker that
+    dropped a clip stays one line behind for the rest of the file -- from then on it yields the lines of the NEXT worker
+    rank (which that worker yields too) and never its own.  `dataset_config.fix_shard_skip=true` advances the index on
+    dropped clips instead (disjoint shards; a conscious deviation)."""
 
     def __init__(self, dataset_config, tokenizer=None, split="train"):
         super().__init__()
-        g = dataset_config.get
+        g = _cfg_get(dataset_config)
         self.prompts = {}
         with open(g("multitask_prompt_path")) as f:
             for line in f:
@@ -144,9 +179,11 @@ class MultiTaskDatasetRaw(torch.utils.data.IterableDataset):
         self.pad_or_trim = g("pad_or_trim", False)
         self.fix_length_audio = g("fix_length_audio", -1)
         self.inference_mode = g("inference_mode", False)
+        self.normalize = bool(g("normalize", False))
+        self.input_type = _input_type(g)
         self.max_audio_length = g("max_audio_length", 30)
         self.audio_sample_rate = g("audio_sample_rate", 16000)
-        self.ds_rate = g("encoder_projector_ds_rate", 5)
+        self.fix_shard_skip = bool(g("fix_shard_skip", False))
         self.max_frame_length = g("train_max_frame_length" if split == "train" else "eval_max_frame_length", None)
 
     def _shard(self):
@@ -158,9 +195,11 @@ class MultiTaskDatasetRaw(torch.utils.data.IterableDataset):
 
     def __iter__(self):
         total, mine = self._shard()
+        data_index = 0
         with open(os.path.join(self.data_path, "multitask.jsonl")) as f:
-            for index, line in enumerate(f):
-                if index % total != mine:
+            for line in f:
+                if data_index % total != mine:
+                    data_index += 1
                     continue
                 item = json.loads(line)
                 rate, pcm = load_ark_wav(item["path"])
@@ -168,9 +207,11 @@ class MultiTaskDatasetRaw(torch.utils.data.IterableDataset):
                     raise ValueError(f"{item['path']}: expected {self.audio_sample_rate} Hz audio, got {rate}")
                 audio = torch.from_numpy(pcm.astype(np.float32) / 32768)
                 if len(audio) / self.audio_sample_rate > self.max_audio_length:
-                    continue
-                alen = (self.fix_length_audio if self.fix_length_audio > 0
-                        else whisper_audio_length(len(audio), self.ds_rate, pad_to_30s=bool(self.pad_or_trim)))
+                    if self.fix_shard_skip:
+                        data_index += 1
+                    continue   # reference: the index does NOT advance here (class docstring)
+                data_index += 1
+                audio, alen = _prepare_audio(audio, self.input_type, self.normalize, self.fix_length_audio, bool(self.pad_or_trim))
                 prompt = self.prompt_style.format(random.choice(self.prompts[item["task"]]))
                 if item["task"] in self.append_info_tasks:
                     prompt = prompt.format(item[item["task"]])
@@ -178,23 +219,42 @@ class MultiTaskDatasetRaw(torch.utils.data.IterableDataset):
                 if self.inference_mode:
                     s = make_sample(audio, prompt_ids, None, self.tokenizer.eos_token_id, alen)
                     s.update(key=item["key"], target=item["target"])
-                else:
-                    full = self.tokenizer.encode(prompt + str(item["target"]))
-                    s = make_sample(audio, prompt_ids, full[len(prompt_ids):], self.tokenizer.eos_token_id, alen)
+                else:   # :137-139: prompt + answer tokenised as one string
+                    s = make_sample(audio, prompt_ids, None, self.tokenizer.eos_token_id, alen,
+                                    example_ids=self.tokenizer.encode(prompt + "{}".format(item["target"])))
                 yield s
 
     def collator(self, samples):
-        return collate(samples, self.tokenizer.pad_token_id, left_pad_prompt=False)
+        return collate(samples, self.tokenizer.pad_token_id, left_pad_prompt=False, input_type=self.input_type)
 
     def dynamic_batch_iter(self):
-        """`MultiTaskDynamicBatchDataset` (speech_dataset_large.py:235-263): in-order batches under max_frame_length"""
+        """in-order batches under max_frame_length, already collated"""
         for group in dynamic_batches(iter(self), int(self.max_frame_length)):
             yield self.collator(group)
 
 
+class MultiTaskDynamicBatchDatasetRaw(torch.utils.data.IterableDataset):
+    """`MultiTaskDynamicBatchDataset` (speech_dataset_large.py:235-256): yields LISTS of samples grouped by the dynamic-frame
+    window; the reference's DataLoader is built with `batch_size=None, collate_fn=dataset.collator`
+    (utils/config_utils.py:94-99), so this object exposes the wrapped dataset's collator."""
+
+    def __init__(self, dataset: MultiTaskDatasetRaw, max_frame_length: int):
+        super().__init__()
+        self.dp = dataset
+        self.max_frame_length = int(max_frame_length)
+        self.collator = dataset.collator
+
+    def __iter__(self):
+        return dynamic_batches(iter(self.dp), self.max_frame_length)
+
+
 def get_speech_dataset(dataset_config, tokenizer, split):
     """plugin entry (dataset_config.file = ".../slam_model_hip.py:get_speech_dataset"): kaldi-ark multitask layout when
-    the config names `multitask_prompt_path` (aispeech_asr recipes), JSONL otherwise (asr_librispeech recipes)."""
-    if dataset_config.get("multitask_prompt_path", None):
-        return MultiTaskDatasetRaw(dataset_config, tokenizer, split)
+    the config names `multitask_prompt_path` (aispeech_asr recipes; returns the dynamic-batch wrapper like
+    speech_dataset_large.py:265-271), JSONL otherwise (asr_librispeech recipes, speech_dataset.py:295-298)."""
+    g = _cfg_get(dataset_config)
+    if g("multitask_prompt_path", None):
+        ds = MultiTaskDatasetRaw(dataset_config, tokenizer, split)
+        mfl = g("train_max_frame_length" if split == "train" else "eval_max_frame_length", None)
+        return MultiTaskDynamicBatchDatasetRaw(ds, mfl) if mfl else ds
     return SpeechDatasetJsonlRaw(dataset_config, tokenizer, split)

@@ -51,6 +51,8 @@ PRESETS = {
                        vocab=128256, rope_theta=500000.0, rms_eps=1e-5),
     "tinyllama-1.1b": dict(llm_dim=2048, llm_layers=22, llm_heads=32, llm_kv_heads=4, llm_head_dim=64, llm_ffn=5632,
                            vocab=32000, rope_theta=10000.0, rms_eps=1e-5),
+    "vicuna-13b": dict(llm_dim=5120, llm_layers=40, llm_heads=40, llm_kv_heads=40, llm_head_dim=128, llm_ffn=13824,
+                       vocab=32000, rope_theta=10000.0, rms_eps=1e-5),
     "vicuna-7b": dict(llm_dim=4096, llm_layers=32, llm_heads=32, llm_kv_heads=32, llm_head_dim=128, llm_ffn=11008,
                       vocab=32000, rope_theta=10000.0, rms_eps=1e-5),
 }
@@ -613,6 +615,7 @@ class HipLlamaLora(nn.Module):
         d, Hq, Hkv, D, Fd = cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"], cfg["llm_ffn"]
         self.lora_p = float(cfg.get("lora_dropout", 0.0) or 0.0)
         self._drop_calls = 0
+        self.lm_head_chunk_rows = None   # None: rows per lm_head/CE chunk derived from a 1 GB bf16 logits buffer (tests override)
         self.layers = []
         targets = tuple(cfg.get("lora_targets") or ())
         r, alpha = cfg["lora_r"], cfg["lora_alpha"]
@@ -746,7 +749,7 @@ class HipLlamaLora(nn.Module):
             row_loss = torch.empty((M,), dtype=torch.float32, device=h.device)
             row_ok = torch.empty((M,), dtype=torch.int32, device=h.device)
             dhN = torch.empty((M, d), dtype=torch.bfloat16, device=h.device) if train else None
-            Rc = max(256, min(M, ((1 << 29) // V) // 256 * 256))
+            Rc = self.lm_head_chunk_rows or max(256, min(M, ((1 << 29) // V) // 256 * 256))
             chunk = torch.empty((min(Rc, M), V), dtype=torch.bfloat16, device=h.device)
             for r0 in range(0, M, Rc):
                 r1 = min(M, r0 + Rc)
@@ -952,20 +955,29 @@ class HipLlamaLora(nn.Module):
 
 # ======================================================================================== composite
 class _SlamStep(torch.autograd.Function):
-    """autograd entry: forward returned the loss computed by the HIP path; backward runs the HIP backward and
-    deposits gradients directly into the flat grad buffer (`.grad` of every trainable parameter views it)."""
+    """autograd entry: forward returned the loss computed by the HIP path; backward runs the HIP backward.
+
+    Two ways of handing the gradients over:
+      * flat-buffer mode (default, fast path): gradients are deposited in place into the flat grad buffer that `.grad`
+        of every trainable parameter views; autograd sees no parameter gradients (returns None for them), gradient
+        accumulation is an in-place add by the kernels, `GradSync` all-reduces buffer prefixes during the backward;
+      * `model.autograd_params` (DDP-compatible): the trainable parameters are real inputs of this node and the backward
+        returns views of a FRESH flat buffer as their gradients, so AccumulateGrad (and with it the reducer hooks of
+        `torch.nn.parallel.DistributedDataParallel`, src/slam_llm/pipeline/finetune.py:181-184) fires for each of
+        them; autograd adopts the views without a copy when `.grad` is None and adds into `.grad` otherwise."""
 
     @staticmethod
-    def forward(ctx, anchor, model, stash, loss_value):
+    def forward(ctx, anchor, model, stash, loss_value, *params):
         ctx.model, ctx.stash = model, stash
+        ctx.n_params = len(params)
         return loss_value.clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         model, stash = ctx.model, ctx.stash
         ctx.stash = None
-        model._run_backward(stash, grad_out)
-        return None, None, None, None
+        grads = model._run_backward(stash, grad_out, as_autograd=ctx.n_params > 0)
+        return (None, None, None, None) + tuple(grads)
 
 
 class SlamHipModel(nn.Module):
@@ -1000,20 +1012,81 @@ class SlamHipModel(nn.Module):
         self._anchor = torch.zeros(1, device=self.device_, requires_grad=True)
         self._stale = True
         self.return_logits = None  # None: logits only in eval mode
-        self.grad_hooks = []       # callables(prefix_end_offset) for data-parallel bucket launches
+        self.grad_hooks = []       # GradSync-like objects: .on_backward_begin(), .on_prefix(end_offset)
         self._always_refresh = True
+        # True: trainable parameters are autograd inputs of the step and receive their gradients through AccumulateGrad
+        # (what DistributedDataParallel needs); set by model_factory when train_config.enable_ddp is on
+        self.autograd_params = bool(kwargs.get("autograd_params", False))
 
     # ---- weights -------------------------------------------------------------------------------------
-    def load_weights(self, W: Dict[str, torch.Tensor]):
-        """W: {name: tensor} with the reference's state_dict names (fp32 or bf16, any device)."""
+    def load_weights(self, W: Dict[str, torch.Tensor], seed: int = 42):
+        """W: {name: tensor} with the reference's state_dict names (fp32 or bf16, any device).  Trainable tensors that
+        W does not carry (a fresh fine-tune from pretrained encoder/LLM weights) are initialised the way the reference's
+        modules initialise themselves -- see `init_missing_trainables`."""
         self.encoder.load(W)
         self.llm.load(W)
+        missing = []
         with torch.no_grad():
             for name, p in self.store.params.items():
                 if name in W:
                     p.copy_(W[name].to(self.device_, torch.float32))
+                else:
+                    missing.append(name)
+        if missing:
+            self.init_missing_trainables(missing, seed)
         self._stale = True
         return self
+
+    @torch.no_grad()
+    def init_missing_trainables(self, names, seed: int = 42):
+        """Fresh-module initialisation of the reference's trainable parts (the flat store itself is zero-filled, which
+        would leave the projector at a fixed point -- relu(0) kills every gradient but linear2.bias -- and LoRA with
+        A = B = 0 untrainable):
+          * projector nn.Linear / nn.Conv1d (src/slam_llm/models/projector.py:11-13,35-38): torch's reset_parameters,
+            kaiming_uniform_(a=sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for the weight and the same bound for the bias;
+          * peft 0.6.0 LoRA: lora_A kaiming_uniform_(a=sqrt(5)), lora_B zeros (SURVEY Appendix A);
+          * Q-Former (projector.py:60-67): query ~ N(0, 1); Blip2QFormerModel._init_weights: Linear weights N(0, 0.02),
+            biases 0, LayerNorm weight 1 / bias 0; the output nn.Linear by reset_parameters, nn.LayerNorm 1 / 0.
+        Seeded from train_config.seed through a CPU generator (the same values on every rank)."""
+        g = torch.Generator().manual_seed(int(seed))
+        st = self.store
+        shapes = {n: shape for n, shape, _ in st.entries}
+
+        def uniform(shape, bound):
+            return (torch.rand(shape, generator=g) * 2 - 1) * bound
+
+        def fan_in_of(weight_name):
+            sh = shapes[weight_name]
+            return int(math.prod(sh[1:]))
+
+        qformer_inner = "encoder_projector.qformer."
+        for name in names:
+            p, sh = st.params[name], shapes[name]
+            if "lora_B" in name:
+                val = torch.zeros(sh)
+            elif "lora_A" in name:
+                val = uniform(sh, 1.0 / math.sqrt(sh[1]))
+            elif name == "encoder_projector.query":
+                val = torch.randn(sh, generator=g)
+            elif name.startswith(qformer_inner):
+                if "LayerNorm" in name or "layernorm" in name:
+                    val = torch.ones(sh) if name.endswith("weight") else torch.zeros(sh)
+                elif name.endswith("bias"):
+                    val = torch.zeros(sh)
+                else:
+                    val = torch.randn(sh, generator=g) * 0.02
+            elif name == "encoder_projector.norm.weight":
+                val = torch.ones(sh)
+            elif name == "encoder_projector.norm.bias":
+                val = torch.zeros(sh)
+            elif name.endswith(".weight"):
+                val = uniform(sh, 1.0 / math.sqrt(fan_in_of(name)))
+            elif name.endswith(".bias"):
+                val = uniform(sh, 1.0 / math.sqrt(fan_in_of(name[: -len("bias")] + "weight")))
+            else:
+                raise RuntimeError(f"no initialisation rule for trainable tensor {name}")
+            p.copy_(val.to(self.device_, torch.float32))
+        self._stale = True
 
     def init_random(self, seed: int = 42, lora_b_std: float = 0.02):
         self.encoder.init_random(seed)
@@ -1044,6 +1117,16 @@ class SlamHipModel(nn.Module):
         super().train(mode)
         return self
 
+    def _apply(self, fn, *args, **kwargs):
+        """`.cuda(local_rank)` of the reference's pipeline (finetune.py:181) is a no-op move; anything that would change
+        the dtype or the device of the trainable parameters (`model.to(torch.bfloat16)` of the pure_bf16 route,
+        finetune.py:154-155; `.cpu()`) would silently detach them from the flat master buffer the kernels read."""
+        probe = fn(torch.empty(0, dtype=torch.float32, device=self.device_))
+        if probe.dtype != torch.float32 or probe.device != self.device_:
+            raise RuntimeError(f"SlamHipModel lives on {self.device_} with fp32 trainable masters (bf16 compute copies are "
+                               f"internal); cannot convert to {probe.dtype} on {probe.device}")
+        return super()._apply(fn, *args, **kwargs)
+
     # ---- forward -------------------------------------------------------------------------------------
     def forward(self, input_ids=None, attention_mask=None, labels=None, **kwargs):
         """same contract as slam_model.forward (src/slam_llm/models/slam_model.py:283-407)."""
@@ -1066,9 +1149,12 @@ class SlamHipModel(nn.Module):
             # raw-waveform encoder (slam_model.py:335-341); equal-length unpadded clips only this round
             if audio is None:
                 raise RuntimeError("hubert encoder needs the raw `audio` batch key")
-            am = kwargs.get("audio_mask", None)
-            if am is not None and not bool((am > 0).all()):
-                raise NotImplementedError("ragged raw-audio batches for the HuBERT branch are not supported yet")
+            am, alen = kwargs.get("audio_mask", None), kwargs.get("audio_len", None)
+            ragged = (am is not None and not bool((am > 0).all())) or \
+                     (alen is not None and not bool((alen.to(audio.device) == audio.shape[1]).all()))
+            if ragged:   # zero-padded clips would be encoded as full-length audio (and fairseq's padding mask is not built)
+                raise NotImplementedError("ragged raw-audio batches for the HuBERT branch are not supported yet: batch "
+                                          "equal-length clips (audio_mask / audio_len say this batch is padded)")
             enc = self.encoder.forward_wav(audio.float())
         else:
             if audio_mel is None:
@@ -1134,7 +1220,8 @@ class SlamHipModel(nn.Module):
             if train:
                 stash.update(lstash)
                 stash.update(spans=spans, Ta=Ta, batch_B=B, batch_T=T, pack_idx=pack_idx)  # (B, T of the LLM pass itself live in lstash)
-                loss = _SlamStep.apply(self._anchor, self, stash, loss_val)
+                plist = tuple(self.store.params.values()) if self.autograd_params else ()
+                loss = _SlamStep.apply(self._anchor, self, stash, loss_val, *plist)
             else:
                 loss = loss_val
         if not self.metric:
@@ -1142,9 +1229,21 @@ class SlamHipModel(nn.Module):
         outputs = SimpleNamespace(loss=loss, logits=logits.view(B, T, -1) if logits is not None else None)
         return outputs, acc
 
-    def _run_backward(self, stash: dict, grad_out: torch.Tensor):
+    def _run_backward(self, stash: dict, grad_out: torch.Tensor, as_autograd: bool = False):
         st = self.store
-        accumulate = any(p.grad is not None for p in st.params.values())
+        if as_autograd:
+            if self.grad_hooks:
+                raise RuntimeError("autograd_params mode hands gradients to autograd/DDP; detach GradSync")
+            # fresh buffer: what we return belongs to autograd (adopted as .grad or added into it) and must not be
+            # overwritten by the next backward
+            st.grad = torch.empty_like(st.flat)
+            accumulate = False
+        else:
+            accumulate = any(p.grad is not None for p in st.params.values())
+        for hk in self.grad_hooks:
+            begin = getattr(hk, "on_backward_begin", None)
+            if begin is not None:
+                begin()
         gs = grad_out.reshape(1).to(torch.float32).contiguous()
         dh0 = self.llm.backward_hip(stash, gs, accumulate, on_layer_done=self._on_layer_done)
         if stash.get("pack_idx") is not None:   # packed rows -> padded [B*T, d] layout (pad rows carry no gradient)
@@ -1153,22 +1252,32 @@ class SlamHipModel(nn.Module):
             dh0 = full
         dproj = ops.embed_splice_bwd(stash["spans"], dh0, stash["batch_B"], stash["batch_T"], stash["Ta"], self.cfg["llm_dim"])
         self.encoder_projector.backward_hip(dproj, stash, accumulate)
+        if as_autograd:
+            return [st.grad_view(name) for name in st.params]
         for name, p in st.params.items():
             if p.grad is None:
                 p.grad = st.grad_view(name)
         for hk in self.grad_hooks:
-            hk(st.size)
+            hk.on_prefix(st.size) if hasattr(hk, "on_prefix") else hk(st.size)
+        return ()
 
     def _on_layer_done(self, li: int):
         if not self.grad_hooks:
             return
         # LoRA grads of layers >= li are final: they occupy the prefix of the flat buffer (reserved last layer first)
-        names = [n for n in self.store.offsets if f".layers.{li}." in n]
-        if not names:
+        ends = getattr(self, "_layer_prefix_end", None)
+        if ends is None:
+            ends = {}
+            for n, (off, cnt, _) in self.store.offsets.items():
+                if ".layers." in n:
+                    k = int(n.split(".layers.")[1].split(".")[0])
+                    ends[k] = max(ends.get(k, 0), off + round_up(cnt, 64))
+            self._layer_prefix_end = ends
+        end = ends.get(li)
+        if end is None:
             return
-        end = max(self.store.offsets[n][0] + round_up(self.store.offsets[n][1], 64) for n in names)
         for hk in self.grad_hooks:
-            hk(end)
+            hk.on_prefix(end) if hasattr(hk, "on_prefix") else hk(end)
 
     # ---- generate ------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -1234,7 +1343,9 @@ class SlamHipModel(nn.Module):
 # ======================================================================================== optimizer
 class SlamAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (src/slam_llm/pipeline/finetune.py:247-251) as ONE fused kernel over the
-    flat master/grad buffers; also refreshes the bf16 compute copies.  Works with LambdaLR (reads group['lr'])."""
+    flat master/grad buffers; also refreshes the bf16 compute copies.  Works with LambdaLR (reads group['lr']).
+    The moments and the step counter round-trip through state_dict()/load_state_dict() (keys `exp_avg`, `exp_avg_sq`
+    as flat tensors in the store's layout, `step`), so a resumed run continues the bias correction."""
 
     def __init__(self, model: SlamHipModel, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         params = list(model.store.params.values())
@@ -1245,12 +1356,27 @@ class SlamAdamW(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(st.flat)
         self._step = 0
 
+    def _flat_grad(self) -> torch.Tensor:
+        """the flat gradient buffer the kernel reads.  Flat-buffer mode: `.grad` of every parameter already views it.
+        autograd_params mode: autograd owns `.grad` (views of the last backward's buffer when it adopted them, other
+        tensors after accumulation or under DDP's bucket views) -> gather whatever is not already in place."""
+        st = self.model.store
+        base = st.grad.data_ptr()
+        for name, p in st.params.items():
+            g = p.grad
+            if g is None:
+                raise RuntimeError(f"SlamAdamW.step(): parameter {name} has no gradient (all trainables are produced by every backward)")
+            off = st.offsets[name][0]
+            if g.data_ptr() != base + 4 * off:
+                st.grad_view(name).copy_(g)
+        return st.grad
+
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
         st = self.model.store
         self._step += 1
-        ops.adamw_step(st.flat, st.grad, self.exp_avg, self.exp_avg_sq, st.flat_bf16, float(g["lr"]), g["betas"][0],
+        ops.adamw_step(st.flat, self._flat_grad(), self.exp_avg, self.exp_avg_sq, st.flat_bf16, float(g["lr"]), g["betas"][0],
                        g["betas"][1], g["eps"], g["weight_decay"], self._step)
         self.model.llm.refresh()
         self.model.encoder_projector.refresh()
@@ -1260,3 +1386,22 @@ class SlamAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = True):
         for p in self.model.store.params.values():
             p.grad = None
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["slam"] = dict(exp_avg=self.exp_avg.detach().cpu(), exp_avg_sq=self.exp_avg_sq.detach().cpu(), step=self._step,
+                          layout=[(n, list(shape), off) for n, shape, off in self.model.store.entries])
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        slam = sd.pop("slam", None)
+        super().load_state_dict(sd)
+        if slam is None:
+            raise KeyError("SlamAdamW.load_state_dict: no 'slam' entry (moments / step): not a SlamAdamW checkpoint")
+        layout = [(n, list(shape), off) for n, shape, off in self.model.store.entries]
+        if [tuple(map(str, e)) for e in slam["layout"]] != [tuple(map(str, e)) for e in layout]:
+            raise ValueError("SlamAdamW.load_state_dict: the checkpoint's parameter layout differs from this model's")
+        self.exp_avg.copy_(slam["exp_avg"])
+        self.exp_avg_sq.copy_(slam["exp_avg_sq"])
+        self._step = int(slam["step"])

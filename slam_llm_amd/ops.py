@@ -23,20 +23,21 @@ class KernelTimer:
     def __init__(self):
         self.rec = {}
 
-    def run(self, name, work, fn):
+    def run(self, name, work, fn, nbytes=0.0):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         out = fn()
         e.record()
-        self.rec.setdefault(name, []).append((s, e, work))
+        self.rec.setdefault(name, []).append((s, e, work, nbytes))
         return out
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for name, lst in self.rec.items():
-            ms = sum(s.elapsed_time(e) for s, e, _ in lst)
-            out[name] = dict(launches=len(lst), total_ms=ms, avg_ms=ms / len(lst), work=sum(w for _, _, w in lst))
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in lst)
+            out[name] = dict(launches=len(lst), total_ms=ms, avg_ms=ms / len(lst), work=sum(w for _, _, w, _ in lst),
+                             bytes=sum(b for _, _, _, b in lst))
         return out
 
 
@@ -44,10 +45,11 @@ TIMER: Optional[KernelTimer] = None
 TIMER_SHAPES = False   # tools: key GEMM timings by shape as well as by kernel instance
 
 
-def _timed(name, work, fn):
+def _timed(name, work, fn, nbytes=0.0):
+    """work = algorithmic FLOPs of the launch, nbytes = its algorithmic HBM bytes (operands read once + result written once)"""
     if TIMER is None:
         return fn()
-    return TIMER.run(name, work, fn)
+    return TIMER.run(name, work, fn, nbytes)
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -91,7 +93,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     _timed(gemm_kernel_name(M, N) + (f" [{M}x{N}x{K}]" if TIMER_SHAPES else ""), 2.0 * M * N * (k_alg or K),
            lambda: call("slam_gemm_bf16_nt", _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, N, K, _p(bias),
                         _p(residual), _ld(residual) if residual is not None else 0, res_row_mod, act, alpha, od,
-                        1 if accumulate else 0, _s()))
+                        1 if accumulate else 0, _s()),
+           nbytes=2.0 * (M * K + N * K) + M * N * (4 if od == F32 else 2))
     return out
 
 

@@ -54,10 +54,12 @@ HUBERT_PRESETS = {
 
 
 def build_config(train_config, model_config) -> dict:
-    enc_name = _get(model_config, "encoder_name", "whisper")
+    enc_name = _get(model_config, "encoder_name", None)
     if enc_name not in ("whisper", "hubert"):
-        raise NotImplementedError(f"encoder_name={enc_name}: the HIP path covers the Whisper (slam_model.py:320-321) and HuBERT "
-                                  "(:335-341) branches; WavLM & co. are SURVEY 8(f) rows")
+        # the recipe dataclasses default encoder_name to None (asr_config.py:14: a text-only LLM in the reference,
+        # slam_model.py:68-116 returns no encoder); this plugin is the speech path only
+        raise NotImplementedError(f"model_config.encoder_name={enc_name!r}: the HIP path covers the Whisper (slam_model.py:320-321) and "
+                                  "HuBERT (:335-341) branches; WavLM & co. are SURVEY 8(f) rows")
     projector = _get(model_config, "encoder_projector", "linear")
     if projector not in ("linear", "cov1d-linear", "q-former"):
         raise NotImplementedError("encoder_projector must be `linear` (EncoderProjectorConcat), `cov1d-linear` "
@@ -86,9 +88,34 @@ def build_config(train_config, model_config) -> dict:
                       lora_r=int(_get(peft, "r", 8)), lora_alpha=float(_get(peft, "lora_alpha", 32)),
                       lora_targets=tuple(_get(peft, "target_modules", ("q_proj", "v_proj"))) if use_peft else (),
                       lora_dropout=float(_get(peft, "lora_dropout", 0.05)) if use_peft else 0.0, **extra)
+    overrides = _get(model_config, "arch_overrides", None)   # ++model_config.arch_overrides={llm_layers: 2, ...}: non-preset geometries
+    if overrides:
+        cfg.update({k: (tuple(v) if isinstance(v, list) else v) for k, v in dict(overrides).items()})
+        if enc_name == "hubert":
+            cfg["enc_dim"] = cfg["hub_dim"]
     if int(_get(model_config, "encoder_dim", cfg["enc_dim"])) != cfg["enc_dim"] or int(_get(model_config, "llm_dim", cfg["llm_dim"])) != cfg["llm_dim"]:
-        raise ValueError("model_config.encoder_dim / llm_dim do not match the selected architecture presets")
+        raise ValueError(f"model_config.encoder_dim / llm_dim ({_get(model_config, 'encoder_dim')}, {_get(model_config, 'llm_dim')}) do not match "
+                         f"the selected architecture ({cfg['enc_dim']}, {cfg['llm_dim']})")
     return cfg
+
+
+def check_supported(train_config, model_config):
+    """what the reference's factory would do with these flags that the HIP path does not implement -> loud errors
+    (src/slam_llm/models/slam_model.py:68-221)."""
+    if _get(train_config, "freeze_encoder", True) is False:
+        raise NotImplementedError("train_config.freeze_encoder=false (unfrozen-encoder training, slam_model.py:110-113) is a SURVEY 8(f) "
+                                  "row: the HIP encoder is forward-only; pass ++train_config.freeze_encoder=true as the speech recipes do")
+    if not bool(_get(train_config, "use_peft", False)) and _get(train_config, "freeze_llm", True) is False:
+        raise NotImplementedError("full LLM fine-tuning (use_peft=false, freeze_llm=false) is out of scope: the HIP LLM is frozen + LoRA")
+    if bool(_get(train_config, "quantization", False)) or bool(_get(train_config, "use_fast_kernels", False)):
+        raise NotImplementedError("quantization / use_fast_kernels are library toggles of the reference stack (slam_model.py:145-146,187-197); "
+                                  "the HIP path is bf16 with its own kernels")
+    if bool(_get(train_config, "enable_fsdp", False)) or bool(_get(train_config, "enable_deepspeed", False)):
+        raise NotImplementedError("FSDP / DeepSpeed are memory strategies the 288 GB part does not need (SURVEY 2e): run the "
+                                  "HIP path with enable_ddp=true (DistributedDataParallel) or single-process")
+    peft = _get(train_config, "peft_config", None)
+    if bool(_get(train_config, "use_peft", False)) and str(_get(peft, "peft_method", "lora")) != "lora":
+        raise NotImplementedError("only peft_method=lora is implemented")
 
 
 def _load_state(path):
@@ -99,9 +126,19 @@ def _load_state(path):
 
 
 def model_factory(train_config, model_config, **kwargs):
-    """returns (model, tokenizer) like src/slam_llm/models/slam_model.py:21-51"""
+    """returns (model, tokenizer) like src/slam_llm/models/slam_model.py:21-51.
+
+    `train_config.enable_ddp` (the flag the reference's pipeline reads before `DDP(model)`, pipeline/finetune.py:181-184)
+    puts the module in autograd_params mode: its trainable parameters then receive their gradients through autograd, so
+    torch's DistributedDataParallel reducer works on it unmodified; `++model_config.autograd_params=false` keeps the
+    flat-buffer backward for callers that drive `slam_llm_amd.train.GradSync` themselves."""
+    check_supported(train_config, model_config)
     cfg = build_config(train_config, model_config)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("slam_llm_amd.model_factory: no HIP device visible (the HIP path has no CPU fallback)")
+    local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)   # ops launch on the CURRENT device's current stream (reference: finetune.py:128-131)
     dev = torch.device("cuda", local_rank)
     tokenizer = None
     llm_path = _get(model_config, "llm_path", None)
@@ -109,9 +146,12 @@ def model_factory(train_config, model_config, **kwargs):
         from transformers import AutoTokenizer
         tokenizer = AutoTokenizer.from_pretrained(llm_path)
         tokenizer.pad_token_id = tokenizer.eos_token_id  # slam_model.py:63-64
+    if "autograd_params" not in kwargs:
+        kwargs["autograd_params"] = bool(_get(model_config, "autograd_params", _get(train_config, "enable_ddp", False)))
+    seed = int(_get(train_config, "seed", 42))
     model = SlamHipModel(cfg, dev, tokenizer=tokenizer, train_config=train_config, model_config=model_config, **kwargs)
     if _get(model_config, "random_init", False):
-        model.init_random(int(_get(train_config, "seed", 42)))
+        model.init_random(seed)
     else:
         W = {}
         for key in ("encoder_state", "llm_state"):
@@ -121,7 +161,7 @@ def model_factory(train_config, model_config, **kwargs):
         if not W:
             raise FileNotFoundError("no weights given: set model_config.encoder_state / llm_state (state dicts in the "
                                     "reference's key names) or model_config.random_init=true")
-        model.load_weights(W)
+        model.load_weights(W, seed=seed)   # projector / LoRA tensors absent from W get the reference's fresh-module init
     ckpt_path = kwargs.get("ckpt_path", None)  # projector/LoRA checkpoint written by save_model_checkpoint_peft
     if ckpt_path is not None:
         logger.info("loading other parts from: %s", ckpt_path)

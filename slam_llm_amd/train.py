@@ -37,14 +37,26 @@ def setup_distributed(device_type: str = "cuda"):
 
 
 class GradSync:
-    """Bucketed mean all-reduce of a flat fp32 gradient buffer, launched on buffer prefixes as they complete."""
+    """Bucketed mean all-reduce of the flat fp32 gradient buffer, launched on buffer prefixes as they complete.
 
-    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 32 << 20, group=None):
-        self.flat = flat_grad
+    Semantics follow DDP (src/slam_llm/pipeline/finetune.py:181-184): every ARMED backward ends with the gradient
+    buffer averaged over ranks.  Two rules make gradient accumulation correct:
+      * `on_backward_begin` (called by the model before its first backward kernel) waits for every collective the
+        previous backward left in flight and resets the prefix cursor, so a backward never accumulates into memory a
+        collective is still reading/writing and every backward reduces its own prefixes (DDP without `no_sync`:
+        avg(avg(g1) + g2) = avg(g1) + avg(g2));
+      * `train_step` disarms the object on micro-steps that do not end in an optimizer step: the sum of micro-step
+        gradients is linear, so ONE reduction of the accumulated buffer on the last micro-step gives the same result
+        with 1/k of the traffic.
+    `source` is the model (its `store.grad` is read at launch time, so a re-allocated buffer is followed) or a tensor."""
+
+    def __init__(self, source, bucket_bytes: int = 32 << 20, group=None):
+        self.source = source
         self.bucket = max(1, bucket_bytes // 4)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.done = 0
+        self.armed = True
         self.handles = []
         # ncclAvg needs (R)CCL >= 2.10; otherwise (and on gloo) sum and scale after the wait
         self.avg_native = False
@@ -54,35 +66,58 @@ class GradSync:
             except Exception:  # noqa: BLE001  (version query unavailable: stay on the always-valid SUM path)
                 self.avg_native = False
 
+    @property
+    def flat(self) -> torch.Tensor:
+        src = self.source
+        return src if isinstance(src, torch.Tensor) else src.store.grad
+
     def attach(self, model):
-        model.grad_hooks.append(self.on_prefix)
+        if getattr(model, "autograd_params", False):
+            raise RuntimeError("GradSync is the fast path of the flat-buffer backward; a model in autograd_params mode is "
+                               "reduced by torch's DistributedDataParallel instead")
+        model.grad_hooks.append(self)
         return self
 
+    def arm(self, on: bool = True):
+        self.armed = bool(on)
+        return self
+
+    def on_backward_begin(self):
+        """a new backward is about to write the gradient buffer: retire whatever the previous one left in flight"""
+        if self.handles or self.done:
+            self._wait()
+
     def on_prefix(self, end: int):
-        """gradients in flat[0:end] are final for this step"""
-        if self.world == 1:
+        """gradients in flat[0:end] are final for this backward"""
+        if self.world == 1 or not self.armed:
             return
-        total = self.flat.numel()
+        flat = self.flat
+        total = flat.numel()
         if end - self.done < self.bucket and end < total:
             return
-        view = self.flat[self.done:end]
-        if self.avg_native:
-            h = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-        else:
-            h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if end <= self.done:
+            return
+        view = flat[self.done:end]
+        op = dist.ReduceOp.AVG if self.avg_native else dist.ReduceOp.SUM
+        h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
         self.handles.append((h, view))
         self.done = end
 
-    def finish(self):
-        """wait for all buckets (call before optimizer.step())."""
-        if self.world > 1 and self.done < self.flat.numel():
-            self.on_prefix(self.flat.numel())
+    __call__ = on_prefix   # plain-callable hook form
+
+    def _wait(self):
         for h, view in self.handles:
             h.wait()
             if not self.avg_native:
                 view.div_(self.world)
         self.handles.clear()
         self.done = 0
+
+    def finish(self):
+        """flush the tail and wait for all buckets (call before optimizer.step())."""
+        if self.world > 1 and self.armed and self.done < self.flat.numel():
+            self.on_prefix(self.flat.numel())
+        self._wait()
 
 
 def all_ranks_have_data(has_batch: bool, device) -> bool:
@@ -97,7 +132,11 @@ def all_ranks_have_data(has_batch: bool, device) -> bool:
 
 def train_step(model, batch: dict, optimizer, scheduler=None, grad_sync: Optional[GradSync] = None,
                gradient_accumulation_steps: int = 1, do_step: bool = True):
-    """One iteration of train_utils.py:112-169.  Returns (loss, acc) as device tensors (no host sync)."""
+    """One iteration of train_utils.py:112-169.  Returns (loss, acc) as device tensors (no host sync).
+    With gradient accumulation the caller passes do_step=False on all but the last micro-step (the reference's
+    `(step + 1) % gradient_accumulation_steps == 0` test, train_utils.py:132/153)."""
+    if grad_sync is not None:
+        grad_sync.arm(do_step)   # one reduction of the accumulated buffer instead of one per micro-step (same result)
     outputs, acc = model(**batch)
     loss = outputs.loss
     if gradient_accumulation_steps != 1:

@@ -43,6 +43,24 @@ def _worker(rank, world, port, q):
         hk(n)
     gs.finish()
     ok = ok and torch.allclose(flat, torch.full((n,), 0.5))
+    # gradient accumulation, k = 2 (reference: DDP all-reduces every backward, utils/train_utils.py:128-152; the result must be
+    # avg(g1) + avg(g2) on every rank).  (a) train_step's protocol: disarmed on the non-stepping micro-step, one reduction of
+    # the accumulated buffer on the last one.  (b) always armed (a caller that never disarms): every backward reduces, and
+    # on_backward_begin retires the previous backward's collectives before the kernels accumulate into the buffer.
+    g1 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    g2 = torch.full((n,), 10.0 * (rank + 1))
+    want = torch.arange(n, dtype=torch.float32) * 1.5 + 15.0
+    for always_armed in (False, True):
+        flat.zero_()
+        for micro, g in enumerate((g1, g2)):
+            gs.arm(always_armed or micro == 1)
+            gs.on_backward_begin()
+            flat.add_(g)                       # the backward kernels accumulate in place
+            for end in (40_000, n):
+                gs.on_prefix(end)
+        gs.finish()
+        ok = ok and torch.allclose(flat, want)
+    gs.arm(True)
     # uneven shards: rank 1 runs dry first -> everybody stops (reference: Join / monitored_barrier)
     flags = [all_ranks_have_data(step < (3 if rank == 0 else 2), torch.device("cpu")) for step in range(3)]
     q.put((rank, bool(ok), flags))

@@ -1,0 +1,209 @@
+"""Two ranks around the REAL SlamHipModel on one MI355X (gloo between the ranks: SLAM_DIST_BACKEND, train.py:32): the
+data-parallel path of src/slam_llm/pipeline/finetune.py:181-184 + utils/train_utils.py:91,128-152 --
+  * GradSync fast path: after the backward the flat gradient == mean of the two ranks' single-rank gradients,
+  * parameters identical across ranks after 3 optimizer steps,
+  * gradient accumulation (k = 2) == the reference's all-reduce-every-backward result,
+  * uneven shards (rank 1 runs dry first) end the epoch cleanly on both ranks,
+  * the module wrapped in torch.nn.parallel.DistributedDataParallel (autograd_params mode) gives the same numbers with
+    torch.optim.AdamW(model.parameters()), and `.module` / state_dict keys are what checkpoint_handler.py:190-200 walks.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                          SLAM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        from oracle import slam_oracle as O
+        from slam_llm_amd.model import SlamAdamW, SlamHipModel
+        from slam_llm_amd.train import GradSync, all_ranks_have_data, setup_distributed, train_step
+        r, lr, w = setup_distributed("cuda")
+        assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+        dev = torch.device("cuda:0")
+        cfg = dict(O.make_config(), lora_dropout=0.0)
+        W = O.init_weights(cfg, seed=42)
+        res = {}
+
+        def batch_for(rk, i):   # rank- and step-specific batch (different clip count and answer lengths per rank)
+            audio = O.synth_audio(2 + rk, 1.0 + 0.5 * i, seed=100 + 10 * rk + i)
+            ob = O.synth_batch(cfg, audio, prompt_len=5, answer_lens=(4 + rk, 7, 3 + i), seed=200 + 10 * rk + i, left_pad=False, pad_to_30s=False)
+            return {k: v.to(dev) for k, v in ob.items()}
+
+        def local_grad(model, batches, scale=1.0):
+            """single-rank gradient of sum_i scale * loss(batch_i), hooks detached"""
+            hooks, model.grad_hooks = model.grad_hooks, []
+            for p in model.parameters():
+                p.grad = None
+            for b in batches:
+                out, _ = model(**{k: v.clone() for k, v in b.items()})
+                (out.loss * scale).backward()
+            g = model.store.grad.clone()
+            for p in model.parameters():
+                p.grad = None
+            model.grad_hooks = hooks
+            return g
+
+        model = SlamHipModel(dict(cfg), dev).load_weights(W)
+        model.train()
+        # ---- 1. GradSync: all-reduced flat gradient == mean of the single-rank gradients ------------------------
+        want = (local_grad(model, [batch_for(0, 0)]) + local_grad(model, [batch_for(1, 0)])) / 2
+        gs = GradSync(model, bucket_bytes=64 * 1024).attach(model)   # small buckets: several prefix launches inside the backward
+        out, _ = model(**batch_for(rank, 0))
+        out.loss.backward()
+        gs.finish()
+        got = model.store.grad.clone()
+        res["gradsync_cos"] = _cos(got, want)
+        res["gradsync_maxdiff"] = float((got - want).abs().max() / (want.abs().max() + 1e-30))
+        for p in model.parameters():
+            p.grad = None
+        # ---- 2. gradient accumulation k = 2 through train_step == mean over ranks of (g(b0) + g(b1)) / 2 -------------
+        want = (local_grad(model, [batch_for(0, 0), batch_for(0, 1)], 0.5) + local_grad(model, [batch_for(1, 0), batch_for(1, 1)], 0.5)) / 2
+
+        class _NoStep:   # keeps the accumulated buffer for inspection
+            def step(self): pass
+            def zero_grad(self): pass
+        train_step(model, batch_for(rank, 0), _NoStep(), None, gs, gradient_accumulation_steps=2, do_step=False)
+        train_step(model, batch_for(rank, 1), _NoStep(), None, gs, gradient_accumulation_steps=2, do_step=True)
+        got = model.store.grad.clone()
+        res["accum_cos"] = _cos(got, want)
+        res["accum_maxdiff"] = float((got - want).abs().max() / (want.abs().max() + 1e-30))
+        for p in model.parameters():
+            p.grad = None
+        # ---- 3. three optimizer steps, uneven shards: rank 0 has 4 batches, rank 1 only 3 -> both stop after 3 ------------
+        opt = SlamAdamW(model, lr=1e-3)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: min((s + 1) / 2, 1.0))
+        n_mine, steps = (4 if rank == 0 else 3), 0
+        for i in range(5):
+            if not all_ranks_have_data(i < n_mine, dev):
+                break
+            train_step(model, batch_for(rank, i), opt, sched, gs)
+            steps += 1
+        res["steps_run"] = steps
+        flat = model.store.flat.clone()
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        res["params_equal_across_ranks"] = bool(torch.equal(both[0], both[1]))
+        res["params_moved"] = float((flat - SlamHipModel(dict(cfg), dev).load_weights(W).store.flat).abs().max())
+
+        # ---- 4. the same through DistributedDataParallel (what the reference's pipeline does) ----------------------------
+        m2 = SlamHipModel(dict(cfg), dev, autograd_params=True).load_weights(W)
+        m2.train()
+        m2 = m2.cuda(0)                                    # finetune.py:181 `model.cuda(local_rank)` must keep the flat views
+        assert next(iter(m2.store.params.values())).data_ptr() == m2.store.flat.data_ptr()
+        ddp = torch.nn.parallel.DistributedDataParallel(m2, device_ids=[0], find_unused_parameters=False)
+        assert ddp.module is m2
+        names = [n for n, _ in ddp.module.named_parameters()]
+        res["ddp_has_reference_keys"] = ("encoder_projector.linear1.weight" in names and
+                                         any(n.endswith("layers.0.self_attn.q_proj.lora_A.default.weight") for n in names))
+        want = (local_grad(model_ref := SlamHipModel(dict(cfg), dev).load_weights(W).train(), [batch_for(0, 0)])
+                + local_grad(model_ref, [batch_for(1, 0)])) / 2
+        out, _ = ddp(**batch_for(rank, 0))
+        out.loss.backward()
+        got = torch.zeros_like(want)
+        for name, p in m2.store.params.items():
+            off, n, shape = m2.store.offsets[name]
+            got[off:off + n] = p.grad.flatten()
+        mask = torch.zeros_like(want, dtype=torch.bool)
+        for name in m2.store.params:
+            off, n, _ = m2.store.offsets[name]
+            mask[off:off + n] = True
+        res["ddp_cos"] = _cos(got[mask], want[mask])
+        res["ddp_maxdiff"] = float((got[mask] - want[mask]).abs().max() / (want[mask].abs().max() + 1e-30))
+        # reference optimizer on .parameters() (finetune.py:247-251), 3 steps, grad accumulation 2 on the way
+        topt = torch.optim.AdamW(ddp.parameters(), lr=1e-3, weight_decay=0.0)
+        topt.zero_grad()
+        losses = []
+        for i in range(3):
+            for micro in range(2):
+                out, _ = ddp(**batch_for(rank, (i + micro) % 3))
+                (out.loss / 2).backward()
+            topt.step()
+            topt.zero_grad()
+            losses.append(float(out.loss.detach()))
+        flat2 = m2.store.flat.clone()
+        both = [torch.empty_like(flat2) for _ in range(world)]
+        dist.all_gather(both, flat2)
+        res["ddp_params_equal_across_ranks"] = bool(torch.equal(both[0], both[1]))
+        res["ddp_losses_finite"] = all(l == l and abs(l) < 1e4 for l in losses)
+        # SlamAdamW on a DDP-reduced model (gathers whatever autograd left in .grad)
+        sopt = SlamAdamW(m2, lr=1e-3)
+        out, _ = ddp(**batch_for(rank, 0))
+        out.loss.backward()
+        sopt.step()
+        sopt.zero_grad()
+        flat3 = m2.store.flat.clone()
+        both = [torch.empty_like(flat3) for _ in range(world)]
+        dist.all_gather(both, flat3)
+        res["ddp_slamadamw_equal"] = bool(torch.equal(both[0], both[1])) and bool((flat3 != flat2).any())
+        torch.cuda.synchronize()
+        q.put((rank, res, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as ex:  # noqa: BLE001
+        import traceback
+        q.put((rank, {}, traceback.format_exc() + repr(ex)))
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_real_model_gradsync_and_ddp(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=800) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, res, err in results:
+        assert err is None, f"rank {rank}:\n{err}"
+    for rank, res, _ in results:
+        assert res["gradsync_cos"] >= 0.9999 and res["gradsync_maxdiff"] < 2e-2, (rank, res)
+        assert res["accum_cos"] >= 0.9999 and res["accum_maxdiff"] < 2e-2, (rank, res)
+        assert res["steps_run"] == 3, (rank, res)
+        assert res["params_equal_across_ranks"] and res["params_moved"] > 0, (rank, res)
+        assert res["ddp_has_reference_keys"], (rank, res)
+        assert res["ddp_cos"] >= 0.9999 and res["ddp_maxdiff"] < 2e-2, (rank, res)
+        assert res["ddp_params_equal_across_ranks"] and res["ddp_losses_finite"] and res["ddp_slamadamw_equal"], (rank, res)
+    for p in procs:
+        assert p.exitcode == 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launches_two_ranks_on_one_gpu(dev):
+    """`python bench.py --gpus 2` without a torchrun environment (it used to assert out): spawns its ranks itself;
+    on a 1-GPU box they share the device over gloo.  Tiny clip count: this is the launch path, not a measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for extra in ([], ["--ddp"]):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c1",
+                            "--clips", "2", "--no-cpu-baseline"] + extra, capture_output=True, text=True, env=env, timeout=800)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        out = json.loads(line)
+        assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
+        assert out["config"]["global_batch_clips"] == 4

@@ -171,7 +171,7 @@ def test_kaldi_ark_multitask_dataset_matches_reference_layout(tmp_path):
     assert rate == 16000 and np.array_equal(pcm, clips[1])
     tok = SimpleNamespace(encode=lambda text: [3 + (ord(c) % 50) for c in text], eos_token_id=2, pad_token_id=0)
     cfg = dict(multitask_prompt_path=str(tmp_path / "multiprompt.jsonl"), train_scp_file_path=str(tmp_path), append_info_tasks=["hotword"],
-               prompt_style="USER: {}\n ASSISTANT:", pad_or_trim=False, max_audio_length=30)
+               prompt_style="USER: {}\n ASSISTANT:", pad_or_trim=False, max_audio_length=30, input_type="mel")
     ds = get_speech_dataset(cfg, tok, "train")
     assert isinstance(ds, MultiTaskDatasetRaw)
     samples = list(ds)
@@ -196,3 +196,56 @@ def test_kaldi_ark_multitask_dataset_matches_reference_layout(tmp_path):
     # rank 1 of 2 (one DataLoader worker each) sees the odd lines only
     ds._shard = lambda: (2, 1)
     assert [s["audio"].shape[0] for s in ds] == [4000]
+
+
+def test_rank_worker_sharding_reproduces_the_reference_including_its_skip_quirk(tmp_path):
+    """tests/golden/shard.json = the reference's own MultiTaskDataset.__iter__ (speech_dataset_large.py:62-156, exec'd
+    unmodified by oracle/make_golden_shard.py) at world x workers = 1x1, 2x1, 2x2 over a file with too-long clips mid-file:
+    the `continue` at :92-93 skips `data_index += 1`, so the dropping worker lags one line afterwards (duplicates its
+    neighbour's lines).  The product must yield exactly the same utterances per (rank, worker), and the same token layout;
+    `fix_shard_skip=true` is the documented deviation (disjoint shards)."""
+    import json
+    from slam_llm_amd.dataset import MultiTaskDatasetRaw, MultiTaskDynamicBatchDatasetRaw, get_speech_dataset
+    fx = json.load(open(G.GOLD + "/shard.json"))
+    ark = tmp_path / "wav.ark"
+    with open(ark, "wb") as f, open(tmp_path / "multitask.jsonl", "w") as j:
+        for i, sec in enumerate(fx["seconds"]):
+            pcm = (np.arange(int(sec * 16000)) % 7).astype(np.int16)
+            f.write(f"utt{i} ".encode())
+            off = f.tell()
+            f.write(_riff(pcm))
+            j.write(json.dumps({"key": f"utt{i}", "task": "ASR", "target": f"text {i}", "path": f"{ark}:{off}"}) + "\n")
+    (tmp_path / "multiprompt.jsonl").write_text(json.dumps({"task": "ASR", "prompt": "Transcribe."}) + "\n")
+
+    class Tok:
+        eos_token_id, pad_token_id = 2, 0
+
+        def encode(self, text):
+            return [1] + [3 + ord(c) % 50 for c in text]
+    cfg = dict(multitask_prompt_path=str(tmp_path / "multiprompt.jsonl"), train_scp_file_path=str(tmp_path), append_info_tasks=[],
+               prompt_style="USER: {}\n ASSISTANT:", pad_or_trim=False, max_audio_length=30, input_type="mel", inference_mode=True)
+    for key, want in fx["shards"].items():
+        shape, rank, wid = key.split(":")
+        world, workers = (int(x) for x in shape.split("x"))
+        ds = MultiTaskDatasetRaw(cfg, Tok(), "train")
+        ds._shard = lambda: (world * workers, int(rank) * workers + int(wid))
+        assert [s["key"] for s in ds] == want, key
+    # the documented fix: disjoint shards that together cover every kept utterance exactly once
+    kept = fx["shards"]["1x1:0:0"]
+    seen = []
+    for r in range(4):
+        ds = MultiTaskDatasetRaw(dict(cfg, fix_shard_skip=True), Tok(), "train")
+        ds._shard = lambda: (4, r)
+        seen += [s["key"] for s in ds]
+    assert sorted(seen, key=lambda k: int(k[3:])) == kept
+    # training-mode token layout (prompt + answer tokenised as one string, :137-151) == the reference's samples
+    ds = MultiTaskDatasetRaw(dict(cfg, inference_mode=False), Tok(), "train")
+    for s, ref in zip(ds, fx["layout"]):
+        assert s["input_ids"].tolist() == ref["input_ids"] and s["labels"].tolist() == ref["labels"] and s["audio_length"] == ref["audio_length"]
+    # the plugin entry returns the dynamic-batch wrapper (speech_dataset_large.py:265-271): lists of samples + .collator, the
+    # DataLoader contract of utils/config_utils.py:94-99 (batch_size=None, collate_fn=dataset.collator)
+    dsw = get_speech_dataset(dict(cfg, inference_mode=False, train_max_frame_length=400), Tok(), "train")
+    assert isinstance(dsw, MultiTaskDynamicBatchDatasetRaw)
+    batches = list(torch.utils.data.DataLoader(dsw, batch_size=None, collate_fn=dsw.collator))
+    assert sum(b["input_ids"].shape[0] for b in batches) == len(kept)
+    assert all(b["input_ids"].shape[0] * b["input_ids"].shape[1] <= 400 or b["input_ids"].shape[0] == 1 for b in batches)

@@ -16,11 +16,17 @@ from tests import golden_util as G
 pytestmark = pytest.mark.gpu
 
 
-def build(cfg, dev):
+def build(cfg, dev, chunk_rows=None):
     from slam_llm_amd.model import SlamHipModel
     W = O.init_weights(cfg, seed=42)
     model = SlamHipModel(dict(cfg, lora_dropout=0.0), dev).load_weights(W)
+    model.llm.lm_head_chunk_rows = chunk_rows   # rows per lm_head / CE chunk (None: one 1 GB-buffer-derived chunk at these sizes)
     return model, W
+
+
+# the lm_head + CE + dh pipeline runs in row chunks (3 at the headline C3 shape); 16 rows forces >= 3 chunks (with a ragged
+# last one) at fixture dims so the chunk bookkeeping (row_loss / dhN / logits slices) is pinned by the reference fixtures
+CHUNKS = [None, 16]
 
 
 def batch_from_fixture(fx, dev):
@@ -34,11 +40,12 @@ def rel_err(got, ref):
     return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
 
 
+@pytest.mark.parametrize("chunk", CHUNKS)
 @pytest.mark.parametrize("name", list(CASES))
-def test_forward_matches_reference_fixture(dev, name):
+def test_forward_matches_reference_fixture(dev, name, chunk):
     fx = G.load(name)
     cfg = CASES[name]["cfg"]
-    model, W = build(cfg, dev)
+    model, W = build(cfg, dev, chunk)
     model.train()
     b = batch_from_fixture(fx, dev)
     enc = model.encoder.forward_btc(b["audio_mel"].float().contiguous())
@@ -63,12 +70,16 @@ def test_forward_matches_reference_fixture(dev, name):
     assert abs(float(acc) - float(fx["acc.0"])) <= 1.0 / max(1, int((b['labels'][:, 1:] != -100).sum()))
 
 
+@pytest.mark.parametrize("chunk", CHUNKS)
 @pytest.mark.parametrize("name", list(CASES))
-def test_gradients_and_training_steps_match_reference(dev, name):
+def test_gradients_and_training_steps_match_reference(dev, name, chunk):
     from slam_llm_amd.model import SlamAdamW
     fx = G.load(name)
     cfg = CASES[name]["cfg"]
-    model, W = build(cfg, dev)
+    model, W = build(cfg, dev, chunk)
+    if chunk:
+        b0 = batch_from_fixture(fx, dev)
+        assert b0["input_ids"].numel() > 2 * chunk, "fixture too small to force three lm_head chunks"
     model.train()
     b = batch_from_fixture(fx, dev)
     opt = SlamAdamW(model, lr=1e-2, weight_decay=0.01)
@@ -397,14 +408,81 @@ def test_generate_matches_reference_tokens(dev, scale):
     eos = int(fx[f"s{scale}.eos"])
     for nb, lp, pad, rp in GEN_RUNS:
         if rp != 1.0:
-            # the repetition penalty pulls repeated tokens towards their runners-up: ranking margins shrink below bf16
-            # logit noise, exact token equality with the fp32 reference is not a property of a bf16 path.  The processor
-            # itself is pinned bit-exactly on the CPU (tests/test_host_logic.py, product bookkeeping on fp32 logits).
-            continue
+            continue   # margin-aware comparison: test_generate_with_repetition_penalty_margin_aware
         got = model.generate(**{k: v.clone() for k, v in b.items()}, max_new_tokens=C["max_new_tokens"], num_beams=nb,
                              length_penalty=lp, eos_token_id=eos, pad_token_id=pad, repetition_penalty=rp)
         want = fx[gen_key(scale, nb, lp, pad, rp)]
         assert tuple(got.shape) == want.shape and (got.cpu().numpy() == want).all(), (nb, lp, pad, got, want)
+
+
+@pytest.mark.parametrize("scale", [24.0, 5.0])
+def test_generate_with_repetition_penalty_margin_aware(dev, scale):
+    """the two `repetition_penalty=1.3` fixture runs of the reference's generate (greedy and beam 4) on the HIP path.
+    The penalty pulls an already-emitted token towards its runner-up, so some decisions have fp32 margins below the bf16
+    logit noise and bit-equality with the fp32 reference is not a property of a bf16 path THERE.  Margin-aware statement:
+      * noise = measured |HIP - oracle| on the prompt's next-token logits (x3 safety);
+      * greedy: a row must equal the reference token for token up to (excluding) the first step whose fp32 top-2 margin is
+        below 2 x noise; rows that never get that close must match completely;
+      * beam 4: an item either reproduces the reference hypothesis or returns one whose fp32 score (sum of processed
+        log-probs / length**length_penalty, teacher-forced through the oracle) is within the noise of the reference's."""
+    from tests.test_oracle_golden import gen_key
+    C, fx, W, model, b = _generate_setup(dev, scale)
+    cfg, eos, L = C["cfg"], int(fx[f"s{scale}.eos"]), C["max_new_tokens"]
+    cpu = {k: v.cpu() for k, v in b.items()}
+    enc = O.whisper_encoder(W, cfg, cpu["audio_mel"].permute(0, 2, 1))
+    emb_w = W["llm.base_model.model.model.embed_tokens.weight"]
+    embeds_ref = O.embed_splice(emb_w, cpu["input_ids"].clone(), cpu["modality_mask"].bool(), O.projector_concat(W, enc, cfg["ds_rate"]))
+    mask = cpu["attention_mask"].long()
+
+    def ref_logits(toks):       # [B, t] -> fp32 next-token logits [B, V]
+        x = torch.cat([embeds_ref, F.embedding(toks, emb_w)], dim=1)
+        m = torch.cat([mask, torch.ones_like(toks)], dim=1)
+        return O.llama_forward(W, cfg, x, m, None, position_ids=O.generate_position_ids(m))[1][:, -1, :]
+
+    embeds, am = model(**{k: v.clone() for k, v in b.items()}, inference_mode=True)
+    B, T, d = embeds.shape
+    lg0, _ = model.llm.prefill(embeds.reshape(B * T, d), B, T, am, L)
+    noise = 3.0 * float((lg0.float().cpu() - ref_logits(torch.zeros((B, 0), dtype=torch.int64))).abs().max())
+    compared = 0
+    # ---- greedy
+    trace = []
+    want = O.slam_generate(W, cfg, {k: v.clone() for k, v in cpu.items()}, max_new_tokens=L, num_beams=1, eos=eos, pad=1,
+                           repetition_penalty=1.3, trace=trace)
+    assert (want.numpy() == fx[gen_key(scale, 1, 1.0, 1, 1.3)]).all()
+    got = model.generate(**{k: v.clone() for k, v in b.items()}, max_new_tokens=L, num_beams=1, eos_token_id=eos, pad_token_id=1,
+                         repetition_penalty=1.3).cpu()
+    margins = torch.stack([t["margin"] for t in trace])          # [steps, B]
+    for r in range(B):
+        close = (margins[:, r] < 2 * noise).nonzero()
+        upto = int(close[0]) if close.numel() else want.shape[1]
+        assert got.shape[1] >= min(upto, want.shape[1]) and torch.equal(got[r, :upto], want[r, :upto]), (scale, r, upto, got[r], want[r])
+        compared += upto
+    # ---- beam 4
+    want = torch.from_numpy(fx[gen_key(scale, 4, 1.0, 1, 1.3)])
+    got = model.generate(**{k: v.clone() for k, v in b.items()}, max_new_tokens=L, num_beams=4, length_penalty=1.0, eos_token_id=eos,
+                         pad_token_id=1, repetition_penalty=1.3).cpu()
+
+    def score(seq_rows):        # teacher-forced fp32 score of one hypothesis per item
+        n = seq_rows.shape[1]
+        total, length, alive = torch.zeros(B), torch.zeros(B), torch.ones(B, dtype=torch.bool)
+        for t in range(n):
+            lp = O._repetition_penalty(F.log_softmax(ref_logits(seq_rows[:, :t]).float(), -1), seq_rows[:, :t], 1.3)
+            tok = seq_rows[:, t]
+            total += torch.where(alive, lp.gather(1, tok[:, None])[:, 0], torch.zeros(B))
+            length += alive.float()
+            alive = alive & (tok != eos)
+        return total / length.clamp(min=1)
+    n = max(got.shape[1], want.shape[1])
+    pad_to = lambda x: torch.cat([x, torch.full((B, n - x.shape[1]), 1, dtype=torch.int64)], 1)  # noqa: E731
+    got_p, want_p = pad_to(got), pad_to(want)
+    s_got, s_want = score(got_p), score(want_p)
+    for r in range(B):
+        if torch.equal(got_p[r], want_p[r]):
+            compared += n
+        else:
+            assert float(s_got[r]) >= float(s_want[r]) - 2 * noise, (scale, r, float(s_got[r]), float(s_want[r]), noise, got[r], want[r])
+    assert compared > 0, "nothing was comparable: the margin criterion is vacuous on this fixture"
+    print(f"rp=1.3 scale {scale}: noise {noise:.4f}, token positions compared exactly: {compared}")
 
 
 def test_kv_cache_decode_logits_match_oracle_teacher_forced(dev):
