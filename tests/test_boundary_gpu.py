@@ -18,8 +18,8 @@ TINY_ARCH = dict(enc_dim=128, enc_heads=2, enc_layers=2, n_mels=80, llm_dim=128,
                  llm_head_dim=64, llm_ffn=256, vocab=512)
 
 
-def _tiny_recipe(**train_over):
-    return recipe_configs("asr_librispeech",
+def _tiny_recipe(peft=None, **train_over):
+    return recipe_configs("asr_librispeech", peft=peft,
                           model=dict(file=PLUGIN + ":model_factory", encoder_name="whisper", encoder_path="/ckpt/whisper/tiny.pt",
                                      llm_name="tinyllama-1.1b", encoder_dim=128, llm_dim=128, arch_overrides=TINY_ARCH, random_init=True),
                           train=dict(use_peft=True, freeze_encoder=True, freeze_llm=True, **train_over))
@@ -68,7 +68,7 @@ def test_model_factory_train_step_and_inference_batch(dev, tmp_path):
 def test_enable_ddp_recipe_flag_selects_autograd_params(dev):
     get_factory, _, _ = loaders()
     import logging
-    tc, mc, _ = _tiny_recipe(enable_ddp=True)
+    tc, mc, _ = _tiny_recipe(peft=dict(lora_dropout=0.0), enable_ddp=True)   # dropout off: two backward passes must be identical
     model, _ = get_factory(mc, logging.getLogger("t"))(tc, mc)
     assert model.autograd_params is True
     model.train()
