@@ -24,6 +24,9 @@
 
 namespace {
 
+// tools only: shader-clock / real-time stamps of workgroup 0 (effective clock of a launch = d(shader cycles) / d(100 MHz ticks))
+__device__ unsigned long long g_clk_probe[4];
+
 struct GemmParams {
   const bf16_t* A;
   const bf16_t* B;
@@ -48,6 +51,11 @@ constexpr int ROWB = BK * 2;     // 128 bytes per LDS row
 __device__ __forceinline__ void glds16(const bf16_t* g, char* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ... offen lds): 32-bit per-lane byte offset, range-checked
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t srd, unsigned voff, char* l) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)l, 16, (int)voff, 0, 0, 0);
 }
 
 // exact-erf GELU.  erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16 output rounding):
@@ -263,8 +271,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
   constexpr int NIA = BM / 8 / NW;
   constexpr int NIB = BN / 8 / NW;
   static_assert(BK == 64, "two 32-deep phases per K-tile");
+  // VAR: 0/1 schedule A/B reference (1 = shipped); 20/30/40/50 = timing ablations used by tools/gemm_bench.py
+  // (no DMA / no fragment reads / neither / DMA never waited for: wrong results by design)
+  constexpr bool NODMA = (VAR == 20 || VAR == 40), NOFRAG = (VAR == 30 || VAR == 40);
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_clk_probe[0] = __builtin_readcyclecounter();
+    g_clk_probe[1] = wall_clock64();
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -349,12 +364,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
   __syncthreads();
   if (nt > 1) stage(1, 1);
   load_frags(smem, 0, a0, b0);
+  if constexpr (NOFRAG) load_frags(smem, 1, a1, b1);
 
   for (int t = 0; t < nt; t++) {
     const int cur = t & 1;
     const char* st = smem + cur * STAGE;
     // ---- phase A: ks = 0 MFMAs, prefetch ks = 1 fragments of this tile ----
-    load_frags(st, 1, a1, b1);
+    if constexpr (!NOFRAG) load_frags(st, 1, a1, b1);   // VAR >= 20: timing ablations (wrong results by design, tools only)
 #pragma unroll
     for (int i = 0; i < FM; i++)
 #pragma unroll
@@ -366,13 +382,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     }
     if constexpr (VAR >= 1) __builtin_amdgcn_sched_barrier(0);  // keep phase A's MFMAs in front of the barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (VAR == 50) {   // ablation: DMA issued but never waited for (reads race with it: wrong results)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     // ---- phase B: ks = 1 MFMAs, DMA of tile t+2 into the stage just released, ks = 0 fragments of tile t+1 ----
     // branch-free tail: past the last tile the DMA re-fetches tile nt-1 into the (already released) stage and the
     // fragment prefetch reads data nobody consumes -- keeps the whole iteration one schedulable basic block
-    stage(min(t + 2, nt - 1), cur);
-    load_frags(smem + (cur ^ 1) * STAGE, 0, a0, b0);
+    if constexpr (!NODMA) stage(min(t + 2, nt - 1), cur);
+    if constexpr (!NOFRAG) load_frags(smem + (cur ^ 1) * STAGE, 0, a0, b0);
 #pragma unroll
     for (int i = 0; i < FM; i++)
 #pragma unroll
@@ -391,18 +412,28 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
     }
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_clk_probe[2] = __builtin_readcyclecounter();
+    g_clk_probe[3] = wall_clock64();
+  }
   gemm_epilogue<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, frow, fg);
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Persistent variant of the pipelined kernel: one workgroup per CU walks a strided list of output tiles and treats
-// (tile, k-tile) as ONE stream -- the DMA of the next tile's first two k-tiles is issued in the last two phase-B
-// slots of the current tile and its first fragments are read before the epilogue, so the pipeline never drains:
-// no exposed prologue (2 dependent HBM/L2 round trips per tile) and the epilogue's stores retire under the next
-// tile's MFMAs.  Pays most on short-K products (Whisper K = 1280: 20 k-tiles per tile).
+// Persistent variant of the pipelined kernel (auto rule: K <= 2048): one workgroup per CU walks a strided list of output
+// tiles and treats (tile, k-tile) as ONE stream -- the DMA of the next tile's first two k-tiles is issued in the last two
+// phase-B slots of the current tile and its first fragments are read right after the epilogue, so the pipeline never
+// drains: no exposed prologue (2 dependent HBM/L2 round trips per tile) and the epilogue's stores retire under the next
+// tile's MFMAs.  The LDS-DMA goes through buffer descriptors (buffer_load_dwordx4 ... offen lds): the per-lane part of every source
+// address is ONE 32-bit byte offset per operand computed before the loop, the tile / k-tile / row-group part is a scalar
+// added to it (1 VALU per 1 KiB DMA instead of the ~4 of a clamped 64-bit pointer), and rows past M / N are handled by the
+// descriptor's bounds check (they read as zeros) instead of per-lane clamps.  The byte offset is carried in the VGPR
+// offset, which the hardware range-checks against num_records (the SGPR offset is not part of that check on gfx9).
+// Requires (M + BM) * lda * 2 < 2^32 and (N + BN) * ldb * 2 < 2^32 (the launcher falls back to the one-tile kernel otherwise).
 // ------------------------------------------------------------------------------------------------------------
+
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_persist_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_persist2_kernel(GemmParams p, unsigned bytes_a, unsigned bytes_b) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int FM = WTM / 16, FN = WTN / 16;
@@ -420,11 +451,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_persist_kernel(GemmParams
   const int srow = lane >> 3;
   const int schunk = (lane & 7) ^ srow;
 
+  const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, bytes_a, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, bytes_b, 0x00020000);
+  const unsigned lda2 = (unsigned)p.lda * 2u, ldb2 = (unsigned)p.ldb * 2u;   // row pitch in bytes
+  // per-lane byte offset of this lane's 16-byte chunk inside an 8-row DMA group (the swizzle lives in the SOURCE chunk)
+  const unsigned voff_a = (unsigned)(wave * 8 + srow) * lda2 + (unsigned)schunk * 16u;
+  const unsigned voff_b = (unsigned)(wave * 8 + srow) * ldb2 + (unsigned)schunk * 16u;
+
   auto tile_origin = [&](int vbid, int& m0, int& n0) {  // same XCD-aware bijection as the one-tile kernels
     const int xcd = vbid & 7, q = nwg >> 3, r = nwg & 7;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int bid = base + (vbid >> 3);
-    constexpr int GM = 8;
+    const int GM = p.group_m;
     const int per_group = GM * p.tiles_n;
     const int group = bid / per_group;
     const int first_m = group * GM;
@@ -433,32 +471,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_persist_kernel(GemmParams
     m0 = (first_m + within % gsz) * BM;
     n0 = (within / gsz) * BN;
   };
-  // DMA source addresses are recomputed from the (uniform) tile origin at every issue instead of living in 16 VGPRs:
-  // ~4 VALU per 16-byte DMA, hidden under the MFMAs, and the same code serves the current and the next tile
-  // (the choice is a scalar select -> the k-loop stays one basic block).  32-bit element offsets: < 2^31 elements.
-  const int lrow = wave * 8 + srow;          // this lane's row inside an 8-row DMA group sequence (j * NW * 8 apart)
-  const int lcol = schunk * 8;
   auto stage = [&](int mo, int no, int kt, int s) {
     char* sa = smem + s * STAGE;
     char* sb = sa + BM * ROWB;
-    const int koff = kt * BK + lcol;
+    // scalar parts, pinned to SGPRs (readfirstlane also stops the compiler from re-associating them into a per-lane multiply)
+    const unsigned sa0 = __builtin_amdgcn_readfirstlane((unsigned)mo * lda2 + (unsigned)kt * (BK * 2));
+    const unsigned sb0 = __builtin_amdgcn_readfirstlane((unsigned)no * ldb2 + (unsigned)kt * (BK * 2));
 #pragma unroll
-    for (int j = 0; j < NIA; j++) {
-      const int r = min(mo + j * NW * 8 + lrow, p.M - 1);
-      glds16(p.A + ((int64_t)r * p.lda + koff), sa + (j * NW + wave) * 1024);
-    }
+    for (int j = 0; j < NIA; j++)
+      blds16(srd_a, voff_a + __builtin_amdgcn_readfirstlane(sa0 + (unsigned)(j * NW * 8) * lda2), sa + (j * NW + wave) * 1024);
 #pragma unroll
-    for (int j = 0; j < NIB; j++) {
-      const int r = min(no + j * NW * 8 + lrow, p.N - 1);
-      glds16(p.B + ((int64_t)r * p.ldb + koff), sb + (j * NW + wave) * 1024);
-    }
+    for (int j = 0; j < NIB; j++)
+      blds16(srd_b, voff_b + __builtin_amdgcn_readfirstlane(sb0 + (unsigned)(j * NW * 8) * ldb2), sb + (j * NW + wave) * 1024);
   };
 
   const int frow = lane & 15;
   const int fg = lane >> 4;
-  // fragment addresses: row = (wave tile base) + i*16 + frow, so (row & 7) == (frow & 7) for every fragment and the
-  // i / j dependence is a compile-time multiple of 16 rows -> two base registers + immediate offsets (the generic
-  // per-fragment offset/swizzle arrays of the one-tile kernel cost 24 VGPRs the persistent loop cannot afford)
   static_assert(WTM % 8 == 0 && WTN % 8 == 0, "wave tile bases must keep row & 7 == frow & 7");
   const int a_base = (wm * WTM + frow) * ROWB;
   const int b_base = BM * ROWB + (wn * WTN + frow) * ROWB;
@@ -494,9 +522,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_persist_kernel(GemmParams
 #pragma unroll
       for (int j = 0; j < FN; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // one k-tile of the stream; LAST = the tile's final k-tile: the next tile's first fragments are NOT prefetched into
-    // a0/b0 there (48 VGPRs that would have to survive the epilogue next to the 128 accumulators -> spills); they are
-    // read right after the epilogue instead, from a stage whose DMA completed one barrier earlier.
     auto ktile = [&](int t, auto last_tag) {
       constexpr bool LAST = decltype(last_tag)::value;
       const int cur = par;
@@ -515,7 +540,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_persist_kernel(GemmParams
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      // stream position t+2: still this tile, or k-tile 0 / 1 of the next one (scalar selects, no branch)
       const bool nx = t + 2 >= nt;
       stage(nx ? m1 : m0, nx ? n1 : n0, nx ? t + 2 - nt : t + 2, cur);
       if constexpr (!LAST) load_frags(smem + (cur ^ 1) * STAGE, 0, a0, b0);
@@ -572,13 +596,13 @@ int launch_gemm(GemmParams& p, hipStream_t stream) {
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_gemm_persist(GemmParams& p, hipStream_t stream) {
+int launch_gemm_persist2(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   constexpr int lds = 2 * (BM + BN) * ROWB;
   static bool attr_set = false;
   static int n_cu = 0;
-  auto kern = gemm_nt_persist_kernel<BM, BN, WM, WN>;
+  auto kern = gemm_nt_persist2_kernel<BM, BN, WM, WN>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
@@ -594,11 +618,19 @@ int launch_gemm_persist(GemmParams& p, hipStream_t stream) {
     n_cu = prop.multiProcessorCount;
     attr_set = true;
   }
+  // exact extents of the two operand views: rows past the end are out of range for the descriptor and read as zeros
+  const uint64_t bytes_a = ((uint64_t)(p.M - 1) * (uint64_t)p.lda + (uint64_t)p.K) * 2ull;
+  const uint64_t bytes_b = ((uint64_t)(p.N - 1) * (uint64_t)p.ldb + (uint64_t)p.K) * 2ull;
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   const int64_t grid = nwg < n_cu ? nwg : n_cu;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), lds, stream, p);
-  SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(persistent)");
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), lds, stream, p, (unsigned)bytes_a, (unsigned)bytes_b);
+  SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(persistent, descriptor DMA)");
   return 0;
+}
+
+// the descriptor form addresses every byte of a (row-padded) operand with 32 bits
+static inline bool fits_descriptor(int64_t rows, int64_t ld, int tile) {
+  return (uint64_t)(rows + tile) * (uint64_t)ld * 2ull < (1ull << 32);
 }
 
 int g_gemm_cfg = 0;  // 0 = auto
@@ -612,8 +644,18 @@ extern "C" int slam_gemm_set_group_m(int group_m) {   // tuning knob (tools): ra
   return 0;
 }
 
+extern "C" int slam_gemm_debug_clock(unsigned long long* out4) {   // tools: stamps of the last pipelined-kernel launch (sync first)
+  SLAM_CHECK_ARG(out4 != nullptr, "slam_gemm_debug_clock: null output");
+  hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_clk_probe), 4 * sizeof(unsigned long long));
+  if (e != hipSuccess) {
+    slam_set_error("slam_gemm_debug_clock: %s", hipGetErrorString(e));
+    return -2;
+  }
+  return 0;
+}
+
 extern "C" int slam_gemm_set_config(int cfg) {
-  SLAM_CHECK_ARG(cfg >= 0 && cfg <= 7, "slam_gemm_set_config: cfg %d out of range [0,7]", cfg);
+  SLAM_CHECK_ARG(cfg >= 0 && cfg <= 11, "slam_gemm_set_config: cfg %d out of range [0,11]", cfg);
   g_gemm_cfg = cfg;
   return 0;
 }
@@ -663,8 +705,11 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     // time in units of "one CU doing one 128x128 tile": a 256x256 round = 4 tiles of work at ~1.3-1.4x speed (ties go to the big tile)
     const double t256 = (double)((tiles256 + 255) / 256) * (4.0 / 1.4);
     const double t128 = (double)((tiles128 + 511) / 512) * 2.0;
+    // the persistent form (next tile's first two k-tiles DMA'd under the current tile's tail, no pipeline drain between
+    // tiles) pays on short-K products, where prologue + epilogue are a visible share of a tile: +3-4 % at K = 1280
+    // (Whisper), +-1 % at K >= 4096 (profiles/r02_gemm_experiments.md)
     if (N <= 64) cfg = 3;
-    else if (t256 < t128) cfg = 6;
+    else if (t256 < t128) cfg = (K <= 2048) ? 7 : 6;
     else cfg = 1;
   }
   switch (cfg) {
@@ -674,9 +719,14 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     case 4: return launch_gemm<256, 256, 2, 4>(p, s);
     case 5: return launch_gemm<256, 256, 2, 4, 0>(p, s);  // pipelined, compiler-placed barrier (A/B reference)
     case 6: return launch_gemm<256, 256, 2, 4, 1>(p, s);  // pipelined, phase A pinned before the barrier (shipped)
-    case 7:                                                // persistent pipelined (needs >= 2 k-tiles)
-      if (p.K < 2 * BK) return launch_gemm<256, 256, 2, 4, 1>(p, s);
-      return launch_gemm_persist<256, 256, 2, 4>(p, s);
+    case 7:                                                // persistent pipelined, descriptor DMA (auto: short-K products)
+      if (p.K < 2 * BK || !fits_descriptor(p.M, p.lda, 256) || !fits_descriptor(p.N, p.ldb, 256)) return launch_gemm<256, 256, 2, 4, 1>(p, s);
+      return launch_gemm_persist2<256, 256, 2, 4>(p, s);
+    // timing ablations of the pipelined loop (tools/gemm_bench.py; results are wrong by design)
+    case 8: return launch_gemm<256, 256, 2, 4, 20>(p, s);   // no DMA in the k-loop
+    case 9: return launch_gemm<256, 256, 2, 4, 30>(p, s);   // no fragment reads in the k-loop
+    case 10: return launch_gemm<256, 256, 2, 4, 40>(p, s);  // neither (MFMA + barrier only)
+    case 11: return launch_gemm<256, 256, 2, 4, 50>(p, s);  // DMA issued but never waited for
   }
   slam_set_error("slam_gemm_bf16_nt: bad config %d", cfg);
   return -1;

@@ -90,7 +90,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if (M <= SKINNY_MAX_M and bias is None and act == ACT_NONE and alpha == 1.0 and not accumulate and res_row_mod == 0
             and _GEMM_CFG == 0):
         return gemm_skinny(a, b, out, residual=residual)  # a few rows (decode): HBM-bound weight-streaming kernel
-    _timed(gemm_kernel_name(M, N) + (f" [{M}x{N}x{K}]" if TIMER_SHAPES else ""), 2.0 * M * N * (k_alg or K),
+    _timed(gemm_kernel_name(M, N, K) + (f" [{M}x{N}x{K}]" if TIMER_SHAPES else ""), 2.0 * M * N * (k_alg or K),
            lambda: call("slam_gemm_bf16_nt", _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, N, K, _p(bias),
                         _p(residual), _ld(residual) if residual is not None else 0, res_row_mod, act, alpha, od,
                         1 if accumulate else 0, _s()),
@@ -120,10 +120,11 @@ def gemm_skinny(a, b, out, residual=None, b2=None, swiglu=False):
 _GEMM_CFG = 0
 _GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
                4: "gemm_nt_kernel<256,256,2,4>", 5: "gemm_nt_pipe_kernel<256,256,2,4,0>",
-               6: "gemm_nt_pipe_kernel<256,256,2,4,1>", 7: "gemm_nt_persist_kernel<256,256,2,4>"}
+               6: "gemm_nt_pipe_kernel<256,256,2,4,1>", 7: "gemm_nt_persist2_kernel<256,256,2,4>",
+               8: "ablate_nodma", 9: "ablate_nofrag", 10: "ablate_mfma_only", 11: "ablate_nowait"}
 
 
-def gemm_kernel_name(M: int, N: int) -> str:
+def gemm_kernel_name(M: int, N: int, K: int = 1 << 30) -> str:
     """which template instance slam_gemm_bf16_nt's auto rule launches for this shape (mirrors gemm_bf16.hip)"""
     cfg = _GEMM_CFG
     if cfg == 0:
@@ -131,7 +132,7 @@ def gemm_kernel_name(M: int, N: int) -> str:
         tiles128 = ((M + 127) // 128) * ((N + 127) // 128)
         t256 = ((tiles256 + 255) // 256) * (4.0 / 1.4)
         t128 = ((tiles128 + 511) // 512) * 2.0
-        cfg = 3 if N <= 64 else (6 if t256 < t128 else 1)
+        cfg = 3 if N <= 64 else ((7 if K <= 2048 else 6) if t256 < t128 else 1)
     return _GEMM_NAMES[cfg]
 
 

@@ -47,6 +47,38 @@ def test_gemm_plain(dev, cfg, M, N, K):
     assert_close(c, ref, atol=2e-2 * math.sqrt(K / 64), rtol=1e-2, what=f"gemm cfg{cfg} {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 1280, 1280), (1500, 520, 1280), (260, 3840, 128), (3000, 5120, 1280)])
+def test_gemm_persistent_descriptor_dma_on_strided_views(dev, M, N, K):
+    """the auto rule sends K <= 2048 products (the Whisper encoder) to the persistent kernel, whose LDS-DMA uses buffer
+    descriptors: operands that are column slices of wider buffers (ld > K), M / N that are not tile multiples (rows past the
+    end must read as zeros through the descriptor's range check, never as the NaNs placed right behind the views), fused
+    epilogues, several tiles per workgroup."""
+    ops = _ops()
+    g = torch.Generator(device=dev).manual_seed(5)
+    a_full = torch.full((M + 300, K + 192), float("nan"), device=dev, dtype=torch.bfloat16)
+    b_full = torch.full((N + 300, K + 64), float("nan"), device=dev, dtype=torch.bfloat16)
+    a_full[:M, 64:64 + K] = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
+    b_full[:N, :K] = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
+    a, b = a_full[:M, 64:64 + K], b_full[:N, :K]
+    assert ops.gemm_kernel_name(M, N, K).startswith("gemm_nt_persist2") or M * N < 128 * 128 * 600
+    bias = torch.randn(N, generator=g, device=dev)
+    res = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16)
+    ref = a.float() @ b.float().T
+    for cfg in (0, 7):
+        ops.gemm_set_config(cfg)
+        try:
+            c = ops.gemm_nt(a, b)
+            assert_close(c, ref, atol=2e-2 * math.sqrt(K / 64), rtol=1e-2, what=f"cfg{cfg} plain")
+            c = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_GELU, residual=res)
+            want = torch.nn.functional.gelu(ref + bias) + res.float()
+            assert_close(c, want, atol=3e-2 * math.sqrt(K / 64), rtol=1e-2, what=f"cfg{cfg} bias+gelu+residual")
+            acc = torch.ones((M, N), device=dev, dtype=torch.float32)
+            ops.gemm_nt(a, b, out=acc, accumulate=True, alpha=0.5)
+            assert_close(acc, 1.0 + 0.5 * ref, atol=1e-3 * math.sqrt(K / 64), rtol=1e-3, what=f"cfg{cfg} fp32 accumulate")
+        finally:
+            ops.gemm_set_config(0)
+
+
 def test_gemm_asymmetric_identity(dev):
     """A = I with an asymmetric B catches row/col swaps in the MFMA output mapping."""
     ops = _ops()
