@@ -68,7 +68,15 @@ int slam_gemm_debug_clock(unsigned long long* out4);
 /* ---- conv front end (src/slam_llm/models/encoder.py:18-19): k=3, pad=1 im2col, stride 1|2 ---------
  * in [B, Tin, C] (f32 or bf16) -> out [B*Tout, Kp] bf16, column j*C + c = in[b, t*stride + j - 1, c]. */
 int slam_conv1d_k3_im2col(const void* in, int in_dtype, void* out, int64_t B, int64_t Tin, int64_t C,
-                          int64_t stride, int64_t Kp, void* stream);
+                          int64_t stride, int64_t Kp, const int32_t* n_valid, void* stream);
+/* n_valid (nullable, [B]): frames at or beyond n_valid[b] read as zero (ragged encoder: each clip sees the zero padding it
+ * would see alone; the reference zero-pads in mel space, speech_dataset_large.py:194-197, and has no length argument). */
+
+/* row gather, bf16: dst[r, 0:width) = src[idx[r]*src_stride + 0:width), idx[r] < 0 -> zeros.  Packs the valid rows of a padded
+ * batch, un-packs them (inverse index), and builds the projector's k-frame windows (models/projector.py:15-23) over a packed
+ * encoder output (width = k*d spans k consecutive rows). */
+int slam_gather_rows_bf16(const void* src, int64_t src_stride, const int32_t* idx, void* dst, int64_t ld_dst, int64_t n,
+                          int64_t width, void* stream);
 
 /* general conv1d im2col (HuBERT/WavLM feature encoder and grouped positional conv, models/slam_model.py:335-341):
  * rows (b*Tin+t) with stride ld_in, channel slice [c0, c0+C) -> out [B*Tout, Kp] bf16, col = j*C + c. */
@@ -124,7 +132,7 @@ int slam_attn_set_fwd_qf(int qf);   /* tuning knob: query fragments (16 rows) pe
 int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, void* O,
                   int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B, int64_t Tq, int64_t Tk,
                   int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
-                  const int32_t* seg_lo, void* stream);
+                  const int32_t* seg_lo, const int32_t* seg_hi, void* stream);
 int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                   const void* Qt, const void* Kt, const void* O, int64_t ldo, const void* dO,
                   int64_t lddo, const void* dOt, const float* LSE, float* Delta, const uint8_t* key_mask,

@@ -24,17 +24,30 @@ def window_class(elem_len: int, buffer_lens: List[int], max_frame_length: int) -
     return (len(buffer_lens) + 1) * max(elem_len, max(buffer_lens)) > max_frame_length
 
 
-def dynamic_batches(samples: Iterable[dict], max_frame_length: int) -> Iterator[List[dict]]:
-    """MultiTaskDynamicBatchDataset.__iter__ (speech_dataset_large.py:244-256)."""
+def dynamic_batches(samples: Iterable[dict], max_frame_length: int, budget: str = "padded") -> Iterator[List[dict]]:
+    """MultiTaskDynamicBatchDataset.__iter__ (speech_dataset_large.py:244-256).
+    budget "padded": the reference's window -- (n + 1) * max_len > max_frame_length closes the batch ("frames" = PADDED LLM
+    positions).  budget "sum": packed-aware window for the varlen path (no pad tokens reach the LLM, `++model_config.varlen`):
+    a batch closes when the SUM of its sequence lengths would exceed max_frame_length, so the budget counts real tokens;
+    `frames_for_hbm()` sizes it from the stash footprint.  Same greedy in-order grouping either way (a stated extension: the
+    reference has only the padded window)."""
+    if budget not in ("padded", "sum"):
+        raise ValueError("frame budget must be 'padded' (reference window_class) or 'sum' (packed-aware)")
     buf: List[dict] = []
+    total = 0
     for elem in samples:
         n = len(elem["input_ids"])
-        if not window_class(n, [len(e["input_ids"]) for e in buf], max_frame_length):
+        if budget == "padded":
+            close = window_class(n, [len(e["input_ids"]) for e in buf], max_frame_length)
+        else:
+            close = len(buf) == 0 or total + n > max_frame_length
+        if not close:
             buf.append(elem)
+            total += n
         else:
             if buf:
                 yield buf
-            buf = [elem]
+            buf, total = [elem], n
     if buf:
         yield buf
 
@@ -117,6 +130,7 @@ def collate(samples: List[dict], pad_token_id: int, left_pad_prompt: bool, n_sam
         out["audio"] = torch.stack([torch.nn.functional.pad(s["audio"][:amax].float(), (0, amax - min(len(s["audio"]), amax)))
                                     for s in samples])
         out["audio_len"] = alen
+    out["audio_len_list"] = [int(x) for x in out["audio_len"]]   # host copy: survives the train loop's tensor-only .to(device)
     if "key" in samples[0]:  # inference-mode batches carry the utterance ids / references (speech_dataset.py:259-273)
         out["keys"] = [s.get("key") for s in samples]
         out["targets"] = [s.get("target") for s in samples]

@@ -151,19 +151,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     lrow[f] = 0.f;
   }
 
-  const int kend = CAUSAL ? min(Tk, qb0 + 4 * QW) : Tk;
+  // packed batches (seg_lo/seg_hi over QUERY rows, both non-decreasing): query q sees keys seg_lo[q] <= k < seg_hi[q]
+  // (and k <= q when causal; the bidirectional form is the ragged Whisper / HuBERT encoder: one clip = one segment).
+  // Keys before the start of the block's first sequence / past the end of its last one are never visible.
+  const bool seg_both = !CAUSAL && p.seg_lo != nullptr;
+  const int kend = CAUSAL ? min(Tk, qb0 + 4 * QW) : (seg_both ? min(Tk, p.seg_hi[(int64_t)b * Tq + min(qb0 + 4 * QW - 1, Tq - 1)]) : Tk);
   const int ntiles = (kend + 63) / 64;
   const float sl2 = p.scale * LOG2E;
-  // packed batches: keys before the start of the tile's first sequence are never visible -> start there
   const int tbeg = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(qb0, Tq - 1)] / 64 : 0;
-  int qlo[QF];
+  int qlo[QF], qhi[QF];
 #pragma unroll
-  for (int f = 0; f < QF; f++) qlo[f] = 0;
-  int lo_wave_max = 0;   // largest sequence start among this wave's 32 queries
+  for (int f = 0; f < QF; f++) {
+    qlo[f] = 0;
+    qhi[f] = 0x7fffffff;
+  }
+  int lo_wave_max = 0;            // largest sequence start among this wave's queries
+  int hi_wave_min = 0x7fffffff;   // smallest sequence end among them
   if (p.seg_lo) {
 #pragma unroll
     for (int f = 0; f < QF; f++) qlo[f] = p.seg_lo[(int64_t)b * Tq + min(qw0 + f * 16 + li, Tq - 1)];
     lo_wave_max = p.seg_lo[(int64_t)b * Tq + min(qw0 + QW - 1, Tq - 1)];
+    if (seg_both) {
+#pragma unroll
+      for (int f = 0; f < QF; f++) qhi[f] = p.seg_hi[(int64_t)b * Tq + min(qw0 + f * 16 + li, Tq - 1)];
+      hi_wave_min = p.seg_hi[(int64_t)b * Tq + min(qw0, Tq - 1)];
+    }
   }
 
   frag_t kreg[KI], vreg[VI];
@@ -226,7 +238,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
     // ---- online softmax (per query = lane&15, replicated over the 4 lane groups) ----
     // interior tiles (no key mask, fully inside [0, Tk), fully below the causal diagonal of this wave) skip all masking
-    const bool tile_full = (p.kmask == nullptr) && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0;
+    const bool tile_full = (p.kmask == nullptr) && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0 &&
+                           k0 + 64 <= hi_wave_min;
     if (tile_full) {
 #pragma unroll
       for (int f = 0; f < QF; f++) {
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int key = k0 + kf * 16 + 4 * g + r;
-            const bool ok = kv[kf][r] && (!CAUSAL || key <= q) && key >= qlo[f];
+            const bool ok = kv[kf][r] && (!CAUSAL || key <= q) && key >= qlo[f] && key < qhi[f];
             const float x = ok ? s[f][kf][r] * sl2 : -INFINITY;
             s[f][kf][r] = x;
             mt = fmaxf(mt, x);
@@ -704,9 +717,10 @@ extern "C" int slam_attn_set_fwd_qf(int qf) {
 extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt,
                              void* O, int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B,
                              int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D,
-                             int causal, float scale, const int32_t* seg_lo, void* stream) {
+                             int causal, float scale, const int32_t* seg_lo, const int32_t* seg_hi, void* stream) {
   SLAM_CHECK_ARG(Q && K && Vt && O, "slam_attn_fwd: null pointer");
-  SLAM_CHECK_ARG(!seg_lo || (causal && Tq == Tk), "slam_attn_fwd: packed sequences (seg_lo) need causal self-attention");
+  SLAM_CHECK_ARG(!seg_lo || Tq == Tk, "slam_attn_fwd: packed sequences (seg_lo) need self-attention");
+  SLAM_CHECK_ARG(!seg_lo || causal || seg_hi, "slam_attn_fwd: bidirectional packed sequences need seg_hi (per query row)");
   if (int rc = check_common("slam_attn_fwd", B, Tq, Tk, Tqp, Tkp, Hq, Hkv, D, causal)) return rc;
   SLAM_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "slam_attn_fwd: leading dims must be multiples of 8");
   AttnParams p = {};
@@ -714,6 +728,7 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = LSE; p.kmask = key_mask;
   p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
   p.seg_lo = seg_lo;
+  p.seg_hi = causal ? nullptr : seg_hi;   // (the causal forward only needs the sequence starts)
   hipStream_t s = (hipStream_t)stream;
   // measured (tools/attn_bwd_bench.py, tools/attn_one.py): D = 128 with two fragments needs 261 VGPRs = one wave per SIMD,
   // one fragment (171 VGPRs, two waves) is 13 % faster at the Llama shape; D = 64 (182 vs 120 VGPRs) prefers two (+5 %)

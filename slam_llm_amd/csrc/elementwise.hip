@@ -181,28 +181,59 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------
 // conv1d(k=3, pad=1, stride s) im2col: in [B, Tin, C] -> out [B*Tout, Kp], col = j*C + c
 // ------------------------------------------------------------------------------------------
+// 8 output columns (16 bytes) per thread; needs C % 8 == 0 (a chunk never straddles two taps) and Kp % 8 == 0.
+// n_valid (nullable, [B]): input frames at or beyond n_valid[b] read as zero -- a clip that is shorter than the batch's
+// padded length then sees exactly the zero padding it would see alone (ragged encoder), whatever sits in the pad rows.
 template <typename TIN>
 __global__ __launch_bounds__(256) void im2col_k3_kernel(const TIN* __restrict__ in, bf16_t* __restrict__ out,
                                                         int B, int Tin, int Tout, int C, int Kp,
-                                                        int stride) {
-  const int64_t total = (int64_t)B * Tout * Kp;
+                                                        int stride, const int* __restrict__ n_valid) {
+  const int KC = Kp / 8;
+  const int64_t total = (int64_t)B * Tout * KC;
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int col = (int)(i % Kp);
-    const int64_t row = i / Kp;
+    const int col = (int)(i % KC) * 8;
+    const int64_t row = i / KC;
     const int t = (int)(row % Tout);
     const int b = (int)(row / Tout);
-    float v = 0.f;
+    u16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = 0;
     if (col < 3 * C) {
       const int j = col / C, c = col % C;
       const int ti = t * stride + j - 1;
-      if (ti >= 0 && ti < Tin) {
-        if constexpr (sizeof(TIN) == 4)
-          v = in[((int64_t)b * Tin + ti) * C + c];
-        else
-          v = bf2f(in[((int64_t)b * Tin + ti) * C + c]);
+      const int lim = n_valid ? min(Tin, n_valid[b]) : Tin;
+      if (ti >= 0 && ti < lim) {
+        if constexpr (sizeof(TIN) == 4) {
+          const float4 a = *reinterpret_cast<const float4*>(in + ((int64_t)b * Tin + ti) * C + c);
+          const float4 d = *reinterpret_cast<const float4*>(in + ((int64_t)b * Tin + ti) * C + c + 4);
+          o[0] = f2bf(a.x); o[1] = f2bf(a.y); o[2] = f2bf(a.z); o[3] = f2bf(a.w);
+          o[4] = f2bf(d.x); o[5] = f2bf(d.y); o[6] = f2bf(d.z); o[7] = f2bf(d.w);
+        } else {
+          o = *reinterpret_cast<const u16x8_t*>(in + ((int64_t)b * Tin + ti) * C + c);
+        }
       }
     }
-    out[i] = f2bf(v);
+    *reinterpret_cast<u16x8_t*>(out + row * Kp + col) = o;
+  }
+}
+
+// dst[r, 0:width) = src[idx[r] * src_stride + 0:width)  (16 bytes per thread; idx[r] < 0 -> zeros).  One kernel for
+// packing valid rows out of a padded batch, un-packing (inverse index, pad rows zero) and the projector's k-frame windows
+// over a packed encoder output (width = k*d > src_stride = d: k consecutive rows are one contiguous window).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, int64_t src_stride,
+                                                          const int* __restrict__ idx, bf16_t* __restrict__ dst,
+                                                          int64_t ld_dst, int64_t n, int width) {
+  const int WC = width / 8;
+  const int64_t total = n * WC;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / WC;
+    const int c = (int)(i % WC) * 8;
+    const int sidx = idx[r];
+    u16x8_t v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = 0;
+    if (sidx >= 0) v = *reinterpret_cast<const u16x8_t*>(src + (int64_t)sidx * src_stride + c);
+    *reinterpret_cast<u16x8_t*>(dst + r * ld_dst + c) = v;
   }
 }
 
@@ -584,24 +615,38 @@ extern "C" int slam_swiglu_bwd(const void* gate_up, int64_t ldgu, const void* dh
 }
 
 extern "C" int slam_conv1d_k3_im2col(const void* in, int in_dtype, void* out, int64_t B, int64_t Tin,
-                                     int64_t C, int64_t stride, int64_t Kp, void* stream) {
+                                     int64_t C, int64_t stride, int64_t Kp, const int32_t* n_valid, void* stream) {
   SLAM_CHECK_ARG(in && out, "slam_conv1d_k3_im2col: null pointer");
   SLAM_CHECK_ARG(stride == 1 || stride == 2, "slam_conv1d_k3_im2col: stride %ld unsupported", (long)stride);
   SLAM_CHECK_ARG(Kp >= 3 * C, "slam_conv1d_k3_im2col: Kp=%ld < 3*C=%ld", (long)Kp, (long)(3 * C));
   SLAM_CHECK_ARG(B > 0 && Tin > 0 && C > 0, "slam_conv1d_k3_im2col: bad shape");
+  SLAM_CHECK_ARG(C % 8 == 0 && Kp % 8 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                 "slam_conv1d_k3_im2col: C=%ld and Kp=%ld must be multiples of 8, buffers 16-byte aligned", (long)C, (long)Kp);
   const int64_t Tout = (Tin + 2 - 3) / stride + 1;
-  const int64_t total = B * Tout * Kp;
+  const int64_t total = B * Tout * (Kp / 8);
   if (in_dtype == SLAM_F32)
     hipLaunchKernelGGL(im2col_k3_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)in, (bf16_t*)out, (int)B, (int)Tin, (int)Tout, (int)C, (int)Kp, (int)stride);
+                       (const float*)in, (bf16_t*)out, (int)B, (int)Tin, (int)Tout, (int)C, (int)Kp, (int)stride, n_valid);
   else if (in_dtype == SLAM_BF16)
     hipLaunchKernelGGL(im2col_k3_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)in, (bf16_t*)out, (int)B, (int)Tin, (int)Tout, (int)C, (int)Kp, (int)stride);
+                       (const bf16_t*)in, (bf16_t*)out, (int)B, (int)Tin, (int)Tout, (int)C, (int)Kp, (int)stride, n_valid);
   else {
     slam_set_error("slam_conv1d_k3_im2col: in_dtype %d unknown", in_dtype);
     return -1;
   }
   SLAM_CHECK_LAUNCH("slam_conv1d_k3_im2col");
+  return 0;
+}
+
+extern "C" int slam_gather_rows_bf16(const void* src, int64_t src_stride, const int32_t* idx, void* dst, int64_t ld_dst,
+                                     int64_t n, int64_t width, void* stream) {
+  SLAM_CHECK_ARG(src && idx && dst, "slam_gather_rows_bf16: null pointer");
+  SLAM_CHECK_ARG(n > 0 && width > 0 && width % 8 == 0 && src_stride % 8 == 0 && ld_dst % 8 == 0 && ld_dst >= width &&
+                     ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+                 "slam_gather_rows_bf16: width / strides must be multiples of 8 elements, buffers 16-byte aligned");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_grid(n * (width / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, src_stride, idx, (bf16_t*)dst, ld_dst, n, (int)width);
+  SLAM_CHECK_LAUNCH("slam_gather_rows_bf16");
   return 0;
 }
 

@@ -238,14 +238,15 @@ class MultiTaskDynamicBatchDatasetRaw(torch.utils.data.IterableDataset):
     window; the reference's DataLoader is built with `batch_size=None, collate_fn=dataset.collator`
     (utils/config_utils.py:94-99), so this object exposes the wrapped dataset's collator."""
 
-    def __init__(self, dataset: MultiTaskDatasetRaw, max_frame_length: int):
+    def __init__(self, dataset: MultiTaskDatasetRaw, max_frame_length: int, budget: str = "padded"):
         super().__init__()
         self.dp = dataset
         self.max_frame_length = int(max_frame_length)
+        self.budget = budget   # dataset_config.frame_budget: "padded" (reference window) | "sum" (packed-aware, varlen path)
         self.collator = dataset.collator
 
     def __iter__(self):
-        return dynamic_batches(iter(self.dp), self.max_frame_length)
+        return dynamic_batches(iter(self.dp), self.max_frame_length, self.budget)
 
 
 def get_speech_dataset(dataset_config, tokenizer, split):
@@ -256,5 +257,5 @@ def get_speech_dataset(dataset_config, tokenizer, split):
     if g("multitask_prompt_path", None):
         ds = MultiTaskDatasetRaw(dataset_config, tokenizer, split)
         mfl = g("train_max_frame_length" if split == "train" else "eval_max_frame_length", None)
-        return MultiTaskDynamicBatchDatasetRaw(ds, mfl) if mfl else ds
+        return MultiTaskDynamicBatchDatasetRaw(ds, mfl, g("frame_budget", "padded")) if mfl else ds
     return SpeechDatasetJsonlRaw(dataset_config, tokenizer, split)

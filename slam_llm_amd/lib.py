@@ -33,7 +33,8 @@ SIGNATURES = {
     "slam_gemm_set_group_m": [I32],
     "slam_gemm_debug_clock": [P],
     "slam_attn_set_fwd_qf": [I32],
-    "slam_conv1d_k3_im2col": [P, I32, P, I64, I64, I64, I64, I64, P],
+    "slam_conv1d_k3_im2col": [P, I32, P, I64, I64, I64, I64, I64, P, P],
+    "slam_gather_rows_bf16": [P, I64, P, P, I64, I64, I64, P],
     "slam_conv1d_im2col": [P, I32, I64, I64, I64, P, I64, I64, I64, I64, I64, I64, I64, P],
     "slam_layernorm_fwd": [P, I64, P, P, P, I64, I64, I64, F, I32, P, P, P],
     "slam_layernorm_bwd": [P, I64, P, P, P, P, I64, P, I64, P, P, I64, I64, I32, P],
@@ -43,7 +44,7 @@ SIGNATURES = {
     "slam_rmsnorm_bwd": [P, I64, P, P, P, I64, P, I64, P, I64, P, I64, I64, P],
     "slam_head_rope_transpose": [P, I64, I64, P, P, I32, P, I64, I64, I64, I64, I64, P, P],
     "slam_transpose_bf16": [P, I64, P, I64, I64, I64, I64, P],
-    "slam_attn_fwd": [P, I64, P, I64, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P],
+    "slam_attn_fwd": [P, I64, P, I64, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P],
     "slam_attn_bwd": [P, I64, P, I64, P, I64, P, P, P, I64, P, I64, P, P, P, P, P, I64, P, I64, P, I64,
                       I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P, P, P, P],
     "slam_swiglu_fwd": [P, I64, P, I64, I64, I64, P],

@@ -346,6 +346,61 @@ class HipWhisperEncoder(nn.Module):
     def forward(self, x):
         return self.extract_variable_length_features(x)
 
+    @torch.no_grad()
+    def forward_packed(self, mel: torch.Tensor, n_frames: List[int]):
+        """Ragged batch without pad frames (`++model_config.varlen_encoder=true`, pad_or_trim off).
+        mel [B, Tmax, n_mels] f32, zero padded in mel space like the reference's collator (speech_dataset_large.py:194-197);
+        n_frames[b] = real mel frames of clip b (host ints).  Every clip is encoded exactly as if it were alone in the
+        batch (B = 1 through src/slam_llm/models/encoder.py:13-30): conv2 sees zeros past the clip's own conv1 frames, the
+        positional embedding restarts at every clip, attention is restricted to the clip's own frames (seg_lo / seg_hi).
+        This is a STATED deviation from the reference for ragged batches, where real frames also attend to the pad frames
+        of the zero-padded batch; it is identical to the reference for B = 1 and for equal-length clips.
+        Returns (packed encoder output [sum T2_b, d] bf16, T2 list)."""
+        cfg, w = self.cfg, self.w
+        B, T, nm = mel.shape
+        d, H, dev = cfg["enc_dim"], cfg["enc_heads"], mel.device
+        assert len(n_frames) == B and max(n_frames) <= T
+        T2 = [(n + 1) // 2 for n in n_frames]
+        T2max = (T + 1) // 2
+        assert max(T2) <= w["pos"].shape[0], "audio longer than the encoder's positional table"
+        nf = torch.tensor(n_frames, dtype=torch.int32).to(dev, non_blocking=True)
+        cols = ops.conv1d_k3_im2col(mel, 1, self.kp1, n_valid=nf)
+        h1 = ops.gemm_nt(cols, w["conv1"], bias=w["conv1_b"], act=ACT_GELU)
+        del cols
+        cols2 = ops.conv1d_k3_im2col(h1.view(B, T, d), 2, 3 * d, n_valid=nf)   # rows past a clip's conv1 frames read as zero
+        xpad = ops.gemm_nt(cols2, w["conv2"], bias=w["conv2_b"], act=ACT_GELU, residual=w["pos"], res_row_mod=T2max)
+        del cols2, h1
+        # pack the valid rows; per-row segment bounds for the attention
+        starts, idx, lo, hi = [], [], [], []
+        acc = 0
+        for b_, t2 in enumerate(T2):
+            starts.append(acc)
+            idx.append(torch.arange(b_ * T2max, b_ * T2max + t2, dtype=torch.int32))
+            lo.append(torch.full((t2,), acc, dtype=torch.int32))
+            hi.append(torch.full((t2,), acc + t2, dtype=torch.int32))
+            acc += t2
+        M = acc
+        meta = torch.stack([torch.cat(idx), torch.cat(lo), torch.cat(hi)]).to(dev, non_blocking=True)
+        x = ops.gather_rows(xpad, meta[0])
+        del xpad
+        seg = (meta[1], meta[2])
+        scale = 64 ** -0.5
+        hbuf = torch.empty((M, d), dtype=torch.bfloat16, device=dev)
+        qkv = torch.empty((M, 3 * d), dtype=torch.bfloat16, device=dev)
+        obuf = torch.empty((M, d), dtype=torch.bfloat16, device=dev)
+        fbuf = torch.empty((M, 4 * d), dtype=torch.bfloat16, device=dev)
+        for i in range(cfg["enc_layers"]):
+            ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], out=hbuf)
+            ops.gemm_nt(hbuf, w[f"{i}.qkv"], out=qkv, bias=w[f"{i}.qkv_b"])
+            vt = ops.head_rope_transpose(qkv, 2 * d, 1, M, H, 64)
+            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, 1, M, H, H, 64, False, scale, want_lse=False, out=obuf, seg=seg)
+            ops.gemm_nt(obuf, w[f"{i}.out"], out=x, bias=w[f"{i}.out_b"], residual=x)
+            ops.layernorm(x, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], out=hbuf)
+            ops.gemm_nt(hbuf, w[f"{i}.fc1"], out=fbuf, bias=w[f"{i}.fc1_b"], act=ACT_GELU)
+            ops.gemm_nt(fbuf, w[f"{i}.fc2"], out=x, bias=w[f"{i}.fc2_b"], residual=x)
+        out = ops.layernorm(x, w["lnp_w"], w["lnp_b"])
+        return out, T2
+
 
 
 # ======================================================================================== hubert encoder
@@ -482,18 +537,21 @@ class HipProjectorConcat(nn.Module):
 
     def forward_hip(self, enc: torch.Tensor, stash: Optional[dict]):
         """enc [B, T2, d] bf16 -> [B, Ta, dl] bf16"""
-        s, p = self.store, self.prefix
         B, T2, d = enc.shape
         Ta = T2 // self.k
         xp = enc[:, : Ta * self.k, :]
         if T2 % self.k:
             xp = xp.contiguous()
-        xp = xp.reshape(B * Ta, self.k * d)
+        return self.forward_rows(xp.reshape(B * Ta, self.k * d), stash).view(B, Ta, self.dl)
+
+    def forward_rows(self, xp: torch.Tensor, stash: Optional[dict]):
+        """xp [rows, k*d] bf16: already k-frame stacked rows (any batch layout, e.g. the ragged encoder's windows) -> [rows, dl]"""
+        s, p = self.store, self.prefix
         h = ops.gemm_nt(xp, s.bf16_view(p + "linear1.weight"), bias=s.master_view(p + "linear1.bias"), act=ACT_RELU)
         y = ops.gemm_nt(h, s.bf16_view(p + "linear2.weight"), bias=s.master_view(p + "linear2.bias"))
         if stash is not None:
             stash["proj"] = (xp, h)
-        return y.view(B, Ta, self.dl)
+        return y
 
     def backward_hip(self, dy: torch.Tensor, stash: dict, accumulate: bool):
         s, p = self.store, self.prefix
@@ -549,19 +607,22 @@ class HipProjectorCov1d(nn.Module):
 
     def forward_hip(self, enc: torch.Tensor, stash: Optional[dict]):
         """enc [B, T2, d] bf16 -> [B, T2 // k, dl] bf16"""
-        s, p = self.store, self.prefix
         B, T2, d = enc.shape
         Ta = T2 // self.k
         xp = enc[:, : Ta * self.k, :]
         if T2 % self.k:
             xp = xp.contiguous()
-        xp = xp.reshape(B * Ta, self.k * d)
+        return self.forward_rows(xp.reshape(B * Ta, self.k * d), stash).view(B, Ta, self.dl)
+
+    def forward_rows(self, xp: torch.Tensor, stash: Optional[dict]):
+        """xp [rows, k*d] bf16 k-frame stacked rows -> [rows, dl]"""
+        s, p = self.store, self.prefix
         c = ops.gemm_nt(xp, self.wc, bias=s.master_view(p + "conv1d.bias"), act=ACT_RELU)
         h = ops.gemm_nt(c, s.bf16_view(p + "linear1.weight"), bias=s.master_view(p + "linear1.bias"), act=ACT_RELU)
         y = ops.gemm_nt(h, s.bf16_view(p + "linear2.weight"), bias=s.master_view(p + "linear2.bias"))
         if stash is not None:
             stash["proj"] = (xp, c, h)
-        return y.view(B, Ta, self.dl)
+        return y
 
     def backward_hip(self, dy: torch.Tensor, stash: dict, accumulate: bool):
         s, p = self.store, self.prefix
@@ -1167,8 +1228,15 @@ class SlamHipModel(nn.Module):
                     alen = kwargs.get("audio_len", None)
                     nmax = min(480000, round_up(int(audio.shape[1]), 160))
                     audio_mel = ops.logmel(audio.float(), self.cfg["n_mels"], n_samples=nmax, n_valid=alen, per_clip=True)
-            enc = self.encoder.forward_btc(audio_mel.float().contiguous())
-        if self.projector_name == "q-former":
+            n_frames = self._ragged_frames(audio_mel, kwargs) if self.cfg.get("varlen_encoder", False) else None
+            if n_frames is not None:
+                proj = self._encode_project_ragged(audio_mel.float().contiguous(), n_frames, stash)
+                enc = None
+            else:
+                enc = self.encoder.forward_btc(audio_mel.float().contiguous())
+        if enc is None:
+            pass
+        elif self.projector_name == "q-former":
             # audio_mel_post_mask is consumed only by this branch (slam_model.py:354-355); None = attend to all
             pmask = kwargs.get("audio_mel_post_mask", None) if self.encoder_name == "whisper" else None
             proj = self.encoder_projector.forward_hip(enc, pmask, stash)
@@ -1201,7 +1269,8 @@ class SlamHipModel(nn.Module):
             lo = starts.repeat_interleave(lens, output_size=Mp).to(torch.int32).contiguous()
             hi = (starts + lens).repeat_interleave(lens, output_size=Mp).to(torch.int32).contiguous()
             pos = (torch.arange(Mp, device=dev, dtype=torch.int32) - lo).contiguous()
-            h_packed = embeds.index_select(0, pack_idx)
+            pack_idx32 = pack_idx.to(torch.int32)
+            h_packed = ops.gather_rows(embeds, pack_idx32)
             t_packed = targets.index_select(0, pack_idx).contiguous() if targets is not None else None
             out2, logits_p, lstash = self.llm.forward_hip(h_packed, 1, Mp, None, t_packed, n_valid, train, want_logits,
                                                           packed=(pos, lo, hi, T))
@@ -1229,6 +1298,64 @@ class SlamHipModel(nn.Module):
         outputs = SimpleNamespace(loss=loss, logits=logits.view(B, T, -1) if logits is not None else None)
         return outputs, acc
 
+    # ---- ragged encoder (++model_config.varlen_encoder=true) ---------------------------------------------
+    def _ragged_frames(self, audio_mel: torch.Tensor, kwargs) -> Optional[List[int]]:
+        """real mel frames per clip as host ints, or None when the batch is not ragged (equal lengths, or pad_or_trim on:
+        every clip is 3000 frames) -- then the reference-padded path runs and results equal the reference's bit for bit.
+        `audio_len_list` (a python list the collators add; the reference's train loop moves tensors only,
+        utils/train_utils.py:101-111) avoids the device -> host sync that `audio_len.tolist()` costs."""
+        if self.cfg.get("pad_or_trim", True):
+            return None
+        lens = kwargs.get("audio_len_list", None)
+        if lens is None:
+            al = kwargs.get("audio_len", None)
+            if al is None:
+                return None
+            lens = al.tolist()
+        frames = [min(int(n), 480000) // 160 for n in lens]
+        if len(frames) != audio_mel.shape[0] or min(frames) < 1:
+            return None
+        if min(frames) == max(frames) == audio_mel.shape[1]:
+            return None
+        return frames
+
+    def _encode_project_ragged(self, audio_mel: torch.Tensor, n_frames: List[int], stash: Optional[dict]) -> torch.Tensor:
+        """packed encoder -> projector -> padded [B, Ta_max, dl] for the splice (rows past a clip's own audio tokens are zero,
+        which is what the splice's clamp `min(sum(mask), Ta)` never reads anyway)."""
+        dev = self.device_
+        enc, T2 = self.encoder.forward_packed(audio_mel, n_frames)
+        B, d = len(T2), enc.shape[1]
+        if self.projector_name == "q-former":   # cross-attends over the frames under a key mask: hand it the padded layout
+            T2max = max(T2)
+            inv = torch.full((B, T2max), -1, dtype=torch.int32)
+            acc = 0
+            for b_, t2 in enumerate(T2):
+                inv[b_, :t2] = torch.arange(acc, acc + t2, dtype=torch.int32)
+                acc += t2
+            inv = inv.to(dev, non_blocking=True)
+            encp = ops.gather_rows(enc, inv.view(-1)).view(B, T2max, d)
+            return self.encoder_projector.forward_hip(encp, (inv >= 0).to(torch.float32), stash)
+        k = self.cfg["ds_rate"]
+        Ta = [t2 // k for t2 in T2]
+        Tam = max(Ta)
+        if Tam < 1:
+            raise RuntimeError("every clip of the batch is shorter than one projector frame")
+        win, inv, valid = [], torch.full((B, Tam), -1, dtype=torch.int32), []
+        acc = row = 0
+        for b_, (t2, ta) in enumerate(zip(T2, Ta)):
+            win.append(acc + k * torch.arange(ta, dtype=torch.int32))      # first encoder row of every k-frame window
+            inv[b_, :ta] = torch.arange(row, row + ta, dtype=torch.int32)
+            valid.append(b_ * Tam + torch.arange(ta, dtype=torch.int32))
+            acc += t2
+            row += ta
+        win = torch.cat(win).to(dev, non_blocking=True)
+        inv = inv.view(-1).to(dev, non_blocking=True)
+        xp = ops.gather_rows(enc, win, width=k * d)                        # [sum Ta, k*d]: the reference's view(B, T//k, k*d) per clip
+        y = self.encoder_projector.forward_rows(xp, stash)                 # [sum Ta, dl]
+        if stash is not None:
+            stash["proj_valid_rows"] = torch.cat(valid).to(dev, non_blocking=True)
+        return ops.gather_rows(y, inv).view(B, Tam, y.shape[1])
+
     def _run_backward(self, stash: dict, grad_out: torch.Tensor, as_autograd: bool = False):
         st = self.store
         if as_autograd:
@@ -1247,10 +1374,13 @@ class SlamHipModel(nn.Module):
         gs = grad_out.reshape(1).to(torch.float32).contiguous()
         dh0 = self.llm.backward_hip(stash, gs, accumulate, on_layer_done=self._on_layer_done)
         if stash.get("pack_idx") is not None:   # packed rows -> padded [B*T, d] layout (pad rows carry no gradient)
-            full = torch.zeros((stash["batch_B"] * stash["batch_T"], dh0.shape[1]), dtype=dh0.dtype, device=dh0.device)
-            full.index_copy_(0, stash["pack_idx"], dh0)
-            dh0 = full
+            n_rows = stash["batch_B"] * stash["batch_T"]
+            inv = torch.full((n_rows,), -1, dtype=torch.int32, device=dh0.device)
+            inv[stash["pack_idx"]] = torch.arange(dh0.shape[0], dtype=torch.int32, device=dh0.device)
+            dh0 = ops.gather_rows(dh0, inv)   # pad rows come out zero
         dproj = ops.embed_splice_bwd(stash["spans"], dh0, stash["batch_B"], stash["batch_T"], stash["Ta"], self.cfg["llm_dim"])
+        if stash.get("proj_valid_rows") is not None:   # ragged encoder: the projector ran on the clips' own rows only
+            dproj = ops.gather_rows(dproj, stash["proj_valid_rows"])
         self.encoder_projector.backward_hip(dproj, stash, accumulate)
         if as_autograd:
             return [st.grad_view(name) for name in st.params]

@@ -213,14 +213,29 @@ def logmel(audio: torch.Tensor, n_mels: int, n_samples: int = 480000, n_valid: O
 
 
 # ------------------------------------------------------------------------------------------------ conv/norm
-def conv1d_k3_im2col(x: torch.Tensor, stride: int, Kp: int) -> torch.Tensor:
-    """x [B, Tin, C] (f32|bf16) -> [B*Tout, Kp] bf16"""
+def conv1d_k3_im2col(x: torch.Tensor, stride: int, Kp: int, n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B, Tin, C] (f32|bf16) -> [B*Tout, Kp] bf16; n_valid int32 [B]: frames >= n_valid[b] read as zero"""
     B, Tin, C = x.shape
     assert x.is_contiguous()
     Tout = (Tin + 2 - 3) // stride + 1
     out = torch.empty((B * Tout, Kp), dtype=torch.bfloat16, device=x.device)
     call("slam_conv1d_k3_im2col", _p(x), F32 if x.dtype == torch.float32 else BF16, _p(out), B, Tin, C, stride,
-         Kp, _s())
+         Kp, _p(n_valid), _s())
+    return out
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, width: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[r, :width] = src.flatten()[idx[r] * src.stride(0) : + width]; idx int32, < 0 -> zero row.  width defaults to
+    src.shape[1]; a larger width spans consecutive rows of a contiguous src (the projector's k-frame windows)."""
+    assert src.dtype == torch.bfloat16 and src.dim() == 2 and src.stride(1) == 1 and idx.dtype == torch.int32
+    width = width or src.shape[1]
+    if width > src.shape[1]:
+        assert src.is_contiguous(), "multi-row windows need a contiguous source"
+    n = idx.numel()
+    if out is None:
+        out = torch.empty((n, width), dtype=torch.bfloat16, device=src.device)
+    if n:
+        call("slam_gather_rows_bf16", _p(src), src.stride(0), _p(idx), _p(out), _ld(out), n, width, _s())
     return out
 
 
@@ -318,7 +333,8 @@ def transpose(x2d, Rp=None, out=None):
 # ------------------------------------------------------------------------------------------------ attention
 def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_lse=True, out=None, Tk=None, seg=None):
     """self-attention: q/k rows (b*T + t).  Cross-attention: pass Tk (key rows b*Tk + t); vt is [B,Hkv,D,Tkp].
-    seg = (lo, hi) int32 [B*T]: packed sequences (B = 1), query q sees keys lo[q] <= k <= q."""
+    seg = (lo, hi) int32 [B*T]: packed sequences (B = 1), query q sees keys lo[q] <= k <= q (causal) or
+    lo[q] <= k < hi[q] (bidirectional: the ragged encoder, one clip per segment)."""
     Tk = Tk or T
     Tkp, Tqp = vt.shape[-1], round_up(T, 64)
     if out is None:
@@ -327,7 +343,7 @@ def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_
     _timed("attn_fwd", 4.0 * B * Hq * T * Tk * D * (0.5 if causal else 1.0),
            lambda: call("slam_attn_fwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(vt), _p(out), _ld(out), _p(lse),
                         _p(key_mask), B, T, Tk, Tqp, Tkp, Hq, Hkv, D, 1 if causal else 0, scale, _p(seg[0]) if seg else None,
-                        _s()))
+                        _p(seg[1]) if seg else None, _s()))
     return out, lse
 
 

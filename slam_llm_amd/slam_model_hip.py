@@ -72,7 +72,10 @@ def build_config(train_config, model_config) -> dict:
     # ++model_config.pad_or_trim=false: per-clip mel (aispeech recipes); ++model_config.varlen=true: right-padded batches run
     # the LLM on packed sequences (no pad tokens) -- identical results on every valid token, see DESIGN.md
     extra = dict(encoder_name=enc_name, projector=projector, pad_or_trim=bool(_get(model_config, "pad_or_trim", True)),
-                 varlen=bool(_get(model_config, "varlen", False)))
+                 varlen=bool(_get(model_config, "varlen", False)),
+                 # ++model_config.varlen_encoder=true (with pad_or_trim=false): ragged clips are encoded without pad frames, each
+                 # exactly as if alone in the batch -- a stated deviation from the reference's zero-padded batch
+                 varlen_encoder=bool(_get(model_config, "varlen_encoder", False)))
     if enc_name == "hubert":
         hp = _get(model_config, "arch_encoder") or _guess_preset(str(_get(model_config, "encoder_path", "hubert-large")).replace("_", "-"), HUBERT_PRESETS)
         extra.update(HUBERT_PRESETS[hp])

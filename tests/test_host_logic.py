@@ -249,3 +249,26 @@ def test_rank_worker_sharding_reproduces_the_reference_including_its_skip_quirk(
     batches = list(torch.utils.data.DataLoader(dsw, batch_size=None, collate_fn=dsw.collator))
     assert sum(b["input_ids"].shape[0] for b in batches) == len(kept)
     assert all(b["input_ids"].shape[0] * b["input_ids"].shape[1] <= 400 or b["input_ids"].shape[0] == 1 for b in batches)
+
+
+def test_packed_aware_frame_budget():
+    """budget='sum' (varlen path): batches close on the SUM of real sequence lengths; same in-order greedy grouping, every
+    sample exactly once, no batch above the budget unless it is a single over-long sample; 'padded' stays the reference window"""
+    rng = np.random.RandomState(7)
+    lens = [int(x) for x in rng.randint(40, 400, size=200)] + [5000]
+    samples = [{"input_ids": torch.zeros(n, dtype=torch.int64), "idx": i} for i, n in enumerate(lens)]
+    groups = list(batcher.dynamic_batches(samples, 3000, budget="sum"))
+    assert [s["idx"] for g in groups for s in g] == list(range(len(lens)))
+    for g in groups:
+        tot = sum(len(s["input_ids"]) for s in g)
+        assert tot <= 3000 or len(g) == 1
+    # greedy: adding the next group's first element would have overflowed
+    for g, nxt in zip(groups[:-1], groups[1:]):
+        assert sum(len(s["input_ids"]) for s in g) + len(nxt[0]["input_ids"]) > 3000
+    ref = list(batcher.dynamic_batches(samples, 3000))          # default = the reference's padded window
+    assert [len(g) for g in ref] == [len(g) for g in O.dynamic_batches(lens, 3000)]
+    n_sum, n_pad = len(groups), len(ref)
+    assert n_sum <= n_pad          # counting real tokens never needs more batches than counting padded positions
+    with pytest.raises(ValueError):
+        list(batcher.dynamic_batches(samples, 3000, budget="mean"))
+    assert batcher.frames_for_hbm() > 60000

@@ -592,3 +592,88 @@ def test_edge_shapes_match_oracle(dev, case):
         assert cs > 0.998, f"{case}: grad {n} cosine {cs}"
         assert abs(float(mine.norm()) - float(gref.norm())) < 4e-2 * float(gref.norm()) + 1e-6, n
     print(case, "T =", batch["input_ids"].shape[1], "worst grad cosine", worst)
+
+
+# ------------------------------------------------------------------------------------------------ ragged encoder (N1)
+def _ragged_reference(W, cfg, audio_list, ob):
+    """fp32 oracle of the ragged path: every clip through the encoder + projector ALONE (B = 1, the reference's own
+    variable-length forward, encoder.py:13-30), then the usual splice / LLM / loss on the right-padded batch."""
+    projs = []
+    for a in audio_list:
+        n = a.shape[0] // O.HOP * O.HOP
+        mel = O.log_mel_spectrogram(a[:n], cfg["n_mels"]).permute(1, 0)[None]          # [1, frames, n_mels]
+        enc = O.whisper_encoder(W, cfg, mel.permute(0, 2, 1))
+        projs.append(O.projector_concat(W, enc, cfg["ds_rate"])[0])
+    Tam = max(p.shape[0] for p in projs)
+    proj = torch.stack([torch.cat([p, p.new_zeros(Tam - p.shape[0], p.shape[1])]) for p in projs])
+    emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+    return O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
+
+
+@pytest.mark.parametrize("varlen_llm", [False, True])
+def test_ragged_encoder_step_matches_per_clip_oracle(dev, varlen_llm):
+    """++model_config.varlen_encoder=true, pad_or_trim off: clips of different lengths are encoded without pad frames, each
+    exactly as if it were alone in the batch (stated deviation from the zero-padded reference batch).  Loss, accuracy
+    and every trainable gradient vs the fp32 oracle that runs each clip through the reference's variable-length encoder with
+    B = 1; with and without the packed LLM pass."""
+    from slam_llm_amd import batcher
+    from slam_llm_amd.model import SlamHipModel
+    cfg = CASES["step_tiny"]["cfg"]
+    W = O.init_weights(cfg, seed=42)
+    model = SlamHipModel(dict(cfg, lora_dropout=0.0, pad_or_trim=False, varlen_encoder=True, varlen=varlen_llm), dev).load_weights(W)
+    model.train()
+    g = torch.Generator().manual_seed(11)
+    lens = [16000 * 3 + 800, 16000 * 1 + 160 * 7, 16000 * 2, 4800]        # ragged, not multiples of the projector's 5 x 2 x 160
+    audio = [(torch.randn(n, generator=g) * 0.1).clamp(-1, 1) for n in lens]
+    samples = []
+    for i, a in enumerate(audio):
+        alen = batcher.whisper_audio_length(len(a), 5, pad_to_30s=False)
+        samples.append(batcher.make_sample(a, torch.randint(3, cfg["vocab"], (4 + i,), generator=g).tolist(),
+                                           torch.randint(3, cfg["vocab"], (3 + 2 * i,), generator=g).tolist(), 2, alen))
+    batch = batcher.collate(samples, 0, left_pad_prompt=False)
+    assert batch["audio_len_list"] == lens
+    ob = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    names = O.trainable_names(W)
+    for n in names:
+        W[n].requires_grad_(True)
+    loss_ref, logits_ref = _ragged_reference(W, cfg, audio, ob)
+    loss_ref.backward()
+    preds = torch.argmax(logits_ref, -1)
+    acc_ref = O.compute_accuracy(preds[:, :-1], ob["labels"][:, 1:], -100)
+    gb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    outputs, acc = model(**gb)
+    outputs.loss.backward()
+    assert abs(float(outputs.loss) - float(loss_ref)) < 1e-2, (float(outputs.loss), float(loss_ref))
+    assert abs(float(acc) - float(acc_ref)) <= 1.0 / int((ob["labels"][:, 1:] != -100).sum()) + 1e-6
+    for n, p in model.store.params.items():
+        cs = G.cosine(W[n].grad.numpy(), p.grad.float().cpu().numpy())
+        assert cs > 0.999, f"grad {n}: cosine {cs}"
+
+
+def test_ragged_encoder_equals_padded_path_when_nothing_is_ragged(dev):
+    """B = 1: the ragged encoder is bit-identical to the reference-padded path; equal-length batches: equal to rounding, and the
+    model does not even enter it (the deviation only exists where the reference lets real frames attend to pad frames)"""
+    from slam_llm_amd.model import SlamHipModel
+    cfg = CASES["step_tiny"]["cfg"]
+    W = O.init_weights(cfg, seed=42)
+    m_pad = SlamHipModel(dict(cfg, lora_dropout=0.0, pad_or_trim=False), dev).load_weights(W).eval()
+    m_rag = SlamHipModel(dict(cfg, lora_dropout=0.0, pad_or_trim=False, varlen_encoder=True), dev).load_weights(W).eval()
+    for n_clips, n in ((1, 16000 * 2 + 480), (3, 16000)):
+        audio = O.synth_audio(n_clips, n / 16000.0, seed=5)
+        mel = ops_logmel(dev, audio, cfg["n_mels"], n)
+        enc_pad = m_pad.encoder.forward_btc(mel)
+        enc_rag, T2 = m_rag.encoder.forward_packed(mel, [n // 160] * n_clips)
+        assert T2 == [enc_pad.shape[1]] * n_clips
+        if n_clips == 1:
+            assert torch.equal(enc_rag.view(enc_pad.shape), enc_pad)
+        else:   # same mathematics, different key-tile alignment of the online softmax (packed rows): equal to bf16 rounding
+            assert rel_err(enc_rag.view(enc_pad.shape).float().cpu().numpy(), enc_pad.float().cpu().numpy()) < 1e-2
+        # the model itself takes the reference-padded path when no clip is shorter than the batch (bit-equal to the reference)
+        assert m_rag._ragged_frames(mel, {"audio_len_list": [n] * n_clips}) is None
+    assert m_rag._ragged_frames(mel, {"audio_len_list": [n, n - 1600, n]}) == [n // 160, (n - 1600) // 160, n // 160]
+
+
+def ops_logmel(dev, audio, n_mels, n):
+    from slam_llm_amd import ops
+    nv = torch.full((audio.shape[0],), n, dtype=torch.int32, device=dev)
+    return ops.logmel(audio.to(dev), n_mels, n_samples=n // 160 * 160, n_valid=nv, per_clip=True)

@@ -393,6 +393,62 @@ def test_cross_attention_fwd_bwd(dev):
         assert_close(got, r, atol=3e-2 * float(r.abs().max()), rtol=3e-2, what=nme)
 
 
+@pytest.mark.parametrize("lens,H,D", [((70, 133, 37), 4, 64), ((5, 64, 1, 200, 63), 2, 64), ((1500, 431, 1500), 2, 64), ((130, 70), 2, 128)])
+def test_packed_bidirectional_attention_equals_per_clip(dev, lens, H, D):
+    """the ragged encoder's attention: clips concatenated along T (B = 1), query q sees keys seg_lo[q] <= k < seg_hi[q] and
+    nothing else == bidirectional attention run on every clip alone (fp32 torch reference).  Covers clips shorter than one
+    64-key tile, boundaries in the middle of tiles and of 16-row fragments, and full 1500-frame clips."""
+    ops = _ops()
+    T = sum(lens)
+    qkv, q2, k2, v2, qt, kt, vt = _prep_attn(ops, dev, 1, T, H, H, D, seed=31)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    lo = torch.tensor(np.repeat(starts, lens), dtype=torch.int32, device=dev)
+    hi = torch.tensor(np.repeat(starts + np.array(lens), lens), dtype=torch.int32, device=dev)
+    scale = D ** -0.5
+    o, _ = ops.attn_fwd(q2, k2, vt, 1, T, H, H, D, False, scale, want_lse=False, seg=(lo, hi))
+    o = o.float().view(T, H, D)
+    for s0, n in zip(starts, lens):
+        qf = q2[s0:s0 + n].float().view(1, n, H, D)
+        kf = k2[s0:s0 + n].float().view(1, n, H, D)
+        vf = v2[s0:s0 + n].float().view(1, n, H, D)
+        ref = _attn_ref(qf, kf, vf, False, None, scale)[0]
+        assert_close(o[s0:s0 + n], ref, atol=2e-2, rtol=2e-2, what=f"clip at {s0} len {n}")
+
+
+def test_gather_rows_pack_unpack_and_windows(dev):
+    """slam_gather_rows_bf16: bit-exact row gather (pack), inverse index with -1 -> zero rows (un-pack), and windows wider than
+    the source row (the projector's k-frame stack over a packed encoder output)"""
+    ops = _ops()
+    src = rnd((301, 136), dev, seed=3)[:, :128]                 # strided source view
+    idx = torch.tensor([5, 0, 300, 17, 17, 299], dtype=torch.int32, device=dev)
+    assert torch.equal(ops.gather_rows(src, idx), src[idx.long()])
+    inv = torch.tensor([2, -1, 0, -1, 1], dtype=torch.int32, device=dev)
+    got = ops.gather_rows(src, inv)
+    assert torch.equal(got[[0, 2, 4]], src[[2, 0, 1]]) and float(got[[1, 3]].abs().max()) == 0.0
+    enc = rnd((97, 64), dev, seed=4)                             # contiguous: windows of k = 5 rows
+    win = torch.tensor([0, 5, 10, 23, 28, 92], dtype=torch.int32, device=dev)
+    got = ops.gather_rows(enc, win, width=5 * 64)
+    for r, w0 in enumerate(win.tolist()):
+        assert torch.equal(got[r], enc[w0:w0 + 5].reshape(-1))
+
+
+@pytest.mark.parametrize("stride,C,dt", [(1, 80, torch.float32), (2, 128, torch.bfloat16)])
+def test_conv_im2col_respects_per_clip_lengths(dev, stride, C, dt):
+    """n_valid: frames at or past a clip's own length read as zero -- equal to running the im2col on a copy whose tail was
+    zeroed, whatever garbage (here: NaN) sits in the pad rows"""
+    ops = _ops()
+    B, T = 3, 50
+    x = rnd((B, T, C), dev, seed=6, dtype=dt)
+    nv = torch.tensor([50, 13, 36], dtype=torch.int32, device=dev)
+    clean = x.clone()
+    dirty = x.clone()
+    for b, n in enumerate(nv.tolist()):
+        clean[b, n:] = 0
+        dirty[b, n:] = float("nan")
+    Kp = ops.round_up(3 * C, 64)
+    assert torch.equal(ops.conv1d_k3_im2col(dirty, stride, Kp, n_valid=nv), ops.conv1d_k3_im2col(clean, stride, Kp))
+
+
 # ----------------------------------------------------------------------------------------- mlp / conv
 def test_swiglu(dev):
     ops = _ops()
