@@ -133,7 +133,7 @@ def physical_cores():
         return os.cpu_count()
 
 
-def cpu_baseline(cfg, n_warm=1, n_meas=3):
+def cpu_baseline(cfg, clip_seconds=CLIP_SECONDS, n_warm=1, n_meas=3):
     """The CPU leg: the oracle -- the fp32 restatement of the reference path, pinned to the reference by
     tests/golden/ (kind "port"; /root/reference itself is not present on the GPU box) -- timed on the host cores on a
     BOUNDED sample of the same workload: ONE 30 s clip at the true layer dimensions, with the encoder / LLM depth reduced
@@ -161,7 +161,7 @@ def cpu_baseline(cfg, n_warm=1, n_meas=3):
     def one_point(le, ll):
         c = dict(cfg, **{Le_key: le, "llm_layers": ll})
         W = O.init_weights(dict(c, enc_layers=1) if hub else c, seed=42)   # (the HuBERT case replaces the encoder/projector entries below)
-        audio = O.synth_audio(1, CLIP_SECONDS, seed=1234)
+        audio = O.synth_audio(1, clip_seconds, seed=1234)
         if hub:
             W = {k: v for k, v in W.items() if not k.startswith(("encoder.", "encoder_projector."))}
             W.update(O.init_hubert_weights(c, seed=7))
@@ -205,11 +205,11 @@ def cpu_baseline(cfg, n_warm=1, n_meas=3):
     fixed = t22 - 2 * b_e - 2 * b_l
     t_full = fixed + Le_full * b_e + Ll_full * b_l
     fmt = lambda r: "[" + ", ".join(f"{x:.2f}" for x in r) + "]"  # noqa: E731
-    return dict(value=CLIP_SECONDS / t_full, unit="audio-seconds/sec", cores=physical_cores(), threads=threads, host_logical_cpus=os.cpu_count(),
+    return dict(value=clip_seconds / t_full, unit="audio-seconds/sec", cores=physical_cores(), threads=threads, host_logical_cpus=os.cpu_count(),
                 kind="port", step_seconds_full_depth=t_full,
                 raw_step_seconds={"(2,2)": r22, "(4,2)": r42, "(2,4)": r24},
                 sample=(f"oracle (CPU restatement of the reference path pinned by tests/golden; the reference itself is absent on the GPU "
-                        f"box) fp32 train step on 1 x 30 s clip at true layer dims, {threads} torch threads on {physical_cores()} physical cores; "
+                        f"box) fp32 train step on 1 x {clip_seconds:g} s clip (recipe-padded to 30 s) at true layer dims, {threads} torch threads on {physical_cores()} physical cores; "
                         f"median of {n_meas} steps after {n_warm} warm-up at (enc,llm) layers (2,2)={t22:.2f}s {fmt(r22)}, (4,2)={t42:.2f}s "
                         f"{fmt(r42)}, (2,4)={t24:.2f}s {fmt(r24)}; per-layer cost enc {b_e:.3f}s llm {b_l:.3f}s, fixed {fixed:.2f}s -> "
                         f"({Le_full},{Ll_full}) layers = {t_full:.1f} s/clip"))
@@ -378,7 +378,7 @@ def main():
         del model, opt, batch, step_model
         torch.cuda.empty_cache()
         try:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(cfg, clip_s)
         except Exception as ex:  # noqa: BLE001  (host too small etc.: report, never fake)
             out["cpu_baseline"] = {"value": None, "unit": "audio-seconds/sec", "cores": physical_cores(), "kind": "port",
                                    "sample": f"failed: {ex!r}"}

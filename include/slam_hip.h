@@ -195,6 +195,16 @@ int slam_ce_finalize(const float* row_loss, const int32_t* row_correct, const in
 int slam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                     int64_t step, float grad_scale, void* stream);
+
+/* AnyPrecisionAdamW (src/slam_llm/policies/anyprecision_optimizer.py:73-178, selected at pipeline/finetune.py:237-245): bf16
+ * momentum / variance (and optional bf16 Kahan compensation: non-null), every tensor op of the reference rounded to its tensor's
+ * dtype in the reference's order.  The scalars are the reference's float32 values (its `step` is a float32 tensor): decay =
+ * 1 - lr*wd, denom_correction = sqrt(1 - beta2^t), neg_step_size = -lr / (1 - beta1^t).  params_are_bf16 = 1 emulates the
+ * reference's pure_bf16 parameters inside the fp32 master buffer (values stay bf16-representable). */
+int slam_adamw_anyprecision_step(float* param, const float* grad, void* exp_avg_bf16, void* exp_avg_sq_bf16,
+                                 void* compensation_bf16, void* param_bf16, int64_t n, float decay, int use_decay,
+                                 float beta1, float one_minus_beta1, float beta2, float one_minus_beta2,
+                                 float denom_correction, float eps, float neg_step_size, int params_are_bf16, void* stream);
 int slam_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 /* counter-based dropout (peft lora_dropout): out (+)= keep(seed, offset + m*N + n) ? x/(1-p) : 0.
  * The mask is a pure function of (seed, offset, index): backward recomputes it (same call on the incoming gradient). */

@@ -472,6 +472,42 @@ def train_steps(W, cfg, batches: List[dict], lr=1e-4, weight_decay=0.0, warmup=1
     return out
 
 
+# ---------------------------------------------------------------------------------------------- f4: AnyPrecisionAdamW
+def anyprecision_adamw_step(p, grad, state: dict, lr: float, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                            use_kahan_summation=False, state_dtype=torch.bfloat16):
+    """One step of AnyPrecisionAdamW (src/slam_llm/policies/anyprecision_optimizer.py:73-178) on one tensor, in place: every
+    tensor op rounds to ITS tensor's dtype, in the reference's order -- decoupled weight decay on p (:128-129), momentum
+    `mul_(b1).add_(g, alpha=1-b1)` (:132, two roundings), variance `mul_(b2).addcmul_(g, g, value=1-b2)` (:135),
+    `(sqrt(v) / sqrt(1 - b2^t)).add_(eps)` (:147-149, three roundings), then `p.addcdiv_(m, denom, value=-lr/(1-b1^t))` (:165) or
+    the Kahan form (:152-160).  `step` is a float32 0-dim TENSOR there, so 1 - b^t, the step size and the denominator correction
+    are float32 values (not Python doubles).  `state` holds step / exp_avg / exp_avg_sq (/ compensation)."""
+    b1, b2 = betas
+    if not state:
+        state["step"] = torch.tensor(0.0)   # a float32 0-dim tensor in the reference (:112): the bias corrections below are fp32
+        state["exp_avg"] = torch.zeros_like(p, dtype=state_dtype)
+        state["exp_avg_sq"] = torch.zeros_like(p, dtype=state_dtype)
+        if use_kahan_summation:
+            state["compensation"] = torch.zeros_like(p, dtype=state_dtype)
+    state["step"] += 1
+    t = state["step"]
+    m, v = state["exp_avg"], state["exp_avg_sq"]
+    if weight_decay:
+        p.mul_(1 - lr * weight_decay)
+    m.mul_(b1).add_(grad, alpha=1 - b1)
+    v.mul_(b2).addcmul_(grad, grad, value=1 - b2)
+    step_size = lr / (1 - b1 ** t)
+    denom = (v.sqrt() / ((1 - b2 ** t) ** 0.5)).add_(eps, alpha=1)
+    if use_kahan_summation:
+        c = state["compensation"]
+        c.addcdiv_(m, denom, value=-step_size)
+        tmp = p.detach().clone()
+        p.add_(c)
+        c.add_(tmp.sub_(p))
+    else:
+        p.addcdiv_(m, denom, value=-step_size)
+    return p
+
+
 # ---------------------------------------------------------------------------------------------- f1: generate (beam / greedy)
 def _repetition_penalty(scores: torch.Tensor, history: torch.Tensor, penalty: float) -> torch.Tensor:
     """HF RepetitionPenaltyLogitsProcessor: every token id already in the row's history gets score*p if score < 0 else

@@ -187,7 +187,76 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// AnyPrecisionAdamW (src/slam_llm/policies/anyprecision_optimizer.py:73-178) with bf16 momentum / variance (/ Kahan
+// compensation) as pipeline/finetune.py:237-245 builds it.  The reference is a chain of tensor ops, each rounding to ITS
+// tensor's dtype; the same roundings are applied here in registers, in the same order:
+//   p.mul_(1 - lr*wd);  m.mul_(b1).add_(g, alpha=1-b1);  v.mul_(b2).addcmul_(g, g, value=1-b2);
+//   denom = (v.sqrt() / dc).add_(eps);  p.addcdiv_(m, denom, value=-step_size)        [or the Kahan form :152-160]
+// PBF = parameters are bf16 in the reference (its pure_bf16 route): the fp32 master buffer then only ever holds
+// bf16-representable values and the gradient is rounded to bf16 first (p.grad has the parameter's dtype there).
+__device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
+
+template <bool PBF, bool KAHAN>
+__global__ __launch_bounds__(256) void adamw_anyprecision_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                                 bf16_t* __restrict__ m, bf16_t* __restrict__ v,
+                                                                 bf16_t* __restrict__ comp, bf16_t* __restrict__ p_bf16,
+                                                                 int64_t n, float decay, int use_decay, float b1, float a1,
+                                                                 float b2, float a2, float dc, float eps, float neg_step) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = PBF ? rbf(g[i]) : g[i];
+    float pi = p[i];
+    if (use_decay) {
+      pi = pi * decay;
+      if (PBF) pi = rbf(pi);
+    }
+    const float mi = rbf(rbf(bf2f(m[i]) * b1) + a1 * gi);
+    const float vi = rbf(rbf(bf2f(v[i]) * b2) + (a2 * gi) * gi);
+    const float den = rbf(rbf(rbf(sqrtf(vi)) / dc) + eps);
+    if (KAHAN) {
+      float ci = rbf(bf2f(comp[i]) + neg_step * (mi / den));
+      const float tmp = pi;
+      pi = pi + ci;
+      if (PBF) pi = rbf(pi);
+      float dlt = tmp - pi;
+      if (PBF) dlt = rbf(dlt);
+      ci = rbf(ci + dlt);
+      comp[i] = f2bf(ci);
+    } else {
+      pi = pi + neg_step * (mi / den);
+      if (PBF) pi = rbf(pi);
+    }
+    p[i] = pi;
+    m[i] = f2bf(mi);
+    v[i] = f2bf(vi);
+    if (p_bf16) p_bf16[i] = f2bf(pi);
+  }
+}
+
 }  // namespace
+
+extern "C" int slam_adamw_anyprecision_step(float* param, const float* grad, void* exp_avg_bf16, void* exp_avg_sq_bf16,
+                                            void* compensation_bf16, void* param_bf16, int64_t n, float decay,
+                                            int use_decay, float beta1, float one_minus_beta1, float beta2,
+                                            float one_minus_beta2, float denom_correction, float eps, float neg_step_size,
+                                            int params_are_bf16, void* stream) {
+  SLAM_CHECK_ARG(param && grad && exp_avg_bf16 && exp_avg_sq_bf16 && n > 0, "slam_adamw_anyprecision_step: bad arguments");
+  SLAM_CHECK_ARG(denom_correction > 0.f, "slam_adamw_anyprecision_step: denom_correction must be > 0 (step >= 1)");
+  int64_t g = cdiv64(n, 256);
+  if (g > 8192) g = 8192;
+  hipStream_t s = (hipStream_t)stream;
+  bf16_t *m = (bf16_t*)exp_avg_bf16, *v = (bf16_t*)exp_avg_sq_bf16, *c = (bf16_t*)compensation_bf16, *pb = (bf16_t*)param_bf16;
+#define SLAM_ANYP(PBF, KAHAN)                                                                                              \
+  hipLaunchKernelGGL((adamw_anyprecision_kernel<PBF, KAHAN>), dim3((unsigned)g), dim3(256), 0, s, param, grad, m, v, c, pb, n, \
+                     decay, use_decay, beta1, one_minus_beta1, beta2, one_minus_beta2, denom_correction, eps, neg_step_size)
+  if (params_are_bf16) {
+    if (c) SLAM_ANYP(true, true); else SLAM_ANYP(true, false);
+  } else {
+    if (c) SLAM_ANYP(false, true); else SLAM_ANYP(false, false);
+  }
+#undef SLAM_ANYP
+  SLAM_CHECK_LAUNCH("slam_adamw_anyprecision_step");
+  return 0;
+}
 
 extern "C" int slam_ce_targets(const int64_t* labels, int32_t* targets, int32_t* n_valid, int64_t B,
                                int64_t T, int64_t ignore_index, void* stream) {

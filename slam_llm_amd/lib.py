@@ -65,6 +65,7 @@ SIGNATURES = {
     "slam_ce_fwd_bwd": [P, I64, P, P, P, P, I64, I64, I32, P],
     "slam_ce_finalize": [P, P, P, I64, P, P],
     "slam_adamw_step": [P, P, P, P, P, I64, F, F, F, F, F, I64, F, P],
+    "slam_adamw_anyprecision_step": [P, P, P, P, P, P, I64, F, I32, F, F, F, F, F, F, F, I32, P],
     "slam_cast_f32_to_bf16": [P, P, I64, P],
     "slam_cast_bf16_to_f32": [P, P, I64, I32, P],
     "slam_dropout_bf16": [P, I64, P, I64, I64, I64, F, ctypes.c_uint64, ctypes.c_uint64, I32, P],

@@ -459,6 +459,39 @@ class HipHubertEncoder(nn.Module):
         w["lnp_w"], w["lnp_b"] = f32(W[p + "layer_norm.weight"]), f32(W[p + "layer_norm.bias"])
         return self
 
+    def init_random(self, seed: int = 42):
+        """seeded random weights generated directly in HBM at the true dimensions (benchmarks: no checkpoints offline)"""
+        cfg, dev, w = self.cfg, self.device_, self.w
+        g = torch.Generator(device=dev).manual_seed(seed)
+        rn = lambda *s, std=0.02: (torch.randn(*s, generator=g, device=dev) * std)  # noqa: E731
+        cin = 1
+        for i, (co, k) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"])):
+            kp = round_up(k * cin, 64)
+            wc = torch.zeros((co, kp), dtype=torch.bfloat16, device=dev)
+            wc[:, : k * cin] = rn(co, k * cin, std=(k * cin) ** -0.5).to(torch.bfloat16)
+            w[f"c{i}"], w[f"c{i}_b"] = wc, rn(co)
+            w[f"c{i}_lw"], w[f"c{i}_lb"] = 1 + rn(co, std=0.1), rn(co, std=0.1)
+            cin = co
+        d, Fd = cfg["hub_dim"], cfg["hub_ffn"]
+        assert d % 64 == 0 and d // cfg["hub_heads"] == 64 and cin % 64 == 0
+        w["fp_lw"], w["fp_lb"] = 1 + rn(cin, std=0.1), rn(cin, std=0.1)
+        w["fp"], w["fp_b"] = rn(d, cin, std=cin ** -0.5).to(torch.bfloat16), rn(d)
+        G, kpos = cfg["hub_pos_groups"], cfg["hub_pos_k"]
+        gch = d // G
+        self.pos_kp = round_up(kpos * gch, 64)
+        pg = torch.zeros((G, gch, self.pos_kp), dtype=torch.bfloat16, device=dev)
+        pg[:, :, : kpos * gch] = rn(G, gch, kpos * gch, std=(kpos * gch) ** -0.5).to(torch.bfloat16)
+        w["pos"], w["pos_b"] = pg, rn(d)
+        for i in range(cfg["hub_layers"]):
+            w[f"{i}.qkv"], w[f"{i}.qkv_b"] = rn(3 * d, d, std=d ** -0.5).to(torch.bfloat16), rn(3 * d)
+            w[f"{i}.out"], w[f"{i}.out_b"] = rn(d, d, std=d ** -0.5).to(torch.bfloat16), rn(d)
+            w[f"{i}.ln1_w"], w[f"{i}.ln1_b"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+            w[f"{i}.fc1"], w[f"{i}.fc1_b"] = rn(Fd, d, std=d ** -0.5).to(torch.bfloat16), rn(Fd)
+            w[f"{i}.fc2"], w[f"{i}.fc2_b"] = rn(d, Fd, std=Fd ** -0.5).to(torch.bfloat16), rn(d)
+            w[f"{i}.ln2_w"], w[f"{i}.ln2_b"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+        w["lnp_w"], w["lnp_b"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+        return self
+
     def out_frames(self, n: int) -> int:
         for k, s_ in zip(self.cfg["hub_conv_kernel"], self.cfg["hub_conv_stride"]):
             n = (n - k) // s_ + 1
@@ -1155,7 +1188,9 @@ class SlamHipModel(nn.Module):
         g = torch.Generator(device=self.device_).manual_seed(seed + 2)
         with torch.no_grad():
             for name, p in self.store.params.items():
-                if name.endswith("bias"):
+                if ("LayerNorm" in name or "layernorm" in name or name.endswith("norm.weight")) and name.endswith("weight"):
+                    p.fill_(1.0)
+                elif name.endswith("bias"):
                     p.normal_(0, 0.02, generator=g)
                 elif "lora_B" in name:
                     p.normal_(0, lora_b_std, generator=g)
@@ -1535,3 +1570,48 @@ class SlamAdamW(torch.optim.Optimizer):
         self.exp_avg.copy_(slam["exp_avg"])
         self.exp_avg_sq.copy_(slam["exp_avg_sq"])
         self._step = int(slam["step"])
+
+
+class SlamAnyPrecisionAdamW(SlamAdamW):
+    """AnyPrecisionAdamW (src/slam_llm/policies/anyprecision_optimizer.py:16-178) as one fused kernel over the flat buffers: bf16
+    momentum and variance as pipeline/finetune.py:237-245 configures it, optional bf16 Kahan compensation.  `pure_bf16=True`
+    reproduces the reference's `model.to(torch.bfloat16)` route (finetune.py:154-155): the fp32 master buffer then only
+    ever holds bf16-representable values (the parameters are rounded once here) and every parameter update rounds like a bf16
+    tensor op would; False keeps this build's fp32 masters under bf16 states."""
+
+    def __init__(self, model: SlamHipModel, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, use_kahan_summation=False,
+                 pure_bf16=False):
+        super().__init__(model, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        st = model.store
+        self.exp_avg = torch.zeros_like(st.flat, dtype=torch.bfloat16)
+        self.exp_avg_sq = torch.zeros_like(st.flat, dtype=torch.bfloat16)
+        self.compensation = torch.zeros_like(st.flat, dtype=torch.bfloat16) if use_kahan_summation else None
+        self.pure_bf16 = bool(pure_bf16)
+        if self.pure_bf16:
+            with torch.no_grad():
+                st.flat.copy_(st.flat.to(torch.bfloat16).float())
+            model.mark_params_updated()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        st = self.model.store
+        self._step += 1
+        ops.adamw_anyprecision_step(st.flat, self._flat_grad(), self.exp_avg, self.exp_avg_sq, self.compensation, st.flat_bf16,
+                                    float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._step,
+                                    params_are_bf16=self.pure_bf16)
+        self.model.llm.refresh()
+        self.model.encoder_projector.refresh()
+        self.model._stale = False
+        self.model._always_refresh = False
+
+    def state_dict(self):
+        sd = super().state_dict()
+        if self.compensation is not None:
+            sd["slam"]["compensation"] = self.compensation.detach().cpu()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        if self.compensation is not None:
+            self.compensation.copy_(state_dict["slam"]["compensation"])

@@ -439,6 +439,17 @@ def adamw_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale=1
          grad_scale, _s())
 
 
+def adamw_anyprecision_step(p, g, m_bf16, v_bf16, comp_bf16, p_bf16, lr, beta1, beta2, eps, wd, step, params_are_bf16=False):
+    """AnyPrecisionAdamW step over flat buffers; the scalars are formed exactly like the reference forms them (its step counter is
+    a float32 0-dim tensor, anyprecision_optimizer.py:112,137-146)"""
+    t = torch.tensor(float(step))
+    neg_step = -float(lr / (1 - beta1 ** t))
+    dc = float((1 - beta2 ** t) ** 0.5)
+    call("slam_adamw_anyprecision_step", _p(p), _p(g), _p(m_bf16), _p(v_bf16), _p(comp_bf16), _p(p_bf16), p.numel(),
+         float(1 - lr * wd), 1 if wd else 0, float(beta1), float(1 - beta1), float(beta2), float(1 - beta2), dc, float(eps), neg_step,
+         1 if params_are_bf16 else 0, _s())
+
+
 def cast_bf16(src_f32, dst_bf16=None):
     if dst_bf16 is None:
         dst_bf16 = torch.empty(src_f32.shape, dtype=torch.bfloat16, device=src_f32.device)

@@ -121,6 +121,64 @@ def check_supported(train_config, model_config):
         raise NotImplementedError("only peft_method=lora is implemented")
 
 
+# ---------------------------------------------------------------------------------------------- peft adapter directories
+PEFT_PREFIX = "llm."   # the LLM sits at `slam_model.llm` (models/slam_model.py:258), so peft's keys gain this prefix in model.state_dict()
+
+
+def read_peft_adapter(adapter_dir: str):
+    """`peft_ckpt` (src/slam_llm/models/slam_model.py:210-213: `PeftModel.from_pretrained(model, model_id=peft_ckpt,
+    is_trainable=True)`): a peft 0.6.0 adapter directory = `adapter_config.json` (the LoraConfig that DEFINES the adapter: r,
+    lora_alpha, target_modules, lora_dropout -- it wins over train_config.peft_config) + `adapter_model.safetensors` or
+    `adapter_model.bin` whose keys carry no adapter name (`...q_proj.lora_A.weight`; peft's get_peft_model_state_dict strips
+    `.default`).  Returns (lora settings for make_config, {state_dict key of this model: tensor})."""
+    import json
+    cfg_path = os.path.join(adapter_dir, "adapter_config.json")
+    if not os.path.isfile(cfg_path):
+        raise FileNotFoundError(f"peft_ckpt: {cfg_path} not found (expected a peft adapter directory)")
+    with open(cfg_path) as f:
+        ac = json.load(f)
+    if str(ac.get("peft_type", "LORA")).upper() != "LORA":
+        raise NotImplementedError(f"peft_ckpt: peft_type {ac.get('peft_type')!r} (only LORA adapters are implemented)")
+    if ac.get("bias", "none") != "none" or ac.get("modules_to_save"):
+        raise NotImplementedError("peft_ckpt: adapters with trainable biases / modules_to_save are not implemented")
+    st_path, bin_path = os.path.join(adapter_dir, "adapter_model.safetensors"), os.path.join(adapter_dir, "adapter_model.bin")
+    if os.path.isfile(st_path):
+        from safetensors.torch import load_file
+        raw = load_file(st_path)
+    elif os.path.isfile(bin_path):
+        raw = torch.load(bin_path, map_location="cpu")
+    else:
+        raise FileNotFoundError(f"peft_ckpt: neither adapter_model.safetensors nor adapter_model.bin in {adapter_dir}")
+    state = {}
+    for k, v in raw.items():
+        for ab in ("lora_A", "lora_B"):
+            if k.endswith(f".{ab}.weight"):
+                k = k[: -len("weight")] + "default.weight"
+        state[PEFT_PREFIX + k] = v
+    lora = dict(lora_r=int(ac["r"]), lora_alpha=float(ac["lora_alpha"]), lora_targets=tuple(ac["target_modules"]),
+                lora_dropout=float(ac.get("lora_dropout", 0.0)))
+    return lora, state
+
+
+def save_peft_adapter(model, adapter_dir: str):
+    """what `model.llm.save_pretrained(dir)` writes under peft 0.6.0: the adapter directory `peft_ckpt` reloads"""
+    import json
+    os.makedirs(adapter_dir, exist_ok=True)
+    cfg = model.cfg
+    ac = dict(peft_type="LORA", task_type="CAUSAL_LM", base_model_name_or_path=None, r=cfg["lora_r"], lora_alpha=cfg["lora_alpha"],
+              lora_dropout=cfg.get("lora_dropout", 0.0), target_modules=list(cfg["lora_targets"]), bias="none", fan_in_fan_out=False,
+              inference_mode=False, init_lora_weights=True, layers_pattern=None, layers_to_transform=None, modules_to_save=None,
+              revision=None, auto_mapping=None)
+    with open(os.path.join(adapter_dir, "adapter_config.json"), "w") as f:
+        json.dump(ac, f, indent=2)
+    sd = {}
+    for k, v in model.state_dict().items():
+        if k.startswith(PEFT_PREFIX) and (".lora_A." in k or ".lora_B." in k):
+            sd[k[len(PEFT_PREFIX):].replace(".default.weight", ".weight")] = v.detach().cpu().clone()
+    torch.save(sd, os.path.join(adapter_dir, "adapter_model.bin"))
+    return sorted(sd)
+
+
 def _load_state(path):
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
@@ -137,6 +195,11 @@ def model_factory(train_config, model_config, **kwargs):
     flat-buffer backward for callers that drive `slam_llm_amd.train.GradSync` themselves."""
     check_supported(train_config, model_config)
     cfg = build_config(train_config, model_config)
+    peft_state = None
+    if kwargs.get("peft_ckpt", None):   # slam_model.py:210-213: the adapter directory defines the LoRA, use_peft or not
+        logger.info("loading peft_ckpt from: %s", kwargs.get("peft_ckpt"))
+        lora, peft_state = read_peft_adapter(str(kwargs.get("peft_ckpt")))
+        cfg.update(lora)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("slam_llm_amd.model_factory: no HIP device visible (the HIP path has no CPU fallback)")
@@ -165,6 +228,15 @@ def model_factory(train_config, model_config, **kwargs):
             raise FileNotFoundError("no weights given: set model_config.encoder_state / llm_state (state dicts in the "
                                     "reference's key names) or model_config.random_init=true")
         model.load_weights(W, seed=seed)   # projector / LoRA tensors absent from W get the reference's fresh-module init
+    if peft_state is not None:
+        own = set(model.state_dict().keys())
+        unknown = [k for k in peft_state if k not in own]
+        missing = [k for k in own if (".lora_A." in k or ".lora_B." in k) and k not in peft_state]
+        if unknown or missing:
+            raise RuntimeError(f"peft_ckpt does not match the model: {len(unknown)} unknown keys (e.g. {unknown[:2]}), "
+                               f"{len(missing)} adapter tensors missing (e.g. {missing[:2]})")
+        model.load_state_dict(peft_state, strict=False)
+        model.mark_params_updated()
     ckpt_path = kwargs.get("ckpt_path", None)  # projector/LoRA checkpoint written by save_model_checkpoint_peft
     if ckpt_path is not None:
         logger.info("loading other parts from: %s", ckpt_path)

@@ -196,3 +196,34 @@ def test_true_width_step_matches_oracle(dev):
         gn, mn = float(grads[n].norm()), float(p.grad.float().norm())
         assert abs(mn - gn) <= 3e-2 * gn + 1e-9, f"grad {n}: norm {mn} vs {gn}"
     print(f"true-width step: loss {float(outputs.loss):.4f} vs {float(loss_ref):.4f}, worst gradient cosine {worst:.6f}")
+
+
+def test_peft_ckpt_adapter_directory_round_trip(dev, tmp_path):
+    """train a few steps, write the adapter the way peft's save_pretrained does, reload it through model_factory(peft_ckpt=...)
+    (slam_model.py:210-213): the adapter's own config wins over train_config.peft_config, LoRA tensors and the loss are identical"""
+    from slam_llm_amd.slam_model_hip import model_factory, save_peft_adapter
+    tc, mc, _ = _tiny_recipe(peft=dict(r=16, lora_alpha=32, target_modules=["q_proj", "k_proj", "v_proj", "o_proj"], lora_dropout=0.0))
+    model, _ = model_factory(tc, mc)
+    model.train()
+    cfg = model.cfg
+    ob = O.synth_batch(cfg, O.synth_audio(2, 1.0, seed=5), prompt_len=4, answer_lens=(3, 6), seed=6, left_pad=True, pad_to_30s=False)
+    gb = {k: v.to(dev) for k, v in ob.items()}
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2)
+    for _ in range(2):
+        out, _ = model(**{k: v.clone() for k, v in gb.items()})
+        out.loss.backward()
+        opt.step()
+        opt.zero_grad()
+    keys = save_peft_adapter(model, str(tmp_path / "adapter"))
+    assert "base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight" in keys and len(keys) == 2 * 4 * cfg["llm_layers"]
+    torch.save({k: v for k, v in model.state_dict().items() if k.startswith("encoder_projector.")}, tmp_path / "proj.pt")
+    tc2, mc2, _ = _tiny_recipe(peft=dict(r=8))          # the recipe says r = 8 on q,v: the adapter directory must win
+    m2, _ = model_factory(tc2, mc2, peft_ckpt=str(tmp_path / "adapter"), ckpt_path=str(tmp_path / "proj.pt"))
+    assert m2.cfg["lora_r"] == 16 and m2.cfg["lora_targets"] == ("q_proj", "k_proj", "v_proj", "o_proj")
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    model.eval(); m2.eval()
+    with torch.no_grad():
+        a, _ = model(**{k: v.clone() for k, v in gb.items()})
+        b, _ = m2(**{k: v.clone() for k, v in gb.items()})
+    assert float(a.loss) == float(b.loss)

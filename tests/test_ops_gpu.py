@@ -2,6 +2,7 @@
 
 Tolerances: bf16 outputs carry ~2^-8 relative rounding; accumulations are fp32.  Each check states its bound."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -795,3 +796,39 @@ def test_decode_attention_fused(dev, D, Hq, Hkv, lora):
             sc = (Kh[:, hq // rep] @ qf[r, hq].cpu()) * D ** -0.5
             ref[r, hq] = torch.softmax(sc, 0) @ Vh[:, hq // rep]
     assert_close(out.view(R, Hq, D), ref, atol=2e-2, rtol=1e-2, what="decode attention")
+
+
+@pytest.mark.parametrize("name", ["fp32_params", "bf16_params", "bf16_params_kahan"])
+def test_anyprecision_adamw_matches_reference_class_fixture(dev, name):
+    """fused AnyPrecisionAdamW kernel vs tests/golden/anyprecision.npz (written by the REFERENCE's optimizer class, 6 steps): bf16
+    momentum / variance / compensation may differ from the CPU run by one bf16 ulp on a handful of elements (fma contraction of
+    a + alpha*b differs between the reference's CPU kernels and the GPU); parameters follow within that."""
+    ops = _ops()
+    from tests.test_oracle_golden import ANYPRECISION_CASES
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "anyprecision.npz"))
+    pdt, kahan, wd = ANYPRECISION_CASES[name]
+    pbf = pdt == torch.bfloat16
+    p = torch.from_numpy(fx["p0"]).to(dev)
+    if pbf:
+        p = p.to(torch.bfloat16).float()
+    n = p.numel()
+    m = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    v = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    c = torch.zeros(n, dtype=torch.bfloat16, device=dev) if kahan else None
+    pb = torch.empty(n, dtype=torch.bfloat16, device=dev)
+
+    def ulps(got, want):      # distance in bf16 ulps
+        a = got.float().cpu().view(torch.int32) >> 16
+        b = torch.from_numpy(want).view(torch.int32) >> 16
+        return (a - b).abs()
+    for s in range(6):
+        g = torch.from_numpy(fx[f"grad.{s}"]).to(dev)
+        ops.adamw_anyprecision_step(p, g, m, v, c, pb, float(fx["lr"]), 0.9, 0.999, 1e-8, wd, s + 1, params_are_bf16=pbf)
+        for nme, t in (("m", m), ("v", v)) + ((("c", c),) if kahan else ()):
+            d = ulps(t, fx[f"{name}.{nme}.{s}"])
+            assert int(d.max()) <= (1 if nme != "c" else 4) and float((d > 0).float().mean()) < 0.02, (name, nme, s, int(d.max()), float((d > 0).float().mean()))
+        want = torch.from_numpy(fx[f"{name}.p.{s}"])
+        err = (p.cpu() - want).abs()
+        tol = (2.0 ** -7 if pbf else 1e-5) * want.abs().clamp(min=1e-3)
+        assert float((err > tol).float().mean()) < 0.02, (name, s, float(err.max()))
+        assert torch.equal(pb.float().cpu(), p.cpu().to(torch.bfloat16).float())

@@ -139,3 +139,25 @@ def test_generate_matches_reference_generate(scale):
                               num_beams=nb, length_penalty=lp, eos=eos, pad=pad, repetition_penalty=rp)
         want = fx[gen_key(scale, nb, lp, pad, rp)]
         assert got.shape == want.shape and (got.numpy() == want).all(), (nb, lp, pad, got, want)
+
+
+ANYPRECISION_CASES = {"fp32_params": (torch.float32, False, 0.01), "bf16_params": (torch.bfloat16, False, 0.01),
+                      "bf16_params_kahan": (torch.bfloat16, True, 0.0)}
+
+
+@pytest.mark.parametrize("name", sorted(ANYPRECISION_CASES))
+def test_anyprecision_adamw_restatement_matches_reference_class(name):
+    """oracle.anyprecision_adamw_step == the reference's AnyPrecisionAdamW (fixture written by the reference class itself,
+    oracle/make_golden_anyprecision.py): parameters and bf16 states bit for bit over 6 steps"""
+    fx = G.load("anyprecision")
+    pdt, kahan, wd = ANYPRECISION_CASES[name]
+    p = torch.from_numpy(fx["p0"]).to(pdt).clone()
+    state = {}
+    for s in range(6):
+        g = torch.from_numpy(fx[f"grad.{s}"]).to(pdt)
+        O.anyprecision_adamw_step(p, g, state, float(fx["lr"]), weight_decay=wd, use_kahan_summation=kahan)
+        assert np.array_equal(p.float().numpy(), fx[f"{name}.p.{s}"]), (name, s)
+        assert np.array_equal(state["exp_avg"].float().numpy(), fx[f"{name}.m.{s}"])
+        assert np.array_equal(state["exp_avg_sq"].float().numpy(), fx[f"{name}.v.{s}"])
+        if kahan:
+            assert np.array_equal(state["compensation"].float().numpy(), fx[f"{name}.c.{s}"])

@@ -283,3 +283,24 @@ def test_dataset_rejects_missing_input_type(tmp_path):
     _, get_dataset, _ = loaders()
     with pytest.raises(ValueError, match="input_type"):
         _jsonl_dataset(tmp_path, get_dataset, None)
+
+
+def test_peft_adapter_directory_key_mapping(tmp_path):
+    """`peft_ckpt` (slam_model.py:210-213): adapter_config.json defines the LoRA, adapter_model.bin keys have the adapter name
+    stripped (peft 0.6.0 get_peft_model_state_dict) -> mapped to this model's state_dict keys"""
+    from slam_llm_amd.slam_model_hip import read_peft_adapter
+    d = tmp_path / "adapter"
+    d.mkdir()
+    (d / "adapter_config.json").write_text(json.dumps(dict(peft_type="LORA", r=4, lora_alpha=8, lora_dropout=0.1, bias="none",
+                                                           target_modules=["q_proj", "v_proj"], task_type="CAUSAL_LM")))
+    sd = {f"base_model.model.model.layers.{i}.self_attn.{m}.lora_{ab}.weight": torch.full((2, 2), float(i))
+          for i in range(2) for m in ("q_proj", "v_proj") for ab in "AB"}
+    torch.save(sd, d / "adapter_model.bin")
+    lora, state = read_peft_adapter(str(d))
+    assert lora == dict(lora_r=4, lora_alpha=8.0, lora_targets=("q_proj", "v_proj"), lora_dropout=0.1)
+    assert sorted(state)[0] == "llm.base_model.model.model.layers.0.self_attn.q_proj.lora_A.default.weight" and len(state) == 8
+    with pytest.raises(FileNotFoundError):
+        read_peft_adapter(str(tmp_path))
+    (d / "adapter_config.json").write_text(json.dumps(dict(peft_type="PREFIX_TUNING", r=4, lora_alpha=8, target_modules=[])))
+    with pytest.raises(NotImplementedError):
+        read_peft_adapter(str(d))

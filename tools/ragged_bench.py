@@ -1,6 +1,10 @@
 """GPU: the SURVEY 8d RAGGED set (clip durations ~U(2 s, 30 s), seed 1235, pad_or_trim off, answers ~U{8..128}) through the
-reference's dynamic-frame batcher (B * T_max <= 12000, right-padding collator) -- padded LLM pass vs cfg["varlen"] (packed
-sequences, no pad tokens).  Prints audio-seconds/sec for both on the SAME batches (true clip durations, SURVEY 8d metric)."""
+dynamic-frame batcher, four ways on the SAME clips:
+  padded          reference semantics: zero-padded mel batch through the encoder, padded [B, T_max] LLM pass
+  packed_llm      ++model_config.varlen=true: pad rows dropped before the LLM (seg_lo/seg_hi attention, per-token RoPE)
+  ragged          + ++model_config.varlen_encoder=true: per-clip frame counts through the encoder (no pad frames)
+  ragged_sum36k   ragged, batches formed by the packed-aware budget (sum of real tokens <= 36 000 instead of B * T_max <= 12 000)
+Prints audio-seconds/sec (true clip durations, SURVEY 8d metric) for each."""
 import json
 import os
 import sys
@@ -16,7 +20,7 @@ def main():
     from slam_llm_amd.train import train_step
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(1235)
-    n_clips = 160
+    n_clips = 320
     secs = torch.rand(n_clips, generator=g) * 28 + 2
     samples = []
     for s_ in secs.tolist():
@@ -25,11 +29,21 @@ def main():
         A = int(torch.randint(8, 129, (1,), generator=g))
         samples.append(batcher.make_sample(torch.zeros(n), torch.randint(3, 128000, (16,), generator=g).tolist(),
                                            torch.randint(3, 128000, (A - 1,), generator=g).tolist(), 2, alen))
-    groups = list(batcher.dynamic_batches(iter(samples), 12000))[:-1]
     res = {}
-    for varlen in (False, True):
+    variants = [("padded", dict(), 12000, "padded"), ("packed_llm", dict(varlen=True), 12000, "padded"),
+                ("ragged", dict(varlen=True, varlen_encoder=True), 12000, "padded"),
+                ("ragged_sum36k", dict(varlen=True, varlen_encoder=True), 36000, "sum")]
+    only = sys.argv[1].split(",") if len(sys.argv) > 1 else None
+    for name, extra, mfl, budget in variants:
+        if only and name not in only:
+            continue
+        groups = list(batcher.dynamic_batches(iter(samples), mfl, budget=budget))[:-1]
+        if budget == "padded":
+            groups = groups[:5]
+        else:
+            groups = groups[:3]
         cfg = make_config("whisper-large-v3", "llama-3-8b", lora_r=16, lora_alpha=32, lora_targets=("q_proj", "v_proj"),
-                          lora_dropout=0.05, pad_or_trim=False, varlen=varlen)
+                          lora_dropout=0.05, pad_or_trim=False, **extra)
         model = SlamHipModel(cfg, dev).init_random(42)
         model.train()
         opt = SlamAdamW(model, lr=1e-4)
@@ -41,6 +55,8 @@ def main():
         audio_s = sum(float(b["audio_len"].sum()) / 16000 for b in batches)
         tokens = sum(int(b["attention_mask"].sum()) for b in batches)
         padded = sum(b["attention_mask"].numel() for b in batches)
+        enc_rows_padded = sum(b["audio"].shape[0] * ((b["audio"].shape[1] // 160 + 1) // 2) for b in batches)
+        enc_rows_real = sum(sum((n // 160 + 1) // 2 for n in b["audio_len_list"]) for b in batches)
         for b in batches:        # one untimed pass over every batch shape (allocator, RoPE tables, kernel caches warm)
             train_step(model, b, opt)
         torch.cuda.synchronize()
@@ -49,10 +65,14 @@ def main():
             train_step(model, b, opt)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        res["packed" if varlen else "padded"] = dict(audio_s_per_s=audio_s / dt, ms_per_batch=dt / len(batches) * 1e3)
-        res["batches"], res["clips"], res["valid_tokens"], res["padded_tokens"] = len(batches), sum(len(g_) for g_ in groups), tokens, padded
+        res[name] = dict(audio_s_per_s=round(audio_s / dt, 1), ms_per_batch=round(dt / len(batches) * 1e3, 1), batches=len(batches),
+                         clips=sum(len(g_) for g_ in groups), llm_tokens_valid=tokens, llm_tokens_padded=padded,
+                         encoder_rows_real=enc_rows_real, encoder_rows_padded=enc_rows_padded,
+                         peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
+        print(name, res[name], flush=True)
         del model, opt, batches
         torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
     print(json.dumps(res))
 
 
