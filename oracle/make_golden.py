@@ -387,6 +387,55 @@ def gen_hubert():
     print("hubert_tiny.npz written", tuple(out.shape))
 
 
+def gen_hubert_ragged():
+    """Ragged raw-audio batch through the HF twin of fairseq's HuBERT with a padding mask.  The frame-level mask is fairseq's
+    rule (the reference calls fairseq, slam_model.py:336; HF derives frame lengths from the conv arithmetic instead and can
+    differ by one frame), injected by overriding HF's `_get_feature_vector_attention_mask`; everything downstream (padded frames
+    zeroed before the positional conv, masked as keys in every layer) is HF's own code, identical to fairseq's."""
+    from transformers import HubertConfig, HubertModel
+    cfg = HUBERT_TINY
+    hc = HubertConfig(hidden_size=cfg["hub_dim"], num_hidden_layers=cfg["hub_layers"], num_attention_heads=cfg["hub_heads"],
+                      intermediate_size=cfg["hub_ffn"], conv_dim=list(cfg["hub_conv_dim"]), conv_kernel=list(cfg["hub_conv_kernel"]),
+                      conv_stride=list(cfg["hub_conv_stride"]), conv_bias=True, feat_extract_norm="layer",
+                      do_stable_layer_norm=True, feat_proj_layer_norm=True, num_conv_pos_embeddings=cfg["hub_pos_k"],
+                      num_conv_pos_embedding_groups=cfg["hub_pos_groups"], hidden_dropout=0.0, attention_dropout=0.0,
+                      activation_dropout=0.0, feat_proj_dropout=0.0, layerdrop=0.0, mask_time_prob=0.0, mask_feature_prob=0.0,
+                      layer_norm_eps=cfg["hub_eps"], hidden_act="gelu", feat_extract_activation="gelu")
+    hc._attn_implementation = "eager"
+    m = HubertModel(hc).eval()
+    W = O.init_hubert_weights(cfg, seed=7)
+    sd = m.state_dict()
+    with torch.no_grad():
+        for k in sd:
+            if "pos_conv_embed.conv.parametrizations" in k or k == "masked_spec_embed":
+                continue
+            sd[k].copy_(W["encoder." + k])
+        w = W["encoder.encoder.pos_conv_embed.conv.weight"]
+        sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"].copy_(w)
+        sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"].copy_(w.norm(dim=(0, 1), keepdim=True))
+    m.load_state_dict(sd)
+    n_valid = torch.tensor([16000, 9000, 12345])
+    N = int(n_valid.max())
+    clips = O.synth_audio(3, 1.0, seed=4322)
+    wav = torch.zeros(3, N)
+    for b, n in enumerate(n_valid.tolist()):   # dataset `normalize` per clip (speech_dataset.py:96-97), collator zero padding (:238-244)
+        wav[b, :n] = torch.nn.functional.layer_norm(clips[b, :n], (n,))
+    amask = (torch.arange(N)[None, :] < n_valid[:, None]).long()
+
+    def fairseq_frame_mask(feature_vector_length, attention_mask):
+        return ~O.hubert_frame_padding_mask(attention_mask.shape[1], feature_vector_length, attention_mask.sum(-1))
+    m._get_feature_vector_attention_mask = fairseq_frame_mask
+    with torch.no_grad():
+        out = m(wav, attention_mask=amask).last_hidden_state
+    pad = O.hubert_frame_padding_mask(N, out.shape[1], n_valid)
+    fx = {"wav": wav.numpy(), "n_valid": n_valid.numpy(), "weights_sha256": np.array(wsum(W)), "out_shape": np.array(out.shape),
+          "frame_padding_mask": pad.numpy()}
+    valid = out.masked_fill(pad[:, :, None], 0.0)     # rows of padded frames are unspecified: compare valid frames only
+    pack(fx, "out", valid.numpy(), limit=65536)
+    np.savez_compressed(os.path.join(GOLD, "hubert_tiny_ragged.npz"), **fx)
+    print("hubert_tiny_ragged.npz written", tuple(out.shape), "valid frames", (~pad).sum(1).tolist())
+
+
 def gen_qformer():
     """The reference's EncoderProjectorQFormer (projector.py:51-80), imported unmodified, in eval mode (dropout off):
     output and gradients of every parameter for a fixed random cotangent."""
@@ -426,6 +475,7 @@ if __name__ == "__main__":
     gen_mel()
     gen_batcher()
     gen_hubert()
+    gen_hubert_ragged()
     gen_qformer()
     for nme, c in CASES.items():
         gen_step(nme, **c)

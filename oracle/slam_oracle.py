@@ -132,13 +132,29 @@ def hubert_config(**kw) -> dict:
     return c
 
 
-def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, prefix="encoder.") -> torch.Tensor:
+def hubert_frame_padding_mask(n_samples: int, n_frames: int, n_valid: torch.Tensor) -> torch.Tensor:
+    """fairseq HubertModel.forward_padding_mask (fairseq/models/hubert/hubert.py, fairseq is an un-vendored, unpinned dependency
+    of the reference: README.md:89-95): the sample-level padding mask [B, N] is cut to a multiple of the frame count, viewed as
+    [B, T', N // T'] and a frame is PADDING iff ALL of its samples are -- i.e. clip b keeps ceil(n_valid[b] / (N // T')) frames.
+    Returns bool [B, T'] with True = padding (what the reference forwards as `results["padding_mask"]`, slam_model.py:336-341)."""
+    chunk = n_samples // n_frames
+    keep = torch.clamp((n_valid + chunk - 1) // chunk, max=n_frames)
+    return torch.arange(n_frames)[None, :] >= keep[:, None]
+
+
+def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, prefix="encoder.",
+                   n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The HuBERT branch of slam_model.forward (src/slam_llm/models/slam_model.py:335-341: fairseq
     `self.encoder(source=audio, padding_mask=...)["encoder_out"]`), restated from the HF twin of fairseq's model
     (transformers/models/hubert/modeling_hubert.py: HubertFeatureEncoder with LayerNorm conv layers :127-151,
     HubertFeatureProjection :216-233, HubertPositionalConvEmbedding :45-93 (weight-norm folded into the weight),
-    HubertEncoderStableLayerNorm :550-625).  Equal-length, unpadded batches only (mask = None).
-    wav [B, N] (already layer-normed by the dataset, speech_dataset.py:96-97) -> [B, T', hub_dim]."""
+    HubertEncoderStableLayerNorm :550-625).
+    wav [B, N] (already layer-normed by the dataset, speech_dataset.py:96-97) -> [B, T', hub_dim].
+    n_valid [B] (ragged batch, zero-padded waveforms; the reference passes `padding_mask = 1 - audio_mask`): the conv stack runs
+    over the padded waveform, the frame mask follows fairseq (hubert_frame_padding_mask), padded frames are zeroed before the
+    positional conv (fairseq TransformerEncoder.extract_features: `x = index_put(x, padding_mask, 0)`; HF :571-575 the same) and
+    masked as attention KEYS in every layer; their own output rows are garbage (never read: the splice takes the clip's first
+    len//320//5 projector frames)."""
     x = wav[:, None, :]
     for i, (k, st) in enumerate(zip(cfg["hub_conv_kernel"], cfg["hub_conv_stride"])):
         p = f"{prefix}feature_extractor.conv_layers.{i}."
@@ -152,6 +168,11 @@ def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pre
     x = F.linear(x, W[p + "projection.weight"], W[p + "projection.bias"])
     p = prefix + "encoder."
     kpos = cfg["hub_pos_k"]
+    key_bias = None
+    if n_valid is not None:
+        pad = hubert_frame_padding_mask(wav.shape[1], x.shape[1], n_valid)
+        x = x.masked_fill(pad[:, :, None], 0.0)
+        key_bias = torch.zeros(pad.shape).masked_fill(pad, float("-inf"))[:, None, None, :]
     pos = F.conv1d(x.transpose(1, 2), W[p + "pos_conv_embed.conv.weight"], W[p + "pos_conv_embed.conv.bias"],
                    padding=kpos // 2, groups=cfg["hub_pos_groups"])
     if kpos % 2 == 0:
@@ -166,7 +187,10 @@ def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pre
         q = F.linear(h, W[q_ + "attention.q_proj.weight"], W[q_ + "attention.q_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
         k = F.linear(h, W[q_ + "attention.k_proj.weight"], W[q_ + "attention.k_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
         v = F.linear(h, W[q_ + "attention.v_proj.weight"], W[q_ + "attention.v_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
-        a = F.softmax((q @ k.transpose(2, 3)) * hd ** -0.5, dim=-1) @ v
+        sc = (q @ k.transpose(2, 3)) * hd ** -0.5
+        if key_bias is not None:
+            sc = sc + key_bias
+        a = F.softmax(sc, dim=-1) @ v
         a = a.transpose(1, 2).reshape(B, T, d)
         x = x + F.linear(a, W[q_ + "attention.out_proj.weight"], W[q_ + "attention.out_proj.bias"])
         h = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], eps)

@@ -497,9 +497,20 @@ class HipHubertEncoder(nn.Module):
             n = (n - k) // s_ + 1
         return n
 
+    def valid_frames(self, n_padded: int, n_valid: List[int]) -> List[int]:
+        """frames fairseq keeps per clip: its forward_padding_mask views the sample mask as [B, T', N // T'] and calls a frame
+        padding iff ALL its samples are (fairseq/models/hubert/hubert.py; the reference passes `padding_mask = 1 - audio_mask`,
+        slam_model.py:336) -> ceil(n / (N // T')), at most T'."""
+        T = self.out_frames(n_padded)
+        chunk = n_padded // T
+        return [min(T, (int(n) + chunk - 1) // chunk) for n in n_valid]
+
     @torch.no_grad()
-    def forward_wav(self, wav: torch.Tensor) -> torch.Tensor:
-        """wav [B, N] f32 (already normalised by the dataset) -> [B, T', hub_dim] bf16"""
+    def forward_wav(self, wav: torch.Tensor, n_valid: Optional[List[int]] = None) -> torch.Tensor:
+        """wav [B, N] f32 (already normalised by the dataset) -> [B, T', hub_dim] bf16.
+        n_valid (host ints, ragged batch of zero-padded waveforms): the conv stack runs over the padded waveform like the
+        reference's, padded frames (fairseq's rule, valid_frames) are zeroed before the positional conv and masked as attention
+        keys in every layer; their own output rows are unspecified (the splice never reads them)."""
         cfg, w = self.cfg, self.w
         B, N = wav.shape
         x2d, Tin, cin = wav.contiguous().view(B * N, 1), N, 1
@@ -513,6 +524,16 @@ class HipHubertEncoder(nn.Module):
         M = B * T
         h = ops.layernorm(x2d, w["fp_lw"], w["fp_lb"], eps)
         h = ops.gemm_nt(h, w["fp"], bias=w["fp_b"])
+        key_mask = None
+        if n_valid is not None:
+            keep = self.valid_frames(N, n_valid)
+            idx = torch.arange(M, dtype=torch.int32).view(B, T)
+            km = torch.zeros((B, round_up(T, 64)), dtype=torch.uint8)
+            for b_, kf in enumerate(keep):
+                idx[b_, kf:] = -1
+                km[b_, :kf] = 1
+            h = ops.gather_rows(h, idx.view(-1).to(wav.device, non_blocking=True))   # padded frames -> zero rows
+            key_mask = km.to(wav.device, non_blocking=True)
         G, kpos = cfg["hub_pos_groups"], cfg["hub_pos_k"]
         gch = d // G
         x = torch.empty((M, d), dtype=torch.bfloat16, device=wav.device)
@@ -531,7 +552,7 @@ class HipHubertEncoder(nn.Module):
             ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, out=hbuf)
             ops.gemm_nt(hbuf, w[f"{i}.qkv"], out=qkv, bias=w[f"{i}.qkv_b"])
             vt = ops.head_rope_transpose(qkv, 2 * d, B, T, H, 64)
-            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, want_lse=False, out=obuf)
+            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=False, out=obuf)
             ops.gemm_nt(obuf, w[f"{i}.out"], out=x, bias=w[f"{i}.out_b"], residual=x)
             ops.layernorm(x, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], eps, out=hbuf)
             ops.gemm_nt(hbuf, w[f"{i}.fc1"], out=fbuf, bias=w[f"{i}.fc1_b"], act=ACT_GELU)
@@ -1233,25 +1254,37 @@ class SlamHipModel(nn.Module):
         if input_ids is None or input_ids.device.type != "cuda":
             raise RuntimeError("SlamHipModel.forward needs the batch resident in HBM (move it with .to(device) as the "
                                "reference's train loop does, utils/train_utils.py:101-111)")
-        if self._stale or (self._always_refresh and self.training):
-            # params may have been updated by a foreign optimizer (torch.optim.AdamW on .parameters());
-            # refreshing is one cheap pass over the ~30 M trainable parameters.  SlamAdamW refreshes itself.
+        if self._stale or self._always_refresh:
+            # params may have been updated by a foreign optimizer (torch.optim.AdamW on .parameters()) -- also right before an
+            # eval-mode forward (the reference's evaluation() follows optimizer.step() directly, utils/train_utils.py:173-177);
+            # refreshing is one cheap pass over the ~30 M trainable parameters.  SlamAdamW refreshes itself and turns this off.
             self._refresh()
         B, T = input_ids.shape
         train = torch.is_grad_enabled() and labels is not None
         stash = {} if train else None
 
+        hub_pad = None
         if self.encoder_name == "hubert":
-            # raw-waveform encoder (slam_model.py:335-341); equal-length unpadded clips only this round
+            # raw-waveform encoder (slam_model.py:335-341)
             if audio is None:
                 raise RuntimeError("hubert encoder needs the raw `audio` batch key")
-            am, alen = kwargs.get("audio_mask", None), kwargs.get("audio_len", None)
-            ragged = (am is not None and not bool((am > 0).all())) or \
-                     (alen is not None and not bool((alen.to(audio.device) == audio.shape[1]).all()))
-            if ragged:   # zero-padded clips would be encoded as full-length audio (and fairseq's padding mask is not built)
-                raise NotImplementedError("ragged raw-audio batches for the HuBERT branch are not supported yet: batch "
-                                          "equal-length clips (audio_mask / audio_len say this batch is padded)")
-            enc = self.encoder.forward_wav(audio.float())
+            # valid samples per clip as host ints: the collator's python list when present (no sync), else audio_len / audio_mask
+            nv = kwargs.get("audio_len_list", None)
+            if nv is None and kwargs.get("audio_len", None) is not None:
+                nv = kwargs["audio_len"].tolist()
+            if nv is None and kwargs.get("audio_mask", None) is not None:
+                nv = (kwargs["audio_mask"] > 0).sum(1).tolist()
+            hub_pad = None
+            if nv is not None and min(nv) < audio.shape[1]:
+                # ragged batch: the reference hands fairseq `padding_mask = 1 - audio_mask` (slam_model.py:336)
+                enc = self.encoder.forward_wav(audio.float(), [int(n) for n in nv])
+                keep = self.encoder.valid_frames(audio.shape[1], nv)
+                hub_pad = torch.zeros((len(keep), enc.shape[1]), dtype=torch.float32)
+                for b_, kf in enumerate(keep):
+                    hub_pad[b_, kf:] = 1.0     # fairseq's frame padding mask: 1 = PADDING
+                hub_pad = hub_pad.to(dev, non_blocking=True)
+            else:
+                enc = self.encoder.forward_wav(audio.float())
         else:
             if audio_mel is None:
                 if audio is None:
@@ -1273,7 +1306,18 @@ class SlamHipModel(nn.Module):
             pass
         elif self.projector_name == "q-former":
             # audio_mel_post_mask is consumed only by this branch (slam_model.py:354-355); None = attend to all
-            pmask = kwargs.get("audio_mel_post_mask", None) if self.encoder_name == "whisper" else None
+            if self.encoder_name == "whisper":
+                pmask = kwargs.get("audio_mel_post_mask", None)
+            elif hub_pad is None:
+                pmask = None                    # nothing padded: fairseq returns no mask, the Q-Former attends to everything
+            elif self.cfg.get("hubert_qformer_mask_fix", False):
+                pmask = 1.0 - hub_pad           # corrected: attend to the REAL frames (++model_config.hubert_qformer_mask_fix=true)
+            else:
+                # reference behaviour: fairseq's padding mask (1 = padding) is handed to the Q-Former as
+                # encoder_attention_mask (1 = attend) WITHOUT inversion (slam_model.py:338-341 vs the av_hubert branch :346): a
+                # padded clip cross-attends to its padding frames only; a clip without padding has an all-zero mask, which HF
+                # turns into one constant additive bias = ordinary attention over all frames.
+                pmask = torch.where(hub_pad.sum(1, keepdim=True) > 0, hub_pad, torch.ones_like(hub_pad))
             proj = self.encoder_projector.forward_hip(enc, pmask, stash)
         else:
             proj = self.encoder_projector.forward_hip(enc, stash)  # [B, Ta, dl]

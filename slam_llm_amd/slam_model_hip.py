@@ -75,7 +75,10 @@ def build_config(train_config, model_config) -> dict:
                  varlen=bool(_get(model_config, "varlen", False)),
                  # ++model_config.varlen_encoder=true (with pad_or_trim=false): ragged clips are encoded without pad frames, each
                  # exactly as if alone in the batch -- a stated deviation from the reference's zero-padded batch
-                 varlen_encoder=bool(_get(model_config, "varlen_encoder", False)))
+                 varlen_encoder=bool(_get(model_config, "varlen_encoder", False)),
+                 # HuBERT + Q-Former on ragged batches: the reference forwards fairseq's padding mask un-inverted;
+                 # default = reference behaviour, true = attend to the real frames
+                 hubert_qformer_mask_fix=bool(_get(model_config, "hubert_qformer_mask_fix", False)))
     if enc_name == "hubert":
         hp = _get(model_config, "arch_encoder") or _guess_preset(str(_get(model_config, "encoder_path", "hubert-large")).replace("_", "-"), HUBERT_PRESETS)
         extra.update(HUBERT_PRESETS[hp])

@@ -677,3 +677,61 @@ def ops_logmel(dev, audio, n_mels, n):
     from slam_llm_amd import ops
     nv = torch.full((audio.shape[0],), n, dtype=torch.int32, device=dev)
     return ops.logmel(audio.to(dev), n_mels, n_samples=n // 160 * 160, n_valid=nv, per_clip=True)
+
+
+# ------------------------------------------------------------------------------------------------ ragged HuBERT (g15)
+def test_hubert_ragged_batch_matches_masked_twin_fixture(dev):
+    """ragged raw-audio batch with the padding mask the reference hands fairseq (slam_model.py:336): valid frames vs the fixture
+    produced by the HF twin run with fairseq's frame-mask rule (bf16 path: <= 3e-2 of tensor scale)"""
+    from oracle.make_golden_cases import HUBERT_TINY
+    from slam_llm_amd.model import HipHubertEncoder
+    fx = G.load("hubert_tiny_ragged")
+    W = O.init_hubert_weights(HUBERT_TINY, seed=7)
+    enc = HipHubertEncoder(dict(HUBERT_TINY), dev).load(W)
+    nv = [int(x) for x in fx["n_valid"]]
+    out = enc.forward_wav(torch.from_numpy(fx["wav"]).to(dev), nv)
+    keep = enc.valid_frames(fx["wav"].shape[1], nv)
+    pad = torch.from_numpy(fx["frame_padding_mask"])
+    assert keep == (~pad).sum(1).tolist()
+    got = out.float().cpu().masked_fill(pad[:, :, None], 0.0).numpy()
+    g, a = G.sub(fx, "out", got)
+    assert rel_err(a, g) < 3e-2 and G.cosine(g, a) > 0.9995, (rel_err(a, g), G.cosine(g, a))
+
+
+def test_hubert_ragged_linear_step_matches_oracle(dev):
+    """HuBERT -> linear projector -> LLM on a ragged raw-audio batch through the dataset plugin's collator (input_type raw:
+    len // 320 // 5 placeholders per clip, audio_mask): loss vs the fp32 oracle, and it trains"""
+    from oracle.make_golden_cases import HUBERT_TINY
+    from slam_llm_amd import batcher
+    from slam_llm_amd.model import SlamAdamW, SlamHipModel
+    cfg = dict(O.make_config(), **HUBERT_TINY)
+    cfg.update(encoder_name="hubert", enc_dim=HUBERT_TINY["hub_dim"])
+    W = {k: v for k, v in O.init_weights(cfg, seed=42).items() if not k.startswith("encoder.")}
+    W.update(O.init_hubert_weights(HUBERT_TINY, seed=7))
+    model = SlamHipModel(dict(cfg, lora_dropout=0.0), dev).load_weights(W)
+    model.train()
+    g = torch.Generator().manual_seed(3)
+    lens = [16000, 9000, 12345]
+    samples = []
+    for i, n in enumerate(lens):
+        a = torch.nn.functional.layer_norm(torch.randn(n, generator=g) * 0.1, (n,))
+        samples.append(batcher.make_sample(a, torch.randint(3, cfg["vocab"], (4,), generator=g).tolist(),
+                                           torch.randint(3, cfg["vocab"], (3 + i,), generator=g).tolist(), 2, batcher.raw_audio_length(n)))
+    batch = batcher.collate(samples, 0, left_pad_prompt=True, input_type="raw")
+    assert batch["audio_mask"].sum(1).tolist() == lens and [s["audio_length"] for s in samples] == [10, 5, 7]
+    ob = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    with torch.no_grad():
+        enc = O.hubert_encoder(W, cfg, ob["audio"], n_valid=torch.tensor(lens))
+        proj = O.projector_concat(W, enc, cfg["ds_rate"])
+        emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+        loss_ref, _ = O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
+    gb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    opt = SlamAdamW(model, lr=1e-3)
+    losses = []
+    for _ in range(3):
+        outputs, _ = model(**{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in gb.items()})
+        outputs.loss.backward()
+        opt.step(); opt.zero_grad()
+        losses.append(float(outputs.loss.detach()))
+    assert abs(losses[0] - float(loss_ref)) < 1.5e-2, (losses[0], float(loss_ref))
+    assert losses[2] < losses[0]

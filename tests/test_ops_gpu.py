@@ -800,10 +800,15 @@ def test_decode_attention_fused(dev, D, Hq, Hkv, lora):
 
 @pytest.mark.parametrize("name", ["fp32_params", "bf16_params", "bf16_params_kahan"])
 def test_anyprecision_adamw_matches_reference_class_fixture(dev, name):
-    """fused AnyPrecisionAdamW kernel vs tests/golden/anyprecision.npz (written by the REFERENCE's optimizer class, 6 steps): bf16
-    momentum / variance / compensation may differ from the CPU run by one bf16 ulp on a handful of elements (fma contraction of
-    a + alpha*b differs between the reference's CPU kernels and the GPU); parameters follow within that."""
+    """fused AnyPrecisionAdamW kernel, 6 steps, against
+      (a) the oracle restatement executed with torch ops ON THE DEVICE -- the platform the reference's optimizer runs on; the
+          restatement itself is pinned bit for bit to the reference's own class by tests/test_oracle_golden.py -- expected equal up
+          to one bf16 ulp on a handful of elements (fma contraction of a + alpha*b);
+      (b) for fp32 parameters also tests/golden/anyprecision.npz (written by the reference class on the CPU).  The bf16-parameter
+          fixtures are NOT comparable on a GPU: torch's CPU kernel rounds `alpha` of `add_(bf16, alpha=)` to bf16 first (0.1 ->
+          0.10009765625: 20 % of the momenta move by one ulp), the device kernel keeps it in fp32 -- as does this kernel."""
     ops = _ops()
+    from oracle import slam_oracle as O
     from tests.test_oracle_golden import ANYPRECISION_CASES
     fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "anyprecision.npz"))
     pdt, kahan, wd = ANYPRECISION_CASES[name]
@@ -811,6 +816,8 @@ def test_anyprecision_adamw_matches_reference_class_fixture(dev, name):
     p = torch.from_numpy(fx["p0"]).to(dev)
     if pbf:
         p = p.to(torch.bfloat16).float()
+    p_ref = p.to(pdt).clone()
+    st_ref = {}
     n = p.numel()
     m = torch.zeros(n, dtype=torch.bfloat16, device=dev)
     v = torch.zeros(n, dtype=torch.bfloat16, device=dev)
@@ -819,16 +826,25 @@ def test_anyprecision_adamw_matches_reference_class_fixture(dev, name):
 
     def ulps(got, want):      # distance in bf16 ulps
         a = got.float().cpu().view(torch.int32) >> 16
-        b = torch.from_numpy(want).view(torch.int32) >> 16
+        b = want.float().cpu().view(torch.int32) >> 16
         return (a - b).abs()
     for s in range(6):
         g = torch.from_numpy(fx[f"grad.{s}"]).to(dev)
         ops.adamw_anyprecision_step(p, g, m, v, c, pb, float(fx["lr"]), 0.9, 0.999, 1e-8, wd, s + 1, params_are_bf16=pbf)
-        for nme, t in (("m", m), ("v", v)) + ((("c", c),) if kahan else ()):
-            d = ulps(t, fx[f"{name}.{nme}.{s}"])
-            assert int(d.max()) <= (1 if nme != "c" else 4) and float((d > 0).float().mean()) < 0.02, (name, nme, s, int(d.max()), float((d > 0).float().mean()))
-        want = torch.from_numpy(fx[f"{name}.p.{s}"])
-        err = (p.cpu() - want).abs()
-        tol = (2.0 ** -7 if pbf else 1e-5) * want.abs().clamp(min=1e-3)
+        O.anyprecision_adamw_step(p_ref, g.to(pdt), st_ref, float(fx["lr"]), weight_decay=wd, use_kahan_summation=kahan)
+        pairs = [("m", m, st_ref["exp_avg"]), ("v", v, st_ref["exp_avg_sq"])] + ([("c", c, st_ref["compensation"])] if kahan else [])
+        for nme, t, want in pairs:
+            d = ulps(t, want)
+            assert float((d > 0).float().mean()) < 0.02, (name, nme, s, float((d > 0).float().mean()))
+            if nme == "c":   # the compensation is the rounding residual of p: a 1-ulp difference upstream moves it by up to one ulp OF p
+                assert bool(((t.float() - want.float()).abs() <= 2.0 ** -7 * p_ref.float().abs() + 1e-12).all()), (name, s)
+            else:
+                assert int(d.max()) <= 1, (name, nme, s, int(d.max()))
+        err = (p - p_ref.float()).abs().cpu()
+        tol = (2.0 ** -7 if pbf else 1e-5) * p_ref.float().abs().clamp(min=1e-3).cpu()
         assert float((err > tol).float().mean()) < 0.02, (name, s, float(err.max()))
         assert torch.equal(pb.float().cpu(), p.cpu().to(torch.bfloat16).float())
+        if not pbf:
+            want = torch.from_numpy(fx[f"{name}.p.{s}"])
+            assert float(((p.cpu() - want).abs() > 1e-5 * want.abs().clamp(min=1e-3)).float().mean()) < 0.02
+            assert float((ulps(m, torch.from_numpy(fx[f"{name}.m.{s}"])) > 0).float().mean()) < 0.02

@@ -83,6 +83,20 @@ def test_hubert_encoder_matches_hf_twin_of_reference():
     G.check_packed(fx, "out", out.numpy(), atol=3e-5, rtol=1e-4)
 
 
+def test_hubert_ragged_batch_matches_masked_twin():
+    """ragged raw-audio batch: oracle (fairseq frame-mask rule + zeroed padded frames + key masking) == HF HubertModel run
+    with that frame mask (fixture), on the valid frames"""
+    from oracle.make_golden_cases import HUBERT_TINY
+    fx = G.load("hubert_tiny_ragged")
+    W = O.init_hubert_weights(HUBERT_TINY, seed=7)
+    nv = torch.from_numpy(fx["n_valid"])
+    with torch.no_grad():
+        out = O.hubert_encoder(W, HUBERT_TINY, torch.from_numpy(fx["wav"]), n_valid=nv)
+    pad = O.hubert_frame_padding_mask(fx["wav"].shape[1], out.shape[1], nv)
+    assert np.array_equal(pad.numpy(), fx["frame_padding_mask"]) and (~pad).sum(1).tolist() == [49, 28, 38]
+    G.check_packed(fx, "out", out.masked_fill(pad[:, :, None], 0.0).numpy(), atol=3e-5, rtol=1e-4)
+
+
 def test_qformer_projector_matches_reference_module():
     from oracle.make_golden_cases import QFORMER_CASE as C
     fx = G.load("qformer")
