@@ -19,6 +19,7 @@
 // never masked.  A row with no visible key yields O = 0, LSE = +inf (P = 0 in the backward)
 // so pad rows stay finite.  Positions/rows beyond T are handled by clamped/zero loads and guarded stores.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -693,6 +694,353 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward dK/dV, second form (shipped): the round-1 kernel above is LATENCY bound -- ~9.7 k cycles per 32-query tile against
+// 0.5 k cycles of MFMA work per wave: one 32 KiB tile per workgroup in flight (64 KiB per CU) cannot cover the ~2 us an HBM/L2
+// round trip takes under load.  Here
+//   * a workgroup is 8 waves x 16 keys = 128 keys, so every staged Q / dO tile is used by twice as many keys (half the bytes
+//     per FLOP);
+//   * the tiles are DMA'd HBM -> LDS (global_load_lds_dwordx4, no staging registers) into a ring of 4 stages; three tiles
+//     (96 KiB per CU) are in flight while the fourth is consumed; the waits are counted (vmcnt), one raw barrier per tile;
+//   * the LDS images keep the XOR swizzles of the first form: the DMA destination is lane-linear, so the swizzle is applied
+//     to the per-lane SOURCE chunk (same involution as on the read side).
+// The arithmetic per wave and tile is unchanged (same masks, same RoPE / GQA epilogue).
+// ------------------------------------------------------------------------------------------
+// The DMA is issued from inline asm: hipcc (ROCm 7.2) protects every LDS read that follows a global_load_lds BUILTIN with
+// s_waitcnt vmcnt(0) (it cannot tell the ring stages apart), which drains the three tiles in flight on every iteration.  An
+// asm DMA is invisible to that bookkeeping; the counted vmcnt + barrier below order it by hand.  M0 (the DMA's LDS base) is
+// compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(lds_dst_uniform)
+               : "memory");
+}
+// buffer-descriptor form (buffer_load_dwordx4 ... offen lds): one 32-bit byte offset per lane, range-checked against
+// num_records (rows past the end of the tensor read as zeros: no clamps), the tile part of the address is a scalar
+__device__ __forceinline__ void bufdma16_asm(__amdgpu_buffer_rsrc_t srd, unsigned voff, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(srd), "s"(lds_dst_uniform)
+               : "memory");
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// hand-placed LDS reads: the result register is "ready" for the compiler at once, so every use MUST sit behind an lds_wait
+// that names it (LDS operations return in order: lgkmcnt(N) = all but the youngest N have landed)
+template <int OFF>
+__device__ __forceinline__ frag_t lds_read128(unsigned addr) {
+  frag_t r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ void lds_landed(frag_t& r) { asm volatile("" : "+v"(r)); }
+template <int N, class... T>
+__device__ __forceinline__ void lds_wait(T&... regs) {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  (lds_landed(regs), ...);
+}
+// XOR key of the 16-byte chunks of row `row` of a row-major ring sub-tile
+template <int D>
+__device__ __forceinline__ int ring_swz(int row) {
+  const int i = ((row >> 3) << 2) | (row & 3);   // position of the row inside its fragment (0..15)
+  return D == 128 ? i : (i >> 1);
+}
+
+// ABL != 0: timing ablations for tools/attn_bwd_bench.py (WRONG results): 1 no DMA inside the loop, 2 no softmax arithmetic,
+// 5 no barrier
+template <int D, bool CAUSAL, int ABL = 0>
+__global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
+  constexpr int KD = D / 32;
+  constexpr int DF = D / 16;
+  constexpr int ROWB = D * 2;
+  constexpr int KCH = D / 8;
+  constexpr int KCM = KCH - 1;
+  constexpr int NS = 4;                       // ring stages
+  constexpr int SUB = 32 * ROWB;              // bytes of one sub-tile: [32][D] row-major == [D][32] transposed
+  constexpr int STG = 4 * SUB + 1024;         // Q | dO | Qt | dOt | LSE[32] Delta[32] (+ the rest of that DMA piece)
+  constexpr int NI = SUB / 1024;              // 1 KiB DMA instructions per sub-tile (8 for D = 128, 4 for D = 64)
+  constexpr int NU = 4 * NI / 8;              // tile DMA instructions per wave and stage
+  constexpr int PW = NU;                      // (wave 0: + 1, the LSE / Delta line)
+  constexpr int RPI = 1024 / ROWB;            // rows of a row-major sub-tile per DMA instruction (4 | 8)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.z, hk = blockIdx.y;
+  const int G = p.Hq / p.Hkv;
+  const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
+  const int kb0 = blockIdx.x * 128, kw0 = kb0 + wave * 16;
+  const int key = kw0 + li;
+  const bool kok = key < Tk && (!p.kmask || p.kmask[(int64_t)b * Tkp + min(key, Tkp - 1)] != 0);
+
+  frag_t kf[KD], vf[KD];
+#pragma unroll
+  for (int kd = 0; kd < KD; kd++) {
+    const bool inb = key < Tk;
+    kf[kd] = inb ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * Tk + key) * p.ldk + hk * D + kd * 32 + g * 8) : zero_frag();
+    vf[kd] = inb ? *reinterpret_cast<const frag_t*>(p.V + ((int64_t)b * Tk + key) * p.ldv + hk * D + kd * 32 + g * 8) : zero_frag();
+  }
+  f32x4_t dk[DF], dv[DF];
+#pragma unroll
+  for (int df = 0; df < DF; df++) {
+    dk[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    dv[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const float sl2 = p.scale * LOG2E;
+  const int qstart = CAUSAL ? (kb0 / 32) * 32 : 0;
+  const int qend = p.seg_hi ? min(Tq, p.seg_hi[(int64_t)b * Tk + min(kb0 + 127, Tk - 1)]) : Tq;
+  int khi = p.seg_hi ? p.seg_hi[(int64_t)b * Tk + min(key, Tk - 1)] : 0x7fffffff;
+  // every ordinary load above must have RETURNED before the first asm DMA is issued: hipcc would otherwise sink its
+  // s_waitcnt vmcnt(0) for them to their first use inside the tile loop, where the hardware counter also holds the DMAs
+#pragma unroll
+  for (int kd = 0; kd < KD; kd++) asm volatile("" : "+v"(kf[kd]), "+v"(vf[kd]));
+  asm volatile("" : "+v"(khi));
+  // wave-uniform facts for the mask-free path: all 16 keys of this wave exist and are attendable; first query row that some
+  // key of the wave must NOT see (seg_hi is non-decreasing: the wave's first key has the smallest)
+  const bool wave_all_keys = __builtin_amdgcn_readfirstlane(__all(kok ? 1 : 0));
+  const int qlim = min(Tq, __builtin_amdgcn_readfirstlane(khi));
+  const int nq = max(0, (qend - qstart + 31) / 32);
+  const int ntiles = G * nq;
+
+  // ---- DMA issue of one tile into one stage.  This wave owns DMA instructions idx = wave + 8u (u < NU) of the 4 * NI that
+  // make a stage: sub-tile sub = idx / NI (0 Q, 1 dO, 2 Q^T, 3 dO^T), piece j = idx % NI.  Per lane ONE byte offset per owned
+  // instruction is computed here; per tile only a scalar is added (the first form spent more VALU on 64-bit address math and
+  // the tile-index division than on the softmax). ----
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_offset_of(lds));
+  const int nB = gridDim.z;
+  const __amdgpu_buffer_rsrc_t srd_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, (unsigned)((((int64_t)nB * Tq - 1) * p.ldq + (int64_t)p.Hq * D) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_do = __builtin_amdgcn_make_buffer_rsrc((void*)p.dO, 0, (unsigned)((((int64_t)nB * Tq - 1) * p.lddo + (int64_t)p.Hq * D) * 2), 0x00020000);
+  const unsigned tbytes = (unsigned)((int64_t)nB * p.Hq * D * Tqp * 2);
+  const __amdgpu_buffer_rsrc_t srd_qt = __builtin_amdgcn_make_buffer_rsrc((void*)p.Qt, 0, tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_dot = __builtin_amdgcn_make_buffer_rsrc((void*)p.dOt, 0, tbytes, 0x00020000);
+  // D = 128 (NI = 8): instruction u of this wave is piece j = wave of sub-tile u.  D = 64 (NI = 4): waves 0-3 take Q and Q^T,
+  // waves 4-7 take dO and dO^T, piece j = wave & 3.  Either way the first NU / 2 are row-major, the rest transposed, and the
+  // descriptor of each is fixed per wave.
+  const bool second = (D == 64) && wave >= 4;
+  const int jpiece = (D == 128) ? wave : (wave & 3);
+  __amdgpu_buffer_rsrc_t srd_u[NU];
+  unsigned voff[NU], ldu[NU], dsto[NU];
+#pragma unroll
+  for (int u = 0; u < NU; u++) {
+    const int sub = (D == 128) ? u : 2 * u + (second ? 1 : 0);   // 0 Q, 1 dO, 2 Q^T, 3 dO^T
+    const bool isdo = sub & 1;
+    if (u < NU / 2) {
+      const int row = jpiece * RPI + lane / KCH, c = lane % KCH;
+      ldu[u] = (unsigned)(isdo ? p.lddo : p.ldq);
+      srd_u[u] = isdo ? srd_do : srd_q;
+      voff[u] = (unsigned)(((int64_t)b * Tq + row) * ldu[u] + ((c ^ ring_swz<D>(row)) << 3)) * 2u;
+    } else {
+      const int d = jpiece * 16 + (lane >> 2), c = lane & 3;
+      ldu[u] = 0;
+      srd_u[u] = isdo ? srd_dot : srd_qt;
+      voff[u] = (unsigned)((int64_t)d * Tqp + ((c ^ ((d >> 2) & 3)) << 3)) * 2u;
+    }
+    dsto[u] = (unsigned)(sub * SUB + jpiece * 1024);
+  }
+  // the LSE / Delta line: the DMA image is lane-linear (lane l -> byte 16 l of the 1 KiB piece); lanes 0-7 carry LSE, lanes
+  // 8-15 Delta (bytes 128-255), the rest repeat lane 0
+  const float* ld_src = (lane < 16 && lane >= 8 ? p.Delta + (lane - 8) * 4 : p.LSE + (lane < 8 ? lane * 4 : 0));
+  int i_hh = 0, i_qi = 0;   // (head of the GQA group, query tile) of the next tile to issue -- advanced incrementally, no division
+  auto issue = [&](int s) {
+    const int h = hk * G + i_hh, q0 = qstart + i_qi * 32;
+    const unsigned st = lds0 + (unsigned)(s * STG);
+    const unsigned s_row = (unsigned)q0 * 2u;                                              // x ld below
+    const unsigned s_t = (unsigned)((((int64_t)b * p.Hq + h) * D) * Tqp + q0) * 2u;
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(st + dsto[u]);
+      const unsigned so = (u < NU / 2) ? s_row * ldu[u] + (unsigned)(h * D) * 2u : s_t;
+      bufdma16_asm(srd_u[u], voff[u] + __builtin_amdgcn_readfirstlane(so), dst);
+    }
+    // LSE[q0 .. q0+31] (lanes 0-7, 16 bytes each) and Delta[q0 .. q0+31] (lanes 16-23 -> +1 KiB... see ld_lane_off): wave 0
+    // alone fetches them, one instruction with per-lane 64-bit addresses (every extra LDS-DMA instruction costs its wave
+    // 100-200 cycles of issue, MI355X_MICROARCH "LDS-DMA piece issue cost")
+    if (wave == 0) {
+      const int64_t e = ((int64_t)b * p.Hq + h) * Tqp + q0;
+      glds16_asm(ld_src + e, __builtin_amdgcn_readfirstlane(st + (unsigned)(4 * SUB)));
+    }
+    // advance to the next tile; past the end the last tile is re-fetched into a stage nobody reads (keeps the counts uniform)
+    if (i_hh * nq + i_qi + 1 < ntiles) {
+      if (++i_qi == nq) {
+        i_qi = 0;
+        ++i_hh;
+      }
+    }
+  };
+
+  // per-lane LDS read addresses (stage 0).  Row-major Q / dO sub-tiles: fragment f, A-operand row i = li is tile row
+  // 8 * (i / 4) + 4 f + i % 4 (so that the lane's eight S^T values are the CONTIGUOUS queries 8 g .. 8 g + 7 and the second
+  // product's Q^T / dO^T operand is one 16-byte LDS read); a row's 16-byte chunks are XOR-swizzled with swz(row) below, which
+  // is distinct over the 16 rows of a fragment (conflict-free b128 reads).  Transposed sub-tiles: [D][32 queries], 64-byte
+  // rows, chunk ^ ((d >> 2) & 3).
+  unsigned aA0[KD];
+  {
+    const int row = 8 * (li >> 2) + (li & 3);   // + 4 f through the instruction offset
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) aA0[kd] = lds0 + (unsigned)(row * ROWB + (((kd * 4 + g) ^ ring_swz<D>(row)) << 4));
+  }
+  const unsigned aL0 = lds0 + (unsigned)(32 * g);
+  const unsigned aB0 = lds0 + (unsigned)(li * 64 + ((g ^ ((li >> 2) & 3)) << 4));
+
+  if (ntiles > 0) {
+    issue(0);
+    issue(1);
+    issue(2);
+  }
+  int c_qi = 0;   // query tile of the tile being consumed
+  for (int it = 0; it < ntiles; it++) {
+    const int q0 = qstart + c_qi * 32;
+    if (++c_qi == nq) c_qi = 0;
+    const int s = it & (NS - 1);
+    // tile `it` has landed when at most the two younger tiles' DMA of this wave are outstanding; after the barrier every
+    // wave's share has, and everybody is done reading stage (it - 1) % NS, which the next DMA refills
+    if constexpr (ABL != 1) {
+      if (wave == 0) {
+        if constexpr (PW == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        if constexpr (PW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+    }
+    static_assert(PW == 4 || PW == 2, "counted waits above assume 4 (D = 128) or 2 (D = 64) tile DMA per wave and stage");
+    if constexpr (ABL != 5) __builtin_amdgcn_s_barrier();
+    if constexpr (ABL != 1) issue((it + 3) & (NS - 1));   // (issuing these in the softmax stretch instead measured 2 % slower)
+    if (kw0 >= Tk || (CAUSAL && q0 + 31 < kw0)) continue;
+    // ---- one tile, LDS reads and their waits placed by hand (hipcc's own order was read -> wait -> two MFMAs, sixteen times
+    // per tile: every pair of products exposed a full LDS latency, and since the barrier releases all eight waves at once
+    // nothing else was runnable; timing ablations in profiles/r02_attention_bwd.md).  The reads are asm so that the compiler
+    // cannot re-serialise them; a wait names the registers it completes ("+v"), which orders their consumers behind it.
+    const unsigned so = (unsigned)(s * STG);
+    unsigned aA[KD];
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) aA[kd] = aA0[kd] + so;
+    const unsigned aL = aL0 + so, aB = aB0 + so;
+    frag_t q0f[KD], d0f[KD], q1f[KD], d1f[KD], lse0, lse1, del0, del1;
+    frag_t bq[DF], bd[DF];
+    static_for<0, KD>([&](auto kd) {
+      q0f[kd] = lds_read128<0>(aA[kd]);
+      d0f[kd] = lds_read128<SUB>(aA[kd]);
+    });
+    lse0 = lds_read128<4 * SUB>(aL);
+    lse1 = lds_read128<4 * SUB + 16>(aL);
+    del0 = lds_read128<4 * SUB + 128>(aL);
+    del1 = lds_read128<4 * SUB + 144>(aL);
+    f32x4_t sacc[2], dp[2];
+    sacc[0] = sacc[1] = dp[0] = dp[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // fragment 0 products while fragment 1's operands are fetched (2 * KD + 4 reads outstanding at every wait)
+    static_for<0, KD>([&](auto kd) {
+      lds_wait<2 * KD + 2>(q0f[kd], d0f[kd]);
+      q1f[kd] = lds_read128<4 * ROWB>(aA[kd]);
+      d1f[kd] = lds_read128<SUB + 4 * ROWB>(aA[kd]);
+      sacc[0] = mfma16(q0f[kd], kf[kd], sacc[0]);
+      dp[0] = mfma16(d0f[kd], vf[kd], dp[0]);
+    });
+    // fragment 1 products while the first half of the dO^T / Q^T operands is fetched
+    static_for<0, KD>([&](auto kd) {
+      if constexpr (kd == 0) lds_wait<2 * KD - 2>(lse0, lse1, del0, del1, q1f[kd], d1f[kd]);
+      else lds_wait<2 * KD - 2>(q1f[kd], d1f[kd]);
+      bd[kd] = lds_read128<3 * SUB + kd * 1024>(aB);
+      bq[kd] = lds_read128<2 * SUB + kd * 1024>(aB);
+      sacc[1] = mfma16(q1f[kd], kf[kd], sacc[1]);
+      dp[1] = mfma16(d1f[kd], vf[kd], dp[1]);
+    });
+    // softmax arithmetic (covers the latency of those reads).  Element (f, r) of this lane is query q0 + 8g + 4f + r.
+    f32x4_t pm[2], ds[2];
+    const f32x4_t l4[2] = {__builtin_bit_cast(f32x4_t, lse0), __builtin_bit_cast(f32x4_t, lse1)};
+    const f32x4_t e4[2] = {__builtin_bit_cast(f32x4_t, del0), __builtin_bit_cast(f32x4_t, del1)};
+    // interior tile: every (key, query) pair of this wave is visible -- no masks (3 of 4 tiles at the Llama shape)
+    const bool interior = wave_all_keys && q0 + 32 <= qlim && (!CAUSAL || kw0 + 15 <= q0);
+    if (interior) {
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float pv = fast_exp2(__builtin_fmaf(sacc[f][r], sl2, -LOG2E * l4[f][r]));
+          pm[f][r] = pv;
+          ds[f][r] = pv * (dp[f][r] - e4[f][r]) * p.scale;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int q = q0 + 8 * g + 4 * f + r;
+          if constexpr (ABL == 2) {
+            pm[f][r] = sacc[f][r];
+            ds[f][r] = dp[f][r];
+            continue;
+          }
+          const bool ok = kok && q < Tq && (!CAUSAL || key <= q) && q < khi;
+          const float pv = ok ? fast_exp2(__builtin_fmaf(sacc[f][r], sl2, -LOG2E * l4[f][r])) : 0.f;
+          pm[f][r] = pv;
+          ds[f][r] = ok ? pv * (dp[f][r] - e4[f][r]) * p.scale : 0.f;
+        }
+      }
+    }
+    const frag_t pb = pack_frag(pm[0], pm[1]);
+    const frag_t dsb = pack_frag(ds[0], ds[1]);
+    // dV / dK products, operands KD fragments ahead
+    static_for<0, DF>([&](auto df) {
+      if constexpr (df + KD < DF) {
+        bd[df + KD] = lds_read128<3 * SUB + (df + KD) * 1024>(aB);
+        bq[df + KD] = lds_read128<2 * SUB + (df + KD) * 1024>(aB);
+        lds_wait<2 * KD>(bd[df], bq[df]);
+      } else {
+        lds_wait<2 * (DF - df - 1)>(bd[df], bq[df]);
+      }
+      dv[df] = mfma16(bd[df], pb, dv[df]);
+      dk[df] = mfma16(bq[df], dsb, dk[df]);
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMAs still target this workgroup's LDS
+  if (key >= Tk) return;
+  if (p.rope_cos) rope_grad_inplace<DF>(dk, p.rope_cos, p.rope_sin, p.rope_pos ? p.rope_pos[(int64_t)b * Tk + key] : key, D, g);
+  bf16_t* krow = p.dK + ((int64_t)b * Tk + key) * p.lddk + hk * D;
+  bf16_t* vrow = p.dV + ((int64_t)b * Tk + key) * p.lddv + hk * D;
+#pragma unroll
+  for (int df = 0; df < DF; df++) {
+    uint2 w;
+    w.x = pack2bf(dk[df][0], dk[df][1]);
+    w.y = pack2bf(dk[df][2], dk[df][3]);
+    *reinterpret_cast<uint2*>(krow + df * 16 + 4 * g) = w;
+    w.x = pack2bf(dv[df][0], dv[df][1]);
+    w.y = pack2bf(dv[df][2], dv[df][3]);
+    *reinterpret_cast<uint2*>(vrow + df * 16 + 4 * g) = w;
+  }
+}
+
+template <int D, bool CAUSAL, int ABL = 0>
+int launch_dkdv_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
+  constexpr int lds = 4 * (4 * 32 * D * 2 + 1024);
+  static bool attr_set = false;
+  auto kern = attn_bwd_dkdv_ring_kernel<D, CAUSAL, ABL>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      slam_set_error("slam_attn_bwd: cannot raise the LDS limit to %d", lds);
+      return -2;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  return 0;
+}
+
+int g_attn_bwd_variant = 0;   // 0 = ring kernels (shipped), 1 = round-1 kernels (A/B reference for tools)
 int g_attn_fwd_qf = 0;   // 16-row query fragments per wave of the forward kernel: 0 = auto, 1 / 2 forced (tools)
 
 int check_common(const char* name, int64_t B, int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv,
@@ -707,6 +1055,12 @@ int check_common(const char* name, int64_t B, int64_t Tq, int64_t Tk, int64_t Tq
 }
 
 }  // namespace
+
+extern "C" int slam_attn_set_bwd_variant(int variant) {   // tools: 0 = DMA-ring backward kernels (shipped), 1 = round-1 kernels
+  SLAM_CHECK_ARG(variant == 0 || variant == 1 || variant == 11 || variant == 12 || variant == 15, "slam_attn_set_bwd_variant: %d (0 | 1 | 11, 12, 15 timing ablations)", variant);
+  g_attn_bwd_variant = variant;
+  return 0;
+}
 
 extern "C" int slam_attn_set_fwd_qf(int qf) {
   SLAM_CHECK_ARG(qf >= 0 && qf <= 2, "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2)", qf);
@@ -773,23 +1127,38 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   hipStream_t s = (hipStream_t)stream;
   dim3 gq((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B);
   dim3 gk((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);
+  dim3 gk2((unsigned)cdiv64(Tk, 128), (unsigned)Hkv, (unsigned)B);
+  const bool ring = g_attn_bwd_variant != 1;
+  int rc = 0;
+  if (g_attn_bwd_variant > 10 && D == 128 && causal) {   // timing ablations of the D = 128 causal ring kernel (tools only)
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, dim3(256), 0, s, p);
+    switch (g_attn_bwd_variant) {
+      case 11: rc = launch_dkdv_ring<128, true, 1>(p, gk2, s); break;
+      case 12: rc = launch_dkdv_ring<128, true, 2>(p, gk2, s); break;
+      default: rc = launch_dkdv_ring<128, true, 5>(p, gk2, s); break;
+    }
+    if (rc) return rc;
+    SLAM_CHECK_LAUNCH("slam_attn_bwd");
+    return 0;
+  }
   if (D == 64) {
     if (causal) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, dim3(256), 0, s, p);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true>), gk, dim3(256), 0, s, p);
+      if (ring) rc = launch_dkdv_ring<64, true>(p, gk2, s); else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true>), gk, dim3(256), 0, s, p);
     } else {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), gq, dim3(256), 0, s, p);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false>), gk, dim3(256), 0, s, p);
+      if (ring) rc = launch_dkdv_ring<64, false>(p, gk2, s); else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false>), gk, dim3(256), 0, s, p);
     }
   } else {
     if (causal) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, dim3(256), 0, s, p);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, true>), gk, dim3(256), 0, s, p);
+      if (ring) rc = launch_dkdv_ring<128, true>(p, gk2, s); else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, true>), gk, dim3(256), 0, s, p);
     } else {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<128, false>), gq, dim3(256), 0, s, p);
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false>), gk, dim3(256), 0, s, p);
+      if (ring) rc = launch_dkdv_ring<128, false>(p, gk2, s); else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false>), gk, dim3(256), 0, s, p);
     }
   }
+  if (rc) return rc;
   SLAM_CHECK_LAUNCH("slam_attn_bwd");
   return 0;
 }

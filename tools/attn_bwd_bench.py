@@ -34,7 +34,24 @@ def fwd():
     ops.attn_fwd(q2, k2, vt, B, T, Hq, Hkv, D, True, scale, key_mask=km, out=o)
 
 
-for name, f, flops in (("fwd", fwd, 4.0 * B * Hq * T * T * D * 0.5), ("bwd", bwd, 10.0 * B * Hq * T * T * D * 0.5)):
+from slam_llm_amd.lib import call as _call  # noqa: E402
+
+
+def variant(v):
+    def run():
+        _call("slam_attn_set_bwd_variant", v)
+        bwd()
+        _call("slam_attn_set_bwd_variant", 0)
+    return run
+
+
+bwd_old = variant(1)
+ABL = {11: "no DMA in loop", 12: "no softmax VALU", 15: "no barrier"}
+
+
+for name, f, flops in (("fwd", fwd, 4.0 * B * Hq * T * T * D * 0.5), ("bwd (ring kernels)", bwd, 10.0 * B * Hq * T * T * D * 0.5),
+                       ("bwd (round-1 kernels)", bwd_old, 10.0 * B * Hq * T * T * D * 0.5)) + tuple(
+                           (f"bwd ablation: {n}", variant(v), 10.0 * B * Hq * T * T * D * 0.5) for v, n in ABL.items()):
     for _ in range(3):
         f()
     torch.cuda.synchronize()
