@@ -71,6 +71,11 @@ int slam_conv1d_k3_im2col(const void* in, int in_dtype, void* out, int64_t B, in
                           int64_t stride, int64_t Kp, const int32_t* n_valid, void* stream);
 /* n_valid (nullable, [B]): frames at or beyond n_valid[b] read as zero (ragged encoder: each clip sees the zero padding it
  * would see alone; the reference zero-pads in mel space, speech_dataset_large.py:194-197, and has no length argument). */
+/* adjoint of the above for unfrozen-encoder training (train_config.freeze_encoder=false, src/slam_llm/models/slam_model.py:110-113:
+ * autograd then runs F.conv1d's backward, models/encoder.py:18-19): dcols [B*Tout, ldc >= 3C] bf16 = dz . W -> dx [B, Tin, C] bf16,
+ * dx[b, t, c] = sum of dcols[b, o, j*C + c] over stride*o + j - 1 == t. */
+int slam_conv1d_k3_col2im(const void* dcols, int64_t ldc, void* dx, int64_t B, int64_t Tin, int64_t C, int64_t stride,
+                          void* stream);
 
 /* row gather, bf16: dst[r, 0:width) = src[idx[r]*src_stride + 0:width), idx[r] < 0 -> zeros.  Packs the valid rows of a padded
  * batch, un-packs them (inverse index), and builds the projector's k-frame windows (models/projector.py:15-23) over a packed

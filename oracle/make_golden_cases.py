@@ -27,3 +27,7 @@ GENERATE_CASE = dict(cfg=O.make_config(), lm_head_scales=(24.0, 5.0), clip_sampl
 
 # cov1d-linear projector (f4, models/projector.py:29-49): T not a multiple of k (tail frames dropped by the strided conv)
 COV1D_CASE = dict(enc_dim=128, llm_dim=192, k=5, B=2, T=43)
+
+# unfrozen-encoder training (f4, train_config.freeze_encoder=false): step_tiny's architecture, odd mel frame count (conv2's last
+# window hangs over the edge) and T2 not a multiple of the projector's k (tail frames get zero gradient)
+UNFROZEN_CASE = dict(cfg=O.make_config(), clip_seconds=1.77, answer_lens=(5, 9), left_pad=True, lr=2e-3)

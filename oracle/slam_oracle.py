@@ -293,26 +293,36 @@ def _mha(W, p, hq, hkv, H, key_mask=None):
     return (F.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, Tq, d)
 
 
-def projector_qformer(W, cfg, x: torch.Tensor, atts: Optional[torch.Tensor], prefix="encoder_projector.") -> torch.Tensor:
+def projector_qformer(W, cfg, x: torch.Tensor, atts: Optional[torch.Tensor], prefix="encoder_projector.",
+                      hidden_masks: Optional[list] = None) -> torch.Tensor:
     """EncoderProjectorQFormer.forward (src/slam_llm/models/projector.py:69-80) over HF Blip2QFormerModel
-    (transformers/models/blip_2/modeling_blip_2.py:536-760, 849-940), dropout = 0 (eval-mode parity; the HIP path
-    implements no dropout).  x [B, Tk, d_enc], atts [B, Tk] (1 = attend) -> [B, Q, llm_dim]."""
+    (transformers/models/blip_2/modeling_blip_2.py:536-760, 849-940).  x [B, Tk, d_enc], atts [B, Tk] (1 = attend) ->
+    [B, Q, llm_dim].  hidden_masks=None is eval mode (no dropout).  Train mode: the stack's hidden dropouts
+    (hidden_dropout_prob: after the query LayerNorm, Blip2QFormerModel.forward; after each output projection before the
+    residual add, Blip2QFormerSelfOutput / Blip2QFormerOutput) multiply by the given masks [B, Q, d] (values 0 or 1/(1-p)),
+    consumed in forward order -- torch's dropout RNG stream cannot be shared with a device kernel, so the masks are an input.
+    The attention-probability dropout (attention_probs_dropout_prob) is not modelled."""
     eps, H = cfg["qf_eps"], cfg["qf_heads"]
     B = x.shape[0]
     d = cfg["qf_dim"]
     P = prefix + "qformer."
-    h = F.layer_norm(W[prefix + "query"].expand(B, -1, -1), (d,), W[P + "layernorm.weight"], W[P + "layernorm.bias"], eps)
+    masks = iter(hidden_masks) if hidden_masks is not None else None
+
+    def drop(t):
+        return t if masks is None else t * next(masks)
+
+    h = drop(F.layer_norm(W[prefix + "query"].expand(B, -1, -1), (d,), W[P + "layernorm.weight"], W[P + "layernorm.bias"], eps))
     for l in range(cfg["qf_layers"]):
         L = f"{P}encoder.layer.{l}."
         a = _mha(W, L + "attention.attention.", h, h, H)
-        h = F.layer_norm(F.linear(a, W[L + "attention.output.dense.weight"], W[L + "attention.output.dense.bias"]) + h, (d,),
+        h = F.layer_norm(drop(F.linear(a, W[L + "attention.output.dense.weight"], W[L + "attention.output.dense.bias"])) + h, (d,),
                          W[L + "attention.output.LayerNorm.weight"], W[L + "attention.output.LayerNorm.bias"], eps)
         if l % cfg["qf_cross_freq"] == 0:
             c = _mha(W, L + "crossattention.attention.", h, x, H, atts)
-            h = F.layer_norm(F.linear(c, W[L + "crossattention.output.dense.weight"], W[L + "crossattention.output.dense.bias"]) + h,
+            h = F.layer_norm(drop(F.linear(c, W[L + "crossattention.output.dense.weight"], W[L + "crossattention.output.dense.bias"])) + h,
                              (d,), W[L + "crossattention.output.LayerNorm.weight"], W[L + "crossattention.output.LayerNorm.bias"], eps)
         f = F.gelu(F.linear(h, W[L + "intermediate_query.dense.weight"], W[L + "intermediate_query.dense.bias"]))
-        h = F.layer_norm(F.linear(f, W[L + "output_query.dense.weight"], W[L + "output_query.dense.bias"]) + h, (d,),
+        h = F.layer_norm(drop(F.linear(f, W[L + "output_query.dense.weight"], W[L + "output_query.dense.bias"])) + h, (d,),
                          W[L + "output_query.LayerNorm.weight"], W[L + "output_query.LayerNorm.bias"], eps)
     y = F.linear(h, W[prefix + "linear.weight"], W[prefix + "linear.bias"])
     return F.layer_norm(y, (y.shape[-1],), W[prefix + "norm.weight"], W[prefix + "norm.bias"], 1e-5)
@@ -475,10 +485,14 @@ def lr_lambda(step: int, warmup: int, total: int) -> float:
     return max(0.0, 1 - (step - warmup) / (total - warmup))
 
 
-def train_steps(W, cfg, batches: List[dict], lr=1e-4, weight_decay=0.0, warmup=1000, total=100000):
+def train_steps(W, cfg, batches: List[dict], lr=1e-4, weight_decay=0.0, warmup=1000, total=100000, train_encoder=False):
     """Loop body of src/slam_llm/utils/train_utils.py:112-169 (fp32, no autocast, grad-accum 1) with
-    torch.optim.AdamW + LambdaLR as built at pipeline/finetune.py:247-260.  Mutates W in place."""
+    torch.optim.AdamW + LambdaLR as built at pipeline/finetune.py:247-260.  Mutates W in place.
+    train_encoder: train_config.freeze_encoder=false (models/slam_model.py:110-113) -- every encoder PARAMETER trains too
+    (openai-whisper's positional_embedding is a registered buffer, not a parameter)."""
     names = trainable_names(W)
+    if train_encoder:
+        names = names + [n for n in W if n.startswith("encoder.") and not n.endswith("positional_embedding")]
     for n in W:
         W[n].requires_grad_(n in names)
     params = [W[n] for n in names]
@@ -543,8 +557,24 @@ def _repetition_penalty(scores: torch.Tensor, history: torch.Tensor, penalty: fl
     return scores.scatter(1, history, sc)
 
 
+def warp_scores(scores: torch.Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0) -> torch.Tensor:
+    """HF TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper (transformers/generation/logits_process.py), the
+    order `_get_logits_processor` appends them in when do_sample=True; min_tokens_to_keep = 1, filter value -inf."""
+    if temperature != 1.0:
+        scores = scores / temperature
+    if top_k:
+        kth = torch.topk(scores, min(int(top_k), scores.shape[-1]))[0][..., -1, None]
+        scores = scores.masked_fill(scores < kth, -float("inf"))
+    if top_p < 1.0:
+        srt, idx = torch.sort(scores, descending=False)
+        remove = srt.softmax(dim=-1).cumsum(dim=-1) <= (1 - top_p)
+        remove[..., -1:] = False
+        scores = scores.masked_fill(remove.scatter(1, idx, remove), -float("inf"))
+    return scores
+
+
 def greedy_search(step_fn, batch_size: int, max_new_tokens: int, eos: int, pad: int, min_length: int = 1,
-                  repetition_penalty: float = 1.0, trace: Optional[list] = None):
+                  repetition_penalty: float = 1.0, trace: Optional[list] = None, sample: Optional[dict] = None):
     """HF `GenerationMixin._sample` with do_sample=False (transformers/generation/utils.py), the num_beams=1 branch of
     `self.llm.generate(...)` at slam_model.py:438-452.  The prompt is inputs_embeds only, so the token history starts
     empty: MinLengthLogitsProcessor(min_length) therefore masks eos while fewer than `min_length` tokens exist.
@@ -556,7 +586,10 @@ def greedy_search(step_fn, batch_size: int, max_new_tokens: int, eos: int, pad: 
         logits = _repetition_penalty(step_fn(toks, rows).float().clone(), toks, repetition_penalty)
         if toks.shape[1] < min_length:
             logits[:, eos] = -float("inf")
-        nxt = logits.argmax(-1)
+        if sample is not None:   # do_sample=True: warpers, softmax, one multinomial draw per row (HF `_sample`)
+            nxt = torch.multinomial(F.softmax(warp_scores(logits, **sample), dim=-1), num_samples=1).squeeze(1)
+        else:
+            nxt = logits.argmax(-1)
         if trace is not None:   # decision margins for margin-aware comparisons of a reduced-precision path (tests)
             top2 = torch.topk(logits, 2, dim=-1)[0]
             trace.append({"margin": torch.where(alive, top2[:, 0] - top2[:, 1], torch.full((batch_size,), float("inf"))),
@@ -570,7 +603,7 @@ def greedy_search(step_fn, batch_size: int, max_new_tokens: int, eos: int, pad: 
 
 def beam_search(step_fn, batch_size: int, num_beams: int, max_new_tokens: int, eos: int, pad: int,
                 min_length: int = 1, length_penalty: float = 1.0, repetition_penalty: float = 1.0,
-                trace: Optional[list] = None):
+                trace: Optional[list] = None, sample: Optional[dict] = None):
     """HF `GenerationMixin._beam_search` (transformers 5.x vectorised form; early_stopping=False, one eos id,
     num_return_sequences=1), restated per batch item.  Each item keeps `num_beams` running hypotheses and
     `num_beams` finished ones; every step the best 2*num_beams continuations are ranked, the non-terminated ones
@@ -600,9 +633,19 @@ def beam_search(step_fn, batch_size: int, num_beams: int, max_new_tokens: int, e
         V = lp_all.shape[-1]
         all_hit = True
         new_src = []
+        if sample is not None:
+            # do_sample=True (`_get_top_k_continuations`): the warpers run on the per-hypothesis log-probs, then K continuations
+            # are DRAWN without replacement from softmax(accumulated scores) -- one batched multinomial call, order as drawn
+            lp_all = warp_scores(lp_all, **sample)
+            acc_all = (lp_all.view(batch_size, nb, V) + torch.stack(run_score)[:, :, None]).view(batch_size, nb * V)
+            drawn = torch.multinomial(F.softmax(acc_all, dim=-1), num_samples=K)
         for b in range(batch_size):
             acc = (lp_all[b * nb:(b + 1) * nb] + run_score[b][:, None]).reshape(-1)
-            top_lp, top_idx = torch.topk(acc, K)
+            if sample is not None:
+                top_idx = drawn[b]
+                top_lp = acc[top_idx]
+            else:
+                top_lp, top_idx = torch.topk(acc, K)
             if trace is not None and open_[b]:
                 # every ranking decision of the step is a comparison between neighbours of the sorted top K+1 candidates
                 srt = torch.topk(acc, K + 1)[0]
@@ -650,11 +693,12 @@ def generate_position_ids(attention_mask: torch.Tensor) -> torch.Tensor:
 
 
 def slam_generate(W, cfg, batch: dict, max_new_tokens=200, num_beams=4, min_length=1, length_penalty=1.0,
-                  eos=2, pad=0, repetition_penalty=1.0, trace: Optional[list] = None):
+                  eos=2, pad=0, repetition_penalty=1.0, trace: Optional[list] = None, sample: Optional[dict] = None):
     """slam_model.generate (src/slam_llm/models/slam_model.py:409-456): forward(..., inference_mode=True) returns
     (inputs_embeds, attention_mask) [slam_model.py:394-395], then `self.llm.generate(inputs_embeds=...,
-    attention_mask=..., num_beams, max_new_tokens, min_length, length_penalty, eos/pad ids)`.  do_sample=False,
-    top_p = temperature = 1.0 are no-ops; repetition_penalty is HF's RepetitionPenaltyLogitsProcessor.  The oracle re-runs the full sequence every step
+    attention_mask=..., num_beams, max_new_tokens, min_length, length_penalty, eos/pad ids)`.  sample=None is
+    do_sample=False; sample={temperature, top_k, top_p} is do_sample=True (draws from torch's global CPU generator exactly as HF
+    does: seed it first).  repetition_penalty is HF's RepetitionPenaltyLogitsProcessor.  The oracle re-runs the full sequence every step
     (no KV cache) in fp32."""
     mel = batch["audio_mel"]
     enc = whisper_encoder(W, cfg, mel.permute(0, 2, 1))
@@ -674,8 +718,9 @@ def slam_generate(W, cfg, batch: dict, max_new_tokens=200, num_beams=4, min_leng
         return logits[:, -1, :]
 
     if num_beams == 1:
-        return greedy_search(step_fn, B, max_new_tokens, eos, pad, min_length, repetition_penalty, trace)
-    return beam_search(step_fn, B, num_beams, max_new_tokens, eos, pad, min_length, length_penalty, repetition_penalty, trace)
+        return greedy_search(step_fn, B, max_new_tokens, eos, pad, min_length, repetition_penalty, trace, sample)
+    return beam_search(step_fn, B, num_beams, max_new_tokens, eos, pad, min_length, length_penalty, repetition_penalty, trace,
+                       sample)
 
 
 # ---------------------------------------------------------------------------------------------- a9: batcher + collators

@@ -244,17 +244,59 @@ class FusedLinear:
 
 # ======================================================================================== whisper encoder
 class HipWhisperEncoder(nn.Module):
-    """Frozen Whisper audio encoder, inference-only (src/slam_llm/models/encoder.py:13-30).
-    bf16 weights/activations, LayerNorm statistics in fp32 (deviation from the fp32 reference: stated in DESIGN.md)."""
+    """Whisper audio encoder (src/slam_llm/models/encoder.py:13-30).  bf16 weights/activations, LayerNorm
+    statistics in fp32 (deviation from the fp32 reference: stated in DESIGN.md).
 
-    def __init__(self, cfg: dict, device):
+    Frozen (store=None, the recipes' `freeze_encoder=true`): inference-only, weights held as bf16 compute copies.
+    Trainable (store given, `train_config.freeze_encoder=false`, models/slam_model.py:110-113): every parameter of the
+    reference module lives in the flat fp32 store under its reference name (`encoder.blocks.N.attn.query.weight`, ...; the
+    sinusoidal `positional_embedding` is a buffer there and stays fixed), forward_train() keeps what the hand-written
+    backward_hip() needs, and the bf16 compute copies (`self.w`) are rebuilt from the store by refresh() after each step."""
+
+    def __init__(self, cfg: dict, device, store: Optional["TrainableStore"] = None, prefix="encoder."):
         super().__init__()
         self.cfg = cfg
         self.device_ = device
         self.w = {}
+        self.store, self.prefix = store, prefix
+        if store is not None:
+            d, nm = cfg["enc_dim"], cfg["n_mels"]
+            assert d % 64 == 0 and d // cfg["enc_heads"] == 64, "whisper head_dim must be 64"
+            r, p = store.reserve, prefix
+            # reserved in the order the backward produces them (GradSync prefixes): ln_post, blocks last -> first, convs
+            r(p + "ln_post.weight", (d,)); r(p + "ln_post.bias", (d,))
+            for i in reversed(range(cfg["enc_layers"])):
+                b = f"{p}blocks.{i}."
+                r(b + "mlp.2.weight", (d, 4 * d)); r(b + "mlp.2.bias", (d,))
+                r(b + "mlp.0.weight", (4 * d, d)); r(b + "mlp.0.bias", (4 * d,))
+                r(b + "mlp_ln.weight", (d,)); r(b + "mlp_ln.bias", (d,))
+                r(b + "attn.out.weight", (d, d)); r(b + "attn.out.bias", (d,))
+                for n in ("query", "key", "value"):   # back to back: the bf16 copies form the fused [3d, d] operand
+                    r(b + f"attn.{n}.weight", (d, d))
+                r(b + "attn.query.bias", (d,)); r(b + "attn.value.bias", (d,))   # (the key projection has no bias)
+                r(b + "attn_ln.weight", (d,)); r(b + "attn_ln.bias", (d,))
+            r(p + "conv2.weight", (d, d, 3)); r(p + "conv2.bias", (d,))
+            r(p + "conv1.weight", (d, nm, 3)); r(p + "conv1.bias", (d,))
+
+    @property
+    def trainable(self) -> bool:
+        return self.store is not None
+
+    def bind(self):
+        for name, prm in self.store.params.items():
+            if name.startswith(self.prefix):
+                _attach(self, name[len(self.prefix):], prm)
 
     def load(self, W: Dict[str, torch.Tensor], prefix="encoder."):
         cfg, dev = self.cfg, self.device_
+        if self.trainable:
+            with torch.no_grad():
+                for name, prm in self.store.params.items():
+                    if name.startswith(self.prefix):
+                        prm.copy_(W[prefix + name[len(self.prefix):]].to(dev))
+            self.w["pos"] = W[prefix + "positional_embedding"].to(device=dev, dtype=torch.bfloat16).contiguous()
+            self.kp1 = round_up(3 * cfg["n_mels"], 64)
+            return self
         d, nm = cfg["enc_dim"], cfg["n_mels"]
         assert d % 64 == 0 and d // cfg["enc_heads"] == 64, "whisper head_dim must be 64"
         bf = lambda t: t.to(device=dev, dtype=torch.bfloat16).contiguous()  # noqa: E731
@@ -287,6 +329,21 @@ class HipWhisperEncoder(nn.Module):
         rn = lambda *s, std=0.02: (torch.randn(*s, generator=g, device=dev) * std)  # noqa: E731
         w = self.w
         self.kp1 = round_up(3 * nm, 64)
+        if self.trainable:
+            from .host_tables import sinusoids
+            w["pos"] = sinusoids(cfg["enc_ctx"], d).to(device=dev, dtype=torch.bfloat16)
+            with torch.no_grad():
+                for name, prm in self.store.params.items():
+                    if not name.startswith(self.prefix):
+                        continue
+                    if name.endswith("_ln.weight") or name.endswith("ln_post.weight"):
+                        prm.copy_(1 + rn(*prm.shape, std=0.1))
+                    elif name.endswith(".bias"):
+                        prm.copy_(rn(*prm.shape, std=0.1 if "ln" in name.rsplit(".", 2)[-2] else 0.02))
+                    else:
+                        fan_in = int(math.prod(prm.shape[1:]))
+                        prm.copy_(rn(*prm.shape, std=fan_in ** -0.5))
+            return self
         c1 = torch.zeros((d, self.kp1), dtype=torch.bfloat16, device=dev)
         c1[:, : 3 * nm] = rn(d, 3 * nm, std=(3 * nm) ** -0.5).to(torch.bfloat16)
         w["conv1"], w["conv1_b"] = c1, rn(d)
@@ -345,6 +402,150 @@ class HipWhisperEncoder(nn.Module):
 
     def forward(self, x):
         return self.extract_variable_length_features(x)
+
+    # ---- trainable mode ----------------------------------------------------------------------------------
+    def refresh(self):
+        """rebuild the bf16 compute copies (and the transposes the backward multiplies by) from the store; called with the
+        model's refresh after every optimizer step"""
+        if not self.trainable:
+            return
+        st, p, cfg, w = self.store, self.prefix, self.cfg, self.w
+        d, nm = cfg["enc_dim"], cfg["n_mels"]
+        self.kp1 = round_up(3 * nm, 64)
+        c1 = torch.zeros((d, self.kp1), dtype=torch.bfloat16, device=self.device_)
+        c1[:, : 3 * nm] = st.bf16_view(p + "conv1.weight").permute(0, 2, 1).reshape(d, 3 * nm)   # tap-major columns (im2col order)
+        w["conv1"], w["conv1_b"] = c1, st.master_view(p + "conv1.bias")
+        w["conv2"] = st.bf16_view(p + "conv2.weight").permute(0, 2, 1).reshape(d, 3 * d).contiguous()
+        w["conv2_b"] = st.master_view(p + "conv2.bias")
+        w["conv2T"] = ops.transpose(w["conv2"], Rp=d)                # [3d, d]: dcols = dz . W
+        for i in range(cfg["enc_layers"]):
+            b = f"{p}blocks.{i}."
+            off = st.offsets[b + "attn.query.weight"][0]
+            w[f"{i}.qkv"] = st.flat_bf16[off: off + 3 * d * d].view(3 * d, d)
+            qb = torch.zeros((3 * d,), dtype=torch.float32, device=self.device_)
+            qb[:d] = st.master_view(b + "attn.query.bias")
+            qb[2 * d:] = st.master_view(b + "attn.value.bias")
+            w[f"{i}.qkv_b"] = qb
+            w[f"{i}.out"], w[f"{i}.out_b"] = st.bf16_view(b + "attn.out.weight"), st.master_view(b + "attn.out.bias")
+            w[f"{i}.ln1_w"], w[f"{i}.ln1_b"] = st.master_view(b + "attn_ln.weight"), st.master_view(b + "attn_ln.bias")
+            w[f"{i}.fc1"], w[f"{i}.fc1_b"] = st.bf16_view(b + "mlp.0.weight"), st.master_view(b + "mlp.0.bias")
+            w[f"{i}.fc2"], w[f"{i}.fc2_b"] = st.bf16_view(b + "mlp.2.weight"), st.master_view(b + "mlp.2.bias")
+            w[f"{i}.ln2_w"], w[f"{i}.ln2_b"] = st.master_view(b + "mlp_ln.weight"), st.master_view(b + "mlp_ln.bias")
+            for nme in ("qkv", "out", "fc1", "fc2"):
+                w[f"{i}.{nme}T"] = ops.transpose(w[f"{i}.{nme}"], Rp=w[f"{i}.{nme}"].shape[0])
+        w["lnp_w"], w["lnp_b"] = st.master_view(p + "ln_post.weight"), st.master_view(p + "ln_post.bias")
+
+    def forward_train(self, mel: torch.Tensor, stash: dict) -> torch.Tensor:
+        """forward_btc that keeps the activations backward_hip() needs in stash["encoder"] (GELU pre-activations instead of
+        fused-epilogue outputs; GELU outputs, im2col matrices and head transposes are recomputed in the backward).
+        Stash size: 11 [M, d]-sized bf16 tensors per block (M = B * T2): 42 GB for 31 x 30 s through Whisper-large-v3."""
+        cfg, w = self.cfg, self.w
+        B, T, nm = mel.shape
+        d, H = cfg["enc_dim"], cfg["enc_heads"]
+        T2 = (T + 1) // 2
+        assert T2 <= w["pos"].shape[0], "audio longer than the encoder's positional table"
+        M = B * T2
+        scale = 64 ** -0.5
+        z1 = ops.gemm_nt(ops.conv1d_k3_im2col(mel, 1, self.kp1), w["conv1"], bias=w["conv1_b"])
+        h1 = ops.gelu_fwd(z1)
+        z2 = ops.gemm_nt(ops.conv1d_k3_im2col(h1.view(B, T, d), 2, 3 * d), w["conv2"], bias=w["conv2_b"])
+        del h1
+        x = (ops.gelu_fwd(z2).view(B, T2, d) + w["pos"][:T2]).view(M, d)
+        S = {"mel": mel, "z1": z1, "z2": z2, "B": B, "T": T, "T2": T2, "blocks": []}
+        for i in range(cfg["enc_layers"]):
+            h, m1, r1 = ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], stats=True)
+            qkv = ops.gemm_nt(h, w[f"{i}.qkv"], bias=w[f"{i}.qkv_b"])
+            vt = ops.head_rope_transpose(qkv, 2 * d, B, T2, H, 64)
+            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T2, H, H, 64, False, scale, want_lse=True)
+            del vt
+            x1 = ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"], residual=x)
+            h2, m2, r2 = ops.layernorm(x1, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], stats=True)
+            z = ops.gemm_nt(h2, w[f"{i}.fc1"], bias=w[f"{i}.fc1_b"])
+            x2 = ops.gemm_nt(ops.gelu_fwd(z), w[f"{i}.fc2"], bias=w[f"{i}.fc2_b"], residual=x1)
+            S["blocks"].append(dict(x=x, m1=m1, r1=r1, h=h, qkv=qkv, a=a, lse=lse, x1=x1, m2=m2, r2=r2, h2=h2, z=z))
+            x = x2
+        out, mo, ro = ops.layernorm(x, w["lnp_w"], w["lnp_b"], stats=True)
+        S.update(x_last=x, mo=mo, ro=ro)
+        stash["encoder"] = S
+        return out.view(B, T2, d)
+
+    def _lin_grads(self, dy: torch.Tensor, x: torch.Tensor, w_name: str, acc: bool, N: Optional[int] = None,
+                   K: Optional[int] = None, bias: Tuple = ()):
+        """dW (+)= dy^T x into the flat gradient buffer at parameter `w_name` (N x K rows may span the fused q|k|v block);
+        bias = ((param name, first column of dy, width), ...) column sums"""
+        st = self.store
+        M = dy.shape[0]
+        Mp = round_up(M, 64)
+        off, _, shape = st.offsets[w_name]
+        N, K = N or shape[0], K or shape[1]
+        ops.gemm_nt(ops.transpose(dy, Rp=Mp), ops.transpose(x, Rp=Mp), out=st.grad[off: off + N * K].view(N, K), accumulate=acc)
+        for name, c0, n in bias:
+            ops.colsum(dy[:, c0: c0 + n], st.grad_view(name), accumulate=acc)
+
+    def backward_hip(self, dout: torch.Tensor, stash: dict, acc: bool):
+        """dout [B*T2, d] bf16 = dL/d(encoder output); deposits every encoder gradient into the flat grad buffer
+        (hand-written adjoint of extract_variable_length_features, models/encoder.py:13-30)"""
+        cfg, w, st, p = self.cfg, self.w, self.store, self.prefix
+        S = stash.pop("encoder")
+        B, T, T2 = S["B"], S["T"], S["T2"]
+        d, H, nm = cfg["enc_dim"], cfg["enc_heads"], cfg["n_mels"]
+        M = B * T2
+        scale = 64 ** -0.5
+        gv = st.grad_view
+        dx = ops.layernorm_bwd(S["x_last"], S["mo"], S["ro"], w["lnp_w"], dout, dgamma=gv(p + "ln_post.weight"),
+                               dbeta=gv(p + "ln_post.bias"), accumulate=acc)
+        for i in reversed(range(cfg["enc_layers"])):
+            R = S["blocks"][i]
+            b = f"{p}blocks.{i}."
+            # MLP: x2 = x1 + fc2(gelu(fc1(LN2(x1))))
+            f = ops.gelu_fwd(R["z"])
+            self._lin_grads(dx, f, b + "mlp.2.weight", acc, bias=((b + "mlp.2.bias", 0, d),))
+            dz = ops.gelu_bwd(R["z"], ops.gemm_nt(dx, w[f"{i}.fc2T"]))
+            del f
+            self._lin_grads(dz, R["h2"], b + "mlp.0.weight", acc, bias=((b + "mlp.0.bias", 0, 4 * d),))
+            dh2 = ops.gemm_nt(dz, w[f"{i}.fc1T"])
+            del dz
+            dx1 = ops.layernorm_bwd(R["x1"], R["m2"], R["r2"], w[f"{i}.ln2_w"], dh2, dgamma=gv(b + "mlp_ln.weight"),
+                                    dbeta=gv(b + "mlp_ln.bias"), accumulate=acc)
+            ops.add_(dx1, dx)
+            # attention: x1 = x + out(attn(qkv(LN1(x))))
+            self._lin_grads(dx1, R["a"], b + "attn.out.weight", acc, bias=((b + "attn.out.bias", 0, d),))
+            da = ops.gemm_nt(dx1, w[f"{i}.outT"])
+            qkv = R["qkv"]
+            qt = ops.head_rope_transpose(qkv, 0, B, T2, H, 64)
+            kt = ops.head_rope_transpose(qkv, d, B, T2, H, 64)
+            dat = ops.head_rope_transpose(da, 0, B, T2, H, 64)
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], qt, kt, R["a"], da, dat, R["lse"], dqkv[:, :d],
+                         dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T2, H, H, 64, False, scale)
+            del qt, kt, dat, da
+            self._lin_grads(dqkv, R["h"], b + "attn.query.weight", acc, N=3 * d, K=d,
+                            bias=((b + "attn.query.bias", 0, d), (b + "attn.value.bias", 2 * d, d)))
+            dh = ops.gemm_nt(dqkv, w[f"{i}.qkvT"])
+            del dqkv
+            dx = ops.layernorm_bwd(R["x"], R["m1"], R["r1"], w[f"{i}.ln1_w"], dh, dgamma=gv(b + "attn_ln.weight"),
+                                   dbeta=gv(b + "attn_ln.bias"), accumulate=acc)
+            ops.add_(dx, dx1)
+            S["blocks"][i] = None
+        # conv stem: x0 = gelu(conv2(gelu(conv1(mel)))) + pos  (pos is a fixed buffer)
+        dz2 = ops.gelu_bwd(S["z2"], dx)
+        h1 = ops.gelu_fwd(S["z1"])
+        cols2 = ops.conv1d_k3_im2col(h1.view(B, T, d), 2, 3 * d)
+        del h1
+        Mp = round_up(M, 64)
+        g2 = ops.gemm_nt(ops.transpose(dz2, Rp=Mp), ops.transpose(cols2, Rp=Mp), out_dtype=torch.float32)   # [d, 3d], tap-major
+        del cols2
+        g2 = g2.view(d, 3, d).permute(0, 2, 1)          # -> the parameter's [co, ci, tap] layout
+        gv(p + "conv2.weight").add_(g2) if acc else gv(p + "conv2.weight").copy_(g2)
+        ops.colsum(dz2, gv(p + "conv2.bias"), accumulate=acc)
+        dh1 = ops.conv1d_k3_col2im(ops.gemm_nt(dz2, w["conv2T"]), B, T, d, 2)
+        dz1 = ops.gelu_bwd(S["z1"], dh1.view(B * T, d))
+        cols1 = ops.conv1d_k3_im2col(S["mel"], 1, self.kp1)
+        M1p = round_up(B * T, 64)
+        g1 = ops.gemm_nt(ops.transpose(dz1, Rp=M1p), ops.transpose(cols1, Rp=M1p), out_dtype=torch.float32)  # [d, kp1]
+        g1 = g1[:, : 3 * nm].reshape(d, 3, nm).permute(0, 2, 1)
+        gv(p + "conv1.weight").add_(g1) if acc else gv(p + "conv1.weight").copy_(g1)
+        ops.colsum(dz1, gv(p + "conv1.bias"), accumulate=acc)
 
     @torch.no_grad()
     def forward_packed(self, mel: torch.Tensor, n_frames: List[int]):
@@ -578,6 +779,7 @@ class HipProjectorConcat(nn.Module):
         store.reserve(prefix + "linear2.bias", (self.dl,))
         self.linear1 = nn.Module()
         self.linear2 = nn.Module()
+        self.need_dx = False   # True when the encoder is trainable: backward_hip then returns dL/d(encoder output)
 
     def bind(self):
         s, p = self.store, self.prefix
@@ -586,8 +788,9 @@ class HipProjectorConcat(nn.Module):
 
     def refresh(self):
         s, p = self.store, self.prefix
-        # linear1's transpose would only serve dL/d(encoder output): the encoder is frozen, never needed
+        # linear1's transpose only serves dL/d(encoder output): built when the encoder is trainable
         self.w2T = ops.transpose(s.bf16_view(p + "linear2.weight"), Rp=self.dl)  # [hid, dl]
+        self.w1T = ops.transpose(s.bf16_view(p + "linear1.weight"), Rp=self.hid) if self.need_dx else None  # [k*d, hid]
 
     def forward_hip(self, enc: torch.Tensor, stash: Optional[dict]):
         """enc [B, T2, d] bf16 -> [B, Ta, dl] bf16"""
@@ -596,6 +799,8 @@ class HipProjectorConcat(nn.Module):
         xp = enc[:, : Ta * self.k, :]
         if T2 % self.k:
             xp = xp.contiguous()
+        if stash is not None:
+            stash["proj_shape"] = (B, T2)
         return self.forward_rows(xp.reshape(B * Ta, self.k * d), stash).view(B, Ta, self.dl)
 
     def forward_rows(self, xp: torch.Tensor, stash: Optional[dict]):
@@ -606,6 +811,16 @@ class HipProjectorConcat(nn.Module):
         if stash is not None:
             stash["proj"] = (xp, h)
         return y
+
+    def _unstack(self, dxp: torch.Tensor, stash: dict):
+        """dL/d(stacked rows) [B*Ta, k*d] -> dL/d(encoder output) [B*T2, d] (frames past Ta*k were dropped: zero gradient)"""
+        B, T2 = stash.pop("proj_shape")
+        Ta = T2 // self.k
+        if T2 == Ta * self.k:
+            return dxp.view(B * T2, self.d)
+        out = torch.zeros((B, T2, self.d), dtype=dxp.dtype, device=dxp.device)
+        out[:, : Ta * self.k] = dxp.view(B, Ta * self.k, self.d)
+        return out.view(B * T2, self.d)
 
     def backward_hip(self, dy: torch.Tensor, stash: dict, accumulate: bool):
         s, p = self.store, self.prefix
@@ -622,6 +837,10 @@ class HipProjectorConcat(nn.Module):
         xT = ops.transpose(xp, Rp=Mp)
         ops.gemm_nt(dhT, xT, out=s.grad_view(p + "linear1.weight"), accumulate=accumulate)
         ops.colsum(dh, s.grad_view(p + "linear1.bias"), accumulate=accumulate)
+        if self.need_dx:
+            return self._unstack(ops.gemm_nt(dh, self.w1T), stash)
+        stash.pop("proj_shape", None)
+        return None
 
     def forward(self, x):
         return self.forward_hip(x, None)
@@ -666,6 +885,8 @@ class HipProjectorCov1d(nn.Module):
         xp = enc[:, : Ta * self.k, :]
         if T2 % self.k:
             xp = xp.contiguous()
+        if stash is not None:
+            stash["proj_shape"] = (B, T2)
         return self.forward_rows(xp.reshape(B * Ta, self.k * d), stash).view(B, Ta, self.dl)
 
     def forward_rows(self, xp: torch.Tensor, stash: Optional[dict]):
@@ -1105,13 +1326,18 @@ class SlamHipModel(nn.Module):
         self.metric = kwargs.get("metric", "acc")
         self.store = TrainableStore(self.device_)
         self.encoder_name = cfg.get("encoder_name", "whisper")
+        self.projector_name = cfg.get("projector", "linear")
+        # train_config.freeze_encoder=false (models/slam_model.py:110-113): the encoder's parameters join the trainable store
+        self.train_encoder = not bool(cfg.get("freeze_encoder", True))
+        if self.train_encoder and (self.encoder_name != "whisper" or self.projector_name != "linear" or cfg.get("varlen_encoder", False)):
+            raise NotImplementedError("freeze_encoder=false is implemented for the Whisper encoder with the linear projector on padded "
+                                      "batches (hand-written encoder backward); HuBERT / q-former / cov1d-linear / varlen_encoder are not")
         if self.encoder_name == "hubert":
             self.encoder = HipHubertEncoder(cfg, self.device_)
             cfg["enc_dim"] = cfg["hub_dim"]
-        else:
+        elif not self.train_encoder:
             self.encoder = HipWhisperEncoder(cfg, self.device_)
         self.llm = HipLlamaLora(cfg, self.store, self.device_)          # reserves LoRA (last layer first)
-        self.projector_name = cfg.get("projector", "linear")
         if self.projector_name == "q-former":
             from .qformer import HipProjectorQFormer
             self.encoder_projector = HipProjectorQFormer(cfg, self.store)
@@ -1121,9 +1347,14 @@ class SlamHipModel(nn.Module):
             raise ValueError(f"unknown encoder_projector {self.projector_name!r} (linear | cov1d-linear | q-former)")
         else:
             self.encoder_projector = HipProjectorConcat(cfg, self.store)  # projector last = produced last in backward
+        if self.train_encoder:
+            self.encoder = HipWhisperEncoder(cfg, self.device_, store=self.store)   # ... except a trainable encoder, after it
+            self.encoder_projector.need_dx = True
         self.store.allocate()
         self.llm.bind()
         self.encoder_projector.bind()
+        if self.train_encoder:
+            self.encoder.bind()
         self._anchor = torch.zeros(1, device=self.device_, requires_grad=True)
         self._stale = True
         self.return_logits = None  # None: logits only in eval mode
@@ -1209,6 +1440,8 @@ class SlamHipModel(nn.Module):
         g = torch.Generator(device=self.device_).manual_seed(seed + 2)
         with torch.no_grad():
             for name, p in self.store.params.items():
+                if name.startswith("encoder."):
+                    continue   # a trainable encoder initialised itself above
                 if ("LayerNorm" in name or "layernorm" in name or name.endswith("norm.weight")) and name.endswith("weight"):
                     p.fill_(1.0)
                 elif name.endswith("bias"):
@@ -1226,8 +1459,15 @@ class SlamHipModel(nn.Module):
 
     def _refresh(self):
         self.store.refresh_bf16()
+        self.refresh_derived()
+
+    def refresh_derived(self):
+        """everything computed FROM the bf16 copies of the trainable parameters (fused / transposed / re-laid-out operands);
+        the fused optimizers call this after writing the bf16 copies themselves"""
         self.llm.refresh()
         self.encoder_projector.refresh()
+        if self.train_encoder:
+            self.encoder.refresh()
         self._stale = False
 
     def train(self, mode: bool = True):
@@ -1301,7 +1541,8 @@ class SlamHipModel(nn.Module):
                 proj = self._encode_project_ragged(audio_mel.float().contiguous(), n_frames, stash)
                 enc = None
             else:
-                enc = self.encoder.forward_btc(audio_mel.float().contiguous())
+                mel_c = audio_mel.float().contiguous()
+                enc = self.encoder.forward_train(mel_c, stash) if (self.train_encoder and train) else self.encoder.forward_btc(mel_c)
         if enc is None:
             pass
         elif self.projector_name == "q-former":
@@ -1460,7 +1701,9 @@ class SlamHipModel(nn.Module):
         dproj = ops.embed_splice_bwd(stash["spans"], dh0, stash["batch_B"], stash["batch_T"], stash["Ta"], self.cfg["llm_dim"])
         if stash.get("proj_valid_rows") is not None:   # ragged encoder: the projector ran on the clips' own rows only
             dproj = ops.gather_rows(dproj, stash["proj_valid_rows"])
-        self.encoder_projector.backward_hip(dproj, stash, accumulate)
+        d_enc = self.encoder_projector.backward_hip(dproj, stash, accumulate)
+        if self.train_encoder:
+            self.encoder.backward_hip(d_enc, stash, accumulate)
         if as_autograd:
             return [st.grad_view(name) for name in st.params]
         for name, p in st.params.items():
@@ -1494,14 +1737,19 @@ class SlamHipModel(nn.Module):
         """slam_model.generate (src/slam_llm/models/slam_model.py:409-456): forward(..., inference_mode=True) for
         the spliced prompt embeddings, then HF `llm.generate(inputs_embeds=..., attention_mask=..., num_beams=4,
         max_new_tokens=200, min_length=1, length_penalty=1.0, eos/pad from the tokenizer)`.  Here: one prefill
-        pass + KV-cache decode steps on the HIP path; beam / greedy bookkeeping in slam_llm_amd/decode.py.
+        pass + KV-cache decode steps on the HIP path; beam / greedy / sampling bookkeeping in slam_llm_amd/decode.py
+        (do_sample=True: temperature / top_k / top_p warpers + multinomial draws, greedy or beam-sample like HF).
         Returns the NEW tokens only [B, <=max_new_tokens] (HF's behaviour for inputs_embeds prompts)."""
         from . import decode
+        sample = None
         if kwargs.get("do_sample", False):
-            raise NotImplementedError("sampling decode is not implemented (the reference recipes decode with do_sample=False)")
-        for k_, neutral in (("top_p", 1.0), ("temperature", 1.0)):
-            if float(kwargs.get(k_, neutral)) != neutral:
-                raise NotImplementedError(f"{k_} != {neutral} is not implemented")
+            # HF's GenerationConfig default top_k is 50 in the transformers 4.x line the reference was written against (unset in
+            # 5.x); top_k=0 / None disables it.  `generator=` (optional) makes the draws reproducible.
+            tk = kwargs.get("top_k", 50)
+            sample = dict(temperature=float(kwargs.get("temperature", 1.0)), top_k=int(tk) if tk else 0,
+                          top_p=float(kwargs.get("top_p", 1.0)), generator=kwargs.get("generator"))
+            if sample["temperature"] <= 0.0 or not 0.0 < sample["top_p"] <= 1.0:
+                raise ValueError(f"generate: temperature must be > 0 and top_p in (0, 1] (got {sample['temperature']}, {sample['top_p']})")
         tok = self.tokenizer
         eos = kwargs.get("eos_token_id", getattr(tok, "eos_token_id", None))
         pad = kwargs.get("pad_token_id", getattr(tok, "pad_token_id", None))
@@ -1526,10 +1774,10 @@ class SlamHipModel(nn.Module):
 
         if num_beams == 1:
             return decode.greedy_search(step_fn, B, max_new, int(eos), int(pad), int(kwargs.get("min_length", 1)),
-                                        self.device_, float(kwargs.get("repetition_penalty", 1.0)))
+                                        self.device_, float(kwargs.get("repetition_penalty", 1.0)), sample)
         return decode.beam_search(step_fn, B, num_beams, max_new, int(eos), int(pad), int(kwargs.get("min_length", 1)),
                                   float(kwargs.get("length_penalty", 1.0)), self.device_,
-                                  float(kwargs.get("repetition_penalty", 1.0)))
+                                  float(kwargs.get("repetition_penalty", 1.0)), sample)
 
 
     @torch.no_grad()
@@ -1587,9 +1835,7 @@ class SlamAdamW(torch.optim.Optimizer):
         self._step += 1
         ops.adamw_step(st.flat, self._flat_grad(), self.exp_avg, self.exp_avg_sq, st.flat_bf16, float(g["lr"]), g["betas"][0],
                        g["betas"][1], g["eps"], g["weight_decay"], self._step)
-        self.model.llm.refresh()
-        self.model.encoder_projector.refresh()
-        self.model._stale = False
+        self.model.refresh_derived()
         self.model._always_refresh = False
 
     def zero_grad(self, set_to_none: bool = True):
@@ -1644,9 +1890,7 @@ class SlamAnyPrecisionAdamW(SlamAdamW):
         ops.adamw_anyprecision_step(st.flat, self._flat_grad(), self.exp_avg, self.exp_avg_sq, self.compensation, st.flat_bf16,
                                     float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._step,
                                     params_are_bf16=self.pure_bf16)
-        self.model.llm.refresh()
-        self.model.encoder_projector.refresh()
-        self.model._stale = False
+        self.model.refresh_derived()
         self.model._always_refresh = False
 
     def state_dict(self):

@@ -224,6 +224,14 @@ def conv1d_k3_im2col(x: torch.Tensor, stride: int, Kp: int, n_valid: Optional[to
     return out
 
 
+def conv1d_k3_col2im(dcols: torch.Tensor, B: int, Tin: int, C: int, stride: int) -> torch.Tensor:
+    """adjoint of conv1d_k3_im2col: dcols [B*Tout, >= 3C] bf16 -> dx [B, Tin, C] bf16"""
+    assert dcols.dtype == torch.bfloat16 and dcols.stride(1) == 1
+    dx = torch.empty((B, Tin, C), dtype=torch.bfloat16, device=dcols.device)
+    call("slam_conv1d_k3_col2im", _p(dcols), _ld(dcols), _p(dx), B, Tin, C, stride, _s())
+    return dx
+
+
 def gather_rows(src: torch.Tensor, idx: torch.Tensor, width: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[r, :width] = src.flatten()[idx[r] * src.stride(0) : + width]; idx int32, < 0 -> zero row.  width defaults to
     src.shape[1]; a larger width spans consecutive rows of a contiguous src (the projector's k-frame windows)."""

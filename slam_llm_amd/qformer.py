@@ -5,8 +5,12 @@ HF `Blip2QFormerModel` (BERT-style post-LN layers: self-attention over the queri
 states every 2nd layer with `encoder_attention_mask`, GELU feed-forward; transformers/models/blip_2/
 modeling_blip_2.py:536-760, 849-940) -> Linear(768 -> llm_dim) -> LayerNorm(llm_dim, 1e-5).
 State-dict keys are the reference's (`encoder_projector.query`, `encoder_projector.qformer.encoder.layer.N...`).
-Dropout (the reference's Blip2QFormerConfig() default 0.1, live in train mode) is NOT applied -- stated deviation,
-same status as LoRA dropout.
+Dropout: the reference's Blip2QFormerConfig() defaults (hidden_dropout_prob = attention_probs_dropout_prob = 0.1) are
+live in train mode.  The four HIDDEN dropouts of the stack (after the query LayerNorm, and after each of the self-attention /
+cross-attention / feed-forward output projections, before the residual add -- modeling_blip_2.py Blip2QFormerSelfOutput /
+Blip2QFormerOutput / Blip2QFormerModel.forward) are applied with the counter-based mask of slam_dropout_bf16 (recomputed,
+never stored, in the backward; `qf_dropout`, default 0.1, 0 in eval mode).  The dropout on the attention PROBABILITIES lives
+inside the fused attention kernel in HF's formulation and is not applied -- stated deviation.
 
 All products are NT GEMMs (weights' transposes are refreshed once per optimizer step), attention runs on the MFMA
 kernels (self: Tq = Tk = Q; cross: Tq = Q, Tk = encoder frames with the key-padding mask), weight gradients are
@@ -32,6 +36,8 @@ class HipProjectorQFormer(nn.Module):
         self.L, self.Q = cfg["qf_layers"], cfg["qf_queries"]
         self.eps, self.cross_freq = cfg.get("qf_eps", 1e-12), cfg.get("qf_cross_freq", 2)
         self.d_enc, self.dl = cfg["enc_dim"], cfg["llm_dim"]
+        self.p_drop = float(cfg.get("qf_dropout", 0.1) or 0.0)
+        self._drop_calls = 0
         d, Fd = self.d, self.F
         assert d % 64 == 0 and d // self.H == 64 and Fd % 64 == 0 and self.d_enc % 64 == 0 and self.dl % 64 == 0
         r, p = store.reserve, prefix
@@ -117,10 +123,30 @@ class HipProjectorQFormer(nn.Module):
             km[:, :Tk] = (enc_mask > 0).to(torch.uint8)
         f32 = st.master_view
         scale = 64 ** -0.5
+        use_drop = train and self.training and self.p_drop > 0.0
+        seed = (torch.initial_seed() ^ 0x51F0) if use_drop else 0
+
+        def drop_key():
+            """(p, seed, offset) of the next hidden dropout of this forward, or None"""
+            if not use_drop:
+                return None
+            self._drop_calls += 1
+            return (self.p_drop, seed, self._drop_calls << 40)
+
+        def out_proj(x, w_name, b_name, residual, key):
+            """dense -> dropout -> + residual (Blip2QFormerSelfOutput / Blip2QFormerOutput up to the LayerNorm)"""
+            if key is None:
+                return ops.gemm_nt(x, st.bf16_view(w_name), bias=f32(b_name), residual=residual)
+            t = ops.gemm_nt(x, st.bf16_view(w_name), bias=f32(b_name))
+            return ops.dropout(t, *key, out=residual.clone(), accumulate=True)
+
         q0 = st.bf16_view(self.prefix + "query").view(Q, d)
         h0, m0, r0 = ops.layernorm(q0, f32(P + "layernorm.weight"), f32(P + "layernorm.bias"), self.eps, stats=True)
         h = h0.unsqueeze(0).expand(B, Q, d).reshape(M, d).contiguous()
-        S = {"layers": [], "B": B, "Tk": Tk, "km": km, "enc2d": enc2d, "q0": q0, "m0": m0, "r0": r0}
+        k0 = drop_key()
+        if k0 is not None:
+            h = ops.dropout(h, *k0)
+        S = {"layers": [], "B": B, "Tk": Tk, "km": km, "enc2d": enc2d, "q0": q0, "m0": m0, "r0": r0, "k0": k0}
         for l in range(self.L):
             Lp = f"{P}encoder.layer.{l}."
             A = Lp + "attention."
@@ -129,9 +155,10 @@ class HipProjectorQFormer(nn.Module):
             kt = ops.head_rope_transpose(qkv, d, B, Q, H, 64) if train else None
             vt = ops.head_rope_transpose(qkv, 2 * d, B, Q, H, 64)
             a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, Q, H, H, 64, False, scale, want_lse=train)
-            s1 = ops.gemm_nt(a, st.bf16_view(A + "output.dense.weight"), bias=f32(A + "output.dense.bias"), residual=h)
+            k1 = drop_key()
+            s1 = out_proj(a, A + "output.dense.weight", A + "output.dense.bias", h, k1)
             h1, m1, r1 = ops.layernorm(s1, f32(A + "output.LayerNorm.weight"), f32(A + "output.LayerNorm.bias"), self.eps, stats=True)
-            rec = dict(h=h, qkv=qkv, qt=qt, kt=kt, a=a, lse=lse, s1=s1, m1=m1, r1=r1, h1=h1, cross=None)
+            rec = dict(h=h, qkv=qkv, qt=qt, kt=kt, a=a, lse=lse, s1=s1, m1=m1, r1=r1, h1=h1, cross=None, k1=k1)
             hx = h1
             if l % self.cross_freq == 0:
                 C = Lp + "crossattention."
@@ -142,14 +169,16 @@ class HipProjectorQFormer(nn.Module):
                 ktc = ops.head_rope_transpose(kvc, 0, B, Tk, H, 64) if train else None
                 qtc = ops.head_rope_transpose(qc, 0, B, Q, H, 64) if train else None
                 c, lsec = ops.attn_fwd(qc, kvc[:, :d], vtc, B, Q, H, H, 64, False, scale, key_mask=km, want_lse=train, Tk=Tk)
-                s2 = ops.gemm_nt(c, st.bf16_view(C + "output.dense.weight"), bias=f32(C + "output.dense.bias"), residual=h1)
+                k2 = drop_key()
+                s2 = out_proj(c, C + "output.dense.weight", C + "output.dense.bias", h1, k2)
                 hx, mc, rc = ops.layernorm(s2, f32(C + "output.LayerNorm.weight"), f32(C + "output.LayerNorm.bias"), self.eps, stats=True)
-                rec["cross"] = dict(qc=qc, kvc=kvc, ktc=ktc, qtc=qtc, c=c, lse=lsec, s2=s2, mc=mc, rc=rc, hx=hx)
+                rec["cross"] = dict(qc=qc, kvc=kvc, ktc=ktc, qtc=qtc, c=c, lse=lsec, s2=s2, mc=mc, rc=rc, hx=hx, k2=k2)
             z = ops.gemm_nt(hx, st.bf16_view(Lp + "intermediate_query.dense.weight"), bias=f32(Lp + "intermediate_query.dense.bias"))
             f = ops.gelu_fwd(z)
-            s3 = ops.gemm_nt(f, st.bf16_view(Lp + "output_query.dense.weight"), bias=f32(Lp + "output_query.dense.bias"), residual=hx)
+            k3 = drop_key()
+            s3 = out_proj(f, Lp + "output_query.dense.weight", Lp + "output_query.dense.bias", hx, k3)
             h, m3, r3 = ops.layernorm(s3, f32(Lp + "output_query.LayerNorm.weight"), f32(Lp + "output_query.LayerNorm.bias"), self.eps, stats=True)
-            rec.update(hx=hx, z=z, f=f, s3=s3, m3=m3, r3=r3)
+            rec.update(hx=hx, z=z, f=f, s3=s3, m3=m3, r3=r3, k3=k3)
             S["layers"].append(rec)
         y = ops.gemm_nt(h, st.bf16_view(self.prefix + "linear.weight"), bias=f32(self.prefix + "linear.bias"))
         out, mo, ro = ops.layernorm(y, f32(self.prefix + "norm.weight"), f32(self.prefix + "norm.bias"), 1e-5, stats=True)
@@ -171,6 +200,10 @@ class HipProjectorQFormer(nn.Module):
             return ops.layernorm_bwd(x, mean, rstd, f32(name + ".weight"), dy, dgamma=gv(name + ".weight"), dbeta=gv(name + ".bias"),
                                      accumulate=acc)
 
+        def undrop(dy, key):
+            """gradient through a hidden dropout: the same mask, recomputed (the residual branch keeps dy itself)"""
+            return dy if key is None else ops.dropout(dy, *key)
+
         dy = ln_bwd(S["y"], S["mo"], S["ro"], p + "norm", dout)
         dh = self._lin_bwd(dy, S["h_last"], p + "linear.weight", p + "linear.bias", self.dl, d, acc, p + "linear.weight")
         for l in reversed(range(self.L)):
@@ -178,7 +211,7 @@ class HipProjectorQFormer(nn.Module):
             Lp = f"{P}encoder.layer.{l}."
             # feed-forward block
             ds3 = ln_bwd(R["s3"], R["m3"], R["r3"], Lp + "output_query.LayerNorm", dh)
-            df = self._lin_bwd(ds3, R["f"], Lp + "output_query.dense.weight", Lp + "output_query.dense.bias", d, Fd, acc,
+            df = self._lin_bwd(undrop(ds3, R["k3"]), R["f"], Lp + "output_query.dense.weight", Lp + "output_query.dense.bias", d, Fd, acc,
                                Lp + "output_query.dense.weight")
             dz = ops.gelu_bwd(R["z"], df)
             dhx = self._lin_bwd(dz, R["hx"], Lp + "intermediate_query.dense.weight", Lp + "intermediate_query.dense.bias", Fd, d,
@@ -189,7 +222,7 @@ class HipProjectorQFormer(nn.Module):
                 X = R["cross"]
                 C = Lp + "crossattention."
                 ds2 = ln_bwd(X["s2"], X["mc"], X["rc"], C + "output.LayerNorm", dhx)
-                dc = self._lin_bwd(ds2, X["c"], C + "output.dense.weight", C + "output.dense.bias", d, d, acc, C + "output.dense.weight")
+                dc = self._lin_bwd(undrop(ds2, X["k2"]), X["c"], C + "output.dense.weight", C + "output.dense.bias", d, d, acc, C + "output.dense.weight")
                 dct = ops.head_rope_transpose(dc, 0, B, Q, H, 64)
                 dqc = torch.empty_like(X["qc"])
                 dkvc = torch.empty_like(X["kvc"])
@@ -204,7 +237,7 @@ class HipProjectorQFormer(nn.Module):
             # self-attention block
             A = Lp + "attention."
             ds1 = ln_bwd(R["s1"], R["m1"], R["r1"], A + "output.LayerNorm", dh1)
-            da = self._lin_bwd(ds1, R["a"], A + "output.dense.weight", A + "output.dense.bias", d, d, acc, A + "output.dense.weight")
+            da = self._lin_bwd(undrop(ds1, R["k1"]), R["a"], A + "output.dense.weight", A + "output.dense.bias", d, d, acc, A + "output.dense.weight")
             dat = ops.head_rope_transpose(da, 0, B, Q, H, 64)
             qkv = R["qkv"]
             dqkv = torch.empty_like(qkv)
@@ -214,6 +247,7 @@ class HipProjectorQFormer(nn.Module):
                                A + "attention.qkv")
             dh = self._add(dh, ds1)
         # queries: h0 = LN(query) broadcast over the batch -> sum the batch, then LayerNorm backward
+        dh = undrop(dh, S["k0"])
         dsum = torch.empty((Q * d,), dtype=torch.float32, device=dh.device)
         ops.colsum(dh.view(B, Q * d), dsum)
         dsum_bf = ops.cast_bf16(dsum).view(Q, d)

@@ -78,7 +78,9 @@ def build_config(train_config, model_config) -> dict:
                  varlen_encoder=bool(_get(model_config, "varlen_encoder", False)),
                  # HuBERT + Q-Former on ragged batches: the reference forwards fairseq's padding mask un-inverted;
                  # default = reference behaviour, true = attend to the real frames
-                 hubert_qformer_mask_fix=bool(_get(model_config, "hubert_qformer_mask_fix", False)))
+                 hubert_qformer_mask_fix=bool(_get(model_config, "hubert_qformer_mask_fix", False)),
+                 # train_config.freeze_encoder=false: the (Whisper) encoder trains with the projector and the adapters
+                 freeze_encoder=bool(_get(train_config, "freeze_encoder", True)))
     if enc_name == "hubert":
         hp = _get(model_config, "arch_encoder") or _guess_preset(str(_get(model_config, "encoder_path", "hubert-large")).replace("_", "-"), HUBERT_PRESETS)
         extra.update(HUBERT_PRESETS[hp])
@@ -88,7 +90,8 @@ def build_config(train_config, model_config) -> dict:
         enc = _get(model_config, "arch_encoder") or _guess_preset("whisper-" + str(_get(model_config, "encoder_path", "")).split("/")[-1].replace(".pt", ""), enc_presets)
     if projector == "q-former":
         extra.update(qf_dim=768, qf_heads=12, qf_ffn=3072, qf_eps=1e-12, qf_cross_freq=2,
-                     qf_layers=int(_get(model_config, "qformer_layers", 8)), qf_queries=int(_get(model_config, "query_len", 64)))
+                     qf_layers=int(_get(model_config, "qformer_layers", 8)), qf_queries=int(_get(model_config, "query_len", 64)),
+                     qf_dropout=float(_get(model_config, "qformer_dropout", 0.1)))   # Blip2QFormerConfig() default, train mode only
     cfg = make_config(enc, llm,
                       ds_rate=int(_get(model_config, "encoder_projector_ds_rate", 5)),
                       lora_r=int(_get(peft, "r", 8)), lora_alpha=float(_get(peft, "lora_alpha", 32)),
@@ -108,9 +111,11 @@ def build_config(train_config, model_config) -> dict:
 def check_supported(train_config, model_config):
     """what the reference's factory would do with these flags that the HIP path does not implement -> loud errors
     (src/slam_llm/models/slam_model.py:68-221)."""
-    if _get(train_config, "freeze_encoder", True) is False:
-        raise NotImplementedError("train_config.freeze_encoder=false (unfrozen-encoder training, slam_model.py:110-113) is a SURVEY 8(f) "
-                                  "row: the HIP encoder is forward-only; pass ++train_config.freeze_encoder=true as the speech recipes do")
+    if _get(train_config, "freeze_encoder", True) is False and (
+            _get(model_config, "encoder_name", None) != "whisper" or str(_get(model_config, "encoder_projector", "linear")) != "linear"):
+        raise NotImplementedError("train_config.freeze_encoder=false (unfrozen-encoder training, slam_model.py:110-113) is implemented for "
+                                  "encoder_name=whisper with encoder_projector=linear only (hand-written encoder backward); pass "
+                                  "++train_config.freeze_encoder=true as the speech recipes do")
     if not bool(_get(train_config, "use_peft", False)) and _get(train_config, "freeze_llm", True) is False:
         raise NotImplementedError("full LLM fine-tuning (use_peft=false, freeze_llm=false) is out of scope: the HIP LLM is frozen + LoRA")
     if bool(_get(train_config, "quantization", False)) or bool(_get(train_config, "use_fast_kernels", False)):

@@ -122,6 +122,60 @@ def test_decode_bookkeeping_matches_reference_generate(scale):
         assert tuple(got.shape) == want.shape and (got.numpy() == want).all(), (nb, lp, pad, got, want)
 
 
+def test_sampling_decode_bookkeeping_matches_reference_generate():
+    """do_sample=True: the product's warpers + multinomial bookkeeping (greedy-sample and beam-sample), driven on CPU by the
+    oracle's fp32 model step and seeded like the fixture run, reproduces the tokens the reference's generate(do_sample=True)
+    drew (tests/golden/generate_sample.npz, written by oracle/make_golden_sample.py from the reference + HF)."""
+    import torch.nn.functional as F
+    from oracle import slam_oracle as O
+    from oracle.make_golden_cases import GENERATE_CASE as C
+    from oracle.make_golden_sample import RUNS, key
+    from slam_llm_amd import decode
+    from tests.test_oracle_golden import generate_case_weights
+    fx, fg = G.load("generate_sample"), G.load("generate")
+    cfg, W = C["cfg"], generate_case_weights(float(fx["scale"]))
+    batch = {k[len("batch."):]: torch.from_numpy(fg[k]) for k in fg.files if k.startswith("batch.")}
+    enc = O.whisper_encoder(W, cfg, batch["audio_mel"].permute(0, 2, 1))
+    proj = O.projector_concat(W, enc, cfg["ds_rate"])
+    emb_w = W["llm.base_model.model.model.embed_tokens.weight"]
+    embeds = O.embed_splice(emb_w, batch["input_ids"].clone(), batch["modality_mask"].bool(), proj)
+    mask = batch["attention_mask"].long()
+    B = embeds.shape[0]
+
+    def step_fn(tokens, src_rows):
+        item = torch.arange(tokens.shape[0]) // (tokens.shape[0] // B)
+        x = torch.cat([embeds[item], F.embedding(tokens, emb_w)], dim=1)
+        m = torch.cat([mask[item], torch.ones_like(tokens)], dim=1)
+        return O.llama_forward(W, cfg, x, m, None, position_ids=O.generate_position_ids(m))[1][:, -1, :]
+
+    eos = int(fx["eos"])
+    for nb, temp, tk, tp, rp, seed in RUNS:
+        sample = dict(temperature=temp, top_k=tk, top_p=tp)
+        torch.manual_seed(seed)
+        if nb == 1:
+            got = decode.greedy_search(step_fn, B, C["max_new_tokens"], eos, 1, 1, "cpu", rp, sample)
+        else:
+            got = decode.beam_search(step_fn, B, nb, C["max_new_tokens"], eos, 1, 1, 1.0, "cpu", rp, sample)
+        want = fx[key(nb, temp, tk, tp, rp, seed)]
+        assert tuple(got.shape) == want.shape and (got.numpy() == want).all(), (nb, temp, tk, tp, rp, got, want)
+        # and the oracle restatement, seeded the same way
+        torch.manual_seed(seed)
+        mine = O.slam_generate(W, cfg, {k: v.clone() for k, v in batch.items()}, max_new_tokens=C["max_new_tokens"], num_beams=nb,
+                               eos=eos, pad=1, repetition_penalty=rp, sample=sample)
+        assert (mine.numpy() == want).all()
+
+
+def test_sampling_warpers():
+    from slam_llm_amd import decode
+    s = torch.tensor([[2.0, 1.0, 0.0, -1.0, -3.0]])
+    assert torch.equal(decode.warp_scores(s, 2.0), s / 2.0)
+    assert torch.isinf(decode.warp_scores(s, top_k=2)[0, 2:]).all() and torch.equal(decode.warp_scores(s, top_k=2)[0, :2], s[0, :2])
+    p = torch.softmax(s, -1)[0]
+    kept = ~torch.isinf(decode.warp_scores(s, top_p=0.9)[0])          # smallest head set with cumulative prob > 0.9
+    assert kept.tolist() == [True, True, True, False, False] and float(p[:2].sum()) < 0.9 <= float(p[:3].sum())
+    assert (~torch.isinf(decode.warp_scores(s, top_p=1e-6)[0])).tolist() == [True, False, False, False, False]
+
+
 def test_inference_collator_reproduces_reference_layout():
     """inference-mode samples ([audio, prompt], no labels) through the product collator == the batch of
     tests/golden/generate.npz (built by the oracle's restatement of speech_dataset.py:120-134 + :216-273)."""

@@ -108,6 +108,69 @@ def test_gradients_and_training_steps_match_reference(dev, name, chunk):
     assert set(sd.keys()) == set(O.trainable_names(W)), set(sd.keys()) ^ set(O.trainable_names(W))
 
 
+def test_unfrozen_encoder_training_matches_reference_fixture(dev):
+    """f4: train_config.freeze_encoder=false -- the hand-written Whisper backward (conv stem incl. col2im, LayerNorm, attention,
+    GELU MLP) against the reference's slam_model with a trainable encoder (tests/golden/step_unfrozen.npz): first-step gradient of
+    every trainable tensor (encoder + projector + LoRA), three AdamW steps, and the state_dict now carries the encoder."""
+    from oracle.make_golden_cases import UNFROZEN_CASE as C
+    from slam_llm_amd.model import SlamAdamW, SlamHipModel
+    fx = G.load("step_unfrozen")
+    cfg = C["cfg"]
+    W = O.init_weights(cfg, seed=42)
+    model = SlamHipModel(dict(cfg, lora_dropout=0.0, freeze_encoder=False), dev).load_weights(W)
+    model.train()
+    b = batch_from_fixture(fx, dev)
+    enc_names = [n for n in model.store.params if n.startswith("encoder.")]
+    assert len(enc_names) == 4 + 15 * cfg["enc_layers"] + 2
+    opt = SlamAdamW(model, lr=C["lr"], weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: O.lr_lambda(s, 2, 10))
+    losses, worst = [], 1.0
+    for step in range(3):
+        outputs, acc = model(**{k: v.clone() for k, v in b.items()})
+        outputs.loss.backward()
+        if step == 0:
+            for n, p in model.store.params.items():
+                g = p.grad.float().cpu().numpy()
+                gold, mine = G.sub(fx, "grad." + n, g)
+                cs = G.cosine(gold, mine)
+                worst = min(worst, cs)
+                assert cs > 0.995, f"grad {n}: cosine {cs}"
+                gn = float(fx["grad." + n + ".__norm"])
+                mn = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                assert abs(mn - gn) < 5e-2 * gn + 1e-7, f"grad {n}: norm {mn} vs {gn}"
+        opt.step(); sched.step(); opt.zero_grad()
+        losses.append(float(outputs.loss))
+    print("unfrozen encoder: worst gradient cosine", worst, "losses", losses)
+    assert abs(losses[0] - losses[1]) < 1e-6
+    for s_ in range(3):
+        assert abs(losses[s_] - float(fx[f"loss.{s_}"])) < 3e-2, (s_, losses[s_], float(fx[f"loss.{s_}"]))
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(O.trainable_names(W)) | set(enc_names)
+    # gradient accumulation through the encoder backward: a second backward adds
+    out1, _ = model(**{k: v.clone() for k, v in b.items()})
+    out1.loss.backward()
+    g1 = model.store.grad.clone()
+    out2, _ = model(**{k: v.clone() for k, v in b.items()})
+    out2.loss.backward()
+    assert torch.allclose(model.store.grad, 2 * g1, rtol=2e-2, atol=2e-6)
+    # eval-mode forward of the trainable encoder == the frozen encoder built from the same weights
+    model.eval()
+    frozen = SlamHipModel(dict(cfg, lora_dropout=0.0), dev).load_weights({k: v.detach().clone() for k, v in
+                                                                          dict(W, **{n: p.detach().cpu() for n, p in model.store.params.items()}).items()})
+    frozen.eval()
+    with torch.no_grad():
+        l1, _ = model(**{k: v.clone() for k, v in b.items()})
+        l2, _ = frozen(**{k: v.clone() for k, v in b.items()})
+    assert abs(float(l1.loss) - float(l2.loss)) < 1e-5
+
+
+def test_unfrozen_encoder_rejects_unimplemented_combinations(dev):
+    from oracle.make_golden_cases import UNFROZEN_CASE as C
+    from slam_llm_amd.model import SlamHipModel
+    with pytest.raises(NotImplementedError, match="freeze_encoder"):
+        SlamHipModel(dict(C["cfg"], freeze_encoder=False, projector="cov1d-linear"), dev)
+
+
 def test_matches_oracle_with_gpu_logmel(dev):
     """raw audio in -> GPU log-mel inside the step; oracle computes the same on the CPU."""
     cfg = CASES["step_tiny"]["cfg"]
@@ -171,7 +234,7 @@ def test_hubert_linear_llm_step_matches_oracle(dev):
     W = O.init_weights(cfg, seed=42)
     W = {k: v for k, v in W.items() if not k.startswith("encoder.")}
     W.update(O.init_hubert_weights(HUBERT_TINY, seed=7))
-    model = SlamHipModel(dict(cfg, lora_dropout=0.0), dev).load_weights(W)
+    model = SlamHipModel(dict(cfg, lora_dropout=0.0, qf_dropout=0.0), dev).load_weights(W)
     model.train()
     wav = torch.nn.functional.layer_norm(O.synth_audio(2, 1.0, seed=9), (16000,))
     with torch.no_grad():
@@ -198,7 +261,7 @@ def test_qformer_projector_matches_reference_fixture(dev):
     from slam_llm_amd.model import TrainableStore
     from slam_llm_amd.qformer import HipProjectorQFormer
     fx = G.load("qformer")
-    cfg = dict(C["cfg"], enc_dim=C["enc_dim"], llm_dim=C["llm_dim"])
+    cfg = dict(C["cfg"], enc_dim=C["enc_dim"], llm_dim=C["llm_dim"], qf_dropout=0.0)   # the fixture is the eval-mode module
     W = O.init_qformer_weights(C["cfg"], C["enc_dim"], C["llm_dim"], seed=11)
     store = TrainableStore(dev)
     qf = HipProjectorQFormer(cfg, store)
@@ -232,6 +295,66 @@ def test_qformer_projector_matches_reference_fixture(dev):
         assert abs(mn - gn) < 4e-2 * gn, f"grad {n}: norm {mn} vs {gn}"
     # state-dict keys equal the reference module's
     assert {k for k in qf.state_dict()} == {k[len("encoder_projector."):] for k in W}
+
+
+def test_qformer_hidden_dropout_matches_oracle_with_the_same_masks(dev):
+    """train mode: the four kinds of hidden dropout (query LayerNorm output; self / cross / feed-forward output projections) --
+    the masks the kernels drew are rebuilt from their (seed, offset) keys and handed to the fp32 oracle; output and every
+    parameter gradient must agree as in the eval-mode fixture test"""
+    from oracle.make_golden_cases import QFORMER_CASE as C
+    from slam_llm_amd import ops
+    from slam_llm_amd.model import TrainableStore
+    from slam_llm_amd.qformer import HipProjectorQFormer
+    fx = G.load("qformer")
+    cfg = dict(C["cfg"], enc_dim=C["enc_dim"], llm_dim=C["llm_dim"], qf_dropout=0.1)
+    W = O.init_qformer_weights(C["cfg"], C["enc_dim"], C["llm_dim"], seed=11)
+    store = TrainableStore(dev)
+    qf = HipProjectorQFormer(cfg, store)
+    store.allocate()
+    qf.bind()
+    with torch.no_grad():
+        for n, p in store.params.items():
+            p.copy_(W[n].to(dev))
+    store.refresh_bf16()
+    qf.refresh()
+    qf.train()
+    x = torch.from_numpy(fx["x"]).to(dev).to(torch.bfloat16)
+    atts = torch.from_numpy(fx["atts"]).to(dev)
+    stash = {}
+    out = qf.forward_hip(x, atts, stash)
+    S = stash["qformer"]
+    B, Q, d = x.shape[0], C["cfg"]["qf_queries"], C["cfg"]["qf_dim"]
+    keys = [S["k0"]]
+    for R in S["layers"]:
+        keys.append(R["k1"])
+        if R["cross"] is not None:
+            keys.append(R["cross"]["k2"])
+        keys.append(R["k3"])
+    assert all(k is not None for k in keys) and len({k[2] for k in keys}) == len(keys)
+    ones = torch.ones((B * Q, d), dtype=torch.bfloat16, device=dev)
+    masks = [ops.dropout(ones, *k).float().cpu().view(B, Q, d) for k in keys]
+    kept = torch.stack(masks).ne(0).float().mean().item()
+    assert abs(kept - 0.9) < 0.01 and all(set(m.unique().tolist()) <= {0.0, float(torch.tensor(1 / 0.9).bfloat16())} for m in masks)
+    masks = [m.ne(0).float() / 0.9 for m in masks]
+    Wg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    ref = O.projector_qformer(Wg, C["cfg"], x.float().cpu(), atts.cpu(), hidden_masks=masks)
+    a, g = out.float().cpu().numpy(), ref.detach().numpy()
+    assert rel_err(a, g) < 3e-2 and G.cosine(g, a) > 0.9995, (rel_err(a, g), G.cosine(g, a))
+    cot = torch.from_numpy(fx["cot"])
+    (ref * cot.reshape(ref.shape)).sum().backward()
+    qf.backward_hip(cot.to(dev).to(torch.bfloat16).reshape(-1, C["llm_dim"]).contiguous(), stash, acc=False)
+    for n in W:
+        gold, mine = Wg[n].grad.numpy(), store.grad_view(n).float().cpu().numpy().reshape(Wg[n].shape)
+        gn = float(np.sqrt((gold.astype(np.float64) ** 2).sum()))
+        if gn < 1e-4:
+            continue
+        assert G.cosine(gold, mine) > 0.998, (n, G.cosine(gold, mine))
+        assert abs(float(np.sqrt((mine.astype(np.float64) ** 2).sum())) - gn) < 4e-2 * gn, n
+    # eval mode: no dropout, no keys drawn
+    qf.eval()
+    calls = qf._drop_calls
+    qf.forward_hip(x, atts, {})
+    assert qf._drop_calls == calls
 
 
 def test_cov1d_projector_matches_reference_fixture(dev):
@@ -305,7 +428,7 @@ def test_c4_hubert_qformer_llm_step_matches_oracle(dev):
     W = {k: v for k, v in O.init_weights(cfg, seed=42).items() if not k.startswith(("encoder.", "encoder_projector."))}
     W.update(O.init_hubert_weights(HUBERT_TINY, seed=7))
     W.update(O.init_qformer_weights(qcfg, cfg["enc_dim"], cfg["llm_dim"], seed=11))
-    model = SlamHipModel(dict(cfg, lora_dropout=0.0), dev).load_weights(W)
+    model = SlamHipModel(dict(cfg, lora_dropout=0.0, qf_dropout=0.0), dev).load_weights(W)
     model.train()
     wav = torch.nn.functional.layer_norm(O.synth_audio(2, 1.0, seed=9), (16000,))
     Q = qcfg["qf_queries"]
@@ -514,12 +637,28 @@ def test_kv_cache_decode_logits_match_oracle_teacher_forced(dev):
     print("teacher-forced decode: worst err/bound", worst)
 
 
-def test_generate_rejects_unimplemented_modes(dev):
+def test_sampling_generate_on_the_hip_path(dev):
+    """do_sample=True through SlamHipModel.generate (bit-exact bookkeeping vs the reference is pinned on CPU by
+    tests/test_host_logic.py; a bf16 path cannot reproduce fp32 draws): degenerate settings collapse to the greedy / beam
+    tokens of the reference fixture, a fixed generator reproduces itself, different seeds differ, every token respects top_k."""
+    from tests.test_oracle_golden import gen_key
     C, fx, W, model, b = _generate_setup(dev, 24.0)
-    with pytest.raises(NotImplementedError):
-        model.generate(**b, do_sample=True, eos_token_id=2, pad_token_id=0)
-    with pytest.raises(NotImplementedError):
-        model.generate(**b, top_p=0.9, eos_token_id=2, pad_token_id=0)
+    eos = int(fx["s24.0.eos"])
+    kw = dict(max_new_tokens=C["max_new_tokens"], eos_token_id=eos, pad_token_id=C["pad"])
+    greedy = fx[gen_key(24.0, 1, 1.0, C["pad"], 1.0)]
+    for deg in (dict(top_k=1), dict(top_p=1e-6, top_k=0), dict(temperature=1e-3, top_k=0)):
+        got = model.generate(**{k: v.clone() for k, v in b.items()}, num_beams=1, do_sample=True, **deg, **kw)
+        assert tuple(got.shape) == greedy.shape and (got.cpu().numpy() == greedy).all(), (deg, got, greedy)
+
+    def run(seed, **extra):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        return model.generate(**{k: v.clone() for k, v in b.items()}, do_sample=True, generator=g, **extra, **kw).cpu()
+    a1, a2, a3 = run(5, num_beams=1, temperature=3.0), run(5, num_beams=1, temperature=3.0), run(6, num_beams=1, temperature=3.0)
+    assert torch.equal(a1, a2) and not torch.equal(a1, a3)
+    b1, b2 = run(7, num_beams=4, temperature=2.0, top_k=20), run(7, num_beams=4, temperature=2.0, top_k=20)
+    assert torch.equal(b1, b2) and b1.shape[0] == a1.shape[0]
+    with pytest.raises(ValueError):
+        model.generate(**b, do_sample=True, temperature=0.0, eos_token_id=2, pad_token_id=0)
 
 
 def test_single_utterance_inference_equals_batch_generate(dev, tmp_path):

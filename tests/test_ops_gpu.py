@@ -848,3 +848,24 @@ def test_anyprecision_adamw_matches_reference_class_fixture(dev, name):
             want = torch.from_numpy(fx[f"{name}.p.{s}"])
             assert float(((p.cpu() - want).abs() > 1e-5 * want.abs().clamp(min=1e-3)).float().mean()) < 0.02
             assert float((ulps(m, torch.from_numpy(fx[f"{name}.m.{s}"])) > 0).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("stride,T", [(1, 37), (2, 37), (2, 40)])
+def test_conv_col2im_is_the_adjoint_of_im2col(dev, stride, T):
+    """slam_conv1d_k3_col2im vs autograd through an unfold-style im2col (fp32): <im2col(x), c> == <x, col2im(c)>"""
+    from slam_llm_amd import ops
+    B, C = 3, 64
+    g = torch.Generator().manual_seed(5)
+    To = (T + 2 - 3) // stride + 1
+    dcols = torch.randn(B * To, 3 * C, generator=g).to(torch.bfloat16)
+    x = torch.zeros(B, T, C, requires_grad=True)
+    xp = torch.nn.functional.pad(x, (0, 0, 1, 1))
+    cols = torch.cat([xp[:, j: j + stride * (To - 1) + 1: stride] for j in range(3)], dim=-1).reshape(B * To, 3 * C)
+    (cols * dcols.float()).sum().backward()
+    got = ops.conv1d_k3_col2im(dcols.to(dev), B, T, C, stride).float().cpu()
+    assert torch.allclose(got, x.grad, atol=2e-2, rtol=1e-2), (got - x.grad).abs().max()
+    # and im2col itself agrees with the same unfold
+    xr = torch.randn(B, T, C, generator=g).to(torch.bfloat16)
+    xpr = torch.nn.functional.pad(xr.float(), (0, 0, 1, 1))
+    ref = torch.cat([xpr[:, j: j + stride * (To - 1) + 1: stride] for j in range(3)], dim=-1).reshape(B * To, 3 * C)
+    assert torch.equal(ops.conv1d_k3_im2col(xr.to(dev), stride, 3 * C).float().cpu(), ref)

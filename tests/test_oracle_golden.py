@@ -59,6 +59,31 @@ def test_forward_backward_and_optimizer_match_reference(name):
             assert G.cosine(gold - init, mine - init) > 0.999, n
 
 
+def test_unfrozen_encoder_training_matches_reference():
+    """train_config.freeze_encoder=false: the oracle's autograd through its Whisper restatement == the reference's slam_model
+    with a trainable encoder (fixture written by oracle/make_golden_unfrozen.py): losses, every gradient, final parameters"""
+    from oracle.make_golden_cases import UNFROZEN_CASE as C
+    fx = G.load("step_unfrozen")
+    cfg = C["cfg"]
+    W = O.init_weights(cfg, seed=42)
+    batch = {k[len("batch."):]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("batch.")}
+    outs = O.train_steps(W, cfg, [dict(batch) for _ in range(3)], lr=C["lr"], weight_decay=0.01, warmup=2, total=10, train_encoder=True)
+    for s in range(3):
+        assert abs(float(outs[s]["loss"]) - float(fx[f"loss.{s}"])) < 2e-5
+    enc_names = [n for n in outs[0]["grads"] if n.startswith("encoder.")]
+    assert len(enc_names) == 4 + 15 * cfg["enc_layers"] + 2 and "encoder.positional_embedding" not in outs[0]["grads"]
+    for n, g in outs[0]["grads"].items():
+        # key-projection rows feed a softmax that is invariant to per-query constants: their bias does not exist, fine
+        G.check_packed(fx, "grad." + n, g.numpy(), atol=1e-6, rtol=1e-3, norm_rtol=1e-4)
+    W0 = O.init_weights(cfg, seed=42)
+    for n in outs[0]["grads"]:
+        gold, mine = G.sub(fx, "final." + n, W[n].detach().numpy())
+        _, init = G.sub(fx, "final." + n, W0[n].detach().numpy())
+        assert np.abs(gold - mine).max() < 2e-3, n
+        if np.abs(gold - init).max() > 0:
+            assert G.cosine(gold - init, mine - init) > 0.999, n
+
+
 def test_dynamic_batcher_matches_reference_window_class():
     # fixtures come from the reference's own MultiTaskDynamicBatchDataset/window_class (speech_dataset_large.py:235-263)
     fx = G.load("batcher")
