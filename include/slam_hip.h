@@ -138,7 +138,17 @@ int slam_attn_set_bwd_variant(int variant);   /* tools: 0 = DMA-ring dK/dV kerne
 int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, void* O,
                   int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B, int64_t Tq, int64_t Tk,
                   int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
-                  const int32_t* seg_lo, const int32_t* seg_hi, void* stream);
+                  const int32_t* seg_lo, const int32_t* seg_hi, const float* rp_gate, const float* rp_tab, int64_t rp_T,
+                  int64_t rp_ld, void* stream);
+/* rp_gate / rp_tab (nullable, forward only, D = 64, bidirectional): WavLM's gated relative position bias
+ * (src/slam_llm/models/wavlm/modules.py:504-533, called from models/slam_model.py:333-334 through models/encoder.py:109-127):
+ * score(q, k) = scale q.k + rp_gate[b][h][q] * rp_tab[h * rp_ld + (k - q + rp_T - 1)]; rp_gate [B, Hq, Tqp] f32 from
+ * slam_wavlm_gate, rp_tab = the bucketed `relative_attention_bias` of layer 0 laid out by relative distance (host table),
+ * with 64 readable floats before and after each row's 2 rp_T - 1 entries. */
+int slam_wavlm_gate(const void* x, int64_t ldx, const float* w, const float* bias, const float* grep_a, float* gate,
+                    int64_t B, int64_t T, int64_t H, int64_t Tp, void* stream);
+/* gate[b][h][t] = a * (g * grep_a[h] - 1) + 2 with (a, g) = sigmoid of the two 4-sums of grep_linear(x[b, t, h*64:(h+1)*64])
+ * (x = the layer's attention INPUT [B*T, H*64] bf16, w [8, 64] / bias [8] f32 = grep_linear; modules.py:522-531). */
 int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
                   const void* Qt, const void* Kt, const void* O, int64_t ldo, const void* dO,
                   int64_t lddo, const void* dOt, const float* LSE, float* Delta, const uint8_t* key_mask,

@@ -31,3 +31,9 @@ COV1D_CASE = dict(enc_dim=128, llm_dim=192, k=5, B=2, T=43)
 # unfrozen-encoder training (f4, train_config.freeze_encoder=false): step_tiny's architecture, odd mel frame count (conv2's last
 # window hangs over the edge) and T2 not a multiple of the projector's k (tail frames get zero gradient)
 UNFROZEN_CASE = dict(cfg=O.make_config(), clip_seconds=1.77, answer_lens=(5, 9), left_pad=True, lr=2e-3)
+
+# WavLM encoder (f4, models/wavlm/WavLM.py): WavLM-Large's structure (layer_norm extractor, no conv bias, layer_norm_first, gated
+# relative position bias), narrow widths; 40 buckets / max distance 24 so that the log-spaced and the clamped buckets both occur
+# inside ~50 frames
+WAVLM_TINY = O.wavlm_config(hub_conv_dim=(64,) * 7, hub_dim=128, hub_heads=2, hub_layers=2, hub_ffn=256, hub_pos_k=16,
+                            hub_pos_groups=4, wavlm_buckets=40, wavlm_max_distance=24)

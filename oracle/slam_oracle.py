@@ -234,6 +234,131 @@ def init_hubert_weights(cfg: dict, seed: int = 7, prefix="encoder.") -> Dict[str
     W[p + "layer_norm.weight"], W[p + "layer_norm.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
     return W
 
+# ---------------------------------------------------------------------------------------------- f4: WavLM encoder
+def wavlm_config(**kw) -> dict:
+    """WavLM-Large geometry (src/slam_llm/models/wavlm/WavLM.py:162-214 fields as the released checkpoint sets them:
+    extractor_mode="layer_norm", conv_bias=False, normalize=True, layer_norm_first=True, 24 x 1024 / 16 heads / ffn 4096,
+    conv_pos 128 / 16 groups, relative_position_embedding + gru_rel_pos with 320 buckets, max_distance 800).  The conv stack,
+    feature projection and positional conv share HuBERT's keys (hub_*); tests shrink widths, not structure."""
+    c = hubert_config()
+    c.update(wavlm_buckets=320, wavlm_max_distance=800)
+    c.update(kw)
+    return c
+
+
+def wavlm_relative_buckets(rel: torch.Tensor, num_buckets: int, max_distance: int) -> torch.Tensor:
+    """MultiheadAttention._relative_positions_bucket, bidirectional (src/slam_llm/models/wavlm/modules.py:417-442): half of the
+    buckets per sign; exact up to num_buckets/4, then log-spaced up to max_distance, clamped to the last bucket."""
+    nb = num_buckets // 2
+    out = (rel > 0).long() * nb
+    a = rel.abs()
+    max_exact = nb // 2
+    large = max_exact + (torch.log(a.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    return out + torch.where(a < max_exact, a, large)
+
+
+def wavlm_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, prefix="encoder.model.",
+                  n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The WavLM branch of slam_model.forward (src/slam_llm/models/slam_model.py:333-334:
+    `self.encoder.extract_features(audio, 1 - audio_mask)` -> models/encoder.py:126-127 -> WavLM.extract_features,
+    models/wavlm/WavLM.py:323-376) in eval mode.  wav [B, N] (layer-normed by the dataset when cfg.normalize) -> [B, T', d].
+    * feature extractor, "layer_norm" mode (WavLM.py:378-505): conv (no bias) -> LayerNorm over channels -> GELU, 7 times;
+    * LayerNorm -> post_extract_proj (:343-351); padding mask per frame = all samples of the frame padded (:311-321);
+    * TransformerEncoder.extract_features (:572-613): padded frames zeroed, x += GELU(SamePad(weight-normed grouped conv(x)));
+    * layer_norm_first layers (:690-715): x += attn(LN(x)); x += fc2(gelu(fc1(LN(x)))); final LayerNorm (:567-568);
+    * attention (modules.py:504-562): scores = q.k / sqrt(hd) + gate[b,h,q] * position_bias[h,q,k], where position_bias is
+      layer 0's `relative_attention_bias` embedding of the bucketed distance k - q (compute_bias :444-455, shared by ALL
+      layers) and gate = a * (g * grep_a - 1) + 2 with (a, g) = sigmoid of the two 4-sums of grep_linear(per-head slice of the
+      attention INPUT) (:522-531); key padding mask -> -inf."""
+    x = wav[:, None, :]
+    for i, (k, st) in enumerate(zip(cfg["hub_conv_kernel"], cfg["hub_conv_stride"])):
+        p = f"{prefix}feature_extractor.conv_layers.{i}."
+        x = F.conv1d(x, W[p + "0.weight"], None, stride=st)
+        x = F.layer_norm(x.transpose(-2, -1), (x.shape[1],), W[p + "2.1.weight"], W[p + "2.1.bias"], 1e-5)
+        x = F.gelu(x.transpose(-2, -1))
+    x = x.transpose(1, 2)
+    x = F.layer_norm(x, (x.shape[-1],), W[prefix + "layer_norm.weight"], W[prefix + "layer_norm.bias"], 1e-5)
+    x = F.linear(x, W[prefix + "post_extract_proj.weight"], W[prefix + "post_extract_proj.bias"])
+    B, T, d = x.shape
+    key_bias = None
+    if n_valid is not None:
+        pad = hubert_frame_padding_mask(wav.shape[1], T, n_valid)      # WavLM.forward_padding_mask: the same rule
+        x = x.masked_fill(pad[:, :, None], 0.0)
+        key_bias = torch.zeros(pad.shape).masked_fill(pad, float("-inf"))[:, None, None, :]
+    p = prefix + "encoder."
+    g_, v_ = W[p + "pos_conv.0.weight_g"], W[p + "pos_conv.0.weight_v"]      # nn.utils.weight_norm(dim=2): w = g * v / ||v||_(0,1)
+    pw = g_ * v_ / v_.norm(dim=(0, 1), keepdim=True)
+    kpos = cfg["hub_pos_k"]
+    pos = F.conv1d(x.transpose(1, 2), pw, W[p + "pos_conv.0.bias"], padding=kpos // 2, groups=cfg["hub_pos_groups"])
+    if kpos % 2 == 0:
+        pos = pos[:, :, :-1]
+    x = x + F.gelu(pos).transpose(1, 2)
+    H = cfg["hub_heads"]
+    hd = d // H
+    rel = torch.arange(T)[None, :] - torch.arange(T)[:, None]                 # memory - context = k - q
+    buckets = wavlm_relative_buckets(rel, cfg["wavlm_buckets"], cfg["wavlm_max_distance"])
+    pos_bias = F.embedding(buckets, W[p + "layers.0.self_attn.relative_attention_bias.weight"]).permute(2, 0, 1)   # [H, T, T]
+    for i in range(cfg["hub_layers"]):
+        q_ = f"{p}layers.{i}."
+        h = F.layer_norm(x, (d,), W[q_ + "self_attn_layer_norm.weight"], W[q_ + "self_attn_layer_norm.bias"], 1e-5)
+        hh = h.view(B, T, H, hd).permute(0, 2, 1, 3)                           # per-head slices of the attention input
+        gl = F.linear(hh, W[q_ + "self_attn.grep_linear.weight"], W[q_ + "self_attn.grep_linear.bias"]).view(B, H, T, 2, 4).sum(-1)
+        ga, gb = torch.sigmoid(gl).chunk(2, dim=-1)
+        gate = ga * (gb * W[q_ + "self_attn.grep_a"] - 1.0) + 2.0              # [B, H, T, 1]
+        q = F.linear(h, W[q_ + "self_attn.q_proj.weight"], W[q_ + "self_attn.q_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
+        k = F.linear(h, W[q_ + "self_attn.k_proj.weight"], W[q_ + "self_attn.k_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
+        v = F.linear(h, W[q_ + "self_attn.v_proj.weight"], W[q_ + "self_attn.v_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
+        sc = (q @ k.transpose(2, 3)) * hd ** -0.5 + gate * pos_bias[None]
+        if key_bias is not None:
+            sc = sc + key_bias
+        a = (F.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(B, T, d)
+        x = x + F.linear(a, W[q_ + "self_attn.out_proj.weight"], W[q_ + "self_attn.out_proj.bias"])
+        h = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], 1e-5)
+        x = x + F.linear(F.gelu(F.linear(h, W[q_ + "fc1.weight"], W[q_ + "fc1.bias"])), W[q_ + "fc2.weight"], W[q_ + "fc2.bias"])
+    return F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5)
+
+
+def init_wavlm_weights(cfg: dict, seed: int = 9, prefix="encoder.model.") -> Dict[str, torch.Tensor]:
+    """seeded weights under the reference WavLM's own state-dict names (as `slam_model.state_dict()` would carry them:
+    `encoder` = WavLMEncoder, `.model` = WavLM, models/encoder.py:109-127)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, std=0.02):
+        return torch.randn(*shape, generator=g) * std
+
+    W = {}
+    cin = 1
+    for i, (co, k) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"])):
+        p = f"{prefix}feature_extractor.conv_layers.{i}."
+        W[p + "0.weight"] = rn(co, cin, k, std=(1.0 / (cin * k)) ** 0.5)
+        W[p + "2.1.weight"], W[p + "2.1.bias"] = 1 + rn(co, std=0.1), rn(co, std=0.1)
+        cin = co
+    d, ffn, H = cfg["hub_dim"], cfg["hub_ffn"], cfg["hub_heads"]
+    W[prefix + "layer_norm.weight"], W[prefix + "layer_norm.bias"] = 1 + rn(cin, std=0.1), rn(cin, std=0.1)
+    W[prefix + "post_extract_proj.weight"], W[prefix + "post_extract_proj.bias"] = rn(d, cin, std=cin ** -0.5), rn(d)
+    W[prefix + "mask_emb"] = torch.rand(d, generator=g)
+    p = prefix + "encoder."
+    gch = d // cfg["hub_pos_groups"]
+    W[p + "pos_conv.0.weight_v"] = rn(d, gch, cfg["hub_pos_k"], std=(1.0 / (gch * cfg["hub_pos_k"])) ** 0.5)
+    W[p + "pos_conv.0.weight_g"] = W[p + "pos_conv.0.weight_v"].norm(dim=(0, 1), keepdim=True) * (1 + rn(1, 1, cfg["hub_pos_k"], std=0.1))
+    W[p + "pos_conv.0.bias"] = rn(d)
+    for i in range(cfg["hub_layers"]):
+        q_ = f"{p}layers.{i}."
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            W[q_ + f"self_attn.{n}.weight"], W[q_ + f"self_attn.{n}.bias"] = rn(d, d, std=d ** -0.5), rn(d)
+        W[q_ + "self_attn.grep_linear.weight"], W[q_ + "self_attn.grep_linear.bias"] = rn(8, d // H, std=0.3), rn(8, std=0.3)
+        W[q_ + "self_attn.grep_a"] = 1 + rn(1, H, 1, 1, std=0.3)
+        if i == 0:
+            W[q_ + "self_attn.relative_attention_bias.weight"] = rn(cfg["wavlm_buckets"], H, std=1.0)
+        W[q_ + "self_attn_layer_norm.weight"], W[q_ + "self_attn_layer_norm.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+        W[q_ + "fc1.weight"], W[q_ + "fc1.bias"] = rn(ffn, d, std=d ** -0.5), rn(ffn)
+        W[q_ + "fc2.weight"], W[q_ + "fc2.bias"] = rn(d, ffn, std=ffn ** -0.5), rn(d)
+        W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+    W[p + "layer_norm.weight"], W[p + "layer_norm.bias"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
+    return W
+
+
 # ---------------------------------------------------------------------------------------------- a3: projector
 def projector_concat(W, x: torch.Tensor, k: int, prefix="encoder_projector.") -> torch.Tensor:
     """EncoderProjectorConcat.forward, src/slam_llm/models/projector.py:15-27."""

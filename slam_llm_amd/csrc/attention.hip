@@ -51,6 +51,12 @@ struct AttnParams {
   // sequence); both non-decreasing, null for ordinary batches.  Causal only.
   const int* seg_lo;
   const int* seg_hi;
+  // gated relative position bias (WavLM, forward only): score(q, k) = scale * q.k + rp_gate[b][h][q] * rp_tab[h][k - q + rp_T - 1]
+  // (src/slam_llm/models/wavlm/modules.py:504-533: position_bias from the bucketed embedding of layer 0, gated per query);
+  // rp_tab rows have stride rp_ld and 64 readable floats of slack before index 0 and after index 2 rp_T - 2
+  const float* rp_gate;
+  const float* rp_tab;
+  int rp_T, rp_ld;
 };
 
 // gradient of HF's rotate_half RoPE for one row held as DF fragments of 4 consecutive head-dim elements per lane:
@@ -109,7 +115,7 @@ constexpr float LN2 = 0.6931471805599453f;
 // forward: 4 waves x 32 query rows per workgroup, 64-key K / V^T tiles staged through LDS
 // ------------------------------------------------------------------------------------------
 // QF = 16-row query fragments per wave (2: 128-query workgroups; 1: 64-query workgroups, fewer VGPRs -> more waves per SIMD)
-template <int D, bool CAUSAL, int QF>
+template <int D, bool CAUSAL, int QF, bool RP = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
@@ -179,6 +185,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
   }
 
+  float rp_g[QF];
+#pragma unroll
+  for (int f = 0; f < QF; f++)
+    rp_g[f] = RP ? p.rp_gate[((int64_t)b * p.Hq + h) * Tqp + min(qw0 + f * 16 + li, Tq - 1)] * LOG2E : 0.f;
+
   frag_t kreg[KI], vreg[VI];
   auto gload = [&](int k0) {
 #pragma unroll
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
     // ---- online softmax (per query = lane&15, replicated over the 4 lane groups) ----
     // interior tiles (no key mask, fully inside [0, Tk), fully below the causal diagonal of this wave) skip all masking
-    const bool tile_full = (p.kmask == nullptr) && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0 &&
+    const bool tile_full = !RP && (p.kmask == nullptr) && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0 &&
                            k0 + 64 <= hi_wave_min;
     if (tile_full) {
 #pragma unroll
@@ -284,15 +295,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         const int q = qw0 + f * 16 + li;
         float mt = -INFINITY;
 #pragma unroll
-        for (int kf = 0; kf < 4; kf++)
+        for (int kf = 0; kf < 4; kf++) {
+          float bias[4] = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (RP) {   // gate[q] * table[key - q + T - 1], in log2 units like the scores
+            const float* tp = p.rp_tab + (int64_t)h * p.rp_ld + (k0 + kf * 16 + 4 * g - min(q, Tq - 1) + p.rp_T - 1);
+#pragma unroll
+            for (int r = 0; r < 4; r++) bias[r] = rp_g[f] * tp[r];
+          }
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int key = k0 + kf * 16 + 4 * g + r;
             const bool ok = kv[kf][r] && (!CAUSAL || key <= q) && key >= qlo[f] && key < qhi[f];
-            const float x = ok ? s[f][kf][r] * sl2 : -INFINITY;
+            const float x = ok ? fmaf(s[f][kf][r], sl2, bias[r]) : -INFINITY;
             s[f][kf][r] = x;
             mt = fmaxf(mt, x);
           }
+        }
         mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float mnew = fmaxf(mrow[f], mt);
@@ -1071,8 +1089,13 @@ extern "C" int slam_attn_set_fwd_qf(int qf) {
 extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt,
                              void* O, int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B,
                              int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D,
-                             int causal, float scale, const int32_t* seg_lo, const int32_t* seg_hi, void* stream) {
+                             int causal, float scale, const int32_t* seg_lo, const int32_t* seg_hi, const float* rp_gate,
+                             const float* rp_tab, int64_t rp_T, int64_t rp_ld, void* stream) {
   SLAM_CHECK_ARG(Q && K && Vt && O, "slam_attn_fwd: null pointer");
+  SLAM_CHECK_ARG((rp_gate == nullptr) == (rp_tab == nullptr), "slam_attn_fwd: rp_gate / rp_tab must both be set or both null");
+  SLAM_CHECK_ARG(!rp_gate || (D == 64 && !causal && !seg_lo && rp_T >= Tq && rp_T >= Tk && rp_ld >= 2 * rp_T - 1),
+                 "slam_attn_fwd: the gated relative position bias is implemented for head_dim 64, bidirectional, unpacked batches, "
+                 "with a table covering the sequence (rp_T >= T, rp_ld >= 2 rp_T - 1)");
   SLAM_CHECK_ARG(!seg_lo || Tq == Tk, "slam_attn_fwd: packed sequences (seg_lo) need self-attention");
   SLAM_CHECK_ARG(!seg_lo || causal || seg_hi, "slam_attn_fwd: bidirectional packed sequences need seg_hi (per query row)");
   if (int rc = check_common("slam_attn_fwd", B, Tq, Tk, Tqp, Tkp, Hq, Hkv, D, causal)) return rc;
@@ -1083,7 +1106,14 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
   p.seg_lo = seg_lo;
   p.seg_hi = causal ? nullptr : seg_hi;   // (the causal forward only needs the sequence starts)
+  p.rp_gate = rp_gate; p.rp_tab = rp_tab; p.rp_T = (int)rp_T; p.rp_ld = (int)rp_ld;
   hipStream_t s = (hipStream_t)stream;
+  if (rp_gate) {
+    dim3 grid((unsigned)cdiv64(Tq, 128), (unsigned)Hq, (unsigned)B);
+    hipLaunchKernelGGL((attn_fwd_kernel<64, false, 2, true>), grid, dim3(256), 0, s, p);
+    SLAM_CHECK_LAUNCH("slam_attn_fwd");
+    return 0;
+  }
   // measured (tools/attn_bwd_bench.py, tools/attn_one.py): D = 128 with two fragments needs 261 VGPRs = one wave per SIMD,
   // one fragment (171 VGPRs, two waves) is 13 % faster at the Llama shape; D = 64 (182 vs 120 VGPRs) prefers two (+5 %)
   const int qf = g_attn_fwd_qf ? g_attn_fwd_qf : (D == 128 ? 1 : 2);

@@ -580,6 +580,37 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__
   }
 }
 
+// WavLM gate of the relative position bias (modules.py:522-531): one thread per (row, head)
+__global__ __launch_bounds__(256) void wavlm_gate_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const float* __restrict__ grep_a,
+                                                         float* __restrict__ gate, int B, int T, int H, int Tp) {
+  __shared__ float ws[8 * 64 + 8];
+  for (int i = threadIdx.x; i < 8 * 64 + 8; i += 256) ws[i] = i < 512 ? w[i] : bias[i - 512];
+  __syncthreads();
+  const int64_t total = (int64_t)B * T * H;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int h = (int)(i % H);
+    const int64_t m = i / H;
+    const int t = (int)(m % T), b = (int)(m / T);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = ws[512 + j];
+#pragma unroll
+    for (int c8 = 0; c8 < 8; c8++) {
+      const u16x8_t xv = *reinterpret_cast<const u16x8_t*>(x + m * ldx + h * 64 + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float xf = bf2f(xv[e]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = fmaf(xf, ws[j * 64 + c8 * 8 + e], v[j]);
+      }
+    }
+    const float a = 1.f / (1.f + __expf(-(v[0] + v[1] + v[2] + v[3])));
+    const float g = 1.f / (1.f + __expf(-(v[4] + v[5] + v[6] + v[7])));
+    gate[((int64_t)b * H + h) * Tp + t] = a * (g * grep_a[h] - 1.f) + 2.f;
+  }
+}
+
 inline unsigned ew_grid(int64_t total_items) {
   int64_t g = cdiv64(total_items, 256);
   if (g > 16384) g = 16384;
@@ -679,6 +710,16 @@ extern "C" int slam_conv1d_k3_col2im(const void* dcols, int64_t ldc, void* dx, i
   hipLaunchKernelGGL(col2im_k3_kernel, dim3(ew_grid(B * Tin * (C / 8))), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dcols, ldc, (bf16_t*)dx, (int)B, (int)Tin, (int)Tout, (int)C, (int)stride);
   SLAM_CHECK_LAUNCH("slam_conv1d_k3_col2im");
+  return 0;
+}
+
+extern "C" int slam_wavlm_gate(const void* x, int64_t ldx, const float* w, const float* bias, const float* grep_a, float* gate,
+                               int64_t B, int64_t T, int64_t H, int64_t Tp, void* stream) {
+  SLAM_CHECK_ARG(x && w && bias && grep_a && gate, "slam_wavlm_gate: null pointer");
+  SLAM_CHECK_ARG(B > 0 && T > 0 && H > 0 && Tp >= T && ldx % 8 == 0 && ldx >= H * 64, "slam_wavlm_gate: bad shape (head_dim is 64)");
+  hipLaunchKernelGGL(wavlm_gate_kernel, dim3(ew_grid(B * T * H)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, w, bias,
+                     grep_a, gate, (int)B, (int)T, (int)H, (int)Tp);
+  SLAM_CHECK_LAUNCH("slam_wavlm_gate");
   return 0;
 }
 

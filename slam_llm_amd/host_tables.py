@@ -18,3 +18,17 @@ def rope_tables(T: int, D: int, theta: float):
     inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
     fr = torch.arange(T, dtype=torch.float32)[:, None] * inv[None, :]
     return fr.cos().contiguous(), fr.sin().contiguous()
+
+
+def wavlm_relative_buckets(T: int, num_buckets: int, max_distance: int) -> torch.Tensor:
+    """bucket index of every relative distance k - q in [-(T-1), T-1] (entry i <-> distance i - (T-1)), WavLM's bidirectional
+    T5-style bucketing (src/slam_llm/models/wavlm/modules.py:417-442): one half of the buckets per sign, distances below
+    num_buckets/4 exact, beyond that log-spaced up to max_distance and clamped to the last bucket.  int64 [2T-1]."""
+    import math
+    rel = torch.arange(-(T - 1), T)
+    half = num_buckets // 2
+    exact = half // 2
+    a = rel.abs()
+    log_part = exact + (torch.log(a.float() / exact) / math.log(max_distance / exact) * (half - exact)).to(torch.long)
+    log_part = torch.clamp(log_part, max=half - 1)
+    return (rel > 0).to(torch.long) * half + torch.where(a < exact, a, log_part)

@@ -753,7 +753,8 @@ class HipHubertEncoder(nn.Module):
             ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, out=hbuf)
             ops.gemm_nt(hbuf, w[f"{i}.qkv"], out=qkv, bias=w[f"{i}.qkv_b"])
             vt = ops.head_rope_transpose(qkv, 2 * d, B, T, H, 64)
-            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=False, out=obuf)
+            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=False, out=obuf,
+                         relpos=self._relpos(i, hbuf, B, T))
             ops.gemm_nt(obuf, w[f"{i}.out"], out=x, bias=w[f"{i}.out_b"], residual=x)
             ops.layernorm(x, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], eps, out=hbuf)
             ops.gemm_nt(hbuf, w[f"{i}.fc1"], out=fbuf, bias=w[f"{i}.fc1_b"], act=ACT_GELU)
@@ -761,8 +762,96 @@ class HipHubertEncoder(nn.Module):
         out = ops.layernorm(x, w["lnp_w"], w["lnp_b"], eps)
         return out.view(B, T, d)
 
+    def _relpos(self, layer: int, attn_in: torch.Tensor, B: int, T: int):
+        """additive attention bias of layer `layer` given its input (HuBERT: none)"""
+        return None
+
     def forward(self, source=None, padding_mask=None, **kw):
         return {"encoder_out": self.forward_wav(source).transpose(0, 1), "padding_mask": None}
+
+
+class HipWavLMEncoder(HipHubertEncoder):
+    """Frozen WavLM encoder (src/slam_llm/models/wavlm/WavLM.py:220-376 as called through models/encoder.py:109-127 from
+    models/slam_model.py:333-334), WavLM-Large's configuration: "layer_norm" conv feature extractor without conv bias, feature
+    LayerNorm + projection, weight-normed grouped positional conv, layer_norm_first transformer -- i.e. HuBERT-large's graph (the
+    parent class) -- plus the gated relative position bias in every attention (modules.py:504-533): layer 0's bucketed
+    `relative_attention_bias` is laid out once per sequence length as a per-head table over the relative distance k - q, each
+    layer's gate comes from slam_wavlm_gate on that layer's attention input, and the attention kernel adds gate[q] * table[k - q]
+    to the scores.  Weights are read under the reference module's own state-dict names (`encoder.model.*`)."""
+
+    def load(self, W: Dict[str, torch.Tensor], prefix="encoder.model."):
+        cfg, dev, w = self.cfg, self.device_, self.w
+        bf = lambda t: t.to(device=dev, dtype=torch.bfloat16).contiguous()  # noqa: E731
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        cin = 1
+        for i, (co, k) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"])):
+            p = f"{prefix}feature_extractor.conv_layers.{i}."
+            kp = round_up(k * cin, 64)
+            wc = torch.zeros((co, kp), dtype=torch.bfloat16, device=dev)
+            wc[:, : k * cin] = bf(W[p + "0.weight"].permute(0, 2, 1).reshape(co, k * cin))
+            cb = W.get(p + "0.bias")                                  # conv_bias=False in the released WavLM configurations
+            w[f"c{i}"], w[f"c{i}_b"] = wc, (f32(cb) if cb is not None else torch.zeros(co, dtype=torch.float32, device=dev))
+            w[f"c{i}_lw"], w[f"c{i}_lb"] = f32(W[p + "2.1.weight"]), f32(W[p + "2.1.bias"])
+            cin = co
+        d, H = cfg["hub_dim"], cfg["hub_heads"]
+        assert d % 64 == 0 and d // H == 64 and cin % 64 == 0
+        w["fp_lw"], w["fp_lb"] = f32(W[prefix + "layer_norm.weight"]), f32(W[prefix + "layer_norm.bias"])
+        w["fp"], w["fp_b"] = bf(W[prefix + "post_extract_proj.weight"]), f32(W[prefix + "post_extract_proj.bias"])
+        p = prefix + "encoder."
+        if p + "pos_conv.0.weight_g" in W:      # nn.utils.weight_norm(dim=2): w = g * v / ||v|| over dims (0, 1)
+            g_, v_ = W[p + "pos_conv.0.weight_g"].float(), W[p + "pos_conv.0.weight_v"].float()
+        else:                                   # the parametrizations API's names for the same two tensors
+            g_, v_ = W[p + "pos_conv.0.parametrizations.weight.original0"].float(), W[p + "pos_conv.0.parametrizations.weight.original1"].float()
+        pw = g_ * v_ / v_.norm(dim=(0, 1), keepdim=True)
+        G, kpos = cfg["hub_pos_groups"], cfg["hub_pos_k"]
+        gch = d // G
+        self.pos_kp = round_up(kpos * gch, 64)
+        pg = torch.zeros((G, gch, self.pos_kp), dtype=torch.bfloat16, device=dev)
+        for g in range(G):
+            pg[g, :, : kpos * gch] = bf(pw[g * gch:(g + 1) * gch].permute(0, 2, 1).reshape(gch, kpos * gch))
+        w["pos"], w["pos_b"] = pg, f32(W[p + "pos_conv.0.bias"])
+        for i in range(cfg["hub_layers"]):
+            q = f"{p}layers.{i}."
+            a = q + "self_attn."
+            w[f"{i}.qkv"] = bf(torch.cat([W[a + "q_proj.weight"], W[a + "k_proj.weight"], W[a + "v_proj.weight"]], 0))
+            w[f"{i}.qkv_b"] = f32(torch.cat([W[a + "q_proj.bias"], W[a + "k_proj.bias"], W[a + "v_proj.bias"]], 0))
+            w[f"{i}.out"], w[f"{i}.out_b"] = bf(W[a + "out_proj.weight"]), f32(W[a + "out_proj.bias"])
+            w[f"{i}.ln1_w"], w[f"{i}.ln1_b"] = f32(W[q + "self_attn_layer_norm.weight"]), f32(W[q + "self_attn_layer_norm.bias"])
+            w[f"{i}.fc1"], w[f"{i}.fc1_b"] = bf(W[q + "fc1.weight"]), f32(W[q + "fc1.bias"])
+            w[f"{i}.fc2"], w[f"{i}.fc2_b"] = bf(W[q + "fc2.weight"]), f32(W[q + "fc2.bias"])
+            w[f"{i}.ln2_w"], w[f"{i}.ln2_b"] = f32(W[q + "final_layer_norm.weight"]), f32(W[q + "final_layer_norm.bias"])
+            w[f"{i}.gw"], w[f"{i}.gb"] = f32(W[a + "grep_linear.weight"]), f32(W[a + "grep_linear.bias"])
+            w[f"{i}.ga"] = f32(W[a + "grep_a"].reshape(H))
+        w["rel_bias"] = f32(W[p + "layers.0.self_attn.relative_attention_bias.weight"])      # [buckets, H]
+        w["lnp_w"], w["lnp_b"] = f32(W[p + "layer_norm.weight"]), f32(W[p + "layer_norm.bias"])
+        self._tables = {}
+        return self
+
+    def init_random(self, seed: int = 42):
+        super().init_random(seed)
+        cfg, dev, w = self.cfg, self.device_, self.w
+        g = torch.Generator(device=dev).manual_seed(seed + 17)
+        H = cfg["hub_heads"]
+        for i in range(cfg["hub_layers"]):
+            w[f"{i}.gw"] = torch.randn(8, 64, generator=g, device=dev) * 0.1
+            w[f"{i}.gb"] = torch.randn(8, generator=g, device=dev) * 0.1
+            w[f"{i}.ga"] = torch.ones(H, device=dev)
+        for i in range(len(cfg["hub_conv_dim"])):
+            w[f"c{i}_b"] = torch.zeros_like(w[f"c{i}_b"])
+        w["rel_bias"] = torch.randn(cfg["wavlm_buckets"], H, generator=g, device=dev)
+        self._tables = {}
+        return self
+
+    def _relpos(self, layer: int, attn_in: torch.Tensor, B: int, T: int):
+        w, H = self.w, self.cfg["hub_heads"]
+        tab = self._tables.get(T)
+        if tab is None:
+            from .host_tables import wavlm_relative_buckets
+            buckets = wavlm_relative_buckets(T, self.cfg["wavlm_buckets"], self.cfg["wavlm_max_distance"]).to(self.device_)
+            tab = ops.relpos_table(w["rel_bias"].index_select(0, buckets).t().contiguous())      # [H, 2T-1] (+ slack)
+            self._tables = {T: tab}
+        gate = ops.wavlm_gate(attn_in, w[f"{layer}.gw"], w[f"{layer}.gb"], w[f"{layer}.ga"], B, T, H)
+        return (gate, tab, T)
 
 # ======================================================================================== projector
 class HipProjectorConcat(nn.Module):
@@ -1332,8 +1421,8 @@ class SlamHipModel(nn.Module):
         if self.train_encoder and (self.encoder_name != "whisper" or self.projector_name != "linear" or cfg.get("varlen_encoder", False)):
             raise NotImplementedError("freeze_encoder=false is implemented for the Whisper encoder with the linear projector on padded "
                                       "batches (hand-written encoder backward); HuBERT / q-former / cov1d-linear / varlen_encoder are not")
-        if self.encoder_name == "hubert":
-            self.encoder = HipHubertEncoder(cfg, self.device_)
+        if self.encoder_name in ("hubert", "wavlm"):
+            self.encoder = (HipHubertEncoder if self.encoder_name == "hubert" else HipWavLMEncoder)(cfg, self.device_)
             cfg["enc_dim"] = cfg["hub_dim"]
         elif not self.train_encoder:
             self.encoder = HipWhisperEncoder(cfg, self.device_)
@@ -1504,10 +1593,10 @@ class SlamHipModel(nn.Module):
         stash = {} if train else None
 
         hub_pad = None
-        if self.encoder_name == "hubert":
-            # raw-waveform encoder (slam_model.py:335-341)
+        if self.encoder_name in ("hubert", "wavlm"):
+            # raw-waveform encoders (slam_model.py:335-341 HuBERT, :333-334 WavLM: both get `1 - audio_mask` as the padding mask)
             if audio is None:
-                raise RuntimeError("hubert encoder needs the raw `audio` batch key")
+                raise RuntimeError(f"{self.encoder_name} encoder needs the raw `audio` batch key")
             # valid samples per clip as host ints: the collator's python list when present (no sync), else audio_len / audio_mask
             nv = kwargs.get("audio_len_list", None)
             if nv is None and kwargs.get("audio_len", None) is not None:
@@ -1547,7 +1636,7 @@ class SlamHipModel(nn.Module):
             pass
         elif self.projector_name == "q-former":
             # audio_mel_post_mask is consumed only by this branch (slam_model.py:354-355); None = attend to all
-            if self.encoder_name == "whisper":
+            if self.encoder_name in ("whisper", "wavlm"):   # (the WavLM branch never produces a post mask, slam_model.py:333-334)
                 pmask = kwargs.get("audio_mel_post_mask", None)
             elif hub_pad is None:
                 pmask = None                    # nothing padded: fairseq returns no mask, the Q-Former attends to everything

@@ -339,10 +339,12 @@ def transpose(x2d, Rp=None, out=None):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_lse=True, out=None, Tk=None, seg=None):
+def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_lse=True, out=None, Tk=None, seg=None,
+             relpos=None):
     """self-attention: q/k rows (b*T + t).  Cross-attention: pass Tk (key rows b*Tk + t); vt is [B,Hkv,D,Tkp].
     seg = (lo, hi) int32 [B*T]: packed sequences (B = 1), query q sees keys lo[q] <= k <= q (causal) or
-    lo[q] <= k < hi[q] (bidirectional: the ragged encoder, one clip per segment)."""
+    lo[q] <= k < hi[q] (bidirectional: the ragged encoder, one clip per segment).
+    relpos = (gate [B,Hq,Tqp] f32, table from relpos_table(), rp_T): WavLM's gated relative position bias."""
     Tk = Tk or T
     Tkp, Tqp = vt.shape[-1], round_up(T, 64)
     if out is None:
@@ -351,8 +353,27 @@ def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_
     _timed("attn_fwd", 4.0 * B * Hq * T * Tk * D * (0.5 if causal else 1.0),
            lambda: call("slam_attn_fwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(vt), _p(out), _ld(out), _p(lse),
                         _p(key_mask), B, T, Tk, Tqp, Tkp, Hq, Hkv, D, 1 if causal else 0, scale, _p(seg[0]) if seg else None,
-                        _p(seg[1]) if seg else None, _s()))
+                        _p(seg[1]) if seg else None, _p(relpos[0]) if relpos else None,
+                        (relpos[1].data_ptr() + 64 * 4) if relpos else None, relpos[2] if relpos else 0,
+                        relpos[1].shape[1] if relpos else 0, _s()))
     return out, lse
+
+
+def relpos_table(values_hr: torch.Tensor) -> torch.Tensor:
+    """values_hr [H, 2T-1] f32 (bias as a function of the relative distance k - q + T - 1) -> the padded table attn_fwd's
+    relpos wants: rows of stride 2T-1+128, 64 zero floats of slack on both sides"""
+    H, n = values_hr.shape
+    tab = torch.zeros((H, n + 128), dtype=torch.float32, device=values_hr.device)
+    tab[:, 64: 64 + n] = values_hr
+    return tab
+
+
+def wavlm_gate(x2d: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, grep_a: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
+    """x2d [B*T, H*64] bf16 (the attention input), grep_linear w [8,64] / bias [8] f32, grep_a [H] f32 -> gate [B,H,Tp] f32"""
+    Tp = round_up(T, 64)
+    gate = torch.zeros((B, H, Tp), dtype=torch.float32, device=x2d.device)
+    call("slam_wavlm_gate", _p(x2d), _ld(x2d), _p(w), _p(bias), _p(grep_a), _p(gate), B, T, H, Tp, _s())
+    return gate
 
 
 def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T, Hq, Hkv, D, causal, scale,

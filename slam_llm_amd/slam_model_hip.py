@@ -52,14 +52,21 @@ HUBERT_PRESETS = {
                           hub_dim=1280, hub_heads=20, hub_layers=48, hub_ffn=5120, hub_pos_k=128, hub_pos_groups=16, hub_eps=1e-5),
 }
 
+WAVLM_PRESETS = {
+    # WavLM-Large (the released checkpoint's cfg: extractor_mode layer_norm, conv_bias false, layer_norm_first, gru_rel_pos,
+    # 320 buckets / max_distance 800; models/wavlm/WavLM.py:162-214).  Base / Base+ use the group-norm extractor and post-LN
+    # layers: not implemented.
+    "wavlm-large": dict(HUBERT_PRESETS["hubert-large"], wavlm_buckets=320, wavlm_max_distance=800),
+}
+
 
 def build_config(train_config, model_config) -> dict:
     enc_name = _get(model_config, "encoder_name", None)
-    if enc_name not in ("whisper", "hubert"):
+    if enc_name not in ("whisper", "hubert", "wavlm"):
         # the recipe dataclasses default encoder_name to None (asr_config.py:14: a text-only LLM in the reference,
         # slam_model.py:68-116 returns no encoder); this plugin is the speech path only
-        raise NotImplementedError(f"model_config.encoder_name={enc_name!r}: the HIP path covers the Whisper (slam_model.py:320-321) and "
-                                  "HuBERT (:335-341) branches; WavLM & co. are SURVEY 8(f) rows")
+        raise NotImplementedError(f"model_config.encoder_name={enc_name!r}: the HIP path covers the Whisper (slam_model.py:320-321), "
+                                  "HuBERT (:335-341) and WavLM (:333-334) branches")
     projector = _get(model_config, "encoder_projector", "linear")
     if projector not in ("linear", "cov1d-linear", "q-former"):
         raise NotImplementedError("encoder_projector must be `linear` (EncoderProjectorConcat), `cov1d-linear` "
@@ -86,6 +93,11 @@ def build_config(train_config, model_config) -> dict:
         extra.update(HUBERT_PRESETS[hp])
         extra["enc_dim"] = extra["hub_dim"]
         enc = None
+    elif enc_name == "wavlm":
+        hp = _get(model_config, "arch_encoder") or _guess_preset(str(_get(model_config, "encoder_path", "wavlm-large")).lower().replace("_", "-"), WAVLM_PRESETS)
+        extra.update(WAVLM_PRESETS[hp])
+        extra["enc_dim"] = extra["hub_dim"]
+        enc = None
     else:
         enc = _get(model_config, "arch_encoder") or _guess_preset("whisper-" + str(_get(model_config, "encoder_path", "")).split("/")[-1].replace(".pt", ""), enc_presets)
     if projector == "q-former":
@@ -100,7 +112,7 @@ def build_config(train_config, model_config) -> dict:
     overrides = _get(model_config, "arch_overrides", None)   # ++model_config.arch_overrides={llm_layers: 2, ...}: non-preset geometries
     if overrides:
         cfg.update({k: (tuple(v) if isinstance(v, list) else v) for k, v in dict(overrides).items()})
-        if enc_name == "hubert":
+        if enc_name in ("hubert", "wavlm"):
             cfg["enc_dim"] = cfg["hub_dim"]
     if int(_get(model_config, "encoder_dim", cfg["enc_dim"])) != cfg["enc_dim"] or int(_get(model_config, "llm_dim", cfg["llm_dim"])) != cfg["llm_dim"]:
         raise ValueError(f"model_config.encoder_dim / llm_dim ({_get(model_config, 'encoder_dim')}, {_get(model_config, 'llm_dim')}) do not match "

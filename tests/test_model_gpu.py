@@ -255,6 +255,63 @@ def test_hubert_linear_llm_step_matches_oracle(dev):
     assert torch.isfinite(model.store.grad).all() and float(model.store.grad.abs().sum()) > 0
 
 
+def test_wavlm_encoder_matches_reference_fixture(dev):
+    """f4: HipWavLMEncoder (HuBERT-large graph + gated relative position bias inside the attention kernel) vs the fixture written
+    by the reference's own WavLM module: equal-length batch and ragged zero-padded batch (valid frames)"""
+    from oracle.make_golden_cases import WAVLM_TINY as C
+    from slam_llm_amd.model import HipWavLMEncoder
+    fx = G.load("wavlm_tiny")
+    W = O.init_wavlm_weights(C, seed=9)
+    enc = HipWavLMEncoder(dict(C), dev).load(W)
+    out = enc.forward_wav(torch.from_numpy(fx["wav"]).to(dev)).float().cpu().numpy()
+    assert list(out.shape) == [int(x) for x in fx["out_shape"]]
+    g, a = G.sub(fx, "out", out)
+    assert rel_err(a, g) < 3e-2 and G.cosine(g, a) > 0.9995, (rel_err(a, g), G.cosine(g, a))
+    nv = [int(x) for x in fx["ragged.n_valid"]]
+    out_r = enc.forward_wav(torch.from_numpy(fx["ragged.wav"]).to(dev), nv).float().cpu()
+    pad = torch.from_numpy(fx["ragged.frame_padding_mask"])
+    g, a = G.sub(fx, "ragged.out", out_r.masked_fill(pad[:, :, None], 0.0).numpy())
+    assert rel_err(a, g) < 3e-2 and G.cosine(g, a) > 0.9995, (rel_err(a, g), G.cosine(g, a))
+    # the bias matters: without it the output is far from the fixture (guards against a silently ignored table)
+    enc.w["rel_bias"].zero_()
+    enc._tables = {}
+    off = enc.forward_wav(torch.from_numpy(fx["wav"]).to(dev)).float().cpu().numpy()
+    g, a = G.sub(fx, "out", off)
+    assert rel_err(a, g) > 6e-2
+
+
+def test_wavlm_llm_step_matches_oracle(dev):
+    """WavLM -> linear projector -> LLM + LoRA training step at tiny widths: loss vs the oracle, and it trains"""
+    from oracle.make_golden_cases import WAVLM_TINY
+    from slam_llm_amd.model import SlamAdamW, SlamHipModel
+    cfg = dict(O.make_config(), **WAVLM_TINY)
+    cfg.update(encoder_name="wavlm", enc_dim=WAVLM_TINY["hub_dim"])
+    W = {k: v for k, v in O.init_weights(cfg, seed=42).items() if not k.startswith("encoder.")}
+    W.update(O.init_wavlm_weights(WAVLM_TINY, seed=9))
+    model = SlamHipModel(dict(cfg, lora_dropout=0.0), dev).load_weights(W)
+    model.train()
+    wav = torch.nn.functional.layer_norm(O.synth_audio(2, 1.0, seed=9), (16000,))
+    Ta = 49 // cfg["ds_rate"]
+    samples = [O.make_sample(Ta, [5, 6, 7], [9, 10, 11, 12], 2), O.make_sample(Ta, [5, 6], [9, 10], 2)]
+    ob = O.collate_left_pad(samples, pad_id=2)
+    with torch.no_grad():
+        enc = O.wavlm_encoder(W, cfg, wav)
+        proj = O.projector_concat(W, enc, cfg["ds_rate"])
+        emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+        loss_ref, _ = O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
+    gb = {k: v.to(dev) for k, v in ob.items()}
+    gb["audio"] = wav.to(dev)
+    opt = SlamAdamW(model, lr=1e-3)
+    losses = []
+    for _ in range(3):
+        outputs, acc = model(**{k: v.clone() for k, v in gb.items()})
+        outputs.loss.backward()
+        opt.step(); opt.zero_grad()
+        losses.append(float(outputs.loss.detach()))
+    assert abs(losses[0] - float(loss_ref)) < 1.5e-2, (losses[0], float(loss_ref))
+    assert losses[2] < losses[0]
+
+
 def test_qformer_projector_matches_reference_fixture(dev):
     """a3': Q-Former projector forward + every parameter gradient vs the reference module's fixture"""
     from oracle.make_golden_cases import QFORMER_CASE as C

@@ -869,3 +869,42 @@ def test_conv_col2im_is_the_adjoint_of_im2col(dev, stride, T):
     xpr = torch.nn.functional.pad(xr.float(), (0, 0, 1, 1))
     ref = torch.cat([xpr[:, j: j + stride * (To - 1) + 1: stride] for j in range(3)], dim=-1).reshape(B * To, 3 * C)
     assert torch.equal(ops.conv1d_k3_im2col(xr.to(dev), stride, 3 * C).float().cpu(), ref)
+
+
+@pytest.mark.parametrize("T,masked", [(49, False), (200, True), (333, False)])
+def test_attention_fwd_gated_relative_position_bias(dev, T, masked):
+    """slam_attn_fwd with rp_gate / rp_tab (WavLM) vs torch fp32: softmax(q.k * scale + gate[b,h,q] * tab[h, k - q] [+ key mask]) v;
+    slam_wavlm_gate vs the same gate arithmetic in torch"""
+    from slam_llm_amd import ops
+    from slam_llm_amd.host_tables import wavlm_relative_buckets
+    B, H, D = 2, 3, 64
+    g = torch.Generator().manual_seed(T)
+    x = (torch.randn(B * T, H * D, generator=g) * 0.8).to(torch.bfloat16)
+    qkv = torch.randn(B * T, 3 * H * D, generator=g).to(torch.bfloat16)
+    gw, gb, ga = torch.randn(8, D, generator=g) * 0.2, torch.randn(8, generator=g) * 0.2, 1 + torch.randn(H, generator=g) * 0.3
+    emb = torch.randn(40, H, generator=g)
+    gate = ops.wavlm_gate(x.to(dev), gw.to(dev), gb.to(dev), ga.to(dev), B, T, H)
+    xh = x.float().view(B, T, H, D).permute(0, 2, 1, 3)
+    gl = torch.sigmoid((xh @ gw.t() + gb).view(B, H, T, 2, 4).sum(-1))
+    gate_ref = gl[..., 0] * (gl[..., 1] * ga[None, :, None] - 1.0) + 2.0
+    assert torch.allclose(gate[:, :, :T].cpu(), gate_ref, atol=2e-5, rtol=1e-5)
+    buckets = wavlm_relative_buckets(T, 40, 24)
+    tab = ops.relpos_table(emb.index_select(0, buckets).t().contiguous().to(dev))
+    qd = qkv.to(dev)
+    vt = ops.head_rope_transpose(qd, 2 * H * D, B, T, H, D)
+    km = None
+    if masked:
+        km = torch.zeros((B, vt.shape[-1]), dtype=torch.uint8)
+        km[0, :T] = 1
+        km[1, : T - 37] = 1
+    out, _ = ops.attn_fwd(qd[:, : H * D], qd[:, H * D: 2 * H * D], vt, B, T, H, H, D, False, D ** -0.5,
+                          key_mask=km.to(dev) if km is not None else None, relpos=(gate, tab, T))
+    q, k, v = (qkv.float()[:, i * H * D:(i + 1) * H * D].view(B, T, H, D).transpose(1, 2) for i in range(3))
+    rel = torch.arange(T)[None, :] - torch.arange(T)[:, None]
+    bias = emb[buckets[rel + T - 1]].permute(2, 0, 1)                       # [H, q, k]
+    sc = q @ k.transpose(2, 3) * D ** -0.5 + gate_ref[..., None] * bias[None]
+    if km is not None:
+        sc = sc.masked_fill(km[:, None, None, :T] == 0, float("-inf"))
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * T, H * D)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < 3e-2, err

@@ -122,6 +122,28 @@ def test_hubert_ragged_batch_matches_masked_twin():
     G.check_packed(fx, "out", out.masked_fill(pad[:, :, None], 0.0).numpy(), atol=3e-5, rtol=1e-4)
 
 
+def test_wavlm_encoder_matches_the_reference_module():
+    """oracle.wavlm_encoder == the reference's own WavLM (models/wavlm/WavLM.py, fixture written by oracle/make_golden_wavlm.py):
+    equal-length and ragged zero-padded batches; the product's host-side bucket table == the oracle's bucket function"""
+    from oracle.make_golden_cases import WAVLM_TINY as C
+    from slam_llm_amd.host_tables import wavlm_relative_buckets
+    fx = G.load("wavlm_tiny")
+    W = O.init_wavlm_weights(C, seed=9)
+    with torch.no_grad():
+        out = O.wavlm_encoder(W, C, torch.from_numpy(fx["wav"]))
+        nv = torch.from_numpy(fx["ragged.n_valid"])
+        out_r = O.wavlm_encoder(W, C, torch.from_numpy(fx["ragged.wav"]), n_valid=nv)
+    assert list(out.shape) == [int(x) for x in fx["out_shape"]]
+    G.check_packed(fx, "out", out.numpy(), atol=3e-5, rtol=1e-4)
+    pad = O.hubert_frame_padding_mask(fx["ragged.wav"].shape[1], out_r.shape[1], nv)
+    assert np.array_equal(pad.numpy(), fx["ragged.frame_padding_mask"])
+    G.check_packed(fx, "ragged.out", out_r.masked_fill(pad[:, :, None], 0.0).numpy(), atol=3e-5, rtol=1e-4)
+    for T, nb, md in ((49, 40, 24), (1500, 320, 800), (7, 320, 800)):
+        rel = torch.arange(-(T - 1), T)
+        assert torch.equal(wavlm_relative_buckets(T, nb, md), O.wavlm_relative_buckets(rel, nb, md))
+        assert int(wavlm_relative_buckets(T, nb, md).max()) < nb
+
+
 def test_qformer_projector_matches_reference_module():
     from oracle.make_golden_cases import QFORMER_CASE as C
     fx = G.load("qformer")

@@ -177,12 +177,33 @@ def test_untouched_recipe_defaults_are_rejected_loudly():
     tc, mc, _ = recipe_configs("asr_librispeech", dict(encoder_name="whisper", encoder_path="large-v2.pt"), dict(use_peft=True))
     with pytest.raises(ValueError, match="llm_dim"):      # vicuna-13b-v1.5 is 5120 wide, the default llm_dim says 4096
         build_config(tc, mc)
-    tc, mc, _ = recipe_configs("aispeech_asr", dict(encoder_name="wavlm"), dict(freeze_encoder=True))
-    with pytest.raises(NotImplementedError, match="wavlm"):
+    tc, mc, _ = recipe_configs("aispeech_asr", dict(encoder_name="beats"), dict(freeze_encoder=True))
+    with pytest.raises(NotImplementedError, match="beats"):
         build_config(tc, mc)
+    # unfrozen encoders other than Whisper + linear projector are refused by name
+    tc, mc, _ = recipe_configs("aispeech_asr", dict(encoder_name="wavlm"), dict(freeze_encoder=False, use_peft=True))
+    with pytest.raises(NotImplementedError, match="freeze_encoder"):
+        check_supported(tc, mc)
     tc, mc, _ = recipe_configs("aispeech_asr", dict(encoder_name="whisper"), dict(freeze_encoder=True, use_peft=True, enable_deepspeed=True))
     with pytest.raises(NotImplementedError, match="DeepSpeed"):
         check_supported(tc, mc)
+
+
+def test_wavlm_and_unfrozen_whisper_recipes_build():
+    """aispeech_asr with the WavLM-Large encoder (models/slam_model.py:89-91, :333-334) and a Whisper recipe with
+    train_config.freeze_encoder=false map to supported configurations"""
+    from slam_llm_amd.slam_model_hip import build_config, check_supported
+    tc, mc, _ = recipe_configs("aispeech_asr", dict(encoder_name="wavlm", encoder_path="/ckpt/WavLM-Large.pt", encoder_dim=1024, llm_name="vicuna-7b-v1.5",
+                                                     llm_dim=4096, encoder_projector="linear", normalize=True),
+                               dict(freeze_encoder=True, use_peft=True))
+    check_supported(tc, mc)
+    cfg = build_config(tc, mc)
+    assert cfg["encoder_name"] == "wavlm" and cfg["enc_dim"] == 1024 and cfg["hub_layers"] == 24 and cfg["wavlm_buckets"] == 320 \
+        and cfg["wavlm_max_distance"] == 800 and cfg["freeze_encoder"] is True
+    tc, mc, _ = recipe_configs("asr_librispeech", dict(encoder_name="whisper", encoder_path="/ckpt/large-v3.pt", encoder_dim=1280, llm_name="llama-3-8b",
+                                                        llm_dim=4096, encoder_projector="linear"), dict(freeze_encoder=False, use_peft=True))
+    check_supported(tc, mc)
+    assert build_config(tc, mc)["freeze_encoder"] is False
 
 
 # ---------------------------------------------------------------------------------------------- dataset formats
