@@ -10,9 +10,11 @@
 //     S^T = K . Q^T          (A = K rows, B = Q rows)        -> lane owns query (l&15), 4 consecutive keys
 //     O^T = V^T . P^T        (A = V^T rows = head-dim, B = P) -> lane owns the same query, 4 consecutive d
 //   Two S^T fragments (32 keys) already ARE a B operand for the second product, provided the V^T operand
-//   enumerates keys in the same order: k-slot (g, e) = key 16*(2a + e/4) + 4g + e%4.  V (and, for the
-//   backward, K, Q and dO) are therefore also kept transposed ([B,H,D,Tp], written by
-//   slam_head_rope_transpose) so that those operands are contiguous 8-byte reads.
+//   enumerates keys in the same order.  The forward and the ring dK/dV kernel feed the first product with PERMUTED rows
+//   (fragment row i = tile row 8(i/4) + 4f + i%4), which makes that order "k-slot (g, e) = key 32a + 8g + e": eight
+//   contiguous keys, one 16-byte read of the transposed operand; the round-1 backward kernels use natural rows and
+//   k-slot (g, e) = key 16*(2a + e/4) + 4g + e%4 (two 8-byte reads).  V (and, for the backward, K, Q and dO) are
+//   therefore also kept transposed ([B,H,D,Tp], written by slam_head_rope_transpose).
 //   All per-query softmax state (m, l, LSE, Delta) is lane-local; row reductions are two xor-shuffles.
 //
 // Masking follows HF: key j is visible to query i iff j <= i (causal) and key_mask[b][j]; query rows are
@@ -110,6 +112,61 @@ __device__ __forceinline__ frag_t join_frag(u16x4_t lo, u16x4_t hi) {
 }
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// hand-placed LDS reads: the result register is "ready" for the compiler at once, so every use MUST sit behind an lds_wait
+// that names it (LDS operations return in order: lgkmcnt(N) = all but the youngest N have landed)
+template <int OFF>
+__device__ __forceinline__ frag_t lds_read128(unsigned addr) {
+  frag_t r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ void lds_landed(frag_t& r) { asm volatile("" : "+v"(r)); }
+template <int N, class... T>
+__device__ __forceinline__ void lds_wait(T&... regs) {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  (lds_landed(regs), ...);
+}
+// reductions over the four 16-lane groups (lanes l, l^16, l^32, l^48) with gfx950's v_permlane16_swap / v_permlane32_swap: of the
+// two results one is the lane's own value and the other its partner's, so max / sum need no select -- and, unlike __shfl_xor
+// (ds_bpermute), they do not go through the LDS queue, whose counter the hand-placed reads of the tile loop are counting on
+// (inline asm: with this hipcc the builtins' second result folds to the first -- `r[1]` of __builtin_amdgcn_permlane16_swap
+// compiles to `extractvalue 0` -- and the two operands must be different registers, which "+v" twice guarantees)
+__device__ __forceinline__ void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float max_across_groups(float v) {
+  float a = v, b = v;
+  swap16(a, b);
+  a = b = fmaxf(a, b);
+  swap32(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float sum_across_groups(float v) {
+  float a = v, b = v;
+  swap16(a, b);
+  a = b = a + b;
+  swap32(a, b);
+  return a + b;
+}
+
+// XOR key of the 16-byte chunks of K-tile row `row` (forward kernel): a fragment reads rows 8(i/4) + i%4 (+ 4f' + 32a), i = 0..15;
+// the key is distinct over them per 256-byte bank window (D = 128: one row per window, 16 keys; D = 64: two rows, 8 keys)
+template <int D>
+__device__ __forceinline__ int fwd_swz(int row) {
+  const int i = (((row >> 3) & 3) << 2) | (row & 3);
+  return D == 128 ? i : (i >> 1);
+}
 
 // ------------------------------------------------------------------------------------------
 // forward: 4 waves x 32 query rows per workgroup, 64-key K / V^T tiles staged through LDS
@@ -212,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int i = 0; i < KI; i++) {
       const int item = tid + i * 256;
       const int row = item / KCH, c = item % KCH;
-      *reinterpret_cast<frag_t*>(ldsK + row * KROWB + ((c ^ (row & KCM)) << 4)) = kreg[i];
+      *reinterpret_cast<frag_t*>(ldsK + row * KROWB + ((c ^ fwd_swz<D>(row)) << 4)) = kreg[i];
     }
 #pragma unroll
     for (int i = 0; i < VI; i++) {
@@ -232,26 +289,55 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     if (CAUSAL && k0 > qw0 + QW - 1) continue;  // whole tile is in this wave's future
 
     // ---- S^T = K . Q^T ----
+    // Key fragment kf = 2a + f' covers tile keys 32a + 8(i/4) + 4f' + i%4 (i = A-operand row): the eight P values a lane then
+    // holds for the pair a are the CONTIGUOUS keys 32a + 8g .. 32a + 8g + 7, so the V^T operand of the second product is one
+    // 16-byte LDS read (it was two 8-byte reads and a register shuffle).  LDS reads are asm with counted waits: all K fragments
+    // are requested up front, products start as they land; the V^T reads of the first pair are requested before the softmax
+    // arithmetic and land behind it.
     f32x4_t s[QF][4];
+    {
+      const int i4 = (li >> 2) * 8 + (li & 3);
+      const unsigned kbase = lds_offset_of(ldsK) + (unsigned)(i4 * KROWB);
+      unsigned ka[KD];
 #pragma unroll
-    for (int kf = 0; kf < 4; kf++) {
-      frag_t kfr[KD];
-      const int row = kf * 16 + li;
+      for (int kd = 0; kd < KD; kd++) ka[kd] = kbase + (unsigned)(((kd * 4 + g) ^ fwd_swz<D>(i4)) << 4);   // (swz ignores bits 2, 5 of the row)
+      frag_t kfr[4][KD];
+      // AHEAD key fragments are requested before the first product; fragment kf + AHEAD is requested when kf's operands have
+      // landed (D = 128: two ahead = 8 reads in flight -- all four up front cost 33 more VGPRs and measured 6 % slower)
+      constexpr int AHEAD = (D == 128) ? 2 : 4;
+      static_for<0, AHEAD>([&](auto kf) {
+        static_for<0, KD>([&](auto kd) { kfr[kf][kd] = lds_read128<((kf >> 1) * 32 + (kf & 1) * 4) * KROWB>(ka[kd]); });
+      });
+      static_for<0, 4>([&](auto kf) {
+        constexpr int younger = (kf + AHEAD <= 4 ? AHEAD - 1 : 3 - kf) * KD;   // reads issued after fragment kf's
+        static_for<0, KD>([&](auto kd) { lds_wait<younger + (KD - 1 - kd)>(kfr[kf][kd]); });
+        if constexpr (kf + AHEAD < 4)
+          static_for<0, KD>([&](auto kd) {
+            kfr[kf + AHEAD][kd] = lds_read128<(((kf + AHEAD) >> 1) * 32 + ((kf + AHEAD) & 1) * 4) * KROWB>(ka[kd]);
+          });
 #pragma unroll
-      for (int kd = 0; kd < KD; kd++)
-        kfr[kd] = *reinterpret_cast<const frag_t*>(ldsK + row * KROWB + (((kd * 4 + g) ^ (row & KCM)) << 4));
+        for (int f = 0; f < QF; f++) {
+          f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int f = 0; f < QF; f++) {
-        f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kd = 0; kd < KD; kd++) a = mfma16(kfr[kd], qf[f][kd], a);
-        s[f][kf] = a;
-      }
+          for (int kd = 0; kd < KD; kd++) acc = mfma16(kfr[kf][kd], qf[f][kd], acc);
+          s[f][kf] = acc;
+        }
+      });
     }
+    const unsigned vbase = lds_offset_of(ldsV) + (unsigned)(li * 128);
+    unsigned va[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) va[a] = vbase + (unsigned)(((a * 4 + g) ^ ((li >> 1) & 7)) << 4);   // rows d = df*16 + li: (d >> 1) & 7 = (li >> 1) & 7
+    frag_t vfr[2][DF];
+    static_for<0, DF>([&](auto df) { vfr[0][df] = lds_read128<df * 16 * 128>(va[0]); });
     // ---- online softmax (per query = lane&15, replicated over the 4 lane groups) ----
+    // The running maximum only moves when a tile exceeds it by more than 2^8 (in the exponent's log2 units): P stays <= 256,
+    // exact in fp32 / bf16, and the O / l rescale becomes a rare wave-uniform branch instead of 2 exp + 16 multiplies per tile
     // interior tiles (no key mask, fully inside [0, Tk), fully below the causal diagonal of this wave) skip all masking
     const bool tile_full = !RP && (p.kmask == nullptr) && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0 &&
                            k0 + 64 <= hi_wave_min;
+    float alpha[QF];
+    bool moved = false;
     if (tile_full) {
 #pragma unroll
       for (int f = 0; f < QF; f++) {
@@ -260,10 +346,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         for (int kf = 0; kf < 4; kf++)
 #pragma unroll
           for (int r = 0; r < 4; r++) mt = fmaxf(mt, s[f][kf][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float mnew = fmaxf(mrow[f], mt * sl2);
-        const float alpha = fast_exp2(mrow[f] - mnew);
+        mt = max_across_groups(mt);
+        mt *= sl2;
+        const bool mv = mt > mrow[f] + 8.0f;
+        const float mnew = mv ? mt : mrow[f];
+        alpha[f] = mv ? fast_exp2(mrow[f] - mnew) : 1.0f;
+        moved |= mv;
         mrow[f] = mnew;
         float rs = 0.f;
 #pragma unroll
@@ -274,17 +362,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             s[f][kf][r] = pv;
             rs += pv;
           }
-        lrow[f] = lrow[f] * alpha + rs;
-#pragma unroll
-        for (int df = 0; df < DF; df++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) o[f][df][r] *= alpha;
+        lrow[f] = lrow[f] * alpha[f] + rs;
       }
     } else {
       bool kv[4][4];
 #pragma unroll
       for (int kf = 0; kf < 4; kf++) {
-        const int kb = k0 + kf * 16 + 4 * g;
+        const int kb = k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4;
         unsigned mk = 0x01010101u;
         if (p.kmask) mk = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tkp + kb);
 #pragma unroll
@@ -296,26 +380,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         float mt = -INFINITY;
 #pragma unroll
         for (int kf = 0; kf < 4; kf++) {
+          const int kb = k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4;
           float bias[4] = {0.f, 0.f, 0.f, 0.f};
           if constexpr (RP) {   // gate[q] * table[key - q + T - 1], in log2 units like the scores
-            const float* tp = p.rp_tab + (int64_t)h * p.rp_ld + (k0 + kf * 16 + 4 * g - min(q, Tq - 1) + p.rp_T - 1);
+            const float* tp = p.rp_tab + (int64_t)h * p.rp_ld + (kb - min(q, Tq - 1) + p.rp_T - 1);
 #pragma unroll
             for (int r = 0; r < 4; r++) bias[r] = rp_g[f] * tp[r];
           }
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const int key = k0 + kf * 16 + 4 * g + r;
+            const int key = kb + r;
             const bool ok = kv[kf][r] && (!CAUSAL || key <= q) && key >= qlo[f] && key < qhi[f];
             const float x = ok ? fmaf(s[f][kf][r], sl2, bias[r]) : -INFINITY;
             s[f][kf][r] = x;
             mt = fmaxf(mt, x);
           }
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float mnew = fmaxf(mrow[f], mt);
+        mt = max_across_groups(mt);
+        const bool mv = mt > mrow[f] + 8.0f;            // (-inf > -inf + 8 is false: a row that has seen no key stays at -inf)
+        const float mnew = mv ? mt : mrow[f];
         const float muse = (mnew == -INFINITY) ? 0.f : mnew;
-        const float alpha = fast_exp2(mrow[f] - muse);
+        alpha[f] = mv ? fast_exp2(mrow[f] - muse) : 1.0f;
+        moved |= mv;
         mrow[f] = mnew;
         float rs = 0.f;
 #pragma unroll
@@ -326,39 +412,36 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             s[f][kf][r] = pv;
             rs += pv;
           }
-        lrow[f] = lrow[f] * alpha + rs;
+        lrow[f] = lrow[f] * alpha[f] + rs;
+      }
+    }
+    if (__any(moved)) {
+#pragma unroll
+      for (int f = 0; f < QF; f++)
 #pragma unroll
         for (int df = 0; df < DF; df++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) o[f][df][r] *= alpha;
-      }
+          for (int r = 0; r < 4; r++) o[f][df][r] *= alpha[f];
     }
     // ---- O^T += V^T . P^T ----
-#pragma unroll
-    for (int a = 0; a < 2; a++) {
+    static_for<0, 2>([&](auto a) {
       frag_t pb[QF];
 #pragma unroll
       for (int f = 0; f < QF; f++) pb[f] = pack_frag(s[f][2 * a], s[f][2 * a + 1]);
+      if constexpr (a == 0) static_for<0, DF>([&](auto df) { vfr[1][df] = lds_read128<df * 16 * 128>(va[1]); });
+      static_for<0, DF>([&](auto df) {
+        lds_wait<(a == 0 ? DF : 0) + (DF - 1 - df)>(vfr[a][df]);
 #pragma unroll
-      for (int df = 0; df < DF; df++) {
-        const int d = df * 16 + li;
-        const int sw = (d >> 1) & 7;
-        const int c0 = a * 4 + (g >> 1);
-        const u16x4_t lo = *reinterpret_cast<const u16x4_t*>(ldsV + d * 128 + ((c0 ^ sw) << 4) + (g & 1) * 8);
-        const u16x4_t hi = *reinterpret_cast<const u16x4_t*>(ldsV + d * 128 + (((c0 + 2) ^ sw) << 4) + (g & 1) * 8);
-        const frag_t vf = join_frag(lo, hi);
-#pragma unroll
-        for (int f = 0; f < QF; f++) o[f][df] = mfma16(vf, pb[f], o[f][df]);
-      }
-    }
+        for (int f = 0; f < QF; f++) o[f][df] = mfma16(vfr[a][df], pb[f], o[f][df]);
+      });
+    });
   }
 
   // ---- epilogue ----
 #pragma unroll
   for (int f = 0; f < QF; f++) {
     float lt = lrow[f];
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
+    lt = sum_across_groups(lt);
     const float inv = lt > 0.f ? 1.0f / lt : 0.f;
     const int q = qw0 + f * 16 + li;
     if (q >= Tq) continue;
@@ -728,9 +811,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
 // s_waitcnt vmcnt(0) (it cannot tell the ring stages apart), which drains the three tiles in flight on every iteration.  An
 // asm DMA is invisible to that bookkeeping; the counted vmcnt + barrier below order it by hand.  M0 (the DMA's LDS base) is
 // compiler-reserved: saved and restored inside the statement.
-__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
-  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
-}
 __device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_dst_uniform) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -748,27 +828,6 @@ __device__ __forceinline__ void bufdma16_asm(__amdgpu_buffer_rsrc_t srd, unsigne
                : "memory");
 }
 
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-// hand-placed LDS reads: the result register is "ready" for the compiler at once, so every use MUST sit behind an lds_wait
-// that names it (LDS operations return in order: lgkmcnt(N) = all but the youngest N have landed)
-template <int OFF>
-__device__ __forceinline__ frag_t lds_read128(unsigned addr) {
-  frag_t r;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-  return r;
-}
-__device__ __forceinline__ void lds_landed(frag_t& r) { asm volatile("" : "+v"(r)); }
-template <int N, class... T>
-__device__ __forceinline__ void lds_wait(T&... regs) {
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-  (lds_landed(regs), ...);
-}
 // XOR key of the 16-byte chunks of row `row` of a row-major ring sub-tile
 template <int D>
 __device__ __forceinline__ int ring_swz(int row) {
