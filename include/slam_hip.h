@@ -63,7 +63,7 @@ int slam_gemm_set_group_m(int group_m);   /* tuning knob: M-tiles per raster gro
 int slam_gemm_set_config(int cfg);
 /* tools only: {shader cycles, 100 MHz ticks} at entry and exit of workgroup 0 of the last pipelined-kernel launch (synchronise
  * first); effective shader clock of the launch = d(cycles) / d(ticks) x 100 MHz -- how the DVFS cost of a variant is read */
-int slam_gemm_debug_clock(unsigned long long* out4);
+int slam_gemm_debug_clock(unsigned long long* out6);   /* [4] = cycles at the k-loop's start, [5] = after the epilogue */
 
 /* ---- conv front end (src/slam_llm/models/encoder.py:18-19): k=3, pad=1 im2col, stride 1|2 ---------
  * in [B, Tin, C] (f32 or bf16) -> out [B*Tout, Kp] bf16, column j*C + c = in[b, t*stride + j - 1, c]. */

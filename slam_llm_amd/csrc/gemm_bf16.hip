@@ -25,7 +25,7 @@
 namespace {
 
 // tools only: shader-clock / real-time stamps of workgroup 0 (effective clock of a launch = d(shader cycles) / d(100 MHz ticks))
-__device__ unsigned long long g_clk_probe[4];
+__device__ unsigned long long g_clk_probe[6];   // workgroup 0: {cycles, 100 MHz ticks} at entry and at k-loop end; cycles at k-loop start and after the epilogue
 
 struct GemmParams {
   const bf16_t* A;
@@ -71,78 +71,215 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
+// swap the odd 16-lane rows of `a` with the even rows of `b` (gfx950).  Inline asm: this hipcc folds the builtin's second result
+// into its first, and the two operands must be different registers.
+__device__ __forceinline__ void swap_rows16(unsigned& a, unsigned& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
 template <int FM, int FN, int WTM, int WTN>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc)[FM][FN], int m0, int n0, int wm,
+__device__ __forceinline__ void gemm_epilogue_generic(const GemmParams& p, f32x4_t (&acc)[FM][FN], int m0, int n0, int wm,
                                               int wn, int frow, int fg) {
-  // ---- epilogue: lane holds C[m = ..+lane&15][n = ..+(lane>>4)*4 + 0..3] ----
+  // ---- epilogue: lane holds C[m = ..+lane&15][n = ..+(lane>>4)*4 + 0..3] of every 16x16 fragment ----
+  // The store tail of a tile is ISSUE bound (one 256x256 bf16 tile = 128 KiB: ~19 k cycles with 8-byte stores, the time of ten
+  // k-tiles -- 14 % of a K = 4096 tile, a third of a K = 1280 one).  bf16 outputs therefore leave in 16-byte stores: the packed
+  // halves of two neighbouring fragments are exchanged between lane rows (v_permlane16_swap: odd rows of the first with even rows
+  // of the second), after which a lane owns EIGHT consecutive columns of fragment 2*jp + (fg & 1), starting at column (fg >> 1) * 8.
+  static_assert(FN % 2 == 0, "fragments are stored in pairs");
+  const bool wide = !p.out_f32 && !p.accumulate;
 #pragma unroll
   for (int i = 0; i < FM; i++) {
     const int m = m0 + wm * WTM + i * 16 + frow;
-    if (m >= p.M) continue;
+    if (m >= p.M) continue;   // (both lanes of an exchanging pair share frow, hence m)
 #pragma unroll
-    for (int j = 0; j < FN; j++) {
-      const int n = n0 + wn * WTN + j * 16 + fg * 4;
-      if (n >= p.N) continue;  // N % 4 == 0 is enforced by the launcher
-      float v[4];
+    for (int jp = 0; jp < FN / 2; jp++) {
+      unsigned pk[2][2] = {{0u, 0u}, {0u, 0u}};
 #pragma unroll
-      for (int e = 0; e < 4; e++) v[e] = acc[i][j][e] * p.alpha;
-      if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (p.act == 1) {
+      for (int hh = 0; hh < 2; hh++) {
+        const int j = 2 * jp + hh;
+        const int n = n0 + wn * WTN + j * 16 + fg * 4;
+        if (n >= p.N) continue;  // N % 4 == 0 is enforced by the launcher
+        float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
-      } else if (p.act == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
-      }
-      if (p.act == 3) {
-        // SwiGLU backward fused into the down_proj dX GEMM: acc = dL/dh for h = silu(gate) * up.  Reads the forward's
-        // gate/up (p.res, columns n and N + n), writes dL/dgate to C[m, n] (below) and dL/dup to C[m, N + n] -- the
-        // [M, F] intermediate dL/dh and its elementwise pass never touch HBM.  Same arithmetic as swiglu_bwd_kernel
-        // (elementwise.hip) applied to the bf16-rounded product.
-        const u16x4_t g4 = *reinterpret_cast<const u16x4_t*>(p.res + (int64_t)m * p.ldr + n);
-        const u16x4_t u4 = *reinterpret_cast<const u16x4_t*>(p.res + (int64_t)m * p.ldr + p.N + n);
-        float du[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const float gf = bf2f(g4[e]), uf = bf2f(u4[e]), df = bf2f(f2bf(v[e]));
-          const float sg = 1.0f / (1.0f + __expf(-gf));
-          v[e] = df * uf * sg * (1.0f + gf * (1.0f - sg));
-          du[e] = df * (gf * sg);
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][e] * p.alpha;
+        if (p.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         }
-        uint2 o2;
-        o2.x = pack2bf(du[0], du[1]);
-        o2.y = pack2bf(du[2], du[3]);
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + p.N + n) = o2;
-      } else if (p.res) {
-        const int rr = p.res_mod > 0 ? (m % p.res_mod) : m;
-        const u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.res + (int64_t)rr * p.ldr + n);
+        if (p.act == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] += bf2f(r4[e]);
+          for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.act == 3) {
+          // SwiGLU backward fused into the down_proj dX GEMM: acc = dL/dh for h = silu(gate) * up.  Reads the forward's
+          // gate/up (p.res, columns n and N + n), writes dL/dgate to C[m, n] (below) and dL/dup to C[m, N + n] -- the
+          // [M, F] intermediate dL/dh and its elementwise pass never touch HBM.  Same arithmetic as swiglu_bwd_kernel
+          // (elementwise.hip) applied to the bf16-rounded product.
+          const u16x4_t g4 = *reinterpret_cast<const u16x4_t*>(p.res + (int64_t)m * p.ldr + n);
+          const u16x4_t u4 = *reinterpret_cast<const u16x4_t*>(p.res + (int64_t)m * p.ldr + p.N + n);
+          float du[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float gf = bf2f(g4[e]), uf = bf2f(u4[e]), df = bf2f(f2bf(v[e]));
+            const float sg = 1.0f / (1.0f + __expf(-gf));
+            v[e] = df * uf * sg * (1.0f + gf * (1.0f - sg));
+            du[e] = df * (gf * sg);
+          }
+          uint2 o2;
+          o2.x = pack2bf(du[0], du[1]);
+          o2.y = pack2bf(du[2], du[3]);
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + p.N + n) = o2;
+        } else if (p.res) {
+          const int rr = p.res_mod > 0 ? (m % p.res_mod) : m;
+          const u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(p.res + (int64_t)rr * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += bf2f(r4[e]);
+        }
+        if (p.out_f32) {
+          float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+          if (p.accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(c);
+            v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+          }
+          *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n;
+          if (p.accumulate) {
+            const u16x4_t o = *reinterpret_cast<const u16x4_t*>(c);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += bf2f(o[e]);
+          }
+          pk[hh][0] = pack2bf(v[0], v[1]);
+          pk[hh][1] = pack2bf(v[2], v[3]);
+          if (!wide) {
+            uint2 o2;
+            o2.x = pk[hh][0];
+            o2.y = pk[hh][1];
+            *reinterpret_cast<uint2*>(c) = o2;
+          }
+        }
       }
-      if (p.out_f32) {
-        float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
-        if (p.accumulate) {
-          const float4 o = *reinterpret_cast<const float4*>(c);
-          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+      if (wide) {
+        swap_rows16(pk[0][0], pk[1][0]);
+        swap_rows16(pk[0][1], pk[1][1]);
+        const int nn = n0 + wn * WTN + (2 * jp + (fg & 1)) * 16 + (fg >> 1) * 8;
+        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nn;
+        if (nn + 8 <= p.N) {
+          *reinterpret_cast<uint4*>(c) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+        } else if (nn < p.N) {
+          uint2 o2;
+          o2.x = pk[0][0];
+          o2.y = pk[0][1];
+          *reinterpret_cast<uint2*>(c) = o2;
         }
-        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n;
-        if (p.accumulate) {
-          const u16x4_t o = *reinterpret_cast<const u16x4_t*>(c);
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += bf2f(o[e]);
-        }
-        uint2 o2;
-        o2.x = pack2bf(v[0], v[1]);
-        o2.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(c) = o2;
       }
     }
   }
+}
+
+// ---- epilogue: lane holds C[m = ..+lane&15][n = ..+(lane>>4)*4 + 0..3] of every 16x16 fragment ----
+// The epilogue must be SHORT CODE.  The first form handled every option (bias, GELU / ReLU / SwiGLU-backward, residual, fp32 /
+// accumulate) with wave-uniform branches inside the unrolled fragment loop: 12 000 lines of ISA and 650 branches per kernel,
+// through which the one live path hopped from cache line to cache line -- 24 000 cycles per 256x256 tile measured with a single
+// workgroup alone on the chip (tools/gemm_epi_probe.py), i.e. the time of ten k-tiles: 13 % of a K = 4096 tile, 27 % of a
+// K = 1280 one.  Now one wave-uniform switch picks a specialised straight-line loop (bias x activation x residual known at
+// compile time; bf16 output in 16-byte stores); the everything-else form is kept out of line for fp32 / accumulating /
+// SwiGLU-backward products.
+template <int FM, int FN, int WTM, int WTN, bool BIAS, int ACT, bool RES>
+__device__ __forceinline__ void gemm_epilogue_bf16(const GemmParams& p, f32x4_t (&acc)[FM][FN], int m0, int n0, int wm, int wn,
+                                                   int frow, int fg) {
+  static_assert(FN % 2 == 0, "fragments are stored in pairs");
+  // bf16 outputs leave in 16-byte stores: the packed halves of two neighbouring fragments are exchanged between lane rows
+  // (v_permlane16_swap: odd rows of the first with even rows of the second), after which a lane owns EIGHT consecutive columns of
+  // fragment 2*jp + (fg & 1), starting at column (fg >> 1) * 8.
+  const int nbase = n0 + wn * WTN;
+  float4 bias4[FN];
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      const int n = nbase + j * 16 + fg * 4;
+      bias4[j] = n < p.N ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FM; i++) {
+    const int m = m0 + wm * WTM + i * 16 + frow;
+    if (m >= p.M) continue;   // (both lanes of an exchanging pair share frow, hence m)
+    const bf16_t* rrow = nullptr;
+    if constexpr (RES) rrow = p.res + (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : m) * p.ldr;
+    bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc;
+#pragma unroll
+    for (int jp = 0; jp < FN / 2; jp++) {
+      unsigned pk[2][2];
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++) {
+        const int j = 2 * jp + hh;
+        const int n = nbase + j * 16 + fg * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][e] * p.alpha;
+        if constexpr (BIAS) {
+          v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w;
+        }
+        if constexpr (ACT == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+        } else if constexpr (ACT == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (RES) {
+          if (n < p.N) {
+            const u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(rrow + n);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += bf2f(r4[e]);
+          }
+        }
+        pk[hh][0] = pack2bf(v[0], v[1]);
+        pk[hh][1] = pack2bf(v[2], v[3]);
+      }
+      swap_rows16(pk[0][0], pk[1][0]);
+      swap_rows16(pk[0][1], pk[1][1]);
+      const int nn = nbase + (2 * jp + (fg & 1)) * 16 + (fg >> 1) * 8;
+      if (nn + 8 <= p.N) {
+        *reinterpret_cast<uint4*>(crow + nn) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+      } else if (nn < p.N) {   // N % 4 == 0 is enforced by the launcher
+        uint2 o2;
+        o2.x = pk[0][0];
+        o2.y = pk[0][1];
+        *reinterpret_cast<uint2*>(crow + nn) = o2;
+      }
+    }
+  }
+}
+
+template <int FM, int FN, int WTM, int WTN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc)[FM][FN], int m0, int n0, int wm,
+                                              int wn, int frow, int fg) {
+  if (p.out_f32 || p.accumulate || p.act == 3) {
+    gemm_epilogue_generic<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, frow, fg);
+    return;
+  }
+  const int key = (p.bias ? 1 : 0) | (p.res ? 2 : 0) | (p.act << 2);   // wave uniform
+#define SLAM_EPI(B_, A_, R_) gemm_epilogue_bf16<FM, FN, WTM, WTN, B_, A_, R_>(p, acc, m0, n0, wm, wn, frow, fg)
+  switch (key) {
+    case 0: SLAM_EPI(false, 0, false); break;
+    case 1: SLAM_EPI(true, 0, false); break;
+    case 2: SLAM_EPI(false, 0, true); break;
+    case 3: SLAM_EPI(true, 0, true); break;
+    case 4: SLAM_EPI(false, 1, false); break;
+    case 5: SLAM_EPI(true, 1, false); break;
+    case 6: SLAM_EPI(false, 1, true); break;
+    case 7: SLAM_EPI(true, 1, true); break;
+    case 8: SLAM_EPI(false, 2, false); break;
+    case 9: SLAM_EPI(true, 2, false); break;
+    case 10: SLAM_EPI(false, 2, true); break;
+    default: SLAM_EPI(true, 2, true); break;
+  }
+#undef SLAM_EPI
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -366,6 +503,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
   load_frags(smem, 0, a0, b0);
   if constexpr (NOFRAG) load_frags(smem, 1, a1, b1);
 
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[4] = __builtin_readcyclecounter();
   for (int t = 0; t < nt; t++) {
     const int cur = t & 1;
     const char* st = smem + cur * STAGE;
@@ -417,6 +555,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
     g_clk_probe[3] = wall_clock64();
   }
   gemm_epilogue<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, frow, fg);
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[5] = __builtin_readcyclecounter();
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -573,6 +712,238 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_persist2_kernel(GemmParam
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// 4-wave variant with a HAND-ORDERED k-loop (cfg 12).  256x256x64 tiles like the pipelined kernel, but 2 x 2 waves of 128x128
+// (one wave per SIMD, 64 accumulators = 256 AGPRs): a wave tile twice as large halves the LDS bytes read per MFMA (128 KB
+// instead of 192 KB per workgroup and K-tile).  With one wave per SIMD nothing hides a stall, so the instruction ORDER is the
+// kernel: every MFMA, ds_read, LDS-DMA and wait of the loop is an `asm volatile` statement (the compiler only allocates
+// registers; it cannot re-serialise the stream, which is what sank the compiler-scheduled attempt of round 1, -30 %):
+//   phase A(t): 64 MFMA on the ks=0 fragments, one ds_read_b128 of a ks=1 fragment after every 4th
+//   s_waitcnt vmcnt(0); s_barrier           tile t+1 has landed, stage t&1 is free
+//   phase B(t): 64 MFMA on the ks=1 fragments, one LDS-DMA piece of tile t+2 after every 4th, one ds_read of a ks=0 fragment of
+//               tile t+1 after every 4th (offset by two)
+// Two K-tiles per loop trip so that the LDS stage is a compile-time constant of each half.
+// ------------------------------------------------------------------------------------------------------------
+template <int I, int N, class F>
+__device__ __forceinline__ void gemm_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    gemm_static_for<I + 1, N>(f);
+  }
+}
+__device__ __forceinline__ void w4_mfma(f32x4_t& c, const bf16x8_t& a, const bf16x8_t& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <int OFF>
+__device__ __forceinline__ void w4_lds_read(bf16x8_t& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void w4_dma(__amdgpu_buffer_rsrc_t srd, unsigned voff, unsigned soff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(srd), "s"(soff), "s"(lds_dst)
+               : "memory");
+}
+
+__device__ __forceinline__ void w4_gload(bf16x8_t& dst, __amdgpu_buffer_rsrc_t srd, unsigned voff, unsigned soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void w4_lds_write(unsigned addr, const bf16x8_t& v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void w4_vmwait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// REG = false: operand tiles by LDS-DMA (one instruction per KiB, but 60-180 issue cycles each, which a lone wave per SIMD
+// cannot hide).  REG = true: global -> registers (buffer_load_dwordx4, issued in phase A of tile t for tile t+2) -> ds_write_b128
+// in phase B, after the barrier that releases the stage: two cheap instructions per KiB and 64 staging VGPRs.
+template <int BM, int BN, bool REG, int ABL = 0>   // ABL (tools, wrong results): 1 no operand traffic in the loop, 2 no fragment reads, 3 neither
+__global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned bytes_a, unsigned bytes_b) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_clk_probe[0] = __builtin_readcyclecounter();
+    g_clk_probe[1] = wall_clock64();
+  }
+  constexpr int WTM = BM / 2, WTN = BN / 2;          // 128 x 128 per wave
+  constexpr int FM = WTM / 16, FN = WTN / 16;        // 8 x 8 fragments
+  constexpr int STAGE = (BM + BN) * ROWB;            // 64 KiB
+  constexpr int NIA = BM / 8 / 4, NIB = BN / 8 / 4;  // 1 KiB DMA pieces per wave and K-tile: 8 + 8
+  static_assert(BK == 64 && FM == 8 && FN == 8 && NIA == 8 && NIB == 8, "schedule below is written for 256x256x64, 4 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    bid = base + (bid >> 3);
+  }
+  const int GM = p.group_m;
+  const int per_group = GM * p.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GM;
+  const int gsz = min(GM, p.tiles_m - first_m);
+  const int within = bid - group * per_group;
+  const int tm = first_m + within % gsz;
+  const int tn = within / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // DMA: piece j of this wave covers tile rows (j*4 + wave)*8 .. +7; lane -> (row = lane>>3, 16-byte chunk (lane&7) ^ row)
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ srow;
+  const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, bytes_a, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, bytes_b, 0x00020000);
+  unsigned a_vo[NIA], b_vo[NIB];
+#pragma unroll
+  for (int j = 0; j < NIA; j++) a_vo[j] = (unsigned)(((int64_t)min(m0 + (j * 4 + wave) * 8 + srow, p.M - 1) * p.lda + schunk * 8) * 2);
+#pragma unroll
+  for (int j = 0; j < NIB; j++) b_vo[j] = (unsigned)(((int64_t)min(n0 + (j * 4 + wave) * 8 + srow, p.N - 1) * p.ldb + schunk * 8) * 2);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+  const unsigned dma_a = lds0 + (unsigned)(wave * 1024), dma_b = dma_a + (unsigned)(BM * ROWB);
+
+  // fragment reads: row (lane & 15) of fragment i of this wave's panel, chunk (ks*4 + lane>>4) ^ (row & 7)
+  const int frow = lane & 15, fg = lane >> 4;
+  unsigned fa[2][2], fb[2][2];   // per-lane byte address [stage][ks] (the ds_read immediate only reaches 64 KiB: one stage)
+#pragma unroll
+  for (int st = 0; st < 2; st++)
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const unsigned ch = (unsigned)(((ks * 4 + fg) ^ (frow & 7)) << 4);
+      fa[st][ks] = lds0 + (unsigned)(st * STAGE + (wm * WTM + frow) * ROWB) + ch;
+      fb[st][ks] = lds0 + (unsigned)(st * STAGE + BM * ROWB + (wn * WTN + frow) * ROWB) + ch;
+    }
+
+  // four 4x4 quadrants: hipcc leaves ONE 8x8 array of f32x4 (1 KiB) in scratch
+  f32x4_t acc00[4][4], acc01[4][4], acc10[4][4], acc11[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc00[i][j] = acc01[i][j] = acc10[i][j] = acc11[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  auto mfma_ij = [&](auto i, auto j, const bf16x8_t& bfrag, const bf16x8_t& afrag) {
+    if constexpr (i < 4 && j < 4) w4_mfma(acc00[i][j], bfrag, afrag);
+    else if constexpr (i < 4) w4_mfma(acc01[i][j - 4], bfrag, afrag);
+    else if constexpr (j < 4) w4_mfma(acc10[i - 4][j], bfrag, afrag);
+    else w4_mfma(acc11[i - 4][j - 4], bfrag, afrag);
+  };
+  bf16x8_t a0[FM], b0[FN], a1[FM], b1[FN];
+  const int nt = p.K / BK;
+
+  auto dma_tile = [&](int kt, int stage) {   // whole tile, back to back (prologue only)
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(kt * BK * 2));
+    gemm_static_for<0, NIA>([&](auto j) { w4_dma(srd_a, a_vo[j], so, __builtin_amdgcn_readfirstlane(dma_a + (unsigned)(stage * STAGE + j * 4096))); });
+    gemm_static_for<0, NIB>([&](auto j) { w4_dma(srd_b, b_vo[j], so, __builtin_amdgcn_readfirstlane(dma_b + (unsigned)(stage * STAGE + j * 4096))); });
+  };
+  bf16x8_t stg[NIA + NIB];   // REG: one K-tile share of this wave in flight from global memory
+  const unsigned wr0 = lds0 + (unsigned)(wave * 1024 + lane * 16);   // REG: lane-linear image of a 1 KiB piece, like the DMA's
+  dma_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (nt > 1) dma_tile(1, 1);
+  gemm_static_for<0, FN>([&](auto j) { w4_lds_read<j * 16 * ROWB>(b0[j], fb[0][0]); });
+  gemm_static_for<0, FM>([&](auto i) { w4_lds_read<i * 16 * ROWB>(a0[i], fa[0][0]); });
+  if constexpr (REG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the loop's counted vmcnt waits assume only ITS loads are in flight)
+
+  // one K-tile; CUR = its LDS stage (compile time).  MFMA order: i outer, j inner -> a fragment is needed every 8th MFMA, all
+  // b fragments by the first eight: reads are issued b first.
+  auto tile = [&](int t, auto cur_c) {
+    constexpr int CUR = decltype(cur_c)::value;
+    constexpr unsigned SO = CUR * STAGE;
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(min(t + 2, nt - 1) * BK * 2));
+    // ---- phase A ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    gemm_static_for<0, FM>([&](auto i) {
+      gemm_static_for<0, FN>([&](auto j) {
+        mfma_ij(i, j, b0[j], a0[i]);
+        constexpr int n = i * FN + j;          // after MFMA n: every 4th slot a ks=1 fragment read (b first, then a)
+        if constexpr (n % 2 == 0 && n < 32 && !(ABL & 2)) {  // the 16 ks=1 fragment reads ride on the FIRST half: all landed by the phase's end
+          constexpr int r = n / 2;             // 0..15
+          if constexpr (r < FN) w4_lds_read<r * 16 * ROWB>(b1[r], fb[CUR][1]);
+          else w4_lds_read<(r - FN) * 16 * ROWB>(a1[r - FN], fa[CUR][1]);
+        }
+        if constexpr (REG && n % 4 == 3 && !(ABL & 1)) {     // tile t+2 -> staging registers (past the end: tile nt-1 again)
+          constexpr int r = n / 4;
+          if constexpr (r < NIA) w4_gload(stg[r], srd_a, a_vo[r], so);
+          else w4_gload(stg[r], srd_b, b_vo[r - NIA], so);
+        }
+      });
+    });
+    // DMA form: tile t+1 has landed.  Both forms: this wave's ks=1 fragment reads are done, and (REG) its ds_writes of tile t+1
+    // -- issued in the previous phase B -- are in LDS
+    if constexpr (!REG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- phase B ----
+    gemm_static_for<0, FM>([&](auto i) {
+      gemm_static_for<0, FN>([&](auto j) {
+        mfma_ij(i, j, b1[j], a1[i]);
+        constexpr int n = i * FN + j;
+        if constexpr (n % 4 == 1 && !(ABL & 1)) {            // tile t+2 into the stage just released (past the end: tile nt-1 again)
+          constexpr int r = n / 4;
+          if constexpr (REG) {                 // piece r left global memory one phase ago: wait for it alone, write it
+            w4_vmwait<NIA + NIB - 1 - r>();
+            if constexpr (r < NIA) w4_lds_write<r * 4096>(wr0 + SO, stg[r]);
+            else w4_lds_write<BM * ROWB + (r - NIA) * 4096>(wr0 + SO, stg[r]);
+          } else {
+            if constexpr (r < NIA) w4_dma(srd_a, a_vo[r], so, __builtin_amdgcn_readfirstlane(dma_a + (unsigned)(SO + r * 4096)));
+            else w4_dma(srd_b, b_vo[r - NIA], so, __builtin_amdgcn_readfirstlane(dma_b + (unsigned)(SO + (r - NIA) * 4096)));
+          }
+        }
+        if constexpr (n % 2 == 0 && n < 32 && !(ABL & 2)) {  // ks=0 fragments of tile t+1 (landed: waited for before the barrier), first half
+          constexpr int r = n / 2;
+          if constexpr (r < FN) w4_lds_read<r * 16 * ROWB>(b0[r], fb[CUR ^ 1][0]);
+          else w4_lds_read<(r - FN) * 16 * ROWB>(a0[r - FN], fa[CUR ^ 1][0]);
+        }
+      });
+    });
+  };
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    tile(t, std::integral_constant<int, 0>{});
+    tile(t + 1, std::integral_constant<int, 1>{});
+  }
+  if (t < nt) tile(t, std::integral_constant<int, 0>{});
+  // the compiler does not know the asm statements were MFMAs: cover the MFMA -> accumulator-read hazard and drain the
+  // branch-free tail's DMA / reads (they target this workgroup's LDS) before the epilogue
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_clk_probe[2] = __builtin_readcyclecounter();
+    g_clk_probe[3] = wall_clock64();
+  }
+  gemm_epilogue<4, 4, WTM, WTN>(p, acc00, m0, n0, wm, wn, frow, fg);
+  gemm_epilogue<4, 4, WTM, WTN>(p, acc01, m0, n0 + 64, wm, wn, frow, fg);
+  gemm_epilogue<4, 4, WTM, WTN>(p, acc10, m0 + 64, n0, wm, wn, frow, fg);
+  gemm_epilogue<4, 4, WTM, WTN>(p, acc11, m0 + 64, n0 + 64, wm, wn, frow, fg);
+}
+
+template <int BM, int BN, bool REG, int ABL = 0>
+int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  constexpr int lds = 2 * (BM + BN) * ROWB;
+  static bool attr_set = false;
+  auto kern = gemm_nt_w4_kernel<BM, BN, REG, ABL>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      slam_set_error("gemm: cannot raise LDS limit to %d: %s", lds, hipGetErrorString(e));
+      return -2;
+    }
+    attr_set = true;
+  }
+  const uint64_t bytes_a = ((uint64_t)(p.M - 1) * (uint64_t)p.lda + (uint64_t)p.K) * 2ull;
+  const uint64_t bytes_b = ((uint64_t)(p.N - 1) * (uint64_t)p.ldb + (uint64_t)p.K) * 2ull;
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p, (unsigned)bytes_a, (unsigned)bytes_b);
+  SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(4-wave, hand-ordered k-loop)");
+  return 0;
+}
+
 template <int BM, int BN, int WM, int WN, int PIPE = -1>
 int launch_gemm(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -644,9 +1015,9 @@ extern "C" int slam_gemm_set_group_m(int group_m) {   // tuning knob (tools): ra
   return 0;
 }
 
-extern "C" int slam_gemm_debug_clock(unsigned long long* out4) {   // tools: stamps of the last pipelined-kernel launch (sync first)
-  SLAM_CHECK_ARG(out4 != nullptr, "slam_gemm_debug_clock: null output");
-  hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_clk_probe), 4 * sizeof(unsigned long long));
+extern "C" int slam_gemm_debug_clock(unsigned long long* out6) {   // tools: stamps of the last pipelined-kernel launch (sync first)
+  SLAM_CHECK_ARG(out6 != nullptr, "slam_gemm_debug_clock: null output");
+  hipError_t e = hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_clk_probe), 6 * sizeof(unsigned long long));
   if (e != hipSuccess) {
     slam_set_error("slam_gemm_debug_clock: %s", hipGetErrorString(e));
     return -2;
@@ -655,7 +1026,7 @@ extern "C" int slam_gemm_debug_clock(unsigned long long* out4) {   // tools: sta
 }
 
 extern "C" int slam_gemm_set_config(int cfg) {
-  SLAM_CHECK_ARG(cfg >= 0 && cfg <= 11, "slam_gemm_set_config: cfg %d out of range [0,11]", cfg);
+  SLAM_CHECK_ARG(cfg >= 0 && cfg <= 16, "slam_gemm_set_config: cfg %d out of range [0,16]", cfg);
   g_gemm_cfg = cfg;
   return 0;
 }
@@ -727,6 +1098,17 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     case 9: return launch_gemm<256, 256, 2, 4, 30>(p, s);   // no fragment reads in the k-loop
     case 10: return launch_gemm<256, 256, 2, 4, 40>(p, s);  // neither (MFMA + barrier only)
     case 11: return launch_gemm<256, 256, 2, 4, 50>(p, s);  // DMA issued but never waited for
+    case 12:                                                // 4 waves, hand-ordered k-loop
+      if (p.K < 2 * BK || (uint64_t)p.M * (uint64_t)p.lda * 2ull >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldb * 2ull >= (1ull << 32))
+        return launch_gemm<256, 256, 2, 4, 1>(p, s);
+      return launch_gemm_w4<256, 256, false>(p, s);
+    case 13:                                                // 4 waves, hand-ordered k-loop, register-staged operand tiles
+      if (p.K < 2 * BK || (uint64_t)p.M * (uint64_t)p.lda * 2ull >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldb * 2ull >= (1ull << 32))
+        return launch_gemm<256, 256, 2, 4, 1>(p, s);
+      return launch_gemm_w4<256, 256, true>(p, s);
+    case 14: return launch_gemm_w4<256, 256, false, 1>(p, s);   // ablations of cfg 12 (tools)
+    case 15: return launch_gemm_w4<256, 256, false, 2>(p, s);
+    case 16: return launch_gemm_w4<256, 256, false, 3>(p, s);
   }
   slam_set_error("slam_gemm_bf16_nt: bad config %d", cfg);
   return -1;

@@ -121,7 +121,7 @@ _GEMM_CFG = 0
 _GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
                4: "gemm_nt_kernel<256,256,2,4>", 5: "gemm_nt_pipe_kernel<256,256,2,4,0>",
                6: "gemm_nt_pipe_kernel<256,256,2,4,1>", 7: "gemm_nt_persist2_kernel<256,256,2,4>",
-               8: "ablate_nodma", 9: "ablate_nofrag", 10: "ablate_mfma_only", 11: "ablate_nowait"}
+               8: "ablate_nodma", 9: "ablate_nofrag", 10: "ablate_mfma_only", 11: "ablate_nowait", 12: "gemm_nt_w4_kernel<256,256,dma>", 13: "gemm_nt_w4_kernel<256,256,reg>", 14: "w4_ablate_nodma", 15: "w4_ablate_nofrag", 16: "w4_ablate_mfma_only"}
 
 
 def gemm_kernel_name(M: int, N: int, K: int = 1 << 30) -> str:
