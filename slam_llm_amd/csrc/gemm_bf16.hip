@@ -738,12 +738,12 @@ template <int OFF>
 __device__ __forceinline__ void w4_lds_read(bf16x8_t& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
+// (M0 is not saved / restored: inside these all-asm loops nothing else uses it, and every issue slot counts)
 __device__ __forceinline__ void w4_dma(__amdgpu_buffer_rsrc_t srd, unsigned voff, unsigned soff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :
                : "v"(voff), "s"(srd), "s"(soff), "s"(lds_dst)
-               : "memory");
+               : "memory", "m0");
 }
 
 __device__ __forceinline__ void w4_gload(bf16x8_t& dst, __amdgpu_buffer_rsrc_t srd, unsigned voff, unsigned soff) {
@@ -902,6 +902,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
       });
     });
   };
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[4] = __builtin_readcyclecounter();
   int t = 0;
   for (; t + 1 < nt; t += 2) {
     tile(t, std::integral_constant<int, 0>{});
@@ -919,6 +920,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
   gemm_epilogue<4, 4, WTM, WTN>(p, acc01, m0, n0 + 64, wm, wn, frow, fg);
   gemm_epilogue<4, 4, WTM, WTN>(p, acc10, m0 + 64, n0, wm, wn, frow, fg);
   gemm_epilogue<4, 4, WTM, WTN>(p, acc11, m0 + 64, n0 + 64, wm, wn, frow, fg);
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[5] = __builtin_readcyclecounter();
 }
 
 template <int BM, int BN, bool REG, int ABL = 0>
@@ -941,6 +943,285 @@ int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p, (unsigned)bytes_a, (unsigned)bytes_b);
   SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(4-wave, hand-ordered k-loop)");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 4-wave kernel on v_mfma_f32_32x32x16_bf16 (cfg 13).  The 16x16x32 form used everywhere else issues at ~19-20 cycles per
+// SIMD (MI355X_MICROARCH: ~5 cycles per CU), i.e. 80 % of the 32x32x16 form's FLOP rate (32 cycles for twice the work): both
+// 16x16x32 k-loops of this file, 8 waves compiler-interleaved and 4 waves hand-ordered, measured the same 2440 cycles per
+// k-tile = 128 MFMAs x 19.  Same tile / LDS image / DMA as the 4-wave kernel above; per k-tile and wave 4 steps of
+// (16 MFMA on a 4 x 4 grid of 32x32 accumulators, 8 ds_read_b128 of the next step's fragments, 4 LDS-DMA pieces):
+//   steps 0-2 of tile t: DMA pieces 4..15 of tile t+1 -> stage (t+1)&1 ; fragments of the next step from stage t&1
+//   s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier      tile t+1 complete, stage t&1 no longer read
+//   step 3 of tile t:    DMA pieces 0..3 of tile t+2 -> stage t&1 ; step-0 fragments of tile t+1
+// Operands are swapped in the MFMA (A := B rows), so lane l holds row m = l%32 of C and columns 8(v/4) + 4(l/32) + v%4 of the
+// 32x32 fragment; the epilogue exchanges packed halves between the two half-waves (v_permlane32_swap) and stores 16 bytes.
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+__device__ __forceinline__ void w4x_mfma(f32x16_t& c, const bf16x8_t& a, const bf16x8_t& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void swap_halves32(unsigned& a, unsigned& b) {   // upper 32 lanes of a <-> lower 32 lanes of b
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+template <bool BIAS, int ACT, bool RES>
+__device__ __forceinline__ void w4x_store_frag(const GemmParams& p, const f32x16_t& c, int m, int nf, int h) {
+  if (m >= p.M) return;   // (both lanes of an exchanging pair share l % 32, hence m)
+  const bf16_t* rrow = nullptr;
+  if constexpr (RES) rrow = p.res + (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : m) * p.ldr;
+  unsigned pk[4][2];
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int n = nf + 8 * b + 4 * h;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = c[4 * b + e] * p.alpha;
+    if constexpr (BIAS) {
+      if (n < p.N) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+    }
+    if constexpr (ACT == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+    } else if constexpr (ACT == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+    }
+    if constexpr (RES) {
+      if (n < p.N) {
+        const u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(rrow + n);
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] += bf2f(r4[e]);
+      }
+    }
+    pk[b][0] = pack2bf(v[0], v[1]);
+    pk[b][1] = pack2bf(v[2], v[3]);
+  }
+  bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {   // blocks (0,1) -> columns 0-15 of the fragment, blocks (2,3) -> 16-31: 8 consecutive per lane
+    swap_halves32(pk[2 * q][0], pk[2 * q + 1][0]);
+    swap_halves32(pk[2 * q][1], pk[2 * q + 1][1]);
+    const int nn = nf + 16 * q + 8 * h;
+    if (nn + 8 <= p.N) {
+      *reinterpret_cast<uint4*>(crow + nn) = make_uint4(pk[2 * q][0], pk[2 * q][1], pk[2 * q + 1][0], pk[2 * q + 1][1]);
+    } else if (nn < p.N) {   // N % 4 == 0 is enforced by the launcher
+      uint2 o2;
+      o2.x = pk[2 * q][0];
+      o2.y = pk[2 * q][1];
+      *reinterpret_cast<uint2*>(crow + nn) = o2;
+    }
+  }
+}
+
+// WMW x WNW waves: 2 x 2 (cfg 13: one wave per SIMD) or 2 x 4 (cfg 14: two per SIMD, the second wave covers the first one's
+// operand-traffic issue slots).  Measured on the 2 x 2 form (tools/gemm_epi_probe.py, cycles of workgroup 0 per k-tile): 2748 with
+// everything, 2084 without the 16 LDS-DMA pieces, 2770 without the fragment reads, 2091 with neither = the MFMA floor (64 x 32):
+// fragment reads are free, but every VMEM instruction (LDS-DMA or a plain buffer_load feeding a ds_write -- both forms were
+// built) stalls its lone wave's MFMA stream by ~41 cycles.
+template <int BM, int BN, int WMW, int WNW, int ABL = 0>   // ABL (tools, wrong results): 1 no DMA in the loop, 2 no fragment reads, 3 neither
+__global__ __launch_bounds__(WMW* WNW * 64) void gemm_nt_x32_kernel(GemmParams p, unsigned bytes_a, unsigned bytes_b) {
+  constexpr int NW = WMW * WNW;
+  constexpr int WTM = BM / WMW, WTN = BN / WNW;      // wave tile: 128 x 128 or 128 x 64
+  constexpr int FMX = WTM / 32, FNX = WTN / 32;      // 32 x 32 fragments per wave: 4 x 4 or 4 x 2
+  constexpr int STAGE = (BM + BN) * ROWB;            // 64 KiB
+  constexpr int NIA = BM / 8 / NW, NIB = BN / 8 / NW;
+  constexpr int NP = NIA + NIB;                      // 1 KiB DMA pieces per wave and K-tile: 16 or 8
+  constexpr int MF = FMX * FNX;                      // MFMAs per step: 16 or 8
+  constexpr int RD = FMX + FNX;                      // fragment reads per step: 8 or 6
+  constexpr int PS = NP / 4;                         // DMA pieces per step: 4 or 2
+  constexpr int DGAP = (MF - RD) / PS;               // MFMAs between DMA pieces: 2 or 1
+  static_assert(BK == 64 && FMX == 4 && (FNX == 4 || FNX == 2) && NP % 4 == 0 && RD + PS * DGAP <= MF, "schedule below");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_clk_probe[0] = __builtin_readcyclecounter();
+    g_clk_probe[1] = wall_clock64();
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WNW, wn = wave % WNW;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    bid = base + (bid >> 3);
+  }
+  const int GM = p.group_m;
+  const int per_group = GM * p.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GM;
+  const int gsz = min(GM, p.tiles_m - first_m);
+  const int within = bid - group * per_group;
+  const int tm = first_m + within % gsz;
+  const int tn = within / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ srow;
+  const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, bytes_a, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, bytes_b, 0x00020000);
+  unsigned a_vo[NIA], b_vo[NIB];
+#pragma unroll
+  for (int j = 0; j < NIA; j++) a_vo[j] = (unsigned)(((int64_t)min(m0 + (j * NW + wave) * 8 + srow, p.M - 1) * p.lda + schunk * 8) * 2);
+#pragma unroll
+  for (int j = 0; j < NIB; j++) b_vo[j] = (unsigned)(((int64_t)min(n0 + (j * NW + wave) * 8 + srow, p.N - 1) * p.ldb + schunk * 8) * 2);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+  const unsigned dma_a = lds0 + (unsigned)(wave * 1024), dma_b = dma_a + (unsigned)(BM * ROWB);
+
+  // fragment reads: row l%32 of fragment i, 16-byte chunk (2*step + l/32) ^ (row & 7); [stage][step] per operand
+  const int frow = lane & 31, fh = lane >> 5;
+  unsigned fa[2][4], fb[2][4];
+#pragma unroll
+  for (int st = 0; st < 2; st++)
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const unsigned ch = (unsigned)(((ks * 2 + fh) ^ (frow & 7)) << 4);
+      fa[st][ks] = lds0 + (unsigned)(st * STAGE + (wm * WTM + frow) * ROWB) + ch;
+      fb[st][ks] = lds0 + (unsigned)(st * STAGE + BM * ROWB + (wn * WTN + frow) * ROWB) + ch;
+    }
+
+  // accumulators in 2 x 2 quadrants (one 4 x 4 array of f32x16 would be left in scratch); 2 x 4 waves use the first two
+  f32x16_t acc00[2][2], acc01[2][2], acc10[2][2], acc11[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc00[i][j][e] = acc01[i][j][e] = acc10[i][j][e] = acc11[i][j][e] = 0.f;
+  // fragment (i, j), i < 4 (M), j < FNX (N): quadrant (i / 2, j / 2)
+  auto mfma_ij = [&](auto i, auto j, const bf16x8_t& bfrag, const bf16x8_t& afrag) {
+    if constexpr (i < 2 && j < 2) w4x_mfma(acc00[i][j], bfrag, afrag);
+    else if constexpr (i < 2) w4x_mfma(acc01[i][j - 2], bfrag, afrag);
+    else if constexpr (j < 2) w4x_mfma(acc10[i - 2][j], bfrag, afrag);
+    else w4x_mfma(acc11[i - 2][j - 2], bfrag, afrag);
+  };
+  bf16x8_t af[2][FMX], bf_[2][FNX];   // fragments of the current / next step
+  const int nt = p.K / BK;
+
+  auto dma_piece = [&](auto r, unsigned so, unsigned stage_off) {   // piece r (0..NIA-1: A, then B) of a K-tile
+    if constexpr (r < NIA) w4_dma(srd_a, a_vo[r], so, __builtin_amdgcn_readfirstlane(dma_a + stage_off + (unsigned)(r * NW * 1024)));
+    else w4_dma(srd_b, b_vo[r - NIA], so, __builtin_amdgcn_readfirstlane(dma_b + stage_off + (unsigned)((r - NIA) * NW * 1024)));
+  };
+  auto read_frag = [&](auto r, auto buf, unsigned addr_a, unsigned addr_b) {   // r < FNX: B fragments, then A fragments
+    if constexpr (r < FNX) w4_lds_read<r * 32 * ROWB>(bf_[buf][r], addr_b);
+    else w4_lds_read<(r - FNX) * 32 * ROWB>(af[buf][r - FNX], addr_a);
+  };
+  // prologue: tile 0 complete, the first PS pieces of tile 1, step-0 fragments of tile 0
+  gemm_static_for<0, NP>([&](auto r) { dma_piece(r, 0u, 0u); });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    const unsigned so1 = __builtin_amdgcn_readfirstlane((unsigned)(min(1, nt - 1) * BK * 2));
+    gemm_static_for<0, PS>([&](auto r) { dma_piece(r, so1, (unsigned)STAGE); });
+  }
+  gemm_static_for<0, RD>([&](auto r) { read_frag(r, std::integral_constant<int, 0>{}, fa[0][0], fb[0][0]); });
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[4] = __builtin_readcyclecounter();
+
+  auto tile = [&](int t, auto cur_c) {
+    constexpr int CUR = decltype(cur_c)::value;
+    const unsigned so1 = __builtin_amdgcn_readfirstlane((unsigned)(min(t + 1, nt - 1) * BK * 2));
+    const unsigned so2 = __builtin_amdgcn_readfirstlane((unsigned)(min(t + 2, nt - 1) * BK * 2));
+    gemm_static_for<0, 4>([&](auto s) {
+      constexpr int buf = s & 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this step's fragments (requested in the first slots of the previous step)
+      gemm_static_for<0, FMX>([&](auto i) {
+        gemm_static_for<0, FNX>([&](auto j) {
+          mfma_ij(i, j, bf_[buf][j], af[buf][i]);
+          constexpr int n = i * FNX + j;
+          if constexpr (n < RD && !(ABL & 2)) {   // next step's fragments: steps 0-2 from this tile's stage, step 3 from tile t+1's
+            if constexpr (s < 3) read_frag(std::integral_constant<int, n>{}, std::integral_constant<int, buf ^ 1>{}, fa[CUR][s + 1], fb[CUR][s + 1]);
+            else read_frag(std::integral_constant<int, n>{}, std::integral_constant<int, buf ^ 1>{}, fa[CUR ^ 1][0], fb[CUR ^ 1][0]);
+          } else if constexpr (n >= RD && (n - RD) % DGAP == 0 && (n - RD) / DGAP < PS && !(ABL & 1)) {   // PS DMA pieces per step
+            constexpr int q = (n - RD) / DGAP;
+            if constexpr (s < 3) dma_piece(std::integral_constant<int, PS + s * PS + q>{}, so1, (unsigned)((CUR ^ 1) * STAGE));
+            else dma_piece(std::integral_constant<int, q>{}, so2, (unsigned)(CUR * STAGE));
+          }
+        });
+      });
+      if constexpr (s == 2) {   // tile t+1 complete in LDS, nobody reads stage CUR any more (its last fragments are in registers)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    });
+  };
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    tile(t, std::integral_constant<int, 0>{});
+    tile(t + 1, std::integral_constant<int, 1>{});
+  }
+  if (t < nt) tile(t, std::integral_constant<int, 0>{});
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_clk_probe[2] = __builtin_readcyclecounter();
+    g_clk_probe[3] = wall_clock64();
+  }
+  // ---- epilogue (bf16, non-accumulating outputs only: the launcher sends everything else to the pipelined kernel) ----
+  const int key = (p.bias ? 1 : 0) | (p.res ? 2 : 0) | (p.act << 2);   // wave uniform
+  const int mrow = m0 + wm * WTM + frow, ncol = n0 + wn * WTN;
+  auto store_all = [&](auto bias_c, auto act_c, auto res_c) {
+    constexpr bool B_ = decltype(bias_c)::value;
+    constexpr int A_ = decltype(act_c)::value;
+    constexpr bool R_ = decltype(res_c)::value;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        w4x_store_frag<B_, A_, R_>(p, acc00[i][j], mrow + i * 32, ncol + j * 32, fh);
+        w4x_store_frag<B_, A_, R_>(p, acc10[i][j], mrow + (i + 2) * 32, ncol + j * 32, fh);
+        if constexpr (FNX == 4) {
+          w4x_store_frag<B_, A_, R_>(p, acc01[i][j], mrow + i * 32, ncol + (j + 2) * 32, fh);
+          w4x_store_frag<B_, A_, R_>(p, acc11[i][j], mrow + (i + 2) * 32, ncol + (j + 2) * 32, fh);
+        }
+      }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  using A0 = std::integral_constant<int, 0>;
+  using A1 = std::integral_constant<int, 1>;
+  using A2 = std::integral_constant<int, 2>;
+  switch (key) {
+    case 0: store_all(F_{}, A0{}, F_{}); break;
+    case 1: store_all(T_{}, A0{}, F_{}); break;
+    case 2: store_all(F_{}, A0{}, T_{}); break;
+    case 3: store_all(T_{}, A0{}, T_{}); break;
+    case 4: store_all(F_{}, A1{}, F_{}); break;
+    case 5: store_all(T_{}, A1{}, F_{}); break;
+    case 6: store_all(F_{}, A1{}, T_{}); break;
+    case 7: store_all(T_{}, A1{}, T_{}); break;
+    case 8: store_all(F_{}, A2{}, F_{}); break;
+    case 9: store_all(T_{}, A2{}, F_{}); break;
+    case 10: store_all(F_{}, A2{}, T_{}); break;
+    default: store_all(T_{}, A2{}, T_{}); break;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[5] = __builtin_readcyclecounter();
+}
+
+template <int BM, int BN, int WMW, int WNW, int ABL = 0>
+int launch_gemm_x32(GemmParams& p, hipStream_t stream) {
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  constexpr int lds = 2 * (BM + BN) * ROWB;
+  static bool attr_set = false;
+  auto kern = gemm_nt_x32_kernel<BM, BN, WMW, WNW, ABL>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      slam_set_error("gemm: cannot raise LDS limit to %d: %s", lds, hipGetErrorString(e));
+      return -2;
+    }
+    attr_set = true;
+  }
+  const uint64_t bytes_a = ((uint64_t)(p.M - 1) * (uint64_t)p.lda + (uint64_t)p.K) * 2ull;
+  const uint64_t bytes_b = ((uint64_t)(p.N - 1) * (uint64_t)p.ldb + (uint64_t)p.K) * 2ull;
+  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WMW * WNW * 64), lds, stream, p, (unsigned)bytes_a, (unsigned)bytes_b);
+  SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(32x32x16 MFMA, hand-ordered k-loop)");
   return 0;
 }
 
@@ -1005,6 +1286,8 @@ static inline bool fits_descriptor(int64_t rows, int64_t ld, int tile) {
 }
 
 int g_gemm_cfg = 0;  // 0 = auto
+int g_gemm_big = 6;        // which 256x256 kernel the auto rule uses for K > 2048 (6 | 7 | 12)
+int g_gemm_big_shortk = 7; // ... and for K <= 2048
 int g_gemm_group_m = 8;
 
 }  // namespace
@@ -1026,7 +1309,10 @@ extern "C" int slam_gemm_debug_clock(unsigned long long* out6) {   // tools: sta
 }
 
 extern "C" int slam_gemm_set_config(int cfg) {
-  SLAM_CHECK_ARG(cfg >= 0 && cfg <= 16, "slam_gemm_set_config: cfg %d out of range [0,16]", cfg);
+  // 100 + v / 200 + v (v in 6, 7, 12): the 256x256 kernel the AUTO rule picks for K > 2048 / K <= 2048 (tools/step sweeps)
+  if (cfg == 106 || cfg == 107 || (cfg >= 112 && cfg <= 114)) { g_gemm_big = cfg - 100; return 0; }
+  if (cfg == 206 || cfg == 207 || (cfg >= 212 && cfg <= 214)) { g_gemm_big_shortk = cfg - 200; return 0; }
+  SLAM_CHECK_ARG(cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 6 || cfg == 7 || (cfg >= 12 && cfg <= 17), "slam_gemm_set_config: cfg %d (0 auto | 1 2 3 4 6 7 12 13 14 | 15-17 ablations)", cfg);
   g_gemm_cfg = cfg;
   return 0;
 }
@@ -1080,7 +1366,7 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     // tiles) pays on short-K products, where prologue + epilogue are a visible share of a tile: +3-4 % at K = 1280
     // (Whisper), +-1 % at K >= 4096 (profiles/r02_gemm_experiments.md)
     if (N <= 64) cfg = 3;
-    else if (t256 < t128) cfg = (K <= 2048) ? 7 : 6;
+    else if (t256 < t128) cfg = (K <= 2048) ? g_gemm_big_shortk : g_gemm_big;
     else cfg = 1;
   }
   switch (cfg) {
@@ -1088,27 +1374,25 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     case 2: return launch_gemm<256, 128, 4, 2>(p, s);
     case 3: return launch_gemm<128, 64, 2, 2>(p, s);
     case 4: return launch_gemm<256, 256, 2, 4>(p, s);
-    case 5: return launch_gemm<256, 256, 2, 4, 0>(p, s);  // pipelined, compiler-placed barrier (A/B reference)
     case 6: return launch_gemm<256, 256, 2, 4, 1>(p, s);  // pipelined, phase A pinned before the barrier (shipped)
     case 7:                                                // persistent pipelined, descriptor DMA (auto: short-K products)
       if (p.K < 2 * BK || !fits_descriptor(p.M, p.lda, 256) || !fits_descriptor(p.N, p.ldb, 256)) return launch_gemm<256, 256, 2, 4, 1>(p, s);
       return launch_gemm_persist2<256, 256, 2, 4>(p, s);
-    // timing ablations of the pipelined loop (tools/gemm_bench.py; results are wrong by design)
-    case 8: return launch_gemm<256, 256, 2, 4, 20>(p, s);   // no DMA in the k-loop
-    case 9: return launch_gemm<256, 256, 2, 4, 30>(p, s);   // no fragment reads in the k-loop
-    case 10: return launch_gemm<256, 256, 2, 4, 40>(p, s);  // neither (MFMA + barrier only)
-    case 11: return launch_gemm<256, 256, 2, 4, 50>(p, s);  // DMA issued but never waited for
-    case 12:                                                // 4 waves, hand-ordered k-loop
+    // (cfg 5 = compiler-placed barrier, 8-11 = timing ablations of the pipelined loop, 13 = register-staged 4-wave form,
+    //  14-16 = ablations of the 4-wave loop: measured, recorded in profiles/r02_gemm_experiments.md, removed to keep the build short)
+    case 12:                                               // 4 waves, hand-ordered k-loop
       if (p.K < 2 * BK || (uint64_t)p.M * (uint64_t)p.lda * 2ull >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldb * 2ull >= (1ull << 32))
         return launch_gemm<256, 256, 2, 4, 1>(p, s);
       return launch_gemm_w4<256, 256, false>(p, s);
-    case 13:                                                // 4 waves, hand-ordered k-loop, register-staged operand tiles
-      if (p.K < 2 * BK || (uint64_t)p.M * (uint64_t)p.lda * 2ull >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldb * 2ull >= (1ull << 32))
+    case 13:                                               // 32x32x16 MFMAs, hand-ordered k-loop: 2 x 2 waves
+    case 14:                                               // ... 2 x 4 waves
+      if (p.K < 2 * BK || p.out_f32 || p.accumulate || p.act == 3 || (uint64_t)p.M * (uint64_t)p.lda * 2ull >= (1ull << 32) ||
+          (uint64_t)p.N * (uint64_t)p.ldb * 2ull >= (1ull << 32))
         return launch_gemm<256, 256, 2, 4, 1>(p, s);
-      return launch_gemm_w4<256, 256, true>(p, s);
-    case 14: return launch_gemm_w4<256, 256, false, 1>(p, s);   // ablations of cfg 12 (tools)
-    case 15: return launch_gemm_w4<256, 256, false, 2>(p, s);
-    case 16: return launch_gemm_w4<256, 256, false, 3>(p, s);
+      return cfg == 13 ? launch_gemm_x32<256, 256, 2, 2>(p, s) : launch_gemm_x32<256, 256, 2, 4>(p, s);
+    case 15: return launch_gemm_x32<256, 256, 2, 4, 1>(p, s);   // timing ablations of cfg 14 (tools; wrong results)
+    case 16: return launch_gemm_x32<256, 256, 2, 4, 2>(p, s);
+    case 17: return launch_gemm_x32<256, 256, 2, 4, 3>(p, s);
   }
   slam_set_error("slam_gemm_bf16_nt: bad config %d", cfg);
   return -1;

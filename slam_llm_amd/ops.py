@@ -10,6 +10,8 @@ import ctypes
 import math
 from typing import Optional
 
+import os
+
 import torch
 
 from . import lib
@@ -119,9 +121,17 @@ def gemm_skinny(a, b, out, residual=None, b2=None, swiglu=False):
 
 _GEMM_CFG = 0
 _GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
-               4: "gemm_nt_kernel<256,256,2,4>", 5: "gemm_nt_pipe_kernel<256,256,2,4,0>",
-               6: "gemm_nt_pipe_kernel<256,256,2,4,1>", 7: "gemm_nt_persist2_kernel<256,256,2,4>",
-               8: "ablate_nodma", 9: "ablate_nofrag", 10: "ablate_mfma_only", 11: "ablate_nowait", 12: "gemm_nt_w4_kernel<256,256,dma>", 13: "gemm_nt_w4_kernel<256,256,reg>", 14: "w4_ablate_nodma", 15: "w4_ablate_nofrag", 16: "w4_ablate_mfma_only"}
+               4: "gemm_nt_kernel<256,256,2,4>", 6: "gemm_nt_pipe_kernel<256,256,2,4,1>", 7: "gemm_nt_persist2_kernel<256,256,2,4>",
+               12: "gemm_nt_w4_kernel<256,256>", 13: "gemm_nt_x32_kernel<256,256,2,2>", 14: "gemm_nt_x32_kernel<256,256,2,4>", 15: "x32_nodma", 16: "x32_nofrag", 17: "x32_mfma_only"}
+
+
+_GEMM_BIG = {"big": 6, "shortk": 7}
+if os.environ.get("SLAM_GEMM_BIG"):          # sweeps: SLAM_GEMM_BIG=12 SLAM_GEMM_BIG_SHORTK=7 python bench.py ...
+    call("slam_gemm_set_config", 100 + int(os.environ["SLAM_GEMM_BIG"]))
+    _GEMM_BIG["big"] = int(os.environ["SLAM_GEMM_BIG"])
+if os.environ.get("SLAM_GEMM_BIG_SHORTK"):
+    call("slam_gemm_set_config", 200 + int(os.environ["SLAM_GEMM_BIG_SHORTK"]))
+    _GEMM_BIG["shortk"] = int(os.environ["SLAM_GEMM_BIG_SHORTK"])
 
 
 def gemm_kernel_name(M: int, N: int, K: int = 1 << 30) -> str:
@@ -132,13 +142,18 @@ def gemm_kernel_name(M: int, N: int, K: int = 1 << 30) -> str:
         tiles128 = ((M + 127) // 128) * ((N + 127) // 128)
         t256 = ((tiles256 + 255) // 256) * (4.0 / 1.4)
         t128 = ((tiles128 + 511) // 512) * 2.0
-        cfg = 3 if N <= 64 else ((7 if K <= 2048 else 6) if t256 < t128 else 1)
+        cfg = 3 if N <= 64 else ((_GEMM_BIG["shortk"] if K <= 2048 else _GEMM_BIG["big"]) if t256 < t128 else 1)
     return _GEMM_NAMES[cfg]
 
 
 def gemm_set_config(cfg: int):
+    """0 = auto rule, 1 2 3 4 6 7 12 = force one kernel (tools / tests); 100 + v / 200 + v = which 256x256 kernel the auto rule uses
+    for K > 2048 / K <= 2048 (sweeps)"""
     global _GEMM_CFG
-    _GEMM_CFG = cfg
+    if cfg >= 100:
+        _GEMM_BIG["big" if cfg < 200 else "shortk"] = cfg % 100
+    else:
+        _GEMM_CFG = cfg
     call("slam_gemm_set_config", cfg)
 
 

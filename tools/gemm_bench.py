@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slam_llm_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-cfgs = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "4,5".split(","))]
+cfgs = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "6,7,12".split(","))]
 shapes = [(11780, 4096, 4096), (11780, 28672, 4096), (11780, 4096, 14336), (11780, 6144, 4160), (46500, 5120, 1280),
           (46500, 1280, 5120), (4096, 128256, 4096), (8192, 8192, 8192)]
 res = []
@@ -26,7 +26,7 @@ for (M, N, K) in shapes:
     for cfg in cfgs:
         ops.gemm_set_config(cfg)
         ops.gemm_nt(a, b, out=c)
-        if ref is not None and cfg not in (8, 9, 10, 11, 14, 15, 16):
+        if ref is not None:
             err = (c.float() - ref).abs().max().item() / ref.abs().max().item()
             assert err < 2e-2, f"cfg {cfg} wrong result: rel err {err}"
     for rnd in range(4):
