@@ -188,36 +188,44 @@ __device__ __forceinline__ void gemm_epilogue_generic(const GemmParams& p, f32x4
 // K = 1280 one.  Now one wave-uniform switch picks a specialised straight-line loop (bias x activation x residual known at
 // compile time; bf16 output in 16-byte stores); the everything-else form is kept out of line for fp32 / accumulating /
 // SwiGLU-backward products.
-template <int FM, int FN, int WTM, int WTN, bool BIAS, int ACT, bool RES>
+template <int FM, int FN, int WTM, int WTN, bool BIAS, int ACT, bool RES, bool INNER>
 __device__ __forceinline__ void gemm_epilogue_bf16(const GemmParams& p, f32x4_t (&acc)[FM][FN], int m0, int n0, int wm, int wn,
                                                    int frow, int fg) {
   static_assert(FN % 2 == 0, "fragments are stored in pairs");
   // bf16 outputs leave in 16-byte stores: the packed halves of two neighbouring fragments are exchanged between lane rows
   // (v_permlane16_swap: odd rows of the first with even rows of the second), after which a lane owns EIGHT consecutive columns of
   // fragment 2*jp + (fg & 1), starting at column (fg >> 1) * 8.
+  // INNER: the workgroup's whole tile lies inside [0, M) x [0, N) -- no per-lane guards (all but the last tile row / column).
+  // A row's residual values are requested together, ahead of its arithmetic (one wait per row, not one per fragment).
   const int nbase = n0 + wn * WTN;
   float4 bias4[FN];
   if constexpr (BIAS) {
 #pragma unroll
     for (int j = 0; j < FN; j++) {
       const int n = nbase + j * 16 + fg * 4;
-      bias4[j] = n < p.N ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bias4[j] = (INNER || n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 #pragma unroll
   for (int i = 0; i < FM; i++) {
     const int m = m0 + wm * WTM + i * 16 + frow;
-    if (m >= p.M) continue;   // (both lanes of an exchanging pair share frow, hence m)
-    const bf16_t* rrow = nullptr;
-    if constexpr (RES) rrow = p.res + (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : m) * p.ldr;
-    bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc;
+    if (!INNER && m >= p.M) continue;   // (both lanes of an exchanging pair share frow, hence m)
+    u16x4_t res4[FN];
+    if constexpr (RES) {
+      const bf16_t* rrow = p.res + (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : m) * p.ldr + nbase + fg * 4;
+#pragma unroll
+      for (int j = 0; j < FN; j++) {
+        if (INNER || nbase + j * 16 + fg * 4 < p.N) res4[j] = *reinterpret_cast<const u16x4_t*>(rrow + j * 16);
+        else res4[j] = u16x4_t{0, 0, 0, 0};
+      }
+    }
+    bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nbase + (fg & 1) * 16 + (fg >> 1) * 8;
 #pragma unroll
     for (int jp = 0; jp < FN / 2; jp++) {
       unsigned pk[2][2];
 #pragma unroll
       for (int hh = 0; hh < 2; hh++) {
         const int j = 2 * jp + hh;
-        const int n = nbase + j * 16 + fg * 4;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] = acc[i][j][e] * p.alpha;
@@ -232,25 +240,27 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const GemmParams& p, f32x4_t 
           for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
         }
         if constexpr (RES) {
-          if (n < p.N) {
-            const u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(rrow + n);
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] += bf2f(r4[e]);
-          }
+          for (int e = 0; e < 4; e++) v[e] += bf2f(res4[j][e]);
         }
         pk[hh][0] = pack2bf(v[0], v[1]);
         pk[hh][1] = pack2bf(v[2], v[3]);
       }
       swap_rows16(pk[0][0], pk[1][0]);
       swap_rows16(pk[0][1], pk[1][1]);
-      const int nn = nbase + (2 * jp + (fg & 1)) * 16 + (fg >> 1) * 8;
-      if (nn + 8 <= p.N) {
-        *reinterpret_cast<uint4*>(crow + nn) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
-      } else if (nn < p.N) {   // N % 4 == 0 is enforced by the launcher
-        uint2 o2;
-        o2.x = pk[0][0];
-        o2.y = pk[0][1];
-        *reinterpret_cast<uint2*>(crow + nn) = o2;
+      bf16_t* c = crow + jp * 32;
+      if constexpr (INNER) {
+        *reinterpret_cast<uint4*>(c) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+      } else {
+        const int nn = nbase + (2 * jp + (fg & 1)) * 16 + (fg >> 1) * 8;
+        if (nn + 8 <= p.N) {
+          *reinterpret_cast<uint4*>(c) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+        } else if (nn < p.N) {   // N % 4 == 0 is enforced by the launcher
+          uint2 o2;
+          o2.x = pk[0][0];
+          o2.y = pk[0][1];
+          *reinterpret_cast<uint2*>(c) = o2;
+        }
       }
     }
   }
@@ -264,7 +274,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
     return;
   }
   const int key = (p.bias ? 1 : 0) | (p.res ? 2 : 0) | (p.act << 2);   // wave uniform
-#define SLAM_EPI(B_, A_, R_) gemm_epilogue_bf16<FM, FN, WTM, WTN, B_, A_, R_>(p, acc, m0, n0, wm, wn, frow, fg)
+  // (tile extents: every caller's workgroup tile is WM x WN wave tiles of WTM x WTN; m0 / n0 may carry a quadrant offset, which
+  // only makes this test conservative by less than a tile)
+  const bool inner = (m0 + wm * WTM + WTM <= p.M) && (n0 + wn * WTN + WTN <= p.N);
+#define SLAM_EPI(B_, A_, R_)                                                                                       \
+  do {                                                                                                             \
+    if (inner) gemm_epilogue_bf16<FM, FN, WTM, WTN, B_, A_, R_, true>(p, acc, m0, n0, wm, wn, frow, fg);          \
+    else gemm_epilogue_bf16<FM, FN, WTM, WTN, B_, A_, R_, false>(p, acc, m0, n0, wm, wn, frow, fg);               \
+  } while (0)
   switch (key) {
     case 0: SLAM_EPI(false, 0, false); break;
     case 1: SLAM_EPI(true, 0, false); break;
@@ -946,284 +963,11 @@ int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
   return 0;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// 4-wave kernel on v_mfma_f32_32x32x16_bf16 (cfg 13).  The 16x16x32 form used everywhere else issues at ~19-20 cycles per
-// SIMD (MI355X_MICROARCH: ~5 cycles per CU), i.e. 80 % of the 32x32x16 form's FLOP rate (32 cycles for twice the work): both
-// 16x16x32 k-loops of this file, 8 waves compiler-interleaved and 4 waves hand-ordered, measured the same 2440 cycles per
-// k-tile = 128 MFMAs x 19.  Same tile / LDS image / DMA as the 4-wave kernel above; per k-tile and wave 4 steps of
-// (16 MFMA on a 4 x 4 grid of 32x32 accumulators, 8 ds_read_b128 of the next step's fragments, 4 LDS-DMA pieces):
-//   steps 0-2 of tile t: DMA pieces 4..15 of tile t+1 -> stage (t+1)&1 ; fragments of the next step from stage t&1
-//   s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier      tile t+1 complete, stage t&1 no longer read
-//   step 3 of tile t:    DMA pieces 0..3 of tile t+2 -> stage t&1 ; step-0 fragments of tile t+1
-// Operands are swapped in the MFMA (A := B rows), so lane l holds row m = l%32 of C and columns 8(v/4) + 4(l/32) + v%4 of the
-// 32x32 fragment; the epilogue exchanges packed halves between the two half-waves (v_permlane32_swap) and stores 16 bytes.
-// ------------------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-__device__ __forceinline__ void w4x_mfma(f32x16_t& c, const bf16x8_t& a, const bf16x8_t& b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void swap_halves32(unsigned& a, unsigned& b) {   // upper 32 lanes of a <-> lower 32 lanes of b
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-
-template <bool BIAS, int ACT, bool RES>
-__device__ __forceinline__ void w4x_store_frag(const GemmParams& p, const f32x16_t& c, int m, int nf, int h) {
-  if (m >= p.M) return;   // (both lanes of an exchanging pair share l % 32, hence m)
-  const bf16_t* rrow = nullptr;
-  if constexpr (RES) rrow = p.res + (int64_t)(p.res_mod > 0 ? (m % p.res_mod) : m) * p.ldr;
-  unsigned pk[4][2];
-#pragma unroll
-  for (int b = 0; b < 4; b++) {
-    const int n = nf + 8 * b + 4 * h;
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) v[e] = c[4 * b + e] * p.alpha;
-    if constexpr (BIAS) {
-      if (n < p.N) {
-        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-      }
-    }
-    if constexpr (ACT == 1) {
-#pragma unroll
-      for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
-    } else if constexpr (ACT == 2) {
-#pragma unroll
-      for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
-    }
-    if constexpr (RES) {
-      if (n < p.N) {
-        const u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(rrow + n);
-#pragma unroll
-        for (int e = 0; e < 4; e++) v[e] += bf2f(r4[e]);
-      }
-    }
-    pk[b][0] = pack2bf(v[0], v[1]);
-    pk[b][1] = pack2bf(v[2], v[3]);
-  }
-  bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc;
-#pragma unroll
-  for (int q = 0; q < 2; q++) {   // blocks (0,1) -> columns 0-15 of the fragment, blocks (2,3) -> 16-31: 8 consecutive per lane
-    swap_halves32(pk[2 * q][0], pk[2 * q + 1][0]);
-    swap_halves32(pk[2 * q][1], pk[2 * q + 1][1]);
-    const int nn = nf + 16 * q + 8 * h;
-    if (nn + 8 <= p.N) {
-      *reinterpret_cast<uint4*>(crow + nn) = make_uint4(pk[2 * q][0], pk[2 * q][1], pk[2 * q + 1][0], pk[2 * q + 1][1]);
-    } else if (nn < p.N) {   // N % 4 == 0 is enforced by the launcher
-      uint2 o2;
-      o2.x = pk[2 * q][0];
-      o2.y = pk[2 * q][1];
-      *reinterpret_cast<uint2*>(crow + nn) = o2;
-    }
-  }
-}
-
-// WMW x WNW waves: 2 x 2 (cfg 13: one wave per SIMD) or 2 x 4 (cfg 14: two per SIMD, the second wave covers the first one's
-// operand-traffic issue slots).  Measured on the 2 x 2 form (tools/gemm_epi_probe.py, cycles of workgroup 0 per k-tile): 2748 with
-// everything, 2084 without the 16 LDS-DMA pieces, 2770 without the fragment reads, 2091 with neither = the MFMA floor (64 x 32):
-// fragment reads are free, but every VMEM instruction (LDS-DMA or a plain buffer_load feeding a ds_write -- both forms were
-// built) stalls its lone wave's MFMA stream by ~41 cycles.
-template <int BM, int BN, int WMW, int WNW, int ABL = 0>   // ABL (tools, wrong results): 1 no DMA in the loop, 2 no fragment reads, 3 neither
-__global__ __launch_bounds__(WMW* WNW * 64) void gemm_nt_x32_kernel(GemmParams p, unsigned bytes_a, unsigned bytes_b) {
-  constexpr int NW = WMW * WNW;
-  constexpr int WTM = BM / WMW, WTN = BN / WNW;      // wave tile: 128 x 128 or 128 x 64
-  constexpr int FMX = WTM / 32, FNX = WTN / 32;      // 32 x 32 fragments per wave: 4 x 4 or 4 x 2
-  constexpr int STAGE = (BM + BN) * ROWB;            // 64 KiB
-  constexpr int NIA = BM / 8 / NW, NIB = BN / 8 / NW;
-  constexpr int NP = NIA + NIB;                      // 1 KiB DMA pieces per wave and K-tile: 16 or 8
-  constexpr int MF = FMX * FNX;                      // MFMAs per step: 16 or 8
-  constexpr int RD = FMX + FNX;                      // fragment reads per step: 8 or 6
-  constexpr int PS = NP / 4;                         // DMA pieces per step: 4 or 2
-  constexpr int DGAP = (MF - RD) / PS;               // MFMAs between DMA pieces: 2 or 1
-  static_assert(BK == 64 && FMX == 4 && (FNX == 4 || FNX == 2) && NP % 4 == 0 && RD + PS * DGAP <= MF, "schedule below");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    g_clk_probe[0] = __builtin_readcyclecounter();
-    g_clk_probe[1] = wall_clock64();
-  }
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WNW, wn = wave % WNW;
-
-  const int nwg = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    bid = base + (bid >> 3);
-  }
-  const int GM = p.group_m;
-  const int per_group = GM * p.tiles_n;
-  const int group = bid / per_group;
-  const int first_m = group * GM;
-  const int gsz = min(GM, p.tiles_m - first_m);
-  const int within = bid - group * per_group;
-  const int tm = first_m + within % gsz;
-  const int tn = within / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int srow = lane >> 3;
-  const int schunk = (lane & 7) ^ srow;
-  const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, bytes_a, 0x00020000);
-  const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, bytes_b, 0x00020000);
-  unsigned a_vo[NIA], b_vo[NIB];
-#pragma unroll
-  for (int j = 0; j < NIA; j++) a_vo[j] = (unsigned)(((int64_t)min(m0 + (j * NW + wave) * 8 + srow, p.M - 1) * p.lda + schunk * 8) * 2);
-#pragma unroll
-  for (int j = 0; j < NIB; j++) b_vo[j] = (unsigned)(((int64_t)min(n0 + (j * NW + wave) * 8 + srow, p.N - 1) * p.ldb + schunk * 8) * 2);
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
-  const unsigned dma_a = lds0 + (unsigned)(wave * 1024), dma_b = dma_a + (unsigned)(BM * ROWB);
-
-  // fragment reads: row l%32 of fragment i, 16-byte chunk (2*step + l/32) ^ (row & 7); [stage][step] per operand
-  const int frow = lane & 31, fh = lane >> 5;
-  unsigned fa[2][4], fb[2][4];
-#pragma unroll
-  for (int st = 0; st < 2; st++)
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      const unsigned ch = (unsigned)(((ks * 2 + fh) ^ (frow & 7)) << 4);
-      fa[st][ks] = lds0 + (unsigned)(st * STAGE + (wm * WTM + frow) * ROWB) + ch;
-      fb[st][ks] = lds0 + (unsigned)(st * STAGE + BM * ROWB + (wn * WTN + frow) * ROWB) + ch;
-    }
-
-  // accumulators in 2 x 2 quadrants (one 4 x 4 array of f32x16 would be left in scratch); 2 x 4 waves use the first two
-  f32x16_t acc00[2][2], acc01[2][2], acc10[2][2], acc11[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc00[i][j][e] = acc01[i][j][e] = acc10[i][j][e] = acc11[i][j][e] = 0.f;
-  // fragment (i, j), i < 4 (M), j < FNX (N): quadrant (i / 2, j / 2)
-  auto mfma_ij = [&](auto i, auto j, const bf16x8_t& bfrag, const bf16x8_t& afrag) {
-    if constexpr (i < 2 && j < 2) w4x_mfma(acc00[i][j], bfrag, afrag);
-    else if constexpr (i < 2) w4x_mfma(acc01[i][j - 2], bfrag, afrag);
-    else if constexpr (j < 2) w4x_mfma(acc10[i - 2][j], bfrag, afrag);
-    else w4x_mfma(acc11[i - 2][j - 2], bfrag, afrag);
-  };
-  bf16x8_t af[2][FMX], bf_[2][FNX];   // fragments of the current / next step
-  const int nt = p.K / BK;
-
-  auto dma_piece = [&](auto r, unsigned so, unsigned stage_off) {   // piece r (0..NIA-1: A, then B) of a K-tile
-    if constexpr (r < NIA) w4_dma(srd_a, a_vo[r], so, __builtin_amdgcn_readfirstlane(dma_a + stage_off + (unsigned)(r * NW * 1024)));
-    else w4_dma(srd_b, b_vo[r - NIA], so, __builtin_amdgcn_readfirstlane(dma_b + stage_off + (unsigned)((r - NIA) * NW * 1024)));
-  };
-  auto read_frag = [&](auto r, auto buf, unsigned addr_a, unsigned addr_b) {   // r < FNX: B fragments, then A fragments
-    if constexpr (r < FNX) w4_lds_read<r * 32 * ROWB>(bf_[buf][r], addr_b);
-    else w4_lds_read<(r - FNX) * 32 * ROWB>(af[buf][r - FNX], addr_a);
-  };
-  // prologue: tile 0 complete, the first PS pieces of tile 1, step-0 fragments of tile 0
-  gemm_static_for<0, NP>([&](auto r) { dma_piece(r, 0u, 0u); });
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  {
-    const unsigned so1 = __builtin_amdgcn_readfirstlane((unsigned)(min(1, nt - 1) * BK * 2));
-    gemm_static_for<0, PS>([&](auto r) { dma_piece(r, so1, (unsigned)STAGE); });
-  }
-  gemm_static_for<0, RD>([&](auto r) { read_frag(r, std::integral_constant<int, 0>{}, fa[0][0], fb[0][0]); });
-  if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[4] = __builtin_readcyclecounter();
-
-  auto tile = [&](int t, auto cur_c) {
-    constexpr int CUR = decltype(cur_c)::value;
-    const unsigned so1 = __builtin_amdgcn_readfirstlane((unsigned)(min(t + 1, nt - 1) * BK * 2));
-    const unsigned so2 = __builtin_amdgcn_readfirstlane((unsigned)(min(t + 2, nt - 1) * BK * 2));
-    gemm_static_for<0, 4>([&](auto s) {
-      constexpr int buf = s & 1;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this step's fragments (requested in the first slots of the previous step)
-      gemm_static_for<0, FMX>([&](auto i) {
-        gemm_static_for<0, FNX>([&](auto j) {
-          mfma_ij(i, j, bf_[buf][j], af[buf][i]);
-          constexpr int n = i * FNX + j;
-          if constexpr (n < RD && !(ABL & 2)) {   // next step's fragments: steps 0-2 from this tile's stage, step 3 from tile t+1's
-            if constexpr (s < 3) read_frag(std::integral_constant<int, n>{}, std::integral_constant<int, buf ^ 1>{}, fa[CUR][s + 1], fb[CUR][s + 1]);
-            else read_frag(std::integral_constant<int, n>{}, std::integral_constant<int, buf ^ 1>{}, fa[CUR ^ 1][0], fb[CUR ^ 1][0]);
-          } else if constexpr (n >= RD && (n - RD) % DGAP == 0 && (n - RD) / DGAP < PS && !(ABL & 1)) {   // PS DMA pieces per step
-            constexpr int q = (n - RD) / DGAP;
-            if constexpr (s < 3) dma_piece(std::integral_constant<int, PS + s * PS + q>{}, so1, (unsigned)((CUR ^ 1) * STAGE));
-            else dma_piece(std::integral_constant<int, q>{}, so2, (unsigned)(CUR * STAGE));
-          }
-        });
-      });
-      if constexpr (s == 2) {   // tile t+1 complete in LDS, nobody reads stage CUR any more (its last fragments are in registers)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-    });
-  };
-  int t = 0;
-  for (; t + 1 < nt; t += 2) {
-    tile(t, std::integral_constant<int, 0>{});
-    tile(t + 1, std::integral_constant<int, 1>{});
-  }
-  if (t < nt) tile(t, std::integral_constant<int, 0>{});
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    g_clk_probe[2] = __builtin_readcyclecounter();
-    g_clk_probe[3] = wall_clock64();
-  }
-  // ---- epilogue (bf16, non-accumulating outputs only: the launcher sends everything else to the pipelined kernel) ----
-  const int key = (p.bias ? 1 : 0) | (p.res ? 2 : 0) | (p.act << 2);   // wave uniform
-  const int mrow = m0 + wm * WTM + frow, ncol = n0 + wn * WTN;
-  auto store_all = [&](auto bias_c, auto act_c, auto res_c) {
-    constexpr bool B_ = decltype(bias_c)::value;
-    constexpr int A_ = decltype(act_c)::value;
-    constexpr bool R_ = decltype(res_c)::value;
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        w4x_store_frag<B_, A_, R_>(p, acc00[i][j], mrow + i * 32, ncol + j * 32, fh);
-        w4x_store_frag<B_, A_, R_>(p, acc10[i][j], mrow + (i + 2) * 32, ncol + j * 32, fh);
-        if constexpr (FNX == 4) {
-          w4x_store_frag<B_, A_, R_>(p, acc01[i][j], mrow + i * 32, ncol + (j + 2) * 32, fh);
-          w4x_store_frag<B_, A_, R_>(p, acc11[i][j], mrow + (i + 2) * 32, ncol + (j + 2) * 32, fh);
-        }
-      }
-  };
-  using T_ = std::true_type;
-  using F_ = std::false_type;
-  using A0 = std::integral_constant<int, 0>;
-  using A1 = std::integral_constant<int, 1>;
-  using A2 = std::integral_constant<int, 2>;
-  switch (key) {
-    case 0: store_all(F_{}, A0{}, F_{}); break;
-    case 1: store_all(T_{}, A0{}, F_{}); break;
-    case 2: store_all(F_{}, A0{}, T_{}); break;
-    case 3: store_all(T_{}, A0{}, T_{}); break;
-    case 4: store_all(F_{}, A1{}, F_{}); break;
-    case 5: store_all(T_{}, A1{}, F_{}); break;
-    case 6: store_all(F_{}, A1{}, T_{}); break;
-    case 7: store_all(T_{}, A1{}, T_{}); break;
-    case 8: store_all(F_{}, A2{}, F_{}); break;
-    case 9: store_all(T_{}, A2{}, F_{}); break;
-    case 10: store_all(F_{}, A2{}, T_{}); break;
-    default: store_all(T_{}, A2{}, T_{}); break;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[5] = __builtin_readcyclecounter();
-}
-
-template <int BM, int BN, int WMW, int WNW, int ABL = 0>
-int launch_gemm_x32(GemmParams& p, hipStream_t stream) {
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + BN - 1) / BN;
-  constexpr int lds = 2 * (BM + BN) * ROWB;
-  static bool attr_set = false;
-  auto kern = gemm_nt_x32_kernel<BM, BN, WMW, WNW, ABL>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-      slam_set_error("gemm: cannot raise LDS limit to %d: %s", lds, hipGetErrorString(e));
-      return -2;
-    }
-    attr_set = true;
-  }
-  const uint64_t bytes_a = ((uint64_t)(p.M - 1) * (uint64_t)p.lda + (uint64_t)p.K) * 2ull;
-  const uint64_t bytes_b = ((uint64_t)(p.N - 1) * (uint64_t)p.ldb + (uint64_t)p.K) * 2ull;
-  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WMW * WNW * 64), lds, stream, p, (unsigned)bytes_a, (unsigned)bytes_b);
-  SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(32x32x16 MFMA, hand-ordered k-loop)");
-  return 0;
-}
+// (Round 2 also built this loop on v_mfma_f32_32x32x16_bf16 -- 2 x 2 and 2 x 4 waves, operand tiles by LDS-DMA and by
+// buffer_load -> ds_write with one and two k-tiles of register staging; all correct, all slower: 2740-2870 cycles per k-tile
+// against an MFMA-only floor of 2065-2090, i.e. every VMEM instruction of the loop stalls the SIMD for 40-50 cycles whatever issues
+// it, and the 16x16x32 stream interleaves with them better.  Numbers in profiles/r02_gemm_experiments.md; code in the history
+// (commit "GEMM experiments: 32x32x16-MFMA hand-ordered kernels").)
 
 template <int BM, int BN, int WM, int WN, int PIPE = -1>
 int launch_gemm(GemmParams& p, hipStream_t stream) {
@@ -1286,7 +1030,7 @@ static inline bool fits_descriptor(int64_t rows, int64_t ld, int tile) {
 }
 
 int g_gemm_cfg = 0;  // 0 = auto
-int g_gemm_big = 6;        // which 256x256 kernel the auto rule uses for K > 2048 (6 | 7 | 12)
+int g_gemm_big = 12;       // which 256x256 kernel the auto rule uses for K > 2048 (6 | 7 | 12): in the C3 step 12 -> 401.7 ms, 6 -> 408.3 ms
 int g_gemm_big_shortk = 7; // ... and for K <= 2048
 int g_gemm_group_m = 8;
 
@@ -1310,9 +1054,9 @@ extern "C" int slam_gemm_debug_clock(unsigned long long* out6) {   // tools: sta
 
 extern "C" int slam_gemm_set_config(int cfg) {
   // 100 + v / 200 + v (v in 6, 7, 12): the 256x256 kernel the AUTO rule picks for K > 2048 / K <= 2048 (tools/step sweeps)
-  if (cfg == 106 || cfg == 107 || (cfg >= 112 && cfg <= 114)) { g_gemm_big = cfg - 100; return 0; }
-  if (cfg == 206 || cfg == 207 || (cfg >= 212 && cfg <= 214)) { g_gemm_big_shortk = cfg - 200; return 0; }
-  SLAM_CHECK_ARG(cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 6 || cfg == 7 || (cfg >= 12 && cfg <= 17), "slam_gemm_set_config: cfg %d (0 auto | 1 2 3 4 6 7 12 13 14 | 15-17 ablations)", cfg);
+  if (cfg == 106 || cfg == 107 || cfg == 112) { g_gemm_big = cfg - 100; return 0; }
+  if (cfg == 206 || cfg == 207 || cfg == 212) { g_gemm_big_shortk = cfg - 200; return 0; }
+  SLAM_CHECK_ARG(cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 6 || cfg == 7 || cfg == 12, "slam_gemm_set_config: cfg %d (0 auto | 1 2 3 4 6 7 12)", cfg);
   g_gemm_cfg = cfg;
   return 0;
 }
@@ -1384,15 +1128,6 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
       if (p.K < 2 * BK || (uint64_t)p.M * (uint64_t)p.lda * 2ull >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldb * 2ull >= (1ull << 32))
         return launch_gemm<256, 256, 2, 4, 1>(p, s);
       return launch_gemm_w4<256, 256, false>(p, s);
-    case 13:                                               // 32x32x16 MFMAs, hand-ordered k-loop: 2 x 2 waves
-    case 14:                                               // ... 2 x 4 waves
-      if (p.K < 2 * BK || p.out_f32 || p.accumulate || p.act == 3 || (uint64_t)p.M * (uint64_t)p.lda * 2ull >= (1ull << 32) ||
-          (uint64_t)p.N * (uint64_t)p.ldb * 2ull >= (1ull << 32))
-        return launch_gemm<256, 256, 2, 4, 1>(p, s);
-      return cfg == 13 ? launch_gemm_x32<256, 256, 2, 2>(p, s) : launch_gemm_x32<256, 256, 2, 4>(p, s);
-    case 15: return launch_gemm_x32<256, 256, 2, 4, 1>(p, s);   // timing ablations of cfg 14 (tools; wrong results)
-    case 16: return launch_gemm_x32<256, 256, 2, 4, 2>(p, s);
-    case 17: return launch_gemm_x32<256, 256, 2, 4, 3>(p, s);
   }
   slam_set_error("slam_gemm_bf16_nt: bad config %d", cfg);
   return -1;

@@ -122,10 +122,10 @@ def gemm_skinny(a, b, out, residual=None, b2=None, swiglu=False):
 _GEMM_CFG = 0
 _GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
                4: "gemm_nt_kernel<256,256,2,4>", 6: "gemm_nt_pipe_kernel<256,256,2,4,1>", 7: "gemm_nt_persist2_kernel<256,256,2,4>",
-               12: "gemm_nt_w4_kernel<256,256>", 13: "gemm_nt_x32_kernel<256,256,2,2>", 14: "gemm_nt_x32_kernel<256,256,2,4>", 15: "x32_nodma", 16: "x32_nofrag", 17: "x32_mfma_only"}
+               12: "gemm_nt_w4_kernel<256,256>"}
 
 
-_GEMM_BIG = {"big": 6, "shortk": 7}
+_GEMM_BIG = {"big": 12, "shortk": 7}
 if os.environ.get("SLAM_GEMM_BIG"):          # sweeps: SLAM_GEMM_BIG=12 SLAM_GEMM_BIG_SHORTK=7 python bench.py ...
     call("slam_gemm_set_config", 100 + int(os.environ["SLAM_GEMM_BIG"]))
     _GEMM_BIG["big"] = int(os.environ["SLAM_GEMM_BIG"])
