@@ -198,6 +198,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const GemmParams& p, f32x4_t 
   // INNER: the workgroup's whole tile lies inside [0, M) x [0, N) -- no per-lane guards (all but the last tile row / column).
   // A row's residual values are requested together, ahead of its arithmetic (one wait per row, not one per fragment).
   const int nbase = n0 + wn * WTN;
+  const bool scaled = p.alpha != 1.0f;
   float4 bias4[FN];
   if constexpr (BIAS) {
 #pragma unroll
@@ -228,7 +229,11 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const GemmParams& p, f32x4_t 
         const int j = 2 * jp + hh;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = acc[i][j][e] * p.alpha;
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][e];
+        if (scaled) {   // wave-uniform, almost never taken (alpha = 1 everywhere but the LoRA scaling products)
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] *= p.alpha;
+        }
         if constexpr (BIAS) {
           v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w;
         }
@@ -920,6 +925,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
     });
   };
   if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[4] = __builtin_readcyclecounter();
+  // (a variant that stops fetching in the last two tiles -- three instantiations of the tile body -- made hipcc spill around the
+  // asm statements: 876 bytes of scratch, wrong results (a spilled "=v" of a ds_read is stored before the data lands), removed)
   int t = 0;
   for (; t + 1 < nt; t += 2) {
     tile(t, std::integral_constant<int, 0>{});

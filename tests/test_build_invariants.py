@@ -1,0 +1,42 @@
+"""CPU: invariants of the compiled gfx950 code that the hand-scheduled kernels rely on.
+
+The k-loop of gemm_nt_w4_kernel, the tile loops of attn_fwd_kernel and attn_bwd_dkdv_ring_kernel place their LDS reads, LDS-DMA and
+MFMAs as `asm volatile` statements whose result registers are "ready" for the compiler at once.  If hipcc ever SPILLS such a
+register (stores it to scratch before the data has landed) the kernel computes garbage -- it happened once with three
+instantiations of the GEMM tile body (876 bytes of scratch, wrong results).  Zero scratch is therefore a build invariant."""
+import os
+import re
+import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slam_llm_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+FILES = {"gemm_bf16.hip": ([], ("gemm_nt_w4_kernel", "gemm_nt_pipe_kernel", "gemm_nt_persist2_kernel")),
+         "attention.hip": (["-mllvm", "-amdgpu-mfma-vgpr-form"], ("attn_fwd_kernel", "attn_bwd_dkdv_ring_kernel"))}
+
+
+def _scratch_by_kernel(src, extra):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra, "-S", "--cuda-device-only",
+                        os.path.join(CSRC, src), "-o", out], check=True, capture_output=True, cwd=CSRC)
+        text = open(out).read()
+    res = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+        res[m.group(1)] = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
+    return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_hand_scheduled_kernels_use_no_scratch():
+    with ThreadPoolExecutor(2) as ex:
+        futs = {src: ex.submit(_scratch_by_kernel, src, extra) for src, (extra, _) in FILES.items()}
+    for src, (_, names) in FILES.items():
+        scratch = futs[src].result()
+        for name in names:
+            hits = {k: v for k, v in scratch.items() if name in k}
+            assert hits, f"{name}: no instance found in {src}"
+            assert all(v == 0 for v in hits.values()), f"{src}: scratch in {', '.join(k for k, v in hits.items() if v)}"
