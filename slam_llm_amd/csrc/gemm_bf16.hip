@@ -271,9 +271,36 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const GemmParams& p, f32x4_t 
   }
 }
 
+// fp32 outputs without bias / activation / residual (weight-gradient products, optionally accumulating): 16 bytes per lane as is
+template <int FM, int FN, int WTM, int WTN, bool ACCUM>
+__device__ __forceinline__ void gemm_epilogue_f32(const GemmParams& p, f32x4_t (&acc)[FM][FN], int m0, int n0, int wm, int wn,
+                                                  int frow, int fg) {
+#pragma unroll
+  for (int i = 0; i < FM; i++) {
+    const int m = m0 + wm * WTM + i * 16 + frow;
+    if (m >= p.M) continue;
+    float* crow = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n0 + wn * WTN + fg * 4;
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      if (n0 + wn * WTN + j * 16 + fg * 4 >= p.N) continue;
+      float4 v = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+      if constexpr (ACCUM) {
+        const float4 o = *reinterpret_cast<const float4*>(crow + j * 16);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      *reinterpret_cast<float4*>(crow + j * 16) = v;
+    }
+  }
+}
+
 template <int FM, int FN, int WTM, int WTN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc)[FM][FN], int m0, int n0, int wm,
                                               int wn, int frow, int fg) {
+  if (p.out_f32 && !p.bias && !p.res && p.act == 0) {
+    if (p.accumulate) gemm_epilogue_f32<FM, FN, WTM, WTN, true>(p, acc, m0, n0, wm, wn, frow, fg);
+    else gemm_epilogue_f32<FM, FN, WTM, WTN, false>(p, acc, m0, n0, wm, wn, frow, fg);
+    return;
+  }
   if (p.out_f32 || p.accumulate || p.act == 3) {
     gemm_epilogue_generic<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, frow, fg);
     return;
