@@ -997,6 +997,11 @@ int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
   return 0;
 }
 
+// (A persistent form of this kernel -- one workgroup per CU, the branch-free tail fetching the NEXT output tile's first two
+// k-tiles so that no prologue and no workgroup launch separates two tiles -- was built and measured: correct, 3-18 % SLOWER than
+// the one-tile kernel on every shape (1223 vs 1386 TF at 11780 x 4096 x 4096, 949 vs 1156 at K = 1280): static striding loses the
+// dispatcher's load balancing, and the epilogue inside the tile loop spills.  Removed; profiles/r02_gemm_experiments.md.)
+
 // (Round 2 also built this loop on v_mfma_f32_32x32x16_bf16 -- 2 x 2 and 2 x 4 waves, operand tiles by LDS-DMA and by
 // buffer_load -> ds_write with one and two k-tiles of register staging; all correct, all slower: 2740-2870 cycles per k-tile
 // against an MFMA-only floor of 2065-2090, i.e. every VMEM instruction of the loop stalls the SIMD for 40-50 cycles whatever issues
