@@ -156,6 +156,19 @@ def _worker(rank, world, port, q):
         both = [torch.empty_like(flat3) for _ in range(world)]
         dist.all_gather(both, flat3)
         res["ddp_slamadamw_equal"] = bool(torch.equal(both[0], both[1])) and bool((flat3 != flat2).any())
+        # ---- unfrozen encoder (train_config.freeze_encoder=false): its gradients ride the same flat buffer / prefixes ----------
+        mu = SlamHipModel(dict(cfg, freeze_encoder=False), dev).load_weights(W)
+        mu.train()
+        want = (local_grad(mu, [batch_for(0, 0)]) + local_grad(mu, [batch_for(1, 0)])) / 2
+        gsu = GradSync(mu, bucket_bytes=256 * 1024).attach(mu)
+        out, _ = mu(**batch_for(rank, 0))
+        out.loss.backward()
+        gsu.finish()
+        got = mu.store.grad.clone()
+        enc_lo = min(off for n, (off, _, _) in mu.store.offsets.items() if n.startswith("encoder."))
+        res["unfrozen_cos"] = _cos(got, want)
+        res["unfrozen_encoder_cos"] = _cos(got[enc_lo:], want[enc_lo:])
+        res["unfrozen_has_encoder"] = bool(got[enc_lo:].abs().sum() > 0) and enc_lo > 0
         torch.cuda.synchronize()
         q.put((rank, res, None))
         dist.barrier()
@@ -186,6 +199,7 @@ def test_two_ranks_real_model_gradsync_and_ddp(dev):
         assert res["ddp_has_reference_keys"], (rank, res)
         assert res["ddp_cos"] >= 0.9999 and res["ddp_maxdiff"] < 2e-2, (rank, res)
         assert res["ddp_params_equal_across_ranks"] and res["ddp_losses_finite"] and res["ddp_slamadamw_equal"], (rank, res)
+        assert res["unfrozen_has_encoder"] and res["unfrozen_cos"] >= 0.9999 and res["unfrozen_encoder_cos"] >= 0.999, (rank, res)
     for p in procs:
         assert p.exitcode == 0
 
