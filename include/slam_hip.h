@@ -139,7 +139,11 @@ int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
                   int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B, int64_t Tq, int64_t Tk,
                   int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
                   const int32_t* seg_lo, const int32_t* seg_hi, const float* rp_gate, const float* rp_tab, int64_t rp_T,
-                  int64_t rp_ld, void* stream);
+                  int64_t rp_ld, float drop_p, uint64_t drop_seed, void* stream);
+/* drop_p > 0 (forward and backward, D = 64 bidirectional): dropout on the attention PROBABILITIES (HF Blip2QFormer
+ * attention_probs_dropout_prob inside EncoderProjectorQFormer, models/projector.py:51-67, train mode): P keeps its full-row
+ * normalisation, element (b, h, q, k) is kept with slam_dropout_bf16's counter-based mask at index ((b*Hq + h)*Tqp + q)*Tkp + k
+ * (seed = drop_seed, offset 0) and scaled by 1/(1-p); slam_attn_bwd recomputes the same mask. */
 /* rp_gate / rp_tab (nullable, forward only, D = 64, bidirectional): WavLM's gated relative position bias
  * (src/slam_llm/models/wavlm/modules.py:504-533, called from models/slam_model.py:333-334 through models/encoder.py:109-127):
  * score(q, k) = scale q.k + rp_gate[b][h][q] * rp_tab[h * rp_ld + (k - q + rp_T - 1)]; rp_gate [B, Hq, Tqp] f32 from
@@ -155,7 +159,7 @@ int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
                   void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv, int64_t B,
                   int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D,
                   int causal, float scale, const float* rope_cos, const float* rope_sin, const int32_t* rope_pos,
-                  const int32_t* seg_lo, const int32_t* seg_hi, void* stream);
+                  const int32_t* seg_lo, const int32_t* seg_hi, float drop_p, uint64_t drop_seed, void* stream);
 
 /* ---- SwiGLU (LlamaMLP) : gate_up [M, 2F] = [gate | up] ---------------------------------------------- */
 int slam_swiglu_fwd(const void* gate_up, int64_t ldgu, void* h, int64_t ldh, int64_t M, int64_t F,

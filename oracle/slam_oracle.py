@@ -405,7 +405,7 @@ def qformer_config(**kw) -> dict:
     return c
 
 
-def _mha(W, p, hq, hkv, H, key_mask=None):
+def _mha(W, p, hq, hkv, H, key_mask=None, prob_mask=None):
     B, Tq, d = hq.shape
     Tk = hkv.shape[1]
     hd = d // H
@@ -415,35 +415,43 @@ def _mha(W, p, hq, hkv, H, key_mask=None):
     s = (q @ k.transpose(2, 3)) * hd ** -0.5
     if key_mask is not None:
         s = s.masked_fill(~key_mask.bool()[:, None, None, :], torch.finfo(torch.float32).min)
-    return (F.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, Tq, d)
+    pr = F.softmax(s, dim=-1)
+    if prob_mask is not None:     # attention_probs_dropout_prob (train mode): [B, H, Tq, Tk], values 0 or 1/(1-p)
+        pr = pr * prob_mask
+    return (pr @ v).transpose(1, 2).reshape(B, Tq, d)
 
 
 def projector_qformer(W, cfg, x: torch.Tensor, atts: Optional[torch.Tensor], prefix="encoder_projector.",
-                      hidden_masks: Optional[list] = None) -> torch.Tensor:
+                      hidden_masks: Optional[list] = None, attn_masks: Optional[list] = None) -> torch.Tensor:
     """EncoderProjectorQFormer.forward (src/slam_llm/models/projector.py:69-80) over HF Blip2QFormerModel
     (transformers/models/blip_2/modeling_blip_2.py:536-760, 849-940).  x [B, Tk, d_enc], atts [B, Tk] (1 = attend) ->
     [B, Q, llm_dim].  hidden_masks=None is eval mode (no dropout).  Train mode: the stack's hidden dropouts
     (hidden_dropout_prob: after the query LayerNorm, Blip2QFormerModel.forward; after each output projection before the
     residual add, Blip2QFormerSelfOutput / Blip2QFormerOutput) multiply by the given masks [B, Q, d] (values 0 or 1/(1-p)),
     consumed in forward order -- torch's dropout RNG stream cannot be shared with a device kernel, so the masks are an input.
-    The attention-probability dropout (attention_probs_dropout_prob) is not modelled."""
+    attn_masks: the attention-probability dropout (attention_probs_dropout_prob, Blip2QFormerMultiHeadAttention: applied to the
+    softmax output before the value product), one [B, H, Tq, Tk] mask per attention call in forward order (self, cross, ...)."""
     eps, H = cfg["qf_eps"], cfg["qf_heads"]
     B = x.shape[0]
     d = cfg["qf_dim"]
     P = prefix + "qformer."
     masks = iter(hidden_masks) if hidden_masks is not None else None
+    amasks = iter(attn_masks) if attn_masks is not None else None
 
     def drop(t):
         return t if masks is None else t * next(masks)
 
+    def amask():
+        return None if amasks is None else next(amasks)
+
     h = drop(F.layer_norm(W[prefix + "query"].expand(B, -1, -1), (d,), W[P + "layernorm.weight"], W[P + "layernorm.bias"], eps))
     for l in range(cfg["qf_layers"]):
         L = f"{P}encoder.layer.{l}."
-        a = _mha(W, L + "attention.attention.", h, h, H)
+        a = _mha(W, L + "attention.attention.", h, h, H, prob_mask=amask())
         h = F.layer_norm(drop(F.linear(a, W[L + "attention.output.dense.weight"], W[L + "attention.output.dense.bias"])) + h, (d,),
                          W[L + "attention.output.LayerNorm.weight"], W[L + "attention.output.LayerNorm.bias"], eps)
         if l % cfg["qf_cross_freq"] == 0:
-            c = _mha(W, L + "crossattention.attention.", h, x, H, atts)
+            c = _mha(W, L + "crossattention.attention.", h, x, H, atts, prob_mask=amask())
             h = F.layer_norm(drop(F.linear(c, W[L + "crossattention.output.dense.weight"], W[L + "crossattention.output.dense.bias"])) + h,
                              (d,), W[L + "crossattention.output.LayerNorm.weight"], W[L + "crossattention.output.LayerNorm.bias"], eps)
         f = F.gelu(F.linear(h, W[L + "intermediate_query.dense.weight"], W[L + "intermediate_query.dense.bias"]))

@@ -59,7 +59,24 @@ struct AttnParams {
   const float* rp_gate;
   const float* rp_tab;
   int rp_T, rp_ld;
+  // dropout on the attention probabilities (HF Blip2QFormer `attention_probs_dropout_prob`, train mode; D = 64 bidirectional
+  // kernels only): P is normalised with the full row sum, then element (b, h, q, k) is kept with the counter-based mask of
+  // slam_dropout_bf16 at index ((b*Hq + h)*Tqp + q)*Tkp + k and scaled by 1/(1-p) before the second product; the backward
+  // kernels recompute the same mask.  drop_thresh = 0: none.
+  unsigned drop_thresh;
+  float drop_scale;
+  unsigned long long drop_seed;
 };
+
+// keep bits (bit r) of keys kb .. kb+3 (kb % 4 == 0) for query q of flattened (batch, head) bh
+__device__ __forceinline__ unsigned attn_keep4(const AttnParams& p, int bh, int q, int kb) {
+  const unsigned long long idx = ((unsigned long long)bh * (unsigned)p.Tqp + (unsigned)q) * (unsigned)p.Tkp + (unsigned)kb;
+  const unsigned long long h64 = slam_mix64(p.drop_seed ^ ((idx >> 2) * 0xD1342543DE82EF95ull));
+  unsigned bits = 0;
+#pragma unroll
+  for (int e = 0; e < 4; e++) bits |= ((unsigned)((h64 >> (16 * e)) & 0xFFFFull) >= p.drop_thresh ? 1u : 0u) << e;
+  return bits;
+}
 
 // gradient of HF's rotate_half RoPE for one row held as DF fragments of 4 consecutive head-dim elements per lane:
 // dx1 = dy1 cos + dy2 sin, dx2 = dy2 cos - dy1 sin with (1, 2) = (d, d + D/2) -> fragments (df, df + DF/2) of the same lane
@@ -172,7 +189,7 @@ __device__ __forceinline__ int fwd_swz(int row) {
 // forward: 4 waves x 32 query rows per workgroup, 64-key K / V^T tiles staged through LDS
 // ------------------------------------------------------------------------------------------
 // QF = 16-row query fragments per wave (2: 128-query workgroups; 1: 64-query workgroups, fewer VGPRs -> more waves per SIMD)
-template <int D, bool CAUSAL, int QF, bool RP = false>
+template <int D, bool CAUSAL, int QF, bool RP = false, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     // The running maximum only moves when a tile exceeds it by more than 2^8 (in the exponent's log2 units): P stays <= 256,
     // exact in fp32 / bf16, and the O / l rescale becomes a rare wave-uniform branch instead of 2 exp + 16 multiplies per tile
     // interior tiles (no key mask, fully inside [0, Tk), fully below the causal diagonal of this wave) skip all masking
-    const bool tile_full = !RP && (p.kmask == nullptr) && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0 &&
+    const bool tile_full = !RP && !DROP && (p.kmask == nullptr) && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0 &&
                            k0 + 64 <= hi_wave_min;
     float alpha[QF];
     bool moved = false;
@@ -405,13 +422,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         mrow[f] = mnew;
         float rs = 0.f;
 #pragma unroll
-        for (int kf = 0; kf < 4; kf++)
+        for (int kf = 0; kf < 4; kf++) {
+          unsigned keep = 0xFu;
+          if constexpr (DROP) keep = attn_keep4(p, b * p.Hq + h, min(q, Tq - 1), k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4);
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const float pv = fast_exp2(s[f][kf][r] - muse);
-            s[f][kf][r] = pv;
-            rs += pv;
+            rs += pv;                                    // the row sum is over the UNdropped probabilities
+            s[f][kf][r] = DROP ? (((keep >> r) & 1u) ? pv * p.drop_scale : 0.f) : pv;
           }
+        }
         lrow[f] = lrow[f] * alpha[f] + rs;
       }
     }
@@ -463,7 +483,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 // four waves, next tile prefetched into registers during the MFMA phase)
 //   S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - Delta) * scale, dQ^T += K^T(as [d x keys]) . dS^T
 // ------------------------------------------------------------------------------------------
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
@@ -588,12 +608,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     for (int kf = 0; kf < 2; kf++) {
       const int kb = k0 + kf * 16 + 4 * g;
       const unsigned mk = ldsMask[kf * 4 + g];
+      unsigned keep = 0xFu;
+      if constexpr (DROP) keep = attn_keep4(p, b * p.Hq + h, min(q, Tq - 1), kb);
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int key = kb + r;
         const bool ok = ((mk >> (8 * r)) & 0xffu) != 0 && key < Tk && (!CAUSAL || key <= q) && qok && key >= qlo;
         const float pv = ok ? fast_exp2(st[kf][r] * sl2 - lse2) : 0.f;
-        st[kf][r] = pv * (dpt[kf][r] - delta) * p.scale;
+        const float dpm = DROP ? (((keep >> r) & 1u) ? dpt[kf][r] * p.drop_scale : 0.f) : dpt[kf][r];   // d(dropped P) -> dP
+        st[kf][r] = pv * (dpm - delta) * p.scale;
       }
     }
     const frag_t dsb = pack_frag(st[0], st[1]);
@@ -624,7 +647,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 // LDS and shared by the four waves;  S = Q K^T, dP = dO V^T (lane owns key (l&15), 4 consecutive queries),
 //   dV^T += dO^T(as [d x q]) . P,   dK^T += Q^T(as [d x q]) . dS
 // ------------------------------------------------------------------------------------------
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
@@ -759,8 +782,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
         const int q = qb + r;
         const bool ok = kok && q < Tq && (!CAUSAL || key <= q) && q < khi;
         const float pv = ok ? fast_exp2(s[f][r] * sl2 - ls[r] * LOG2E) : 0.f;
-        pm[f][r] = pv;
-        ds[f][r] = ok ? pv * (dp[f][r] - dl[r]) * p.scale : 0.f;
+        bool kept = true;   // this lane walks QUERIES: one mask word per element (its key is bit key & 3 of the word)
+        if constexpr (DROP) kept = (attn_keep4(p, b * p.Hq + h, min(q, Tq - 1), key & ~3) >> (key & 3)) & 1u;
+        pm[f][r] = DROP ? (kept ? pv * p.drop_scale : 0.f) : pv;                                  // dV sees the dropped P
+        const float dpm = DROP ? (kept ? dp[f][r] * p.drop_scale : 0.f) : dp[f][r];
+        ds[f][r] = ok ? pv * (dpm - dl[r]) * p.scale : 0.f;
       }
     }
     const frag_t pb = pack_frag(pm[0], pm[1]);
@@ -1149,8 +1175,11 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
                              void* O, int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B,
                              int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D,
                              int causal, float scale, const int32_t* seg_lo, const int32_t* seg_hi, const float* rp_gate,
-                             const float* rp_tab, int64_t rp_T, int64_t rp_ld, void* stream) {
+                             const float* rp_tab, int64_t rp_T, int64_t rp_ld, float drop_p, uint64_t drop_seed, void* stream) {
   SLAM_CHECK_ARG(Q && K && Vt && O, "slam_attn_fwd: null pointer");
+  SLAM_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "slam_attn_fwd: drop_p=%f must be in [0, 1)", (double)drop_p);
+  SLAM_CHECK_ARG(drop_p == 0.f || (D == 64 && !causal && !seg_lo && !rp_gate),
+                 "slam_attn_fwd: attention-probability dropout is implemented for head_dim 64, bidirectional, unpacked batches");
   SLAM_CHECK_ARG((rp_gate == nullptr) == (rp_tab == nullptr), "slam_attn_fwd: rp_gate / rp_tab must both be set or both null");
   SLAM_CHECK_ARG(!rp_gate || (D == 64 && !causal && !seg_lo && rp_T >= Tq && rp_T >= Tk && rp_ld >= 2 * rp_T - 1),
                  "slam_attn_fwd: the gated relative position bias is implemented for head_dim 64, bidirectional, unpacked batches, "
@@ -1166,7 +1195,16 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.seg_lo = seg_lo;
   p.seg_hi = causal ? nullptr : seg_hi;   // (the causal forward only needs the sequence starts)
   p.rp_gate = rp_gate; p.rp_tab = rp_tab; p.rp_T = (int)rp_T; p.rp_ld = (int)rp_ld;
+  p.drop_thresh = drop_p > 0.f ? slam_drop_thresh16(drop_p) : 0u;
+  p.drop_scale = 1.0f / (1.0f - drop_p);
+  p.drop_seed = drop_seed;
   hipStream_t s = (hipStream_t)stream;
+  if (drop_p > 0.f) {
+    dim3 grid((unsigned)cdiv64(Tq, 128), (unsigned)Hq, (unsigned)B);
+    hipLaunchKernelGGL((attn_fwd_kernel<64, false, 2, false, true>), grid, dim3(256), 0, s, p);
+    SLAM_CHECK_LAUNCH("slam_attn_fwd");
+    return 0;
+  }
   if (rp_gate) {
     dim3 grid((unsigned)cdiv64(Tq, 128), (unsigned)Hq, (unsigned)B);
     hipLaunchKernelGGL((attn_fwd_kernel<64, false, 2, true>), grid, dim3(256), 0, s, p);
@@ -1195,8 +1233,11 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
                              int64_t lddk, void* dV, int64_t lddv, int64_t B, int64_t Tq, int64_t Tk, int64_t Tqp,
                              int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
                              const float* rope_cos, const float* rope_sin, const int32_t* rope_pos,
-                             const int32_t* seg_lo, const int32_t* seg_hi, void* stream) {
+                             const int32_t* seg_lo, const int32_t* seg_hi, float drop_p, uint64_t drop_seed, void* stream) {
   SLAM_CHECK_ARG(Q && K && V && Qt && Kt && O && dO && dOt && LSE && Delta && dQ && dK && dV, "slam_attn_bwd: null pointer");
+  SLAM_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "slam_attn_bwd: drop_p=%f must be in [0, 1)", (double)drop_p);
+  SLAM_CHECK_ARG(drop_p == 0.f || (D == 64 && !causal && !seg_lo && !rope_cos),
+                 "slam_attn_bwd: attention-probability dropout is implemented for head_dim 64, bidirectional, unpacked batches");
   SLAM_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr), "slam_attn_bwd: rope_cos/rope_sin must both be set or both null");
   SLAM_CHECK_ARG(!rope_cos || Tq == Tk, "slam_attn_bwd: the fused RoPE gradient needs self-attention (Tq == Tk)");
   SLAM_CHECK_ARG((seg_lo == nullptr) == (seg_hi == nullptr), "slam_attn_bwd: seg_lo/seg_hi must both be set or both null");
@@ -1213,7 +1254,17 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.LSE = (float*)LSE; p.Delta = Delta; p.kmask = key_mask;
   p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
   p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_pos = rope_pos; p.seg_lo = seg_lo; p.seg_hi = seg_hi;
+  p.drop_thresh = drop_p > 0.f ? slam_drop_thresh16(drop_p) : 0u;
+  p.drop_scale = 1.0f / (1.0f - drop_p);
+  p.drop_seed = drop_seed;
   hipStream_t s = (hipStream_t)stream;
+  if (drop_p > 0.f) {   // same mask as the forward, recomputed (round-1 dK/dV kernel: the ring kernel has no dropout form)
+    dim3 gq_((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B), gk_((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false, true>), gq_, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false, true>), gk_, dim3(256), 0, s, p);
+    SLAM_CHECK_LAUNCH("slam_attn_bwd");
+    return 0;
+  }
   dim3 gq((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B);
   dim3 gk((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);
   dim3 gk2((unsigned)cdiv64(Tk, 128), (unsigned)Hkv, (unsigned)B);

@@ -46,10 +46,10 @@ SIGNATURES = {
     "slam_rmsnorm_bwd": [P, I64, P, P, P, I64, P, I64, P, I64, P, I64, I64, P],
     "slam_head_rope_transpose": [P, I64, I64, P, P, I32, P, I64, I64, I64, I64, I64, P, P],
     "slam_transpose_bf16": [P, I64, P, I64, I64, I64, I64, P],
-    "slam_attn_fwd": [P, I64, P, I64, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P, P, I64, I64, P],
+    "slam_attn_fwd": [P, I64, P, I64, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P, P, I64, I64, F, U64, P],
     "slam_wavlm_gate": [P, I64, P, P, P, P, I64, I64, I64, I64, P],
     "slam_attn_bwd": [P, I64, P, I64, P, I64, P, P, P, I64, P, I64, P, P, P, P, P, I64, P, I64, P, I64,
-                      I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P, P, P, P],
+                      I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P, P, P, F, U64, P],
     "slam_swiglu_fwd": [P, I64, P, I64, I64, I64, P],
     "slam_swiglu_bwd": [P, I64, P, I64, P, I64, I64, I64, P],
     "slam_relu_bwd": [P, I64, P, I64, I64, I64, P],

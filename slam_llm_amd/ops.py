@@ -355,11 +355,12 @@ def transpose(x2d, Rp=None, out=None):
 
 # ------------------------------------------------------------------------------------------------ attention
 def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_lse=True, out=None, Tk=None, seg=None,
-             relpos=None):
+             relpos=None, drop=None):
     """self-attention: q/k rows (b*T + t).  Cross-attention: pass Tk (key rows b*Tk + t); vt is [B,Hkv,D,Tkp].
     seg = (lo, hi) int32 [B*T]: packed sequences (B = 1), query q sees keys lo[q] <= k <= q (causal) or
     lo[q] <= k < hi[q] (bidirectional: the ragged encoder, one clip per segment).
-    relpos = (gate [B,Hq,Tqp] f32, table from relpos_table(), rp_T): WavLM's gated relative position bias."""
+    relpos = (gate [B,Hq,Tqp] f32, table from relpos_table(), rp_T): WavLM's gated relative position bias.
+    drop = (p, seed): dropout on the attention probabilities (counter-based mask; attn_bwd with the same pair recomputes it)."""
     Tk = Tk or T
     Tkp, Tqp = vt.shape[-1], round_up(T, 64)
     if out is None:
@@ -370,7 +371,8 @@ def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_
                         _p(key_mask), B, T, Tk, Tqp, Tkp, Hq, Hkv, D, 1 if causal else 0, scale, _p(seg[0]) if seg else None,
                         _p(seg[1]) if seg else None, _p(relpos[0]) if relpos else None,
                         (relpos[1].data_ptr() + 64 * 4) if relpos else None, relpos[2] if relpos else 0,
-                        relpos[1].shape[1] if relpos else 0, _s()))
+                        relpos[1].shape[1] if relpos else 0, float(drop[0]) if drop else 0.0,
+                        (int(drop[1]) & (2 ** 64 - 1)) if drop else 0, _s()))
     return out, lse
 
 
@@ -392,7 +394,7 @@ def wavlm_gate(x2d: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, grep_a: t
 
 
 def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T, Hq, Hkv, D, causal, scale,
-             key_mask=None, Tk=None, rope=None, seg=None):
+             key_mask=None, Tk=None, rope=None, seg=None, drop=None):
     """rope = (cos, sin[, positions]) tables: dq/dk come out as gradients w.r.t. the pre-RoPE projections (fused
     epilogue; explicit int32 positions for packed batches).  seg = (lo, hi): packed sequences, see attn_fwd."""
     Tk = Tk or T
@@ -404,7 +406,8 @@ def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T,
                         _ld(dq2d), _p(dk2d), _ld(dk2d), _p(dv2d), _ld(dv2d), B, T, Tk, Tqp, Tkp, Hq, Hkv, D,
                         1 if causal else 0, scale, _p(rope[0]) if rope else None, _p(rope[1]) if rope else None,
                         _p(rope[2]) if rope and len(rope) > 2 else None, _p(seg[0]) if seg else None,
-                        _p(seg[1]) if seg else None, _s()))
+                        _p(seg[1]) if seg else None, float(drop[0]) if drop else 0.0,
+                        (int(drop[1]) & (2 ** 64 - 1)) if drop else 0, _s()))
     return delta
 
 

@@ -9,8 +9,9 @@ Dropout: the reference's Blip2QFormerConfig() defaults (hidden_dropout_prob = at
 live in train mode.  The four HIDDEN dropouts of the stack (after the query LayerNorm, and after each of the self-attention /
 cross-attention / feed-forward output projections, before the residual add -- modeling_blip_2.py Blip2QFormerSelfOutput /
 Blip2QFormerOutput / Blip2QFormerModel.forward) are applied with the counter-based mask of slam_dropout_bf16 (recomputed,
-never stored, in the backward; `qf_dropout`, default 0.1, 0 in eval mode).  The dropout on the attention PROBABILITIES lives
-inside the fused attention kernel in HF's formulation and is not applied -- stated deviation.
+never stored, in the backward; `qf_dropout`, default 0.1, 0 in eval mode).  The dropout on the attention PROBABILITIES
+(`attention_probs_dropout_prob`, Blip2QFormerMultiHeadAttention) is applied inside the fused attention kernels (same mask
+generator, one seed per attention call, recomputed by the backward kernels).
 
 All products are NT GEMMs (weights' transposes are refreshed once per optimizer step), attention runs on the MFMA
 kernels (self: Tq = Tk = Q; cross: Tq = Q, Tk = encoder frames with the key-padding mask), weight gradients are
@@ -133,6 +134,13 @@ class HipProjectorQFormer(nn.Module):
             self._drop_calls += 1
             return (self.p_drop, seed, self._drop_calls << 40)
 
+        def attn_drop():
+            """(p, seed) of the next attention-probability dropout, or None"""
+            if not use_drop:
+                return None
+            self._drop_calls += 1
+            return (self.p_drop, (seed * 0x9E3779B1 + self._drop_calls) & (2 ** 63 - 1))
+
         def out_proj(x, w_name, b_name, residual, key):
             """dense -> dropout -> + residual (Blip2QFormerSelfOutput / Blip2QFormerOutput up to the LayerNorm)"""
             if key is None:
@@ -154,11 +162,12 @@ class HipProjectorQFormer(nn.Module):
             qt = ops.head_rope_transpose(qkv, 0, B, Q, H, 64) if train else None
             kt = ops.head_rope_transpose(qkv, d, B, Q, H, 64) if train else None
             vt = ops.head_rope_transpose(qkv, 2 * d, B, Q, H, 64)
-            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, Q, H, H, 64, False, scale, want_lse=train)
+            ad = attn_drop()
+            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, Q, H, H, 64, False, scale, want_lse=train, drop=ad)
             k1 = drop_key()
             s1 = out_proj(a, A + "output.dense.weight", A + "output.dense.bias", h, k1)
             h1, m1, r1 = ops.layernorm(s1, f32(A + "output.LayerNorm.weight"), f32(A + "output.LayerNorm.bias"), self.eps, stats=True)
-            rec = dict(h=h, qkv=qkv, qt=qt, kt=kt, a=a, lse=lse, s1=s1, m1=m1, r1=r1, h1=h1, cross=None, k1=k1)
+            rec = dict(h=h, qkv=qkv, qt=qt, kt=kt, a=a, lse=lse, s1=s1, m1=m1, r1=r1, h1=h1, cross=None, k1=k1, ad=ad)
             hx = h1
             if l % self.cross_freq == 0:
                 C = Lp + "crossattention."
@@ -168,11 +177,12 @@ class HipProjectorQFormer(nn.Module):
                 vtc = ops.head_rope_transpose(kvc, d, B, Tk, H, 64)
                 ktc = ops.head_rope_transpose(kvc, 0, B, Tk, H, 64) if train else None
                 qtc = ops.head_rope_transpose(qc, 0, B, Q, H, 64) if train else None
-                c, lsec = ops.attn_fwd(qc, kvc[:, :d], vtc, B, Q, H, H, 64, False, scale, key_mask=km, want_lse=train, Tk=Tk)
+                adc = attn_drop()
+                c, lsec = ops.attn_fwd(qc, kvc[:, :d], vtc, B, Q, H, H, 64, False, scale, key_mask=km, want_lse=train, Tk=Tk, drop=adc)
                 k2 = drop_key()
                 s2 = out_proj(c, C + "output.dense.weight", C + "output.dense.bias", h1, k2)
                 hx, mc, rc = ops.layernorm(s2, f32(C + "output.LayerNorm.weight"), f32(C + "output.LayerNorm.bias"), self.eps, stats=True)
-                rec["cross"] = dict(qc=qc, kvc=kvc, ktc=ktc, qtc=qtc, c=c, lse=lsec, s2=s2, mc=mc, rc=rc, hx=hx, k2=k2)
+                rec["cross"] = dict(qc=qc, kvc=kvc, ktc=ktc, qtc=qtc, c=c, lse=lsec, s2=s2, mc=mc, rc=rc, hx=hx, k2=k2, ad=adc)
             z = ops.gemm_nt(hx, st.bf16_view(Lp + "intermediate_query.dense.weight"), bias=f32(Lp + "intermediate_query.dense.bias"))
             f = ops.gelu_fwd(z)
             k3 = drop_key()
@@ -227,7 +237,7 @@ class HipProjectorQFormer(nn.Module):
                 dqc = torch.empty_like(X["qc"])
                 dkvc = torch.empty_like(X["kvc"])
                 ops.attn_bwd(X["qc"], X["kvc"][:, :d], X["kvc"][:, d:], X["qtc"], X["ktc"], X["c"], dc, dct, X["lse"], dqc,
-                             dkvc[:, :d], dkvc[:, d:], B, Q, H, H, 64, False, scale, key_mask=km, Tk=Tk)
+                             dkvc[:, :d], dkvc[:, d:], B, Q, H, H, 64, False, scale, key_mask=km, Tk=Tk, drop=X["ad"])
                 dh1 = self._lin_bwd(dqc, R["h1"], C + "attention.query.weight", C + "attention.query.bias", d, d, acc,
                                     C + "attention.query.weight")
                 self._lin_bwd(dkvc, enc2d, C + "attention.key.weight", C + "attention.key.bias", 2 * d, self.d_enc, acc, None)
@@ -242,7 +252,7 @@ class HipProjectorQFormer(nn.Module):
             qkv = R["qkv"]
             dqkv = torch.empty_like(qkv)
             ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], R["qt"], R["kt"], R["a"], da, dat, R["lse"], dqkv[:, :d],
-                         dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, Q, H, H, 64, False, scale)
+                         dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, Q, H, H, 64, False, scale, drop=R["ad"])
             dh = self._lin_bwd(dqkv, R["h"], A + "attention.query.weight", A + "attention.query.bias", 3 * d, d, acc,
                                A + "attention.qkv")
             dh = self._add(dh, ds1)

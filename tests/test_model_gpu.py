@@ -354,10 +354,10 @@ def test_qformer_projector_matches_reference_fixture(dev):
     assert {k for k in qf.state_dict()} == {k[len("encoder_projector."):] for k in W}
 
 
-def test_qformer_hidden_dropout_matches_oracle_with_the_same_masks(dev):
-    """train mode: the four kinds of hidden dropout (query LayerNorm output; self / cross / feed-forward output projections) --
-    the masks the kernels drew are rebuilt from their (seed, offset) keys and handed to the fp32 oracle; output and every
-    parameter gradient must agree as in the eval-mode fixture test"""
+def test_qformer_train_mode_dropout_matches_oracle_with_the_same_masks(dev):
+    """train mode: the four kinds of hidden dropout (query LayerNorm output; self / cross / feed-forward output projections) and
+    the dropout on the attention probabilities of every self- / cross-attention -- the masks the kernels drew are rebuilt from
+    their keys / seeds and handed to the fp32 oracle; output and every parameter gradient must agree as in the eval-mode test"""
     from oracle.make_golden_cases import QFORMER_CASE as C
     from slam_llm_amd import ops
     from slam_llm_amd.model import TrainableStore
@@ -393,8 +393,16 @@ def test_qformer_hidden_dropout_matches_oracle_with_the_same_masks(dev):
     kept = torch.stack(masks).ne(0).float().mean().item()
     assert abs(kept - 0.9) < 0.01 and all(set(m.unique().tolist()) <= {0.0, float(torch.tensor(1 / 0.9).bfloat16())} for m in masks)
     masks = [m.ne(0).float() / 0.9 for m in masks]
+    # attention-probability masks, one per attention call in forward order (self, cross of layer 0, self of layer 1, ...)
+    H, Tk = C["cfg"]["qf_heads"], x.shape[1]
+    amasks = []
+    for R in S["layers"]:
+        amasks.append(torch.from_numpy(G.attn_keep_mask(R["ad"][1], 0.1, B, H, Q, Q, 64, 64)) / 0.9)
+        if R["cross"] is not None:
+            amasks.append(torch.from_numpy(G.attn_keep_mask(R["cross"]["ad"][1], 0.1, B, H, Q, Tk, 64, 64)) / 0.9)
+    assert all(abs(float(a.ne(0).float().mean()) - 0.9) < 0.03 for a in amasks)
     Wg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
-    ref = O.projector_qformer(Wg, C["cfg"], x.float().cpu(), atts.cpu(), hidden_masks=masks)
+    ref = O.projector_qformer(Wg, C["cfg"], x.float().cpu(), atts.cpu(), hidden_masks=masks, attn_masks=amasks)
     a, g = out.float().cpu().numpy(), ref.detach().numpy()
     assert rel_err(a, g) < 3e-2 and G.cosine(g, a) > 0.9995, (rel_err(a, g), G.cosine(g, a))
     cot = torch.from_numpy(fx["cot"])

@@ -908,3 +908,53 @@ def test_attention_fwd_gated_relative_position_bias(dev, T, masked):
     ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * T, H * D)
     err = (out.float().cpu() - ref).abs().max().item()
     assert err < 3e-2, err
+
+
+@pytest.mark.parametrize("B,Tq,Tk,H,masked", [(2, 8, 8, 3, False), (2, 64, 150, 2, True), (1, 100, 100, 2, False)])
+def test_attention_probability_dropout_fwd_bwd(dev, B, Tq, Tk, H, masked):
+    """slam_attn_fwd / slam_attn_bwd with drop_p > 0 (Q-Former self- and cross-attention shapes, D = 64, bidirectional) vs torch
+    autograd through softmax(q.k) * mask / (1-p) @ v with the SAME mask, rebuilt on the host from the seed (tests/golden_util.py)"""
+    from slam_llm_amd import ops
+    from tests import golden_util as G
+    D, pdrop, seed = 64, 0.1, 0x1234567
+    g = torch.Generator().manual_seed(Tq * 31 + Tk)
+    q = torch.randn(B * Tq, H * D, generator=g).to(torch.bfloat16)
+    kv = torch.randn(B * Tk, 2 * H * D, generator=g).to(torch.bfloat16)
+    do = torch.randn(B * Tq, H * D, generator=g).to(torch.bfloat16)
+    qd, kvd, dod = q.to(dev), kv.to(dev), do.to(dev)
+    vt = ops.head_rope_transpose(kvd, H * D, B, Tk, H, D)
+    kt = ops.head_rope_transpose(kvd, 0, B, Tk, H, D)
+    qt = ops.head_rope_transpose(qd, 0, B, Tq, H, D)
+    dot = ops.head_rope_transpose(dod, 0, B, Tq, H, D)
+    Tqp, Tkp = qt.shape[-1], kt.shape[-1]
+    km = None
+    if masked:
+        km = torch.zeros((B, Tkp), dtype=torch.uint8)
+        km[0, :Tk] = 1
+        km[1, : Tk - 37] = 1
+    scale = D ** -0.5
+    o, lse = ops.attn_fwd(qd, kvd[:, : H * D], vt, B, Tq, H, H, D, False, scale, key_mask=km.to(dev) if masked else None, Tk=Tk,
+                          drop=(pdrop, seed))
+    dq = torch.empty_like(qd)
+    dkv = torch.empty_like(kvd)
+    ops.attn_bwd(qd, kvd[:, : H * D], kvd[:, H * D:], qt, kt, o, dod, dot, lse, dq, dkv[:, : H * D], dkv[:, H * D:], B, Tq, H, H, D,
+                 False, scale, key_mask=km.to(dev) if masked else None, Tk=Tk, drop=(pdrop, seed))
+    keep = torch.from_numpy(G.attn_keep_mask(seed, pdrop, B, H, Tq, Tk, Tqp, Tkp))
+    assert abs(float(keep.mean()) - (1 - pdrop)) < 0.03
+    qf = q.float().view(B, Tq, H, D).transpose(1, 2).requires_grad_(True)
+    kf = kv.float()[:, : H * D].reshape(B, Tk, H, D).transpose(1, 2).requires_grad_(True)
+    vf = kv.float()[:, H * D:].reshape(B, Tk, H, D).transpose(1, 2).requires_grad_(True)
+    sc = qf @ kf.transpose(2, 3) * scale
+    if masked:
+        sc = sc.masked_fill(km[:, None, None, :Tk] == 0, float("-inf"))
+    ref = ((torch.softmax(sc, -1) * keep / (1 - pdrop)) @ vf).transpose(1, 2).reshape(B * Tq, H * D)
+    ref.backward(do.float())
+    assert_close(o, ref.detach(), atol=3e-2, rtol=2e-2, what="attn fwd with dropout")
+    for got, want, nm in ((dq.view(B, Tq, H, D).transpose(1, 2), qf.grad, "dq"), (dkv[:, : H * D].reshape(B, Tk, H, D).transpose(1, 2), kf.grad, "dk"),
+                          (dkv[:, H * D:].reshape(B, Tk, H, D).transpose(1, 2), vf.grad, "dv")):
+        err = (got.float().cpu() - want).abs().max().item()
+        assert err < 4e-2 * max(1.0, want.abs().max().item()), (nm, err, want.abs().max().item())
+    # a different seed gives a different mask; p = 0 equals the plain kernel
+    o2, _ = ops.attn_fwd(qd, kvd[:, : H * D], vt, B, Tq, H, H, D, False, scale, key_mask=km.to(dev) if masked else None, Tk=Tk,
+                         drop=(pdrop, seed + 1))
+    assert not torch.equal(o2, o)
