@@ -1149,7 +1149,9 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     // tiles) pays on short-K products, where prologue + epilogue are a visible share of a tile: +3-4 % at K = 1280
     // (Whisper), +-1 % at K >= 4096 (profiles/r02_gemm_experiments.md)
     if (N <= 64) cfg = 3;
-    else if (t256 < t128) cfg = (K <= 2048) ? g_gemm_big_shortk : g_gemm_big;
+    // 4-wave kernel: faster k-loop, longer epilogue (64 fragments per wave) -- it wins from K = 4096 up unless the output is narrow
+    // (N = 1280 with a residual epilogue, Whisper fc2: 1084 vs 1124 TF for the 8-wave pipelined kernel, tools/gemm_enc_bench.py)
+    else if (t256 < t128) cfg = (K <= 2048) ? g_gemm_big_shortk : ((g_gemm_big == 12 && N < 2048) ? 6 : g_gemm_big);
     else cfg = 1;
   }
   switch (cfg) {

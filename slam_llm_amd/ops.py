@@ -142,7 +142,8 @@ def gemm_kernel_name(M: int, N: int, K: int = 1 << 30) -> str:
         tiles128 = ((M + 127) // 128) * ((N + 127) // 128)
         t256 = ((tiles256 + 255) // 256) * (4.0 / 1.4)
         t128 = ((tiles128 + 511) // 512) * 2.0
-        cfg = 3 if N <= 64 else ((_GEMM_BIG["shortk"] if K <= 2048 else _GEMM_BIG["big"]) if t256 < t128 else 1)
+        big = 6 if (_GEMM_BIG["big"] == 12 and N < 2048) else _GEMM_BIG["big"]
+        cfg = 3 if N <= 64 else ((_GEMM_BIG["shortk"] if K <= 2048 else big) if t256 < t128 else 1)
     return _GEMM_NAMES[cfg]
 
 
