@@ -215,7 +215,15 @@ class FusedLinear:
     def backward(self, dy: torch.Tensor, x_ext: Optional[torch.Tensor], store: Optional[TrainableStore],
                  accumulate: bool, out=None, drop=None) -> torch.Tensor:
         """returns dx_ext [M, K+Rp] (columns [:K] are dL/dx); deposits adapter gradients into the store."""
-        dx_ext = ops.gemm_nt(dy, self.WextT, out=out)
+        if self.Rp and self.K % 256 == 0:
+            # two products instead of one [M, K + Rp] output: the Rp (64) extension columns would open a 17th column of 256-wide
+            # tiles that is 25 % full -- at the Llama qkv shape 799 tiles = 3.12 rounds over 256 CUs, paid as 4 (measured 1.1 PF
+            # vs 1.3 for its neighbours).  K columns = whole tiles, the extension = one narrow (N <= 64) product.
+            dx_ext = out if out is not None else torch.empty((dy.shape[0], self.K + self.Rp), dtype=torch.bfloat16, device=dy.device)
+            ops.gemm_nt(dy, self.WextT[: self.K], out=dx_ext[:, : self.K])
+            ops.gemm_nt(dy, self.WextT[self.K:], out=dx_ext[:, self.K:])
+        else:
+            dx_ext = ops.gemm_nt(dy, self.WextT, out=out)
         if self.adapters:
             # x_ext = [x | u] with u = dropout(x) A^T: the columns [K:] of dx_ext are dL/du, and dL/dx gets the second hop
             xin = x_ext[:, : self.K]
