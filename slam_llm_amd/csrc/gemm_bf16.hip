@@ -271,6 +271,68 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const GemmParams& p, f32x4_t 
   }
 }
 
+// SwiGLU backward fused into the down_proj dX product (act 3): acc = dL/dh for h = silu(gate) * up; p.res = the forward's
+// [gate | up] ([M, 2N]); writes dL/dgate to C[m, n] and dL/dup to C[m, N + n] -- the [M, F] intermediate and its elementwise pass
+// (1.7 GB of traffic per layer at the Llama shape) never touch HBM.  Same arithmetic as swiglu_bwd_kernel (elementwise.hip) on the
+// bf16-rounded product; same 16-byte store scheme as gemm_epilogue_bf16, for both outputs.
+template <int FM, int FN, int WTM, int WTN, bool INNER>
+__device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmParams& p, f32x4_t (&acc)[FM][FN], int m0, int n0, int wm, int wn,
+                                                         int frow, int fg) {
+  static_assert(FN % 2 == 0, "fragments are stored in pairs");
+  const int nbase = n0 + wn * WTN;
+#pragma unroll
+  for (int i = 0; i < FM; i++) {
+    const int m = m0 + wm * WTM + i * 16 + frow;
+    if (!INNER && m >= p.M) continue;
+    const bf16_t* grow = p.res + (int64_t)m * p.ldr + nbase + fg * 4;
+    u16x4_t g4[FN], u4[FN];
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      if (INNER || nbase + j * 16 + fg * 4 < p.N) {
+        g4[j] = *reinterpret_cast<const u16x4_t*>(grow + j * 16);
+        u4[j] = *reinterpret_cast<const u16x4_t*>(grow + p.N + j * 16);
+      } else {
+        g4[j] = u4[j] = u16x4_t{0, 0, 0, 0};
+      }
+    }
+    bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nbase + (fg & 1) * 16 + (fg >> 1) * 8;
+#pragma unroll
+    for (int jp = 0; jp < FN / 2; jp++) {
+      unsigned pg[2][2], pu[2][2];
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++) {
+        const int j = 2 * jp + hh;
+        float dg[4], du[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float gf = bf2f(g4[j][e]), uf = bf2f(u4[j][e]), df = bf2f(f2bf(acc[i][j][e] * p.alpha));
+          const float sg = 1.0f / (1.0f + __expf(-gf));
+          dg[e] = df * uf * sg * (1.0f + gf * (1.0f - sg));
+          du[e] = df * (gf * sg);
+        }
+        pg[hh][0] = pack2bf(dg[0], dg[1]); pg[hh][1] = pack2bf(dg[2], dg[3]);
+        pu[hh][0] = pack2bf(du[0], du[1]); pu[hh][1] = pack2bf(du[2], du[3]);
+      }
+      swap_rows16(pg[0][0], pg[1][0]);
+      swap_rows16(pg[0][1], pg[1][1]);
+      swap_rows16(pu[0][0], pu[1][0]);
+      swap_rows16(pu[0][1], pu[1][1]);
+      bf16_t* c = crow + jp * 32;
+      const int nn = nbase + (2 * jp + (fg & 1)) * 16 + (fg >> 1) * 8;
+      if (INNER || nn + 8 <= p.N) {
+        *reinterpret_cast<uint4*>(c) = make_uint4(pg[0][0], pg[0][1], pg[1][0], pg[1][1]);
+        *reinterpret_cast<uint4*>(c + p.N) = make_uint4(pu[0][0], pu[0][1], pu[1][0], pu[1][1]);
+      } else if (nn < p.N) {   // N % 4 == 0 is enforced by the launcher
+        uint2 o2;
+        o2.x = pg[0][0]; o2.y = pg[0][1];
+        *reinterpret_cast<uint2*>(c) = o2;
+        o2.x = pu[0][0]; o2.y = pu[0][1];
+        *reinterpret_cast<uint2*>(c + p.N) = o2;
+      }
+    }
+  }
+}
+
 // fp32 outputs without bias / activation / residual (weight-gradient products, optionally accumulating): 16 bytes per lane as is
 template <int FM, int FN, int WTM, int WTN, bool ACCUM>
 __device__ __forceinline__ void gemm_epilogue_f32(const GemmParams& p, f32x4_t (&acc)[FM][FN], int m0, int n0, int wm, int wn,
@@ -299,6 +361,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
   if (p.out_f32 && !p.bias && !p.res && p.act == 0) {
     if (p.accumulate) gemm_epilogue_f32<FM, FN, WTM, WTN, true>(p, acc, m0, n0, wm, wn, frow, fg);
     else gemm_epilogue_f32<FM, FN, WTM, WTN, false>(p, acc, m0, n0, wm, wn, frow, fg);
+    return;
+  }
+  if (p.act == 3 && !p.out_f32 && !p.accumulate) {   // (the launcher guarantees no bias and a [gate | up] residual)
+    if ((m0 + wm * WTM + WTM <= p.M) && (n0 + wn * WTN + WTN <= p.N))
+      gemm_epilogue_swiglu_bwd<FM, FN, WTM, WTN, true>(p, acc, m0, n0, wm, wn, frow, fg);
+    else
+      gemm_epilogue_swiglu_bwd<FM, FN, WTM, WTN, false>(p, acc, m0, n0, wm, wn, frow, fg);
     return;
   }
   if (p.out_f32 || p.accumulate || p.act == 3) {
