@@ -149,6 +149,13 @@ __device__ __forceinline__ frag_t lds_read128(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
   return r;
 }
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ u32x2_t lds_read64(unsigned addr) {
+  u32x2_t r;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
 __device__ __forceinline__ void lds_landed(frag_t& r) { asm volatile("" : "+v"(r)); }
 template <int N, class... T>
 __device__ __forceinline__ void lds_wait(T&... regs) {
@@ -479,12 +486,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// backward dQ: workgroup = 4 waves x 16 queries; 32-key K / V / K^T tiles are staged through LDS (shared by the
+// backward dQ: workgroup = 4 waves x QF x 16 queries; 32-key K / V / K^T tiles are staged through LDS (shared by the
 // four waves, next tile prefetched into registers during the MFMA phase)
 //   S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - Delta) * scale, dQ^T += K^T(as [d x keys]) . dS^T
+// Row i of key fragment kf is key 8 (i / 4) + 4 kf + i % 4 of the tile, so the eight dS^T values a lane packs for the
+// last product are keys 8 g .. 8 g + 7 and its K^T operand is ONE 16-byte LDS read.  With QF = 2 every K / V / K^T
+// fragment read from LDS feeds two MFMAs (at QF = 1 the kernel issues one b128 read per MFMA and is LDS-bound).
 // ------------------------------------------------------------------------------------------
-template <int D, bool CAUSAL, bool DROP = false>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+template <int D, bool CAUSAL, bool DROP = false, int QF = 1>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
   constexpr int ROWB = D * 2;
@@ -492,6 +502,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int KCM = KCH - 1;
   constexpr int NKV = 32 * KCH / 256;  // 16-byte chunks per thread of a [32][D] tile
   constexpr int NKT = D * 4 / 256;     // 16-byte chunks per thread of the [D][32] transposed tile
+  constexpr int QB = 64 * QF;          // queries per workgroup
   __shared__ __attribute__((aligned(16))) char lds[2 * 32 * ROWB + D * 64];
   __shared__ unsigned ldsMask[8];  // key-padding mask bytes of the current 32-key tile
   char* ldsK = lds;
@@ -503,43 +514,51 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.Hq / p.Hkv);
   const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
-  const int qb0 = blockIdx.x * 64, qw0 = qb0 + wave * 16;
-  const int q = qw0 + li;
-  const bool qok = q < Tq;
+  const int qb0 = blockIdx.x * QB, qw0 = qb0 + wave * 16 * QF;
 
-  frag_t qf[KD], dof[KD];
+  frag_t qf[QF][KD], dof[QF][KD];
+  float lse2[QF], delta[QF];
+  int qlo[QF];
 #pragma unroll
-  for (int kd = 0; kd < KD; kd++) {
-    qf[kd] = qok ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * Tq + q) * p.ldq + h * D + kd * 32 + g * 8) : zero_frag();
-    dof[kd] = qok ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * Tq + q) * p.lddo + h * D + kd * 32 + g * 8) : zero_frag();
-  }
-  const float lse2 = qok ? p.LSE[((int64_t)b * p.Hq + h) * Tqp + q] * LOG2E : INFINITY;
-  // Delta[q] = sum_d dO[q,d] O[q,d]: this lane already holds a quarter of dO's row; the 4 lanes of a row (li + 16 g)
-  // combine theirs.  Written out for the dK/dV kernel that runs next on the stream (no separate delta pass over O, dO).
-  float delta = 0.f;
-  if (qok) {
+  for (int f = 0; f < QF; f++) {
+    const int q = qw0 + f * 16 + li;
+    const bool qok = q < Tq;
 #pragma unroll
     for (int kd = 0; kd < KD; kd++) {
-      const frag_t of = *reinterpret_cast<const frag_t*>(p.O + ((int64_t)b * Tq + q) * p.ldo + h * D + kd * 32 + g * 8);
-      const u16x8_t ov = __builtin_bit_cast(u16x8_t, of), dv = __builtin_bit_cast(u16x8_t, dof[kd]);
-#pragma unroll
-      for (int e = 0; e < 8; e++) delta = fmaf(bf2f(ov[e]), bf2f(dv[e]), delta);
+      qf[f][kd] = qok ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * Tq + q) * p.ldq + h * D + kd * 32 + g * 8) : zero_frag();
+      dof[f][kd] = qok ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * Tq + q) * p.lddo + h * D + kd * 32 + g * 8) : zero_frag();
     }
+    lse2[f] = qok ? p.LSE[((int64_t)b * p.Hq + h) * Tqp + q] * LOG2E : INFINITY;
+    // Delta[q] = sum_d dO[q,d] O[q,d]: this lane already holds a quarter of dO's row; the 4 lanes of a row (li + 16 g)
+    // combine theirs.  Written out for the dK/dV kernel that runs next on the stream (no separate delta pass over O, dO).
+    float dl = 0.f;
+    if (qok) {
+#pragma unroll
+      for (int kd = 0; kd < KD; kd++) {
+        const frag_t of = *reinterpret_cast<const frag_t*>(p.O + ((int64_t)b * Tq + q) * p.ldo + h * D + kd * 32 + g * 8);
+        const u16x8_t ov = __builtin_bit_cast(u16x8_t, of), dv = __builtin_bit_cast(u16x8_t, dof[f][kd]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) dl = fmaf(bf2f(ov[e]), bf2f(dv[e]), dl);
+      }
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (qok && g == 0) p.Delta[((int64_t)b * p.Hq + h) * Tqp + q] = dl;
+    delta[f] = dl;
+    qlo[f] = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(q, Tq - 1)] : 0;
   }
-  delta += __shfl_xor(delta, 16, 64);
-  delta += __shfl_xor(delta, 32, 64);
-  if (qok && g == 0) p.Delta[((int64_t)b * p.Hq + h) * Tqp + q] = delta;
   const float sl2 = p.scale * LOG2E;
 
-  f32x4_t dq[DF];
+  f32x4_t dq[QF][DF];
 #pragma unroll
-  for (int df = 0; df < DF; df++) dq[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < QF; f++)
+#pragma unroll
+    for (int df = 0; df < DF; df++) dq[f][df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int kend = CAUSAL ? min(Tk, qb0 + 64) : Tk;
+  const int kend = CAUSAL ? min(Tk, qb0 + QB) : Tk;
   const int ntiles = (kend + 31) / 32;
   const bf16_t* ktb = p.Kt + ((int64_t)(b * p.Hkv + hk) * D) * Tkp;
   const int tbeg = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(qb0, Tq - 1)] / 32 : 0;   // packed batches (see AttnParams)
-  const int qlo = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(q, Tq - 1)] : 0;
 
   frag_t kreg[NKV], vreg[NKV], ktreg[NKT];
   unsigned mreg = 0x01010101u;
@@ -586,58 +605,73 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     lstore();
     __syncthreads();
     if (it + 1 < ntiles) gload(k0 + 32);
-    if (qw0 >= Tq || (CAUSAL && k0 > qw0 + 15)) continue;
+    if (qw0 >= Tq || (CAUSAL && k0 > qw0 + 16 * QF - 1)) continue;
 
-    f32x4_t st[2], dpt[2];
+    f32x4_t st[QF][2], dpt[QF][2];
 #pragma unroll
     for (int kf = 0; kf < 2; kf++) {
-      const int row = kf * 16 + li;
-      f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f}, c = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int row = 8 * (li >> 2) + 4 * kf + (li & 3);
+#pragma unroll
+      for (int f = 0; f < QF; f++) {
+        st[f][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dpt[f][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int kd = 0; kd < KD; kd++) {
         const int off = row * ROWB + (((kd * 4 + g) ^ (row & KCM)) << 4);
         const frag_t kfr = *reinterpret_cast<const frag_t*>(ldsK + off);
         const frag_t vfr = *reinterpret_cast<const frag_t*>(ldsV + off);
-        a = mfma16(kfr, qf[kd], a);
-        c = mfma16(vfr, dof[kd], c);
-      }
-      st[kf] = a;
-      dpt[kf] = c;
-    }
 #pragma unroll
-    for (int kf = 0; kf < 2; kf++) {
-      const int kb = k0 + kf * 16 + 4 * g;
-      const unsigned mk = ldsMask[kf * 4 + g];
-      unsigned keep = 0xFu;
-      if constexpr (DROP) keep = attn_keep4(p, b * p.Hq + h, min(q, Tq - 1), kb);
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int key = kb + r;
-        const bool ok = ((mk >> (8 * r)) & 0xffu) != 0 && key < Tk && (!CAUSAL || key <= q) && qok && key >= qlo;
-        const float pv = ok ? fast_exp2(st[kf][r] * sl2 - lse2) : 0.f;
-        const float dpm = DROP ? (((keep >> r) & 1u) ? dpt[kf][r] * p.drop_scale : 0.f) : dpt[kf][r];   // d(dropped P) -> dP
-        st[kf][r] = pv * (dpm - delta) * p.scale;
+        for (int f = 0; f < QF; f++) {
+          st[f][kf] = mfma16(kfr, qf[f][kd], st[f][kf]);
+          dpt[f][kf] = mfma16(vfr, dof[f][kd], dpt[f][kf]);
+        }
       }
     }
-    const frag_t dsb = pack_frag(st[0], st[1]);
+    frag_t dsb[QF];
+    const unsigned mk2 = ldsMask[2 * g], mk3 = ldsMask[2 * g + 1];
+#pragma unroll
+    for (int f = 0; f < QF; f++) {
+      const int q = qw0 + f * 16 + li;
+      const bool qok = q < Tq;
+#pragma unroll
+      for (int kf = 0; kf < 2; kf++) {
+        const int kb = k0 + 8 * g + 4 * kf;
+        const unsigned mk = kf ? mk3 : mk2;
+        unsigned keep = 0xFu;
+        if constexpr (DROP) keep = attn_keep4(p, b * p.Hq + h, min(q, Tq - 1), kb);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int key = kb + r;
+          const bool ok = ((mk >> (8 * r)) & 0xffu) != 0 && key < Tk && (!CAUSAL || key <= q) && qok && key >= qlo[f];
+          const float pv = ok ? fast_exp2(st[f][kf][r] * sl2 - lse2[f]) : 0.f;
+          const float dpm = DROP ? (((keep >> r) & 1u) ? dpt[f][kf][r] * p.drop_scale : 0.f) : dpt[f][kf][r];   // d(dropped P) -> dP
+          st[f][kf][r] = pv * (dpm - delta[f]) * p.scale;
+        }
+      }
+      dsb[f] = pack_frag(st[f][0], st[f][1]);
+    }
 #pragma unroll
     for (int df = 0; df < DF; df++) {
       const int d = df * 16 + li;
-      const int sw = (d >> 2) & 3;
-      const u16x4_t lo = *reinterpret_cast<const u16x4_t*>(ldsKt + d * 64 + (((g >> 1) ^ sw) << 4) + (g & 1) * 8);
-      const u16x4_t hi = *reinterpret_cast<const u16x4_t*>(ldsKt + d * 64 + (((2 + (g >> 1)) ^ sw) << 4) + (g & 1) * 8);
-      dq[df] = mfma16(join_frag(lo, hi), dsb, dq[df]);
+      const frag_t ktf = *reinterpret_cast<const frag_t*>(ldsKt + d * 64 + ((g ^ ((d >> 2) & 3)) << 4));
+#pragma unroll
+      for (int f = 0; f < QF; f++) dq[f][df] = mfma16(ktf, dsb[f], dq[f][df]);
     }
   }
-  if (!qok) return;
-  if (p.rope_cos) rope_grad_inplace<DF>(dq, p.rope_cos, p.rope_sin, p.rope_pos ? p.rope_pos[(int64_t)b * Tq + q] : q, D, g);
-  bf16_t* orow = p.dQ + ((int64_t)b * Tq + q) * p.lddq + h * D;
 #pragma unroll
-  for (int df = 0; df < DF; df++) {
-    uint2 w;
-    w.x = pack2bf(dq[df][0], dq[df][1]);
-    w.y = pack2bf(dq[df][2], dq[df][3]);
-    *reinterpret_cast<uint2*>(orow + df * 16 + 4 * g) = w;
+  for (int f = 0; f < QF; f++) {
+    const int q = qw0 + f * 16 + li;
+    if (q >= Tq) continue;
+    if (p.rope_cos) rope_grad_inplace<DF>(dq[f], p.rope_cos, p.rope_sin, p.rope_pos ? p.rope_pos[(int64_t)b * Tq + q] : q, D, g);
+    bf16_t* orow = p.dQ + ((int64_t)b * Tq + q) * p.lddq + h * D;
+#pragma unroll
+    for (int df = 0; df < DF; df++) {
+      uint2 w;
+      w.x = pack2bf(dq[f][df][0], dq[f][df][1]);
+      w.y = pack2bf(dq[f][df][2], dq[f][df][3]);
+      *reinterpret_cast<uint2*>(orow + df * 16 + 4 * g) = w;
+    }
   }
 }
 
@@ -1127,6 +1161,286 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward dQ, ring form: the arithmetic of attn_bwd_dq_kernel<D, CAUSAL, false, QF> (same fragment mapping, same masks),
+// with the 32-key K | V | K^T tiles DMA'd HBM -> LDS into a ring of 3 stages (two tiles in flight while one is consumed),
+// counted vmcnt waits and ONE raw barrier per tile (the register-staged form needs two __syncthreads and 6 ds_write_b128
+// per thread and tile).  The key-padding mask bytes of a tile ride along as one extra DMA piece of wave 0.
+// ------------------------------------------------------------------------------------------
+template <int D, bool CAUSAL, int QF>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) {
+  constexpr int KD = D / 32;
+  constexpr int DF = D / 16;
+  constexpr int ROWB = D * 2;
+  constexpr int KCH = D / 8;
+  constexpr int NS = 3;                       // ring stages
+  constexpr int SUB = 32 * ROWB;              // bytes of one sub-tile: [32][D] row-major == [D][32] transposed
+  constexpr int STG = 3 * SUB + 1024;         // K | V | K^T | mask[32] (+ the rest of that DMA piece)
+  constexpr int NI = SUB / 1024;              // 1 KiB DMA instructions per sub-tile (8 for D = 128, 4 for D = 64)
+  constexpr int PS = NI / 4;                  // ... per wave and sub-tile
+  constexpr int NU = 3 * PS;                  // tile DMA instructions per wave and stage (wave 0: + 1, the mask line)
+  constexpr int RPI = 1024 / ROWB;            // rows of a row-major sub-tile per DMA instruction (4 | 8)
+  constexpr int QB = 64 * QF;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int hk = h / (p.Hq / p.Hkv);
+  const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
+  const int qb0 = blockIdx.x * QB, qw0 = qb0 + wave * 16 * QF;
+
+  frag_t qf[QF][KD], dof[QF][KD];
+  float lse2[QF], delta[QF];
+  int qlo[QF];
+#pragma unroll
+  for (int f = 0; f < QF; f++) {
+    const int q = qw0 + f * 16 + li;
+    const bool qok = q < Tq;
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) {
+      qf[f][kd] = qok ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * Tq + q) * p.ldq + h * D + kd * 32 + g * 8) : zero_frag();
+      dof[f][kd] = qok ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * Tq + q) * p.lddo + h * D + kd * 32 + g * 8) : zero_frag();
+    }
+    lse2[f] = qok ? p.LSE[((int64_t)b * p.Hq + h) * Tqp + q] * LOG2E : INFINITY;
+    float dl = 0.f;   // Delta[q] = sum_d dO[q,d] O[q,d], written out for the dK/dV kernel that runs next on the stream
+    if (qok) {
+#pragma unroll
+      for (int kd = 0; kd < KD; kd++) {
+        const frag_t of = *reinterpret_cast<const frag_t*>(p.O + ((int64_t)b * Tq + q) * p.ldo + h * D + kd * 32 + g * 8);
+        const u16x8_t ov = __builtin_bit_cast(u16x8_t, of), dv = __builtin_bit_cast(u16x8_t, dof[f][kd]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) dl = fmaf(bf2f(ov[e]), bf2f(dv[e]), dl);
+      }
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (qok && g == 0) p.Delta[((int64_t)b * p.Hq + h) * Tqp + q] = dl;
+    delta[f] = dl;
+    qlo[f] = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(q, Tq - 1)] : 0;
+  }
+  const float sl2 = p.scale * LOG2E;
+  // wave-uniform facts for the mask-free path: all queries of the wave exist; first key the LAST query of the wave may see
+  // (seg_lo is non-decreasing, so every other query of the wave sees at least as far back)
+  const bool wave_all_q = qw0 + 16 * QF <= Tq;
+  int qlo_hi = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(qw0 + 16 * QF - 1, Tq - 1)] : 0;
+  f32x4_t dq[QF][DF];
+#pragma unroll
+  for (int f = 0; f < QF; f++)
+#pragma unroll
+    for (int df = 0; df < DF; df++) dq[f][df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int kend = CAUSAL ? min(Tk, qb0 + QB) : Tk;
+  const int ntiles = (kend + 31) / 32;
+  const int tbeg = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(qb0, Tq - 1)] / 32 : 0;   // packed batches (see AttnParams)
+  // every ordinary load above must have RETURNED before the first asm DMA is issued (see attn_bwd_dkdv_ring_kernel)
+#pragma unroll
+  for (int f = 0; f < QF; f++) {
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) asm volatile("" : "+v"(qf[f][kd]), "+v"(dof[f][kd]));
+    asm volatile("" : "+v"(lse2[f]), "+v"(delta[f]), "+v"(qlo[f]));
+  }
+  int tb = tbeg;
+  asm volatile("" : "+s"(tb), "+s"(qlo_hi));
+
+  // ---- DMA issue.  Sub-tile sub (0 K, 1 V, 2 K^T) is NI pieces of 1 KiB; this wave owns pieces j = wave + 4 v (v < PS) of
+  // each.  Row-major pieces cover RPI rows (lane -> row, 16-byte chunk; the XOR swizzle is applied to the SOURCE chunk, the LDS
+  // image is lane-linear), transposed pieces 16 d-rows of 64 bytes.  Rows past the end of the tensor read as zeros (descriptor
+  // range check); rows past Tk of a batch in the middle read the next batch's rows, which the key < Tk mask discards. ----
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_offset_of(lds));
+  const int nB = gridDim.z;
+  const __amdgpu_buffer_rsrc_t srd_k = __builtin_amdgcn_make_buffer_rsrc((void*)p.K, 0, (unsigned)((((int64_t)nB * Tk - 1) * p.ldk + (int64_t)p.Hkv * D) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_v = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, (unsigned)((((int64_t)nB * Tk - 1) * p.ldv + (int64_t)p.Hkv * D) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_kt = __builtin_amdgcn_make_buffer_rsrc((void*)p.Kt, 0, (unsigned)((int64_t)nB * p.Hkv * D * Tkp * 2), 0x00020000);
+  unsigned voff[NU], dsto[NU];
+#pragma unroll
+  for (int u = 0; u < NU; u++) {
+    const int sub = u / PS, j = (u % PS) * 4 + wave;
+    if (sub < 2) {
+      const int row = j * RPI + lane / KCH, c = lane % KCH;
+      const int64_t ld = sub ? p.ldv : p.ldk;
+      voff[u] = (unsigned)(((int64_t)b * Tk + row) * ld + hk * D + ((c ^ ring_swz<D>(row)) << 3)) * 2u;
+    } else {
+      const int d = j * 16 + (lane >> 2), c = lane & 3;
+      voff[u] = (unsigned)((((int64_t)b * p.Hkv + hk) * D + d) * Tkp + ((c ^ ((d >> 2) & 3)) << 3)) * 2u;
+    }
+    dsto[u] = (unsigned)(sub * SUB + j * 1024);
+  }
+  // the mask line: lanes 0 / 1 carry the 32 mask bytes of the tile, the other lanes repeat lane 0's address
+  const uint8_t* mk_src = p.kmask ? p.kmask + (int64_t)b * Tkp + (lane == 1 ? 16 : 0) : reinterpret_cast<const uint8_t*>(p.Kt);
+  const unsigned ldk2 = (unsigned)p.ldk * 2u, ldv2 = (unsigned)p.ldv * 2u;
+  auto issue = [&](int tile, int s) {
+    const int k0 = min(tile, ntiles - 1) * 32;   // past the end: the last tile again, into a stage nobody reads
+    const unsigned st = lds0 + (unsigned)(s * STG);
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const int sub = u / PS;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(st + dsto[u]);
+      const unsigned so = sub == 0 ? (unsigned)k0 * ldk2 : (sub == 1 ? (unsigned)k0 * ldv2 : (unsigned)k0 * 2u);
+      bufdma16_asm(sub == 0 ? srd_k : (sub == 1 ? srd_v : srd_kt), voff[u] + __builtin_amdgcn_readfirstlane(so), dst);
+    }
+    if (wave == 0) glds16_asm(mk_src + (p.kmask ? k0 : 0), __builtin_amdgcn_readfirstlane(st + (unsigned)(3 * SUB)));
+  };
+
+  // per-lane LDS read offsets (stage 0): K / V fragment kf, A-operand row i = li is tile row 8 (i / 4) + 4 kf + i % 4
+  int aA[KD];
+  {
+    const int row = 8 * (li >> 2) + (li & 3);
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) aA[kd] = row * ROWB + (((kd * 4 + g) ^ ring_swz<D>(row)) << 4);
+  }
+  const int aB = 2 * SUB + li * 64 + ((g ^ ((li >> 2) & 3)) << 4);
+  const int aM = 3 * SUB + 8 * g;
+
+  if (ntiles > tb) {
+    issue(tb, 0);
+    issue(tb + 1, 1);
+  }
+  int s = 0;
+  for (int it = tb; it < ntiles; it++) {
+    const int k0 = it * 32;
+    // tile `it` has landed when at most the younger tile's DMA of this wave is outstanding; after the barrier every wave's
+    // share has, and everybody is done reading the stage of tile it - 1, which the next DMA refills
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NU + 1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NU) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int sc = s;
+    {
+      const int s2 = s == 0 ? NS - 1 : s - 1;   // (s + 2) % 3
+      issue(it + 2, s2);
+    }
+    s = s == NS - 1 ? 0 : s + 1;
+    if (qw0 >= Tq || (CAUSAL && k0 > qw0 + 16 * QF - 1)) continue;
+
+    // LDS reads and their waits placed by hand (see attn_bwd_dkdv_ring_kernel): fragment 0's K / V operands and the mask
+    // first, fragment 1's while fragment 0's products run, the K^T operands while fragment 1's run and through the softmax
+    const unsigned so = lds0 + (unsigned)(sc * STG);
+    unsigned rA[KD];
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) rA[kd] = so + (unsigned)aA[kd];
+    const unsigned rB = so + (unsigned)aB, rM = so + (unsigned)aM;
+    frag_t k0f[KD], v0f[KD], k1f[KD], v1f[KD], ktf[DF];
+    u32x2_t mk;
+    static_for<0, KD>([&](auto kd) {
+      k0f[kd] = lds_read128<0>(rA[kd]);
+      v0f[kd] = lds_read128<SUB>(rA[kd]);
+    });
+    mk = lds_read64<0>(rM);
+    f32x4_t st[QF][2], dpt[QF][2];
+#pragma unroll
+    for (int f = 0; f < QF; f++)
+#pragma unroll
+      for (int kf = 0; kf < 2; kf++) {
+        st[f][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dpt[f][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    static_for<0, KD>([&](auto kd) {
+      lds_wait<2 * KD - 1>(k0f[kd], v0f[kd]);
+      k1f[kd] = lds_read128<4 * ROWB>(rA[kd]);
+      v1f[kd] = lds_read128<SUB + 4 * ROWB>(rA[kd]);
+#pragma unroll
+      for (int f = 0; f < QF; f++) {
+        st[f][0] = mfma16(k0f[kd], qf[f][kd], st[f][0]);
+        dpt[f][0] = mfma16(v0f[kd], dof[f][kd], dpt[f][0]);
+      }
+    });
+    static_for<0, KD>([&](auto kd) {
+      if constexpr (kd == 0) {
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * KD - 2) : "memory");
+        asm volatile("" : "+v"(mk));
+        lds_landed(k1f[kd]);
+        lds_landed(v1f[kd]);
+      } else {
+        lds_wait<2 * KD - 2>(k1f[kd], v1f[kd]);
+      }
+      ktf[2 * kd] = lds_read128<(2 * kd) * 1024>(rB);
+      ktf[2 * kd + 1] = lds_read128<(2 * kd + 1) * 1024>(rB);
+#pragma unroll
+      for (int f = 0; f < QF; f++) {
+        st[f][1] = mfma16(k1f[kd], qf[f][kd], st[f][1]);
+        dpt[f][1] = mfma16(v1f[kd], dof[f][kd], dpt[f][1]);
+      }
+    });
+    static_assert(DF == 2 * KD, "two K^T fragments are requested per k-step above");
+    if (!p.kmask) mk = u32x2_t{0x01010101u, 0x01010101u};
+    frag_t dsb[QF];
+    // interior tile: every (key, query) pair of this wave is visible -- no masks (most tiles of a long causal sequence)
+    const bool interior = wave_all_q && k0 + 32 <= Tk && (!CAUSAL || k0 + 31 <= qw0) && k0 >= qlo_hi &&
+                          __all(mk[0] == 0x01010101u && mk[1] == 0x01010101u);
+    if (interior) {
+#pragma unroll
+      for (int f = 0; f < QF; f++) {
+#pragma unroll
+        for (int kf = 0; kf < 2; kf++) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float pv = fast_exp2(__builtin_fmaf(st[f][kf][r], sl2, -lse2[f]));
+            st[f][kf][r] = pv * (dpt[f][kf][r] - delta[f]) * p.scale;
+          }
+        }
+        dsb[f] = pack_frag(st[f][0], st[f][1]);
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < QF; f++) {
+        const int q = qw0 + f * 16 + li;
+        const bool qok = q < Tq;
+#pragma unroll
+        for (int kf = 0; kf < 2; kf++) {
+          const int kb = k0 + 8 * g + 4 * kf;
+          const unsigned m4 = kf ? mk[1] : mk[0];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int key = kb + r;
+            const bool ok = ((m4 >> (8 * r)) & 0xffu) != 0 && key < Tk && (!CAUSAL || key <= q) && qok && key >= qlo[f];
+            const float pv = ok ? fast_exp2(__builtin_fmaf(st[f][kf][r], sl2, -lse2[f])) : 0.f;
+            st[f][kf][r] = pv * (dpt[f][kf][r] - delta[f]) * p.scale;
+          }
+        }
+        dsb[f] = pack_frag(st[f][0], st[f][1]);
+      }
+    }
+    static_for<0, DF>([&](auto df) {
+      lds_wait<DF - 1 - df>(ktf[df]);
+#pragma unroll
+      for (int f = 0; f < QF; f++) dq[f][df] = mfma16(ktf[df], dsb[f], dq[f][df]);
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMAs still target this workgroup's LDS
+#pragma unroll
+  for (int f = 0; f < QF; f++) {
+    const int q = qw0 + f * 16 + li;
+    if (q >= Tq) continue;
+    if (p.rope_cos) rope_grad_inplace<DF>(dq[f], p.rope_cos, p.rope_sin, p.rope_pos ? p.rope_pos[(int64_t)b * Tq + q] : q, D, g);
+    bf16_t* orow = p.dQ + ((int64_t)b * Tq + q) * p.lddq + h * D;
+#pragma unroll
+    for (int df = 0; df < DF; df++) {
+      uint2 w;
+      w.x = pack2bf(dq[f][df][0], dq[f][df][1]);
+      w.y = pack2bf(dq[f][df][2], dq[f][df][3]);
+      *reinterpret_cast<uint2*>(orow + df * 16 + 4 * g) = w;
+    }
+  }
+}
+
+template <int D, bool CAUSAL, int QF>
+int launch_dq_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
+  constexpr int lds = 3 * (3 * 32 * D * 2 + 1024);
+  static bool attr_set = false;
+  auto kern = attn_bwd_dq_ring_kernel<D, CAUSAL, QF>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      slam_set_error("slam_attn_bwd: cannot raise the LDS limit to %d", lds);
+      return -2;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  return 0;
+}
+
 template <int D, bool CAUSAL, int ABL = 0>
 int launch_dkdv_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr int lds = 4 * (4 * 32 * D * 2 + 1024);
@@ -1143,7 +1457,7 @@ int launch_dkdv_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
   return 0;
 }
 
-int g_attn_bwd_variant = 0;   // 0 = ring kernels (shipped), 1 = round-1 kernels (A/B reference for tools)
+int g_attn_bwd_variant = 0;   // 0 = ring kernels (shipped), 1 = round-1 kernels, 2 = ring dK/dV + register-staged dQ (A/B in tools)
 int g_attn_fwd_qf = 0;   // 16-row query fragments per wave of the forward kernel: 0 = auto, 1 / 2 forced (tools)
 
 int check_common(const char* name, int64_t B, int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv,
@@ -1160,7 +1474,7 @@ int check_common(const char* name, int64_t B, int64_t Tq, int64_t Tk, int64_t Tq
 }  // namespace
 
 extern "C" int slam_attn_set_bwd_variant(int variant) {   // tools: 0 = DMA-ring backward kernels (shipped), 1 = round-1 kernels
-  SLAM_CHECK_ARG(variant == 0 || variant == 1 || variant == 11 || variant == 12 || variant == 15, "slam_attn_set_bwd_variant: %d (0 | 1 | 11, 12, 15 timing ablations)", variant);
+  SLAM_CHECK_ARG(variant == 0 || variant == 1 || variant == 2 || variant == 11 || variant == 12 || variant == 15, "slam_attn_set_bwd_variant: %d (0 | 1 | 2 | 11, 12, 15 timing ablations)", variant);
   g_attn_bwd_variant = variant;
   return 0;
 }
@@ -1226,6 +1540,24 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   return 0;
 }
 
+// dQ launch: 32 queries per wave (128 per workgroup) once there is more than one 64-query block; the ring form whenever the
+// 32-bit byte offsets of its DMA descriptors can address the tensors (variant 2: register-staged form, for A/B in tools)
+template <int D, bool CAUSAL>
+static int launch_dq(const AttnParams& p, int64_t B, hipStream_t s) {
+  if (p.Tq > 64 && g_attn_bwd_variant != 1) {
+    dim3 g2((unsigned)cdiv64(p.Tq, 128), (unsigned)p.Hq, (unsigned)B);
+    const int64_t lim = (int64_t)1 << 31;
+    const bool fits = (B * p.Tk * p.ldk + (int64_t)p.Hkv * D) * 2 < lim && (B * p.Tk * p.ldv + (int64_t)p.Hkv * D) * 2 < lim &&
+                      B * p.Hkv * D * p.Tkp * 2 < lim;
+    if (fits && g_attn_bwd_variant != 2) return launch_dq_ring<D, CAUSAL, 2>(p, g2, s);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL, false, 2>), g2, dim3(256), 0, s, p);
+  } else {
+    dim3 g1((unsigned)cdiv64(p.Tq, 64), (unsigned)p.Hq, (unsigned)B);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL, false, 1>), g1, dim3(256), 0, s, p);
+  }
+  return 0;
+}
+
 extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V,
                              int64_t ldv, const void* Qt, const void* Kt, const void* O, int64_t ldo,
                              const void* dO, int64_t lddo, const void* dOt, const float* LSE,
@@ -1265,13 +1597,12 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
     SLAM_CHECK_LAUNCH("slam_attn_bwd");
     return 0;
   }
-  dim3 gq((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B);
   dim3 gk((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);
   dim3 gk2((unsigned)cdiv64(Tk, 128), (unsigned)Hkv, (unsigned)B);
   const bool ring = g_attn_bwd_variant != 1;
   int rc = 0;
   if (g_attn_bwd_variant > 10 && D == 128 && causal) {   // timing ablations of the D = 128 causal ring kernel (tools only)
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, dim3(256), 0, s, p);
+    if ((rc = launch_dq<128, true>(p, B, s))) return rc;
     switch (g_attn_bwd_variant) {
       case 11: rc = launch_dkdv_ring<128, true, 1>(p, gk2, s); break;
       case 12: rc = launch_dkdv_ring<128, true, 2>(p, gk2, s); break;
@@ -1283,18 +1614,18 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   }
   if (D == 64) {
     if (causal) {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, dim3(256), 0, s, p);
+      if ((rc = launch_dq<64, true>(p, B, s))) return rc;
       if (ring) rc = launch_dkdv_ring<64, true>(p, gk2, s); else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true>), gk, dim3(256), 0, s, p);
     } else {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), gq, dim3(256), 0, s, p);
+      if ((rc = launch_dq<64, false>(p, B, s))) return rc;
       if (ring) rc = launch_dkdv_ring<64, false>(p, gk2, s); else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false>), gk, dim3(256), 0, s, p);
     }
   } else {
     if (causal) {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, dim3(256), 0, s, p);
+      if ((rc = launch_dq<128, true>(p, B, s))) return rc;
       if (ring) rc = launch_dkdv_ring<128, true>(p, gk2, s); else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, true>), gk, dim3(256), 0, s, p);
     } else {
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, false>), gq, dim3(256), 0, s, p);
+      if ((rc = launch_dq<128, false>(p, B, s))) return rc;
       if (ring) rc = launch_dkdv_ring<128, false>(p, gk2, s); else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false>), gk, dim3(256), 0, s, p);
     }
   }

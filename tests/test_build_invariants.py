@@ -1,6 +1,6 @@
 """CPU: invariants of the compiled gfx950 code that the hand-scheduled kernels rely on.
 
-The k-loop of gemm_nt_w4_kernel, the tile loops of attn_fwd_kernel and attn_bwd_dkdv_ring_kernel place their LDS reads, LDS-DMA and
+The k-loop of gemm_nt_w4_kernel, the tile loops of attn_fwd_kernel, attn_bwd_dkdv_ring_kernel and attn_bwd_dq_ring_kernel place their LDS reads, LDS-DMA and
 MFMAs as `asm volatile` statements whose result registers are "ready" for the compiler at once.  If hipcc ever SPILLS such a
 register (stores it to scratch before the data has landed) the kernel computes garbage -- it happened once with three
 instantiations of the GEMM tile body (876 bytes of scratch, wrong results).  Zero scratch is therefore a build invariant."""
@@ -17,7 +17,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # (gemm_nt_persist2_kernel is compiler-scheduled -- no asm loads -- and spills three loop-invariant dwords around the epilogue inside
 # its tile loop: harmless, not part of the invariant)
 FILES = {"gemm_bf16.hip": ([], ("gemm_nt_w4_kernel", "gemm_nt_pipe_kernel")),
-         "attention.hip": (["-mllvm", "-amdgpu-mfma-vgpr-form"], ("attn_fwd_kernel", "attn_bwd_dkdv_ring_kernel"))}
+         "attention.hip": (["-mllvm", "-amdgpu-mfma-vgpr-form"], ("attn_fwd_kernel", "attn_bwd_dkdv_ring_kernel", "attn_bwd_dq_ring_kernel"))}
 
 
 def _scratch_by_kernel(src, extra):

@@ -50,7 +50,8 @@ ABL = {11: "no DMA in loop", 12: "no softmax VALU", 15: "no barrier"}
 
 
 for name, f, flops in (("fwd", fwd, 4.0 * B * Hq * T * T * D * 0.5), ("bwd (ring kernels)", bwd, 10.0 * B * Hq * T * T * D * 0.5),
-                       ("bwd (round-1 kernels)", bwd_old, 10.0 * B * Hq * T * T * D * 0.5)) + tuple(
+                       ("bwd (round-1 kernels)", bwd_old, 10.0 * B * Hq * T * T * D * 0.5),
+                       ("bwd (ring dK/dV, register-staged dQ)", variant(2), 10.0 * B * Hq * T * T * D * 0.5)) + tuple(
                            (f"bwd ablation: {n}", variant(v), 10.0 * B * Hq * T * T * D * 0.5) for v, n in ABL.items()):
     for _ in range(3):
         f()
