@@ -1167,7 +1167,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
 // counted vmcnt waits and ONE raw barrier per tile (the register-staged form needs two __syncthreads and 6 ds_write_b128
 // per thread and tile).  The key-padding mask bytes of a tile ride along as one extra DMA piece of wave 0.
 // ------------------------------------------------------------------------------------------
-template <int D, bool CAUSAL, int QF>
+__device__ unsigned long long g_attn_probe[2 * 16 * 8];   // tools: cycle stamps of two waves of one workgroup (PROBE form)
+
+template <int D, bool CAUSAL, int QF, bool PROBE = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
@@ -1186,6 +1188,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
+  // (giving the four waves the same 32 queries of the four heads of a GQA group instead -- every wave then runs to the same
+  // causal diagonal, 19 % fewer workgroup-tiles at the Llama shape -- measured the same kernel time:
+  // profiles/r02_attention_bwd.md)
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.Hq / p.Hkv);
   const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
@@ -1221,9 +1226,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
     qlo[f] = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(q, Tq - 1)] : 0;
   }
   const float sl2 = p.scale * LOG2E;
-  // wave-uniform facts for the mask-free path: all queries of the wave exist; first key the LAST query of the wave may see
-  // (seg_lo is non-decreasing, so every other query of the wave sees at least as far back)
-  const bool wave_all_q = qw0 + 16 * QF <= Tq;
+  // wave-uniform fact for the mask-free path: first key the LAST query of the wave may see (seg_lo is non-decreasing, so
+  // every other query of the wave sees at least as far back)
   int qlo_hi = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(qw0 + 16 * QF - 1, Tq - 1)] : 0;
   f32x4_t dq[QF][DF];
 #pragma unroll
@@ -1298,20 +1302,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
     issue(tb + 1, 1);
   }
   int s = 0;
+  const bool prb = PROBE && blockIdx.x == 2 && blockIdx.y == 5 && blockIdx.z == 3 && (wave == 0 || wave == 3);
+  auto stamp = [&](int it, int i) {
+    if constexpr (PROBE) {
+      if (prb) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if (lane == 0 && it < 16) g_attn_probe[((wave ? 1 : 0) * 16 + it) * 8 + i] = t;
+      }
+    }
+  };
   for (int it = tb; it < ntiles; it++) {
     const int k0 = it * 32;
+    stamp(it, 0);
     // tile `it` has landed when at most the younger tile's DMA of this wave is outstanding; after the barrier every wave's
     // share has, and everybody is done reading the stage of tile it - 1, which the next DMA refills
     if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NU + 1) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NU) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    stamp(it, 1);
     const int sc = s;
     {
       const int s2 = s == 0 ? NS - 1 : s - 1;   // (s + 2) % 3
       issue(it + 2, s2);
     }
     s = s == NS - 1 ? 0 : s + 1;
+    stamp(it, 2);
     if (qw0 >= Tq || (CAUSAL && k0 > qw0 + 16 * QF - 1)) continue;
 
     // LDS reads and their waits placed by hand (see attn_bwd_dkdv_ring_kernel): fragment 0's K / V operands and the mask
@@ -1364,11 +1380,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
       }
     });
     static_assert(DF == 2 * KD, "two K^T fragments are requested per k-step above");
+    stamp(it, 3);
     if (!p.kmask) mk = u32x2_t{0x01010101u, 0x01010101u};
     frag_t dsb[QF];
-    // interior tile: every (key, query) pair of this wave is visible -- no masks (most tiles of a long causal sequence)
-    const bool interior = wave_all_q && k0 + 32 <= Tk && (!CAUSAL || k0 + 31 <= qw0) && k0 >= qlo_hi &&
-                          __all(mk[0] == 0x01010101u && mk[1] == 0x01010101u);
+    // interior tile: every (key, query) pair of this wave is visible -- no masks (most tiles of a long causal sequence).
+    // Query rows past Tq need no mask: their Q / dO fragments are zero and their LSE is +inf, so P and dS come out as 0.
+    const bool all_keys = __all(mk[0] == 0x01010101u && mk[1] == 0x01010101u);
+    const bool interior = all_keys && k0 + 32 <= Tk && (!CAUSAL || k0 + 31 <= qw0) && k0 >= qlo_hi;
     if (interior) {
 #pragma unroll
       for (int f = 0; f < QF; f++) {
@@ -1383,18 +1401,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
         dsb[f] = pack_frag(st[f][0], st[f][1]);
       }
     } else {
+      // diagonal / boundary / padded tile: query q sees the key RANGE [qlo, min(q, Tk - 1)] (one unsigned compare per element
+      // instead of four predicates) minus the padded keys
+      const int kbase = k0 + 8 * g;
 #pragma unroll
       for (int f = 0; f < QF; f++) {
         const int q = qw0 + f * 16 + li;
-        const bool qok = q < Tq;
+        const int hi = q < Tq ? (CAUSAL ? min(q, Tk - 1) : Tk - 1) : qlo[f] - 1;
+        const unsigned span = (unsigned)(hi - qlo[f]);
+        const bool any = hi >= qlo[f];
+        const int rel = kbase - qlo[f];
 #pragma unroll
         for (int kf = 0; kf < 2; kf++) {
-          const int kb = k0 + 8 * g + 4 * kf;
           const unsigned m4 = kf ? mk[1] : mk[0];
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const int key = kb + r;
-            const bool ok = ((m4 >> (8 * r)) & 0xffu) != 0 && key < Tk && (!CAUSAL || key <= q) && qok && key >= qlo[f];
+            const bool ok = any && (unsigned)(rel + 4 * kf + r) <= span && (m4 & (0xffu << (8 * r))) != 0;
             const float pv = ok ? fast_exp2(__builtin_fmaf(st[f][kf][r], sl2, -lse2[f])) : 0.f;
             st[f][kf][r] = pv * (dpt[f][kf][r] - delta[f]) * p.scale;
           }
@@ -1402,16 +1424,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
         dsb[f] = pack_frag(st[f][0], st[f][1]);
       }
     }
+    stamp(it, 4);
     static_for<0, DF>([&](auto df) {
       lds_wait<DF - 1 - df>(ktf[df]);
 #pragma unroll
       for (int f = 0; f < QF; f++) dq[f][df] = mfma16(ktf[df], dsb[f], dq[f][df]);
     });
+    stamp(it, 5);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMAs still target this workgroup's LDS
+  int li_e = li;
+  asm volatile("" : "+v"(li_e));   // recompute the row addresses here instead of keeping them alive across the tile loop
 #pragma unroll
   for (int f = 0; f < QF; f++) {
-    const int q = qw0 + f * 16 + li;
+    const int q = qw0 + f * 16 + li_e;
     if (q >= Tq) continue;
     if (p.rope_cos) rope_grad_inplace<DF>(dq[f], p.rope_cos, p.rope_sin, p.rope_pos ? p.rope_pos[(int64_t)b * Tq + q] : q, D, g);
     bf16_t* orow = p.dQ + ((int64_t)b * Tq + q) * p.lddq + h * D;
@@ -1425,11 +1451,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
   }
 }
 
-template <int D, bool CAUSAL, int QF>
+template <int D, bool CAUSAL, int QF, bool PROBE = false>
 int launch_dq_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr int lds = 3 * (3 * 32 * D * 2 + 1024);
   static bool attr_set = false;
-  auto kern = attn_bwd_dq_ring_kernel<D, CAUSAL, QF>;
+  auto kern = attn_bwd_dq_ring_kernel<D, CAUSAL, QF, PROBE>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       slam_set_error("slam_attn_bwd: cannot raise the LDS limit to %d", lds);
@@ -1473,8 +1499,18 @@ int check_common(const char* name, int64_t B, int64_t Tq, int64_t Tk, int64_t Tq
 
 }  // namespace
 
+extern "C" int slam_attn_debug_clock(unsigned long long* out256) {   // tools: stamps of the last PROBE dQ launch (variant 14; sync first)
+  SLAM_CHECK_ARG(out256 != nullptr, "slam_attn_debug_clock: null output");
+  hipError_t e = hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_attn_probe), 256 * sizeof(unsigned long long));
+  if (e != hipSuccess) {
+    slam_set_error("slam_attn_debug_clock: %s", hipGetErrorString(e));
+    return -2;
+  }
+  return 0;
+}
+
 extern "C" int slam_attn_set_bwd_variant(int variant) {   // tools: 0 = DMA-ring backward kernels (shipped), 1 = round-1 kernels
-  SLAM_CHECK_ARG(variant == 0 || variant == 1 || variant == 2 || variant == 11 || variant == 12 || variant == 15, "slam_attn_set_bwd_variant: %d (0 | 1 | 2 | 11, 12, 15 timing ablations)", variant);
+  SLAM_CHECK_ARG(variant == 0 || variant == 1 || variant == 2 || variant == 14 || variant == 11 || variant == 12 || variant == 15, "slam_attn_set_bwd_variant: %d (0 | 1 | 2 | 11, 12, 15 timing ablations)", variant);
   g_attn_bwd_variant = variant;
   return 0;
 }
@@ -1549,6 +1585,9 @@ static int launch_dq(const AttnParams& p, int64_t B, hipStream_t s) {
     const int64_t lim = (int64_t)1 << 31;
     const bool fits = (B * p.Tk * p.ldk + (int64_t)p.Hkv * D) * 2 < lim && (B * p.Tk * p.ldv + (int64_t)p.Hkv * D) * 2 < lim &&
                       B * p.Hkv * D * p.Tkp * 2 < lim;
+    if (fits && g_attn_bwd_variant == 14) {
+      if constexpr (D == 128 && CAUSAL) return launch_dq_ring<D, CAUSAL, 2, true>(p, g2, s);
+    }
     if (fits && g_attn_bwd_variant != 2) return launch_dq_ring<D, CAUSAL, 2>(p, g2, s);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL, false, 2>), g2, dim3(256), 0, s, p);
   } else {

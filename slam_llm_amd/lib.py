@@ -34,6 +34,7 @@ SIGNATURES = {
     "slam_gemm_debug_clock": [P],
     "slam_attn_set_fwd_qf": [I32],
     "slam_attn_set_bwd_variant": [I32],
+    "slam_attn_debug_clock": [P],
     "slam_conv1d_k3_im2col": [P, I32, P, I64, I64, I64, I64, I64, P, P],
     "slam_conv1d_k3_col2im": [P, I64, P, I64, I64, I64, I64, P],
     "slam_gather_rows_bf16": [P, I64, P, P, I64, I64, I64, P],

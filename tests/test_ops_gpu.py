@@ -311,6 +311,42 @@ def test_attention_bwd(dev, B, T, Hq, Hkv, D, masked):
     assert torch.equal(fused[:, (Hq + Hkv) * D:], dqkv[:, (Hq + Hkv) * D:])  # dV untouched by RoPE
 
 
+@pytest.mark.parametrize("B,T,Hq,Hkv,D", [(2, 380, 8, 2, 128), (1, 200, 4, 1, 64), (2, 130, 4, 4, 64), (1, 97, 2, 1, 128)])
+def test_attention_bwd_dq_forms_agree(dev, B, T, Hq, Hkv, D):
+    """the dQ launch forms (DMA ring, register-staged tiles with 32 / 16 queries per wave) are the same arithmetic in the
+    same order: their dQ must agree to rounding noise, with left padding and RoPE"""
+    ops = _ops()
+    from slam_llm_amd.lib import call
+    from slam_llm_amd.host_tables import rope_tables
+    qkv, q2, k2, v2, qt, kt, vt = _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed=31)
+    Tp = vt.shape[-1]
+    km = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
+    km[:, :T] = 1
+    km[0, :5] = 0
+    scale = D ** -0.5
+    cos, sin = (t.to(dev) for t in rope_tables(T, D, 10000.0))
+    o, lse = ops.attn_fwd(q2, k2, vt, B, T, Hq, Hkv, D, True, scale, key_mask=km)
+    do = rnd((B * T, Hq * D), dev, seed=32)
+    do.view(B, T, Hq * D)[0, :5] = 0
+    dot = ops.head_rope_transpose(do, 0, B, T, Hq, D)
+    outs = {}
+    try:
+        for v in (0, 2, 1):
+            call("slam_attn_set_bwd_variant", v)
+            g = torch.zeros_like(qkv)
+            ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, g[:, : Hq * D], g[:, Hq * D:(Hq + Hkv) * D], g[:, (Hq + Hkv) * D:],
+                         B, T, Hq, Hkv, D, True, scale, key_mask=km, rope=(cos, sin))
+            outs[v] = g[:, : Hq * D].float()
+    finally:
+        call("slam_attn_set_bwd_variant", 0)
+    ref = outs[1]
+    tol = 1e-2 * float(ref.abs().max())
+    for v in (0, 2):
+        assert torch.isfinite(outs[v]).all()
+        assert float((outs[v] - ref).abs().max()) <= tol, (v, float((outs[v] - ref).abs().max()), tol)
+    assert float((outs[0] - outs[2]).abs().max()) <= 1e-3 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("lens,Hq,Hkv,D", [((70, 133, 37), 4, 2, 128), ((5, 64, 1, 200, 63), 2, 2, 64), ((380, 380), 4, 1, 128)])
 def test_packed_sequences_attention_equals_per_sequence(dev, lens, Hq, Hkv, D):
     """packed ("varlen") causal attention: sequences concatenated along T with seg_lo / seg_hi == attention run on every

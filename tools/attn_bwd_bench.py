@@ -49,21 +49,31 @@ bwd_old = variant(1)
 ABL = {11: "no DMA in loop", 12: "no softmax VALU", 15: "no barrier"}
 
 
-for name, f, flops in (("fwd", fwd, 4.0 * B * Hq * T * T * D * 0.5), ("bwd (ring kernels)", bwd, 10.0 * B * Hq * T * T * D * 0.5),
-                       ("bwd (round-1 kernels)", bwd_old, 10.0 * B * Hq * T * T * D * 0.5),
-                       ("bwd (ring dK/dV, register-staged dQ)", variant(2), 10.0 * B * Hq * T * T * D * 0.5)) + tuple(
-                           (f"bwd ablation: {n}", variant(v), 10.0 * B * Hq * T * T * D * 0.5) for v, n in ABL.items()):
-    for _ in range(3):
-        f()
+def timed(f, n=10):
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(20):
+    for _ in range(n):
         f()
     e.record()
     torch.cuda.synchronize()
-    us = s.elapsed_time(e) * 1e3 / 20
-    print(f"{name}: {us:.1f} us  {flops / us / 1e6:.1f} TF", flush=True)
+    return s.elapsed_time(e) * 1e3 / n
+
+
+# the clocks follow the recent load (power limit): variants are timed INTERLEAVED, five rounds, best and median reported
+CASES = [("fwd", fwd, 4.0), ("bwd (ring kernels)", bwd, 10.0), ("bwd (round-1 kernels)", bwd_old, 10.0),
+         ("bwd (ring dK/dV, register-staged dQ)", variant(2), 10.0)] + [(f"bwd ablation: {n}", variant(v), 10.0) for v, n in ABL.items()]
+for _, f, _ in CASES:
+    for _ in range(3):
+        f()
+res = {n: [] for n, _, _ in CASES}
+for _ in range(5):
+    for n, f, _ in CASES:
+        res[n].append(timed(f))
+for n, _, c in CASES:
+    v = sorted(res[n])
+    flops = c * B * Hq * T * T * D * 0.5
+    print(f"{n}: best {v[0]:.1f} us  median {v[2]:.1f} us  {flops / v[2] / 1e6:.1f} TF", flush=True)
 
 from slam_llm_amd.lib import call  # noqa: E402
 call("slam_attn_set_fwd_qf", 1)
