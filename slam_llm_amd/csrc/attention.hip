@@ -193,10 +193,33 @@ __device__ __forceinline__ int fwd_swz(int row) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The DMA is issued from inline asm: hipcc (ROCm 7.2) protects every LDS read that follows a global_load_lds BUILTIN with
+// s_waitcnt vmcnt(0) (it cannot tell the ring stages apart), which drains the three tiles in flight on every iteration.  An
+// asm DMA is invisible to that bookkeeping; the counted vmcnt + barrier below order it by hand.  M0 (the DMA's LDS base) is
+// compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(lds_dst_uniform)
+               : "memory");
+}
+// buffer-descriptor form (buffer_load_dwordx4 ... offen lds): one 32-bit byte offset per lane, range-checked against
+// num_records (rows past the end of the tensor read as zeros: no clamps), the tile part of the address is a scalar
+__device__ __forceinline__ void bufdma16_asm(__amdgpu_buffer_rsrc_t srd, unsigned voff, unsigned lds_dst_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(srd), "s"(lds_dst_uniform)
+               : "memory");
+}
+
+__device__ unsigned long long g_attn_probe[2 * 16 * 8];   // tools: cycle stamps of two waves of one workgroup (PROBE forms)
+
 // forward: 4 waves x 32 query rows per workgroup, 64-key K / V^T tiles staged through LDS
 // ------------------------------------------------------------------------------------------
 // QF = 16-row query fragments per wave (2: 128-query workgroups; 1: 64-query workgroups, fewer VGPRs -> more waves per SIMD)
-template <int D, bool CAUSAL, int QF, bool RP = false, bool DROP = false>
+template <int D, bool CAUSAL, int QF, bool RP = false, bool DROP = false, bool PROBE = false, bool DMA = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
@@ -205,11 +228,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   constexpr int KCM = KCH - 1;
   constexpr int KI = 64 * KCH / 256;
   constexpr int VI = D * 8 / 256;
-  __shared__ __attribute__((aligned(16))) char lds[64 * KROWB + D * 128];
+  // DMA form: the K / V^T tiles go HBM -> LDS by descriptor LDS-DMA into a ring of NS stages (counted vmcnt, one raw barrier
+  // per tile) instead of through staging registers, two __syncthreads and 4-8 ds_write_b128 per thread and tile
+  constexpr int NS = DMA ? (D == 128 ? 2 : 3) : 1;
+  constexpr int STG = 64 * KROWB + D * 128;
+  constexpr int NPW = STG / 1024 / 4;   // 1 KiB DMA pieces per wave and tile (K first, then V^T)
+  __shared__ __attribute__((aligned(16))) char lds[NS * STG];
   char* ldsK = lds;
   char* ldsV = lds + 64 * KROWB;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = DMA ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
   const int hk = h / (p.Hq / p.Hkv);
@@ -266,6 +295,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
   }
 
+  // key-padding bitmap (wave-uniform): bit t = the 64-key tile t holds a padded key.  Tiles without one take the mask-free
+  // path although a mask was passed (an LLM batch is padded at one end: most tiles of most rows are clean).
+  unsigned long long padtiles = 0;
+  bool pad_known = true;
+  if (p.kmask) {
+    const int ndw = Tkp >> 2;
+    if (ndw > 64 * 16) {
+      pad_known = false;   // more than 64 tiles: every tile takes the masked path
+    } else {
+      const unsigned* m32 = reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tkp);
+      for (int c = 0; c * 64 < ndw; c++) {
+        const int dw = c * 64 + lane;
+        const unsigned v = dw < ndw ? m32[dw] : 0x01010101u;
+        const unsigned long long bal = __ballot(((v - 0x01010101u) & ~v & 0x80808080u) != 0);   // some byte of v is zero
+        const unsigned nib = ((bal & 0xffffull) ? 1u : 0u) | ((bal & 0xffff0000ull) ? 2u : 0u) | (((bal >> 32) & 0xffffull) ? 4u : 0u) |
+                             ((bal >> 48) ? 8u : 0u);
+        padtiles |= (unsigned long long)nib << (4 * c);
+      }
+    }
+  }
+
   float rp_g[QF];
 #pragma unroll
   for (int f = 0; f < QF; f++)
@@ -303,13 +353,98 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
   };
 
-  gload(tbeg * 64);
-  for (int it = tbeg; it < ntiles; it++) {
+  const bool prb = PROBE && blockIdx.x == 5 && blockIdx.y == 7 && blockIdx.z == 3 && (wave == 0 || wave == 3);
+  auto stamp = [&](int it, int i) {
+    if constexpr (PROBE) {
+      if (prb) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if (lane == 0 && it < 16) g_attn_probe[((wave ? 1 : 0) * 16 + it) * 8 + i] = t;
+      }
+    }
+  };
+  // ---- DMA form: this wave owns pieces j = wave + 4 u (u < NPW) of the STG / 1024 that make a stage; the first half of them are
+  // K rows (lane -> row, 16-byte chunk; the XOR swizzle is applied to the SOURCE chunk, the LDS image is lane-linear), the second
+  // half V^T rows.  K rows past the end of the tensor read as zeros; rows past Tk of a batch in the middle read the next batch's
+  // rows, which only tiles on the masked path (k0 + 64 > Tk) can contain. ----
+  unsigned voff[NPW], dsto[NPW];
+  __amdgpu_buffer_rsrc_t srd_k, srd_vt;
+  unsigned lds0 = 0, ldk2 = 0;
+  if constexpr (DMA) {
+    lds0 = __builtin_amdgcn_readfirstlane(lds_offset_of(lds));
+    ldk2 = (unsigned)p.ldk * 2u;
+    const int nB = gridDim.z;
+    srd_k = __builtin_amdgcn_make_buffer_rsrc((void*)p.K, 0, (unsigned)((((int64_t)nB * Tk - 1) * p.ldk + (int64_t)p.Hkv * D) * 2), 0x00020000);
+    srd_vt = __builtin_amdgcn_make_buffer_rsrc((void*)p.Vt, 0, (unsigned)((int64_t)nB * p.Hkv * D * Tkp * 2), 0x00020000);
+#pragma unroll
+    for (int u = 0; u < NPW; u++) {
+      const int j = u * 4 + wave;                 // piece of the stage
+      if (u < NPW / 2) {                          // K: [64][D] row-major
+        const int row = j * (1024 / KROWB) + lane / KCH, c = lane % KCH;
+        voff[u] = (unsigned)(((int64_t)b * Tk + row) * p.ldk + hk * D + ((c ^ fwd_swz<D>(row)) << 3)) * 2u;
+      } else {                                    // V^T: [D][64 keys], 128-byte rows
+        const int jv = j - NPW * 2;               // piece inside the V^T sub-tile
+        const int d = jv * 8 + (lane >> 3), c = lane & 7;
+        voff[u] = (unsigned)((((int64_t)b * p.Hkv + hk) * D + d) * Tkp + ((c ^ ((d >> 1) & 7)) << 3)) * 2u;
+      }
+      dsto[u] = (unsigned)(j * 1024);
+    }
+    // every ordinary load above must have RETURNED before the first asm DMA is issued (see attn_bwd_dkdv_ring_kernel)
+#pragma unroll
+    for (int f = 0; f < QF; f++) {
+#pragma unroll
+      for (int kd = 0; kd < KD; kd++) asm volatile("" : "+v"(qf[f][kd]));
+      asm volatile("" : "+v"(qlo[f]), "+v"(qhi[f]), "+v"(rp_g[f]));
+    }
+    asm volatile("" : "+s"(lo_wave_max), "+s"(hi_wave_min), "+s"(padtiles));
+  }
+  auto issue = [&](int tile, int stg) {
+    if constexpr (DMA) {
+      const int k0 = min(tile, ntiles - 1) * 64;   // past the end: the last tile again, into a stage nobody reads
+      const unsigned st = lds0 + (unsigned)(stg * STG);
+#pragma unroll
+      for (int u = 0; u < NPW; u++) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(st + dsto[u]);
+        const unsigned so = (u < NPW / 2) ? (unsigned)k0 * ldk2 : (unsigned)k0 * 2u;
+        bufdma16_asm(u < NPW / 2 ? srd_k : srd_vt, voff[u] + __builtin_amdgcn_readfirstlane(so), dst);
+      }
+    }
+  };
+  int tb = tbeg, stage = 0;
+  if constexpr (DMA) {
+    asm volatile("" : "+s"(tb));
+    if (ntiles > tb) {
+      issue(tb, 0);
+      if constexpr (NS == 3) issue(tb + 1, 1);
+    }
+  } else {
+    gload(tbeg * 64);
+  }
+  for (int it = tb; it < ntiles; it++) {
     const int k0 = it * 64;
-    __syncthreads();
-    lstore();
-    __syncthreads();
-    if (it + 1 < ntiles) gload(k0 + 64);
+    stamp(it, 0);
+    if constexpr (DMA) {
+      // tile `it` has landed when at most the younger tile's DMA of this wave is outstanding; after the barrier every wave's
+      // share has, and everybody is done reading the stage that the next DMA refills
+      if constexpr (NS == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      stamp(it, 1);
+      ldsK = lds + stage * STG;
+      ldsV = ldsK + 64 * KROWB;
+      const int nxt = stage + NS - 1 >= NS ? stage - 1 : stage + NS - 1;   // (stage + NS - 1) % NS
+      stamp(it, 2);
+      issue(it + NS - 1, nxt);
+      stage = stage + 1 == NS ? 0 : stage + 1;
+    } else {
+      __syncthreads();
+      stamp(it, 1);
+      lstore();
+      __syncthreads();
+      stamp(it, 2);
+      if (it + 1 < ntiles) gload(k0 + 64);
+    }
+    stamp(it, 3);
     if (CAUSAL && k0 > qw0 + QW - 1) continue;  // whole tile is in this wave's future
 
     // ---- S^T = K . Q^T ----
@@ -348,6 +483,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         }
       });
     }
+    stamp(it, 4);
     const unsigned vbase = lds_offset_of(ldsV) + (unsigned)(li * 128);
     unsigned va[2];
 #pragma unroll
@@ -357,12 +493,48 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     // ---- online softmax (per query = lane&15, replicated over the 4 lane groups) ----
     // The running maximum only moves when a tile exceeds it by more than 2^8 (in the exponent's log2 units): P stays <= 256,
     // exact in fp32 / bf16, and the O / l rescale becomes a rare wave-uniform branch instead of 2 exp + 16 multiplies per tile
-    // interior tiles (no key mask, fully inside [0, Tk), fully below the causal diagonal of this wave) skip all masking
-    const bool tile_full = !RP && !DROP && (p.kmask == nullptr) && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0 &&
+    // interior tiles (no padded key, fully inside [0, Tk), fully below the causal diagonal of this wave) skip all masking
+    const bool tile_pad = p.kmask != nullptr && (!pad_known || ((padtiles >> it) & 1ull) != 0);
+    const bool tile_full = !RP && !DROP && !tile_pad && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0 &&
                            k0 + 64 <= hi_wave_min;
     float alpha[QF];
     bool moved = false;
-    if (tile_full) {
+    // interior tiles first try the running maximum as it is: P = exp2(s * sl2 - m) with no tile maximum at all (32 v_max and
+    // two cross-group reductions per tile less).  A lane's partial row sum above 64 (so no single P above 64; +inf on the first
+    // tile, where m = -inf) sends the whole wave through the ordinary path below, which moves the maximum.
+    // (bidirectional kernels only: a causal wave of the LLM shape sees three or four tiles, the first of them always slow)
+    bool fast_done = false;
+    if (!CAUSAL && tile_full) {
+      f32x4_t pt[QF][4];
+      float rs[QF];
+      bool over = false;
+#pragma unroll
+      for (int f = 0; f < QF; f++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < 4; kf++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float pv = fast_exp2(fmaf(s[f][kf][r], sl2, -mrow[f]));
+            pt[f][kf][r] = pv;
+            acc += pv;
+          }
+        rs[f] = acc;
+        over |= !(acc <= 64.0f);
+      }
+      if (!__any(over)) {
+        fast_done = true;
+#pragma unroll
+        for (int f = 0; f < QF; f++) {
+          alpha[f] = 1.0f;
+          lrow[f] += rs[f];
+#pragma unroll
+          for (int kf = 0; kf < 4; kf++) s[f][kf] = pt[f][kf];
+        }
+      }
+    }
+    if (fast_done) {
+    } else if (tile_full) {
 #pragma unroll
       for (int f = 0; f < QF; f++) {
         float mt = s[f][0][0];
@@ -389,58 +561,66 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         lrow[f] = lrow[f] * alpha[f] + rs;
       }
     } else {
-      bool kv[4][4];
+      // boundary tile: query q sees the key RANGE [qlo, min(q, qhi - 1, Tk - 1)] -- one unsigned compare per element -- minus
+      // the padded keys, whose mask bytes are only fetched for tiles that hold one (PAD)
+      auto masked = [&](auto pad_c) {
+        constexpr bool PAD = decltype(pad_c)::value;
+        unsigned mk[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+        if constexpr (PAD) {
 #pragma unroll
-      for (int kf = 0; kf < 4; kf++) {
-        const int kb = k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4;
-        unsigned mk = 0x01010101u;
-        if (p.kmask) mk = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tkp + kb);
-#pragma unroll
-        for (int r = 0; r < 4; r++) kv[kf][r] = ((mk >> (8 * r)) & 0xffu) != 0 && (kb + r) < Tk;
-      }
-#pragma unroll
-      for (int f = 0; f < QF; f++) {
-        const int q = qw0 + f * 16 + li;
-        float mt = -INFINITY;
-#pragma unroll
-        for (int kf = 0; kf < 4; kf++) {
-          const int kb = k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4;
-          float bias[4] = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (RP) {   // gate[q] * table[key - q + T - 1], in log2 units like the scores
-            const float* tp = p.rp_tab + (int64_t)h * p.rp_ld + (kb - min(q, Tq - 1) + p.rp_T - 1);
-#pragma unroll
-            for (int r = 0; r < 4; r++) bias[r] = rp_g[f] * tp[r];
-          }
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int key = kb + r;
-            const bool ok = kv[kf][r] && (!CAUSAL || key <= q) && key >= qlo[f] && key < qhi[f];
-            const float x = ok ? fmaf(s[f][kf][r], sl2, bias[r]) : -INFINITY;
-            s[f][kf][r] = x;
-            mt = fmaxf(mt, x);
-          }
+          for (int kf = 0; kf < 4; kf++)
+            mk[kf] = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tkp + k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4);
         }
-        mt = max_across_groups(mt);
-        const bool mv = mt > mrow[f] + 8.0f;            // (-inf > -inf + 8 is false: a row that has seen no key stays at -inf)
-        const float mnew = mv ? mt : mrow[f];
-        const float muse = (mnew == -INFINITY) ? 0.f : mnew;
-        alpha[f] = mv ? fast_exp2(mrow[f] - muse) : 1.0f;
-        moved |= mv;
-        mrow[f] = mnew;
-        float rs = 0.f;
 #pragma unroll
-        for (int kf = 0; kf < 4; kf++) {
-          unsigned keep = 0xFu;
-          if constexpr (DROP) keep = attn_keep4(p, b * p.Hq + h, min(q, Tq - 1), k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4);
+        for (int f = 0; f < QF; f++) {
+          const int q = qw0 + f * 16 + li;
+          const int hi = min(min(qhi[f], Tk) - 1, CAUSAL ? q : 0x7fffffff);
+          const unsigned span = (unsigned)(hi - qlo[f]);
+          const bool any = hi >= qlo[f];
+          const int rel = k0 + 8 * g - qlo[f];
+          float mt = -INFINITY;
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const float pv = fast_exp2(s[f][kf][r] - muse);
-            rs += pv;                                    // the row sum is over the UNdropped probabilities
-            s[f][kf][r] = DROP ? (((keep >> r) & 1u) ? pv * p.drop_scale : 0.f) : pv;
+          for (int kf = 0; kf < 4; kf++) {
+            const int ko = (kf >> 1) * 32 + (kf & 1) * 4;   // key offset of the fragment inside the lane's run
+            float bias[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (RP) {   // gate[q] * table[key - q + T - 1], in log2 units like the scores
+              const float* tp = p.rp_tab + (int64_t)h * p.rp_ld + (k0 + 8 * g + ko - min(q, Tq - 1) + p.rp_T - 1);
+#pragma unroll
+              for (int r = 0; r < 4; r++) bias[r] = rp_g[f] * tp[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              bool ok = any && (unsigned)(rel + ko + r) <= span;
+              if constexpr (PAD) ok = ok && (mk[kf] & (0xffu << (8 * r))) != 0;
+              const float x = ok ? fmaf(s[f][kf][r], sl2, bias[r]) : -INFINITY;
+              s[f][kf][r] = x;
+              mt = fmaxf(mt, x);
+            }
           }
+          mt = max_across_groups(mt);
+          const bool mv = mt > mrow[f] + 8.0f;            // (-inf > -inf + 8 is false: a row that has seen no key stays at -inf)
+          const float mnew = mv ? mt : mrow[f];
+          const float muse = (mnew == -INFINITY) ? 0.f : mnew;
+          alpha[f] = mv ? fast_exp2(mrow[f] - muse) : 1.0f;
+          moved |= mv;
+          mrow[f] = mnew;
+          float rs = 0.f;
+#pragma unroll
+          for (int kf = 0; kf < 4; kf++) {
+            unsigned keep = 0xFu;
+            if constexpr (DROP) keep = attn_keep4(p, b * p.Hq + h, min(q, Tq - 1), k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const float pv = fast_exp2(s[f][kf][r] - muse);
+              rs += pv;                                    // the row sum is over the UNdropped probabilities
+              s[f][kf][r] = DROP ? (((keep >> r) & 1u) ? pv * p.drop_scale : 0.f) : pv;
+            }
+          }
+          lrow[f] = lrow[f] * alpha[f] + rs;
         }
-        lrow[f] = lrow[f] * alpha[f] + rs;
-      }
+      };
+      if (tile_pad) masked(std::true_type{});
+      else masked(std::false_type{});
     }
     if (__any(moved)) {
 #pragma unroll
@@ -450,6 +630,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 4; r++) o[f][df][r] *= alpha[f];
     }
+    stamp(it, 5);
     // ---- O^T += V^T . P^T ----
     static_for<0, 2>([&](auto a) {
       frag_t pb[QF];
@@ -462,7 +643,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         for (int f = 0; f < QF; f++) o[f][df] = mfma16(vfr[a][df], pb[f], o[f][df]);
       });
     });
+    stamp(it, 6);
   }
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMAs still target this workgroup's LDS
 
   // ---- epilogue ----
 #pragma unroll
@@ -867,27 +1050,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
 //     to the per-lane SOURCE chunk (same involution as on the read side).
 // The arithmetic per wave and tile is unchanged (same masks, same RoPE / GQA epilogue).
 // ------------------------------------------------------------------------------------------
-// The DMA is issued from inline asm: hipcc (ROCm 7.2) protects every LDS read that follows a global_load_lds BUILTIN with
-// s_waitcnt vmcnt(0) (it cannot tell the ring stages apart), which drains the three tiles in flight on every iteration.  An
-// asm DMA is invisible to that bookkeeping; the counted vmcnt + barrier below order it by hand.  M0 (the DMA's LDS base) is
-// compiler-reserved: saved and restored inside the statement.
-__device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_dst_uniform) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(g), "s"(lds_dst_uniform)
-               : "memory");
-}
-// buffer-descriptor form (buffer_load_dwordx4 ... offen lds): one 32-bit byte offset per lane, range-checked against
-// num_records (rows past the end of the tensor read as zeros: no clamps), the tile part of the address is a scalar
-__device__ __forceinline__ void bufdma16_asm(__amdgpu_buffer_rsrc_t srd, unsigned voff, unsigned lds_dst_uniform) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(srd), "s"(lds_dst_uniform)
-               : "memory");
-}
-
 // XOR key of the 16-byte chunks of row `row` of a row-major ring sub-tile
 template <int D>
 __device__ __forceinline__ int ring_swz(int row) {
@@ -1167,8 +1329,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
 // counted vmcnt waits and ONE raw barrier per tile (the register-staged form needs two __syncthreads and 6 ds_write_b128
 // per thread and tile).  The key-padding mask bytes of a tile ride along as one extra DMA piece of wave 0.
 // ------------------------------------------------------------------------------------------
-__device__ unsigned long long g_attn_probe[2 * 16 * 8];   // tools: cycle stamps of two waves of one workgroup (PROBE form)
-
 template <int D, bool CAUSAL, int QF, bool PROBE = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) {
   constexpr int KD = D / 32;
@@ -1515,10 +1675,24 @@ extern "C" int slam_attn_set_bwd_variant(int variant) {   // tools: 0 = DMA-ring
   return 0;
 }
 
-extern "C" int slam_attn_set_fwd_qf(int qf) {
-  SLAM_CHECK_ARG(qf >= 0 && qf <= 2, "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2)", qf);
-  g_attn_fwd_qf = qf;
+extern int g_attn_fwd_dma;
+extern "C" int slam_attn_set_fwd_qf(int qf) {   // tools: 0 = auto, 1 / 2 fragments per wave; 10 / 11 = register-staged / DMA tiles
+  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11, "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2; 10 / 11 = staged / DMA tiles)", qf);
+  if (qf >= 10) g_attn_fwd_dma = qf - 10;
+  else g_attn_fwd_qf = qf;
   return 0;
+}
+
+int g_attn_fwd_dma = 1;   // 1 = K / V^T tiles by LDS-DMA ring (shipped), 0 = register-staged tiles (A/B in tools)
+
+// forward launch: the DMA form whenever the 32-bit byte offsets of its descriptors can address K and V^T
+template <int D, bool CAUSAL, int QF, bool RP = false, bool DROP = false, bool PROBE = false>
+static void launch_fwd(const AttnParams& p, int64_t B, hipStream_t s) {
+  dim3 grid((unsigned)cdiv64(p.Tq, 64 * QF), (unsigned)p.Hq, (unsigned)B);
+  const int64_t lim = (int64_t)1 << 31;
+  const bool fits = (B * p.Tk * p.ldk + (int64_t)p.Hkv * D) * 2 < lim && B * p.Hkv * D * p.Tkp * 2 < lim;
+  if (fits && g_attn_fwd_dma) hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, false>), grid, dim3(256), 0, s, p);
 }
 
 extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt,
@@ -1550,27 +1724,22 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.drop_seed = drop_seed;
   hipStream_t s = (hipStream_t)stream;
   if (drop_p > 0.f) {
-    dim3 grid((unsigned)cdiv64(Tq, 128), (unsigned)Hq, (unsigned)B);
-    hipLaunchKernelGGL((attn_fwd_kernel<64, false, 2, false, true>), grid, dim3(256), 0, s, p);
-    SLAM_CHECK_LAUNCH("slam_attn_fwd");
-    return 0;
-  }
-  if (rp_gate) {
-    dim3 grid((unsigned)cdiv64(Tq, 128), (unsigned)Hq, (unsigned)B);
-    hipLaunchKernelGGL((attn_fwd_kernel<64, false, 2, true>), grid, dim3(256), 0, s, p);
-    SLAM_CHECK_LAUNCH("slam_attn_fwd");
-    return 0;
-  }
-  // measured (tools/attn_bwd_bench.py, tools/attn_one.py): D = 128 with two fragments needs 261 VGPRs = one wave per SIMD,
-  // one fragment (171 VGPRs, two waves) is 13 % faster at the Llama shape; D = 64 (182 vs 120 VGPRs) prefers two (+5 %)
-  const int qf = g_attn_fwd_qf ? g_attn_fwd_qf : (D == 128 ? 1 : 2);
-  dim3 grid((unsigned)cdiv64(Tq, 64 * qf), (unsigned)Hq, (unsigned)B);
-  if (D == 64) {
-    if (causal) { if (qf == 2) hipLaunchKernelGGL((attn_fwd_kernel<64, true, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_fwd_kernel<64, true, 1>), grid, dim3(256), 0, s, p); }
-    else { if (qf == 2) hipLaunchKernelGGL((attn_fwd_kernel<64, false, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_fwd_kernel<64, false, 1>), grid, dim3(256), 0, s, p); }
+    launch_fwd<64, false, 2, false, true>(p, B, s);
+  } else if (rp_gate) {
+    launch_fwd<64, false, 2, true>(p, B, s);
+  } else if (g_attn_bwd_variant == 14 && D == 64 && !causal) {   // tools/attn_fwd_probe.py: the same kernel with cycle stamps
+    launch_fwd<64, false, 2, false, false, true>(p, B, s);
   } else {
-    if (causal) { if (qf == 2) hipLaunchKernelGGL((attn_fwd_kernel<128, true, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_fwd_kernel<128, true, 1>), grid, dim3(256), 0, s, p); }
-    else { if (qf == 2) hipLaunchKernelGGL((attn_fwd_kernel<128, false, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_fwd_kernel<128, false, 1>), grid, dim3(256), 0, s, p); }
+    // measured (tools/attn_bwd_bench.py, tools/attn_one.py): D = 128 with two fragments needs 261 VGPRs = one wave per SIMD,
+    // one fragment (171 VGPRs, two waves) is 13 % faster at the Llama shape; D = 64 (182 vs 120 VGPRs) prefers two (+5 %)
+    const int qf = g_attn_fwd_qf ? g_attn_fwd_qf : (D == 128 ? 1 : 2);
+    if (D == 64) {
+      if (causal) { if (qf == 2) launch_fwd<64, true, 2>(p, B, s); else launch_fwd<64, true, 1>(p, B, s); }
+      else { if (qf == 2) launch_fwd<64, false, 2>(p, B, s); else launch_fwd<64, false, 1>(p, B, s); }
+    } else {
+      if (causal) { if (qf == 2) launch_fwd<128, true, 2>(p, B, s); else launch_fwd<128, true, 1>(p, B, s); }
+      else { if (qf == 2) launch_fwd<128, false, 2>(p, B, s); else launch_fwd<128, false, 1>(p, B, s); }
+    }
   }
   SLAM_CHECK_LAUNCH("slam_attn_fwd");
   return 0;
