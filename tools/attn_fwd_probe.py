@@ -25,17 +25,32 @@ def fwd():
     ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, D, False, scale, want_lse=False, out=obuf)
 
 
-for _ in range(3):
-    fwd()
-torch.cuda.synchronize()
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-s.record()
-for _ in range(10):
-    fwd()
-e.record()
-torch.cuda.synchronize()
-us = s.elapsed_time(e) * 100
-print(f"fwd: {us:.1f} us  {4.0 * B * H * T * T * D / us / 1e6:.1f} TF")
+def timed(n=10):
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fwd()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / n
+
+
+# forms timed interleaved (the clocks follow the recent load): (fragments per wave, LDS-DMA tiles)
+FORMS = [("2 fragments per wave, DMA tiles (shipped)", 2, 11), ("1 fragment per wave, DMA tiles", 1, 11),
+         ("2 fragments per wave, register-staged tiles", 2, 10), ("1 fragment per wave, register-staged tiles", 1, 10)]
+res = {n: [] for n, _, _ in FORMS}
+for rnd in range(4):
+    for n, qf, dma in FORMS:
+        call("slam_attn_set_fwd_qf", qf)
+        call("slam_attn_set_fwd_qf", dma)
+        fwd()
+        res[n].append(timed())
+call("slam_attn_set_fwd_qf", 0)
+call("slam_attn_set_fwd_qf", 11)
+for n, _, _ in FORMS:
+    v = sorted(res[n][1:])
+    print(f"fwd, {n}: median {v[1]:.1f} us  {4.0 * B * H * T * T * D / v[1] / 1e6:.1f} TF")
 call("slam_attn_set_bwd_variant", 14)
 for _ in range(3):
     fwd()
