@@ -60,6 +60,8 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t srd, unsigned voff
 
 // exact-erf GELU.  erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16 output rounding):
 // one v_exp + one v_rcp + a 5-term Horner instead of libm's branchy erff in the epilogue of every fc1 tile.
+// (v_exp_f32 directly: the argument is <= 0 and an underflow to 0 is the right answer, so __expf's range fix-up -- a compare, a
+// select and two multiplies per element -- is dead weight; 128 elements per thread and tile go through this)
 __device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
@@ -67,8 +69,10 @@ __device__ __forceinline__ float gelu_erf(float x) {
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);
   poly = fmaf(poly, t, 0.254829592f);
-  const float e = 1.0f - poly * t * __expf(-z * z);  // erf(|x|/sqrt2)
-  return 0.5f * x * (1.0f + copysignf(e, x));
+  const float ex = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // exp(-z^2) = 2^(-x^2 / 2 * log2(e))
+  const float e = fmaf(-poly * t, ex, 1.0f);                                  // erf(|x| / sqrt2)
+  const float hx = 0.5f * x;
+  return fmaf(hx, copysignf(e, x), hx);
 }
 
 // swap the odd 16-lane rows of `a` with the even rows of `b` (gfx950).  Inline asm: this hipcc folds the builtin's second result
