@@ -1200,7 +1200,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
     issue(2);
   }
   int c_qi = 0;   // query tile of the tile being consumed
+  constexpr bool PROBE = ABL == 9;   // cycle stamps of waves 0 / 7 of one workgroup (tools/attn_dq_probe.py)
+  const bool prb = PROBE && blockIdx.x == 0 && blockIdx.y == 3 && blockIdx.z == 5 && (wave == 0 || wave == 7);
+  auto stamp = [&](int it, int i) {
+    if constexpr (PROBE) {
+      if (prb) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if (lane == 0 && it < 16) g_attn_probe[((wave ? 1 : 0) * 16 + it) * 8 + i] = t;
+      }
+    }
+  };
   for (int it = 0; it < ntiles; it++) {
+    stamp(it, 0);
     const int q0 = qstart + c_qi * 32;
     if (++c_qi == nq) c_qi = 0;
     const int s = it & (NS - 1);
@@ -1217,7 +1228,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
     }
     static_assert(PW == 4 || PW == 2, "counted waits above assume 4 (D = 128) or 2 (D = 64) tile DMA per wave and stage");
     if constexpr (ABL != 5) __builtin_amdgcn_s_barrier();
-    if constexpr (ABL != 1) issue((it + 3) & (NS - 1));   // (issuing these in the softmax stretch instead measured 2 % slower)
+    stamp(it, 1);
+    // (issuing these in the softmax stretch instead measured 2 % slower; spreading them over four points of the iteration,
+    // rotated by wave, 15 % slower: a DMA instruction in the middle of the chain of reads and products stalls it)
+    if constexpr (ABL != 1) issue((it + 3) & (NS - 1));
+    stamp(it, 2);
     if (kw0 >= Tk || (CAUSAL && q0 + 31 < kw0)) continue;
     // ---- one tile, LDS reads and their waits placed by hand (hipcc's own order was read -> wait -> two MFMAs, sixteen times
     // per tile: every pair of products exposed a full LDS latency, and since the barrier releases all eight waves at once
@@ -1257,6 +1272,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
       sacc[1] = mfma16(q1f[kd], kf[kd], sacc[1]);
       dp[1] = mfma16(d1f[kd], vf[kd], dp[1]);
     });
+    stamp(it, 3);
     // softmax arithmetic (covers the latency of those reads).  Element (f, r) of this lane is query q0 + 8g + 4f + r.
     f32x4_t pm[2], ds[2];
     const f32x4_t l4[2] = {__builtin_bit_cast(f32x4_t, lse0), __builtin_bit_cast(f32x4_t, lse1)};
@@ -1293,6 +1309,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
     }
     const frag_t pb = pack_frag(pm[0], pm[1]);
     const frag_t dsb = pack_frag(ds[0], ds[1]);
+    stamp(it, 4);
     // dV / dK products, operands KD fragments ahead
     static_for<0, DF>([&](auto df) {
       if constexpr (df + KD < DF) {
@@ -1305,6 +1322,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
       dv[df] = mfma16(bd[df], pb, dv[df]);
       dk[df] = mfma16(bq[df], dsb, dk[df]);
     });
+    stamp(it, 5);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMAs still target this workgroup's LDS
   if (key >= Tk) return;
@@ -1670,7 +1688,7 @@ extern "C" int slam_attn_debug_clock(unsigned long long* out256) {   // tools: s
 }
 
 extern "C" int slam_attn_set_bwd_variant(int variant) {   // tools: 0 = DMA-ring backward kernels (shipped), 1 = round-1 kernels
-  SLAM_CHECK_ARG(variant == 0 || variant == 1 || variant == 2 || variant == 14 || variant == 11 || variant == 12 || variant == 15, "slam_attn_set_bwd_variant: %d (0 | 1 | 2 | 11, 12, 15 timing ablations)", variant);
+  SLAM_CHECK_ARG(variant == 0 || variant == 1 || variant == 2 || variant == 14 || variant == 11 || variant == 12 || variant == 15 || variant == 19, "slam_attn_set_bwd_variant: %d (0 | 1 | 2 | 11, 12, 15 timing ablations)", variant);
   g_attn_bwd_variant = variant;
   return 0;
 }
@@ -1814,6 +1832,8 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
     switch (g_attn_bwd_variant) {
       case 11: rc = launch_dkdv_ring<128, true, 1>(p, gk2, s); break;
       case 12: rc = launch_dkdv_ring<128, true, 2>(p, gk2, s); break;
+      case 19: rc = launch_dkdv_ring<128, true, 9>(p, gk2, s); break;
+      case 14: rc = launch_dkdv_ring<128, true, 0>(p, gk2, s); break;
       default: rc = launch_dkdv_ring<128, true, 5>(p, gk2, s); break;
     }
     if (rc) return rc;

@@ -1,7 +1,8 @@
 """GPU: where a wave of the dQ kernel spends a 32-key tile (cycle stamps of the probe form, slam_attn_set_bwd_variant(14)).
 
 Stamps per tile: 0 loop top, 1 after the vmcnt wait + barrier, 2 after the DMA issue, 3 after the S / dP products were issued,
-4 after the softmax, 5 after the dQ products were issued.  Workgroup (2, 5, 3) = queries 256-383 of one head (12 tiles), waves 0 / 3.
+4 after the softmax, 5 after the dQ (dV / dK) products were issued.  dQ: workgroup (2, 5, 3) = queries 256-383 of one head (12 tiles),
+waves 0 / 3; `python tools/attn_dq_probe.py dkdv`: the dK/dV ring kernel, workgroup (0, 3, 5) = keys 0-127, waves 0 / 7, first 12 tiles.
 """
 import os
 import sys
@@ -27,7 +28,8 @@ o, lse = ops.attn_fwd(q2, k2, vt, B, T, Hq, Hkv, D, True, scale, key_mask=km)
 do = torch.randn(B * T, Hq * D, device=dev).to(torch.bfloat16)
 dot = ops.head_rope_transpose(do, 0, B, T, Hq, D)
 dqkv = torch.empty_like(qkv)
-call("slam_attn_set_bwd_variant", 14)
+WHICH = sys.argv[1] if len(sys.argv) > 1 else "dq"   # dq | dkdv
+call("slam_attn_set_bwd_variant", 14 if WHICH == "dq" else 19)
 for _ in range(5):
     ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, dqkv[:, : Hq * D], dqkv[:, Hq * D:(Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:],
                  B, T, Hq, Hkv, D, True, scale, key_mask=km)
@@ -36,8 +38,8 @@ call("slam_attn_set_bwd_variant", 0)
 out = np.zeros(256, dtype=np.uint64)
 call("slam_attn_debug_clock", out.ctypes.data)
 st = out.reshape(2, 16, 8).astype(np.int64)
-names = ["wait+barrier", "DMA issue", "reads + S/dP", "softmax", "dQ products", "-> next top"]
-for w, wn in enumerate(("wave 0", "wave 3")):
+names = ["wait+barrier", "DMA issue", "reads + S/dP", "softmax", "dQ products" if WHICH == "dq" else "dV/dK products", "-> next top"]
+for w, wn in enumerate(("wave 0", "wave 3" if WHICH == "dq" else "wave 7")):
     print(wn)
     for it in range(12):
         r = st[w, it]
