@@ -80,6 +80,33 @@ def test_gemm_persistent_descriptor_dma_on_strided_views(dev, M, N, K):
             ops.gemm_set_config(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(516, 600, 448), (260, 256, 4096), (2 * 256 + 16, 1000, 192), (257, 260, 128)])
+def test_gemm_thin_tail_tile_of_the_4wave_kernel(dev, M, N, K):
+    """the 4-wave kernel computes an M-tail tile of at most 16 rows (31 x 380 tokens leave 4) straight from global memory
+    (no staging): same results as the full-tile path with every epilogue, NaNs behind the views never read"""
+    ops = _ops()
+    g = torch.Generator(device=dev).manual_seed(9)
+    a_full = torch.full((M + 40, K + 64), float("nan"), device=dev, dtype=torch.bfloat16)
+    b_full = torch.full((N + 40, K + 128), float("nan"), device=dev, dtype=torch.bfloat16)
+    a_full[:M, :K] = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
+    b_full[:N, 64:64 + K] = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
+    a, b = a_full[:M, :K], b_full[:N, 64:64 + K]
+    bias = torch.randn(N, generator=g, device=dev)
+    res = torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16)
+    ref = a.float() @ b.float().T
+    ops.gemm_set_config(12)
+    try:
+        assert_close(ops.gemm_nt(a, b), ref, atol=2e-2 * math.sqrt(K / 64), rtol=1e-2, what="plain")
+        c = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_GELU, residual=res, alpha=0.5)
+        assert_close(c, torch.nn.functional.gelu(0.5 * ref + bias) + res.float(), atol=3e-2 * math.sqrt(K / 64), rtol=1e-2, what="bias+gelu+res")
+        acc = torch.ones((M, N + 8), device=dev, dtype=torch.float32)
+        ops.gemm_nt(a, b, out=acc[:, :N], accumulate=True, alpha=0.5)
+        assert_close(acc[:, :N], 1.0 + 0.5 * ref, atol=1e-3 * math.sqrt(K / 64), rtol=1e-3, what="fp32 accumulate")
+        assert torch.all(acc[:, N:] == 1.0)
+    finally:
+        ops.gemm_set_config(0)
+
+
 def test_gemm_asymmetric_identity(dev):
     """A = I with an asymmetric B catches row/col swaps in the MFMA output mapping."""
     ops = _ops()
