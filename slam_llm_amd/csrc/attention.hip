@@ -1748,9 +1748,13 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   } else if (g_attn_bwd_variant == 14 && D == 64 && !causal) {   // tools/attn_fwd_probe.py: the same kernel with cycle stamps
     launch_fwd<64, false, 2, false, false, true>(p, B, s);
   } else {
-    // measured (tools/attn_bwd_bench.py, tools/attn_one.py): D = 128 with two fragments needs 261 VGPRs = one wave per SIMD,
-    // one fragment (171 VGPRs, two waves) is 13 % faster at the Llama shape; D = 64 (182 vs 120 VGPRs) prefers two (+5 %)
-    const int qf = g_attn_fwd_qf ? g_attn_fwd_qf : (D == 128 ? 1 : 2);
+    // measured (tools/attn_bwd_bench.py, interleaved): with LDS-DMA tiles two fragments per wave win at both head sizes (D = 128,
+    // Llama shape: 86 vs 108 us -- half the DMA pieces per query, and no staging registers push it past 256 VGPRs any more); with
+    // register-staged tiles (tensors beyond the descriptors' 2 GiB) D = 128 prefers one fragment (119 vs 134 us: 261 VGPRs = one
+    // wave per SIMD with two)
+    const int64_t lim = (int64_t)1 << 31;
+    const bool dma = g_attn_fwd_dma && (B * Tk * ldk + Hkv * D) * 2 < lim && B * Hkv * D * Tkp * 2 < lim;
+    const int qf = g_attn_fwd_qf ? g_attn_fwd_qf : ((D == 128 && !dma) ? 1 : 2);
     if (D == 64) {
       if (causal) { if (qf == 2) launch_fwd<64, true, 2>(p, B, s); else launch_fwd<64, true, 1>(p, B, s); }
       else { if (qf == 2) launch_fwd<64, false, 2>(p, B, s); else launch_fwd<64, false, 1>(p, B, s); }

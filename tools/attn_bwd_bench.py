@@ -76,16 +76,18 @@ for n, _, c in CASES:
     print(f"{n}: best {v[0]:.1f} us  median {v[2]:.1f} us  {flops / v[2] / 1e6:.1f} TF", flush=True)
 
 from slam_llm_amd.lib import call  # noqa: E402
-call("slam_attn_set_fwd_qf", 1)
-for _ in range(3):
-    fwd()
-torch.cuda.synchronize()
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-s.record()
-for _ in range(20):
-    fwd()
-e.record()
-torch.cuda.synchronize()
-us = s.elapsed_time(e) * 1e3 / 20
-print(f"fwd QF=1: {us:.1f} us  {4.0 * B * Hq * T * T * D * 0.5 / us / 1e6:.1f} TF", flush=True)
+# forward forms, interleaved: query fragments per wave x tile staging (11 = LDS-DMA ring, shipped)
+FWD = [("2 fragments per wave, DMA tiles (shipped)", 2, 11), ("1 fragment per wave, DMA tiles", 1, 11),
+       ("1 fragment per wave, register-staged tiles", 1, 10), ("2 fragments per wave, register-staged tiles", 2, 10)]
+fres = {n: [] for n, _, _ in FWD}
+for rnd in range(5):
+    for n, qf, dma in FWD:
+        call("slam_attn_set_fwd_qf", qf)
+        call("slam_attn_set_fwd_qf", dma)
+        fwd()
+        fres[n].append(timed(fwd))
 call("slam_attn_set_fwd_qf", 0)
+call("slam_attn_set_fwd_qf", 11)
+for n, _, _ in FWD:
+    v = sorted(fres[n])
+    print(f"fwd, {n}: median {v[2]:.1f} us  {4.0 * B * Hq * T * T * D * 0.5 / v[2] / 1e6:.1f} TF", flush=True)
