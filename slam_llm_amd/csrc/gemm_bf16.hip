@@ -128,7 +128,7 @@ __device__ __forceinline__ void gemm_epilogue_generic(const GemmParams& p, f32x4
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const float gf = bf2f(g4[e]), uf = bf2f(u4[e]), df = bf2f(f2bf(v[e]));
-            const float sg = 1.0f / (1.0f + __expf(-gf));
+            const float sg = sigmoid_fast(gf);
             v[e] = df * uf * sg * (1.0f + gf * (1.0f - sg));
             du[e] = df * (gf * sg);
           }
@@ -310,7 +310,7 @@ __device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmParams& p, f3
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const float gf = bf2f(g4[j][e]), uf = bf2f(u4[j][e]), df = bf2f(f2bf(acc[i][j][e] * p.alpha));
-          const float sg = 1.0f / (1.0f + __expf(-gf));
+          const float sg = sigmoid_fast(gf);
           dg[e] = df * uf * sg * (1.0f + gf * (1.0f - sg));
           du[e] = df * (gf * sg);
         }
