@@ -17,6 +17,11 @@
 //   therefore also kept transposed ([B,H,D,Tp], written by slam_head_rope_transpose).
 //   All per-query softmax state (m, l, LSE, Delta) is lane-local; row reductions are two xor-shuffles.
 //
+// Shipped forms (round 2): attn_fwd_kernel<..., DMA = true>, attn_bwd_dq_ring_kernel, attn_bwd_dkdv_ring_kernel -- operand tiles by
+// descriptor LDS-DMA into rings of 2-4 stages, counted vmcnt / lgkmcnt waits, one raw barrier per tile, LDS reads placed by hand.
+// The register-staged kernels (attn_fwd_kernel<..., DMA = false>, attn_bwd_dq_kernel, attn_bwd_dkdv_kernel) remain for tensors
+// beyond the descriptors' 32-bit offsets, <= 64 queries, attention dropout, and as A/B references in tools/.
+//
 // Masking follows HF: key j is visible to query i iff j <= i (causal) and key_mask[b][j]; query rows are
 // never masked.  A row with no visible key yields O = 0, LSE = +inf (P = 0 in the backward)
 // so pad rows stay finite.  Positions/rows beyond T are handled by clamped/zero loads and guarded stores.
