@@ -152,6 +152,12 @@ int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
  * with 64 readable floats before and after each row's 2 rp_T - 1 entries. */
 int slam_wavlm_gate(const void* x, int64_t ldx, const float* w, const float* bias, const float* grep_a, float* gate,
                     int64_t B, int64_t T, int64_t H, int64_t Tp, void* stream);
+/* GroupNorm with one group per channel over time + exact GELU: first conv layer of the "default" feature extractor (WavLM Base,
+ * reference src/slam_llm/models/wavlm/WavLM.py:428-441, Fp32GroupNorm(dim, dim)).  x fp32 [B*T, ldx] (time rows), y bf16 [B*T, ldy];
+ * every (clip, channel) is normalised over its T rows (biased variance); workspace of slam_groupnorm_time_workspace_bytes bytes. */
+int64_t slam_groupnorm_time_workspace_bytes(int64_t B, int64_t T, int64_t C);
+int slam_groupnorm_time_gelu(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t B, int64_t T, int64_t C,
+                             const float* weight, const float* bias, float eps, float* workspace, void* stream);
 /* gate[b][h][t] = a * (g * grep_a[h] - 1) + 2 with (a, g) = sigmoid of the two 4-sums of grep_linear(x[b, t, h*64:(h+1)*64])
  * (x = the layer's attention INPUT [B*T, H*64] bf16, w [8, 64] / bias [8] f32 = grep_linear; modules.py:522-531). */
 int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,

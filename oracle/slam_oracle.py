@@ -241,7 +241,15 @@ def wavlm_config(**kw) -> dict:
     conv_pos 128 / 16 groups, relative_position_embedding + gru_rel_pos with 320 buckets, max_distance 800).  The conv stack,
     feature projection and positional conv share HuBERT's keys (hub_*); tests shrink widths, not structure."""
     c = hubert_config()
-    c.update(wavlm_buckets=320, wavlm_max_distance=800)
+    c.update(wavlm_buckets=320, wavlm_max_distance=800, hub_extractor_mode="layer_norm", hub_layer_norm_first=True)
+    c.update(kw)
+    return c
+
+
+def wavlm_base_config(**kw) -> dict:
+    """WavLM Base / Base+ geometry (the released checkpoints' cfg): extractor_mode="default" (GroupNorm after the first conv only),
+    layer_norm_first=False (post-LN layers), 12 x 768 / 12 heads / ffn 3072; everything else as Large."""
+    c = wavlm_config(hub_dim=768, hub_heads=12, hub_layers=12, hub_ffn=3072, hub_extractor_mode="default", hub_layer_norm_first=False)
     c.update(kw)
     return c
 
@@ -272,11 +280,20 @@ def wavlm_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pref
       layers) and gate = a * (g * grep_a - 1) + 2 with (a, g) = sigmoid of the two 4-sums of grep_linear(per-head slice of the
       attention INPUT) (:522-531); key padding mask -> -inf."""
     x = wav[:, None, :]
+    group_mode = cfg.get("hub_extractor_mode", "layer_norm") == "default"
+    pre_ln = cfg.get("hub_layer_norm_first", True)
     for i, (k, st) in enumerate(zip(cfg["hub_conv_kernel"], cfg["hub_conv_stride"])):
         p = f"{prefix}feature_extractor.conv_layers.{i}."
         x = F.conv1d(x, W[p + "0.weight"], None, stride=st)
-        x = F.layer_norm(x.transpose(-2, -1), (x.shape[1],), W[p + "2.1.weight"], W[p + "2.1.bias"], 1e-5)
-        x = F.gelu(x.transpose(-2, -1))
+        if group_mode:
+            # extractor_mode "default" (WavLM.py:428-441, Base / Base+): Fp32GroupNorm(dim, dim) -- one group per channel, i.e.
+            # each channel normalised over TIME -- after the first conv only; the other layers are conv -> GELU
+            if i == 0:
+                x = F.group_norm(x, x.shape[1], W[p + "2.weight"], W[p + "2.bias"], 1e-5)
+            x = F.gelu(x)
+        else:
+            x = F.layer_norm(x.transpose(-2, -1), (x.shape[1],), W[p + "2.1.weight"], W[p + "2.1.bias"], 1e-5)
+            x = F.gelu(x.transpose(-2, -1))
     x = x.transpose(1, 2)
     x = F.layer_norm(x, (x.shape[-1],), W[prefix + "layer_norm.weight"], W[prefix + "layer_norm.bias"], 1e-5)
     x = F.linear(x, W[prefix + "post_extract_proj.weight"], W[prefix + "post_extract_proj.bias"])
@@ -294,6 +311,8 @@ def wavlm_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pref
     if kpos % 2 == 0:
         pos = pos[:, :, :-1]
     x = x + F.gelu(pos).transpose(1, 2)
+    if not pre_ln:      # post-LN encoders normalise HERE (WavLM.py:582-583) and not after the layers (:567-568)
+        x = F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5)
     H = cfg["hub_heads"]
     hd = d // H
     rel = torch.arange(T)[None, :] - torch.arange(T)[:, None]                 # memory - context = k - q
@@ -301,7 +320,8 @@ def wavlm_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pref
     pos_bias = F.embedding(buckets, W[p + "layers.0.self_attn.relative_attention_bias.weight"]).permute(2, 0, 1)   # [H, T, T]
     for i in range(cfg["hub_layers"]):
         q_ = f"{p}layers.{i}."
-        h = F.layer_norm(x, (d,), W[q_ + "self_attn_layer_norm.weight"], W[q_ + "self_attn_layer_norm.bias"], 1e-5)
+        # attention input: LN(x) in layer_norm_first layers (:690-703), x itself in post-LN layers (:716-725)
+        h = F.layer_norm(x, (d,), W[q_ + "self_attn_layer_norm.weight"], W[q_ + "self_attn_layer_norm.bias"], 1e-5) if pre_ln else x
         hh = h.view(B, T, H, hd).permute(0, 2, 1, 3)                           # per-head slices of the attention input
         gl = F.linear(hh, W[q_ + "self_attn.grep_linear.weight"], W[q_ + "self_attn.grep_linear.bias"]).view(B, H, T, 2, 4).sum(-1)
         ga, gb = torch.sigmoid(gl).chunk(2, dim=-1)
@@ -314,9 +334,14 @@ def wavlm_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pref
             sc = sc + key_bias
         a = (F.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(B, T, d)
         x = x + F.linear(a, W[q_ + "self_attn.out_proj.weight"], W[q_ + "self_attn.out_proj.bias"])
-        h = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], 1e-5)
-        x = x + F.linear(F.gelu(F.linear(h, W[q_ + "fc1.weight"], W[q_ + "fc1.bias"])), W[q_ + "fc2.weight"], W[q_ + "fc2.bias"])
-    return F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5)
+        if pre_ln:
+            h = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], 1e-5)
+            x = x + F.linear(F.gelu(F.linear(h, W[q_ + "fc1.weight"], W[q_ + "fc1.bias"])), W[q_ + "fc2.weight"], W[q_ + "fc2.bias"])
+        else:           # post-LN (:726-739): x = LN1(x + attn(x)); x = LN2(x + ffn(x))
+            x = F.layer_norm(x, (d,), W[q_ + "self_attn_layer_norm.weight"], W[q_ + "self_attn_layer_norm.bias"], 1e-5)
+            x = x + F.linear(F.gelu(F.linear(x, W[q_ + "fc1.weight"], W[q_ + "fc1.bias"])), W[q_ + "fc2.weight"], W[q_ + "fc2.bias"])
+            x = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], 1e-5)
+    return F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5) if pre_ln else x
 
 
 def init_wavlm_weights(cfg: dict, seed: int = 9, prefix="encoder.model.") -> Dict[str, torch.Tensor]:
@@ -332,7 +357,11 @@ def init_wavlm_weights(cfg: dict, seed: int = 9, prefix="encoder.model.") -> Dic
     for i, (co, k) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"])):
         p = f"{prefix}feature_extractor.conv_layers.{i}."
         W[p + "0.weight"] = rn(co, cin, k, std=(1.0 / (cin * k)) ** 0.5)
-        W[p + "2.1.weight"], W[p + "2.1.bias"] = 1 + rn(co, std=0.1), rn(co, std=0.1)
+        if cfg.get("hub_extractor_mode", "layer_norm") == "default":
+            if i == 0:
+                W[p + "2.weight"], W[p + "2.bias"] = 1 + rn(co, std=0.1), rn(co, std=0.1)
+        else:
+            W[p + "2.1.weight"], W[p + "2.1.bias"] = 1 + rn(co, std=0.1), rn(co, std=0.1)
         cin = co
     d, ffn, H = cfg["hub_dim"], cfg["hub_ffn"], cfg["hub_heads"]
     W[prefix + "layer_norm.weight"], W[prefix + "layer_norm.bias"] = 1 + rn(cin, std=0.1), rn(cin, std=0.1)

@@ -508,6 +508,75 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// GroupNorm with one group per channel over TIME + exact GELU: the first conv layer of the "default" feature extractor (WavLM
+// Base / Base+, HuBERT-base; src/slam_llm/models/wavlm/WavLM.py:428-441: Fp32GroupNorm(dim, dim, affine=True)).  x is the conv
+// output as fp32 [B*T, C] (time rows), every (clip, channel) is normalised over its T rows.  Three passes, HBM-bound:
+//   partial: per (clip, 256-row chunk) column sums of x and x^2 in fp32 (threads = channels: coalesced rows)
+//   final:   the chunks' partials combined in fp64 -> mean, rstd per (clip, channel)
+//   apply:   y = gelu((x - mean) * rstd * weight + bias) as bf16
+// ------------------------------------------------------------------------------------------
+constexpr int GN_ROWS = 256;
+__global__ __launch_bounds__(256) void gn_time_partial_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ part,
+                                                              int T, int C, int nch) {
+  const int ch = blockIdx.x, b = blockIdx.y;
+  const int r0 = ch * GN_ROWS, r1 = min(T, r0 + GN_ROWS);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f, q = 0.f;
+    const float* p = x + ((int64_t)b * T + r0) * ldx + c;
+    for (int r = r0; r < r1; r++, p += ldx) {
+      const float v = *p;
+      s += v;
+      q = fmaf(v, v, q);
+    }
+    float* o = part + ((int64_t)(b * nch + ch) * 2) * C + c;
+    o[0] = s;
+    o[C] = q;
+  }
+}
+__global__ __launch_bounds__(256) void gn_time_final_kernel(const float* __restrict__ part, float* __restrict__ stats, int T, int C,
+                                                            int nch, float eps) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int ch = 0; ch < nch; ch++) {
+    const float* o = part + ((int64_t)(b * nch + ch) * 2) * C + c;
+    s += (double)o[0];
+    q += (double)o[C];
+  }
+  const double mean = s / T;
+  const double var = fmax(q / T - mean * mean, 0.0);      // biased variance, as torch's group_norm
+  stats[((int64_t)b * 2) * C + c] = (float)mean;
+  stats[((int64_t)b * 2 + 1) * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+__global__ __launch_bounds__(256) void gn_time_apply_gelu_kernel(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y,
+                                                                 int64_t ldy, const float* __restrict__ stats,
+                                                                 const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                 int64_t BT, int T, int C) {
+  const int nq = C >> 2;
+  const int64_t total = BT * nq;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / nq;
+    const int c = (int)(i % nq) * 4;
+    const int b = (int)(m / T);
+    const float4 v = *reinterpret_cast<const float4*>(x + m * ldx + c);
+    const float4 mu = *reinterpret_cast<const float4*>(stats + ((int64_t)b * 2) * C + c);
+    const float4 rs = *reinterpret_cast<const float4*>(stats + ((int64_t)b * 2 + 1) * C + c);
+    const float4 w4 = *reinterpret_cast<const float4*>(weight + c);
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + c);
+    const float z[4] = {fmaf((v.x - mu.x) * rs.x, w4.x, b4.x), fmaf((v.y - mu.y) * rs.y, w4.y, b4.y),
+                        fmaf((v.z - mu.z) * rs.z, w4.z, b4.z), fmaf((v.w - mu.w) * rs.w, w4.w, b4.w)};
+    float g[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) g[e] = 0.5f * z[e] * (1.0f + erff(z[e] * 0.70710678118654752440f));
+    uint2 o;
+    o.x = pack2bf(g[0], g[1]);
+    o.y = pack2bf(g[2], g[3]);
+    *reinterpret_cast<uint2*>(y + m * ldy + c) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // exact GELU forward / backward (Q-Former feed-forward, HF Blip2QFormerIntermediate): y = x * Phi(x)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ z, int64_t ldz, bf16_t* __restrict__ y,
@@ -720,6 +789,30 @@ extern "C" int slam_wavlm_gate(const void* x, int64_t ldx, const float* w, const
   hipLaunchKernelGGL(wavlm_gate_kernel, dim3(ew_grid(B * T * H)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, w, bias,
                      grep_a, gate, (int)B, (int)T, (int)H, (int)Tp);
   SLAM_CHECK_LAUNCH("slam_wavlm_gate");
+  return 0;
+}
+
+extern "C" int64_t slam_groupnorm_time_workspace_bytes(int64_t B, int64_t T, int64_t C) {
+  const int64_t nch = (T + GN_ROWS - 1) / GN_ROWS;
+  return (B * nch * 2 * C + B * 2 * C) * (int64_t)sizeof(float);
+}
+
+extern "C" int slam_groupnorm_time_gelu(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t B, int64_t T, int64_t C,
+                                        const float* weight, const float* bias, float eps, float* workspace, void* stream) {
+  SLAM_CHECK_ARG(x && y && weight && bias && workspace, "slam_groupnorm_time_gelu: null pointer");
+  SLAM_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && B < 65536 &&
+                     T < (1ll << 31) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)workspace % 16) == 0,
+                 "slam_groupnorm_time_gelu: bad shape / alignment (C, ldx, ldy multiples of 4; x 16-byte aligned)");
+  const int nch = (int)((T + GN_ROWS - 1) / GN_ROWS);
+  float* part = workspace;
+  float* stats = workspace + B * nch * 2 * C;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_time_partial_kernel, dim3((unsigned)nch, (unsigned)B), dim3(256), 0, s, x, ldx, part, (int)T, (int)C, nch);
+  hipLaunchKernelGGL(gn_time_final_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)B), dim3(256), 0, s, part, stats, (int)T, (int)C,
+                     nch, eps);
+  hipLaunchKernelGGL(gn_time_apply_gelu_kernel, dim3(ew_grid(B * T * (C / 4))), dim3(256), 0, s, x, ldx, (bf16_t*)y, ldy, stats, weight,
+                     bias, B * T, (int)T, (int)C);
+  SLAM_CHECK_LAUNCH("slam_groupnorm_time_gelu");
   return 0;
 }
 

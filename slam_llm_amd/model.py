@@ -723,11 +723,22 @@ class HipHubertEncoder(nn.Module):
         cfg, w = self.cfg, self.w
         B, N = wav.shape
         x2d, Tin, cin = wav.contiguous().view(B * N, 1), N, 1
+        group_mode = cfg.get("hub_extractor_mode", "layer_norm") == "default"
+        pre_ln = cfg.get("hub_layer_norm_first", True)
         for i, (co, k, st) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"], cfg["hub_conv_stride"])):
             cols, Tout = ops.conv1d_im2col(x2d, B, Tin, 0, cin, k, st, 0, Kp=w[f"c{i}"].shape[1])
-            y = ops.gemm_nt(cols, w[f"c{i}"], bias=w[f"c{i}_b"])
-            del cols
-            x2d = ops.layernorm(y, w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5, out=y, gelu=True)
+            if not group_mode:      # "layer_norm" extractor: conv -> LayerNorm over channels -> GELU, every layer
+                y = ops.gemm_nt(cols, w[f"c{i}"], bias=w[f"c{i}_b"])
+                del cols
+                x2d = ops.layernorm(y, w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5, out=y, gelu=True)
+            elif i == 0:            # "default" extractor: GroupNorm (one group per channel, over TIME) after the first conv only;
+                y = ops.gemm_nt(cols, w[f"c{i}"], bias=w[f"c{i}_b"], out_dtype=torch.float32)   # statistics from the fp32 product
+                del cols
+                x2d = ops.groupnorm_time_gelu(y, B, Tout, w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5)
+                del y
+            else:                   # ... the other layers are conv -> GELU (fused in the GEMM epilogue)
+                x2d = ops.gemm_nt(cols, w[f"c{i}"], bias=w[f"c{i}_b"], act=ACT_GELU)
+                del cols
             Tin, cin = Tout, co
         T, d, H, eps = Tin, cfg["hub_dim"], cfg["hub_heads"], cfg["hub_eps"]
         M = B * T
@@ -757,17 +768,28 @@ class HipHubertEncoder(nn.Module):
         qkv = torch.empty((M, 3 * d), dtype=torch.bfloat16, device=wav.device)
         obuf = torch.empty((M, d), dtype=torch.bfloat16, device=wav.device)
         fbuf = torch.empty((M, cfg["hub_ffn"]), dtype=torch.bfloat16, device=wav.device)
+        if not pre_ln:      # post-LN encoders (Base): the encoder-level LayerNorm comes BEFORE the layers (WavLM.py:582-583)
+            ops.layernorm(x, w["lnp_w"], w["lnp_b"], eps, out=x)
         for i in range(cfg["hub_layers"]):
-            ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, out=hbuf)
-            ops.gemm_nt(hbuf, w[f"{i}.qkv"], out=qkv, bias=w[f"{i}.qkv_b"])
+            if pre_ln:
+                ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, out=hbuf)
+            attn_in = hbuf if pre_ln else x
+            ops.gemm_nt(attn_in, w[f"{i}.qkv"], out=qkv, bias=w[f"{i}.qkv_b"])
             vt = ops.head_rope_transpose(qkv, 2 * d, B, T, H, 64)
             ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=False, out=obuf,
-                         relpos=self._relpos(i, hbuf, B, T))
-            ops.gemm_nt(obuf, w[f"{i}.out"], out=x, bias=w[f"{i}.out_b"], residual=x)
-            ops.layernorm(x, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], eps, out=hbuf)
-            ops.gemm_nt(hbuf, w[f"{i}.fc1"], out=fbuf, bias=w[f"{i}.fc1_b"], act=ACT_GELU)
-            ops.gemm_nt(fbuf, w[f"{i}.fc2"], out=x, bias=w[f"{i}.fc2_b"], residual=x)
-        out = ops.layernorm(x, w["lnp_w"], w["lnp_b"], eps)
+                         relpos=self._relpos(i, attn_in, B, T))
+            if pre_ln:      # x += attn(LN1(x)); x += ffn(LN2(x))
+                ops.gemm_nt(obuf, w[f"{i}.out"], out=x, bias=w[f"{i}.out_b"], residual=x)
+                ops.layernorm(x, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], eps, out=hbuf)
+                ops.gemm_nt(hbuf, w[f"{i}.fc1"], out=fbuf, bias=w[f"{i}.fc1_b"], act=ACT_GELU)
+                ops.gemm_nt(fbuf, w[f"{i}.fc2"], out=x, bias=w[f"{i}.fc2_b"], residual=x)
+            else:           # x = LN1(x + attn(x)); x = LN2(x + ffn(x))   (WavLM.py:716-739)
+                ops.gemm_nt(obuf, w[f"{i}.out"], out=hbuf, bias=w[f"{i}.out_b"], residual=x)
+                ops.layernorm(hbuf, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, out=x)
+                ops.gemm_nt(x, w[f"{i}.fc1"], out=fbuf, bias=w[f"{i}.fc1_b"], act=ACT_GELU)
+                ops.gemm_nt(fbuf, w[f"{i}.fc2"], out=hbuf, bias=w[f"{i}.fc2_b"], residual=x)
+                ops.layernorm(hbuf, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], eps, out=x)
+        out = ops.layernorm(x, w["lnp_w"], w["lnp_b"], eps) if pre_ln else x
         return out.view(B, T, d)
 
     def _relpos(self, layer: int, attn_in: torch.Tensor, B: int, T: int):
@@ -780,7 +802,9 @@ class HipHubertEncoder(nn.Module):
 
 class HipWavLMEncoder(HipHubertEncoder):
     """Frozen WavLM encoder (src/slam_llm/models/wavlm/WavLM.py:220-376 as called through models/encoder.py:109-127 from
-    models/slam_model.py:333-334), WavLM-Large's configuration: "layer_norm" conv feature extractor without conv bias, feature
+    models/slam_model.py:333-334).  Base / Base+ (`hub_extractor_mode="default"`, `hub_layer_norm_first=False`): GroupNorm over
+    time after the first conv only (slam_groupnorm_time_gelu), conv -> GELU for the rest, post-LN layers with the encoder-level
+    LayerNorm in front of them.  WavLM-Large's configuration: "layer_norm" conv feature extractor without conv bias, feature
     LayerNorm + projection, weight-normed grouped positional conv, layer_norm_first transformer -- i.e. HuBERT-large's graph (the
     parent class) -- plus the gated relative position bias in every attention (modules.py:504-533): layer 0's bucketed
     `relative_attention_bias` is laid out once per sequence length as a per-head table over the relative distance k - q, each
@@ -799,7 +823,11 @@ class HipWavLMEncoder(HipHubertEncoder):
             wc[:, : k * cin] = bf(W[p + "0.weight"].permute(0, 2, 1).reshape(co, k * cin))
             cb = W.get(p + "0.bias")                                  # conv_bias=False in the released WavLM configurations
             w[f"c{i}"], w[f"c{i}_b"] = wc, (f32(cb) if cb is not None else torch.zeros(co, dtype=torch.float32, device=dev))
-            w[f"c{i}_lw"], w[f"c{i}_lb"] = f32(W[p + "2.1.weight"]), f32(W[p + "2.1.bias"])
+            if cfg.get("hub_extractor_mode", "layer_norm") == "default":    # Base: GroupNorm after the first conv only
+                if i == 0:
+                    w[f"c{i}_lw"], w[f"c{i}_lb"] = f32(W[p + "2.weight"]), f32(W[p + "2.bias"])
+            else:
+                w[f"c{i}_lw"], w[f"c{i}_lb"] = f32(W[p + "2.1.weight"]), f32(W[p + "2.1.bias"])
             cin = co
         d, H = cfg["hub_dim"], cfg["hub_heads"]
         assert d % 64 == 0 and d // H == 64 and cin % 64 == 0

@@ -386,6 +386,18 @@ def relpos_table(values_hr: torch.Tensor) -> torch.Tensor:
     return tab
 
 
+def groupnorm_time_gelu(x_f32: torch.Tensor, B: int, T: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """x_f32 [B*T, C] fp32 (time rows of B clips) -> gelu(GroupNorm with one group per channel over each clip's T rows) as bf16
+    [B*T, C]: the first conv layer of the "default" feature extractor (WavLM Base; WavLM.py:428-441)"""
+    M, C = x_f32.shape
+    assert M == B * T and x_f32.dtype == torch.float32
+    nbytes = call("slam_groupnorm_time_workspace_bytes", B, T, C)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x_f32.device)
+    y = torch.empty((M, C), dtype=torch.bfloat16, device=x_f32.device)
+    call("slam_groupnorm_time_gelu", _p(x_f32), _ld(x_f32), _p(y), _ld(y), B, T, C, _p(weight), _p(bias), float(eps), _p(ws), _s())
+    return y
+
+
 def wavlm_gate(x2d: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, grep_a: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:
     """x2d [B*T, H*64] bf16 (the attention input), grep_linear w [8,64] / bias [8] f32, grep_a [H] f32 -> gate [B,H,Tp] f32"""
     Tp = round_up(T, 64)

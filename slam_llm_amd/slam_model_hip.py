@@ -54,10 +54,14 @@ HUBERT_PRESETS = {
 
 WAVLM_PRESETS = {
     # WavLM-Large (the released checkpoint's cfg: extractor_mode layer_norm, conv_bias false, layer_norm_first, gru_rel_pos,
-    # 320 buckets / max_distance 800; models/wavlm/WavLM.py:162-214).  Base / Base+ use the group-norm extractor and post-LN
-    # layers: not implemented.
+    # 320 buckets / max_distance 800; models/wavlm/WavLM.py:162-214).
     "wavlm-large": dict(HUBERT_PRESETS["hubert-large"], wavlm_buckets=320, wavlm_max_distance=800),
+    # Base / Base+ (same architecture, different training data): extractor_mode "default" (GroupNorm after the first conv only),
+    # post-LN layers, 12 x 768 / 12 heads / ffn 3072
+    "wavlm-base": dict(HUBERT_PRESETS["hubert-large"], hub_dim=768, hub_heads=12, hub_layers=12, hub_ffn=3072, wavlm_buckets=320,
+                       wavlm_max_distance=800, hub_extractor_mode="default", hub_layer_norm_first=False),
 }
+WAVLM_PRESETS["wavlm-base-plus"] = WAVLM_PRESETS["wavlm-base"]
 
 
 def build_config(train_config, model_config) -> dict:

@@ -280,6 +280,41 @@ def test_wavlm_encoder_matches_reference_fixture(dev):
     assert rel_err(a, g) > 6e-2
 
 
+def test_wavlm_base_encoder_matches_reference_fixture(dev):
+    """f4: the Base / Base+ structure (GroupNorm over time after the first conv via slam_groupnorm_time_gelu, conv -> GELU for the
+    other layers, post-LN layers behind the encoder-level LayerNorm) vs the fixture written by the reference's own WavLM module
+    configured that way: equal-length batch and ragged zero-padded batch (valid frames)"""
+    from oracle.make_golden_cases import WAVLM_BASE_TINY as C
+    from slam_llm_amd.model import HipWavLMEncoder
+    fx = G.load("wavlm_base_tiny")
+    W = O.init_wavlm_weights(C, seed=10)
+    enc = HipWavLMEncoder(dict(C), dev).load(W)
+    out = enc.forward_wav(torch.from_numpy(fx["wav"]).to(dev)).float().cpu().numpy()
+    assert list(out.shape) == [int(x) for x in fx["out_shape"]]
+    g, a = G.sub(fx, "out", out)
+    assert rel_err(a, g) < 3e-2 and G.cosine(g, a) > 0.9995, (rel_err(a, g), G.cosine(g, a))
+    nv = [int(x) for x in fx["ragged.n_valid"]]
+    out_r = enc.forward_wav(torch.from_numpy(fx["ragged.wav"]).to(dev), nv).float().cpu()
+    pad = torch.from_numpy(fx["ragged.frame_padding_mask"])
+    g, a = G.sub(fx, "ragged.out", out_r.masked_fill(pad[:, :, None], 0.0).numpy())
+    assert rel_err(a, g) < 3e-2 and G.cosine(g, a) > 0.9995, (rel_err(a, g), G.cosine(g, a))
+
+
+def test_groupnorm_over_time_with_gelu(dev):
+    """slam_groupnorm_time_gelu == F.gelu(F.group_norm(x, C groups)) on [B, C, T] (one group per channel, statistics over time),
+    T not a multiple of the kernel's row chunk, a large offset to exercise the variance (fp64 combination of the partial sums)"""
+    from slam_llm_amd import ops
+    B, T, C = 3, 1000, 192
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(B * T, C, generator=g, device=dev) * 2.0 + 30.0
+    wgt = 1 + 0.1 * torch.randn(C, generator=g, device=dev)
+    bias = 0.1 * torch.randn(C, generator=g, device=dev)
+    y = ops.groupnorm_time_gelu(x, B, T, wgt, bias, 1e-5).float()
+    ref = torch.nn.functional.gelu(torch.nn.functional.group_norm(x.view(B, T, C).transpose(1, 2), C, wgt, bias, 1e-5)).transpose(1, 2)
+    err = (y.view(B, T, C) - ref).abs().max()
+    assert float(err) < 2e-2, float(err)      # bf16 output rounding of O(1) values
+
+
 def test_wavlm_llm_step_matches_oracle(dev):
     """WavLM -> linear projector -> LLM + LoRA training step at tiny widths: loss vs the oracle, and it trains"""
     from oracle.make_golden_cases import WAVLM_TINY

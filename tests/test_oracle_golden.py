@@ -144,6 +144,25 @@ def test_wavlm_encoder_matches_the_reference_module():
         assert int(wavlm_relative_buckets(T, nb, md).max()) < nb
 
 
+def test_wavlm_base_encoder_matches_the_reference_module():
+    """the Base / Base+ structure (extractor_mode "default": GroupNorm over time after the first conv only; post-LN layers with the
+    encoder-level LayerNorm in front of them): oracle == the reference's own WavLM on the fixture it wrote, equal-length and ragged"""
+    from oracle.make_golden_cases import WAVLM_BASE_TINY as C
+    assert C["hub_extractor_mode"] == "default" and C["hub_layer_norm_first"] is False
+    fx = G.load("wavlm_base_tiny")
+    W = O.init_wavlm_weights(C, seed=10)
+    assert not any(k.endswith("2.1.weight") for k in W) and sum(k.endswith("conv_layers.0.2.weight") for k in W) == 1
+    with torch.no_grad():
+        out = O.wavlm_encoder(W, C, torch.from_numpy(fx["wav"]))
+        nv = torch.from_numpy(fx["ragged.n_valid"])
+        out_r = O.wavlm_encoder(W, C, torch.from_numpy(fx["ragged.wav"]), n_valid=nv)
+    assert list(out.shape) == [int(x) for x in fx["out_shape"]]
+    G.check_packed(fx, "out", out.numpy(), atol=3e-5, rtol=1e-4)
+    pad = O.hubert_frame_padding_mask(fx["ragged.wav"].shape[1], out_r.shape[1], nv)
+    assert np.array_equal(pad.numpy(), fx["ragged.frame_padding_mask"])
+    G.check_packed(fx, "ragged.out", out_r.masked_fill(pad[:, :, None], 0.0).numpy(), atol=3e-5, rtol=1e-4)
+
+
 def test_qformer_projector_matches_reference_module():
     from oracle.make_golden_cases import QFORMER_CASE as C
     fx = G.load("qformer")
