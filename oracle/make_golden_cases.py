@@ -37,6 +37,9 @@ UNFROZEN_CASE = dict(cfg=O.make_config(), clip_seconds=1.77, answer_lens=(5, 9),
 # inside ~50 frames
 WAVLM_TINY = O.wavlm_config(hub_conv_dim=(64,) * 7, hub_dim=128, hub_heads=2, hub_layers=2, hub_ffn=256, hub_pos_k=16,
                             hub_pos_groups=4, wavlm_buckets=40, wavlm_max_distance=24)
+# HuBERT-base structure (HF: feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False) at toy widths
+HUBERT_BASE_TINY = O.hubert_base_config(hub_conv_dim=(64,) * 7, hub_dim=128, hub_heads=2, hub_layers=2, hub_ffn=256, hub_pos_k=16,
+                                        hub_pos_groups=4)
 # WavLM Base structure (group-norm extractor, post-LN layers) at toy widths
 WAVLM_BASE_TINY = O.wavlm_base_config(hub_conv_dim=(64,) * 7, hub_dim=128, hub_heads=2, hub_layers=2, hub_ffn=256, hub_pos_k=16,
                                       hub_pos_groups=4, wavlm_buckets=40, wavlm_max_distance=24)

@@ -132,6 +132,15 @@ def hubert_config(**kw) -> dict:
     return c
 
 
+def hubert_base_config(**kw) -> dict:
+    """HuBERT-base geometry (fairseq hubert_base: extractor_mode="default", layer_norm_first=False; HF HubertConfig:
+    feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False): GroupNorm over time after the first conv only,
+    post-LN layers behind the encoder-level LayerNorm, 12 x 768 / 12 heads / ffn 3072."""
+    c = hubert_config(hub_dim=768, hub_heads=12, hub_layers=12, hub_ffn=3072, hub_extractor_mode="default", hub_layer_norm_first=False)
+    c.update(kw)
+    return c
+
+
 def hubert_frame_padding_mask(n_samples: int, n_frames: int, n_valid: torch.Tensor) -> torch.Tensor:
     """fairseq HubertModel.forward_padding_mask (fairseq/models/hubert/hubert.py, fairseq is an un-vendored, unpinned dependency
     of the reference: README.md:89-95): the sample-level padding mask [B, N] is cut to a multiple of the frame count, viewed as
@@ -156,11 +165,18 @@ def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pre
     masked as attention KEYS in every layer; their own output rows are garbage (never read: the splice takes the clip's first
     len//320//5 projector frames)."""
     x = wav[:, None, :]
+    group_mode = cfg.get("hub_extractor_mode", "layer_norm") == "default"
+    pre_ln = cfg.get("hub_layer_norm_first", True)
     for i, (k, st) in enumerate(zip(cfg["hub_conv_kernel"], cfg["hub_conv_stride"])):
         p = f"{prefix}feature_extractor.conv_layers.{i}."
-        x = F.conv1d(x, W[p + "conv.weight"], W[p + "conv.bias"], stride=st)
-        x = F.layer_norm(x.transpose(-2, -1), (x.shape[1],), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5)
-        x = F.gelu(x.transpose(-2, -1))
+        x = F.conv1d(x, W[p + "conv.weight"], W.get(p + "conv.bias"), stride=st)
+        if group_mode:      # HubertGroupNormConvLayer for layer 0 (modeling_hubert.py:153-176), HubertNoLayerNormConvLayer after it
+            if i == 0:
+                x = F.group_norm(x, x.shape[1], W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5)
+            x = F.gelu(x)
+        else:
+            x = F.layer_norm(x.transpose(-2, -1), (x.shape[1],), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5)
+            x = F.gelu(x.transpose(-2, -1))
     x = x.transpose(1, 2)  # [B, T', C]
     eps = cfg["hub_eps"]
     p = prefix + "feature_projection."
@@ -181,9 +197,11 @@ def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pre
     B, T, d = x.shape
     H = cfg["hub_heads"]
     hd = d // H
+    if not pre_ln:      # HubertEncoder (post-LN, modeling_hubert.py:470-520): the encoder LayerNorm precedes the layers
+        x = F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], eps)
     for i in range(cfg["hub_layers"]):
         q_ = f"{p}layers.{i}."
-        h = F.layer_norm(x, (d,), W[q_ + "layer_norm.weight"], W[q_ + "layer_norm.bias"], eps)
+        h = F.layer_norm(x, (d,), W[q_ + "layer_norm.weight"], W[q_ + "layer_norm.bias"], eps) if pre_ln else x
         q = F.linear(h, W[q_ + "attention.q_proj.weight"], W[q_ + "attention.q_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
         k = F.linear(h, W[q_ + "attention.k_proj.weight"], W[q_ + "attention.k_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
         v = F.linear(h, W[q_ + "attention.v_proj.weight"], W[q_ + "attention.v_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
@@ -193,11 +211,15 @@ def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pre
         a = F.softmax(sc, dim=-1) @ v
         a = a.transpose(1, 2).reshape(B, T, d)
         x = x + F.linear(a, W[q_ + "attention.out_proj.weight"], W[q_ + "attention.out_proj.bias"])
-        h = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], eps)
+        if not pre_ln:  # HubertEncoderLayer (:395-420): x = LN(x + attn(x)); x = LN_final(x + ffn(x))
+            x = F.layer_norm(x, (d,), W[q_ + "layer_norm.weight"], W[q_ + "layer_norm.bias"], eps)
+        h = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], eps) if pre_ln else x
         h = F.linear(F.gelu(F.linear(h, W[q_ + "feed_forward.intermediate_dense.weight"], W[q_ + "feed_forward.intermediate_dense.bias"])),
                      W[q_ + "feed_forward.output_dense.weight"], W[q_ + "feed_forward.output_dense.bias"])
         x = x + h
-    return F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], eps)
+        if not pre_ln:
+            x = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], eps)
+    return F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], eps) if pre_ln else x
 
 
 def init_hubert_weights(cfg: dict, seed: int = 7, prefix="encoder.") -> Dict[str, torch.Tensor]:
@@ -211,9 +233,13 @@ def init_hubert_weights(cfg: dict, seed: int = 7, prefix="encoder.") -> Dict[str
     for i, (co, k) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"])):
         p = f"{prefix}feature_extractor.conv_layers.{i}."
         W[p + "conv.weight"] = rn(co, cin, k, std=(1.0 / (cin * k)) ** 0.5)
-        W[p + "conv.bias"] = rn(co)
-        W[p + "layer_norm.weight"] = 1 + rn(co, std=0.1)
-        W[p + "layer_norm.bias"] = rn(co, std=0.1)
+        if cfg.get("hub_extractor_mode", "layer_norm") == "default":     # base: no conv bias, GroupNorm on layer 0 only
+            if i == 0:
+                W[p + "layer_norm.weight"], W[p + "layer_norm.bias"] = 1 + rn(co, std=0.1), rn(co, std=0.1)
+        else:
+            W[p + "conv.bias"] = rn(co)
+            W[p + "layer_norm.weight"] = 1 + rn(co, std=0.1)
+            W[p + "layer_norm.bias"] = rn(co, std=0.1)
         cin = co
     d, ffn = cfg["hub_dim"], cfg["hub_ffn"]
     p = prefix + "feature_projection."

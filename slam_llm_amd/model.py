@@ -615,7 +615,9 @@ class HipWhisperEncoder(nn.Module):
 # ======================================================================================== hubert encoder
 class HipHubertEncoder(nn.Module):
     """Frozen HuBERT encoder (fairseq HubertModel as called at src/slam_llm/models/slam_model.py:335-341;
-    architecture per its HF twin, transformers/models/hubert/modeling_hubert.py): 7 LayerNorm conv layers
+    architecture per its HF twin, transformers/models/hubert/modeling_hubert.py).  Base geometry (`hub_extractor_mode="default"`,
+    `hub_layer_norm_first=False`): GroupNorm over time after the first conv only, conv -> GELU for the rest, post-LN layers behind
+    the encoder LayerNorm.  Large / xlarge: 7 LayerNorm conv layers
     (im2col + MFMA GEMM + fused LayerNorm-GELU), feature projection, grouped positional conv (one GEMM per group with
     the GELU and the residual add fused in the epilogue), pre-LN transformer, final LayerNorm.  Inference-only.
     Weights use the HF state-dict names under `encoder.` (fairseq -> HF renaming is HF's conversion script)."""
@@ -634,8 +636,10 @@ class HipHubertEncoder(nn.Module):
             kp = round_up(k * cin, 64)
             wc = torch.zeros((co, kp), dtype=torch.bfloat16, device=dev)
             wc[:, : k * cin] = bf(W[p + "conv.weight"].permute(0, 2, 1).reshape(co, k * cin))
-            w[f"c{i}"], w[f"c{i}_b"] = wc, f32(W[p + "conv.bias"])
-            w[f"c{i}_lw"], w[f"c{i}_lb"] = f32(W[p + "layer_norm.weight"]), f32(W[p + "layer_norm.bias"])
+            cb = W.get(p + "conv.bias")                                  # conv_bias=False in the base configuration
+            w[f"c{i}"], w[f"c{i}_b"] = wc, (f32(cb) if cb is not None else torch.zeros(co, dtype=torch.float32, device=dev))
+            if p + "layer_norm.weight" in W:                             # base ("default" extractor): GroupNorm on layer 0 only
+                w[f"c{i}_lw"], w[f"c{i}_lb"] = f32(W[p + "layer_norm.weight"]), f32(W[p + "layer_norm.bias"])
             cin = co
         d = cfg["hub_dim"]
         assert d % 64 == 0 and d // cfg["hub_heads"] == 64 and cin % 64 == 0

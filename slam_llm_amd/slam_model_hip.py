@@ -50,6 +50,10 @@ HUBERT_PRESETS = {
                          hub_dim=1024, hub_heads=16, hub_layers=24, hub_ffn=4096, hub_pos_k=128, hub_pos_groups=16, hub_eps=1e-5),
     "hubert-xlarge": dict(hub_conv_dim=(512,) * 7, hub_conv_kernel=(10, 3, 3, 3, 3, 2, 2), hub_conv_stride=(5, 2, 2, 2, 2, 2, 2),
                           hub_dim=1280, hub_heads=20, hub_layers=48, hub_ffn=5120, hub_pos_k=128, hub_pos_groups=16, hub_eps=1e-5),
+    # base: "default" extractor (GroupNorm over time after the first conv only, no conv bias), post-LN layers
+    "hubert-base": dict(hub_conv_dim=(512,) * 7, hub_conv_kernel=(10, 3, 3, 3, 3, 2, 2), hub_conv_stride=(5, 2, 2, 2, 2, 2, 2),
+                        hub_dim=768, hub_heads=12, hub_layers=12, hub_ffn=3072, hub_pos_k=128, hub_pos_groups=16, hub_eps=1e-5,
+                        hub_extractor_mode="default", hub_layer_norm_first=False),
 }
 
 WAVLM_PRESETS = {

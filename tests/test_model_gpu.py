@@ -280,6 +280,25 @@ def test_wavlm_encoder_matches_reference_fixture(dev):
     assert rel_err(a, g) > 6e-2
 
 
+def test_hubert_base_encoder_matches_hf_fixture(dev):
+    """HuBERT-base structure through the HF state-dict names (no conv bias, GroupNorm on conv layer 0 only, post-LN layers) vs the
+    fixture written by HF HubertModel: equal-length batch and ragged zero-padded batch (valid frames)"""
+    from oracle.make_golden_cases import HUBERT_BASE_TINY as C
+    from slam_llm_amd.model import HipHubertEncoder
+    fx = G.load("hubert_base_tiny")
+    W = O.init_hubert_weights(C, seed=8)
+    enc = HipHubertEncoder(dict(C), dev).load(W)
+    out = enc.forward_wav(torch.from_numpy(fx["wav"]).to(dev)).float().cpu().numpy()
+    assert list(out.shape) == [int(x) for x in fx["out_shape"]]
+    g, a = G.sub(fx, "out", out)
+    assert rel_err(a, g) < 3e-2 and G.cosine(g, a) > 0.9995, (rel_err(a, g), G.cosine(g, a))
+    nv = [int(x) for x in fx["ragged.n_valid"]]
+    out_r = enc.forward_wav(torch.from_numpy(fx["ragged.wav"]).to(dev), nv).float().cpu()
+    pad = torch.from_numpy(fx["ragged.frame_padding_mask"])
+    g, a = G.sub(fx, "ragged.out", out_r.masked_fill(pad[:, :, None], 0.0).numpy())
+    assert rel_err(a, g) < 3e-2 and G.cosine(g, a) > 0.9995, (rel_err(a, g), G.cosine(g, a))
+
+
 def test_wavlm_base_encoder_matches_reference_fixture(dev):
     """f4: the Base / Base+ structure (GroupNorm over time after the first conv via slam_groupnorm_time_gelu, conv -> GELU for the
     other layers, post-LN layers behind the encoder-level LayerNorm) vs the fixture written by the reference's own WavLM module

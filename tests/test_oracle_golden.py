@@ -122,6 +122,24 @@ def test_hubert_ragged_batch_matches_masked_twin():
     G.check_packed(fx, "out", out.masked_fill(pad[:, :, None], 0.0).numpy(), atol=3e-5, rtol=1e-4)
 
 
+def test_hubert_base_encoder_matches_hf_twin():
+    """HuBERT-base structure (GroupNorm over time after the first conv only, no conv bias, post-LN layers): oracle == HF HubertModel
+    configured feat_extract_norm="group", do_stable_layer_norm=False (fixture: oracle/make_golden_hubert_base.py)"""
+    from oracle.make_golden_cases import HUBERT_BASE_TINY as C
+    fx = G.load("hubert_base_tiny")
+    W = O.init_hubert_weights(C, seed=8)
+    assert not any(k.endswith("conv.bias") and "feature_extractor" in k for k in W)
+    with torch.no_grad():
+        out = O.hubert_encoder(W, C, torch.from_numpy(fx["wav"]))
+        nv = torch.from_numpy(fx["ragged.n_valid"])
+        out_r = O.hubert_encoder(W, C, torch.from_numpy(fx["ragged.wav"]), n_valid=nv)
+    assert list(out.shape) == [int(x) for x in fx["out_shape"]]
+    G.check_packed(fx, "out", out.numpy(), atol=3e-5, rtol=1e-4)
+    pad = O.hubert_frame_padding_mask(fx["ragged.wav"].shape[1], out_r.shape[1], nv)
+    assert np.array_equal(pad.numpy(), fx["ragged.frame_padding_mask"])
+    G.check_packed(fx, "ragged.out", out_r.masked_fill(pad[:, :, None], 0.0).numpy(), atol=3e-5, rtol=1e-4)
+
+
 def test_wavlm_encoder_matches_the_reference_module():
     """oracle.wavlm_encoder == the reference's own WavLM (models/wavlm/WavLM.py, fixture written by oracle/make_golden_wavlm.py):
     equal-length and ragged zero-padded batches; the product's host-side bucket table == the oracle's bucket function"""
