@@ -206,6 +206,22 @@ def test_wavlm_and_unfrozen_whisper_recipes_build():
     assert build_config(tc, mc)["freeze_encoder"] is False
 
 
+def test_base_encoder_geometries_are_selected_from_the_checkpoint_name():
+    """WavLM Base / Base+ and HuBERT-base (group-norm extractor, post-LN layers, 12 x 768) through `encoder_path`; the large
+    presets keep the layer-norm extractor / pre-LN defaults"""
+    from slam_llm_amd.slam_model_hip import build_config, check_supported
+    for path, name, dim, layers, post_ln in (("/ckpt/WavLM-Base+.pt", "wavlm", 768, 12, True), ("/ckpt/WavLM-Base.pt", "wavlm", 768, 12, True),
+                                              ("/ckpt/wavlm_base_plus.pt", "wavlm", 768, 12, True), ("/ckpt/WavLM-Large.pt", "wavlm", 1024, 24, False),
+                                              ("/ckpt/hubert_base_ls960.pt", "hubert", 768, 12, True), ("/ckpt/hubert_large_ll60k.pt", "hubert", 1024, 24, False)):
+        tc, mc, _ = recipe_configs("aispeech_asr", dict(encoder_name=name, encoder_path=path, encoder_dim=dim, llm_name="vicuna-7b-v1.5",
+                                                         llm_dim=4096, encoder_projector="linear"), dict(freeze_encoder=True, use_peft=True))
+        check_supported(tc, mc)
+        cfg = build_config(tc, mc)
+        assert cfg["enc_dim"] == dim and cfg["hub_dim"] == dim and cfg["hub_layers"] == layers and cfg["hub_dim"] // cfg["hub_heads"] == 64, path
+        assert (cfg.get("hub_extractor_mode", "layer_norm") == "default") == post_ln, path
+        assert cfg.get("hub_layer_norm_first", True) == (not post_ln), path
+
+
 # ---------------------------------------------------------------------------------------------- dataset formats
 def _wav(path, pcm, rate=16000):
     data = pcm.astype("<i2").tobytes()
