@@ -334,17 +334,22 @@ def test_groupnorm_over_time_with_gelu(dev):
     assert float(err) < 2e-2, float(err)      # bf16 output rounding of O(1) values
 
 
-def test_wavlm_llm_step_matches_oracle(dev):
-    """WavLM -> linear projector -> LLM + LoRA training step at tiny widths: loss vs the oracle, and it trains"""
-    from oracle.make_golden_cases import WAVLM_TINY
+@pytest.mark.parametrize("case", ["large", "base"])
+def test_wavlm_llm_step_matches_oracle(dev, case):
+    """WavLM (Large structure / Base structure) -> linear projector -> LLM + LoRA training step at tiny widths: loss vs the oracle,
+    and it trains"""
+    from oracle.make_golden_cases import WAVLM_BASE_TINY, WAVLM_TINY
     from slam_llm_amd.model import SlamAdamW, SlamHipModel
+    WAVLM_TINY = WAVLM_TINY if case == "large" else WAVLM_BASE_TINY
     cfg = dict(O.make_config(), **WAVLM_TINY)
     cfg.update(encoder_name="wavlm", enc_dim=WAVLM_TINY["hub_dim"])
     W = {k: v for k, v in O.init_weights(cfg, seed=42).items() if not k.startswith("encoder.")}
     W.update(O.init_wavlm_weights(WAVLM_TINY, seed=9))
     model = SlamHipModel(dict(cfg, lora_dropout=0.0), dev).load_weights(W)
     model.train()
-    wav = torch.nn.functional.layer_norm(O.synth_audio(2, 1.0, seed=9), (16000,))
+    wav = O.synth_audio(2, 1.0, seed=9)
+    if case == "large":     # the Large checkpoint's cfg has normalize=True (dataset-side layer norm of the waveform), Base has not
+        wav = torch.nn.functional.layer_norm(wav, (16000,))
     Ta = 49 // cfg["ds_rate"]
     samples = [O.make_sample(Ta, [5, 6, 7], [9, 10, 11, 12], 2), O.make_sample(Ta, [5, 6], [9, 10], 2)]
     ob = O.collate_left_pad(samples, pad_id=2)
