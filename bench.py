@@ -271,7 +271,7 @@ def main():
     from slam_llm_amd import ops
     from slam_llm_amd.model import SlamAdamW, SlamHipModel
     from slam_llm_amd.slam_model_hip import build_config
-    from slam_llm_amd.train import GradSync, lr_lambda, setup_distributed, train_step
+    from slam_llm_amd.train import GradSync, lr_lambda, rccl_version, setup_distributed, train_step
 
     rank, local_rank, world = setup_distributed("cuda")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -307,6 +307,8 @@ def main():
     if world > 1:
         dist.barrier()
     ops.TIMER = ops.KernelTimer()
+    if gsync is not None:
+        gsync.time_finish = True    # HIP events around finish(): the part of the gradient exchange the backward did not hide
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -316,10 +318,13 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.TIMER = ops.TIMER, None
+    comm_exposed_ms = gsync.exposed_ms_per_step() if gsync is not None else None
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed, comm_exposed_ms or 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        elapsed = float(te[0].item())
+        if comm_exposed_ms is not None:
+            comm_exposed_ms = float(te[1].item())
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -370,7 +375,10 @@ def main():
                                + "fwd+bwd+grad all-reduce+fused AdamW",
                    "global_batch_clips": world * n_clips, "seq_len": T, "parallelism": f"dp{world}",
                    "grad_exchange": None if world == 1 else ("DistributedDataParallel" if args.ddp else "GradSync (flat-buffer prefixes)"),
-                   "backend": backend if backend != "nccl" else "nccl (RCCL)",
+                   "backend": backend if backend != "nccl" else f"nccl (RCCL {rccl_version()})",
+                   # max over ranks of the mean HIP-event time of GradSync.finish() per step: tail bucket launch + waits on the compute stream
+                   "comm_exposed_ms": comm_exposed_ms,
+                   "grad_buffer_MB": model.store.grad.numel() * 4 / 1e6 if world > 1 else None,
                    "logits": "full [B*T, V] lm_head computed (chunked), not materialised in fp32"},
         "loss": float(loss), "acc": float(acc),
         "model_flops_per_step_per_gpu": step_flops,

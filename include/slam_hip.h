@@ -133,7 +133,7 @@ int slam_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int
  * seg_lo[q] = first row of q's sequence, seg_hi[k] = one past the last row of k's sequence (int32, non-decreasing,
  * nullable): query q attends keys seg_lo[q] <= k <= q only.  Equals the right-padded batch of the reference's
  * MultiTaskDataset collator (speech_dataset_large.py:180-233) on every valid token. */
-int slam_attn_set_fwd_qf(int qf);   /* tools: 0 = auto, 1 / 2 = query fragments per wave of the forward kernel; 10 / 11 = register-staged / LDS-DMA tiles */
+int slam_attn_set_fwd_qf(int qf);   /* tools: 0 = auto, 1 / 2 = query fragments per wave of the forward kernel; 10 / 11 = register-staged / LDS-DMA tiles; 20 / 21 = hardware round-robin / XCD-aware (shipped) workgroup numbering of ALL attention kernels */
 int slam_attn_debug_clock(unsigned long long* out256);   /* tools: cycle stamps written by the probe form of the dQ kernel (variant 14): [wave 0|3][tile < 16][8] */
 int slam_attn_set_bwd_variant(int variant);   /* tools: 0 = DMA-ring backward kernels (shipped), 1 = the round-1 register-staged kernels, 2 = ring dK/dV with the register-staged dQ, 14 = dQ kernel with cycle stamps, 11/12/15 = timing ablations (wrong results) */
 int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, void* O,

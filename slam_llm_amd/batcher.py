@@ -94,11 +94,16 @@ def _pad1(t: torch.Tensor, left: int, right: int, value) -> torch.Tensor:
 
 
 def collate(samples: List[dict], pad_token_id: int, left_pad_prompt: bool, n_samples: int = 480000,
-            input_type: str = "mel") -> dict:
+            input_type: str = "mel", pad_or_trim: bool = True) -> dict:
     """left_pad_prompt=True: SpeechDatasetJsonl.collator; False: MultiTaskDataset.collator (right padding only).
     input_type "mel": Whisper recipes -- the waveform is carried instead of the CPU log-mel (`audio` + `audio_len`, trimmed
     to n_samples as whisper.pad_or_trim would).  "raw": HuBERT / WavLM recipes -- `audio` zero padded to the longest clip
-    plus the reference's float `audio_mask` (speech_dataset.py:238-244)."""
+    plus the reference's float `audio_mask` (speech_dataset.py:238-244).
+    "mel" batches also carry `audio_mel_post_mask` exactly as the reference's collators build it (speech_dataset.py:246-249,
+    speech_dataset_large.py:198-200): [(Tmax + 1) // 2] columns, ones over each clip's own (frames + 1) // 2 encoder frames --
+    frames = 3000 for every clip under pad_or_trim (whisper.pad_or_trim, speech_dataset.py:101), else the clip's own
+    min(n, n_samples) // 160 with Tmax = the mel length the GPU front end produces for the batch.  Only the Q-Former branch reads
+    it (slam_model.py:354-355)."""
     if left_pad_prompt:
         pl = [s["audio_length"] + s["prompt_length"] for s in samples]
         al = [len(s["input_ids"]) - p for s, p in zip(samples, pl)]
@@ -130,6 +135,15 @@ def collate(samples: List[dict], pad_token_id: int, left_pad_prompt: bool, n_sam
         out["audio"] = torch.stack([torch.nn.functional.pad(s["audio"][:amax].float(), (0, amax - min(len(s["audio"]), amax)))
                                     for s in samples])
         out["audio_len"] = alen
+        if pad_or_trim:
+            frames, tmax = [n_samples // 160] * len(samples), n_samples // 160
+        else:
+            frames = [int(n) // 160 for n in alen]
+            tmax = min(n_samples, (amax + 159) // 160 * 160) // 160      # SlamHipModel.forward: per-clip mel zero padded to the batch max
+        pmask = torch.zeros(len(samples), (tmax + 1) // 2)
+        for i, fr in enumerate(frames):
+            pmask[i, : (fr + 1) // 2] = 1
+        out["audio_mel_post_mask"] = pmask
     out["audio_len_list"] = [int(x) for x in out["audio_len"]]   # host copy: survives the train loop's tensor-only .to(device)
     if "key" in samples[0]:  # inference-mode batches carry the utterance ids / references (speech_dataset.py:259-273)
         out["keys"] = [s.get("key") for s in samples]

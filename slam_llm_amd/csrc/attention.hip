@@ -71,7 +71,32 @@ struct AttnParams {
   unsigned drop_thresh;
   float drop_scale;
   unsigned long long drop_seed;
+  // launch geometry (set by attn_launch): the logical grid is (gx sequence blocks, gy heads, gz batches), launched 1-D
+  int gx, gy, gz;
+  int xcd;   // 1: undo the hardware's round-robin workgroup -> XCD placement (attn_blk)
 };
+
+// Workgroup -> (sequence block, head, batch).  The hardware deals consecutive workgroups round-robin over the 8 XCDs (workgroup L
+// runs on XCD L % 8), each with its own L2: with the plain (block, head, batch) grid the query blocks of one (batch, head) -- and the
+// q-heads of a GQA group, which share one K/V -- land on all eight XCDs and every L2 fetches the same K/V (round 2 counters: 2.3-5.9x
+// the algorithmic bytes, 4.3-4.9 TB/s of fabric traffic).  The grid is therefore launched 1-D and re-numbered with the bijection
+// of the GEMM (gemm_bf16.hip): XCD x owns the contiguous run of logical ids [base(x), base(x+1)), and logical ids run sequence
+// block fastest, then head (GQA siblings adjacent), then batch -- everything that shares a K/V (forward, dQ) or a Q/dO (dK/dV)
+// tile set is co-resident on ONE XCD.
+struct AttnBlk { int x, y, z; };
+__device__ __forceinline__ AttnBlk attn_blk(const AttnParams& p) {
+  int bid = blockIdx.x;
+  if (p.xcd) {
+    const int n = gridDim.x, xcd = bid & 7, q = n >> 3, r = n & 7;
+    bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  AttnBlk o;
+  o.x = bid % p.gx;
+  const int t = bid / p.gx;
+  o.y = t % p.gy;
+  o.z = t / p.gy;
+  return o;
+}
 
 // keep bits (bit r) of keys kb .. kb+3 (kb % 4 == 0) for query q of flattened (batch, head) bh
 __device__ __forceinline__ unsigned attn_keep4(const AttnParams& p, int bh, int q, int kb) {
@@ -245,11 +270,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = DMA ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const AttnBlk blk = attn_blk(p);
+  const int b = blk.z, h = blk.y;
   const int hk = h / (p.Hq / p.Hkv);
   const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
   constexpr int QW = 16 * QF;   // query rows per wave
-  const int qb0 = blockIdx.x * (4 * QW), qw0 = qb0 + wave * QW;
+  const int qb0 = blk.x * (4 * QW), qw0 = qb0 + wave * QW;
 
   frag_t qf[QF][KD];
 #pragma unroll
@@ -358,7 +384,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
   };
 
-  const bool prb = PROBE && blockIdx.x == 5 && blockIdx.y == 7 && blockIdx.z == 3 && (wave == 0 || wave == 3);
+  const bool prb = PROBE && blk.x == 5 && blk.y == 7 && blk.z == 3 && (wave == 0 || wave == 3);
   auto stamp = [&](int it, int i) {
     if constexpr (PROBE) {
       if (prb) {
@@ -377,7 +403,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   if constexpr (DMA) {
     lds0 = __builtin_amdgcn_readfirstlane(lds_offset_of(lds));
     ldk2 = (unsigned)p.ldk * 2u;
-    const int nB = gridDim.z;
+    const int nB = p.gz;
     srd_k = __builtin_amdgcn_make_buffer_rsrc((void*)p.K, 0, (unsigned)((((int64_t)nB * Tk - 1) * p.ldk + (int64_t)p.Hkv * D) * 2), 0x00020000);
     srd_vt = __builtin_amdgcn_make_buffer_rsrc((void*)p.Vt, 0, (unsigned)((int64_t)nB * p.Hkv * D * Tkp * 2), 0x00020000);
 #pragma unroll
@@ -699,10 +725,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const AttnBlk blk = attn_blk(p);
+  const int b = blk.z, h = blk.y;
   const int hk = h / (p.Hq / p.Hkv);
   const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
-  const int qb0 = blockIdx.x * QB, qw0 = qb0 + wave * 16 * QF;
+  const int qb0 = blk.x * QB, qw0 = qb0 + wave * 16 * QF;
 
   frag_t qf[QF][KD], dof[QF][KD];
   float lse2[QF], delta[QF];
@@ -887,10 +914,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.z, hk = blockIdx.y;
+  const AttnBlk blk = attn_blk(p);
+  const int b = blk.z, hk = blk.y;
   const int G = p.Hq / p.Hkv;
   const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
-  const int kb0 = blockIdx.x * 64, kw0 = kb0 + wave * 16;
+  const int kb0 = blk.x * 64, kw0 = kb0 + wave * 16;
   const int key = kw0 + li;
   const bool kok = key < Tk && (!p.kmask || p.kmask[(int64_t)b * Tkp + min(key, Tkp - 1)] != 0);
 
@@ -1083,10 +1111,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.z, hk = blockIdx.y;
+  const AttnBlk blk = attn_blk(p);
+  const int b = blk.z, hk = blk.y;
   const int G = p.Hq / p.Hkv;
   const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
-  const int kb0 = blockIdx.x * 128, kw0 = kb0 + wave * 16;
+  const int kb0 = blk.x * 128, kw0 = kb0 + wave * 16;
   const int key = kw0 + li;
   const bool kok = key < Tk && (!p.kmask || p.kmask[(int64_t)b * Tkp + min(key, Tkp - 1)] != 0);
 
@@ -1124,7 +1153,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
   // instruction is computed here; per tile only a scalar is added (the first form spent more VALU on 64-bit address math and
   // the tile-index division than on the softmax). ----
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_offset_of(lds));
-  const int nB = gridDim.z;
+  const int nB = p.gz;
   const __amdgpu_buffer_rsrc_t srd_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, (unsigned)((((int64_t)nB * Tq - 1) * p.ldq + (int64_t)p.Hq * D) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t srd_do = __builtin_amdgcn_make_buffer_rsrc((void*)p.dO, 0, (unsigned)((((int64_t)nB * Tq - 1) * p.lddo + (int64_t)p.Hq * D) * 2), 0x00020000);
   const unsigned tbytes = (unsigned)((int64_t)nB * p.Hq * D * Tqp * 2);
@@ -1206,7 +1235,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
   }
   int c_qi = 0;   // query tile of the tile being consumed
   constexpr bool PROBE = ABL == 9;   // cycle stamps of waves 0 / 7 of one workgroup (tools/attn_dq_probe.py)
-  const bool prb = PROBE && blockIdx.x == 0 && blockIdx.y == 3 && blockIdx.z == 5 && (wave == 0 || wave == 7);
+  const bool prb = PROBE && blk.x == 0 && blk.y == 3 && blk.z == 5 && (wave == 0 || wave == 7);
   auto stamp = [&](int it, int i) {
     if constexpr (PROBE) {
       if (prb) {
@@ -1374,10 +1403,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
   // (giving the four waves the same 32 queries of the four heads of a GQA group instead -- every wave then runs to the same
   // causal diagonal, 19 % fewer workgroup-tiles at the Llama shape -- measured the same kernel time:
   // profiles/r02_attention_bwd.md)
-  const int b = blockIdx.z, h = blockIdx.y;
+  const AttnBlk blk = attn_blk(p);
+  const int b = blk.z, h = blk.y;
   const int hk = h / (p.Hq / p.Hkv);
   const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
-  const int qb0 = blockIdx.x * QB, qw0 = qb0 + wave * 16 * QF;
+  const int qb0 = blk.x * QB, qw0 = qb0 + wave * 16 * QF;
 
   frag_t qf[QF][KD], dof[QF][KD];
   float lse2[QF], delta[QF];
@@ -1436,7 +1466,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
   // image is lane-linear), transposed pieces 16 d-rows of 64 bytes.  Rows past the end of the tensor read as zeros (descriptor
   // range check); rows past Tk of a batch in the middle read the next batch's rows, which the key < Tk mask discards. ----
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_offset_of(lds));
-  const int nB = gridDim.z;
+  const int nB = p.gz;
   const __amdgpu_buffer_rsrc_t srd_k = __builtin_amdgcn_make_buffer_rsrc((void*)p.K, 0, (unsigned)((((int64_t)nB * Tk - 1) * p.ldk + (int64_t)p.Hkv * D) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t srd_v = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, (unsigned)((((int64_t)nB * Tk - 1) * p.ldv + (int64_t)p.Hkv * D) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t srd_kt = __builtin_amdgcn_make_buffer_rsrc((void*)p.Kt, 0, (unsigned)((int64_t)nB * p.Hkv * D * Tkp * 2), 0x00020000);
@@ -1485,7 +1515,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
     issue(tb + 1, 1);
   }
   int s = 0;
-  const bool prb = PROBE && blockIdx.x == 2 && blockIdx.y == 5 && blockIdx.z == 3 && (wave == 0 || wave == 3);
+  const bool prb = PROBE && blk.x == 2 && blk.y == 5 && blk.z == 3 && (wave == 0 || wave == 3);
   auto stamp = [&](int it, int i) {
     if constexpr (PROBE) {
       if (prb) {
@@ -1634,6 +1664,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
   }
 }
 
+int g_attn_xcd = 1;   // 1 = XCD-aware workgroup numbering (shipped), 0 = hardware round-robin order (A/B in tools)
+
+// every attention kernel is launched through this: logical 3-D grid -> 1-D launch + the geometry attn_blk() needs
+template <class Kern>
+static void attn_launch(Kern kern, dim3 grid, unsigned threads, int lds, hipStream_t s, AttnParams p) {
+  p.gx = (int)grid.x; p.gy = (int)grid.y; p.gz = (int)grid.z;
+  p.xcd = g_attn_xcd;
+  hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(threads), lds, s, p);
+}
+
 template <int D, bool CAUSAL, int QF, bool PROBE = false>
 int launch_dq_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr int lds = 3 * (3 * 32 * D * 2 + 1024);
@@ -1646,7 +1686,7 @@ int launch_dq_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  attn_launch(kern, grid, 256, lds, s, p);
   return 0;
 }
 
@@ -1662,7 +1702,7 @@ int launch_dkdv_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+  attn_launch(kern, grid, 512, lds, s, p);
   return 0;
 }
 
@@ -1700,8 +1740,10 @@ extern "C" int slam_attn_set_bwd_variant(int variant) {   // tools: 0 = DMA-ring
 
 extern int g_attn_fwd_dma;
 extern "C" int slam_attn_set_fwd_qf(int qf) {   // tools: 0 = auto, 1 / 2 fragments per wave; 10 / 11 = register-staged / DMA tiles
-  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11, "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2; 10 / 11 = staged / DMA tiles)", qf);
-  if (qf >= 10) g_attn_fwd_dma = qf - 10;
+  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11 || qf == 20 || qf == 21,
+                 "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2; 10 / 11 = staged / DMA tiles; 20 / 21 = hardware / XCD-aware workgroup order)", qf);
+  if (qf >= 20) g_attn_xcd = qf - 20;   // (all attention kernels, forward and backward)
+  else if (qf >= 10) g_attn_fwd_dma = qf - 10;
   else g_attn_fwd_qf = qf;
   return 0;
 }
@@ -1714,8 +1756,8 @@ static void launch_fwd(const AttnParams& p, int64_t B, hipStream_t s) {
   dim3 grid((unsigned)cdiv64(p.Tq, 64 * QF), (unsigned)p.Hq, (unsigned)B);
   const int64_t lim = (int64_t)1 << 31;
   const bool fits = (B * p.Tk * p.ldk + (int64_t)p.Hkv * D) * 2 < lim && B * p.Hkv * D * p.Tkp * 2 < lim;
-  if (fits && g_attn_fwd_dma) hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, false>), grid, dim3(256), 0, s, p);
+  if (fits && g_attn_fwd_dma) attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true>), grid, 256, 0, s, p);
+  else attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, false>), grid, 256, 0, s, p);
 }
 
 extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt,
@@ -1785,10 +1827,10 @@ static int launch_dq(const AttnParams& p, int64_t B, hipStream_t s) {
       if constexpr (D == 128 && CAUSAL) return launch_dq_ring<D, CAUSAL, 2, true>(p, g2, s);
     }
     if (fits && g_attn_bwd_variant != 2) return launch_dq_ring<D, CAUSAL, 2>(p, g2, s);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL, false, 2>), g2, dim3(256), 0, s, p);
+    attn_launch((attn_bwd_dq_kernel<D, CAUSAL, false, 2>), g2, 256, 0, s, p);
   } else {
     dim3 g1((unsigned)cdiv64(p.Tq, 64), (unsigned)p.Hq, (unsigned)B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL, false, 1>), g1, dim3(256), 0, s, p);
+    attn_launch((attn_bwd_dq_kernel<D, CAUSAL, false, 1>), g1, 256, 0, s, p);
   }
   return 0;
 }
@@ -1827,8 +1869,8 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   hipStream_t s = (hipStream_t)stream;
   if (drop_p > 0.f) {   // same mask as the forward, recomputed (round-1 dK/dV kernel: the ring kernel has no dropout form)
     dim3 gq_((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B), gk_((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false, true>), gq_, dim3(256), 0, s, p);
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false, true>), gk_, dim3(256), 0, s, p);
+    attn_launch((attn_bwd_dq_kernel<64, false, true>), gq_, 256, 0, s, p);
+    attn_launch((attn_bwd_dkdv_kernel<64, false, true>), gk_, 256, 0, s, p);
     SLAM_CHECK_LAUNCH("slam_attn_bwd");
     return 0;
   }
@@ -1852,18 +1894,18 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   if (D == 64) {
     if (causal) {
       if ((rc = launch_dq<64, true>(p, B, s))) return rc;
-      if (ring) rc = launch_dkdv_ring<64, true>(p, gk2, s); else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true>), gk, dim3(256), 0, s, p);
+      if (ring) rc = launch_dkdv_ring<64, true>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<64, true>), gk, 256, 0, s, p);
     } else {
       if ((rc = launch_dq<64, false>(p, B, s))) return rc;
-      if (ring) rc = launch_dkdv_ring<64, false>(p, gk2, s); else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, false>), gk, dim3(256), 0, s, p);
+      if (ring) rc = launch_dkdv_ring<64, false>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<64, false>), gk, 256, 0, s, p);
     }
   } else {
     if (causal) {
       if ((rc = launch_dq<128, true>(p, B, s))) return rc;
-      if (ring) rc = launch_dkdv_ring<128, true>(p, gk2, s); else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, true>), gk, dim3(256), 0, s, p);
+      if (ring) rc = launch_dkdv_ring<128, true>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<128, true>), gk, 256, 0, s, p);
     } else {
       if ((rc = launch_dq<128, false>(p, B, s))) return rc;
-      if (ring) rc = launch_dkdv_ring<128, false>(p, gk2, s); else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, false>), gk, dim3(256), 0, s, p);
+      if (ring) rc = launch_dkdv_ring<128, false>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<128, false>), gk, 256, 0, s, p);
     }
   }
   if (rc) return rc;

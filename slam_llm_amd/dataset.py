@@ -225,7 +225,8 @@ class MultiTaskDatasetRaw(torch.utils.data.IterableDataset):
                 yield s
 
     def collator(self, samples):
-        return collate(samples, self.tokenizer.pad_token_id, left_pad_prompt=False, input_type=self.input_type)
+        return collate(samples, self.tokenizer.pad_token_id, left_pad_prompt=False, input_type=self.input_type,
+                       pad_or_trim=bool(self.pad_or_trim))
 
     def dynamic_batch_iter(self):
         """in-order batches under max_frame_length, already collated"""

@@ -1812,7 +1812,9 @@ class SlamHipModel(nn.Module):
                 raise RuntimeError("autograd_params mode hands gradients to autograd/DDP; detach GradSync")
             # fresh buffer: what we return belongs to autograd (adopted as .grad or added into it) and must not be
             # overwritten by the next backward
-            st.grad = torch.empty_like(st.flat)
+            # (zero-filled: the alignment gaps between parameters whose size is not a multiple of 64 are never written by a kernel,
+            # and the fused optimizers sweep the whole flat buffer -- uninitialised gap values must not reach the moments)
+            st.grad = torch.zeros_like(st.flat)
             accumulate = False
         else:
             accumulate = any(p.grad is not None for p in st.params.values())

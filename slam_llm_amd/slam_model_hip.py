@@ -36,8 +36,17 @@ def _get(cfg, key, default=None):
     return getattr(cfg, key, default)
 
 
+PRESET_ALIASES = {"xtralarge": "xlarge", "extralarge": "xlarge", "x-large": "xlarge", "xtra-large": "xlarge"}
+
+
 def _guess_preset(name: str, table) -> str:
-    n = (name or "").lower().replace("_", "-")
+    """architecture preset from a checkpoint name.  Only the BASENAME votes (a directory such as `/hubert-large-models/` must not
+    pick the geometry of `hubert_base_ls960.pt` inside it); the reference recipes' spellings are normalised first
+    (`hubert_xtralarge_ll60k_finetune_ls960.pt`, examples/asr_librispeech/scripts/finetune_hubert_xtralarge_linear_vicuna_7b.sh)."""
+    import os as _os
+    n = _os.path.basename((name or "").rstrip("/")).lower().replace("_", "-")
+    for a, b in PRESET_ALIASES.items():
+        n = n.replace(a, b)
     for k in sorted(table, key=len, reverse=True):
         if k in n or k.replace("-", "") in n.replace("-", ""):
             return k
@@ -144,6 +153,12 @@ def check_supported(train_config, model_config):
     if bool(_get(train_config, "enable_fsdp", False)) or bool(_get(train_config, "enable_deepspeed", False)):
         raise NotImplementedError("FSDP / DeepSpeed are memory strategies the 288 GB part does not need (SURVEY 2e): run the "
                                   "HIP path with enable_ddp=true (DistributedDataParallel) or single-process")
+    if bool(_get(train_config, "find_unused_parameters", False)):
+        # finetune.py:183-184 forwards this flag to DDP.  Every trainable tensor receives a gradient in every backward of the HIP
+        # step (one autograd node produces them all), so nothing is ever unused -- and DDP's unused-parameter search cannot see
+        # through that node: it would mark all parameters unused up front and then fail with "marked ready twice".
+        raise NotImplementedError("train_config.find_unused_parameters=true is neither needed nor supported on the HIP path (all "
+                                  "trainable parameters get gradients every step); leave it false (the reference default)")
     peft = _get(train_config, "peft_config", None)
     if bool(_get(train_config, "use_peft", False)) and str(_get(peft, "peft_method", "lora")) != "lora":
         raise NotImplementedError("only peft_method=lora is implemented")

@@ -21,19 +21,35 @@ import torch
 import torch.distributed as dist
 
 
-def setup_distributed(device_type: str = "cuda"):
-    """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, local_rank, world)."""
+def setup_distributed(device_type: str = "cuda", init_single: bool = False):
+    """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, local_rank, world).
+    The device is selected BEFORE the process group exists and handed to it as `device_id` (RCCL then builds its communicator
+    eagerly on that device instead of guessing one at the first collective).  `init_single` also initialises the group at
+    world size 1 (tests: the RCCL code path on a 1-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or init_single) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # "nccl" IS RCCL on ROCm; SLAM_DIST_BACKEND=gloo lets two ranks share one GPU for functional tests
         backend = os.environ.get("SLAM_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
+        kw = {}
         if device_type == "cuda":
-            torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            idx = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(idx)
+            if backend == "nccl":
+                kw["device_id"] = torch.device("cuda", idx)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
+
+
+def rccl_version() -> Optional[str]:
+    """version of the collective library behind backend "nccl" (RCCL on ROCm), e.g. "2.26.6"; None when unavailable"""
+    try:
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        return None
 
 
 class GradSync:
@@ -50,11 +66,17 @@ class GradSync:
         with 1/k of the traffic.
     `source` is the model (its `store.grad` is read at launch time, so a re-allocated buffer is followed) or a tensor."""
 
-    def __init__(self, source, bucket_bytes: int = 32 << 20, group=None):
+    def __init__(self, source, bucket_bytes: int = 32 << 20, group=None, force_collectives: bool = False):
         self.source = source
         self.bucket = max(1, bucket_bytes // 4)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # world size 1 normally skips the collectives (nothing to average); force_collectives launches them anyway so that the
+        # RCCL path (ReduceOp selection, async handles on flat-buffer views, stream ordering) runs on a 1-GPU box
+        self.force = bool(force_collectives) and dist.is_initialized()
+        self.launched = 0          # collectives launched so far (tests / bench report)
+        self.exposed_ms = None     # bench: HIP-event time of the last finish() (the part of the exchange the backward did not hide)
+        self.time_finish = False
         self.done = 0
         self.armed = True
         self.handles = []
@@ -89,7 +111,7 @@ class GradSync:
 
     def on_prefix(self, end: int):
         """gradients in flat[0:end] are final for this backward"""
-        if self.world == 1 or not self.armed:
+        if (self.world == 1 and not self.force) or not self.armed:
             return
         flat = self.flat
         total = flat.numel()
@@ -101,6 +123,7 @@ class GradSync:
         op = dist.ReduceOp.AVG if self.avg_native else dist.ReduceOp.SUM
         h = dist.all_reduce(view, op=op, group=self.group, async_op=True)
         self.handles.append((h, view))
+        self.launched += 1
         self.done = end
 
     __call__ = on_prefix   # plain-callable hook form
@@ -115,9 +138,26 @@ class GradSync:
 
     def finish(self):
         """flush the tail and wait for all buckets (call before optimizer.step())."""
-        if self.world > 1 and self.armed and self.done < self.flat.numel():
+        ev = None
+        if self.time_finish and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if (self.world > 1 or self.force) and self.armed and self.done < self.flat.numel():
             self.on_prefix(self.flat.numel())
         self._wait()
+        if ev is not None:
+            ev[1].record()
+            self._finish_events = getattr(self, "_finish_events", [])
+            self._finish_events.append(ev)
+
+    def exposed_ms_per_step(self) -> Optional[float]:
+        """mean HIP-event time of finish() over the calls timed so far (time_finish=True): tail launch + waits on the compute
+        stream = the exposed part of the gradient exchange.  Synchronises."""
+        evs = getattr(self, "_finish_events", [])
+        if not evs:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) / len(evs)
 
 
 def all_ranks_have_data(has_batch: bool, device) -> bool:
@@ -131,21 +171,36 @@ def all_ranks_have_data(has_batch: bool, device) -> bool:
 
 
 def train_step(model, batch: dict, optimizer, scheduler=None, grad_sync: Optional[GradSync] = None,
-               gradient_accumulation_steps: int = 1, do_step: bool = True):
+               gradient_accumulation_steps: int = 1, do_step: bool = True, scaler=None):
     """One iteration of train_utils.py:112-169.  Returns (loss, acc) as device tensors (no host sync).
     With gradient accumulation the caller passes do_step=False on all but the last micro-step (the reference's
-    `(step + 1) % gradient_accumulation_steps == 0` test, train_utils.py:132/153)."""
+    `(step + 1) % gradient_accumulation_steps == 0` test, train_utils.py:132/153).
+    `scaler` (a torch.cuda.amp.GradScaler) selects the reference's `use_fp16` branch (train_utils.py:70-76,128-150):
+    forward under `torch.cuda.amp.autocast`, `scaler.scale(loss).backward()`, `scaler.step(optimizer)`, `scaler.update()`.
+    The HIP path computes in bf16 with fp32 masters whatever the autocast state says; the scale factor reaches the kernels as the
+    backward's incoming gradient (a power of two: exact in bf16 and fp32) and GradScaler unscales the flat gradient views in place."""
     if grad_sync is not None:
         grad_sync.arm(do_step)   # one reduction of the accumulated buffer instead of one per micro-step (same result)
-    outputs, acc = model(**batch)
+    if scaler is not None:
+        with torch.autocast("cuda", dtype=torch.float16):
+            outputs, acc = model(**batch)
+    else:
+        outputs, acc = model(**batch)
     loss = outputs.loss
     if gradient_accumulation_steps != 1:
         loss = loss / gradient_accumulation_steps
-    loss.backward()
+    if scaler is not None:
+        scaler.scale(loss).backward()
+    else:
+        loss.backward()
     if do_step:
         if grad_sync is not None:
             grad_sync.finish()
-        optimizer.step()
+        if scaler is not None:
+            scaler.step(optimizer)
+            scaler.update()
+        else:
+            optimizer.step()
         if scheduler is not None:
             scheduler.step()
         optimizer.zero_grad()

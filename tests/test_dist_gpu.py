@@ -5,7 +5,8 @@ data-parallel path of src/slam_llm/pipeline/finetune.py:181-184 + utils/train_ut
   * gradient accumulation (k = 2) == the reference's all-reduce-every-backward result,
   * uneven shards (rank 1 runs dry first) end the epoch cleanly on both ranks,
   * the module wrapped in torch.nn.parallel.DistributedDataParallel (autograd_params mode) gives the same numbers with
-    torch.optim.AdamW(model.parameters()), and `.module` / state_dict keys are what checkpoint_handler.py:190-200 walks.
+    torch.optim.AdamW(model.parameters()), and `.module` / state_dict keys are what checkpoint_handler.py:190-200 walks,
+  * the `use_fp16` loop body (autocast + GradScaler, train_utils.py:128-150) around the DDP module == the un-scaled DDP run.
 """
 import os
 import socket
@@ -156,6 +157,22 @@ def _worker(rank, world, port, q):
         both = [torch.empty_like(flat3) for _ in range(world)]
         dist.all_gather(both, flat3)
         res["ddp_slamadamw_equal"] = bool(torch.equal(both[0], both[1])) and bool((flat3 != flat2).any())
+        # ---- use_fp16 under DDP (utils/train_utils.py:70-76,128-150: autocast + GradScaler around the DDP-wrapped module) ----------
+        def ddp_run(use_scaler):
+            m = SlamHipModel(dict(cfg), dev, autograd_params=True).load_weights(W)
+            m.train()
+            d = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0])
+            o = torch.optim.AdamW(d.parameters(), lr=1e-3, weight_decay=0.0)
+            sc = torch.cuda.amp.GradScaler() if use_scaler else None
+            for i in range(3):
+                train_step(d, batch_for(rank, i), o, None, None, scaler=sc)
+            return m.store.flat.clone(), (sc.get_scale() if sc else None)
+        (fa, _), (fb, scale_end) = ddp_run(False), ddp_run(True)
+        res["ddp_fp16_rel"] = float((fa - fb).abs().max() / fa.abs().max())
+        res["ddp_fp16_scale"] = scale_end
+        both = [torch.empty_like(fb) for _ in range(world)]
+        dist.all_gather(both, fb)
+        res["ddp_fp16_equal_across_ranks"] = bool(torch.equal(both[0], both[1]))
         # ---- unfrozen encoder (train_config.freeze_encoder=false): its gradients ride the same flat buffer / prefixes ----------
         mu = SlamHipModel(dict(cfg, freeze_encoder=False), dev).load_weights(W)
         mu.train()
@@ -199,6 +216,7 @@ def test_two_ranks_real_model_gradsync_and_ddp(dev):
         assert res["ddp_has_reference_keys"], (rank, res)
         assert res["ddp_cos"] >= 0.9999 and res["ddp_maxdiff"] < 2e-2, (rank, res)
         assert res["ddp_params_equal_across_ranks"] and res["ddp_losses_finite"] and res["ddp_slamadamw_equal"], (rank, res)
+        assert res["ddp_fp16_rel"] <= 1e-6 and res["ddp_fp16_scale"] == 65536.0 and res["ddp_fp16_equal_across_ranks"], (rank, res)
         assert res["unfrozen_has_encoder"] and res["unfrozen_cos"] >= 0.9999 and res["unfrozen_encoder_cos"] >= 0.999, (rank, res)
     for p in procs:
         assert p.exitcode == 0

@@ -44,6 +44,24 @@ def test_collators_match_oracle_restatement_of_reference():
         assert got["audio"].shape[0] == 3 and got["audio_len"].tolist() == [len(s["audio"]) for s in sb]
 
 
+def test_mel_collator_emits_the_reference_post_mask():
+    """`audio_mel_post_mask` as the reference collators build it (speech_dataset.py:246-249,
+    speech_dataset_large.py:198-200) -- ragged clips (pad_or_trim off): ones over each clip's own (frames + 1) // 2 encoder frames
+    out of (Tmax + 1) // 2; pad_or_trim on: every clip is 3000 mel frames."""
+    lens = [16000 * 3 + 77, 16000 * 5, 16000 * 2 + 161]
+    samples = [batcher.make_sample(torch.zeros(n), [5, 6], [7, 8], 2, batcher.whisper_audio_length(n, 5, pad_to_30s=False)) for n in lens]
+    got = batcher.collate(samples, pad_token_id=2, left_pad_prompt=True, pad_or_trim=False)
+    # the oracle's collator is the reference's: feed it mels of the lengths whisper.log_mel_spectrogram gives (n // 160 frames)
+    so = [O.make_sample(s["audio_length"], [5, 6], [7, 8], 2) for s in samples]
+    ref = O.collate_left_pad(so, pad_id=2, mels=[torch.zeros(n // 160, 80) for n in lens])
+    assert torch.equal(got["audio_mel_post_mask"], ref["audio_mel_post_mask"])
+    assert got["audio_mel_post_mask"].shape == (3, (500 + 1) // 2) and got["audio_mel_post_mask"].sum(1).tolist() == [150.0, 250.0, 101.0]
+    got = batcher.collate(samples, pad_token_id=2, left_pad_prompt=False)          # pad_or_trim (default): 3000 frames each
+    assert got["audio_mel_post_mask"].shape == (3, 1500) and bool(got["audio_mel_post_mask"].all())
+    raw = batcher.collate(samples, pad_token_id=2, left_pad_prompt=True, input_type="raw")
+    assert "audio_mel_post_mask" not in raw and raw["audio_mask"].shape == (3, max(lens))
+
+
 def test_golden_batches_are_reproduced_by_product_collator():
     """the batch stored in the step fixtures (built through the oracle, equal to the reference layout) is
     reproduced by the product's make_sample + collate"""

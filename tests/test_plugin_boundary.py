@@ -206,6 +206,21 @@ def test_wavlm_and_unfrozen_whisper_recipes_build():
     assert build_config(tc, mc)["freeze_encoder"] is False
 
 
+def test_preset_guess_uses_the_basename_and_the_recipes_spellings():
+    """the reference HuBERT recipe's checkpoint is `hubert_xtralarge_ll60k_finetune_ls960.pt` (xtralarge = xlarge), and a
+    directory component must not outvote the file name; find_unused_parameters=true is refused loudly (DDP cannot see through the
+    one autograd node that produces every gradient)."""
+    from slam_llm_amd.slam_model_hip import HUBERT_PRESETS, WAVLM_PRESETS, _guess_preset, check_supported
+    assert _guess_preset("/nfs/ckpt/hubert_xtralarge_ll60k_finetune_ls960.pt", HUBERT_PRESETS) == "hubert-xlarge"
+    assert _guess_preset("/hubert-large-models/hubert_base_ls960.pt", HUBERT_PRESETS) == "hubert-base"
+    assert _guess_preset("/ckpt/hubert_large_ll60k.pt", HUBERT_PRESETS) == "hubert-large"
+    assert _guess_preset("/wavlm-large/WavLM-Base+.pt", WAVLM_PRESETS) == "wavlm-base"
+    with pytest.raises(ValueError, match="cannot map"):
+        _guess_preset("/hubert-large/model.pt", HUBERT_PRESETS)
+    with pytest.raises(NotImplementedError, match="find_unused_parameters"):
+        check_supported(dict(use_peft=True, freeze_encoder=True, find_unused_parameters=True), dict(encoder_name="whisper"))
+
+
 def test_base_encoder_geometries_are_selected_from_the_checkpoint_name():
     """WavLM Base / Base+ and HuBERT-base (group-norm extractor, post-LN layers, 12 x 768) through `encoder_path`; the large
     presets keep the layer-norm extractor / pre-LN defaults"""
