@@ -171,8 +171,20 @@ int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
 /* ---- SwiGLU (LlamaMLP) : gate_up [M, 2F] = [gate | up] ---------------------------------------------- */
 int slam_swiglu_fwd(const void* gate_up, int64_t ldgu, void* h, int64_t ldh, int64_t M, int64_t F,
                     void* stream);
+/* interleaved != 0: gate_up is in the block layout written by slam_gemm_swiglu_bf16_nt (below); dgate_up is always [dgate | dup] */
 int slam_swiglu_bwd(const void* gate_up, int64_t ldgu, const void* dh, int64_t lddh, void* dgate_up,
-                    int64_t lddgu, int64_t M, int64_t F, void* stream);
+                    int64_t lddgu, int64_t M, int64_t F, int interleaved, void* stream);
+/* gate|up product of LlamaMLP (transformers/models/llama/modeling_llama.py LlamaMLP.forward, reached from
+ * src/slam_llm/models/slam_model.py:400) with act_fn(gate) * up in its epilogue: GU[M, N] = A[M, K] . B[N, K]^T and
+ * H[M, N/2] = silu(gate) * up from ONE launch (the stand-alone slam_swiglu_fwd pass re-read GU from HBM).  B's rows are
+ * INTERLEAVED in blocks of 64: rows [128 b, 128 b + 64) = gate_proj rows [64 b, 64 b + 64), rows [128 b + 64, 128 b + 128) =
+ * the matching up_proj rows; GU comes out in the same block layout (slam_swiglu_bwd(..., interleaved = 1) reads it).  Served by
+ * the 4-wave 256x256 kernel only: slam_gemm_swiglu_supported() returns 1 when the auto rule picks that kernel for the shape
+ * (K > 2048, K % 64 == 0, N % 128 == 0, N >= 2048, operands within its 32-bit descriptors), else 0 -- then run
+ * slam_gemm_bf16_nt + slam_swiglu_fwd.  silu is evaluated on the bf16-rounded gate / up, exactly like slam_swiglu_fwd. */
+int slam_gemm_swiglu_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb);
+int slam_gemm_swiglu_bf16_nt(const void* A, int64_t lda, const void* B_interleaved, int64_t ldb, void* GU, int64_t ldgu,
+                             void* H, int64_t ldh, int64_t M, int64_t N, int64_t K, void* stream);
 
 /* ---- projector ReLU backward (projector.py:25) and LoRA weight packing (peft Linear: scaling = alpha/r) ---
  * relu_bwd: dh *= (h > 0) in place.  lora_pack_b: dst[row,j] = dstT[j,row] = bf16(scale*B[row,j]), B f32 [rows,r]:

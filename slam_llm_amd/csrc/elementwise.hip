@@ -152,6 +152,10 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
   }
 }
 
+// IL: the forward's [gate | up] was written by the fused gate|up product (slam_gemm_swiglu_bf16_nt) in blocks of
+// [64 gate columns | the matching 64 up columns]; dgate_up always leaves in the plain [dgate | dup] layout (the next product's
+// weight W^T is stored that way).
+template <bool IL>
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, int64_t ldgu,
                                                          const bf16_t* __restrict__ dh, int64_t lddh,
                                                          bf16_t* __restrict__ dgu, int64_t lddgu,
@@ -161,8 +165,10 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t m = i / nch;
     const int c = (int)(i % nch);
-    const u16x8_t g = __builtin_nontemporal_load(reinterpret_cast<const u16x8_t*>(gu + m * ldgu + c * 8));
-    const u16x8_t u = __builtin_nontemporal_load(reinterpret_cast<const u16x8_t*>(gu + m * ldgu + F + c * 8));
+    const int gcol = IL ? ((c >> 3) << 7) + ((c & 7) << 3) : c * 8;      // column of gate[c * 8] in gu
+    const int ucol = IL ? gcol + 64 : F + c * 8;
+    const u16x8_t g = __builtin_nontemporal_load(reinterpret_cast<const u16x8_t*>(gu + m * ldgu + gcol));
+    const u16x8_t u = __builtin_nontemporal_load(reinterpret_cast<const u16x8_t*>(gu + m * ldgu + ucol));
     const u16x8_t d = __builtin_nontemporal_load(reinterpret_cast<const u16x8_t*>(dh + m * lddh + c * 8));
     u16x8_t og, ou;
 #pragma unroll
@@ -736,12 +742,17 @@ extern "C" int slam_swiglu_fwd(const void* gate_up, int64_t ldgu, void* h, int64
 }
 
 extern "C" int slam_swiglu_bwd(const void* gate_up, int64_t ldgu, const void* dh, int64_t lddh,
-                               void* dgate_up, int64_t lddgu, int64_t M, int64_t F, void* stream) {
+                               void* dgate_up, int64_t lddgu, int64_t M, int64_t F, int interleaved, void* stream) {
   SLAM_CHECK_ARG(gate_up && dh && dgate_up, "slam_swiglu_bwd: null pointer");
   SLAM_CHECK_ARG(M > 0 && F > 0 && F % 8 == 0 && ldgu % 8 == 0 && lddh % 8 == 0 && lddgu % 8 == 0,
                  "slam_swiglu_bwd: F/ld must be multiples of 8");
-  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(ew_grid(M * (F / 8))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)gate_up, ldgu, (const bf16_t*)dh, lddh, (bf16_t*)dgate_up, lddgu, M, (int)F);
+  SLAM_CHECK_ARG(!interleaved || F % 64 == 0, "slam_swiglu_bwd: the interleaved [gate64 | up64] layout needs F %% 64 == 0 (F=%ld)", (long)F);
+  if (interleaved)
+    hipLaunchKernelGGL(swiglu_bwd_kernel<true>, dim3(ew_grid(M * (F / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)gate_up, ldgu, (const bf16_t*)dh, lddh, (bf16_t*)dgate_up, lddgu, M, (int)F);
+  else
+    hipLaunchKernelGGL(swiglu_bwd_kernel<false>, dim3(ew_grid(M * (F / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)gate_up, ldgu, (const bf16_t*)dh, lddh, (bf16_t*)dgate_up, lddgu, M, (int)F);
   SLAM_CHECK_LAUNCH("slam_swiglu_bwd");
   return 0;
 }

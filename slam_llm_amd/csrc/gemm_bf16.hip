@@ -37,7 +37,9 @@ struct GemmParams {
   const bf16_t* res;
   int64_t ldr;
   int res_mod;
-  int act;  // 0 none, 1 gelu(erf), 2 relu, 3 swiglu backward (res = [gate | up] of the forward, N = F)
+  int act;  // 0 none, 1 gelu(erf), 2 relu, 3 swiglu backward (res = [gate | up] of the forward, N = F), 4 swiglu forward (C2 = h)
+  void* C2;      // act 4: second output h[M, N/2] = silu(gate) * up (bf16)
+  int64_t ldc2;
   float alpha;
   int out_f32;
   int accumulate;
@@ -333,6 +335,56 @@ __device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmParams& p, f3
         o2.x = pu[0][0]; o2.y = pu[0][1];
         *reinterpret_cast<uint2*>(c + p.N) = o2;
       }
+    }
+  }
+}
+
+// SwiGLU forward fused into the gate|up product (act 4, 4-wave kernel only).  The weight rows are stored INTERLEAVED in blocks of 64
+// (rows [128 b, 128 b + 64) = gate rows [64 b, 64 b + 64), rows [128 b + 64, 128 b + 128) = the matching up rows), so that the 128
+// output columns of one wave are one block: its left 64-column quadrant holds gate, its right quadrant the SAME columns of up, in
+// the same lanes and registers.  Writes the product itself ([gate64 | up64] blocks: the backward's stash, C) and
+// h = silu(gate) * up (C2, [M, N / 2]) -- the stand-alone pass (slam_swiglu_fwd: 675 MB re-read + 338 MB written per Llama-3-8B
+// layer at M = 11 780) disappears.  Same arithmetic as swiglu_fwd_kernel (elementwise.hip): on the bf16-ROUNDED gate / up.
+// N is a multiple of 128 (launcher), so a wave's block is either wholly inside [0, N) or wholly outside; rows are guarded.
+template <bool INNER>
+__device__ __forceinline__ void gemm_epilogue_swiglu_fwd(const GemmParams& p, f32x4_t (&ag)[4][4], f32x4_t (&au)[4][4], int mbase,
+                                                         int nbase, int frow, int fg) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int m = mbase + i * 16 + frow;
+    if (!INNER && m >= p.M) continue;   // (both lanes of an exchanging pair share frow, hence m)
+    bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nbase + (fg & 1) * 16 + (fg >> 1) * 8;
+    bf16_t* hrow = reinterpret_cast<bf16_t*>(p.C2) + (int64_t)m * p.ldc2 + (nbase >> 1) + (fg & 1) * 16 + (fg >> 1) * 8;
+#pragma unroll
+    for (int jp = 0; jp < 2; jp++) {
+      unsigned pg[2][2], pu[2][2], ph[2][2];
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++) {
+        const int j = 2 * jp + hh;
+        pg[hh][0] = pack2bf(ag[i][j][0], ag[i][j][1]);
+        pg[hh][1] = pack2bf(ag[i][j][2], ag[i][j][3]);
+        pu[hh][0] = pack2bf(au[i][j][0], au[i][j][1]);
+        pu[hh][1] = pack2bf(au[i][j][2], au[i][j][3]);
+        float hv[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const unsigned gw = pg[hh][e >> 1], uw = pu[hh][e >> 1];
+          const float gf = __uint_as_float((e & 1) ? (gw & 0xFFFF0000u) : (gw << 16));
+          const float uf = __uint_as_float((e & 1) ? (uw & 0xFFFF0000u) : (uw << 16));
+          hv[e] = gf * sigmoid_fast(gf) * uf;
+        }
+        ph[hh][0] = pack2bf(hv[0], hv[1]);
+        ph[hh][1] = pack2bf(hv[2], hv[3]);
+      }
+      swap_rows16(pg[0][0], pg[1][0]);
+      swap_rows16(pg[0][1], pg[1][1]);
+      swap_rows16(pu[0][0], pu[1][0]);
+      swap_rows16(pu[0][1], pu[1][1]);
+      swap_rows16(ph[0][0], ph[1][0]);
+      swap_rows16(ph[0][1], ph[1][1]);
+      *reinterpret_cast<uint4*>(crow + jp * 32) = make_uint4(pg[0][0], pg[0][1], pg[1][0], pg[1][1]);
+      *reinterpret_cast<uint4*>(crow + 64 + jp * 32) = make_uint4(pu[0][0], pu[0][1], pu[1][0], pu[1][1]);
+      *reinterpret_cast<uint4*>(hrow + jp * 32) = make_uint4(ph[0][0], ph[0][1], ph[1][0], ph[1][1]);
     }
   }
 }
@@ -923,8 +975,14 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
     const int frow = lane & 15, fg = lane >> 4;
     const bf16_t* ap = p.A + (int64_t)min(m0 + frow, p.M - 1) * p.lda + fg * 8;
     const bf16_t* bp[4];
+    // act 4 (fused SwiGLU forward, interleaved [gate64 | up64] column blocks): a wave takes 32 gate columns (fragments 0, 1) and
+    // the 32 matching up columns (fragments 2, 3) of block wave >> 1 instead of 64 consecutive columns
+    const int thin_c0 = (p.act == 4) ? n0 + (wave >> 1) * 128 + (wave & 1) * 32 : n0 + wave * 64;
 #pragma unroll
-    for (int j = 0; j < 4; j++) bp[j] = p.B + (int64_t)min(n0 + wave * 64 + j * 16 + frow, p.N - 1) * p.ldb + fg * 8;
+    for (int j = 0; j < 4; j++) {
+      const int col = (p.act == 4) ? thin_c0 + (j & 1) * 16 + (j >> 1) * 64 : thin_c0 + j * 16;
+      bp[j] = p.B + (int64_t)min(col + frow, p.N - 1) * p.ldb + fg * 8;
+    }
     f32x4_t acc[1][4];
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[0][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -948,6 +1006,34 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
 #pragma unroll
       for (int j = 0; j < 4; j++)
         acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(bp[j] + k), af, acc[0][j], 0, 0, 0);
+    }
+    if (p.act == 4) {
+      // lane holds rows m0 + frow, columns thin_c0 + j * 16 + fg * 4 + 0..3 (gate, j = 0, 1) and + 64 (up); 8-byte stores
+      const int m = m0 + frow;
+      if (m < p.M && thin_c0 < p.N) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int n = thin_c0 + j * 16 + fg * 4;
+          uint2 og, ou, oh;
+          og.x = pack2bf(acc[0][j][0], acc[0][j][1]); og.y = pack2bf(acc[0][j][2], acc[0][j][3]);
+          ou.x = pack2bf(acc[0][j + 2][0], acc[0][j + 2][1]); ou.y = pack2bf(acc[0][j + 2][2], acc[0][j + 2][3]);
+          float hv[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const unsigned gw = (e >> 1) ? og.y : og.x, uw = (e >> 1) ? ou.y : ou.x;
+            const float gf = __uint_as_float((e & 1) ? (gw & 0xFFFF0000u) : (gw << 16));
+            const float uf = __uint_as_float((e & 1) ? (uw & 0xFFFF0000u) : (uw << 16));
+            hv[e] = gf * sigmoid_fast(gf) * uf;
+          }
+          oh.x = pack2bf(hv[0], hv[1]); oh.y = pack2bf(hv[2], hv[3]);
+          bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n;
+          *reinterpret_cast<uint2*>(c) = og;
+          *reinterpret_cast<uint2*>(c + 64) = ou;
+          // h column of interleaved column n (gate half of block n / 128): 64 * (n / 128) + n % 128
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C2) + (int64_t)m * p.ldc2 + ((n >> 7) << 6) + (n & 127)) = oh;
+        }
+      }
+      return;
     }
     gemm_epilogue_generic<1, 4, 16, 64>(p, acc, m0, n0, 0, wave, frow, fg);
     return;
@@ -1077,10 +1163,23 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
     g_clk_probe[2] = __builtin_readcyclecounter();
     g_clk_probe[3] = wall_clock64();
   }
-  gemm_epilogue<4, 4, WTM, WTN>(p, acc00, m0, n0, wm, wn, frow, fg);
-  gemm_epilogue<4, 4, WTM, WTN>(p, acc01, m0, n0 + 64, wm, wn, frow, fg);
-  gemm_epilogue<4, 4, WTM, WTN>(p, acc10, m0 + 64, n0, wm, wn, frow, fg);
-  gemm_epilogue<4, 4, WTM, WTN>(p, acc11, m0 + 64, n0 + 64, wm, wn, frow, fg);
+  if (p.act == 4) {   // fused SwiGLU forward: the left / right quadrants of the wave tile are gate / up of the same 64 columns
+    const int nb = n0 + wn * WTN, mb = m0 + wm * WTM;
+    if (nb < p.N) {
+      if (mb + WTM <= p.M) {
+        gemm_epilogue_swiglu_fwd<true>(p, acc00, acc01, mb, nb, frow, fg);
+        gemm_epilogue_swiglu_fwd<true>(p, acc10, acc11, mb + 64, nb, frow, fg);
+      } else {
+        gemm_epilogue_swiglu_fwd<false>(p, acc00, acc01, mb, nb, frow, fg);
+        gemm_epilogue_swiglu_fwd<false>(p, acc10, acc11, mb + 64, nb, frow, fg);
+      }
+    }
+  } else {
+    gemm_epilogue<4, 4, WTM, WTN>(p, acc00, m0, n0, wm, wn, frow, fg);
+    gemm_epilogue<4, 4, WTM, WTN>(p, acc01, m0, n0 + 64, wm, wn, frow, fg);
+    gemm_epilogue<4, 4, WTM, WTN>(p, acc10, m0 + 64, n0, wm, wn, frow, fg);
+    gemm_epilogue<4, 4, WTM, WTN>(p, acc11, m0 + 64, n0 + 64, wm, wn, frow, fg);
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[5] = __builtin_readcyclecounter();
 }
 
@@ -1242,6 +1341,7 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.bias = bias; p.res = (const bf16_t*)residual; p.ldr = ldr; p.res_mod = (int)res_row_mod;
   p.act = act; p.alpha = alpha; p.out_f32 = (out_dtype == SLAM_F32); p.accumulate = accumulate;
+  p.C2 = nullptr; p.ldc2 = 0;
   p.group_m = g_gemm_group_m;
   hipStream_t s = (hipStream_t)stream;
   int cfg = g_gemm_cfg;
@@ -1282,4 +1382,46 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
   }
   slam_set_error("slam_gemm_bf16_nt: bad config %d", cfg);
   return -1;
+}
+
+// ---- gate|up product with the SwiGLU forward in its epilogue (act 4) -----------------------------------------------------------
+// Runs on the 4-wave kernel only (its wave tile is 128 columns = one [gate64 | up64] block).  slam_gemm_swiglu_supported() tells
+// the host whether the AUTO rule would pick that kernel for the shape anyway and the operands fit its 32-bit descriptors; when it
+// does not, the host runs the plain product + slam_swiglu_fwd.
+extern "C" int slam_gemm_swiglu_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb) {
+  if (M <= 0 || N <= 0 || K < 2 * BK || K % 64 || N % 128 || K <= 2048 || N < 2048) return 0;
+  if (g_gemm_cfg != 0 && g_gemm_cfg != 12) return 0;
+  if (g_gemm_cfg == 0) {
+    if (g_gemm_big != 12) return 0;
+    const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+    const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+    const double t256 = (double)((tiles256 + 255) / 256) * (4.0 / 1.4);
+    const double t128 = (double)((tiles128 + 511) / 512) * 2.0;
+    if (!(t256 < t128)) return 0;
+  }
+  if ((uint64_t)M * (uint64_t)lda * 2ull >= (1ull << 32) || (uint64_t)N * (uint64_t)ldb * 2ull >= (1ull << 32)) return 0;
+  return 1;
+}
+
+extern "C" int slam_gemm_swiglu_bf16_nt(const void* A, int64_t lda, const void* B_interleaved, int64_t ldb, void* GU, int64_t ldgu,
+                                        void* H, int64_t ldh, int64_t M, int64_t N, int64_t K, void* stream) {
+  SLAM_CHECK_ARG(A && B_interleaved && GU && H, "slam_gemm_swiglu_bf16_nt: null operand");
+  SLAM_CHECK_ARG(M > 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "slam_gemm_swiglu_bf16_nt: bad shape");
+  SLAM_CHECK_ARG(K % 64 == 0 && N % 128 == 0, "slam_gemm_swiglu_bf16_nt: K=%ld must be a multiple of 64, N=%ld (= 2 F) of 128", (long)K, (long)N);
+  SLAM_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldgu % 8 == 0 && ldh % 8 == 0 && lda >= K && ldb >= K && ldgu >= N && ldh >= N / 2,
+                 "slam_gemm_swiglu_bf16_nt: leading dimensions must be multiples of 8 elements and cover the rows");
+  SLAM_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B_interleaved % 16) == 0 && ((uintptr_t)GU % 16) == 0 && ((uintptr_t)H % 16) == 0,
+                 "slam_gemm_swiglu_bf16_nt: operands must be 16-byte aligned");
+  SLAM_CHECK_ARG(slam_gemm_swiglu_supported(M, N, K, lda, ldb) == 1,
+                 "slam_gemm_swiglu_bf16_nt: shape %ld x %ld x %ld is not served by the 4-wave kernel (ask slam_gemm_swiglu_supported first)",
+                 (long)M, (long)N, (long)K);
+  GemmParams p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B_interleaved; p.C = GU;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldgu;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.bias = nullptr; p.res = nullptr; p.ldr = 0; p.res_mod = 0;
+  p.act = 4; p.alpha = 1.0f; p.out_f32 = 0; p.accumulate = 0;
+  p.C2 = H; p.ldc2 = ldh;
+  p.group_m = g_gemm_group_m;
+  return launch_gemm_w4<256, 256, false>(p, (hipStream_t)stream);
 }

@@ -54,7 +54,9 @@ SIGNATURES = {
     "slam_attn_bwd": [P, I64, P, I64, P, I64, P, P, P, I64, P, I64, P, P, P, P, P, I64, P, I64, P, I64,
                       I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P, P, P, F, U64, P],
     "slam_swiglu_fwd": [P, I64, P, I64, I64, I64, P],
-    "slam_swiglu_bwd": [P, I64, P, I64, P, I64, I64, I64, P],
+    "slam_swiglu_bwd": [P, I64, P, I64, P, I64, I64, I64, I32, P],
+    "slam_gemm_swiglu_supported": [I64, I64, I64, I64, I64],
+    "slam_gemm_swiglu_bf16_nt": [P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P],
     "slam_relu_bwd": [P, I64, P, I64, I64, I64, P],
     "slam_colsum_bf16": [P, I64, P, I64, I64, I32, P],
     "slam_skinny_gram_workspace_bytes": [I64, I64, I64],

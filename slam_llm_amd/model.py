@@ -34,6 +34,8 @@ import os as _os
 # on the C3 step (A/B in one process: 444.2-446.4 ms fused vs 443.7-444.6 ms separate pass): with one 256x256 workgroup
 # per CU the exp-heavy epilogue is not overlapped with MFMA work.  Off unless SLAM_FUSED_SWIGLU_BWD=1.
 FUSE_SWIGLU_BWD = _os.environ.get("SLAM_FUSED_SWIGLU_BWD", "0") == "1"
+# SwiGLU forward inside the gate|up product's epilogue (slam_gemm_swiglu_bf16_nt): on unless SLAM_FUSED_SWIGLU_FWD=0
+FUSE_SWIGLU_FWD = _os.environ.get("SLAM_FUSED_SWIGLU_FWD", "1") == "1"
 LORA_PAD = 64  # K-extension granule (GEMM K-tile)
 
 
@@ -158,6 +160,11 @@ class FusedLinear:
             self.Wext[self.row0[n]: self.row0[n] + rows, : self.K].copy_(w)
         self.WextT = torch.zeros((Kx, self.N), dtype=torch.bfloat16, device=self.device)
         ops.transpose(self.Wext[:, : self.K], Rp=self.N, out=self.WextT[: self.K])
+        # a frozen [gate ; up] group without adapters also keeps its rows block-interleaved for the fused SwiGLU-forward product
+        # (288 GB: a third copy of these 235 MB per Llama-3-8B layer is free; the decode / eval paths keep using Wext)
+        self.Wil = None
+        if FUSE_SWIGLU_FWD and [n for n, _ in self.parts] == ["gate_proj", "up_proj"] and not self.adapters and (self.N // 2) % 64 == 0:
+            self.Wil = ops.interleave_gate_up(self.Wext)
 
     def refresh(self, store: TrainableStore):
         """re-pack the adapters from the fp32 masters (after an optimizer step)."""
@@ -1197,14 +1204,19 @@ class HipLlamaLora(nn.Module):
             h_mid = L.o.forward(o_ext, st, residual=h, drop=do_)
             x2 = L.gu.new_input(M)
             _, rstd2 = ops.rmsnorm_fwd(h_mid, L.ln2, eps, out=x2[:, :d])
-            gu = L.gu.forward(x2, st, drop=dg_)
             hh = L.down.new_input(M)
-            ops.swiglu_fwd(gu, out=hh[:, :Fd])
+            gu_il = train and L.gu.Wil is not None and ops.gemm_swiglu_supported(M, 2 * Fd, d, x2.stride(0), L.gu.Wil.stride(0))
+            if gu_il:   # one launch: [gate64 | up64]-block stash for the backward + h = silu(gate) * up
+                gu = torch.empty((M, 2 * Fd), dtype=torch.bfloat16, device=h.device)
+                ops.gemm_swiglu(x2[:, :d], L.gu.Wil, gu, hh[:, :Fd])
+            else:
+                gu = L.gu.forward(x2, st, drop=dg_)
+                ops.swiglu_fwd(gu, out=hh[:, :Fd])
             h_out = L.down.forward(hh, st, residual=h_mid, drop=dd_)
             if train:
                 stash["layers"].append(dict(h=h, rstd1=rstd1, x1=x1 if L.qkv.adapters else None, qkv=qkv, qt=qt, kt=kt,
                                             o=o_ext, lse=lse, h_mid=h_mid, rstd2=rstd2,
-                                            x2=x2 if L.gu.adapters else None, gu=gu,
+                                            x2=x2 if L.gu.adapters else None, gu=gu, gu_il=gu_il,
                                             hh=hh if L.down.adapters else None, drops=(dq_, do_, dg_, dd_)))
             h = h_out
         hN, rstdN = ops.rmsnorm_fwd(h, self.norm_w, eps)
@@ -1385,9 +1397,9 @@ class HipLlamaLora(nn.Module):
         for li in reversed(range(len(self.layers))):
             L, S = self.layers[li], stash["layers"][li]
             dq_, do_, dg_, dd_ = S["drops"]
-            if L.down.adapters or not FUSE_SWIGLU_BWD:
+            if L.down.adapters or not FUSE_SWIGLU_BWD or S["gu_il"]:
                 d_hh = L.down.backward(dh, S["hh"], st, accumulate, drop=dd_)
-                dgu = ops.swiglu_bwd(S["gu"], d_hh[:, :Fd])
+                dgu = ops.swiglu_bwd(S["gu"], d_hh[:, :Fd], interleaved=S["gu_il"])
                 del d_hh
             else:
                 # frozen down_proj: dL/dh = dy . W_down never leaves the GEMM -- its epilogue applies the SwiGLU backward

@@ -448,12 +448,36 @@ def swiglu_fwd(gu, out=None):
     return out
 
 
-def swiglu_bwd(gu, dh, out=None):
+def swiglu_bwd(gu, dh, out=None, interleaved: bool = False):
+    """interleaved: gu is the [gate64 | up64]-block stash of gemm_swiglu(); out is always [dgate | dup]"""
     M, F2 = gu.shape
     if out is None:
         out = torch.empty((M, F2), dtype=torch.bfloat16, device=gu.device)
-    call("slam_swiglu_bwd", _p(gu), _ld(gu), _p(dh), _ld(dh), _p(out), _ld(out), M, F2 // 2, _s())
+    call("slam_swiglu_bwd", _p(gu), _ld(gu), _p(dh), _ld(dh), _p(out), _ld(out), M, F2 // 2, 1 if interleaved else 0, _s())
     return out
+
+
+def interleave_gate_up(w: torch.Tensor) -> torch.Tensor:
+    """[gate ; up] rows ([2F, K]) -> blocks of [64 gate rows ; the matching 64 up rows] (the B operand of gemm_swiglu)"""
+    F2, K = w.shape
+    Fd = F2 // 2
+    assert Fd % 64 == 0
+    return torch.stack([w[:Fd].view(Fd // 64, 64, K), w[Fd:].view(Fd // 64, 64, K)], dim=1).reshape(F2, K).contiguous()
+
+
+def gemm_swiglu_supported(M: int, N: int, K: int, lda: int, ldb: int) -> bool:
+    """does slam_gemm_swiglu_bf16_nt serve this shape (the auto rule runs the 4-wave kernel on it)?"""
+    return _GEMM_CFG in (0, 12) and lib.raw().slam_gemm_swiglu_supported(M, N, K, lda, ldb) == 1
+
+
+def gemm_swiglu(a: torch.Tensor, b_il: torch.Tensor, gu: torch.Tensor, h: torch.Tensor):
+    """gu[M, 2F] (block-interleaved [gate64 | up64]) = a @ b_il^T and h[M, F] = silu(gate) * up from one launch"""
+    M, K = a.shape
+    N = b_il.shape[0]
+    _timed(_GEMM_NAMES[12] + (f" [{M}x{N}x{K}]" if TIMER_SHAPES else ""), 2.0 * M * N * K,
+           lambda: call("slam_gemm_swiglu_bf16_nt", _p(a), _ld(a), _p(b_il), _ld(b_il), _p(gu), _ld(gu), _p(h), _ld(h), M, N, K, _s()),
+           nbytes=2.0 * (M * K + N * K) + 2.0 * M * N + 1.0 * M * N)
+    return gu, h
 
 
 # ------------------------------------------------------------------------------------------------ embed / loss / optim

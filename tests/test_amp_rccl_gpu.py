@@ -137,7 +137,7 @@ def _rccl_worker(port, q):
         # ---- GradSync over RCCL (world 1, collectives forced): mean over one rank = identity, bit for bit -------------------
         m1 = SlamHipModel(dict(cfg), dev).load_weights(W)
         m1.train()
-        gs = GradSync(m1, bucket_bytes=64 * 1024, force_collectives=True).attach(m1)
+        gs = GradSync(m1, bucket_bytes=4 * 1024, force_collectives=True).attach(m1)   # (the tiny model's LoRA prefixes are a few KB)
         gs.time_finish = True
         o1 = SlamAdamW(m1, lr=1e-3)
         for b in batches:
@@ -153,19 +153,27 @@ def _rccl_worker(port, q):
         train_step(m1, batches[1], o1, None, gs, gradient_accumulation_steps=2, do_step=True)
         res["finite_after_accum"] = bool(torch.isfinite(m1.store.flat).all())
         # ---- DistributedDataParallel(device_ids=[0]) over RCCL, torch AdamW, with and without GradScaler ---------------------
-        flats = []
-        for use_scaler in (False, True):
-            m2 = SlamHipModel(dict(cfg), dev, autograd_params=True).load_weights(W)
+        def torch_adamw_run(wrap_ddp, autograd_params, use_scaler=False):
+            m2 = SlamHipModel(dict(cfg), dev, autograd_params=autograd_params).load_weights(W)
             m2.train()
             m2 = m2.cuda(0)
-            ddp = torch.nn.parallel.DistributedDataParallel(m2, device_ids=[0])
-            topt = torch.optim.AdamW(ddp.parameters(), lr=1e-3, weight_decay=0.0)
+            step_m = torch.nn.parallel.DistributedDataParallel(m2, device_ids=[0]) if wrap_ddp else m2
+            topt = torch.optim.AdamW(step_m.parameters(), lr=1e-3, weight_decay=0.0)
             sc = torch.cuda.amp.GradScaler() if use_scaler else None
             for b in batches:
-                train_step(ddp, b, topt, None, None, scaler=sc)
-            flats.append(m2.store.flat.clone())
-        res["ddp_rel_vs_plain"] = float((flats[0] - m0.store.flat).abs().max() / m0.store.flat.abs().max())
-        res["ddp_scaler_rel"] = float((flats[1] - flats[0]).abs().max() / flats[0].abs().max())
+                train_step(step_m, b, topt, None, None, scaler=sc)
+            return m2.store.flat.clone()
+
+        def rel(a, b):
+            return float((a - b).abs().max() / b.abs().max())
+        plain = torch_adamw_run(False, False)               # the same optimizer without DDP, flat-buffer backward
+        plain_ag = torch_adamw_run(False, True)             # ... with the parameters as autograd inputs (what DDP needs)
+        ddp_f = torch_adamw_run(True, True)
+        ddp_s = torch_adamw_run(True, True, use_scaler=True)
+        res["autograd_params_rel"] = rel(plain_ag, plain)
+        res["ddp_rel_vs_plain"] = rel(ddp_f, plain_ag)
+        res["ddp_scaler_rel"] = rel(ddp_s, ddp_f)
+        res["torch_vs_fused_adamw_rel"] = rel(plain, m0.store.flat)   # informational: different arithmetic order of the update
         torch.cuda.synchronize()
         dist.barrier(device_ids=[0])
         dist.destroy_process_group()
@@ -185,10 +193,10 @@ def test_rccl_backend_runs_gradsync_and_ddp_at_world_1(dev):
     p.join(timeout=60)
     assert err is None, err
     assert res["backend"] == "nccl" and res["world"] == 1 and res["rccl"], res
-    assert res["gradsync_launched"] >= 2 * 3 and res["gradsync_equal"], res        # several prefix buckets per backward, 3 steps
+    assert res["gradsync_launched"] >= 2 * 3 and res["gradsync_equal"] and res["gradsync_avg_native"], res   # several prefix buckets per backward, 3 steps
     assert res["disarmed_launches"] == 0 and res["finite_after_accum"], res
     assert res["gradsync_exposed_ms"] is not None and res["gradsync_exposed_ms"] >= 0.0, res
-    # DDP averages bucket views it allocated itself and torch.optim.AdamW is a different (unfused) arithmetic order: 1e-4 of max |p|
-    assert res["ddp_rel_vs_plain"] <= 1e-4 and res["ddp_scaler_rel"] <= 1e-6, res
+    # DDP at world 1 = the same run without it (its averaging is a copy through RCCL); GradScaler's power-of-two scale is exact
+    assert res["autograd_params_rel"] <= 1e-6 and res["ddp_rel_vs_plain"] <= 1e-6 and res["ddp_scaler_rel"] <= 1e-6, res
     assert p.exitcode == 0
     print("RCCL world-1:", res)

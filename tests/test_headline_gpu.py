@@ -33,12 +33,18 @@ def _oracle_grads(W, cfg, ob, fwd):
     for n in names:
         W[n].requires_grad_(False)
         W[n].grad = None
-    return float(loss_ref), float(acc_ref), grads
+    return float(loss_ref.detach()), float(acc_ref), grads
 
 
 def _check_grads(model, grads, cos_min=0.999, norm_tol=3e-2):
     worst = 1.0
+    gmax = max(float(g.norm()) for g in grads.values())
     for n, p in model.store.params.items():
+        if n.endswith("key.bias") and float(grads[n].norm()) < 1e-4 * gmax:
+            # attention key biases: mathematically zero gradient (softmax is invariant to a per-query constant); the oracle's value is
+            # fp32 cancellation noise, the HIP one bf16 rounding noise of the dK column sum (same rule as tests/test_model_gpu.py:404)
+            assert float(p.grad.float().abs().max()) < 3e-2, n
+            continue
         cs = G.cosine(grads[n].numpy(), p.grad.float().cpu().numpy())
         worst = min(worst, cs)
         assert cs >= cos_min, f"grad {n}: cosine {cs}"
@@ -287,7 +293,7 @@ def test_attn_xcd_order_is_bit_identical_to_hardware_order(dev):
             dq, dk, dv = torch.empty_like(q2d), torch.empty_like(k2d), torch.empty_like(v2d)
             ops.attn_bwd(q2d, k2d, v2d, qt, kt, o, do2d, dot, lse, dq, dk, dv, B, T, Hq, Hkv, D, True, D ** -0.5)
             torch.cuda.synchronize()
-            res.append((o.clone(), lse.clone(), dq, dk, dv))
+            res.append((o.clone(), lse[..., :T].clone(), dq, dk, dv))     # (LSE columns past T are never written)
     finally:
         call("slam_attn_set_fwd_qf", 21)
     for a, b_ in zip(*res):

@@ -152,6 +152,48 @@ def test_gemm_swiglu_backward_epilogue_equals_separate_pass(dev, M, F_, K):
     assert float((got != want).float().mean()) < 0.01
 
 
+@pytest.mark.parametrize("M,F_,K,forced", [(772, 1024, 4096, True), (600, 1088, 2112, True), (11780, 14336, 4096, False)])
+def test_gemm_swiglu_forward_epilogue_equals_separate_pass(dev, M, F_, K, forced):
+    """act 4 (slam_gemm_swiglu_bf16_nt): ONE launch writes the [gate64 | up64]-block stash and h = silu(gate) * up.  Against
+    gemm_nt (same 4-wave kernel, plain [gate | up] weight) -> swiglu_fwd: the product's elements are the same dot products in the
+    same k order and silu runs on the bf16-rounded values in both, so BOTH outputs must be bit-identical once the column blocks are
+    put back in order.  Shapes: thin M tail (772 = 3 x 256 + 4), a ragged last tile row (600) with a ragged last tile column
+    (N = 2176 = 8.5 x 256), an odd number of k-tiles (K = 33 x 64); the Llama-3-8B shape of the C3 batch under the AUTO rule.  Then the backward
+    elementwise pass reading the block layout == reading the plain one."""
+    ops = _ops()
+    x = rnd((M, K), dev, seed=51)
+    w = rnd((2 * F_, K), dev, seed=52, std=K ** -0.5)
+    try:
+        if forced:
+            ops.gemm_set_config(12)
+        assert ops.gemm_swiglu_supported(M, 2 * F_, K, K, K)
+        gu_ref = ops.gemm_nt(x, w)
+        assert "w4" in ops.gemm_kernel_name(M, 2 * F_, K)
+        h_ref = ops.swiglu_fwd(gu_ref)
+        wil = ops.interleave_gate_up(w)
+        gu_il = torch.full((M, 2 * F_), float("nan"), dtype=torch.bfloat16, device=dev)
+        h = torch.full((M, F_), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm_swiglu(x, wil, gu_il, h)
+    finally:
+        ops.gemm_set_config(0)
+    blocks = gu_il.view(M, F_ // 64, 2, 64)
+    gu_back = torch.cat([blocks[:, :, 0].reshape(M, F_), blocks[:, :, 1].reshape(M, F_)], dim=1)
+    assert torch.equal(gu_back, gu_ref), f"stash differs in {int((gu_back != gu_ref).sum())} elements"
+    assert torch.equal(h, h_ref), f"h differs in {int((h != h_ref).sum())} elements"
+    dh = rnd((M, F_), dev, seed=53)
+    assert torch.equal(ops.swiglu_bwd(gu_il, dh, interleaved=True), ops.swiglu_bwd(gu_ref, dh))
+
+
+def test_gemm_swiglu_forward_is_refused_where_the_4_wave_kernel_does_not_run(dev):
+    ops = _ops()
+    from slam_llm_amd.lib import SlamHipError
+    assert not ops.gemm_swiglu_supported(11780, 11264, 2048, 2048, 2048)      # K <= 2048: the persistent kernel's territory
+    assert not ops.gemm_swiglu_supported(64, 28672, 4096, 4096, 4096)         # small M: 128x128 tiles win the auto rule
+    x, w = rnd((64, 4096), dev, seed=1), rnd((2048, 4096), dev, seed=2)
+    with pytest.raises(SlamHipError, match="not served"):
+        ops.gemm_swiglu(x, w, torch.empty((64, 2048), dtype=torch.bfloat16, device=dev), torch.empty((64, 1024), dtype=torch.bfloat16, device=dev))
+
+
 def test_gemm_rejects_bad_shapes(dev):
     ops = _ops()
     from slam_llm_amd.lib import SlamHipError
