@@ -12,7 +12,13 @@
  *  - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream), calls are thread-agnostic;
  *  - bf16 tensors are raw uint16 bit patterns; leading dimensions (ld*) are in ELEMENTS;
  *  - return 0 on success, < 0 on error; slam_last_error() returns a thread-local message;
- *  - the binding must raise (RuntimeError) on non-zero -- there is no CPU fallback anywhere.
+ *  - the binding must raise (RuntimeError) on non-zero -- there is no CPU fallback anywhere;
+ *  - collectives are NOT part of this ABI, by design: the one exchange of the path (mean all-reduce of the flat fp32 gradient
+ *    buffer per optimizer step; reference: DDP at src/slam_llm/pipeline/finetune.py:181-184) runs through torch.distributed's
+ *    backend "nccl" = RCCL over xGMI on the very device buffers these entry points write (slam_llm_amd/train.py: GradSync, or
+ *    torch's DistributedDataParallel around the module).  SURVEY 8(b) sketched `slam_allreduce_flat(buf, n, dtype, rcclComm_t,
+ *    stream)`; it would wrap the same ncclAllReduce and make the caller own a second communicator next to torch's, so it is not
+ *    exported.
  */
 #ifndef SLAM_HIP_H
 #define SLAM_HIP_H
@@ -60,9 +66,9 @@ int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, vo
 /* tile configuration override: 0 auto, 1 128x128/4 waves, 2 256x128/8 waves, 3 128x64, 4 256x256/8 waves (2-stage loop),
  * 5/6 256x256 register-double-buffered pipeline (6 = shipped schedule) */
 int slam_gemm_set_group_m(int group_m);   /* tuning knob: M-tiles per raster group of the 256x256 kernel (default 8) */
-int slam_gemm_set_config(int cfg);
-/* tools only: {shader cycles, 100 MHz ticks} at entry and exit of workgroup 0 of the last pipelined-kernel launch (synchronise
- * first); effective shader clock of the launch = d(cycles) / d(ticks) x 100 MHz -- how the DVFS cost of a variant is read */
+int slam_gemm_set_config(int cfg);   /* also: 100+v / 200+v = the 256x256 kernel of the auto rule for K > 2048 / <= 2048; 400 / 401 = cycle stamps off / on (tools) */
+/* tools only (after slam_gemm_set_config(401): production launches never write the stamps): {shader cycles, 100 MHz ticks} at
+ * entry and exit of workgroup 0 of the last pipelined-kernel launch (synchronise first); effective shader clock of the launch = d(cycles) / d(ticks) x 100 MHz -- how the DVFS cost of a variant is read */
 int slam_gemm_debug_clock(unsigned long long* out6);   /* [4] = cycles at the k-loop's start, [5] = after the epilogue */
 
 /* ---- conv front end (src/slam_llm/models/encoder.py:18-19): k=3, pad=1 im2col, stride 1|2 ---------

@@ -20,6 +20,7 @@
 //   * workgroup ids are remapped XCD-aware (block b runs on XCD b%8): each XCD gets a contiguous
 //     run of tiles, ordered in groups of 8 M-tiles, so A/B panels are re-used out of that XCD's L2.
 #include "common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmParams p) {
 //   vmcnt(0) ; barrier                            (stage t&1 is now free, tile t+1 is visible)
 //   phase B(t): 32 MFMA on ks=1 fragments         ||  DMA tile t+2 -> stage t&1  ||  ds_read ks=0 fragments of tile t+1
 // ------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int VAR>
+template <int BM, int BN, int WM, int WN, int VAR, bool PROBE = false>   // PROBE (tools): workgroup 0 stamps g_clk_probe
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
   constexpr bool NODMA = (VAR == 20 || VAR == 40), NOFRAG = (VAR == 30 || VAR == 40);
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (PROBE && blockIdx.x == 0 && threadIdx.x == 0) {
     g_clk_probe[0] = __builtin_readcyclecounter();
     g_clk_probe[1] = wall_clock64();
   }
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
   load_frags(smem, 0, a0, b0);
   if constexpr (NOFRAG) load_frags(smem, 1, a1, b1);
 
-  if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[4] = __builtin_readcyclecounter();
+  if (PROBE && blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[4] = __builtin_readcyclecounter();
   for (int t = 0; t < nt; t++) {
     const int cur = t & 1;
     const char* st = smem + cur * STAGE;
@@ -724,12 +725,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (PROBE && blockIdx.x == 0 && threadIdx.x == 0) {
     g_clk_probe[2] = __builtin_readcyclecounter();
     g_clk_probe[3] = wall_clock64();
   }
   gemm_epilogue<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, frow, fg);
-  if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[5] = __builtin_readcyclecounter();
+  if (PROBE && blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[5] = __builtin_readcyclecounter();
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -935,9 +936,9 @@ __device__ __forceinline__ void w4_vmwait() {
 // REG = false: operand tiles by LDS-DMA (one instruction per KiB, but 60-180 issue cycles each, which a lone wave per SIMD
 // cannot hide).  REG = true: global -> registers (buffer_load_dwordx4, issued in phase A of tile t for tile t+2) -> ds_write_b128
 // in phase B, after the barrier that releases the stage: two cheap instructions per KiB and 64 staging VGPRs.
-template <int BM, int BN, bool REG, int ABL = 0>   // ABL (tools, wrong results): 1 no operand traffic in the loop, 2 no fragment reads, 3 neither
+template <int BM, int BN, bool REG, int ABL = 0, bool PROBE = false>   // ABL (tools, wrong results): 1 no operand traffic in the loop, 2 no fragment reads, 3 neither; PROBE (tools): workgroup 0 stamps g_clk_probe
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned bytes_a, unsigned bytes_b) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (PROBE && blockIdx.x == 0 && threadIdx.x == 0) {
     g_clk_probe[0] = __builtin_readcyclecounter();
     g_clk_probe[1] = wall_clock64();
   }
@@ -1147,7 +1148,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
       });
     });
   };
-  if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[4] = __builtin_readcyclecounter();
+  if (PROBE && blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[4] = __builtin_readcyclecounter();
   // (a variant that stops fetching in the last two tiles -- three instantiations of the tile body -- made hipcc spill around the
   // asm statements: 876 bytes of scratch, wrong results (a spilled "=v" of a ds_read is stored before the data lands), removed)
   int t = 0;
@@ -1159,7 +1160,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
   // the compiler does not know the asm statements were MFMAs: cover the MFMA -> accumulator-read hazard and drain the
   // branch-free tail's DMA / reads (they target this workgroup's LDS) before the epilogue
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (PROBE && blockIdx.x == 0 && threadIdx.x == 0) {
     g_clk_probe[2] = __builtin_readcyclecounter();
     g_clk_probe[3] = wall_clock64();
   }
@@ -1180,16 +1181,16 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
     gemm_epilogue<4, 4, WTM, WTN>(p, acc10, m0 + 64, n0, wm, wn, frow, fg);
     gemm_epilogue<4, 4, WTM, WTN>(p, acc11, m0 + 64, n0 + 64, wm, wn, frow, fg);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[5] = __builtin_readcyclecounter();
+  if (PROBE && blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[5] = __builtin_readcyclecounter();
 }
 
-template <int BM, int BN, bool REG, int ABL = 0>
+template <int BM, int BN, bool REG, int ABL = 0, bool PROBE = false>
 int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   constexpr int lds = 2 * (BM + BN) * ROWB;
-  static bool attr_set = false;
-  auto kern = gemm_nt_w4_kernel<BM, BN, REG, ABL>;
+  static std::atomic<bool> attr_set{false};   // (setting the attribute twice from two threads is harmless; the flag only saves the call)
+  auto kern = gemm_nt_w4_kernel<BM, BN, REG, ABL, PROBE>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
@@ -1217,13 +1218,15 @@ int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
 // it, and the 16x16x32 stream interleaves with them better.  Numbers in profiles/r02_gemm_experiments.md; code in the history
 // (commit "GEMM experiments: 32x32x16-MFMA hand-ordered kernels").)
 
-template <int BM, int BN, int WM, int WN, int PIPE = -1>
+template <int BM, int BN, int WM, int WN, int PIPE = -1, bool PROBE = false>
 int launch_gemm(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   constexpr int lds = 2 * (BM + BN) * ROWB;
-  static bool attr_set = false;
-  auto kern = PIPE >= 0 ? gemm_nt_pipe_kernel<BM, BN, WM, WN, (PIPE >= 0 ? PIPE : 0)> : gemm_nt_kernel<BM, BN, WM, WN>;
+  static std::atomic<bool> attr_set{false};
+  void (*kern)(GemmParams);
+  if constexpr (PIPE >= 0) kern = gemm_nt_pipe_kernel<BM, BN, WM, WN, PIPE, PROBE>;
+  else kern = gemm_nt_kernel<BM, BN, WM, WN>;
   if (!attr_set && lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1244,8 +1247,8 @@ int launch_gemm_persist2(GemmParams& p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   constexpr int lds = 2 * (BM + BN) * ROWB;
-  static bool attr_set = false;
-  static int n_cu = 0;
+  static std::atomic<bool> attr_set{false};
+  static std::atomic<int> n_cu{0};
   auto kern = gemm_nt_persist2_kernel<BM, BN, WM, WN>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1259,14 +1262,15 @@ int launch_gemm_persist2(GemmParams& p, hipStream_t stream) {
       slam_set_error("gemm: cannot query the device");
       return -2;
     }
-    n_cu = prop.multiProcessorCount;
+    n_cu = prop.multiProcessorCount;   // (before the flag: a thread that sees the flag sees the count)
     attr_set = true;
   }
   // exact extents of the two operand views: rows past the end are out of range for the descriptor and read as zeros
   const uint64_t bytes_a = ((uint64_t)(p.M - 1) * (uint64_t)p.lda + (uint64_t)p.K) * 2ull;
   const uint64_t bytes_b = ((uint64_t)(p.N - 1) * (uint64_t)p.ldb + (uint64_t)p.K) * 2ull;
   const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
-  const int64_t grid = nwg < n_cu ? nwg : n_cu;
+  const int64_t ncu = n_cu;
+  const int64_t grid = nwg < ncu ? nwg : ncu;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), lds, stream, p, (unsigned)bytes_a, (unsigned)bytes_b);
   SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(persistent, descriptor DMA)");
   return 0;
@@ -1277,10 +1281,12 @@ static inline bool fits_descriptor(int64_t rows, int64_t ld, int tile) {
   return (uint64_t)(rows + tile) * (uint64_t)ld * 2ull < (1ull << 32);
 }
 
-int g_gemm_cfg = 0;  // 0 = auto
-int g_gemm_big = 12;       // which 256x256 kernel the auto rule uses for K > 2048 (6 | 7 | 12): in the C3 step 12 -> 401.7 ms, 6 -> 408.3 ms
-int g_gemm_big_shortk = 7; // ... and for K <= 2048
-int g_gemm_group_m = 8;
+// tuning state (tools / sweeps set it between launches; relaxed atomics: a launch reads each knob once, whole)
+std::atomic<int> g_gemm_cfg{0};  // 0 = auto
+std::atomic<int> g_gemm_big{12};       // which 256x256 kernel the auto rule uses for K > 2048 (6 | 7 | 12): in the C3 step 12 -> 401.7 ms, 6 -> 408.3 ms
+std::atomic<int> g_gemm_big_shortk{7}; // ... and for K <= 2048
+std::atomic<int> g_gemm_group_m{8};
+std::atomic<int> g_gemm_probe{0};      // 1: cfg 6 / 12 launch their PROBE instantiation (workgroup 0 stamps g_clk_probe; tools/gemm_epi_probe.py)
 
 }  // namespace
 
@@ -1302,6 +1308,7 @@ extern "C" int slam_gemm_debug_clock(unsigned long long* out6) {   // tools: sta
 
 extern "C" int slam_gemm_set_config(int cfg) {
   // 100 + v / 200 + v (v in 6, 7, 12): the 256x256 kernel the AUTO rule picks for K > 2048 / K <= 2048 (tools/step sweeps)
+  if (cfg == 400 || cfg == 401) { g_gemm_probe = cfg - 400; return 0; }   // tools: cycle stamps of workgroup 0 (slam_gemm_debug_clock)
   if (cfg == 106 || cfg == 107 || cfg == 112) { g_gemm_big = cfg - 100; return 0; }
   if (cfg == 206 || cfg == 207 || cfg == 212) { g_gemm_big_shortk = cfg - 200; return 0; }
   SLAM_CHECK_ARG(cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 6 || cfg == 7 || cfg == 12, "slam_gemm_set_config: cfg %d (0 auto | 1 2 3 4 6 7 12)", cfg);
@@ -1345,6 +1352,7 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
   p.group_m = g_gemm_group_m;
   hipStream_t s = (hipStream_t)stream;
   int cfg = g_gemm_cfg;
+  const int big = g_gemm_big, big_shortk = g_gemm_big_shortk;
   if (cfg == 0) {
     // auto (measured on MI355X, profiles/r01_perf_ops_first.json, tools/gemm_bench.py): the pipelined 256x256 tile
     // runs 1.25-1.4x the 128x128 one per CU; pick whichever loses less to wave quantisation over the 256 CUs
@@ -1361,7 +1369,7 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     if (N <= 64) cfg = 3;
     // 4-wave kernel: faster k-loop, longer epilogue (64 fragments per wave) -- it wins from K = 4096 up unless the output is narrow
     // (N = 1280 with a residual epilogue, Whisper fc2: 1084 vs 1124 TF for the 8-wave pipelined kernel, tools/gemm_enc_bench.py)
-    else if (t256 < t128) cfg = (K <= 2048) ? g_gemm_big_shortk : ((g_gemm_big == 12 && N < 2048) ? 6 : g_gemm_big);
+    else if (t256 < t128) cfg = (K <= 2048) ? big_shortk : ((big == 12 && N < 2048) ? 6 : big);
     else cfg = 1;
   }
   switch (cfg) {
@@ -1369,7 +1377,9 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     case 2: return launch_gemm<256, 128, 4, 2>(p, s);
     case 3: return launch_gemm<128, 64, 2, 2>(p, s);
     case 4: return launch_gemm<256, 256, 2, 4>(p, s);
-    case 6: return launch_gemm<256, 256, 2, 4, 1>(p, s);  // pipelined, phase A pinned before the barrier (shipped)
+    case 6:                                                // pipelined, phase A pinned before the barrier (shipped)
+      if (g_gemm_probe) return launch_gemm<256, 256, 2, 4, 1, true>(p, s);
+      return launch_gemm<256, 256, 2, 4, 1>(p, s);
     case 7:                                                // persistent pipelined, descriptor DMA (auto: short-K products)
       if (p.K < 2 * BK || !fits_descriptor(p.M, p.lda, 256) || !fits_descriptor(p.N, p.ldb, 256)) return launch_gemm<256, 256, 2, 4, 1>(p, s);
       return launch_gemm_persist2<256, 256, 2, 4>(p, s);
@@ -1378,6 +1388,7 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     case 12:                                               // 4 waves, hand-ordered k-loop
       if (p.K < 2 * BK || (uint64_t)p.M * (uint64_t)p.lda * 2ull >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldb * 2ull >= (1ull << 32))
         return launch_gemm<256, 256, 2, 4, 1>(p, s);
+      if (g_gemm_probe) return launch_gemm_w4<256, 256, false, 0, true>(p, s);
       return launch_gemm_w4<256, 256, false>(p, s);
   }
   slam_set_error("slam_gemm_bf16_nt: bad config %d", cfg);

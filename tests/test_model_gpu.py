@@ -134,10 +134,10 @@ def test_unfrozen_encoder_training_matches_reference_fixture(dev):
                 gold, mine = G.sub(fx, "grad." + n, g)
                 cs = G.cosine(gold, mine)
                 worst = min(worst, cs)
-                assert cs > 0.995, f"grad {n}: cosine {cs}"
+                assert cs > 0.999, f"grad {n}: cosine {cs}"     # (worst measured over the 81 tensors: 0.9994; same bound as the frozen-encoder cases)
                 gn = float(fx["grad." + n + ".__norm"])
                 mn = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
-                assert abs(mn - gn) < 5e-2 * gn + 1e-7, f"grad {n}: norm {mn} vs {gn}"
+                assert abs(mn - gn) < 3e-2 * gn + 1e-7, f"grad {n}: norm {mn} vs {gn}"
         opt.step(); sched.step(); opt.zero_grad()
         losses.append(float(outputs.loss))
     print("unfrozen encoder: worst gradient cosine", worst, "losses", losses)

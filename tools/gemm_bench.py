@@ -7,6 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slam_llm_amd import ops  # noqa: E402
+ops.call("slam_gemm_set_config", 401)   # workgroup 0 of cfg 6 / 12 launches stamps its phases (PROBE instantiation; off in production)
 
 dev = torch.device("cuda:0")
 cfgs = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "6,7,12".split(","))]

@@ -3,6 +3,7 @@ running tiles grows -- is the epilogue's store tail a per-CU cost or a chip-wide
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slam_llm_amd import ops
+ops.call("slam_gemm_set_config", 401)   # workgroup 0 of cfg 6 / 12 launches stamps its phases (PROBE instantiation; off in production)
 dev = torch.device("cuda:0")
 K = 4096
 CFG = int(sys.argv[1]) if len(sys.argv) > 1 else 6

@@ -3,6 +3,7 @@ epilogue shader cycles of workgroup 0's tile plus the effective clock (the persi
 import ctypes, os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from slam_llm_amd import ops
+ops.call("slam_gemm_set_config", 401)   # workgroup 0 of cfg 6 / 12 launches stamps its phases (PROBE instantiation; off in production)
 dev = torch.device("cuda:0")
 for (M, N, K, ep) in ((46500, 3840, 1280, {}), (46500, 3840, 1280, dict(bias=True)), (46500, 5120, 1280, dict(bias=True, act=ops.ACT_GELU)), (46500, 1280, 1280, dict(bias=True, res=True))):
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
