@@ -65,8 +65,15 @@ int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, vo
                       int accumulate, void* stream);
 /* tile configuration override: 0 auto, 1 128x128/4 waves, 2 256x128/8 waves, 3 128x64, 4 256x256/8 waves (2-stage loop),
  * 5/6 256x256 register-double-buffered pipeline (6 = shipped schedule) */
+/* Split-K tail of the 4-wave 256x256 kernel ("stream-K" for the partial last round of tiles): when T tiles leave R = T mod 256
+ * (<= 128) for the last round, those R tiles are computed by R x S workgroups over 1/S of K each, inside the SAME launch; partial
+ * sums go to fp32 slabs, the last arriver of a tile adds them in slice order (bit-reproducible) and runs the epilogue.  The slabs
+ * live in a caller-owned device buffer (the library never allocates): `workspace` = 4096 bytes of ZEROED arrival counters followed
+ * by up to 256 slabs of 256 KiB (64 MiB + 4 KiB serves every plan; smaller buffers shrink S).  No workspace = no split.  All
+ * launches that may split must be ordered on one stream.  null / 0 detaches. */
+int slam_gemm_set_workspace(void* workspace, int64_t bytes);
 int slam_gemm_set_group_m(int group_m);   /* tuning knob: M-tiles per raster group of the 256x256 kernel (default 8) */
-int slam_gemm_set_config(int cfg);   /* also: 100+v / 200+v = the 256x256 kernel of the auto rule for K > 2048 / <= 2048; 400 / 401 = cycle stamps off / on (tools) */
+int slam_gemm_set_config(int cfg);   /* also: 100+v / 200+v = the 256x256 kernel of the auto rule for K > 2048 / <= 2048; 300 / 301 / 302..316 = split-K tail auto / off / forced slices; 400 / 401 = cycle stamps off / on (tools) */
 /* tools only (after slam_gemm_set_config(401): production launches never write the stamps): {shader cycles, 100 MHz ticks} at
  * entry and exit of workgroup 0 of the last pipelined-kernel launch (synchronise first); effective shader clock of the launch = d(cycles) / d(ticks) x 100 MHz -- how the DVFS cost of a variant is read */
 int slam_gemm_debug_clock(unsigned long long* out6);   /* [4] = cycles at the k-loop's start, [5] = after the epilogue */

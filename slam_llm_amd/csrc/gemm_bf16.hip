@@ -28,6 +28,15 @@ namespace {
 // tools only: shader-clock / real-time stamps of workgroup 0 (effective clock of a launch = d(shader cycles) / d(100 MHz ticks))
 __device__ unsigned long long g_clk_probe[6];   // workgroup 0: {cycles, 100 MHz ticks} at entry and at k-loop end; cycles at k-loop start and after the epilogue
 
+// split-K tail workspace (registered by the host with slam_gemm_set_workspace: the library never allocates): [SK_CNT_BYTES of
+// arrival counters, zero | fp32 slabs].  One workspace per process: GEMM launches that may split must be ordered on one stream
+// (they are: every product of the step is launched on torch's current stream).
+constexpr int64_t SK_CNT_BYTES = 4096;
+constexpr int SK_MAX_TILES = (int)(SK_CNT_BYTES / 4);
+std::atomic<void*> g_gemm_ws{nullptr};
+std::atomic<int64_t> g_gemm_ws_bytes{0};
+std::atomic<int> g_gemm_splitk{0};   // -1 off, 0 auto, >= 2 forced number of K slices (tools / tests)
+
 struct GemmParams {
   const bf16_t* A;
   const bf16_t* B;
@@ -46,6 +55,11 @@ struct GemmParams {
   int accumulate;
   int tiles_m, tiles_n;
   int group_m;   // M-tiles per raster group (L2 reuse of the B panel inside an XCD)
+  // split-K tail of the 4-wave kernel (sk_S >= 2; see gemm_nt_w4_kernel): the first sk_main workgroups compute whole tiles, the
+  // other sk_R * sk_S compute 1 / sk_S of the K range of one of the last sk_R tiles each
+  int sk_main, sk_R, sk_S;
+  float* sk_ws;        // [sk_R * sk_S] fp32 slabs of 256 x 256 partial sums, lane-linear
+  unsigned* sk_cnt;    // [sk_R] arrival counters, zero between launches
 };
 
 constexpr int BK = 64;           // bf16 elements per K-tile
@@ -952,12 +966,29 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
+  // ---- workgroup -> tile (XCD-aware bijection: XCD x owns the contiguous run [base(x), base(x + 1)) of the tile order) ----
+  // Split-K tail ("stream-K" for the one-tile-per-workgroup launch): every 256x256 tile costs the same, so T tiles on 256 CUs are
+  // ceil(T / 256) rounds and the last round holds only R = T mod 256 tiles (16 of 2576 for the dL/dh product of the C3 step: 240
+  // CUs idle for a whole tile time).  With sk_S >= 2 the launch carries sk_main = T - R whole-tile workgroups first (the first
+  // sk_main / 8 entries of every XCD's run) and then R * S workgroups that each compute 1 / S of the k-tiles of one of the
+  // remaining R tiles -- they are dispatched last, fill the idle CUs of the last round, write fp32 partial slabs, take a ticket,
+  // and the LAST arriver of a tile sums the S slabs in index order (bit-reproducible, whoever it is) and runs the epilogue.
+  // No workgroup ever waits for another one: nothing here depends on co-residency or dispatch order.
   const int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
+  int sk_tile = -1, sk_split = 0;   // tail bookkeeping (wave-uniform)
   {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int q = nwg >> 3, r = nwg & 7;
+    int xcd = bid & 7, idx = bid >> 3;
+    if (p.sk_S > 1 && bid >= p.sk_main) {
+      const int w = bid - p.sk_main;
+      sk_tile = w % p.sk_R;             // consecutive workgroups: different tiles, the same K slice
+      sk_split = w / p.sk_R;
+      xcd = sk_tile & 7;                // tail tile t is entry sk_main / 8 + t / 8 of XCD (t % 8)'s run
+      idx = (p.sk_main >> 3) + (sk_tile >> 3);
+    }
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    bid = base + (bid >> 3);
+    bid = base + idx;
   }
   const int GM = p.group_m;
   const int per_group = GM * p.tiles_n;
@@ -968,6 +999,10 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
   const int tm = first_m + within % gsz;
   const int tn = within / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
+  if (sk_tile >= 0 && p.M - m0 <= 16) {   // a thin tile among the tail tiles is not split: slice 0 computes all of it below
+    if (sk_split > 0) return;
+    sk_tile = -1;
+  }
 
   // ---- thin M-tail tile (at most 16 valid rows: 31 x 380 = 11780 tokens leave FOUR rows for the 47th row of tiles, 2.1 % of all
   // tiles of every LLM product).  B has no reuse over 16 rows, so nothing is staged: each wave takes 64 of the 256 columns and
@@ -1045,11 +1080,15 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
   const int schunk = (lane & 7) ^ srow;
   const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, bytes_a, 0x00020000);
   const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, bytes_b, 0x00020000);
+  // this workgroup's k-tiles: all of them, or slice sk_split of sk_S (the slice start is folded into the per-lane offsets)
+  const int nt_all = p.K / BK;
+  const int kt0 = sk_tile >= 0 ? (int)((int64_t)sk_split * nt_all / p.sk_S) : 0;
+  const int kt1 = sk_tile >= 0 ? (int)((int64_t)(sk_split + 1) * nt_all / p.sk_S) : nt_all;
   unsigned a_vo[NIA], b_vo[NIB];
 #pragma unroll
-  for (int j = 0; j < NIA; j++) a_vo[j] = (unsigned)(((int64_t)min(m0 + (j * 4 + wave) * 8 + srow, p.M - 1) * p.lda + schunk * 8) * 2);
+  for (int j = 0; j < NIA; j++) a_vo[j] = (unsigned)(((int64_t)min(m0 + (j * 4 + wave) * 8 + srow, p.M - 1) * p.lda + schunk * 8 + (int64_t)kt0 * BK) * 2);
 #pragma unroll
-  for (int j = 0; j < NIB; j++) b_vo[j] = (unsigned)(((int64_t)min(n0 + (j * 4 + wave) * 8 + srow, p.N - 1) * p.ldb + schunk * 8) * 2);
+  for (int j = 0; j < NIB; j++) b_vo[j] = (unsigned)(((int64_t)min(n0 + (j * 4 + wave) * 8 + srow, p.N - 1) * p.ldb + schunk * 8 + (int64_t)kt0 * BK) * 2);
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
   const unsigned dma_a = lds0 + (unsigned)(wave * 1024), dma_b = dma_a + (unsigned)(BM * ROWB);
 
@@ -1078,7 +1117,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
     else w4_mfma(acc11[i - 4][j - 4], bfrag, afrag);
   };
   bf16x8_t a0[FM], b0[FN], a1[FM], b1[FN];
-  const int nt = p.K / BK;
+  const int nt = kt1 - kt0;
 
   auto dma_tile = [&](int kt, int stage) {   // whole tile, back to back (prologue only)
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(kt * BK * 2));
@@ -1164,6 +1203,54 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
     g_clk_probe[2] = __builtin_readcyclecounter();
     g_clk_probe[3] = wall_clock64();
   }
+  if (sk_tile >= 0) {
+    // ---- split-K tail: publish this slice's partial sums, take a ticket; only the last arriver goes on to the epilogue ----
+    // slab layout: float4 number ((quadrant * 16 + i * 4 + j) * 256 + tid): every wave store / load is one contiguous KiB
+    float* slab = p.sk_ws + ((size_t)sk_tile * p.sk_S + sk_split) * (size_t)(BM * BN);
+    auto put = [&](f32x4_t (&a)[4][4], int quad) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          *reinterpret_cast<f32x4_t*>(slab + ((size_t)((quad * 16 + i * 4 + j) * 256 + tid) << 2)) = a[i][j];
+    };
+    put(acc00, 0); put(acc01, 1); put(acc10, 2); put(acc11, 3);
+    // producer side of the hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): every wave drains its stores, workgroup
+    // barrier, ONE lane writes the XCD's L2 back (agent-scope release), asm vmcnt(0) (the compiler may drop the one the fence
+    // implies), then the relaxed agent-scope ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(smem);   // (the k-loop is over: LDS is free)
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *flag = __hip_atomic_fetch_add(p.sk_cnt + sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned ticket = *reinterpret_cast<volatile unsigned*>(flag);
+    if (ticket != (unsigned)(p.sk_S - 1)) return;
+    // consumer side: one agent-scope acquire (invalidates this CU's L1), barrier, plain loads
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      p.sk_cnt[sk_tile] = 0;   // ready for the next launch (published by the kernel boundary; nobody else touches it in this one)
+    }
+    __syncthreads();
+    // fixed summation order s = 0 .. S-1 (this workgroup's own slab is re-read like the others: the result does not depend on
+    // which slice happened to arrive last)
+    const float* slab0 = p.sk_ws + (size_t)sk_tile * p.sk_S * (size_t)(BM * BN);
+    auto get = [&](f32x4_t (&a)[4][4], int quad) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float* src = slab0 + ((size_t)((quad * 16 + i * 4 + j) * 256 + tid) << 2);
+          f32x4_t v = *reinterpret_cast<const f32x4_t*>(src);
+          for (int sl = 1; sl < p.sk_S; sl++) v += *reinterpret_cast<const f32x4_t*>(src + (size_t)sl * (BM * BN));
+          a[i][j] = v;
+        }
+    };
+    get(acc00, 0); get(acc01, 1); get(acc10, 2); get(acc11, 3);
+  }
   if (p.act == 4) {   // fused SwiGLU forward: the left / right quadrants of the wave tile are gate / up of the same 64 columns
     const int nb = n0 + wn * WTN, mb = m0 + wm * WTM;
     if (nb < p.N) {
@@ -1201,7 +1288,34 @@ int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
   }
   const uint64_t bytes_a = ((uint64_t)(p.M - 1) * (uint64_t)p.lda + (uint64_t)p.K) * 2ull;
   const uint64_t bytes_b = ((uint64_t)(p.N - 1) * (uint64_t)p.ldb + (uint64_t)p.K) * 2ull;
-  const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+  // ---- split-K tail plan (see the kernel): R = tiles of the last, partial round; S slices each so that R * S <= one round ----
+  p.sk_main = 0; p.sk_R = 0; p.sk_S = 1; p.sk_ws = nullptr; p.sk_cnt = nullptr;
+  const int mode = g_gemm_splitk;   // -1 off, 0 auto, >= 2 forced slice count (tools / tests)
+  char* ws = (char*)g_gemm_ws.load();
+  const int64_t ws_bytes = g_gemm_ws_bytes;
+  if (mode >= 0 && ws != nullptr && nwg < (1ll << 30)) {
+    const int n_cu = 256;
+    const int nt = p.K / BK;
+    const int R = (int)(nwg % n_cu);
+    int S = 1;
+    if (mode >= 2) S = mode;
+    else if (R > 0 && R <= n_cu / 2 && nwg >= n_cu) {
+      // auto: only a genuinely short last round (<= half the CUs), slices of >= 8 k-tiles, at most 8 slabs to add up.  Measured
+      // on MI355X (profiles/r03_gemm_splitk.md) the tail then costs ~1/S of a tile plus ~15 us instead of a whole tile time.
+      S = n_cu / R;
+      if (S > 8) S = 8;
+      if (S > nt / 8) S = nt / 8;
+    }
+    const int Rt = (mode >= 2) ? (int)(nwg < n_cu ? nwg : (R ? R : n_cu)) : R;   // forced: also under-filled / exact grids
+    const int64_t need = SK_CNT_BYTES + (int64_t)Rt * S * (int64_t)(BM * BN * 4);
+    if (S >= 2 && Rt >= 1 && Rt <= SK_MAX_TILES && nt / S >= 1 && need <= ws_bytes && ((nwg - Rt) % 8) == 0) {
+      p.sk_main = (int)(nwg - Rt); p.sk_R = Rt; p.sk_S = S;
+      p.sk_cnt = reinterpret_cast<unsigned*>(ws);
+      p.sk_ws = reinterpret_cast<float*>(ws + SK_CNT_BYTES);
+      nwg = (int64_t)p.sk_main + (int64_t)Rt * S;
+    }
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p, (unsigned)bytes_a, (unsigned)bytes_b);
   SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(4-wave, hand-ordered k-loop)");
   return 0;
@@ -1306,7 +1420,21 @@ extern "C" int slam_gemm_debug_clock(unsigned long long* out6) {   // tools: sta
   return 0;
 }
 
+extern "C" int slam_gemm_set_workspace(void* workspace, int64_t bytes) {
+  SLAM_CHECK_ARG((workspace == nullptr && bytes == 0) || (workspace != nullptr && bytes >= SK_CNT_BYTES + 2 * 256 * 256 * 4 && ((uintptr_t)workspace % 16) == 0),
+                 "slam_gemm_set_workspace: need a 16-byte aligned device buffer of >= %ld bytes whose first %ld bytes are zero (or null, 0 to detach)",
+                 (long)(SK_CNT_BYTES + 2 * 256 * 256 * 4), (long)SK_CNT_BYTES);
+  g_gemm_ws_bytes = 0;
+  g_gemm_ws = workspace;
+  g_gemm_ws_bytes = bytes;
+  return 0;
+}
+
 extern "C" int slam_gemm_set_config(int cfg) {
+  if (cfg >= 300 && cfg <= 316) {   // split-K tail of the 4-wave kernel: 300 = auto, 301 = off, 302..316 = forced slice count (tools / tests)
+    g_gemm_splitk = (cfg == 300) ? 0 : (cfg == 301 ? -1 : cfg - 300);
+    return 0;
+  }
   // 100 + v / 200 + v (v in 6, 7, 12): the 256x256 kernel the AUTO rule picks for K > 2048 / K <= 2048 (tools/step sweeps)
   if (cfg == 400 || cfg == 401) { g_gemm_probe = cfg - 400; return 0; }   // tools: cycle stamps of workgroup 0 (slam_gemm_debug_clock)
   if (cfg == 106 || cfg == 107 || cfg == 112) { g_gemm_big = cfg - 100; return 0; }

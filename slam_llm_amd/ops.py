@@ -77,6 +77,25 @@ def _ld(t: torch.Tensor) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+_GEMM_WS = {}   # device index -> workspace tensor of the split-K tail (kept alive for the life of the process)
+GEMM_WS_BYTES = 4096 + 512 * 256 * 256 * 4   # counters + 512 slabs of 256 KiB (the auto plans use <= 256; forced sweeps up to 512): 128 MiB of 288 GB
+
+
+def _ensure_gemm_workspace(device: torch.device):
+    """the split-K tail of the 4-wave GEMM needs a caller-owned scratch buffer (slam_gemm_set_workspace); registered once per
+    process, on the first product (one process drives one GPU: a second device would need its own library state)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _GEMM_WS:
+        return
+    if _GEMM_WS:
+        raise lib.SlamHipError(f"slam_llm_amd drives one GPU per process (workspace registered on cuda:{next(iter(_GEMM_WS))}, got cuda:{idx})")
+    if torch.cuda.is_current_stream_capturing():
+        return   # (no allocation inside a graph capture: products captured before the first eager one simply do not split)
+    ws = torch.zeros(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
+    call("slam_gemm_set_workspace", _p(ws), GEMM_WS_BYTES)
+    _GEMM_WS[idx] = ws
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None,
             residual=None, res_row_mod: int = 0, act: int = ACT_NONE, alpha: float = 1.0,
             out_dtype=torch.bfloat16, accumulate: bool = False, k_alg: Optional[int] = None) -> torch.Tensor:
@@ -89,6 +108,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     od = F32 if out.dtype == torch.float32 else BF16
+    _ensure_gemm_workspace(a.device)
     if (M <= SKINNY_MAX_M and bias is None and act == ACT_NONE and alpha == 1.0 and not accumulate and res_row_mod == 0
             and _GEMM_CFG == 0):
         return gemm_skinny(a, b, out, residual=residual)  # a few rows (decode): HBM-bound weight-streaming kernel
@@ -151,7 +171,9 @@ def gemm_set_config(cfg: int):
     """0 = auto rule, 1 2 3 4 6 7 12 = force one kernel (tools / tests); 100 + v / 200 + v = which 256x256 kernel the auto rule uses
     for K > 2048 / K <= 2048 (sweeps)"""
     global _GEMM_CFG
-    if cfg >= 100:
+    if cfg >= 300:      # 300 / 301 / 302..316: split-K tail auto / off / forced slices; 400 / 401: cycle stamps off / on
+        pass
+    elif cfg >= 100:
         _GEMM_BIG["big" if cfg < 200 else "shortk"] = cfg % 100
     else:
         _GEMM_CFG = cfg
@@ -474,6 +496,7 @@ def gemm_swiglu(a: torch.Tensor, b_il: torch.Tensor, gu: torch.Tensor, h: torch.
     """gu[M, 2F] (block-interleaved [gate64 | up64]) = a @ b_il^T and h[M, F] = silu(gate) * up from one launch"""
     M, K = a.shape
     N = b_il.shape[0]
+    _ensure_gemm_workspace(a.device)
     _timed(_GEMM_NAMES[12] + (f" [{M}x{N}x{K}]" if TIMER_SHAPES else ""), 2.0 * M * N * K,
            lambda: call("slam_gemm_swiglu_bf16_nt", _p(a), _ld(a), _p(b_il), _ld(b_il), _p(gu), _ld(gu), _p(h), _ld(h), M, N, K, _s()),
            nbytes=2.0 * (M * K + N * K) + 2.0 * M * N + 1.0 * M * N)

@@ -3,7 +3,10 @@
 The k-loop of gemm_nt_w4_kernel, the tile loops of attn_fwd_kernel, attn_bwd_dkdv_ring_kernel and attn_bwd_dq_ring_kernel place their LDS reads, LDS-DMA and
 MFMAs as `asm volatile` statements whose result registers are "ready" for the compiler at once.  If hipcc ever SPILLS such a
 register (stores it to scratch before the data has landed) the kernel computes garbage -- it happened once with three
-instantiations of the GEMM tile body (876 bytes of scratch, wrong results).  Zero scratch is therefore a build invariant."""
+instantiations of the GEMM tile body (876 bytes of scratch, wrong results).  Zero scratch is therefore a build invariant of the
+attention kernels and the pipelined GEMM.  The 4-wave GEMM (512 registers, split-K tail + fused epilogues around its loop) is allowed
+to park loop-INVARIANT values in scratch outside its hand-ordered region: the invariant there is that no scratch STORE
+appears between the first inline-asm LDS read and the last inline-asm MFMA (prologue reads + the whole k-loop)."""
 import os
 import re
 import subprocess
@@ -16,6 +19,7 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 HIPCC = "/opt/rocm/bin/hipcc"
 # (gemm_nt_persist2_kernel is compiler-scheduled -- no asm loads -- and spills three loop-invariant dwords around the epilogue inside
 # its tile loop: harmless, not part of the invariant)
+REGION_RULE = ("gemm_nt_w4_kernel",)   # kernels checked by region instead of by total scratch size
 FILES = {"gemm_bf16.hip": ([], ("gemm_nt_w4_kernel", "gemm_nt_pipe_kernel")),
          "attention.hip": (["-mllvm", "-amdgpu-mfma-vgpr-form"], ("attn_fwd_kernel", "attn_bwd_dkdv_ring_kernel", "attn_bwd_dq_ring_kernel"))}
 
@@ -29,7 +33,29 @@ def _scratch_by_kernel(src, extra):
     res = {}
     for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
         res[m.group(1)] = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
+    for name in list(res):
+        if res[name] and any(r in name for r in REGION_RULE):
+            res[name] = _scratch_in_asm_region(text, name)
     return res
+
+
+def _scratch_in_asm_region(text, name):
+    """number of scratch STORES between the first inline-asm ds_read and the last inline-asm MFMA of kernel `name` (a spilled asm
+    result is a store inside that region; reloading a loop-invariant value there is harmless)"""
+    start = text.index("\n" + name + ":")
+    lines = text[start: text.index(".end_amdhsa_kernel", start)].split("\n")
+    inasm, first, last = False, None, None
+    for i, l in enumerate(lines):
+        if "ASMSTART" in l:
+            inasm = True
+        elif "ASMEND" in l:
+            inasm = False
+        elif inasm and "ds_read_b128" in l and first is None:
+            first = i
+        elif inasm and "v_mfma" in l:
+            last = i
+    assert first is not None and last is not None and last > first, f"{name}: hand-ordered region not found"
+    return sum(1 for l in lines[first:last + 1] if "scratch_store" in l)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")

@@ -194,6 +194,81 @@ def test_gemm_swiglu_forward_is_refused_where_the_4_wave_kernel_does_not_run(dev
         ops.gemm_swiglu(x, w, torch.empty((64, 2048), dtype=torch.bfloat16, device=dev), torch.empty((64, 1024), dtype=torch.bfloat16, device=dev))
 
 
+@pytest.mark.parametrize("M,N,K,slices,epi", [
+    (4352, 4096, 4096, 0, "bias+res"),      # 17 x 16 = 272 tiles = one round + 16: the AUTO plan (8 slices of 8 k-tiles)
+    (4352, 4096, 4096, 3, "none"),          # forced 3 slices of 21 / 21 / 22 k-tiles
+    (600, 1024, 2112, 3, "gelu"),           # under-filled grid (12 tiles, ragged last tile row), 33 k-tiles in 3 slices of 11
+    (772, 512, 4096, 4, "f32acc"),          # thin 4-row tail tiles among the split tiles; fp32 accumulate epilogue
+    (2048, 2048, 4096, 2, "none"),          # exactly 64 tiles, every one split in two
+])
+def test_gemm_split_k_tail(dev, M, N, K, slices, epi):
+    """split-K tail of the 4-wave kernel (in-launch partial slabs + ticket + fixed-order fix-up): against the unsplit launch of the
+    same kernel (fp32 partial sums are re-associated: bf16 outputs may differ by one rounding on a few elements: <= 2^-7 relative,
+    < 2 % of the elements), against an fp32 matmul, and bit-reproducible from run to run."""
+    ops = _ops()
+    a, b = rnd((M, K), dev, seed=61), rnd((N, K), dev, seed=62, std=K ** -0.5)
+    bias = torch.randn(N, device=dev) if epi in ("bias+res", "gelu") else None
+    res = rnd((M, N), dev, seed=63) if epi == "bias+res" else None
+    act = ops.ACT_GELU if epi == "gelu" else ops.ACT_NONE
+    f32 = epi == "f32acc"
+    base = torch.randn(M, N, device=dev) if f32 else None
+
+    def run(mode):
+        ops.gemm_set_config(mode)
+        out = base.clone() if f32 else torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm_nt(a, b, out=out, bias=bias, residual=res, act=act, accumulate=f32)
+        return out
+    try:
+        ops.gemm_set_config(12)
+        plain = run(301)
+        split1 = run(300 + slices if slices else 300)
+        split2 = run(300 + slices if slices else 300)
+    finally:
+        ops.gemm_set_config(300)
+        ops.gemm_set_config(0)
+    assert torch.equal(split1, split2), "split-K tail is not reproducible"
+    assert bool(torch.isfinite(split1).all())
+    ref = a.float() @ b.float().t()
+    if bias is not None:
+        ref = ref + bias
+    if act == ops.ACT_GELU:
+        ref = F.gelu(ref)
+    if res is not None:
+        ref = ref + res.float()
+    if f32:
+        ref = ref + base
+    assert_close(split1, ref, atol=2e-2, rtol=2e-2, what="split-K vs fp32")
+    assert_close(split1, plain, atol=1e-3 if f32 else 1e-6, rtol=2 ** -7, what="split-K vs unsplit")
+    if not f32:
+        assert float((split1 != plain).float().mean()) < 0.02
+    if slices == 0:   # the auto plan must actually have split this shape: 272 tiles leave 16 for the last round
+        assert (M, N) == (4352, 4096)
+
+
+def test_gemm_swiglu_forward_with_split_k_tail(dev):
+    """the fused SwiGLU-forward epilogue behind the split-K fix-up (the last arriver of a tile runs it on the summed slabs)"""
+    ops = _ops()
+    M, F_, K = 1100, 1024, 4096          # 5 x 8 = 40 tiles, thin? no: 1100 = 4 x 256 + 76
+    x, w = rnd((M, K), dev, seed=71), rnd((2 * F_, K), dev, seed=72, std=K ** -0.5)
+    wil = ops.interleave_gate_up(w)
+    outs = []
+    try:
+        ops.gemm_set_config(12)
+        for mode in (301, 304):
+            ops.gemm_set_config(mode)
+            gu = torch.full((M, 2 * F_), float("nan"), dtype=torch.bfloat16, device=dev)
+            h = torch.full((M, F_), float("nan"), dtype=torch.bfloat16, device=dev)
+            ops.gemm_swiglu(x, wil, gu, h)
+            outs.append((gu, h))
+    finally:
+        ops.gemm_set_config(300)
+        ops.gemm_set_config(0)
+    assert_close(outs[1][0], outs[0][0], atol=1e-6, rtol=2 ** -7, what="stash, split vs unsplit")
+    assert_close(outs[1][1], outs[0][1], atol=1e-3, rtol=2 ** -6, what="h, split vs unsplit")
+    g, u = x.float() @ w[:F_].float().t(), x.float() @ w[F_:].float().t()
+    assert_close(outs[1][1], F.silu(g) * u, atol=2e-2, rtol=3e-2, what="h vs fp32")
+
+
 def test_gemm_rejects_bad_shapes(dev):
     ops = _ops()
     from slam_llm_amd.lib import SlamHipError
