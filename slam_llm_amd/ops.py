@@ -154,6 +154,11 @@ if os.environ.get("SLAM_GEMM_BIG_SHORTK"):
     _GEMM_BIG["shortk"] = int(os.environ["SLAM_GEMM_BIG_SHORTK"])
 
 
+if os.environ.get("SLAM_GEMM_SPLITK"):       # sweeps: off | auto | <slices>
+    _sk = os.environ["SLAM_GEMM_SPLITK"]
+    call("slam_gemm_set_config", 301 if _sk == "off" else (300 if _sk == "auto" else 300 + int(_sk)))
+
+
 def gemm_kernel_name(M: int, N: int, K: int = 1 << 30) -> str:
     """which template instance slam_gemm_bf16_nt's auto rule launches for this shape (mirrors gemm_bf16.hip)"""
     cfg = _GEMM_CFG
