@@ -36,6 +36,8 @@ constexpr int SK_MAX_TILES = (int)(SK_CNT_BYTES / 4);
 std::atomic<void*> g_gemm_ws{nullptr};
 std::atomic<int64_t> g_gemm_ws_bytes{0};
 std::atomic<int> g_gemm_splitk{0};   // -1 off, 0 auto, >= 2 forced number of K slices (tools / tests)
+std::atomic<int> g_gemm_splitk_rmax{32};   // auto plan: split only when the last round holds <= rmax tiles ...
+std::atomic<int> g_gemm_splitk_smax{2};    // ... into at most smax slices (slam_gemm_set_config 320 + rmax / 8, 340 + smax: sweeps)
 
 struct GemmParams {
   const bf16_t* A;
@@ -942,6 +944,10 @@ template <int OFF>
 __device__ __forceinline__ void w4_lds_write(unsigned addr, const bf16x8_t& v) {
   asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
+// 16-byte store that is written through to memory (system-coherent: visible to every XCD once vmcnt drains), no fence needed
+__device__ __forceinline__ void st_writethrough16(float* dst, const f32x4_t& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void w4_vmwait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -1212,20 +1218,17 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          *reinterpret_cast<f32x4_t*>(slab + ((size_t)((quad * 16 + i * 4 + j) * 256 + tid) << 2)) = a[i][j];
+          st_writethrough16(slab + ((size_t)((quad * 16 + i * 4 + j) * 256 + tid) << 2), a[i][j]);
     };
     put(acc00, 0); put(acc01, 1); put(acc10, 2); put(acc11, 3);
-    // producer side of the hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): every wave drains its stores, workgroup
-    // barrier, ONE lane writes the XCD's L2 back (agent-scope release), asm vmcnt(0) (the compiler may drop the one the fence
-    // implies), then the relaxed agent-scope ticket
+    // producer side of the hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, "publish-large"): 256 KiB per workgroup leave
+    // in WRITE-THROUGH 16-byte stores (sc0 sc1) -- the first form used plain stores + an agent-scope release (buffer_wbl2: the
+    // whole XCD L2 written back by each of its 32 workgroups) and cost ~150 us per launch; every wave drains its stores (asm
+    // vmcnt(0)), workgroup barrier, then the relaxed agent-scope ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned* flag = reinterpret_cast<unsigned*>(smem);   // (the k-loop is over: LDS is free)
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      *flag = __hip_atomic_fetch_add(p.sk_cnt + sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid == 0) *flag = __hip_atomic_fetch_add(p.sk_cnt + sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const unsigned ticket = *reinterpret_cast<volatile unsigned*>(flag);
     if (ticket != (unsigned)(p.sk_S - 1)) return;
@@ -1300,11 +1303,12 @@ int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
     const int R = (int)(nwg % n_cu);
     int S = 1;
     if (mode >= 2) S = mode;
-    else if (R > 0 && R <= n_cu / 2 && nwg >= n_cu) {
-      // auto: only a genuinely short last round (<= half the CUs), slices of >= 8 k-tiles, at most 8 slabs to add up.  Measured
-      // on MI355X (profiles/r03_gemm_splitk.md) the tail then costs ~1/S of a tile plus ~15 us instead of a whole tile time.
+    else if (R > 0 && R <= g_gemm_splitk_rmax && nwg >= n_cu) {
+      // auto: only a genuinely short last round (R <= rmax tiles), slices of >= 8 k-tiles, at most smax slabs to add up.  The
+      // thresholds come from profiles/r03_gemm_splitk.md (tools/gemm_splitk_sweep.py on MI355X): the hand-off (slab stores,
+      // ticket, fix-up reads) has a fixed price that only a nearly empty last round pays back.
       S = n_cu / R;
-      if (S > 8) S = 8;
+      if (S > g_gemm_splitk_smax) S = g_gemm_splitk_smax;
       if (S > nt / 8) S = nt / 8;
     }
     const int Rt = (mode >= 2) ? (int)(nwg < n_cu ? nwg : (R ? R : n_cu)) : R;   // forced: also under-filled / exact grids
@@ -1431,6 +1435,8 @@ extern "C" int slam_gemm_set_workspace(void* workspace, int64_t bytes) {
 }
 
 extern "C" int slam_gemm_set_config(int cfg) {
+  if (cfg >= 320 && cfg <= 336) { g_gemm_splitk_rmax = (cfg - 320) * 8; return 0; }   // auto plan: tail tiles <= 8 * (cfg - 320)
+  if (cfg >= 340 && cfg <= 348) { g_gemm_splitk_smax = cfg - 340; return 0; }         // auto plan: at most cfg - 340 slices
   if (cfg >= 300 && cfg <= 316) {   // split-K tail of the 4-wave kernel: 300 = auto, 301 = off, 302..316 = forced slice count (tools / tests)
     g_gemm_splitk = (cfg == 300) ? 0 : (cfg == 301 ? -1 : cfg - 300);
     return 0;

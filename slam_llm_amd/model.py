@@ -1000,6 +1000,9 @@ class HipProjectorCov1d(nn.Module):
         store.reserve(prefix + "linear2.weight", (self.dl, self.hid))
         store.reserve(prefix + "linear2.bias", (self.dl,))
         self.conv1d, self.linear1, self.linear2 = nn.Module(), nn.Module(), nn.Module()
+        self.need_dx = False   # True when the encoder is trainable: backward_hip then returns dL/d(encoder output)
+
+    _unstack = HipProjectorConcat._unstack
 
     def bind(self):
         s, p = self.store, self.prefix
@@ -1013,6 +1016,7 @@ class HipProjectorCov1d(nn.Module):
         self.wc = s.bf16_view(p + "conv1d.weight").permute(0, 2, 1).reshape(d, k * d).contiguous()
         self.w1T = ops.transpose(s.bf16_view(p + "linear1.weight"), Rp=self.hid)  # [d, hid]
         self.w2T = ops.transpose(s.bf16_view(p + "linear2.weight"), Rp=self.dl)   # [hid, dl]
+        self.wcT = ops.transpose(self.wc, Rp=d) if self.need_dx else None          # [k*d, d]: dL/d(k-frame stack) = dc . Wc
 
     def forward_hip(self, enc: torch.Tensor, stash: Optional[dict]):
         """enc [B, T2, d] bf16 -> [B, T2 // k, dl] bf16"""
@@ -1058,6 +1062,10 @@ class HipProjectorCov1d(nn.Module):
         else:
             g.copy_(dwc)
         ops.colsum(dc, s.grad_view(p + "conv1d.bias"), accumulate=accumulate)
+        if self.need_dx:
+            return self._unstack(ops.gemm_nt(dc, self.wcT), stash)
+        stash.pop("proj_shape", None)
+        return None
 
     def forward(self, x):
         return self.forward_hip(x, None)
@@ -1470,9 +1478,9 @@ class SlamHipModel(nn.Module):
         self.projector_name = cfg.get("projector", "linear")
         # train_config.freeze_encoder=false (models/slam_model.py:110-113): the encoder's parameters join the trainable store
         self.train_encoder = not bool(cfg.get("freeze_encoder", True))
-        if self.train_encoder and (self.encoder_name != "whisper" or self.projector_name != "linear" or cfg.get("varlen_encoder", False)):
-            raise NotImplementedError("freeze_encoder=false is implemented for the Whisper encoder with the linear projector on padded "
-                                      "batches (hand-written encoder backward); HuBERT / q-former / cov1d-linear / varlen_encoder are not")
+        if self.train_encoder and (self.encoder_name != "whisper" or cfg.get("varlen_encoder", False)):
+            raise NotImplementedError("freeze_encoder=false is implemented for the Whisper encoder (hand-written encoder backward) with the "
+                                      "linear / cov1d-linear / q-former projectors on padded batches; HuBERT / WavLM / varlen_encoder are not")
         if self.encoder_name in ("hubert", "wavlm"):
             self.encoder = (HipHubertEncoder if self.encoder_name == "hubert" else HipWavLMEncoder)(cfg, self.device_)
             cfg["enc_dim"] = cfg["hub_dim"]

@@ -66,6 +66,7 @@ class HipProjectorQFormer(nn.Module):
         r(p + "linear.weight", (self.dl, d)); r(p + "linear.bias", (self.dl,))
         r(p + "norm.weight", (self.dl,)); r(p + "norm.bias", (self.dl,))
         self.wT = {}
+        self.need_dx = False   # True when the encoder is trainable: backward_hip then returns dL/d(encoder output)
 
     # ---- plumbing --------------------------------------------------------------------------------------
     def bind(self):
@@ -87,8 +88,13 @@ class HipProjectorQFormer(nn.Module):
         for name, (off, n, shape) in st.offsets.items():
             if not name.startswith(self.prefix) or not name.endswith(".weight") or len(shape) != 2:
                 continue
-            if "crossattention.attention.key" in name or "crossattention.attention.value" in name:
-                continue  # d(encoder states) is never needed: the encoder is frozen
+            if "crossattention.attention.key" in name:
+                if self.need_dx:   # trainable encoder: dL/d(encoder states) = d[k | v] . [Wk ; Wv] (fused, reserved back to back)
+                    w = self._fused(name, 2 * d, self.d_enc)
+                    self.wT[name.replace("key.weight", "kv")] = ops.transpose(w, Rp=2 * d)
+                continue
+            if "crossattention.attention.value" in name:
+                continue  # covered by the fused k|v transpose above (frozen encoder: d(encoder states) is never needed)
             if ".attention.attention.key" in name or ".attention.attention.value" in name:
                 continue  # covered by the fused q|k|v transpose below
             if ".attention.attention.query" in name:
@@ -216,6 +222,7 @@ class HipProjectorQFormer(nn.Module):
 
         dy = ln_bwd(S["y"], S["mo"], S["ro"], p + "norm", dout)
         dh = self._lin_bwd(dy, S["h_last"], p + "linear.weight", p + "linear.bias", self.dl, d, acc, p + "linear.weight")
+        d_enc = None   # dL/d(encoder states) [B*Tk, d_enc], only with a trainable encoder (need_dx)
         for l in reversed(range(self.L)):
             R = S["layers"][l]
             Lp = f"{P}encoder.layer.{l}."
@@ -240,7 +247,10 @@ class HipProjectorQFormer(nn.Module):
                              dkvc[:, :d], dkvc[:, d:], B, Q, H, H, 64, False, scale, key_mask=km, Tk=Tk, drop=X["ad"])
                 dh1 = self._lin_bwd(dqc, R["h1"], C + "attention.query.weight", C + "attention.query.bias", d, d, acc,
                                     C + "attention.query.weight")
-                self._lin_bwd(dkvc, enc2d, C + "attention.key.weight", C + "attention.key.bias", 2 * d, self.d_enc, acc, None)
+                dx_enc = self._lin_bwd(dkvc, enc2d, C + "attention.key.weight", C + "attention.key.bias", 2 * d, self.d_enc, acc,
+                                       (C + "attention.kv") if self.need_dx else None)
+                if dx_enc is not None:   # every cross-attention layer reads the same encoder states: their gradients add up
+                    d_enc = dx_enc if d_enc is None else self._add(d_enc, dx_enc)
                 dh1 = self._add(dh1, ds2)
             else:
                 dh1 = dhx
@@ -263,6 +273,7 @@ class HipProjectorQFormer(nn.Module):
         dsum_bf = ops.cast_bf16(dsum).view(Q, d)
         dq0 = ln_bwd(S["q0"], S["m0"], S["r0"], P + "layernorm", dsum_bf)
         ops.cast_f32_(dq0, gv(p + "query"), accumulate=acc)
+        return d_enc
 
     @staticmethod
     def _add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -220,10 +220,15 @@ def test_gemm_split_k_tail(dev, M, N, K, slices, epi):
         return out
     try:
         ops.gemm_set_config(12)
+        if slices == 0:   # the shipped auto plan is conservative (tail <= 32 tiles, 2 slices); exercise the general planner too
+            ops.gemm_set_config(320 + 16)   # tails up to 128 tiles
+            ops.gemm_set_config(340 + 8)    # up to 8 slices
         plain = run(301)
         split1 = run(300 + slices if slices else 300)
         split2 = run(300 + slices if slices else 300)
     finally:
+        ops.gemm_set_config(320 + 4)
+        ops.gemm_set_config(340 + 2)
         ops.gemm_set_config(300)
         ops.gemm_set_config(0)
     assert torch.equal(split1, split2), "split-K tail is not reproducible"

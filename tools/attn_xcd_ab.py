@@ -64,9 +64,19 @@ def whisper():
 
 
 def main():
+    only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "--only" else None
+    if only:   # (before ANY attention launch, the set-up ones included: the PMC pass averages over every launch of a kernel)
+        call("slam_attn_set_fwd_qf", 20 if only == "hw" else 21)
     fns = {}
     fns.update(whisper())
     fns.update(llama())
+    if only:   # one order only, 3 launches each: the run profiled with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        for fn in fns.values():
+            for _ in range(3):
+                fn()
+        torch.cuda.synchronize()
+        call("slam_attn_set_fwd_qf", 21)
+        return
     res = {k: {"hw_order_us": [], "xcd_order_us": []} for k in fns}
     for name, fn in fns.items():
         for knob in (20, 21):
