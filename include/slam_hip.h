@@ -181,6 +181,18 @@ int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
                   int causal, float scale, const float* rope_cos, const float* rope_sin, const int32_t* rope_pos,
                   const int32_t* seg_lo, const int32_t* seg_hi, float drop_p, uint64_t drop_seed, void* stream);
 
+/* ---- a11: grouped positional convolution of HuBERT / WavLM as one implicit-GEMM launch ------------------------------------
+ * fairseq `pos_conv` (Conv1d(d, d, k = taps, padding = taps / 2, groups) + SamePad + GELU) and the residual add around it
+ * (src/slam_llm/models/wavlm/WavLM.py:378-386, 575-580; the same graph in fairseq's HuBERT, models/slam_model.py:335-341):
+ *   x[b, t, g*C + co] = h[b, t, g*C + co] + gelu(bias[g*C + co] + sum_j sum_ci W[g*C + co, ci, j] * h[b, t + j - taps/2, g*C + ci])
+ * h, x: [B*T, ld] bf16 (x != h); w_packed: [groups][taps][C (co)][C padded to a multiple of 32 (ci, zero padded)] bf16 -- the
+ * weight-normed conv weight re-packed tap-major; bias [groups*C] f32.  C = channels per group in {32, 48, 64}
+ * (slam_pos_conv_supported: d = 512 / 768 / 1024 with 16 groups), taps <= 256.  No im2col buffer exists: the taps are LDS row
+ * offsets into one input window per workgroup. */
+int slam_pos_conv_supported(int64_t channels_per_group, int64_t taps);
+int slam_pos_conv_fwd(const void* h, int64_t ldh, const void* w_packed, const float* bias, void* x, int64_t ldx, int64_t B,
+                      int64_t T, int64_t groups, int64_t channels_per_group, int64_t taps, void* stream);
+
 /* ---- SwiGLU (LlamaMLP) : gate_up [M, 2F] = [gate | up] ---------------------------------------------- */
 int slam_swiglu_fwd(const void* gate_up, int64_t ldgu, void* h, int64_t ldh, int64_t M, int64_t F,
                     void* stream);

@@ -57,6 +57,23 @@ __device__ __forceinline__ float sigmoid_fast(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 
+// exact-erf GELU.  erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16 output rounding):
+// one v_exp + one v_rcp + a 5-term Horner instead of libm's branchy erff in the epilogue of every fc1 tile.
+// (v_exp_f32 directly: the argument is <= 0 and an underflow to 0 is the right answer, so __expf's range fix-up -- a compare, a
+// select and two multiplies per element -- is dead weight; 128 elements per thread and tile go through this)
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float ex = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // exp(-z^2) = 2^(-x^2 / 2 * log2(e))
+  const float e = fmaf(-poly * t, ex, 1.0f);                                  // erf(|x| / sqrt2)
+  const float hx = 0.5f * x;
+  return fmaf(hx, copysignf(e, x), hx);
+}
+
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -77,23 +77,6 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t srd, unsigned voff
   __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)l, 16, (int)voff, 0, 0, 0);
 }
 
-// exact-erf GELU.  erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16 output rounding):
-// one v_exp + one v_rcp + a 5-term Horner instead of libm's branchy erff in the epilogue of every fc1 tile.
-// (v_exp_f32 directly: the argument is <= 0 and an underflow to 0 is the right answer, so __expf's range fix-up -- a compare, a
-// select and two multiplies per element -- is dead weight; 128 elements per thread and tile go through this)
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float ex = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // exp(-z^2) = 2^(-x^2 / 2 * log2(e))
-  const float e = fmaf(-poly * t, ex, 1.0f);                                  // erf(|x| / sqrt2)
-  const float hx = 0.5f * x;
-  return fmaf(hx, copysignf(e, x), hx);
-}
-
 // swap the odd 16-lane rows of `a` with the even rows of `b` (gfx950).  Inline asm: this hipcc folds the builtin's second result
 // into its first, and the two operands must be different registers.
 __device__ __forceinline__ void swap_rows16(unsigned& a, unsigned& b) {
@@ -944,10 +927,6 @@ template <int OFF>
 __device__ __forceinline__ void w4_lds_write(unsigned addr, const bf16x8_t& v) {
   asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
-// 16-byte store that is written through to memory (system-coherent: visible to every XCD once vmcnt drains), no fence needed
-__device__ __forceinline__ void st_writethrough16(float* dst, const f32x4_t& v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
-}
 template <int N>
 __device__ __forceinline__ void w4_vmwait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -956,7 +935,9 @@ __device__ __forceinline__ void w4_vmwait() {
 // REG = false: operand tiles by LDS-DMA (one instruction per KiB, but 60-180 issue cycles each, which a lone wave per SIMD
 // cannot hide).  REG = true: global -> registers (buffer_load_dwordx4, issued in phase A of tile t for tile t+2) -> ds_write_b128
 // in phase B, after the barrier that releases the stage: two cheap instructions per KiB and 64 staging VGPRs.
-template <int BM, int BN, bool REG, int ABL = 0, bool PROBE = false>   // ABL (tools, wrong results): 1 no operand traffic in the loop, 2 no fragment reads, 3 neither; PROBE (tools): workgroup 0 stamps g_clk_probe
+// SK: the instantiation that carries the split-K tail (launched only when a split plan is active: the plain instantiation stays
+// byte-for-byte the kernel the headline number is quoted on -- the tail code costs it registers and a few spilled loop invariants)
+template <int BM, int BN, bool REG, int ABL = 0, bool PROBE = false, bool SK = false>   // ABL (tools, wrong results): 1 no operand traffic in the loop, 2 no fragment reads, 3 neither; PROBE (tools): workgroup 0 stamps g_clk_probe
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned bytes_a, unsigned bytes_b) {
   if (PROBE && blockIdx.x == 0 && threadIdx.x == 0) {
     g_clk_probe[0] = __builtin_readcyclecounter();
@@ -986,7 +967,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
   {
     const int q = nwg >> 3, r = nwg & 7;
     int xcd = bid & 7, idx = bid >> 3;
-    if (p.sk_S > 1 && bid >= p.sk_main) {
+    if (SK && p.sk_S > 1 && bid >= p.sk_main) {
       const int w = bid - p.sk_main;
       sk_tile = w % p.sk_R;             // consecutive workgroups: different tiles, the same K slice
       sk_split = w / p.sk_R;
@@ -1005,7 +986,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
   const int tm = first_m + within % gsz;
   const int tn = within / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
-  if (sk_tile >= 0 && p.M - m0 <= 16) {   // a thin tile among the tail tiles is not split: slice 0 computes all of it below
+  if (SK && sk_tile >= 0 && p.M - m0 <= 16) {   // a thin tile among the tail tiles is not split: slice 0 computes all of it below
     if (sk_split > 0) return;
     sk_tile = -1;
   }
@@ -1088,8 +1069,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
   const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, bytes_b, 0x00020000);
   // this workgroup's k-tiles: all of them, or slice sk_split of sk_S (the slice start is folded into the per-lane offsets)
   const int nt_all = p.K / BK;
-  const int kt0 = sk_tile >= 0 ? (int)((int64_t)sk_split * nt_all / p.sk_S) : 0;
-  const int kt1 = sk_tile >= 0 ? (int)((int64_t)(sk_split + 1) * nt_all / p.sk_S) : nt_all;
+  const int kt0 = (SK && sk_tile >= 0) ? (int)((int64_t)sk_split * nt_all / p.sk_S) : 0;
+  const int kt1 = (SK && sk_tile >= 0) ? (int)((int64_t)(sk_split + 1) * nt_all / p.sk_S) : nt_all;
   unsigned a_vo[NIA], b_vo[NIB];
 #pragma unroll
   for (int j = 0; j < NIA; j++) a_vo[j] = (unsigned)(((int64_t)min(m0 + (j * 4 + wave) * 8 + srow, p.M - 1) * p.lda + schunk * 8 + (int64_t)kt0 * BK) * 2);
@@ -1209,7 +1190,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
     g_clk_probe[2] = __builtin_readcyclecounter();
     g_clk_probe[3] = wall_clock64();
   }
-  if (sk_tile >= 0) {
+  if (SK && sk_tile >= 0) {
     // ---- split-K tail: publish this slice's partial sums, take a ticket; only the last arriver goes on to the epilogue ----
     // slab layout: float4 number ((quadrant * 16 + i * 4 + j) * 256 + tid): every wave store / load is one contiguous KiB
     float* slab = p.sk_ws + ((size_t)sk_tile * p.sk_S + sk_split) * (size_t)(BM * BN);
@@ -1218,17 +1199,22 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          st_writethrough16(slab + ((size_t)((quad * 16 + i * 4 + j) * 256 + tid) << 2), a[i][j]);
+          *reinterpret_cast<f32x4_t*>(slab + ((size_t)((quad * 16 + i * 4 + j) * 256 + tid) << 2)) = a[i][j];
     };
     put(acc00, 0); put(acc01, 1); put(acc10, 2); put(acc11, 3);
-    // producer side of the hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, "publish-large"): 256 KiB per workgroup leave
-    // in WRITE-THROUGH 16-byte stores (sc0 sc1) -- the first form used plain stores + an agent-scope release (buffer_wbl2: the
-    // whole XCD L2 written back by each of its 32 workgroups) and cost ~150 us per launch; every wave drains its stores (asm
-    // vmcnt(0)), workgroup barrier, then the relaxed agent-scope ticket
+    // producer side of the hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): every wave drains its stores, workgroup
+    // barrier, ONE lane writes the XCD's L2 back (agent-scope release), asm vmcnt(0) (the compiler may drop the one the fence
+    // implies), then the relaxed agent-scope ticket.  (Write-through `sc0 sc1` slab stores without the release were tried and
+    // measured 2-4 % faster per launch, but the consumer's plain loads then read stale slabs in ~6 % of the elements -- removed;
+    // profiles/r03_gemm_splitk.md.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned* flag = reinterpret_cast<unsigned*>(smem);   // (the k-loop is over: LDS is free)
-    if (tid == 0) *flag = __hip_atomic_fetch_add(p.sk_cnt + sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *flag = __hip_atomic_fetch_add(p.sk_cnt + sk_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const unsigned ticket = *reinterpret_cast<volatile unsigned*>(flag);
     if (ticket != (unsigned)(p.sk_S - 1)) return;
@@ -1241,18 +1227,21 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
     // fixed summation order s = 0 .. S-1 (this workgroup's own slab is re-read like the others: the result does not depend on
     // which slice happened to arrive last)
     const float* slab0 = p.sk_ws + (size_t)sk_tile * p.sk_S * (size_t)(BM * BN);
-    auto get = [&](f32x4_t (&a)[4][4], int quad) {
+    // slab-major: the 64 loads a lane issues per slab are independent of each other (the first form walked the slabs per fragment
+    // and paid one exposed round trip per slab and fragment: ~8 us per slab)
+    auto get = [&](f32x4_t (&a)[4][4], int quad, const float* sp, bool first) {
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float* src = slab0 + ((size_t)((quad * 16 + i * 4 + j) * 256 + tid) << 2);
-          f32x4_t v = *reinterpret_cast<const f32x4_t*>(src);
-          for (int sl = 1; sl < p.sk_S; sl++) v += *reinterpret_cast<const f32x4_t*>(src + (size_t)sl * (BM * BN));
-          a[i][j] = v;
+          const f32x4_t v = *reinterpret_cast<const f32x4_t*>(sp + ((size_t)((quad * 16 + i * 4 + j) * 256 + tid) << 2));
+          a[i][j] = first ? v : a[i][j] + v;
         }
     };
-    get(acc00, 0); get(acc01, 1); get(acc10, 2); get(acc11, 3);
+    for (int sl = 0; sl < p.sk_S; sl++) {
+      const float* sp = slab0 + (size_t)sl * (BM * BN);
+      get(acc00, 0, sp, sl == 0); get(acc01, 1, sp, sl == 0); get(acc10, 2, sp, sl == 0); get(acc11, 3, sp, sl == 0);
+    }
   }
   if (p.act == 4) {   // fused SwiGLU forward: the left / right quadrants of the wave tile are gate / up of the same 64 columns
     const int nb = n0 + wn * WTN, mb = m0 + wm * WTM;
@@ -1274,13 +1263,11 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
   if (PROBE && blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[5] = __builtin_readcyclecounter();
 }
 
-template <int BM, int BN, bool REG, int ABL = 0, bool PROBE = false>
-int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + BN - 1) / BN;
+template <int BM, int BN, bool REG, int ABL, bool PROBE, bool SK>
+int launch_gemm_w4_impl(GemmParams& p, int64_t nwg, hipStream_t stream) {
   constexpr int lds = 2 * (BM + BN) * ROWB;
   static std::atomic<bool> attr_set{false};   // (setting the attribute twice from two threads is harmless; the flag only saves the call)
-  auto kern = gemm_nt_w4_kernel<BM, BN, REG, ABL, PROBE>;
+  auto kern = gemm_nt_w4_kernel<BM, BN, REG, ABL, PROBE, SK>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
@@ -1291,13 +1278,22 @@ int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
   }
   const uint64_t bytes_a = ((uint64_t)(p.M - 1) * (uint64_t)p.lda + (uint64_t)p.K) * 2ull;
   const uint64_t bytes_b = ((uint64_t)(p.N - 1) * (uint64_t)p.ldb + (uint64_t)p.K) * 2ull;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p, (unsigned)bytes_a, (unsigned)bytes_b);
+  SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(4-wave, hand-ordered k-loop)");
+  return 0;
+}
+
+template <int BM, int BN, bool REG, int ABL = 0, bool PROBE = false>
+int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
   int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   // ---- split-K tail plan (see the kernel): R = tiles of the last, partial round; S slices each so that R * S <= one round ----
   p.sk_main = 0; p.sk_R = 0; p.sk_S = 1; p.sk_ws = nullptr; p.sk_cnt = nullptr;
   const int mode = g_gemm_splitk;   // -1 off, 0 auto, >= 2 forced slice count (tools / tests)
   char* ws = (char*)g_gemm_ws.load();
   const int64_t ws_bytes = g_gemm_ws_bytes;
-  if (mode >= 0 && ws != nullptr && nwg < (1ll << 30)) {
+  if (!PROBE && ABL == 0 && mode >= 0 && ws != nullptr && nwg < (1ll << 30)) {
     const int n_cu = 256;
     const int nt = p.K / BK;
     const int R = (int)(nwg % n_cu);
@@ -1306,7 +1302,7 @@ int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
     else if (R > 0 && R <= g_gemm_splitk_rmax && nwg >= n_cu) {
       // auto: only a genuinely short last round (R <= rmax tiles), slices of >= 8 k-tiles, at most smax slabs to add up.  The
       // thresholds come from profiles/r03_gemm_splitk.md (tools/gemm_splitk_sweep.py on MI355X): the hand-off (slab stores,
-      // ticket, fix-up reads) has a fixed price that only a nearly empty last round pays back.
+      // L2 write-back, ticket, fix-up reads: ~35 us) has a fixed price that only a nearly empty last round pays back.
       S = n_cu / R;
       if (S > g_gemm_splitk_smax) S = g_gemm_splitk_smax;
       if (S > nt / 8) S = nt / 8;
@@ -1320,9 +1316,10 @@ int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
       nwg = (int64_t)p.sk_main + (int64_t)Rt * S;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p, (unsigned)bytes_a, (unsigned)bytes_b);
-  SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(4-wave, hand-ordered k-loop)");
-  return 0;
+  if constexpr (!PROBE && ABL == 0) {
+    if (p.sk_S > 1) return launch_gemm_w4_impl<BM, BN, REG, ABL, false, true>(p, nwg, stream);
+  }
+  return launch_gemm_w4_impl<BM, BN, REG, ABL, PROBE, false>(p, nwg, stream);
 }
 
 // (A persistent form of this kernel -- one workgroup per CU, the branch-free tail fetching the NEXT output tile's first two

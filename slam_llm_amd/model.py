@@ -34,6 +34,8 @@ import os as _os
 # on the C3 step (A/B in one process: 444.2-446.4 ms fused vs 443.7-444.6 ms separate pass): with one 256x256 workgroup
 # per CU the exp-heavy epilogue is not overlapped with MFMA work.  Off unless SLAM_FUSED_SWIGLU_BWD=1.
 FUSE_SWIGLU_BWD = _os.environ.get("SLAM_FUSED_SWIGLU_BWD", "0") == "1"
+# HuBERT / WavLM positional conv as one implicit-GEMM launch (slam_pos_conv_fwd); SLAM_POS_CONV_FUSED=0: 16 x (im2col + GEMM)
+POS_CONV_FUSED = _os.environ.get("SLAM_POS_CONV_FUSED", "1") == "1"
 # SwiGLU forward inside the gate|up product's epilogue (slam_gemm_swiglu_bf16_nt): on unless SLAM_FUSED_SWIGLU_FWD=0
 FUSE_SWIGLU_FWD = _os.environ.get("SLAM_FUSED_SWIGLU_FWD", "1") == "1"
 LORA_PAD = 64  # K-extension granule (GEMM K-tile)
@@ -768,12 +770,19 @@ class HipHubertEncoder(nn.Module):
         G, kpos = cfg["hub_pos_groups"], cfg["hub_pos_k"]
         gch = d // G
         x = torch.empty((M, d), dtype=torch.bfloat16, device=wav.device)
-        cols = torch.empty((M, self.pos_kp), dtype=torch.bfloat16, device=wav.device)
-        for g in range(G):  # grouped conv: x[:, grp] = h[:, grp] + gelu(conv_g(h[:, grp]) + b_g)
-            ops.conv1d_im2col(h, B, T, g * gch, gch, kpos, 1, kpos // 2, Kp=self.pos_kp, Tout_limit=T, out=cols)
-            ops.gemm_nt(cols, w["pos"][g], out=x[:, g * gch:(g + 1) * gch], bias=w["pos_b"][g * gch:(g + 1) * gch],
-                        act=ACT_GELU, residual=h[:, g * gch:(g + 1) * gch])
-        del cols, h
+        if POS_CONV_FUSED and ops.pos_conv_supported(gch, kpos):
+            # ONE implicit-GEMM launch: the taps are row offsets into an LDS window, no im2col buffer (csrc/conv.hip)
+            if "pos_tap" not in w:
+                w["pos_tap"] = ops.pos_conv_pack(w["pos"], kpos)
+            ops.pos_conv_fwd(h, w["pos_tap"], w["pos_b"], B, T, out=x)
+        else:
+            cols = torch.empty((M, self.pos_kp), dtype=torch.bfloat16, device=wav.device)
+            for g in range(G):  # grouped conv: x[:, grp] = h[:, grp] + gelu(conv_g(h[:, grp]) + b_g)
+                ops.conv1d_im2col(h, B, T, g * gch, gch, kpos, 1, kpos // 2, Kp=self.pos_kp, Tout_limit=T, out=cols)
+                ops.gemm_nt(cols, w["pos"][g], out=x[:, g * gch:(g + 1) * gch], bias=w["pos_b"][g * gch:(g + 1) * gch],
+                            act=ACT_GELU, residual=h[:, g * gch:(g + 1) * gch])
+            del cols
+        del h
         scale = 64 ** -0.5
         hbuf = torch.empty((M, d), dtype=torch.bfloat16, device=wav.device)
         qkv = torch.empty((M, 3 * d), dtype=torch.bfloat16, device=wav.device)

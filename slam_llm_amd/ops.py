@@ -341,6 +341,31 @@ def conv1d_im2col(x2d, B, Tin, c0, C, k, stride, pad, Kp=None, Tout_limit=0, out
     return out, Tout
 
 
+def pos_conv_supported(channels_per_group: int, taps: int) -> bool:
+    return lib.raw().slam_pos_conv_supported(channels_per_group, taps) == 1
+
+
+def pos_conv_pack(w_im2col: torch.Tensor, taps: int) -> torch.Tensor:
+    """[G, C (co), >= taps*C] im2col-ordered weights (column j*C + ci) -> tap-major [G, taps, C (co), KP] with ci zero padded to a
+    multiple of 32 (the B operand of slam_pos_conv_fwd)"""
+    G, C, _ = w_im2col.shape
+    KP = round_up(C, 32)
+    out = torch.zeros((G, taps, C, KP), dtype=torch.bfloat16, device=w_im2col.device)
+    out[..., :C] = w_im2col[:, :, : taps * C].reshape(G, C, taps, C).permute(0, 2, 1, 3)
+    return out
+
+
+def pos_conv_fwd(h2d: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, B: int, T: int, out: Optional[torch.Tensor] = None):
+    """x = h + gelu(grouped_conv(h) + bias) over [B*T, d] rows (fairseq pos_conv + SamePad + GELU + residual), one launch"""
+    G, taps, C, _ = w_packed.shape
+    if out is None:
+        out = torch.empty((B * T, G * C), dtype=torch.bfloat16, device=h2d.device)
+    _timed("pos_conv", 2.0 * B * T * G * C * taps * C,
+           lambda: call("slam_pos_conv_fwd", _p(h2d), _ld(h2d), _p(w_packed), _p(bias), _p(out), _ld(out), B, T, G, C, taps, _s()),
+           nbytes=2.0 * (2 * B * T * G * C) + 2.0 * w_packed.numel())
+    return out
+
+
 def rmsnorm_fwd(x, weight, eps, out=None, rstd=None):
     M, d = x.shape
     if out is None:

@@ -283,6 +283,40 @@ def test_gemm_rejects_bad_shapes(dev):
         ops.gemm_nt(torch.zeros(8, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16))
 
 
+# ----------------------------------------------------------------------------------------- grouped positional conv
+@pytest.mark.parametrize("C,K,T", [(64, 128, 300), (48, 128, 517), (32, 16, 100), (64, 127, 256)])
+def test_pos_conv_one_launch_matches_torch_grouped_conv(dev, C, K, T):
+    """slam_pos_conv_fwd (implicit GEMM: taps = LDS row offsets) against torch's grouped Conv1d + SamePad + GELU + residual in fp32
+    (fairseq pos_conv, WavLM.py:378-386 / 575-580): channels per group 64 / 48 / 32 (d = 1024 / 768 / 512 with 16 groups), even and
+    odd tap counts, T across tile boundaries; |err| <= 2e-2 + 2e-2 |ref| (bf16 output).  Also against the round-2 path
+    (per-group im2col + GEMM), which must agree to bf16 rounding."""
+    ops = _ops()
+    B, G = 2, 4
+    d = G * C
+    h = rnd((B * T, d), dev, seed=81)
+    Wt = (torch.randn(d, C, K, generator=torch.Generator().manual_seed(82)) * (C * K) ** -0.5)
+    bias = torch.randn(d, generator=torch.Generator().manual_seed(83)) * 0.1
+    w_im2col = Wt.view(G, C, C, K).permute(0, 1, 3, 2).reshape(G, C, K * C).to(torch.bfloat16).to(dev)
+    assert ops.pos_conv_supported(C, K)
+    x = torch.full((B * T, d), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.pos_conv_fwd(h, ops.pos_conv_pack(w_im2col, K), bias.to(dev), B, T, out=x)
+    hf = h.float().cpu().view(B, T, d)
+    conv = F.conv1d(hf.transpose(1, 2), Wt.to(torch.bfloat16).float(), bias, padding=K // 2, groups=G)[..., :T]   # SamePad: drop the extra frame of even kernels
+    ref = hf + F.gelu(conv.transpose(1, 2))
+    assert_close(x.view(B, T, d), ref, atol=2e-2, rtol=2e-2, what="pos_conv vs torch")
+    # the round-2 path: per group im2col + GEMM with the GELU / residual epilogue
+    Kp = ops.round_up(K * C, 64)
+    wpad = torch.zeros((G, C, Kp), dtype=torch.bfloat16, device=dev)
+    wpad[:, :, : K * C] = w_im2col
+    x2 = torch.empty_like(x)
+    cols = torch.empty((B * T, Kp), dtype=torch.bfloat16, device=dev)
+    for g in range(G):
+        ops.conv1d_im2col(h, B, T, g * C, C, K, 1, K // 2, Kp=Kp, Tout_limit=T, out=cols)
+        ops.gemm_nt(cols, wpad[g], out=x2[:, g * C:(g + 1) * C], bias=bias.to(dev)[g * C:(g + 1) * C].contiguous(), act=ops.ACT_GELU,
+                    residual=h[:, g * C:(g + 1) * C])
+    assert_close(x, x2, atol=2e-2, rtol=2 ** -6, what="pos_conv vs im2col + GEMM")
+
+
 # ----------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("M,d", [(37, 64), (1000, 1280), (5, 4096)])
 def test_layernorm(dev, M, d):
