@@ -244,8 +244,10 @@ def traffic_for(kernel_name):
     if not os.path.exists(path):
         return None, None
     table = json.load(open(path))
-    for k, v in table.get("kernels", {}).items():
-        if k in kernel_name or kernel_name.startswith(k):
+    want = kernel_name.rstrip(">")
+    for k, v in table.get("kernels", {}).items():   # (the profiler prints every template argument, ops names the leading ones)
+        have = k.rstrip(">")
+        if have.startswith(want) or want.startswith(have):
             return v, table.get("source")
     return None, table.get("source")
 

@@ -70,7 +70,9 @@ int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, vo
  * sums go to fp32 slabs, the last arriver of a tile adds them in slice order (bit-reproducible) and runs the epilogue.  The slabs
  * live in a caller-owned device buffer (the library never allocates): `workspace` = 4096 bytes of ZEROED arrival counters followed
  * by up to 256 slabs of 256 KiB (64 MiB + 4 KiB serves every plan; smaller buffers shrink S).  No workspace = no split.  All
- * launches that may split must be ordered on one stream.  null / 0 detaches. */
+ * launches that may split must be ordered on one stream.  null / 0 detaches.  The plan is OFF by default
+ * (slam_gemm_set_config(300) = auto plan, 302..316 = forced slices): measured on MI355X the hand-off costs what the idle CUs of the
+ * last round would have saved (profiles/r03_gemm_splitk.md). */
 int slam_gemm_set_workspace(void* workspace, int64_t bytes);
 int slam_gemm_set_group_m(int group_m);   /* tuning knob: M-tiles per raster group of the 256x256 kernel (default 8) */
 int slam_gemm_set_config(int cfg);   /* also: 100+v / 200+v = the 256x256 kernel of the auto rule for K > 2048 / <= 2048; 300 / 301 / 302..316 = split-K tail auto / off / forced slices; 400 / 401 = cycle stamps off / on (tools) */

@@ -35,7 +35,10 @@ constexpr int64_t SK_CNT_BYTES = 4096;
 constexpr int SK_MAX_TILES = (int)(SK_CNT_BYTES / 4);
 std::atomic<void*> g_gemm_ws{nullptr};
 std::atomic<int64_t> g_gemm_ws_bytes{0};
-std::atomic<int> g_gemm_splitk{0};   // -1 off, 0 auto, >= 2 forced number of K slices (tools / tests)
+// -1 off (DEFAULT: on MI355X the hand-off -- slab stores, L2 write-back, ticket, fix-up reads, ~35 us -- costs as much as the idle
+// part of the last round saves on every product of the C3 / C2 / C4 steps, profiles/r03_gemm_splitk.md), 0 auto plan, >= 2 forced
+// number of K slices (tools / tests)
+std::atomic<int> g_gemm_splitk{-1};
 std::atomic<int> g_gemm_splitk_rmax{32};   // auto plan: split only when the last round holds <= rmax tiles ...
 std::atomic<int> g_gemm_splitk_smax{2};    // ... into at most smax slices (slam_gemm_set_config 320 + rmax / 8, 340 + smax: sweeps)
 

@@ -229,7 +229,7 @@ def test_gemm_split_k_tail(dev, M, N, K, slices, epi):
     finally:
         ops.gemm_set_config(320 + 4)
         ops.gemm_set_config(340 + 2)
-        ops.gemm_set_config(300)
+        ops.gemm_set_config(301)    # shipped default: split-K tail off
         ops.gemm_set_config(0)
     assert torch.equal(split1, split2), "split-K tail is not reproducible"
     assert bool(torch.isfinite(split1).all())
@@ -266,7 +266,7 @@ def test_gemm_swiglu_forward_with_split_k_tail(dev):
             ops.gemm_swiglu(x, wil, gu, h)
             outs.append((gu, h))
     finally:
-        ops.gemm_set_config(300)
+        ops.gemm_set_config(301)
         ops.gemm_set_config(0)
     assert_close(outs[1][0], outs[0][0], atol=1e-6, rtol=2 ** -7, what="stash, split vs unsplit")
     assert_close(outs[1][1], outs[0][1], atol=1e-3, rtol=2 ** -6, what="h, split vs unsplit")

@@ -58,7 +58,7 @@ def main():
                 for k, (cfg, sk) in modes.items():
                     res[k].append(run(cfg, sk))
         finally:
-            ops.gemm_set_config(300)
+            ops.gemm_set_config(301)
             ops.gemm_set_config(0)
         med = {k: round(statistics.median(v), 1) for k, v in res.items()}
         best = min(med, key=med.get)
