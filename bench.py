@@ -369,7 +369,9 @@ def main():
                   f"audio-seconds/sec/node ({wl['title']}: not the headline workload)",
         "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic (seeded N(0,0.1^2) audio, random token ids, random-init weights at true dims)",
+        "dtype": "bf16", "data": "synthetic (seeded N(0,0.1^2) audio, random token ids, random-init weights at true dims); lora_dropout 0.05 is live with "
+                                  "counter-based masks, one per fused projection group: statistically, not bitwise, the reference's torch-RNG dropout "
+                                  "(parity tests run at dropout 0)",
         "config": {"workload": f"{wl['title']}{' with the encoder UNFROZEN (freeze_encoder=false)' if args.train_encoder else ''}: {enc_desc} (q_proj,v_proj, dropout 0.05), "
                                f"batch {n_clips} x {clip_s:g} s clips per GPU (T={T}, {n_clips * T} frames"
                                + (" <= 12000 dynamic-frame budget" if args.workload == "c3" else "") + "), "
