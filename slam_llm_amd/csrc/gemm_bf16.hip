@@ -39,7 +39,6 @@ std::atomic<int64_t> g_gemm_ws_bytes{0};
 // part of the last round saves on every product of the C3 / C2 / C4 steps, profiles/r03_gemm_splitk.md), 0 auto plan, >= 2 forced
 // number of K slices (tools / tests)
 std::atomic<int> g_gemm_splitk{-1};
-std::atomic<int> g_gemm_pro2{1};       // 4-wave kernel prologue: 1 = k-tiles 0 and 1 issued together (slam_gemm_set_config 500 / 501 = off / on)
 std::atomic<int> g_gemm_splitk_rmax{32};   // auto plan: split only when the last round holds <= rmax tiles ...
 std::atomic<int> g_gemm_splitk_smax{2};    // ... into at most smax slices (slam_gemm_set_config 320 + rmax / 8, 340 + smax: sweeps)
 
@@ -63,7 +62,6 @@ struct GemmParams {
   int group_m;   // M-tiles per raster group (L2 reuse of the B panel inside an XCD)
   // split-K tail of the 4-wave kernel (sk_S >= 2; see gemm_nt_w4_kernel): the first sk_main workgroups compute whole tiles, the
   // other sk_R * sk_S compute 1 / sk_S of the K range of one of the last sk_R tiles each
-  int pro2;            // 4-wave kernel: issue the first TWO k-tiles' DMA before the first wait (g_gemm_pro2)
   int sk_main, sk_R, sk_S;
   float* sk_ws;        // [sk_R * sk_S] fp32 slabs of 256 x 256 partial sums, lane-linear
   unsigned* sk_cnt;    // [sk_R] arrival counters, zero between launches
@@ -1118,19 +1116,13 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
   };
   bf16x8_t stg[NIA + NIB];   // REG: one K-tile share of this wave in flight from global memory
   const unsigned wr0 = lds0 + (unsigned)(wave * 1024 + lane * 16);   // REG: lane-linear image of a 1 KiB piece, like the DMA's
-  if (p.pro2 && nt > 1) {
-    // both stages are free at the start: k-tiles 0 AND 1 leave together, only tile 0 is waited for (LDS-DMA pieces retire in
-    // order: <= 16 outstanding = this wave's 16 pieces of tile 1) -- one exposed memory round trip per output tile instead of two
-    dma_tile(0, 0);
-    dma_tile(1, 1);
-    w4_vmwait<NIA + NIB>();
-    __builtin_amdgcn_s_barrier();
-  } else {
-    dma_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (nt > 1) dma_tile(1, 1);
-  }
+  // (issuing k-tiles 0 AND 1 before the first wait -- both stages are free at the start, `s_waitcnt vmcnt(16)` -- was measured:
+  // +0.5 % on four C3 shapes, -3 % on 11780 x 4096 x 4096, the step 392.4 / 393.2 vs 390.2 / 393.2 ms: neutral, not kept;
+  // profiles/r03_gemm_prologue_ab.jsonl)
+  dma_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (nt > 1) dma_tile(1, 1);
   gemm_static_for<0, FN>([&](auto j) { w4_lds_read<j * 16 * ROWB>(b0[j], fb[0][0]); });
   gemm_static_for<0, FM>([&](auto i) { w4_lds_read<i * 16 * ROWB>(a0[i], fa[0][0]); });
   if constexpr (REG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the loop's counted vmcnt waits assume only ITS loads are in flight)
@@ -1304,7 +1296,6 @@ int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
   int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   // ---- split-K tail plan (see the kernel): R = tiles of the last, partial round; S slices each so that R * S <= one round ----
   p.sk_main = 0; p.sk_R = 0; p.sk_S = 1; p.sk_ws = nullptr; p.sk_cnt = nullptr;
-  p.pro2 = g_gemm_pro2;
   const int mode = g_gemm_splitk;   // -1 off, 0 auto, >= 2 forced slice count (tools / tests)
   char* ws = (char*)g_gemm_ws.load();
   const int64_t ws_bytes = g_gemm_ws_bytes;
@@ -1454,7 +1445,6 @@ extern "C" int slam_gemm_set_config(int cfg) {
     return 0;
   }
   // 100 + v / 200 + v (v in 6, 7, 12): the 256x256 kernel the AUTO rule picks for K > 2048 / K <= 2048 (tools/step sweeps)
-  if (cfg == 500 || cfg == 501) { g_gemm_pro2 = cfg - 500; return 0; }     // tools: 4-wave prologue, one / two k-tiles in flight before the first wait
   if (cfg == 400 || cfg == 401) { g_gemm_probe = cfg - 400; return 0; }   // tools: cycle stamps of workgroup 0 (slam_gemm_debug_clock)
   if (cfg == 106 || cfg == 107 || cfg == 112) { g_gemm_big = cfg - 100; return 0; }
   if (cfg == 206 || cfg == 207 || cfg == 212) { g_gemm_big_shortk = cfg - 200; return 0; }

@@ -154,8 +154,6 @@ if os.environ.get("SLAM_GEMM_BIG_SHORTK"):
     _GEMM_BIG["shortk"] = int(os.environ["SLAM_GEMM_BIG_SHORTK"])
 
 
-if os.environ.get("SLAM_GEMM_PRO2"):         # sweeps: 0 | 1 (prologue of the 4-wave kernel: one / two k-tiles in flight before the first wait)
-    call("slam_gemm_set_config", 500 + int(os.environ["SLAM_GEMM_PRO2"]))
 if os.environ.get("SLAM_GEMM_SPLITK"):       # sweeps: off | auto | <slices>
     _sk = os.environ["SLAM_GEMM_SPLITK"]
     call("slam_gemm_set_config", 301 if _sk == "off" else (300 if _sk == "auto" else 300 + int(_sk)))
