@@ -190,10 +190,20 @@ int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
  * h, x: [B*T, ld] bf16 (x != h); w_packed: [groups][taps][C (co)][C padded to a multiple of 32 (ci, zero padded)] bf16 -- the
  * weight-normed conv weight re-packed tap-major; bias [groups*C] f32.  C = channels per group in {32, 48, 64}
  * (slam_pos_conv_supported: d = 512 / 768 / 1024 with 16 groups), taps <= 256.  No im2col buffer exists: the taps are LDS row
- * offsets into one input window per workgroup. */
+ * offsets into one input window per workgroup.
+ * General form (the training path): out = residual + act(conv(h) + bias) with `pad` rows of left zero padding (forward: taps / 2);
+ * bias nullable; act 1 = GELU, 0 = none; residual nullable = h itself (read from the input window); pre nullable: also receives
+ * conv(h) + bias before the activation (kept for the backward).  The ADJOINT dL/dh = dL/dx + conv^T(dL/dconv) is the same launch
+ * on dL/dconv with tap-reversed, channel-transposed weights, pad = taps - 1 - taps / 2, act 0, no bias, residual = dL/dx
+ * (unfrozen-encoder training, models/slam_model.py:110-113). */
 int slam_pos_conv_supported(int64_t channels_per_group, int64_t taps);
-int slam_pos_conv_fwd(const void* h, int64_t ldh, const void* w_packed, const float* bias, void* x, int64_t ldx, int64_t B,
-                      int64_t T, int64_t groups, int64_t channels_per_group, int64_t taps, void* stream);
+int slam_pos_conv_fwd(const void* h, int64_t ldh, const void* w_packed, const float* bias, void* x, int64_t ldx, void* pre,
+                      int64_t ldpre, const void* residual, int64_t ldr, int64_t B, int64_t T, int64_t groups,
+                      int64_t channels_per_group, int64_t taps, int64_t pad, int act, void* stream);
+/* adjoint of slam_conv1d_im2col without padding (kernel k, stride s): dx[b, t, c] = sum of dcols[b, o, j*C + c] over t = s*o + j;
+ * the conv feature extractor's dL/d(input) of the unfrozen HuBERT encoder (fairseq ConvFeatureExtractionModel backward). */
+int slam_conv1d_col2im(const void* dcols, int64_t ldc, void* dx, int64_t B, int64_t Tin, int64_t C, int64_t k, int64_t stride,
+                       void* stream);
 
 /* ---- SwiGLU (LlamaMLP) : gate_up [M, 2F] = [gate | up] ---------------------------------------------- */
 int slam_swiglu_fwd(const void* gate_up, int64_t ldgu, void* h, int64_t ldh, int64_t M, int64_t F,

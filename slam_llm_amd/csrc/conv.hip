@@ -22,10 +22,15 @@
 
 namespace {
 
+// Arguments beyond the forward's: `pad` = rows of left padding (taps / 2 for the forward; taps - 1 - taps / 2 for the ADJOINT, which is
+// the same kernel run on dL/d(conv output) with tap-reversed, channel-transposed weights: dL/dh[s] = sum_j W_j^T d[s - j + taps/2]);
+// `bias` nullable; `act` 1 = GELU, 0 = none; `res` nullable: the residual comes from this tensor instead of the window (the adjoint adds
+// the skip path's gradient); `pre` nullable: also write the pre-activation conv + bias (the training forward keeps it for the backward).
 template <int C>   // channels per group: 32 | 48 | 64
 __global__ __launch_bounds__(256, 2) void pos_conv_kernel(const bf16_t* __restrict__ h, int64_t ldh, const bf16_t* __restrict__ wpk,
-                                                          const float* __restrict__ bias, bf16_t* __restrict__ x, int64_t ldx, int B,
-                                                          int T, int K, int tiles_t) {
+                                                          const float* __restrict__ bias, bf16_t* __restrict__ x, int64_t ldx,
+                                                          bf16_t* __restrict__ pre, int64_t ldpre, const bf16_t* __restrict__ res,
+                                                          int64_t ldr, int B, int T, int K, int pad, int act, int tiles_t) {
   constexpr int KP = (C + 31) / 32 * 32;   // channels per tap as the MFMA sees them (zero padded)
   constexpr int KS = KP / 32;              // 32-deep k-steps per tap
   constexpr int NF = C / 16;               // 16-wide output-channel fragments
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void pos_conv_kernel(const bf16_t* __restri
   const int tt = bid % tiles_t;
   const int b = (bid / tiles_t) % B;
   const int g = bid / (tiles_t * B);
-  const int t0 = tt * BM, pad = K / 2;
+  const int t0 = tt * BM;
   const int rows = BM + K - 1;
 
   // ---- window: row r holds h[b, t0 - pad + r, g*C .. g*C + C) (zeros outside the clip and in the channel padding) ----
@@ -105,16 +110,23 @@ __global__ __launch_bounds__(256, 2) void pos_conv_kernel(const bf16_t* __restri
     const int tl = wave * 64 + i * 16 + frow;
     const int t = t0 + tl;
     if (t >= T) continue;
-    const char* rrow = win + (tl + pad) * RB;   // the window row of time step t: the residual h[b, t, g*C ..]
+    // residual: the window row of time step t (= h[b, t, g*C ..], forward) or the caller's tensor (adjoint: the skip gradient)
+    const bf16_t* rrow = res ? res + ((int64_t)b * T + t) * ldr + g * C : reinterpret_cast<const bf16_t*>(win + (tl + pad) * RB);
     bf16_t* xrow = x + ((int64_t)b * T + t) * ldx + g * C;
 #pragma unroll
     for (int n = 0; n < NF; n++) {
       const int co = n * 16 + fg * 4;
-      const float4 bv = *reinterpret_cast<const float4*>(bias + g * C + co);
-      const u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(rrow + co * 2);
+      const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + g * C + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const u16x4_t r4 = *reinterpret_cast<const u16x4_t*>(rrow + co);
       float v[4] = {acc[i][n][0] + bv.x, acc[i][n][1] + bv.y, acc[i][n][2] + bv.z, acc[i][n][3] + bv.w};
+      if (pre) {
+        uint2 pz;
+        pz.x = pack2bf(v[0], v[1]);
+        pz.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(pre + ((int64_t)b * T + t) * ldpre + g * C + co) = pz;
+      }
 #pragma unroll
-      for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]) + bf2f(r4[e]);
+      for (int e = 0; e < 4; e++) v[e] = (act ? gelu_erf(v[e]) : v[e]) + bf2f(r4[e]);
       uint2 o;
       o.x = pack2bf(v[0], v[1]);
       o.y = pack2bf(v[2], v[3]);
@@ -124,8 +136,8 @@ __global__ __launch_bounds__(256, 2) void pos_conv_kernel(const bf16_t* __restri
 }
 
 template <int C>
-int launch_pos_conv(const bf16_t* h, int64_t ldh, const bf16_t* wpk, const float* bias, bf16_t* x, int64_t ldx, int B, int T, int G,
-                    int K, hipStream_t s) {
+int launch_pos_conv(const bf16_t* h, int64_t ldh, const bf16_t* wpk, const float* bias, bf16_t* x, int64_t ldx, bf16_t* pre, int64_t ldpre,
+                    const bf16_t* res, int64_t ldr, int B, int T, int G, int K, int pad, int act, hipStream_t s) {
   constexpr int KP = (C + 31) / 32 * 32;
   const int lds = (256 + K - 1) * (KP * 2 + 16);
   auto kern = pos_conv_kernel<C>;
@@ -136,7 +148,8 @@ int launch_pos_conv(const bf16_t* h, int64_t ldh, const bf16_t* wpk, const float
     }
   }
   const int tiles_t = (T + 255) / 256;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_t * B * G)), dim3(256), lds, s, h, ldh, wpk, bias, x, ldx, B, T, K, tiles_t);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_t * B * G)), dim3(256), lds, s, h, ldh, wpk, bias, x, ldx, pre, ldpre, res, ldr, B, T, K, pad,
+                     act, tiles_t);
   SLAM_CHECK_LAUNCH("slam_pos_conv_fwd");
   return 0;
 }
@@ -147,23 +160,30 @@ extern "C" int slam_pos_conv_supported(int64_t channels_per_group, int64_t taps)
   return (channels_per_group == 32 || channels_per_group == 48 || channels_per_group == 64) && taps >= 1 && taps <= 256 ? 1 : 0;
 }
 
-extern "C" int slam_pos_conv_fwd(const void* h, int64_t ldh, const void* w_packed, const float* bias, void* x, int64_t ldx, int64_t B,
-                                 int64_t T, int64_t groups, int64_t channels_per_group, int64_t taps, void* stream) {
-  SLAM_CHECK_ARG(h && w_packed && bias && x, "slam_pos_conv_fwd: null pointer");
+extern "C" int slam_pos_conv_fwd(const void* h, int64_t ldh, const void* w_packed, const float* bias, void* x, int64_t ldx, void* pre,
+                                 int64_t ldpre, const void* residual, int64_t ldr, int64_t B, int64_t T, int64_t groups,
+                                 int64_t channels_per_group, int64_t taps, int64_t pad, int act, void* stream) {
+  SLAM_CHECK_ARG(h && w_packed && x, "slam_pos_conv_fwd: null pointer");
   SLAM_CHECK_ARG(B > 0 && T > 0 && groups > 0 && B * T < (1ll << 31) && groups * B * ((T + 255) / 256) < (1ll << 31), "slam_pos_conv_fwd: bad shape");
   SLAM_CHECK_ARG(slam_pos_conv_supported(channels_per_group, taps) == 1,
                  "slam_pos_conv_fwd: %ld channels per group / %ld taps unsupported (32 | 48 | 64 channels, <= 256 taps)", (long)channels_per_group, (long)taps);
-  SLAM_CHECK_ARG(ldh % 8 == 0 && ldx % 4 == 0 && ldh >= groups * channels_per_group && ldx >= groups * channels_per_group &&
-                     ((uintptr_t)h % 16) == 0 && ((uintptr_t)x % 8) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)bias % 16) == 0,
+  SLAM_CHECK_ARG(pad >= 0 && pad < taps && (act == 0 || act == 1), "slam_pos_conv_fwd: pad %ld outside [0, taps) or act %d not 0 | 1", (long)pad, act);
+  const int64_t d = groups * channels_per_group;
+  SLAM_CHECK_ARG(ldh % 8 == 0 && ldx % 4 == 0 && ldh >= d && ldx >= d && ((uintptr_t)h % 16) == 0 && ((uintptr_t)x % 8) == 0 &&
+                     ((uintptr_t)w_packed % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0),
                  "slam_pos_conv_fwd: leading dimensions / alignment");
+  SLAM_CHECK_ARG(!pre || (ldpre % 4 == 0 && ldpre >= d && ((uintptr_t)pre % 8) == 0), "slam_pos_conv_fwd: bad pre-activation buffer");
+  SLAM_CHECK_ARG(!residual || (ldr % 4 == 0 && ldr >= d && ((uintptr_t)residual % 8) == 0), "slam_pos_conv_fwd: bad residual buffer");
   SLAM_CHECK_ARG(h != x, "slam_pos_conv_fwd: in-place operation is not supported (neighbouring tiles read each other's rows)");
   const bf16_t* hp = (const bf16_t*)h;
   const bf16_t* wp = (const bf16_t*)w_packed;
+  const bf16_t* rp = (const bf16_t*)residual;
   bf16_t* xp = (bf16_t*)x;
+  bf16_t* pp = (bf16_t*)pre;
   hipStream_t s = (hipStream_t)stream;
   switch ((int)channels_per_group) {
-    case 32: return launch_pos_conv<32>(hp, ldh, wp, bias, xp, ldx, (int)B, (int)T, (int)groups, (int)taps, s);
-    case 48: return launch_pos_conv<48>(hp, ldh, wp, bias, xp, ldx, (int)B, (int)T, (int)groups, (int)taps, s);
-    default: return launch_pos_conv<64>(hp, ldh, wp, bias, xp, ldx, (int)B, (int)T, (int)groups, (int)taps, s);
+    case 32: return launch_pos_conv<32>(hp, ldh, wp, bias, xp, ldx, pp, ldpre, rp, ldr, (int)B, (int)T, (int)groups, (int)taps, (int)pad, act, s);
+    case 48: return launch_pos_conv<48>(hp, ldh, wp, bias, xp, ldx, pp, ldpre, rp, ldr, (int)B, (int)T, (int)groups, (int)taps, (int)pad, act, s);
+    default: return launch_pos_conv<64>(hp, ldh, wp, bias, xp, ldx, pp, ldpre, rp, ldr, (int)B, (int)T, (int)groups, (int)taps, (int)pad, act, s);
   }
 }

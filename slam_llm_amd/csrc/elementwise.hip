@@ -255,6 +255,36 @@ __global__ __launch_bounds__(256) void col2im_k3_kernel(const bf16_t* __restrict
   }
 }
 
+// adjoint of the general im2col (conv feature extractor of HuBERT / WavLM, unfrozen-encoder training): kernel k, stride s, no padding --
+//   dx[b, t, c] = sum_j dcols[b, o, j*C + c]  over the taps j < k with t - j = s * o, 0 <= o < Tout   (at most ceil(k / s) terms)
+__global__ __launch_bounds__(256) void col2im_kernel(const bf16_t* __restrict__ dcols, int64_t ldc, bf16_t* __restrict__ dx, int B, int Tin,
+                                                     int Tout, int C, int k, int stride) {
+  const int CC = C / 8;
+  const int64_t total = (int64_t)B * Tin * CC;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % CC) * 8;
+    const int64_t row = i / CC;
+    const int t = (int)(row % Tin);
+    const int b = (int)(row / Tin);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = 0.f;
+    for (int j = t % stride; j < k; j += stride) {   // t - j must be a multiple of the stride
+      const int num = t - j;
+      if (num < 0) break;
+      const int o = num / stride;
+      if (o >= Tout) continue;
+      const u16x8_t v = *reinterpret_cast<const u16x8_t*>(dcols + ((int64_t)b * Tout + o) * ldc + j * C + c);
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[e] += bf2f(v[e]);
+    }
+    u16x8_t o8;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o8[e] = f2bf(acc[e]);
+    *reinterpret_cast<u16x8_t*>(dx + row * C + c) = o8;
+  }
+}
+
 // dst[r, 0:width) = src[idx[r] * src_stride + 0:width)  (16 bytes per thread; idx[r] < 0 -> zeros).  One kernel for
 // packing valid rows out of a padded batch, un-packing (inverse index, pad rows zero) and the projector's k-frame windows
 // over a packed encoder output (width = k*d > src_stride = d: k consecutive rows are one contiguous window).
@@ -790,6 +820,18 @@ extern "C" int slam_conv1d_k3_col2im(const void* dcols, int64_t ldc, void* dx, i
   hipLaunchKernelGGL(col2im_k3_kernel, dim3(ew_grid(B * Tin * (C / 8))), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)dcols, ldc, (bf16_t*)dx, (int)B, (int)Tin, (int)Tout, (int)C, (int)stride);
   SLAM_CHECK_LAUNCH("slam_conv1d_k3_col2im");
+  return 0;
+}
+
+extern "C" int slam_conv1d_col2im(const void* dcols, int64_t ldc, void* dx, int64_t B, int64_t Tin, int64_t C, int64_t k, int64_t stride,
+                                  void* stream) {
+  SLAM_CHECK_ARG(dcols && dx, "slam_conv1d_col2im: null pointer");
+  SLAM_CHECK_ARG(B > 0 && Tin >= k && C > 0 && C % 8 == 0 && ldc % 8 == 0 && ldc >= k * C && k >= 1 && stride >= 1 && B * Tin < (1ll << 31),
+                 "slam_conv1d_col2im: bad shape (C, ldc multiples of 8, ldc >= k*C, Tin >= k)");
+  const int64_t Tout = (Tin - k) / stride + 1;
+  hipLaunchKernelGGL(col2im_kernel, dim3(ew_grid(B * Tin * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dcols, ldc,
+                     (bf16_t*)dx, (int)B, (int)Tin, (int)Tout, (int)C, (int)k, (int)stride);
+  SLAM_CHECK_LAUNCH("slam_conv1d_col2im");
   return 0;
 }
 

@@ -55,7 +55,8 @@ SIGNATURES = {
     "slam_attn_bwd": [P, I64, P, I64, P, I64, P, P, P, I64, P, I64, P, P, P, P, P, I64, P, I64, P, I64,
                       I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P, P, P, F, U64, P],
     "slam_pos_conv_supported": [I64, I64],
-    "slam_pos_conv_fwd": [P, I64, P, P, P, I64, I64, I64, I64, I64, I64, P],
+    "slam_pos_conv_fwd": [P, I64, P, P, P, I64, P, I64, P, I64, I64, I64, I64, I64, I64, I64, I32, P],
+    "slam_conv1d_col2im": [P, I64, P, I64, I64, I64, I64, I64, P],
     "slam_swiglu_fwd": [P, I64, P, I64, I64, I64, P],
     "slam_swiglu_bwd": [P, I64, P, I64, P, I64, I64, I64, I32, P],
     "slam_gemm_swiglu_supported": [I64, I64, I64, I64, I64],

@@ -631,11 +631,121 @@ class HipHubertEncoder(nn.Module):
     the GELU and the residual add fused in the epilogue), pre-LN transformer, final LayerNorm.  Inference-only.
     Weights use the HF state-dict names under `encoder.` (fairseq -> HF renaming is HF's conversion script)."""
 
-    def __init__(self, cfg: dict, device):
+    def __init__(self, cfg: dict, device, store: Optional["TrainableStore"] = None, prefix="encoder."):
         super().__init__()
         self.cfg, self.device_, self.w = cfg, device, {}
+        self.store, self.prefix = store, prefix
+        if store is not None:
+            self._reserve_trainable()
+
+    # ---- trainable form (train_config.freeze_encoder=false, models/slam_model.py:110-113) ------------------------------------
+    @property
+    def trainable(self) -> bool:
+        return self.store is not None
+
+    def _reserve_trainable(self):
+        """every parameter of the encoder joins the flat fp32 store under its (HF) state-dict name, in the order the backward produces
+        the gradients (GradSync prefixes): final LayerNorm, layers last -> first, positional conv, feature projection, conv stack
+        last -> first.  Implemented for the HuBERT-large / xlarge graph ("layer_norm" feature extractor, layer_norm_first layers);
+        the weight-normed positional conv trains its FOLDED weight (w = g v / ||v|| is formed once at load: same function, the
+        reference's (g, v) parametrisation of that one tensor is not kept)."""
+        cfg, r, p = self.cfg, self.store.reserve, self.prefix
+        if cfg.get("hub_extractor_mode", "layer_norm") != "layer_norm" or not cfg.get("hub_layer_norm_first", True):
+            raise NotImplementedError("freeze_encoder=false is implemented for the layer_norm-extractor / layer_norm_first HuBERT graph "
+                                      "(large, xlarge); the base geometries (GroupNorm extractor, post-LN layers) stay frozen")
+        d, Fd = cfg["hub_dim"], cfg["hub_ffn"]
+        assert d % 64 == 0 and d // cfg["hub_heads"] == 64
+        e = p + "encoder."
+        r(e + "layer_norm.weight", (d,)); r(e + "layer_norm.bias", (d,))
+        for i in reversed(range(cfg["hub_layers"])):
+            q = f"{e}layers.{i}."
+            r(q + "feed_forward.output_dense.weight", (d, Fd)); r(q + "feed_forward.output_dense.bias", (d,))
+            r(q + "feed_forward.intermediate_dense.weight", (Fd, d)); r(q + "feed_forward.intermediate_dense.bias", (Fd,))
+            r(q + "final_layer_norm.weight", (d,)); r(q + "final_layer_norm.bias", (d,))
+            r(q + "attention.out_proj.weight", (d, d)); r(q + "attention.out_proj.bias", (d,))
+            for n in ("q_proj", "k_proj", "v_proj"):     # back to back: the bf16 copies form the fused [3d, d] operand
+                r(q + f"attention.{n}.weight", (d, d))
+            for n in ("q_proj", "k_proj", "v_proj"):     # ... and the fused [3d] bias
+                r(q + f"attention.{n}.bias", (d,))
+            r(q + "layer_norm.weight", (d,)); r(q + "layer_norm.bias", (d,))
+        gch = d // cfg["hub_pos_groups"]
+        r(e + "pos_conv_embed.conv.weight", (d, gch, cfg["hub_pos_k"])); r(e + "pos_conv_embed.conv.bias", (d,))
+        f = p + "feature_projection."
+        cin = cfg["hub_conv_dim"][-1]
+        r(f + "projection.weight", (d, cin)); r(f + "projection.bias", (d,))
+        r(f + "layer_norm.weight", (cin,)); r(f + "layer_norm.bias", (cin,))
+        dims = [1] + list(cfg["hub_conv_dim"])
+        for i in reversed(range(len(cfg["hub_conv_dim"]))):
+            c = f"{p}feature_extractor.conv_layers.{i}."
+            r(c + "layer_norm.weight", (dims[i + 1],)); r(c + "layer_norm.bias", (dims[i + 1],))
+            r(c + "conv.weight", (dims[i + 1], dims[i], cfg["hub_conv_kernel"][i])); r(c + "conv.bias", (dims[i + 1],))
+
+    def bind(self):
+        for name, prm in self.store.params.items():
+            if name.startswith(self.prefix):
+                _attach(self, name[len(self.prefix):], prm)
+
+    def _load_trainable(self, W: Dict[str, torch.Tensor], prefix: str):
+        e = prefix + "encoder."
+        with torch.no_grad():
+            for name, prm in self.store.params.items():
+                if not name.startswith(self.prefix):
+                    continue
+                src = prefix + name[len(self.prefix):]
+                if src == e + "pos_conv_embed.conv.weight" and src not in W:   # weight-norm checkpoint: fold g * v / ||v||
+                    g_, v_ = W[e + "pos_conv_embed.conv.parametrizations.weight.original0"].float(), W[e + "pos_conv_embed.conv.parametrizations.weight.original1"].float()
+                    prm.copy_((g_ * v_ / v_.norm(dim=(0, 1), keepdim=True)).to(self.device_))
+                else:
+                    prm.copy_(W[src].to(self.device_))
+        return self
+
+    def refresh(self):
+        """rebuild the bf16 compute copies (and the transposes / packings the backward multiplies by) from the store"""
+        if not self.trainable:
+            return
+        st, p, cfg, w, dev = self.store, self.prefix, self.cfg, self.w, self.device_
+        d = cfg["hub_dim"]
+        cin = 1
+        for i, (co, k) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"])):
+            c = f"{p}feature_extractor.conv_layers.{i}."
+            kp = round_up(k * cin, 64)
+            wc = torch.zeros((co, kp), dtype=torch.bfloat16, device=dev)
+            wc[:, : k * cin] = st.bf16_view(c + "conv.weight").permute(0, 2, 1).reshape(co, k * cin)   # tap-major columns (im2col order)
+            w[f"c{i}"], w[f"c{i}_b"] = wc, st.master_view(c + "conv.bias")
+            w[f"c{i}T"] = ops.transpose(wc, Rp=co)                                                   # [kp, co]: dcols = dy . Wc
+            w[f"c{i}_lw"], w[f"c{i}_lb"] = st.master_view(c + "layer_norm.weight"), st.master_view(c + "layer_norm.bias")
+            cin = co
+        f = p + "feature_projection."
+        w["fp_lw"], w["fp_lb"] = st.master_view(f + "layer_norm.weight"), st.master_view(f + "layer_norm.bias")
+        w["fp"], w["fp_b"] = st.bf16_view(f + "projection.weight"), st.master_view(f + "projection.bias")
+        w["fpT"] = ops.transpose(w["fp"], Rp=d)
+        e = p + "encoder."
+        G, kpos = cfg["hub_pos_groups"], cfg["hub_pos_k"]
+        gch = d // G
+        self.pos_kp = round_up(kpos * gch, 64)
+        pg = torch.zeros((G, gch, self.pos_kp), dtype=torch.bfloat16, device=dev)
+        pg[:, :, : kpos * gch] = st.bf16_view(e + "pos_conv_embed.conv.weight").view(G, gch, gch, kpos).permute(0, 1, 3, 2).reshape(G, gch, kpos * gch)
+        w["pos"], w["pos_b"] = pg, st.master_view(e + "pos_conv_embed.conv.bias")
+        w["pos_tap"] = ops.pos_conv_pack(pg, kpos)
+        w["pos_adj"] = ops.pos_conv_pack_adjoint(pg, kpos)
+        for i in range(cfg["hub_layers"]):
+            q = f"{e}layers.{i}."
+            off = st.offsets[q + "attention.q_proj.weight"][0]
+            w[f"{i}.qkv"] = st.flat_bf16[off: off + 3 * d * d].view(3 * d, d)
+            boff = st.offsets[q + "attention.q_proj.bias"][0]
+            w[f"{i}.qkv_b"] = st.flat[boff: boff + 3 * d]
+            w[f"{i}.out"], w[f"{i}.out_b"] = st.bf16_view(q + "attention.out_proj.weight"), st.master_view(q + "attention.out_proj.bias")
+            w[f"{i}.ln1_w"], w[f"{i}.ln1_b"] = st.master_view(q + "layer_norm.weight"), st.master_view(q + "layer_norm.bias")
+            w[f"{i}.fc1"], w[f"{i}.fc1_b"] = st.bf16_view(q + "feed_forward.intermediate_dense.weight"), st.master_view(q + "feed_forward.intermediate_dense.bias")
+            w[f"{i}.fc2"], w[f"{i}.fc2_b"] = st.bf16_view(q + "feed_forward.output_dense.weight"), st.master_view(q + "feed_forward.output_dense.bias")
+            w[f"{i}.ln2_w"], w[f"{i}.ln2_b"] = st.master_view(q + "final_layer_norm.weight"), st.master_view(q + "final_layer_norm.bias")
+            for nme in ("qkv", "out", "fc1", "fc2"):
+                w[f"{i}.{nme}T"] = ops.transpose(w[f"{i}.{nme}"], Rp=w[f"{i}.{nme}"].shape[0])
+        w["lnp_w"], w["lnp_b"] = st.master_view(e + "layer_norm.weight"), st.master_view(e + "layer_norm.bias")
 
     def load(self, W: Dict[str, torch.Tensor], prefix="encoder."):
+        if self.trainable:
+            return self._load_trainable(W, prefix)
         cfg, dev, w = self.cfg, self.device_, self.w
         bf = lambda t: t.to(device=dev, dtype=torch.bfloat16).contiguous()  # noqa: E731
         f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
@@ -686,6 +796,18 @@ class HipHubertEncoder(nn.Module):
         cfg, dev, w = self.cfg, self.device_, self.w
         g = torch.Generator(device=dev).manual_seed(seed)
         rn = lambda *s, std=0.02: (torch.randn(*s, generator=g, device=dev) * std)  # noqa: E731
+        if self.trainable:      # the parameters live in the store: LayerNorm 1 / small, biases small, weights ~ fan_in^-1/2
+            with torch.no_grad():
+                for name, prm in self.store.params.items():
+                    if not name.startswith(self.prefix):
+                        continue
+                    if "layer_norm" in name:
+                        prm.copy_((1 + rn(*prm.shape, std=0.1)) if name.endswith("weight") else rn(*prm.shape, std=0.1))
+                    elif name.endswith("bias"):
+                        prm.copy_(rn(*prm.shape))
+                    else:
+                        prm.copy_(rn(*prm.shape, std=float(prm[0].numel()) ** -0.5))
+            return self
         cin = 1
         for i, (co, k) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"])):
             kp = round_up(k * cin, 64)
@@ -815,6 +937,170 @@ class HipHubertEncoder(nn.Module):
     def _relpos(self, layer: int, attn_in: torch.Tensor, B: int, T: int):
         """additive attention bias of layer `layer` given its input (HuBERT: none)"""
         return None
+
+    # ---- training forward / hand-written backward (trainable form) ----------------------------------------------------------
+    def forward_train(self, wav: torch.Tensor, stash: dict, n_valid: Optional[List[int]] = None) -> torch.Tensor:
+        """forward_wav that keeps what backward_hip() needs in stash["encoder"]: per conv layer its input and the conv output with the
+        LayerNorm statistics (the normalised / GELU'd tensors are recomputed), the positional conv's pre-activation, and per
+        transformer layer the same set as the Whisper encoder's training forward."""
+        cfg, w = self.cfg, self.w
+        B, N = wav.shape
+        x2d, Tin, cin = wav.contiguous().view(B * N, 1), N, 1
+        convs = []
+        for i, (co, k, st) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"], cfg["hub_conv_stride"])):
+            cols, Tout = ops.conv1d_im2col(x2d, B, Tin, 0, cin, k, st, 0, Kp=w[f"c{i}"].shape[1])
+            y = ops.gemm_nt(cols, w[f"c{i}"], bias=w[f"c{i}_b"])
+            del cols
+            z, m, r = ops.layernorm(y, w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5, stats=True)
+            xo = ops.gelu_fwd(z)
+            del z
+            convs.append(dict(x_in=x2d, Tin=Tin, cin=cin, y=y, m=m, r=r))
+            x2d, Tin, cin = xo, Tout, co
+        T, d, H, eps = Tin, cfg["hub_dim"], cfg["hub_heads"], cfg["hub_eps"]
+        M = B * T
+        hN, mf, rf = ops.layernorm(x2d, w["fp_lw"], w["fp_lb"], eps, stats=True)
+        h = ops.gemm_nt(hN, w["fp"], bias=w["fp_b"])
+        key_mask = pad_idx = None
+        if n_valid is not None:
+            keep = self.valid_frames(N, n_valid)
+            idx = torch.arange(M, dtype=torch.int32).view(B, T)
+            km = torch.zeros((B, round_up(T, 64)), dtype=torch.uint8)
+            for b_, kf in enumerate(keep):
+                idx[b_, kf:] = -1
+                km[b_, :kf] = 1
+            pad_idx = idx.view(-1).to(wav.device, non_blocking=True)
+            h = ops.gather_rows(h, pad_idx)                        # padded frames -> zero rows
+            key_mask = km.to(wav.device, non_blocking=True)
+        kpos = cfg["hub_pos_k"]
+        pre = torch.empty((M, d), dtype=torch.bfloat16, device=wav.device)
+        x = ops.pos_conv_fwd(h, w["pos_tap"], w["pos_b"], B, T, pre=pre)
+        S = {"convs": convs, "x6": x2d, "mf": mf, "rf": rf, "hN": hN, "h": h, "pre": pre, "pad_idx": pad_idx, "key_mask": key_mask,
+             "B": B, "T": T, "blocks": []}
+        scale = 64 ** -0.5
+        for i in range(cfg["hub_layers"]):
+            hh, m1, r1 = ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, stats=True)
+            qkv = ops.gemm_nt(hh, w[f"{i}.qkv"], bias=w[f"{i}.qkv_b"])
+            vt = ops.head_rope_transpose(qkv, 2 * d, B, T, H, 64)
+            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=True)
+            del vt
+            x1 = ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"], residual=x)
+            h2, m2, r2 = ops.layernorm(x1, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], eps, stats=True)
+            z = ops.gemm_nt(h2, w[f"{i}.fc1"], bias=w[f"{i}.fc1_b"])
+            x2 = ops.gemm_nt(ops.gelu_fwd(z), w[f"{i}.fc2"], bias=w[f"{i}.fc2_b"], residual=x1)
+            S["blocks"].append(dict(x=x, m1=m1, r1=r1, h=hh, qkv=qkv, a=a, lse=lse, x1=x1, m2=m2, r2=r2, h2=h2, z=z))
+            x = x2
+        out, mo, ro = ops.layernorm(x, w["lnp_w"], w["lnp_b"], eps, stats=True)
+        S.update(x_last=x, mo=mo, ro=ro)
+        stash["encoder"] = S
+        return out.view(B, T, d)
+
+    def _lin_grads(self, dy: torch.Tensor, x: torch.Tensor, w_name: str, acc: bool, N: Optional[int] = None, K: Optional[int] = None,
+                   bias: Tuple = ()):
+        """dW (+)= dy^T x into the flat gradient buffer at parameter `w_name` (N x K may span the fused q|k|v block); bias = ((param
+        name, first column of dy, width), ...) column sums"""
+        st = self.store
+        Mp = round_up(dy.shape[0], 64)
+        off, _, shape = st.offsets[w_name]
+        N, K = N or shape[0], K or shape[1]
+        ops.gemm_nt(ops.transpose(dy, Rp=Mp), ops.transpose(x, Rp=Mp), out=st.grad[off: off + N * K].view(N, K), accumulate=acc)
+        for name, c0, n in bias:
+            ops.colsum(dy[:, c0: c0 + n], st.grad_view(name), accumulate=acc)
+
+    def backward_hip(self, dout: torch.Tensor, stash: dict, acc: bool):
+        """dout [B*T, d] bf16 = dL/d(encoder output); deposits every encoder gradient into the flat grad buffer (hand-written adjoint of
+        the HuBERT graph of forward_train: HF HubertModel / fairseq HubertModel.extract_features as called at slam_model.py:335-341)"""
+        cfg, w, st, p = self.cfg, self.w, self.store, self.prefix
+        S = stash.pop("encoder")
+        B, T, key_mask = S["B"], S["T"], S["key_mask"]
+        d, H = cfg["hub_dim"], cfg["hub_heads"]
+        scale = 64 ** -0.5
+        gv = st.grad_view
+        e = p + "encoder."
+        dx = ops.layernorm_bwd(S["x_last"], S["mo"], S["ro"], w["lnp_w"], dout, dgamma=gv(e + "layer_norm.weight"),
+                               dbeta=gv(e + "layer_norm.bias"), accumulate=acc)
+        for i in reversed(range(cfg["hub_layers"])):
+            R = S["blocks"][i]
+            q = f"{e}layers.{i}."
+            fo = ops.gelu_fwd(R["z"])
+            self._lin_grads(dx, fo, q + "feed_forward.output_dense.weight", acc, bias=((q + "feed_forward.output_dense.bias", 0, d),))
+            dz = ops.gelu_bwd(R["z"], ops.gemm_nt(dx, w[f"{i}.fc2T"]))
+            del fo
+            self._lin_grads(dz, R["h2"], q + "feed_forward.intermediate_dense.weight", acc,
+                            bias=((q + "feed_forward.intermediate_dense.bias", 0, cfg["hub_ffn"]),))
+            dh2 = ops.gemm_nt(dz, w[f"{i}.fc1T"])
+            del dz
+            dx1 = ops.layernorm_bwd(R["x1"], R["m2"], R["r2"], w[f"{i}.ln2_w"], dh2, dgamma=gv(q + "final_layer_norm.weight"),
+                                    dbeta=gv(q + "final_layer_norm.bias"), accumulate=acc)
+            ops.add_(dx1, dx)
+            self._lin_grads(dx1, R["a"], q + "attention.out_proj.weight", acc, bias=((q + "attention.out_proj.bias", 0, d),))
+            da = ops.gemm_nt(dx1, w[f"{i}.outT"])
+            qkv = R["qkv"]
+            qt = ops.head_rope_transpose(qkv, 0, B, T, H, 64)
+            kt = ops.head_rope_transpose(qkv, d, B, T, H, 64)
+            dat = ops.head_rope_transpose(da, 0, B, T, H, 64)
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], qt, kt, R["a"], da, dat, R["lse"], dqkv[:, :d],
+                         dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask)
+            del qt, kt, dat, da
+            self._lin_grads(dqkv, R["h"], q + "attention.q_proj.weight", acc, N=3 * d, K=d,
+                            bias=((q + "attention.q_proj.bias", 0, d), (q + "attention.k_proj.bias", d, d), (q + "attention.v_proj.bias", 2 * d, d)))
+            dh = ops.gemm_nt(dqkv, w[f"{i}.qkvT"])
+            del dqkv
+            dx = ops.layernorm_bwd(R["x"], R["m1"], R["r1"], w[f"{i}.ln1_w"], dh, dgamma=gv(q + "layer_norm.weight"),
+                                   dbeta=gv(q + "layer_norm.bias"), accumulate=acc)
+            ops.add_(dx, dx1)
+            S["blocks"][i] = None
+        # ---- positional conv: x0 = h + gelu(conv(h) + b) ----
+        G, kpos = cfg["hub_pos_groups"], cfg["hub_pos_k"]
+        gch = d // G
+        M = B * T
+        Mp = round_up(M, 64)
+        dpre = ops.gelu_bwd(S["pre"], dx)
+        gw = gv(e + "pos_conv_embed.conv.weight")                      # reference layout [d (co), gch (ci), kpos]
+        cols = torch.empty((M, self.pos_kp), dtype=torch.bfloat16, device=dx.device)
+        for g in range(G):   # dW_g[co, j*gch + ci] = sum_t dpre[t, g*gch + co] * h[t + j - kpos/2, g*gch + ci]
+            ops.conv1d_im2col(S["h"], B, T, g * gch, gch, kpos, 1, kpos // 2, Kp=self.pos_kp, Tout_limit=T, out=cols)
+            gwg = ops.gemm_nt(ops.transpose(dpre[:, g * gch:(g + 1) * gch], Rp=Mp), ops.transpose(cols, Rp=Mp), out_dtype=torch.float32)
+            gwg = gwg[:, : kpos * gch].reshape(gch, kpos, gch).permute(0, 2, 1)
+            gw[g * gch:(g + 1) * gch].add_(gwg) if acc else gw[g * gch:(g + 1) * gch].copy_(gwg)
+        del cols
+        ops.colsum(dpre, gv(e + "pos_conv_embed.conv.bias"), accumulate=acc)
+        dh = ops.pos_conv_fwd(dpre, w["pos_adj"], None, B, T, residual=dx, pad=kpos - 1 - kpos // 2, act=False)
+        del dpre, dx
+        if S["pad_idx"] is not None:
+            dh = ops.gather_rows(dh, S["pad_idx"])      # the padded frames were zero-filled in the forward: no gradient through them
+        # ---- feature projection: h = Linear(LayerNorm(x6)) ----
+        f = p + "feature_projection."
+        self._lin_grads(dh, S["hN"], f + "projection.weight", acc, bias=((f + "projection.bias", 0, d),))
+        dhN = ops.gemm_nt(dh, w["fpT"])
+        del dh
+        dxo = ops.layernorm_bwd(S["x6"], S["mf"], S["rf"], w["fp_lw"], dhN, dgamma=gv(f + "layer_norm.weight"), dbeta=gv(f + "layer_norm.bias"),
+                                accumulate=acc)
+        del dhN
+        # ---- conv feature extractor, last layer first: x_i = gelu(LayerNorm(conv_i(x_{i-1}))) ----
+        for i in reversed(range(len(cfg["hub_conv_dim"]))):
+            C_ = S["convs"][i]
+            co, k, sd = cfg["hub_conv_dim"][i], cfg["hub_conv_kernel"][i], cfg["hub_conv_stride"][i]
+            c = f"{p}feature_extractor.conv_layers.{i}."
+            z = ops.layernorm(C_["y"], w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5)
+            dz = ops.gelu_bwd(z, dxo)
+            del z, dxo
+            dy = ops.layernorm_bwd(C_["y"], C_["m"], C_["r"], w[f"c{i}_lw"], dz, dgamma=gv(c + "layer_norm.weight"), dbeta=gv(c + "layer_norm.bias"),
+                                   accumulate=acc)
+            del dz
+            cin, Tin = C_["cin"], C_["Tin"]
+            cols, Tout = ops.conv1d_im2col(C_["x_in"], B, Tin, 0, cin, k, sd, 0, Kp=w[f"c{i}"].shape[1])
+            Mi = dy.shape[0]
+            Mip = round_up(Mi, 64)
+            gwc = ops.gemm_nt(ops.transpose(dy, Rp=Mip), ops.transpose(cols, Rp=Mip), out_dtype=torch.float32)   # [co, kp], tap-major
+            del cols
+            gwc = gwc[:, : k * cin].reshape(co, k, cin).permute(0, 2, 1)
+            gv(c + "conv.weight").add_(gwc) if acc else gv(c + "conv.weight").copy_(gwc)
+            ops.colsum(dy, gv(c + "conv.bias"), accumulate=acc)
+            if i > 0:
+                dxo = ops.conv1d_col2im(ops.gemm_nt(dy, w[f"c{i}T"]), B, Tin, cin, k, sd)
+            del dy
+            S["convs"][i] = None
 
     def forward(self, source=None, padding_mask=None, **kw):
         return {"encoder_out": self.forward_wav(source).transpose(0, 1), "padding_mask": None}
@@ -1487,12 +1773,13 @@ class SlamHipModel(nn.Module):
         self.projector_name = cfg.get("projector", "linear")
         # train_config.freeze_encoder=false (models/slam_model.py:110-113): the encoder's parameters join the trainable store
         self.train_encoder = not bool(cfg.get("freeze_encoder", True))
-        if self.train_encoder and (self.encoder_name != "whisper" or cfg.get("varlen_encoder", False)):
-            raise NotImplementedError("freeze_encoder=false is implemented for the Whisper encoder (hand-written encoder backward) with the "
-                                      "linear / cov1d-linear / q-former projectors on padded batches; HuBERT / WavLM / varlen_encoder are not")
+        if self.train_encoder and (self.encoder_name not in ("whisper", "hubert") or cfg.get("varlen_encoder", False)):
+            raise NotImplementedError("freeze_encoder=false is implemented for the Whisper and HuBERT encoders (hand-written encoder backward) with "
+                                      "the linear / cov1d-linear / q-former projectors on padded batches; WavLM / varlen_encoder are not")
         if self.encoder_name in ("hubert", "wavlm"):
-            self.encoder = (HipHubertEncoder if self.encoder_name == "hubert" else HipWavLMEncoder)(cfg, self.device_)
             cfg["enc_dim"] = cfg["hub_dim"]
+            if not self.train_encoder:
+                self.encoder = (HipHubertEncoder if self.encoder_name == "hubert" else HipWavLMEncoder)(cfg, self.device_)
         elif not self.train_encoder:
             self.encoder = HipWhisperEncoder(cfg, self.device_)
         self.llm = HipLlamaLora(cfg, self.store, self.device_)          # reserves LoRA (last layer first)
@@ -1505,8 +1792,8 @@ class SlamHipModel(nn.Module):
             raise ValueError(f"unknown encoder_projector {self.projector_name!r} (linear | cov1d-linear | q-former)")
         else:
             self.encoder_projector = HipProjectorConcat(cfg, self.store)  # projector last = produced last in backward
-        if self.train_encoder:
-            self.encoder = HipWhisperEncoder(cfg, self.device_, store=self.store)   # ... except a trainable encoder, after it
+        if self.train_encoder:   # ... except a trainable encoder, after it
+            self.encoder = (HipHubertEncoder if self.encoder_name == "hubert" else HipWhisperEncoder)(cfg, self.device_, store=self.store)
             self.encoder_projector.need_dx = True
         self.store.allocate()
         self.llm.bind()
@@ -1532,6 +1819,8 @@ class SlamHipModel(nn.Module):
         missing = []
         with torch.no_grad():
             for name, p in self.store.params.items():
+                if self.train_encoder and name.startswith("encoder."):
+                    continue   # a trainable encoder loaded its own parameters above (incl. the folded weight-norm tensor)
                 if name in W:
                     p.copy_(W[name].to(self.device_, torch.float32))
                 else:
@@ -1673,16 +1962,18 @@ class SlamHipModel(nn.Module):
             if nv is None and kwargs.get("audio_mask", None) is not None:
                 nv = (kwargs["audio_mask"] > 0).sum(1).tolist()
             hub_pad = None
+            hub_train = self.train_encoder and train
             if nv is not None and min(nv) < audio.shape[1]:
                 # ragged batch: the reference hands fairseq `padding_mask = 1 - audio_mask` (slam_model.py:336)
-                enc = self.encoder.forward_wav(audio.float(), [int(n) for n in nv])
+                nvi = [int(n) for n in nv]
+                enc = self.encoder.forward_train(audio.float(), stash, nvi) if hub_train else self.encoder.forward_wav(audio.float(), nvi)
                 keep = self.encoder.valid_frames(audio.shape[1], nv)
                 hub_pad = torch.zeros((len(keep), enc.shape[1]), dtype=torch.float32)
                 for b_, kf in enumerate(keep):
                     hub_pad[b_, kf:] = 1.0     # fairseq's frame padding mask: 1 = PADDING
                 hub_pad = hub_pad.to(dev, non_blocking=True)
             else:
-                enc = self.encoder.forward_wav(audio.float())
+                enc = self.encoder.forward_train(audio.float(), stash) if hub_train else self.encoder.forward_wav(audio.float())
         else:
             if audio_mel is None:
                 if audio is None:

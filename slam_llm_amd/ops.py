@@ -355,15 +355,37 @@ def pos_conv_pack(w_im2col: torch.Tensor, taps: int) -> torch.Tensor:
     return out
 
 
-def pos_conv_fwd(h2d: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, B: int, T: int, out: Optional[torch.Tensor] = None):
-    """x = h + gelu(grouped_conv(h) + bias) over [B*T, d] rows (fairseq pos_conv + SamePad + GELU + residual), one launch"""
+def pos_conv_fwd(h2d: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], B: int, T: int, out: Optional[torch.Tensor] = None,
+                 pre: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, pad: Optional[int] = None, act: bool = True):
+    """x = residual + act(grouped_conv(h) + bias) over [B*T, d] rows, one launch.  Defaults = fairseq pos_conv + SamePad + GELU + the
+    skip connection (residual = h).  pre: also receives conv + bias (training).  The adjoint: pos_conv_fwd(dconv, pos_conv_pack_adjoint(w),
+    None, B, T, residual=dx, pad=taps - 1 - taps // 2, act=False)."""
     G, taps, C, _ = w_packed.shape
     if out is None:
         out = torch.empty((B * T, G * C), dtype=torch.bfloat16, device=h2d.device)
     _timed("pos_conv", 2.0 * B * T * G * C * taps * C,
-           lambda: call("slam_pos_conv_fwd", _p(h2d), _ld(h2d), _p(w_packed), _p(bias), _p(out), _ld(out), B, T, G, C, taps, _s()),
+           lambda: call("slam_pos_conv_fwd", _p(h2d), _ld(h2d), _p(w_packed), _p(bias), _p(out), _ld(out), _p(pre),
+                        _ld(pre) if pre is not None else 0, _p(residual), _ld(residual) if residual is not None else 0, B, T, G, C, taps,
+                        taps // 2 if pad is None else pad, 1 if act else 0, _s()),
            nbytes=2.0 * (2 * B * T * G * C) + 2.0 * w_packed.numel())
     return out
+
+
+def pos_conv_pack_adjoint(w_im2col: torch.Tensor, taps: int) -> torch.Tensor:
+    """weights of the adjoint launch: tap-reversed and channel-transposed, [G, taps, C (ci), KP (co, zero padded)]"""
+    G, C, _ = w_im2col.shape
+    KP = round_up(C, 32)
+    out = torch.zeros((G, taps, C, KP), dtype=torch.bfloat16, device=w_im2col.device)
+    w = w_im2col[:, :, : taps * C].reshape(G, C, taps, C)          # [g, co, j, ci]
+    out[..., :C] = w.flip(2).permute(0, 2, 3, 1)                   # [g, j', ci, co], j' = taps - 1 - j
+    return out
+
+
+def conv1d_col2im(dcols: torch.Tensor, B: int, Tin: int, C: int, k: int, stride: int) -> torch.Tensor:
+    """adjoint of conv1d_im2col(pad = 0): dcols [B*Tout, >= k*C] -> dx [B*Tin, C]"""
+    dx = torch.empty((B * Tin, C), dtype=torch.bfloat16, device=dcols.device)
+    call("slam_conv1d_col2im", _p(dcols), _ld(dcols), _p(dx), B, Tin, C, k, stride, _s())
+    return dx
 
 
 def rmsnorm_fwd(x, weight, eps, out=None, rstd=None):

@@ -170,10 +170,81 @@ def test_unfrozen_encoder_training_matches_reference_fixture(dev):
 def test_unfrozen_encoder_rejects_unimplemented_combinations(dev):
     from oracle.make_golden_cases import HUBERT_TINY, UNFROZEN_CASE as C
     from slam_llm_amd.model import SlamHipModel
-    with pytest.raises(NotImplementedError, match="freeze_encoder"):
-        SlamHipModel(dict(C["cfg"], **HUBERT_TINY, freeze_encoder=False, encoder_name="hubert", enc_dim=HUBERT_TINY["hub_dim"]), dev)
+    with pytest.raises(NotImplementedError, match="freeze_encoder"):      # WavLM (gated relative position bias) stays frozen-only
+        SlamHipModel(dict(C["cfg"], **HUBERT_TINY, freeze_encoder=False, encoder_name="wavlm", enc_dim=HUBERT_TINY["hub_dim"]), dev)
+    with pytest.raises(NotImplementedError, match="freeze_encoder"):      # ... and so do the base geometries (GroupNorm extractor, post-LN)
+        SlamHipModel(dict(C["cfg"], **HUBERT_TINY, freeze_encoder=False, encoder_name="hubert", enc_dim=HUBERT_TINY["hub_dim"],
+                          hub_extractor_mode="default", hub_layer_norm_first=False), dev)
     with pytest.raises(NotImplementedError, match="freeze_encoder"):
         SlamHipModel(dict(C["cfg"], freeze_encoder=False, varlen_encoder=True), dev)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_unfrozen_hubert_encoder_matches_oracle(dev, ragged):
+    """row f4: train_config.freeze_encoder=false with the HuBERT encoder (models/slam_model.py:110-113 + :335-341) -- the hand-written
+    adjoint of the whole graph: 7 conv layers (LayerNorm over channels + GELU; general col2im for k 10 / 3 / 2, strides 5 / 2), feature
+    LayerNorm + projection, grouped positional conv (dX = the implicit-GEMM kernel on tap-reversed, channel-transposed weights; dW per
+    group), pre-LN transformer layers with key biases.  Tiny widths (conv 64, d 128, 2 layers, pos conv k 16 in 4 groups), linear
+    projector, ragged variant: second clip 70 % long (fairseq frame mask, padded frames zeroed before the positional conv and masked
+    as keys).  Loss and EVERY gradient against the oracle's autograd: cosine >= 0.998, norm within 4 %."""
+    from oracle.make_golden_cases import HUBERT_TINY
+    from slam_llm_amd.model import SlamHipModel
+    cfg = dict(O.make_config(), **HUBERT_TINY, lora_dropout=0.0)
+    cfg.update(encoder_name="hubert", enc_dim=HUBERT_TINY["hub_dim"])
+    W = {k: v for k, v in O.init_weights(cfg, seed=42).items() if not k.startswith("encoder.")}
+    W.update(O.init_hubert_weights(HUBERT_TINY, seed=7))
+    N = 16000
+    wav = torch.nn.functional.layer_norm(O.synth_audio(2, 1.0, seed=9), (N,))
+    n_valid = [N, 11200] if ragged else [N, N]
+    if ragged:
+        wav[1, n_valid[1]:] = 0.0
+    alen = [n // 320 // 5 for n in n_valid]                       # speech_dataset.py:98-99
+    samples = [O.make_sample(alen[0], [5, 6, 7], [9, 10, 11, 12], 2), O.make_sample(alen[1], [5, 6], [9, 10], 2)]
+    ob = O.collate_left_pad(samples, pad_id=2)
+    names = O.trainable_names(W) + [n for n in W if n.startswith("encoder.")]
+    for n in names:
+        W[n].requires_grad_(True)
+    enc = O.hubert_encoder(W, cfg, wav, n_valid=torch.tensor(n_valid) if ragged else None)
+    proj = O.projector_concat(W, enc, cfg["ds_rate"])
+    emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+    loss_ref, _ = O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
+    loss_ref.backward()
+    grads = {n: W[n].grad.detach().clone() for n in names}
+    for n in names:
+        W[n].requires_grad_(False)
+        W[n].grad = None
+    model = SlamHipModel(dict(cfg, freeze_encoder=False), dev).load_weights(W)
+    model.train()
+    assert set(model.store.params) == set(names), set(model.store.params) ^ set(names)
+    gb = {k: v.to(dev) for k, v in ob.items()}
+    gb["audio"] = wav.to(dev)
+    gb["audio_len"] = torch.tensor(n_valid, dtype=torch.int32, device=dev)
+    outputs, _ = model(**gb)
+    outputs.loss.backward()
+    assert abs(float(outputs.loss.detach()) - float(loss_ref)) < 1.5e-2, (float(outputs.loss.detach()), float(loss_ref))
+    gmax = max(float(v.norm()) for v in grads.values())
+    worst, worst_name = 1.0, ""
+    for n, p in model.store.params.items():
+        gn, mine = float(grads[n].norm()), p.grad.float().cpu()
+        if n.endswith("k_proj.bias") and gn < 1e-4 * gmax:          # key biases: mathematically zero gradient
+            assert float(mine.abs().max()) < 3e-2, n
+            continue
+        cs = G.cosine(grads[n].numpy(), mine.numpy())
+        if cs < worst:
+            worst, worst_name = cs, n
+        assert cs >= 0.998, f"grad {n}: cosine {cs}"
+        assert abs(float(mine.norm()) - gn) <= 4e-2 * gn + 1e-7, f"grad {n}: norm {float(mine.norm())} vs {gn}"
+    print(f"unfrozen HuBERT (ragged={ragged}): worst gradient cosine {worst:.6f} ({worst_name})")
+    # one optimizer step moves the encoder, and the state_dict carries it under the reference's names
+    from slam_llm_amd.model import SlamAdamW
+    before = model.store.flat.clone()
+    opt = SlamAdamW(model, lr=1e-3)
+    opt.step()
+    opt.zero_grad()
+    assert float((model.store.flat - before).abs().max()) > 0
+    assert "encoder.feature_extractor.conv_layers.0.conv.weight" in model.state_dict()
+    out2, _ = model(**gb)
+    assert bool(torch.isfinite(out2.loss))
 
 
 @pytest.mark.parametrize("projector", ["cov1d-linear", "q-former"])
