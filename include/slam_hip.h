@@ -188,8 +188,8 @@ int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
  * (src/slam_llm/models/wavlm/WavLM.py:378-386, 575-580; the same graph in fairseq's HuBERT, models/slam_model.py:335-341):
  *   x[b, t, g*C + co] = h[b, t, g*C + co] + gelu(bias[g*C + co] + sum_j sum_ci W[g*C + co, ci, j] * h[b, t + j - taps/2, g*C + ci])
  * h, x: [B*T, ld] bf16 (x != h); w_packed: [groups][taps][C (co)][C padded to a multiple of 32 (ci, zero padded)] bf16 -- the
- * weight-normed conv weight re-packed tap-major; bias [groups*C] f32.  C = channels per group in {32, 48, 64}
- * (slam_pos_conv_supported: d = 512 / 768 / 1024 with 16 groups), taps <= 256.  No im2col buffer exists: the taps are LDS row
+ * weight-normed conv weight re-packed tap-major; bias [groups*C] f32.  C = channels per group in {32, 48, 64, 80}
+ * (slam_pos_conv_supported: d = 512 / 768 / 1024 / 1280 with 16 groups), taps <= 256.  No im2col buffer exists: the taps are LDS row
  * offsets into one input window per workgroup.
  * General form (the training path): out = residual + act(conv(h) + bias) with `pad` rows of left zero padding (forward: taps / 2);
  * bias nullable; act 1 = GELU, 0 = none; residual nullable = h itself (read from the input window); pre nullable: also receives

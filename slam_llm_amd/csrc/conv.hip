@@ -26,8 +26,8 @@ namespace {
 // the same kernel run on dL/d(conv output) with tap-reversed, channel-transposed weights: dL/dh[s] = sum_j W_j^T d[s - j + taps/2]);
 // `bias` nullable; `act` 1 = GELU, 0 = none; `res` nullable: the residual comes from this tensor instead of the window (the adjoint adds
 // the skip path's gradient); `pre` nullable: also write the pre-activation conv + bias (the training forward keeps it for the backward).
-template <int C>   // channels per group: 32 | 48 | 64
-__global__ __launch_bounds__(256, 2) void pos_conv_kernel(const bf16_t* __restrict__ h, int64_t ldh, const bf16_t* __restrict__ wpk,
+template <int C>   // channels per group: 32 | 48 | 64 | 80 (d = 512 / 768 / 1024 / 1280 with 16 groups)
+__global__ __launch_bounds__(256, (C <= 64 ? 2 : 1)) void pos_conv_kernel(const bf16_t* __restrict__ h, int64_t ldh, const bf16_t* __restrict__ wpk,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ x, int64_t ldx,
                                                           bf16_t* __restrict__ pre, int64_t ldpre, const bf16_t* __restrict__ res,
                                                           int64_t ldr, int B, int T, int K, int pad, int act, int tiles_t) {
@@ -157,7 +157,7 @@ int launch_pos_conv(const bf16_t* h, int64_t ldh, const bf16_t* wpk, const float
 }  // namespace
 
 extern "C" int slam_pos_conv_supported(int64_t channels_per_group, int64_t taps) {
-  return (channels_per_group == 32 || channels_per_group == 48 || channels_per_group == 64) && taps >= 1 && taps <= 256 ? 1 : 0;
+  return (channels_per_group == 32 || channels_per_group == 48 || channels_per_group == 64 || channels_per_group == 80) && taps >= 1 && taps <= 256 ? 1 : 0;
 }
 
 extern "C" int slam_pos_conv_fwd(const void* h, int64_t ldh, const void* w_packed, const float* bias, void* x, int64_t ldx, void* pre,
@@ -166,7 +166,7 @@ extern "C" int slam_pos_conv_fwd(const void* h, int64_t ldh, const void* w_packe
   SLAM_CHECK_ARG(h && w_packed && x, "slam_pos_conv_fwd: null pointer");
   SLAM_CHECK_ARG(B > 0 && T > 0 && groups > 0 && B * T < (1ll << 31) && groups * B * ((T + 255) / 256) < (1ll << 31), "slam_pos_conv_fwd: bad shape");
   SLAM_CHECK_ARG(slam_pos_conv_supported(channels_per_group, taps) == 1,
-                 "slam_pos_conv_fwd: %ld channels per group / %ld taps unsupported (32 | 48 | 64 channels, <= 256 taps)", (long)channels_per_group, (long)taps);
+                 "slam_pos_conv_fwd: %ld channels per group / %ld taps unsupported (32 | 48 | 64 | 80 channels, <= 256 taps)", (long)channels_per_group, (long)taps);
   SLAM_CHECK_ARG(pad >= 0 && pad < taps && (act == 0 || act == 1), "slam_pos_conv_fwd: pad %ld outside [0, taps) or act %d not 0 | 1", (long)pad, act);
   const int64_t d = groups * channels_per_group;
   SLAM_CHECK_ARG(ldh % 8 == 0 && ldx % 4 == 0 && ldh >= d && ldx >= d && ((uintptr_t)h % 16) == 0 && ((uintptr_t)x % 8) == 0 &&
@@ -184,6 +184,7 @@ extern "C" int slam_pos_conv_fwd(const void* h, int64_t ldh, const void* w_packe
   switch ((int)channels_per_group) {
     case 32: return launch_pos_conv<32>(hp, ldh, wp, bias, xp, ldx, pp, ldpre, rp, ldr, (int)B, (int)T, (int)groups, (int)taps, (int)pad, act, s);
     case 48: return launch_pos_conv<48>(hp, ldh, wp, bias, xp, ldx, pp, ldpre, rp, ldr, (int)B, (int)T, (int)groups, (int)taps, (int)pad, act, s);
+    case 80: return launch_pos_conv<80>(hp, ldh, wp, bias, xp, ldx, pp, ldpre, rp, ldr, (int)B, (int)T, (int)groups, (int)taps, (int)pad, act, s);
     default: return launch_pos_conv<64>(hp, ldh, wp, bias, xp, ldx, pp, ldpre, rp, ldr, (int)B, (int)T, (int)groups, (int)taps, (int)pad, act, s);
   }
 }

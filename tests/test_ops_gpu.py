@@ -284,10 +284,10 @@ def test_gemm_rejects_bad_shapes(dev):
 
 
 # ----------------------------------------------------------------------------------------- grouped positional conv
-@pytest.mark.parametrize("C,K,T", [(64, 128, 300), (48, 128, 517), (32, 16, 100), (64, 127, 256)])
+@pytest.mark.parametrize("C,K,T", [(64, 128, 300), (48, 128, 517), (32, 16, 100), (64, 127, 256), (80, 128, 300)])
 def test_pos_conv_one_launch_matches_torch_grouped_conv(dev, C, K, T):
     """slam_pos_conv_fwd (implicit GEMM: taps = LDS row offsets) against torch's grouped Conv1d + SamePad + GELU + residual in fp32
-    (fairseq pos_conv, WavLM.py:378-386 / 575-580): channels per group 64 / 48 / 32 (d = 1024 / 768 / 512 with 16 groups), even and
+    (fairseq pos_conv, WavLM.py:378-386 / 575-580): channels per group 64 / 48 / 32 / 80 (d = 1024 / 768 / 512 / 1280 with 16 groups), even and
     odd tap counts, T across tile boundaries; |err| <= 2e-2 + 2e-2 |ref| (bf16 output).  Also against the round-2 path
     (per-group im2col + GEMM), which must agree to bf16 rounding."""
     ops = _ops()
