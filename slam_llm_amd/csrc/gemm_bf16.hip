@@ -1406,6 +1406,7 @@ static inline bool fits_descriptor(int64_t rows, int64_t ld, int tile) {
 std::atomic<int> g_gemm_cfg{0};  // 0 = auto
 std::atomic<int> g_gemm_big{12};       // which 256x256 kernel the auto rule uses for K > 2048 (6 | 7 | 12): in the C3 step 12 -> 401.7 ms, 6 -> 408.3 ms
 std::atomic<int> g_gemm_big_shortk{7}; // ... and for K <= 2048
+std::atomic<int> g_gemm_small{1};      // the 128x128 kernel of the auto rule: 1 = two-stage loop, 11 = register-double-buffered pipeline
 std::atomic<int> g_gemm_group_m{8};
 std::atomic<int> g_gemm_probe{0};      // 1: cfg 6 / 12 launch their PROBE instantiation (workgroup 0 stamps g_clk_probe; tools/gemm_epi_probe.py)
 
@@ -1448,7 +1449,8 @@ extern "C" int slam_gemm_set_config(int cfg) {
   if (cfg == 400 || cfg == 401) { g_gemm_probe = cfg - 400; return 0; }   // tools: cycle stamps of workgroup 0 (slam_gemm_debug_clock)
   if (cfg == 106 || cfg == 107 || cfg == 112) { g_gemm_big = cfg - 100; return 0; }
   if (cfg == 206 || cfg == 207 || cfg == 212) { g_gemm_big_shortk = cfg - 200; return 0; }
-  SLAM_CHECK_ARG(cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 6 || cfg == 7 || cfg == 12, "slam_gemm_set_config: cfg %d (0 auto | 1 2 3 4 6 7 12)", cfg);
+  if (cfg == 601 || cfg == 611) { g_gemm_small = cfg - 600; return 0; }   // which 128x128 kernel the auto rule uses when small tiles win (1 | 11)
+  SLAM_CHECK_ARG(cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 6 || cfg == 7 || cfg == 11 || cfg == 12, "slam_gemm_set_config: cfg %d (0 auto | 1 2 3 4 6 7 11 12)", cfg);
   g_gemm_cfg = cfg;
   return 0;
 }
@@ -1507,10 +1509,13 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     // 4-wave kernel: faster k-loop, longer epilogue (64 fragments per wave) -- it wins from K = 4096 up unless the output is narrow
     // (N = 1280 with a residual epilogue, Whisper fc2: 1084 vs 1124 TF for the 8-wave pipelined kernel, tools/gemm_enc_bench.py)
     else if (t256 < t128) cfg = (K <= 2048) ? big_shortk : ((big == 12 && N < 2048) ? 6 : big);
-    else cfg = 1;
+    else cfg = g_gemm_small;
   }
   switch (cfg) {
     case 1: return launch_gemm<128, 128, 2, 2>(p, s);
+    case 11:                                               // 128x128 tiles on the register-double-buffered pipeline (two workgroups per CU)
+      if (p.K < 2 * BK) return launch_gemm<128, 128, 2, 2>(p, s);
+      return launch_gemm<128, 128, 2, 2, 1>(p, s);
     case 2: return launch_gemm<256, 128, 4, 2>(p, s);
     case 3: return launch_gemm<128, 64, 2, 2>(p, s);
     case 4: return launch_gemm<256, 256, 2, 4>(p, s);

@@ -140,12 +140,15 @@ def gemm_skinny(a, b, out, residual=None, b2=None, swiglu=False):
 
 
 _GEMM_CFG = 0
-_GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
+_GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 11: "gemm_nt_pipe_kernel<128,128,2,2,1>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
                4: "gemm_nt_kernel<256,256,2,4>", 6: "gemm_nt_pipe_kernel<256,256,2,4,1>", 7: "gemm_nt_persist2_kernel<256,256,2,4>",
                12: "gemm_nt_w4_kernel<256,256,false,0>"}
 
 
-_GEMM_BIG = {"big": 12, "shortk": 7}
+_GEMM_BIG = {"big": 12, "shortk": 7, "small": 1}
+if os.environ.get("SLAM_GEMM_SMALL"):        # sweeps: SLAM_GEMM_SMALL=1|11 (the 128x128 kernel of the auto rule)
+    call("slam_gemm_set_config", 600 + int(os.environ["SLAM_GEMM_SMALL"]))
+    _GEMM_BIG["small"] = int(os.environ["SLAM_GEMM_SMALL"])
 if os.environ.get("SLAM_GEMM_BIG"):          # sweeps: SLAM_GEMM_BIG=12 SLAM_GEMM_BIG_SHORTK=7 python bench.py ...
     call("slam_gemm_set_config", 100 + int(os.environ["SLAM_GEMM_BIG"]))
     _GEMM_BIG["big"] = int(os.environ["SLAM_GEMM_BIG"])
@@ -168,7 +171,7 @@ def gemm_kernel_name(M: int, N: int, K: int = 1 << 30) -> str:
         t256 = ((tiles256 + 255) // 256) * (4.0 / 1.4)
         t128 = ((tiles128 + 511) // 512) * 2.0
         big = 6 if (_GEMM_BIG["big"] == 12 and N < 2048) else _GEMM_BIG["big"]
-        cfg = 3 if N <= 64 else ((_GEMM_BIG["shortk"] if K <= 2048 else big) if t256 < t128 else 1)
+        cfg = 3 if N <= 64 else ((_GEMM_BIG["shortk"] if K <= 2048 else big) if t256 < t128 else _GEMM_BIG["small"])
     return _GEMM_NAMES[cfg]
 
 
@@ -176,7 +179,9 @@ def gemm_set_config(cfg: int):
     """0 = auto rule, 1 2 3 4 6 7 12 = force one kernel (tools / tests); 100 + v / 200 + v = which 256x256 kernel the auto rule uses
     for K > 2048 / K <= 2048 (sweeps)"""
     global _GEMM_CFG
-    if cfg >= 300:      # 300 / 301 / 302..316: split-K tail auto / off / forced slices; 400 / 401: cycle stamps off / on
+    if cfg in (601, 611):
+        _GEMM_BIG["small"] = cfg - 600
+    elif cfg >= 300:    # 300 / 301 / 302..316: split-K tail auto / off / forced slices; 400 / 401: cycle stamps off / on
         pass
     elif cfg >= 100:
         _GEMM_BIG["big" if cfg < 200 else "shortk"] = cfg % 100

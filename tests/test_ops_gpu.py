@@ -33,7 +33,7 @@ def assert_close(got, ref, atol, rtol, what=""):
 
 
 # ----------------------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 6, 7, 12])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 6, 7, 11, 12])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 64), (1000, 388, 192), (77, 64, 4160), (5000, 4100, 256)])
 def test_gemm_plain(dev, cfg, M, N, K):
     ops = _ops()
