@@ -243,7 +243,9 @@ def test_gemm_split_k_tail(dev, M, N, K, slices, epi):
     if f32:
         ref = ref + base
     assert_close(split1, ref, atol=2e-2, rtol=2e-2, what="split-K vs fp32")
-    assert_close(split1, plain, atol=1e-3 if f32 else 1e-6, rtol=2 ** -7, what="split-K vs unsplit")
+    # (re-associated fp32 partial sums: one bf16 rounding step of the OUTPUT's magnitude, or -- where bias / residual cancel the
+    # product -- of the operands' magnitude, O(1..8) here: 2^-5)
+    assert_close(split1, plain, atol=1e-3 if f32 else 2 ** -5, rtol=2 ** -7, what="split-K vs unsplit")
     if not f32:
         assert float((split1 != plain).float().mean()) < 0.02
     if slices == 0:   # the auto plan must actually have split this shape: 272 tiles leave 16 for the last round
