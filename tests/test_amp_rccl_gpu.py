@@ -173,7 +173,10 @@ def _rccl_worker(port, q):
         res["autograd_params_rel"] = rel(plain_ag, plain)
         res["ddp_rel_vs_plain"] = rel(ddp_f, plain_ag)
         res["ddp_scaler_rel"] = rel(ddp_s, ddp_f)
-        res["torch_vs_fused_adamw_rel"] = rel(plain, m0.store.flat)   # informational: different arithmetic order of the update
+        # informational: torch.optim.AdamW vs the fused kernel agree to 1.5e-8 after one step and then drift apart like any two
+        # last-bit-different Adam runs do (1.6e-6 after two steps, 1.7e-4 after three on this model: a 1e-8 parameter difference flips
+        # bf16 roundings of the next forward, and Adam's normalised update amplifies gradient noise on near-zero-gradient elements)
+        res["torch_vs_fused_adamw_rel"] = rel(plain, m0.store.flat)
         torch.cuda.synchronize()
         dist.barrier(device_ids=[0])
         dist.destroy_process_group()
