@@ -81,9 +81,15 @@ _GEMM_WS = {}   # device index -> workspace tensor of the split-K tail (kept ali
 GEMM_WS_BYTES = 4096 + 512 * 256 * 256 * 4   # counters + 512 slabs of 256 KiB (the auto plans use <= 256; forced sweeps up to 512): 128 MiB of 288 GB
 
 
+_SPLITK_WANTED = False   # the split-K tail is off by default: no scratch buffer until a plan is switched on (gemm_set_config(300 | 302..316))
+
+
 def _ensure_gemm_workspace(device: torch.device):
     """the split-K tail of the 4-wave GEMM needs a caller-owned scratch buffer (slam_gemm_set_workspace); registered once per
-    process, on the first product (one process drives one GPU: a second device would need its own library state)."""
+    process, on the first product after a plan was switched on (one process drives one GPU: a second device would need its own
+    library state)."""
+    if not _SPLITK_WANTED:
+        return
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx in _GEMM_WS:
         return
@@ -160,6 +166,7 @@ if os.environ.get("SLAM_GEMM_BIG_SHORTK"):
 if os.environ.get("SLAM_GEMM_SPLITK"):       # sweeps: off | auto | <slices>
     _sk = os.environ["SLAM_GEMM_SPLITK"]
     call("slam_gemm_set_config", 301 if _sk == "off" else (300 if _sk == "auto" else 300 + int(_sk)))
+    _SPLITK_WANTED = _sk != "off"
 
 
 def gemm_kernel_name(M: int, N: int, K: int = 1 << 30) -> str:
@@ -179,6 +186,9 @@ def gemm_set_config(cfg: int):
     """0 = auto rule, 1 2 3 4 6 7 12 = force one kernel (tools / tests); 100 + v / 200 + v = which 256x256 kernel the auto rule uses
     for K > 2048 / K <= 2048 (sweeps)"""
     global _GEMM_CFG
+    global _SPLITK_WANTED
+    if cfg == 300 or 302 <= cfg <= 316:
+        _SPLITK_WANTED = True
     if cfg in (601, 611):
         _GEMM_BIG["small"] = cfg - 600
     elif cfg >= 300:    # 300 / 301 / 302..316: split-K tail auto / off / forced slices; 400 / 401: cycle stamps off / on
