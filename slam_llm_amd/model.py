@@ -36,8 +36,12 @@ import os as _os
 FUSE_SWIGLU_BWD = _os.environ.get("SLAM_FUSED_SWIGLU_BWD", "0") == "1"
 # HuBERT / WavLM positional conv as one implicit-GEMM launch (slam_pos_conv_fwd); SLAM_POS_CONV_FUSED=0: 16 x (im2col + GEMM)
 POS_CONV_FUSED = _os.environ.get("SLAM_POS_CONV_FUSED", "1") == "1"
-# SwiGLU forward inside the gate|up product's epilogue (slam_gemm_swiglu_bf16_nt): on unless SLAM_FUSED_SWIGLU_FWD=0
-FUSE_SWIGLU_FWD = _os.environ.get("SLAM_FUSED_SWIGLU_FWD", "1") == "1"
+# SwiGLU forward inside the gate|up product's epilogue (slam_gemm_swiglu_bf16_nt).  Correct (bit-identical to product -> swiglu_fwd) and
+# tested, but measured NEUTRAL on the C3 step like its backward twin (three A/Bs on two boxes: -1.3, -0.5, +0.3 ms of ~394: the 5.5 ms
+# elementwise pass it removes comes back as a 1.5x larger store tail in the 32 gate|up launches, 4-wave epilogue, one workgroup per
+# CU) -- and it keeps a third, block-interleaved copy of every [gate ; up] weight (7.5 GB at Llama-3-8B).  Off unless
+# SLAM_FUSED_SWIGLU_FWD=1.
+FUSE_SWIGLU_FWD = _os.environ.get("SLAM_FUSED_SWIGLU_FWD", "0") == "1"
 LORA_PAD = 64  # K-extension granule (GEMM K-tile)
 
 

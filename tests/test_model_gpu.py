@@ -179,6 +179,38 @@ def test_unfrozen_encoder_rejects_unimplemented_combinations(dev):
         SlamHipModel(dict(C["cfg"], freeze_encoder=False, varlen_encoder=True), dev)
 
 
+def test_fused_swiglu_forward_step_is_bit_identical(dev, monkeypatch):
+    """SLAM_FUSED_SWIGLU_FWD=1 (gate|up product with silu(gate) * up in its epilogue + block-interleaved stash read by the backward):
+    the whole step -- loss, accuracy, every gradient -- is bit-identical to the default path (product -> swiglu_fwd -> ... ->
+    swiglu_bwd), at a geometry where the auto rule runs the 4-wave kernel on the gate|up product (M = 12 x 380 = 4560, N = 2 x 1024,
+    K = 4096)."""
+    from slam_llm_amd import model as model_mod, ops
+    cfg = dict(O.make_config(), enc_layers=1, llm_dim=4096, llm_layers=1, llm_heads=32, llm_kv_heads=8, llm_head_dim=128, llm_ffn=1024,
+               vocab=2048, lora_dropout=0.0)
+    W = O.init_weights(cfg, seed=42)
+    audio = O.synth_audio(12, 30.0, seed=77)
+    ob = O.synth_batch(cfg, audio, prompt_len=16, answer_lens=(64,), seed=78, left_pad=False, pad_to_30s=True)
+    gb = {k: v.to(dev) for k, v in ob.items()}
+    M = ob["input_ids"].numel()
+    assert M == 4560 and ops.gemm_swiglu_supported(M, 2048, 4096, 4096, 4096)
+    res = []
+    for fused in (False, True):
+        monkeypatch.setattr(model_mod, "FUSE_SWIGLU_FWD", fused)
+        m = model_mod.SlamHipModel(dict(cfg), dev).load_weights(W)
+        m.train()
+        assert (m.llm.layers[0].gu.Wil is not None) == fused
+        ops.TIMER = ops.KernelTimer()
+        try:
+            out, acc = m(**{k: v.clone() for k, v in gb.items()})
+            out.loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.TIMER = None
+        res.append((out.loss.detach().clone(), acc.clone(), m.store.grad.clone()))
+    for a, b_ in zip(*res):
+        assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize("ragged", [False, True])
 def test_unfrozen_hubert_encoder_matches_oracle(dev, ragged):
     """row f4: train_config.freeze_encoder=false with the HuBERT encoder (models/slam_model.py:110-113 + :335-341) -- the hand-written
