@@ -181,7 +181,12 @@ int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
                   void* dQ, int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv, int64_t B,
                   int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D,
                   int causal, float scale, const float* rope_cos, const float* rope_sin, const int32_t* rope_pos,
-                  const int32_t* seg_lo, const int32_t* seg_hi, float drop_p, uint64_t drop_seed, void* stream);
+                  const int32_t* seg_lo, const int32_t* seg_hi, float drop_p, uint64_t drop_seed, const float* rp_gate,
+                  const float* rp_tab, int64_t rp_T, int64_t rp_ld, float* rp_ds, float* d_gate, float* d_tab, void* stream);
+/* rp_gate (nullable) ... d_tab: backward of WavLM's gated relative position bias (unfrozen WavLM; models/wavlm/modules.py:504-533;
+ * head_dim 64, bidirectional MHA): rp_gate / rp_tab / rp_T / rp_ld as in slam_attn_fwd; rp_ds = scratch [B, Hq, Tq, Tkp] f32 that
+ * receives dL/d(score); d_gate [B, Hq, Tqp] f32 receives dL/d(gate); d_tab [Hq, rp_ld] f32 is ACCUMULATED into (the table is
+ * shared by all layers: zero it once per backward). */
 
 /* ---- a11: grouped positional convolution of HuBERT / WavLM as one implicit-GEMM launch ------------------------------------
  * fairseq `pos_conv` (Conv1d(d, d, k = taps, padding = taps / 2, groups) + SamePad + GELU) and the residual add around it

@@ -26,6 +26,7 @@
 // never masked.  A row with no visible key yields O = 0, LSE = +inf (P = 0 in the backward)
 // so pad rows stay finite.  Positions/rows beyond T are handled by clamped/zero loads and guarded stores.
 #include "common.h"
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -64,6 +65,9 @@ struct AttnParams {
   const float* rp_gate;
   const float* rp_tab;
   int rp_T, rp_ld;
+  // backward of that bias (unfrozen WavLM): the dQ kernel also writes dL/d(score) [B, Hq, Tq, Tkp] f32 (zeros where masked); the
+  // gradients of the gate and of the table are row / diagonal reductions of it (attn_relpos_grad_kernels), no atomics
+  float* rp_ds;
   // dropout on the attention probabilities (HF Blip2QFormer `attention_probs_dropout_prob`, train mode; D = 64 bidirectional
   // kernels only): P is normalised with the full row sum, then element (b, h, q, k) is kept with the counter-based mask of
   // slam_dropout_bf16 at index ((b*Hq + h)*Tqp + q)*Tkp + k and scaled by 1/(1-p) before the second product; the backward
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 // last product are keys 8 g .. 8 g + 7 and its K^T operand is ONE 16-byte LDS read.  With QF = 2 every K / V / K^T
 // fragment read from LDS feeds two MFMAs (at QF = 1 the kernel issues one b128 read per MFMA and is LDS-bound).
 // ------------------------------------------------------------------------------------------
-template <int D, bool CAUSAL, bool DROP = false, int QF = 1>
+template <int D, bool CAUSAL, bool DROP = false, int QF = 1, bool RP = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
@@ -763,6 +767,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     qlo[f] = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(q, Tq - 1)] : 0;
   }
   const float sl2 = p.scale * LOG2E;
+  float rp_g[QF];   // gate[b, h, q] in log2 units (RP: gated relative position bias, as in the forward)
+#pragma unroll
+  for (int f = 0; f < QF; f++)
+    rp_g[f] = RP ? p.rp_gate[((int64_t)b * p.Hq + h) * Tqp + min(qw0 + f * 16 + li, Tq - 1)] * LOG2E : 0.f;
 
   f32x4_t dq[QF][DF];
 #pragma unroll
@@ -859,9 +867,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
         for (int r = 0; r < 4; r++) {
           const int key = kb + r;
           const bool ok = ((mk >> (8 * r)) & 0xffu) != 0 && key < Tk && (!CAUSAL || key <= q) && qok && key >= qlo[f];
-          const float pv = ok ? fast_exp2(st[f][kf][r] * sl2 - lse2[f]) : 0.f;
+          float bias = 0.f;
+          if constexpr (RP) bias = rp_g[f] * p.rp_tab[(int64_t)h * p.rp_ld + (key - min(q, Tq - 1) + p.rp_T - 1)];
+          const float pv = ok ? fast_exp2(fmaf(st[f][kf][r], sl2, bias) - lse2[f]) : 0.f;
           const float dpm = DROP ? (((keep >> r) & 1u) ? dpt[f][kf][r] * p.drop_scale : 0.f) : dpt[f][kf][r];   // d(dropped P) -> dP
-          st[f][kf][r] = pv * (dpm - delta[f]) * p.scale;
+          const float ds0 = pv * (dpm - delta[f]);      // dL/d(score) of (q, key)
+          if constexpr (RP) {
+            if (qok && key < Tkp) p.rp_ds[(((int64_t)b * p.Hq + h) * Tq + q) * Tkp + key] = ds0;
+          }
+          st[f][kf][r] = ds0 * p.scale;
         }
       }
       dsb[f] = pack_frag(st[f][0], st[f][1]);
@@ -896,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 // LDS and shared by the four waves;  S = Q K^T, dP = dO V^T (lane owns key (l&15), 4 consecutive queries),
 //   dV^T += dO^T(as [d x q]) . P,   dK^T += Q^T(as [d x q]) . dS
 // ------------------------------------------------------------------------------------------
-template <int D, bool CAUSAL, bool DROP = false>
+template <int D, bool CAUSAL, bool DROP = false, bool RP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
@@ -1031,7 +1045,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
       for (int r = 0; r < 4; r++) {
         const int q = qb + r;
         const bool ok = kok && q < Tq && (!CAUSAL || key <= q) && q < khi;
-        const float pv = ok ? fast_exp2(s[f][r] * sl2 - ls[r] * LOG2E) : 0.f;
+        float bias = 0.f;
+        if constexpr (RP) {
+          const int qq = min(q, Tq - 1);
+          bias = p.rp_gate[((int64_t)b * p.Hq + h) * Tqp + qq] * LOG2E * p.rp_tab[(int64_t)h * p.rp_ld + (min(key, Tk - 1) - qq + p.rp_T - 1)];
+        }
+        const float pv = ok ? fast_exp2(fmaf(s[f][r], sl2, bias) - ls[r] * LOG2E) : 0.f;
         bool kept = true;   // this lane walks QUERIES: one mask word per element (its key is bit key & 3 of the word)
         if constexpr (DROP) kept = (attn_keep4(p, b * p.Hq + h, min(q, Tq - 1), key & ~3) >> (key & 3)) & 1u;
         pm[f][r] = DROP ? (kept ? pv * p.drop_scale : 0.f) : pv;                                  // dV sees the dropped P
@@ -1664,6 +1683,45 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
   }
 }
 
+// ---- gradients of WavLM's gated relative position bias from dL/d(score) (written by attn_bwd_dq_kernel<..., RP>) ----
+// score(b, h, q, k) += gate[b, h, q] * tab[h][k - q + T - 1]  (src/slam_llm/models/wavlm/modules.py:504-533)
+//   d gate[b, h, q] = sum_k ds[b, h, q, k] * tab[h][k - q + T - 1]                      one wave per row, fixed-order lane sums
+//   d tab[h][r]    += sum_b sum_q gate[b, h, q] * ds[b, h, q, q + r - (T - 1)]           one thread per distance r: consecutive threads
+//                                                                                        read consecutive keys; no atomics, bit-reproducible
+__global__ __launch_bounds__(256) void relpos_dgate_kernel(const float* __restrict__ ds, const float* __restrict__ tab, float* __restrict__ dgate,
+                                                           int B, int H, int Tq, int Tk, int Tkp, int Tqp, int rp_T, int rp_ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t rows = (int64_t)B * H * Tq;
+  for (int64_t row = blockIdx.x * 4ll + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int q = (int)(row % Tq);
+    const int64_t bh = row / Tq;
+    const int h = (int)(bh % H);
+    const float* d = ds + row * Tkp;
+    const float* t = tab + (int64_t)h * rp_ld + (rp_T - 1 - q);
+    float acc = 0.f;
+    for (int k = lane; k < Tk; k += 64) acc = fmaf(d[k], t[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) dgate[bh * Tqp + q] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void relpos_dtab_kernel(const float* __restrict__ ds, const float* __restrict__ gate, float* __restrict__ dtab,
+                                                          int B, int H, int Tq, int Tk, int Tkp, int Tqp, int rp_T, int rp_ld) {
+  const int r = blockIdx.x * 256 + threadIdx.x;     // table index = k - q + rp_T - 1
+  const int h = blockIdx.y;
+  if (r >= 2 * rp_T - 1) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; b++) {
+    const float* d = ds + ((int64_t)b * H + h) * Tq * Tkp;
+    const float* gt = gate + ((int64_t)b * H + h) * Tqp;
+    for (int q = 0; q < Tq; q++) {
+      const int k = q + r - (rp_T - 1);
+      if (k >= 0 && k < Tk) acc = fmaf(gt[q], d[(int64_t)q * Tkp + k], acc);
+    }
+  }
+  dtab[(int64_t)h * rp_ld + r] += acc;
+}
+
 int g_attn_xcd = 1;   // 1 = XCD-aware workgroup numbering (shipped), 0 = hardware round-robin order (A/B in tools)
 
 // every attention kernel is launched through this: logical 3-D grid -> 1-D launch + the geometry attn_blk() needs
@@ -1842,8 +1900,13 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
                              int64_t lddk, void* dV, int64_t lddv, int64_t B, int64_t Tq, int64_t Tk, int64_t Tqp,
                              int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
                              const float* rope_cos, const float* rope_sin, const int32_t* rope_pos,
-                             const int32_t* seg_lo, const int32_t* seg_hi, float drop_p, uint64_t drop_seed, void* stream) {
+                             const int32_t* seg_lo, const int32_t* seg_hi, float drop_p, uint64_t drop_seed, const float* rp_gate,
+                             const float* rp_tab, int64_t rp_T, int64_t rp_ld, float* rp_ds, float* d_gate, float* d_tab, void* stream) {
   SLAM_CHECK_ARG(Q && K && V && Qt && Kt && O && dO && dOt && LSE && Delta && dQ && dK && dV, "slam_attn_bwd: null pointer");
+  SLAM_CHECK_ARG(!rp_gate || (rp_tab && rp_ds && d_gate && d_tab && D == 64 && !causal && !seg_lo && !rope_cos && drop_p == 0.f && Hq == Hkv &&
+                              rp_T >= Tq && rp_T >= Tk && rp_ld >= 2 * rp_T - 1),
+                 "slam_attn_bwd: the gated relative position bias needs rp_tab / rp_ds / d_gate / d_tab, head_dim 64, bidirectional unpacked MHA "
+                 "without dropout or fused RoPE, and a table covering the sequence");
   SLAM_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "slam_attn_bwd: drop_p=%f must be in [0, 1)", (double)drop_p);
   SLAM_CHECK_ARG(drop_p == 0.f || (D == 64 && !causal && !seg_lo && !rope_cos),
                  "slam_attn_bwd: attention-probability dropout is implemented for head_dim 64, bidirectional, unpacked batches");
@@ -1866,7 +1929,20 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.drop_thresh = drop_p > 0.f ? slam_drop_thresh16(drop_p) : 0u;
   p.drop_scale = 1.0f / (1.0f - drop_p);
   p.drop_seed = drop_seed;
+  p.rp_gate = rp_gate; p.rp_tab = rp_tab; p.rp_T = (int)rp_T; p.rp_ld = (int)rp_ld; p.rp_ds = rp_ds;
   hipStream_t s = (hipStream_t)stream;
+  if (rp_gate) {   // WavLM (unfrozen): the bias joins the recomputed scores; dL/d(score) is materialised once and reduced twice
+    dim3 gq_((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B), gk_((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);
+    attn_launch((attn_bwd_dq_kernel<64, false, false, 1, true>), gq_, 256, 0, s, p);
+    attn_launch((attn_bwd_dkdv_kernel<64, false, false, true>), gk_, 256, 0, s, p);
+    const int64_t rows = B * Hq * Tq;
+    hipLaunchKernelGGL(relpos_dgate_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(rows, 4), 65535 * 4)), dim3(256), 0, s, rp_ds, rp_tab, d_gate, (int)B,
+                       (int)Hq, (int)Tq, (int)Tk, (int)Tkp, (int)Tqp, (int)rp_T, (int)rp_ld);
+    hipLaunchKernelGGL(relpos_dtab_kernel, dim3((unsigned)cdiv64(2 * rp_T - 1, 256), (unsigned)Hq), dim3(256), 0, s, rp_ds, rp_gate, d_tab, (int)B,
+                       (int)Hq, (int)Tq, (int)Tk, (int)Tkp, (int)Tqp, (int)rp_T, (int)rp_ld);
+    SLAM_CHECK_LAUNCH("slam_attn_bwd");
+    return 0;
+  }
   if (drop_p > 0.f) {   // same mask as the forward, recomputed (round-1 dK/dV kernel: the ring kernel has no dropout form)
     dim3 gq_((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B), gk_((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);
     attn_launch((attn_bwd_dq_kernel<64, false, true>), gq_, 256, 0, s, p);

@@ -496,12 +496,15 @@ def wavlm_gate(x2d: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, grep_a: t
 
 
 def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T, Hq, Hkv, D, causal, scale,
-             key_mask=None, Tk=None, rope=None, seg=None, drop=None):
+             key_mask=None, Tk=None, rope=None, seg=None, drop=None, relpos=None):
     """rope = (cos, sin[, positions]) tables: dq/dk come out as gradients w.r.t. the pre-RoPE projections (fused
     epilogue; explicit int32 positions for packed batches).  seg = (lo, hi): packed sequences, see attn_fwd."""
     Tk = Tk or T
     Tqp, Tkp = qt.shape[-1], kt.shape[-1]
     delta = torch.empty((B, Hq, Tqp), dtype=torch.float32, device=q2d.device)
+    # relpos = (gate [B,Hq,Tqp] f32, table from relpos_table(), rp_T, d_gate [B,Hq,Tqp] f32 OUT, d_table (same layout as the table, ACCUMULATED)):
+    # WavLM's gated relative position bias in the backward (unfrozen WavLM); dL/d(score) goes through a scratch buffer
+    rp_ds = torch.empty((B, Hq, T, Tkp), dtype=torch.float32, device=q2d.device) if relpos else None
     _timed("attn_bwd", 10.0 * B * Hq * T * Tk * D * (0.5 if causal else 1.0),
            lambda: call("slam_attn_bwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(v2d), _ld(v2d), _p(qt), _p(kt),
                         _p(o2d), _ld(o2d), _p(do2d), _ld(do2d), _p(dot), _p(lse), _p(delta), _p(key_mask), _p(dq2d),
@@ -509,7 +512,10 @@ def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T,
                         1 if causal else 0, scale, _p(rope[0]) if rope else None, _p(rope[1]) if rope else None,
                         _p(rope[2]) if rope and len(rope) > 2 else None, _p(seg[0]) if seg else None,
                         _p(seg[1]) if seg else None, float(drop[0]) if drop else 0.0,
-                        (int(drop[1]) & (2 ** 64 - 1)) if drop else 0, _s()))
+                        (int(drop[1]) & (2 ** 64 - 1)) if drop else 0,
+                        _p(relpos[0]) if relpos else None, (relpos[1].data_ptr() + 64 * 4) if relpos else None, relpos[2] if relpos else 0,
+                        relpos[1].shape[1] if relpos else 0, _p(rp_ds), _p(relpos[3]) if relpos else None,
+                        (relpos[4].data_ptr() + 64 * 4) if relpos else None, _s()))
     return delta
 
 

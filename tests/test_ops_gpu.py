@@ -285,6 +285,70 @@ def test_gemm_rejects_bad_shapes(dev):
         ops.gemm_nt(torch.zeros(8, 64, dtype=torch.bfloat16), torch.zeros(8, 64, dtype=torch.bfloat16))
 
 
+# ----------------------------------------------------------------------------------------- attention: relpos-bias backward
+@pytest.mark.parametrize("T,masked", [(150, False), (200, True)])
+def test_attn_bwd_with_gated_relative_position_bias(dev, T, masked):
+    """unfrozen WavLM (modules.py:504-533): score = scale q.k + gate[b,h,q] * table[h][k - q + T - 1].  The backward kernels recompute P with
+    the bias; the dQ kernel materialises dL/d(score), from which d(gate) (row sums against the table) and d(table) (diagonal sums weighted by
+    the gate, accumulated) are reduced.  Against torch autograd in fp32: dQ / dK / dV cosine >= 0.999 and max err <= 3e-2 max|ref|; d(gate),
+    d(table) cosine >= 0.999 (d(table) checked after TWO backward calls = twice the single-call value: it accumulates)."""
+    ops = _ops()
+    B, H, D = 2, 3, 64
+    Tp = ops.round_up(T, 64)
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(B * T, 3 * H * D, generator=g) * 1.0).to(torch.bfloat16).to(dev)
+    q2d, k2d, v2d = qkv[:, : H * D], qkv[:, H * D: 2 * H * D], qkv[:, 2 * H * D:]
+    do2d = torch.randn(B * T, H * D, generator=g).to(torch.bfloat16).to(dev)
+    gate = (1.0 + torch.rand(B, H, T, generator=g)).to(dev)
+    tabv = (torch.randn(H, 2 * T - 1, generator=g) * 0.5).to(dev)
+    km = None
+    if masked:
+        km = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
+        km[0, :T] = 1
+        km[1, : T - 37] = 1
+    scale = D ** -0.5
+
+    def tr(x2d):
+        t = torch.zeros((B, H, D, Tp), dtype=torch.bfloat16, device=dev)
+        t[..., :T] = x2d.view(B, T, H, D).permute(0, 2, 3, 1)
+        return t
+    gate_p = torch.zeros((B, H, Tp), dtype=torch.float32, device=dev)
+    gate_p[..., :T] = gate
+    tab = ops.relpos_table(tabv)
+    vt, qt, kt, dot = tr(v2d), tr(q2d), tr(k2d), tr(do2d)
+    o2d, lse = ops.attn_fwd(q2d, k2d, vt, B, T, H, H, D, False, scale, key_mask=km, relpos=(gate_p, tab, T))
+    dq, dk, dv = torch.empty_like(q2d), torch.empty_like(k2d), torch.empty_like(v2d)
+    d_gate = torch.zeros_like(gate_p)
+    d_tab = torch.zeros_like(tab)
+    for _ in range(2):
+        ops.attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq, dk, dv, B, T, H, H, D, False, scale, key_mask=km,
+                     relpos=(gate_p, tab, T, d_gate, d_tab))
+    # fp32 reference
+    qf = q2d.float().view(B, T, H, D).transpose(1, 2).detach().requires_grad_(True)
+    kf = k2d.float().view(B, T, H, D).transpose(1, 2).detach().requires_grad_(True)
+    vf = v2d.float().view(B, T, H, D).transpose(1, 2).detach().requires_grad_(True)
+    gr = gate.clone().requires_grad_(True)
+    tr_ = tabv.clone().requires_grad_(True)
+    idx = (torch.arange(T, device=dev)[None, :] - torch.arange(T, device=dev)[:, None] + T - 1)      # [q, k] -> k - q + T - 1
+    sc = (qf @ kf.transpose(2, 3)) * scale + gr[..., None] * tr_[:, idx][None]
+    if masked:
+        sc = sc.masked_fill(km[:, None, None, :T] == 0, float("-inf"))
+    o_ref = torch.softmax(sc, -1) @ vf
+    (o_ref * do2d.float().view(B, T, H, D).transpose(1, 2)).sum().backward()
+    back = lambda t: t.transpose(1, 2).reshape(B * T, H * D)  # noqa: E731
+    assert_close(o2d, back(o_ref.detach()), atol=2e-2, rtol=2e-2, what="forward with bias")
+    for name, got, ref in (("dQ", dq, back(qf.grad)), ("dK", dk, back(kf.grad)), ("dV", dv, back(vf.grad))):
+        cs = float((got.float() * ref).sum() / (got.float().norm() * ref.norm() + 1e-30))
+        err = float((got.float() - ref).abs().max())
+        assert cs >= 0.999 and err <= 3e-2 * float(ref.abs().max()), f"{name}: cosine {cs}, max err {err}"
+    cs = float((d_gate[..., :T] * gr.grad).sum() / (d_gate[..., :T].norm() * gr.grad.norm() + 1e-30))
+    assert cs >= 0.999 and abs(float(d_gate[..., :T].norm()) / float(gr.grad.norm()) - 1) < 3e-2, f"d(gate): cosine {cs}"
+    got_t = d_tab[:, 64: 64 + 2 * T - 1]
+    cs = float((got_t * 2 * tr_.grad).sum() / (got_t.norm() * (2 * tr_.grad).norm() + 1e-30))
+    assert cs >= 0.999 and abs(float(got_t.norm()) / float((2 * tr_.grad).norm()) - 1) < 3e-2, f"d(table): cosine {cs}"
+    assert float(d_tab[:, :64].abs().max()) == 0 and float(d_tab[:, 64 + 2 * T - 1:].abs().max()) == 0      # the slack stays untouched
+
+
 # ----------------------------------------------------------------------------------------- grouped positional conv
 @pytest.mark.parametrize("C,K,T", [(64, 128, 300), (48, 128, 517), (32, 16, 100), (64, 127, 256), (80, 128, 300)])
 def test_pos_conv_one_launch_matches_torch_grouped_conv(dev, C, K, T):
