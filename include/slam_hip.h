@@ -167,6 +167,21 @@ int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
  * with 64 readable floats before and after each row's 2 rp_T - 1 entries. */
 int slam_wavlm_gate(const void* x, int64_t ldx, const float* w, const float* bias, const float* grep_a, float* gate,
                     int64_t B, int64_t T, int64_t H, int64_t Tp, void* stream);
+/* backward of slam_wavlm_gate (unfrozen WavLM): from dgate [B, H, Tp] f32 -> dv [B*T*H, 8] bf16 (dL/d grep_linear outputs: the weight
+ * gradient is the tall-skinny gram dv^T x_h, the bias gradient its column sums), da_term [B*T, Hp] bf16 (column sums = d grep_a; the
+ * caller zero-fills the Hp - H padding columns), dx [B*T, lddx] bf16 (the gate's share of dL/d(attention input), every column of the
+ * H*64 written). */
+/* chain rule of nn.utils.weight_norm(dim = 2) (WavLM's pos_conv.0.weight_g / weight_v, models/wavlm/WavLM.py:378-386): dw, v, dv are
+ * [rows, K] f32 views (rows = d * channels per group, K = taps), g / dg [K]; accumulate adds into dg / dv. */
+int slam_weight_norm_bwd(const float* dw, const float* v, const float* g, float* dg, float* dv, int64_t rows, int64_t K, int accumulate,
+                         void* stream);
+/* gradient of layers.0.self_attn.relative_attention_bias.weight [num_buckets, H] from the gradient of the bias table over the relative
+ * distances (d_table[h][r], r < n = 2T - 1; buckets[r] = bucket of distance r - (T - 1), modules.py:417-455). */
+int slam_relpos_bucket_grad(const float* d_table, int64_t ld, const int32_t* buckets, int64_t n, int64_t H, int64_t num_buckets, float* out,
+                            int accumulate, void* stream);
+int slam_wavlm_gate_bwd(const void* x, int64_t ldx, const float* w, const float* bias, const float* grep_a, const float* dgate,
+                        void* dv, void* da_term, void* dx, int64_t lddx, int64_t B, int64_t T, int64_t H, int64_t Tp, int64_t Hp,
+                        void* stream);
 /* GroupNorm with one group per channel over time + exact GELU: first conv layer of the "default" feature extractor (WavLM Base,
  * reference src/slam_llm/models/wavlm/WavLM.py:428-441, Fp32GroupNorm(dim, dim)).  x fp32 [B*T, ldx] (time rows), y bf16 [B*T, ldy];
  * every (clip, channel) is normalised over its T rows (biased variance); workspace of slam_groupnorm_time_workspace_bytes bytes. */

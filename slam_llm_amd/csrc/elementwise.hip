@@ -716,6 +716,112 @@ __global__ __launch_bounds__(256) void wavlm_gate_kernel(const bf16_t* __restric
   }
 }
 
+// backward of wavlm_gate_kernel (unfrozen WavLM): gate = a (g A - 1) + 2, a = sigmoid(sum of grep_linear outputs 0..3), g = sigmoid(sum of
+// outputs 4..7), A = grep_a[h].  One thread per (row, head), recomputing the forward:
+//   dv[(m, h), j]  = dL/d(grep_linear output j)   (bf16 [M*H, 8]: dW = dv^T x_h as a tall-skinny gram, db = column sums -- both by the
+//                                                   existing fixed-order kernels, nothing is reduced with atomics here)
+//   da_term[m, h]  = dgate * a * g                 (bf16 [M, Hp]: d grep_a = its column sums)
+//   dx[m, h*64 + c] = sum_j dv_j * w[j][c]          (bf16: the gate's contribution to dL/d(attention input))
+__global__ __launch_bounds__(256) void wavlm_gate_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const float* __restrict__ grep_a,
+                                                             const float* __restrict__ dgate, bf16_t* __restrict__ dv, bf16_t* __restrict__ da_term,
+                                                             bf16_t* __restrict__ dx, int64_t lddx, int B, int T, int H, int Tp, int Hp) {
+  __shared__ float ws[8 * 64 + 8 + 128];   // w, bias, then wa[c] = sum_{j<4} w[j][c] and wg[c] = sum_{j>=4} w[j][c]
+  for (int i = threadIdx.x; i < 8 * 64 + 8; i += 256) ws[i] = i < 512 ? w[i] : bias[i - 512];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x & 63, j0 = (threadIdx.x >> 6) * 4;
+    ws[520 + threadIdx.x] = ws[j0 * 64 + c] + ws[(j0 + 1) * 64 + c] + ws[(j0 + 2) * 64 + c] + ws[(j0 + 3) * 64 + c];
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)B * T * H;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int h = (int)(i % H);
+    const int64_t m = i / H;
+    const int t = (int)(m % T), b = (int)(m / T);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = ws[512 + j];
+    u16x8_t xv[8];
+#pragma unroll
+    for (int c8 = 0; c8 < 8; c8++) {
+      xv[c8] = *reinterpret_cast<const u16x8_t*>(x + m * ldx + h * 64 + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float xf = bf2f(xv[c8][e]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = fmaf(xf, ws[j * 64 + c8 * 8 + e], v[j]);
+      }
+    }
+    const float a = 1.f / (1.f + __expf(-(v[0] + v[1] + v[2] + v[3])));
+    const float g = 1.f / (1.f + __expf(-(v[4] + v[5] + v[6] + v[7])));
+    const float A = grep_a[h];
+    const float dg_ = dgate[((int64_t)b * H + h) * Tp + t];
+    const float dsa = dg_ * (g * A - 1.f) * a * (1.f - a);
+    const float dsg = dg_ * a * A * g * (1.f - g);
+    u16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = f2bf(j < 4 ? dsa : dsg);
+    *reinterpret_cast<u16x8_t*>(dv + i * 8) = o;
+    da_term[m * Hp + h] = f2bf(dg_ * a * g);
+#pragma unroll
+    for (int c8 = 0; c8 < 8; c8++) {
+      u16x8_t d8;
+#pragma unroll
+      for (int e = 0; e < 8; e++) d8[e] = f2bf(fmaf(dsa, ws[520 + c8 * 8 + e], dsg * ws[584 + c8 * 8 + e]));
+      *reinterpret_cast<u16x8_t*>(dx + m * lddx + h * 64 + c8 * 8) = d8;
+    }
+  }
+}
+
+// chain rule of nn.utils.weight_norm(dim = 2) on a [rows, K] view of the positional conv weight (rows = d * channels per group, K = taps):
+// w[:, k] = g[k] v[:, k] / ||v[:, k]||  ->  dg[k] = <dw[:, k], v[:, k]> / n,  dv[:, k] = g[k] / n (dw[:, k] - v[:, k] <dw, v> / n^2).
+// One workgroup per tap (fixed-order block reductions: bit-reproducible); the tensor is 8 M elements at WavLM-Large.
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v, const float* __restrict__ g,
+                                                              float* __restrict__ dg, float* __restrict__ dv, int rows, int K, int accumulate) {
+  __shared__ float red[2][256];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  float svv = 0.f, sdv = 0.f;
+  for (int r = tid; r < rows; r += 256) {
+    const float vv = v[(int64_t)r * K + k], dd = dw[(int64_t)r * K + k];
+    svv = fmaf(vv, vv, svv);
+    sdv = fmaf(dd, vv, sdv);
+  }
+  red[0][tid] = svv;
+  red[1][tid] = sdv;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      red[0][tid] += red[0][tid + o];
+      red[1][tid] += red[1][tid + o];
+    }
+    __syncthreads();
+  }
+  svv = red[0][0];
+  sdv = red[1][0];
+  const float n = sqrtf(svv), gk = g[k];
+  if (tid == 0) dg[k] = (accumulate ? dg[k] : 0.f) + sdv / n;
+  const float c1 = gk / n, c2 = sdv / svv;
+  for (int r = tid; r < rows; r += 256) {
+    const int64_t i = (int64_t)r * K + k;
+    const float val = c1 * (dw[i] - v[i] * c2);
+    dv[i] = accumulate ? dv[i] + val : val;
+  }
+}
+
+// d(relative_attention_bias.weight)[bucket, h] (+)= sum over the distances r that fall in the bucket of d_table[h][r]
+// (the bias table is the embedding gathered per relative distance, modules.py:444-455): one thread per (bucket, head), fixed order
+__global__ __launch_bounds__(256) void relpos_bucket_grad_kernel(const float* __restrict__ d_tab, int64_t ld, const int* __restrict__ buckets, int n,
+                                                                 int H, int nb, float* __restrict__ out, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nb * H) return;
+  const int bucket = i / H, h = i % H;
+  float acc = 0.f;
+  for (int r = 0; r < n; r++)
+    if (buckets[r] == bucket) acc += d_tab[(int64_t)h * ld + r];
+  out[i] = accumulate ? out[i] + acc : acc;
+}
+
 inline unsigned ew_grid(int64_t total_items) {
   int64_t g = cdiv64(total_items, 256);
   if (g > 16384) g = 16384;
@@ -842,6 +948,36 @@ extern "C" int slam_wavlm_gate(const void* x, int64_t ldx, const float* w, const
   hipLaunchKernelGGL(wavlm_gate_kernel, dim3(ew_grid(B * T * H)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, w, bias,
                      grep_a, gate, (int)B, (int)T, (int)H, (int)Tp);
   SLAM_CHECK_LAUNCH("slam_wavlm_gate");
+  return 0;
+}
+
+extern "C" int slam_weight_norm_bwd(const float* dw, const float* v, const float* g, float* dg, float* dv, int64_t rows, int64_t K, int accumulate,
+                                    void* stream) {
+  SLAM_CHECK_ARG(dw && v && g && dg && dv && rows > 0 && K > 0 && K < 65536 && rows < (1ll << 31), "slam_weight_norm_bwd: bad arguments");
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, dw, v, g, dg, dv, (int)rows, (int)K, accumulate);
+  SLAM_CHECK_LAUNCH("slam_weight_norm_bwd");
+  return 0;
+}
+
+extern "C" int slam_relpos_bucket_grad(const float* d_table, int64_t ld, const int32_t* buckets, int64_t n, int64_t H, int64_t num_buckets,
+                                       float* out, int accumulate, void* stream) {
+  SLAM_CHECK_ARG(d_table && buckets && out && n > 0 && H > 0 && num_buckets > 0 && ld >= n, "slam_relpos_bucket_grad: bad arguments");
+  hipLaunchKernelGGL(relpos_bucket_grad_kernel, dim3((unsigned)cdiv64(num_buckets * H, 256)), dim3(256), 0, (hipStream_t)stream, d_table, ld,
+                     buckets, (int)n, (int)H, (int)num_buckets, out, accumulate);
+  SLAM_CHECK_LAUNCH("slam_relpos_bucket_grad");
+  return 0;
+}
+
+extern "C" int slam_wavlm_gate_bwd(const void* x, int64_t ldx, const float* w, const float* bias, const float* grep_a, const float* dgate,
+                                   void* dv, void* da_term, void* dx, int64_t lddx, int64_t B, int64_t T, int64_t H, int64_t Tp, int64_t Hp,
+                                   void* stream) {
+  SLAM_CHECK_ARG(x && w && bias && grep_a && dgate && dv && da_term && dx, "slam_wavlm_gate_bwd: null pointer");
+  SLAM_CHECK_ARG(B > 0 && T > 0 && H > 0 && Tp >= T && Hp >= H && ldx % 8 == 0 && lddx % 8 == 0 && ldx >= H * 64 && lddx >= H * 64 &&
+                     ((uintptr_t)dv % 16) == 0 && ((uintptr_t)dx % 16) == 0,
+                 "slam_wavlm_gate_bwd: bad shape / alignment (head_dim is 64)");
+  hipLaunchKernelGGL(wavlm_gate_bwd_kernel, dim3(ew_grid(B * T * H)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, w, bias, grep_a,
+                     dgate, (bf16_t*)dv, (bf16_t*)da_term, (bf16_t*)dx, lddx, (int)B, (int)T, (int)H, (int)Tp, (int)Hp);
+  SLAM_CHECK_LAUNCH("slam_wavlm_gate_bwd");
   return 0;
 }
 

@@ -50,6 +50,9 @@ SIGNATURES = {
     "slam_transpose_bf16": [P, I64, P, I64, I64, I64, I64, P],
     "slam_attn_fwd": [P, I64, P, I64, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P, P, I64, I64, F, U64, P],
     "slam_wavlm_gate": [P, I64, P, P, P, P, I64, I64, I64, I64, P],
+    "slam_weight_norm_bwd": [P, P, P, P, P, I64, I64, I32, P],
+    "slam_relpos_bucket_grad": [P, I64, P, I64, I64, I64, P, I32, P],
+    "slam_wavlm_gate_bwd": [P, I64, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, P],
     "slam_groupnorm_time_workspace_bytes": [I64, I64, I64],
     "slam_groupnorm_time_gelu": [P, I64, P, I64, I64, I64, I64, P, P, F, P, P],
     "slam_attn_bwd": [P, I64, P, I64, P, I64, P, P, P, I64, P, I64, P, P, P, P, P, I64, P, I64, P, I64,

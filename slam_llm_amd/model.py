@@ -647,105 +647,141 @@ class HipHubertEncoder(nn.Module):
     def trainable(self) -> bool:
         return self.store is not None
 
+    def _nm(self) -> SimpleNamespace:
+        """logical tensor -> state-dict name of the trainable form (HF HuBERT names; HipWavLMEncoder overrides with the reference WavLM's)"""
+        p = self.prefix
+        e = p + "encoder."
+        c = lambda i: f"{p}feature_extractor.conv_layers.{i}."   # noqa: E731
+        lyr = lambda i: f"{e}layers.{i}."                        # noqa: E731
+        return SimpleNamespace(
+            conv_w=lambda i: c(i) + "conv.weight", conv_b=lambda i: c(i) + "conv.bias", conv_ln=lambda i: c(i) + "layer_norm",
+            fp_ln=p + "feature_projection.layer_norm", fp=p + "feature_projection.projection",
+            pos_w=e + "pos_conv_embed.conv.weight", pos_g=None, pos_v=None, pos_b=e + "pos_conv_embed.conv.bias",
+            q=lambda i: lyr(i) + "attention.q_proj", k=lambda i: lyr(i) + "attention.k_proj", v=lambda i: lyr(i) + "attention.v_proj",
+            out=lambda i: lyr(i) + "attention.out_proj", ln1=lambda i: lyr(i) + "layer_norm",
+            fc1=lambda i: lyr(i) + "feed_forward.intermediate_dense", fc2=lambda i: lyr(i) + "feed_forward.output_dense",
+            ln2=lambda i: lyr(i) + "final_layer_norm", enc_ln=e + "layer_norm")
+
+    def _reserve_extra_layer(self, i: int):
+        """hook: further trainable tensors of layer i (WavLM: the gate of the relative position bias)"""
+
+    def _reserve_extra_top(self):
+        """hook: further trainable tensors outside the layers (WavLM: mask_emb)"""
+
     def _reserve_trainable(self):
-        """every parameter of the encoder joins the flat fp32 store under its (HF) state-dict name, in the order the backward produces
+        """every parameter of the encoder joins the flat fp32 store under its state-dict name, in the order the backward produces
         the gradients (GradSync prefixes): final LayerNorm, layers last -> first, positional conv, feature projection, conv stack
-        last -> first.  Implemented for the HuBERT-large / xlarge graph ("layer_norm" feature extractor, layer_norm_first layers);
-        the weight-normed positional conv trains its FOLDED weight (w = g v / ||v|| is formed once at load: same function, the
-        reference's (g, v) parametrisation of that one tensor is not kept)."""
-        cfg, r, p = self.cfg, self.store.reserve, self.prefix
+        last -> first.  Implemented for the HuBERT-large / xlarge / WavLM-Large graph ("layer_norm" feature extractor, layer_norm_first
+        layers).  HuBERT (HF names): the weight-normed positional conv trains its FOLDED weight (w = g v / ||v|| formed once at load);
+        WavLM (reference names): weight_g / weight_v stay the parameters, the fold and its chain rule run every step."""
+        cfg, r, N = self.cfg, self.store.reserve, self._nm()
         if cfg.get("hub_extractor_mode", "layer_norm") != "layer_norm" or not cfg.get("hub_layer_norm_first", True):
-            raise NotImplementedError("freeze_encoder=false is implemented for the layer_norm-extractor / layer_norm_first HuBERT graph "
-                                      "(large, xlarge); the base geometries (GroupNorm extractor, post-LN layers) stay frozen")
+            raise NotImplementedError("freeze_encoder=false is implemented for the layer_norm-extractor / layer_norm_first graph (HuBERT large / "
+                                      "xlarge, WavLM-Large); the base geometries (GroupNorm extractor, post-LN layers) stay frozen")
         d, Fd = cfg["hub_dim"], cfg["hub_ffn"]
         assert d % 64 == 0 and d // cfg["hub_heads"] == 64
-        e = p + "encoder."
-        r(e + "layer_norm.weight", (d,)); r(e + "layer_norm.bias", (d,))
+        r(N.enc_ln + ".weight", (d,)); r(N.enc_ln + ".bias", (d,))
         for i in reversed(range(cfg["hub_layers"])):
-            q = f"{e}layers.{i}."
-            r(q + "feed_forward.output_dense.weight", (d, Fd)); r(q + "feed_forward.output_dense.bias", (d,))
-            r(q + "feed_forward.intermediate_dense.weight", (Fd, d)); r(q + "feed_forward.intermediate_dense.bias", (Fd,))
-            r(q + "final_layer_norm.weight", (d,)); r(q + "final_layer_norm.bias", (d,))
-            r(q + "attention.out_proj.weight", (d, d)); r(q + "attention.out_proj.bias", (d,))
-            for n in ("q_proj", "k_proj", "v_proj"):     # back to back: the bf16 copies form the fused [3d, d] operand
-                r(q + f"attention.{n}.weight", (d, d))
-            for n in ("q_proj", "k_proj", "v_proj"):     # ... and the fused [3d] bias
-                r(q + f"attention.{n}.bias", (d,))
-            r(q + "layer_norm.weight", (d,)); r(q + "layer_norm.bias", (d,))
-        gch = d // cfg["hub_pos_groups"]
-        r(e + "pos_conv_embed.conv.weight", (d, gch, cfg["hub_pos_k"])); r(e + "pos_conv_embed.conv.bias", (d,))
-        f = p + "feature_projection."
+            r(N.fc2(i) + ".weight", (d, Fd)); r(N.fc2(i) + ".bias", (d,))
+            r(N.fc1(i) + ".weight", (Fd, d)); r(N.fc1(i) + ".bias", (Fd,))
+            r(N.ln2(i) + ".weight", (d,)); r(N.ln2(i) + ".bias", (d,))
+            r(N.out(i) + ".weight", (d, d)); r(N.out(i) + ".bias", (d,))
+            for n in (N.q, N.k, N.v):     # back to back: the bf16 copies form the fused [3d, d] operand
+                r(n(i) + ".weight", (d, d))
+            for n in (N.q, N.k, N.v):     # ... and the fused [3d] bias
+                r(n(i) + ".bias", (d,))
+            self._reserve_extra_layer(i)
+            r(N.ln1(i) + ".weight", (d,)); r(N.ln1(i) + ".bias", (d,))
+        gch, kpos = d // cfg["hub_pos_groups"], cfg["hub_pos_k"]
+        if N.pos_w is not None:
+            r(N.pos_w, (d, gch, kpos))
+        else:
+            r(N.pos_g, (1, 1, kpos)); r(N.pos_v, (d, gch, kpos))
+        r(N.pos_b, (d,))
         cin = cfg["hub_conv_dim"][-1]
-        r(f + "projection.weight", (d, cin)); r(f + "projection.bias", (d,))
-        r(f + "layer_norm.weight", (cin,)); r(f + "layer_norm.bias", (cin,))
+        r(N.fp + ".weight", (d, cin)); r(N.fp + ".bias", (d,))
+        r(N.fp_ln + ".weight", (cin,)); r(N.fp_ln + ".bias", (cin,))
         dims = [1] + list(cfg["hub_conv_dim"])
         for i in reversed(range(len(cfg["hub_conv_dim"]))):
-            c = f"{p}feature_extractor.conv_layers.{i}."
-            r(c + "layer_norm.weight", (dims[i + 1],)); r(c + "layer_norm.bias", (dims[i + 1],))
-            r(c + "conv.weight", (dims[i + 1], dims[i], cfg["hub_conv_kernel"][i])); r(c + "conv.bias", (dims[i + 1],))
+            r(N.conv_ln(i) + ".weight", (dims[i + 1],)); r(N.conv_ln(i) + ".bias", (dims[i + 1],))
+            r(N.conv_w(i), (dims[i + 1], dims[i], cfg["hub_conv_kernel"][i]))
+            if N.conv_b is not None:
+                r(N.conv_b(i), (dims[i + 1],))
+        self._reserve_extra_top()
 
     def bind(self):
+        # this module is SlamHipModel.encoder: the registered path below it is the name minus "encoder." (WavLM keeps its "model." level)
         for name, prm in self.store.params.items():
             if name.startswith(self.prefix):
-                _attach(self, name[len(self.prefix):], prm)
+                _attach(self, name[len("encoder."):], prm)
 
     def _load_trainable(self, W: Dict[str, torch.Tensor], prefix: str):
-        e = prefix + "encoder."
+        N = self._nm()
         with torch.no_grad():
             for name, prm in self.store.params.items():
                 if not name.startswith(self.prefix):
                     continue
                 src = prefix + name[len(self.prefix):]
-                if src == e + "pos_conv_embed.conv.weight" and src not in W:   # weight-norm checkpoint: fold g * v / ||v||
-                    g_, v_ = W[e + "pos_conv_embed.conv.parametrizations.weight.original0"].float(), W[e + "pos_conv_embed.conv.parametrizations.weight.original1"].float()
+                if name == N.pos_w and src not in W:   # HF checkpoint that kept the weight-norm parametrisation: fold g * v / ||v||
+                    base = src[: -len("weight")]
+                    g_, v_ = W[base + "parametrizations.weight.original0"].float(), W[base + "parametrizations.weight.original1"].float()
                     prm.copy_((g_ * v_ / v_.norm(dim=(0, 1), keepdim=True)).to(self.device_))
                 else:
-                    prm.copy_(W[src].to(self.device_))
+                    prm.copy_(W[src].to(self.device_).reshape(prm.shape))
         return self
+
+    def _pos_weight_master(self) -> torch.Tensor:
+        """fp32 [d, gch, kpos] weight of the positional conv as the forward uses it"""
+        N, st = self._nm(), self.store
+        if N.pos_w is not None:
+            return st.master_view(N.pos_w)
+        g_, v_ = st.master_view(N.pos_g), st.master_view(N.pos_v)      # nn.utils.weight_norm(dim=2): w = g * v / ||v||_(0,1)
+        return g_ * v_ / v_.norm(dim=(0, 1), keepdim=True)
 
     def refresh(self):
         """rebuild the bf16 compute copies (and the transposes / packings the backward multiplies by) from the store"""
         if not self.trainable:
             return
-        st, p, cfg, w, dev = self.store, self.prefix, self.cfg, self.w, self.device_
+        st, cfg, w, dev, N = self.store, self.cfg, self.w, self.device_, self._nm()
         d = cfg["hub_dim"]
         cin = 1
         for i, (co, k) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"])):
-            c = f"{p}feature_extractor.conv_layers.{i}."
             kp = round_up(k * cin, 64)
             wc = torch.zeros((co, kp), dtype=torch.bfloat16, device=dev)
-            wc[:, : k * cin] = st.bf16_view(c + "conv.weight").permute(0, 2, 1).reshape(co, k * cin)   # tap-major columns (im2col order)
-            w[f"c{i}"], w[f"c{i}_b"] = wc, st.master_view(c + "conv.bias")
-            w[f"c{i}T"] = ops.transpose(wc, Rp=co)                                                   # [kp, co]: dcols = dy . Wc
-            w[f"c{i}_lw"], w[f"c{i}_lb"] = st.master_view(c + "layer_norm.weight"), st.master_view(c + "layer_norm.bias")
+            wc[:, : k * cin] = st.bf16_view(N.conv_w(i)).permute(0, 2, 1).reshape(co, k * cin)   # tap-major columns (im2col order)
+            w[f"c{i}"] = wc
+            w[f"c{i}_b"] = st.master_view(N.conv_b(i)) if N.conv_b is not None else torch.zeros(co, dtype=torch.float32, device=dev)
+            w[f"c{i}T"] = ops.transpose(wc, Rp=co)                                             # [kp, co]: dcols = dy . Wc
+            w[f"c{i}_lw"], w[f"c{i}_lb"] = st.master_view(N.conv_ln(i) + ".weight"), st.master_view(N.conv_ln(i) + ".bias")
             cin = co
-        f = p + "feature_projection."
-        w["fp_lw"], w["fp_lb"] = st.master_view(f + "layer_norm.weight"), st.master_view(f + "layer_norm.bias")
-        w["fp"], w["fp_b"] = st.bf16_view(f + "projection.weight"), st.master_view(f + "projection.bias")
+        w["fp_lw"], w["fp_lb"] = st.master_view(N.fp_ln + ".weight"), st.master_view(N.fp_ln + ".bias")
+        w["fp"], w["fp_b"] = st.bf16_view(N.fp + ".weight"), st.master_view(N.fp + ".bias")
         w["fpT"] = ops.transpose(w["fp"], Rp=d)
-        e = p + "encoder."
         G, kpos = cfg["hub_pos_groups"], cfg["hub_pos_k"]
         gch = d // G
         self.pos_kp = round_up(kpos * gch, 64)
         pg = torch.zeros((G, gch, self.pos_kp), dtype=torch.bfloat16, device=dev)
-        pg[:, :, : kpos * gch] = st.bf16_view(e + "pos_conv_embed.conv.weight").view(G, gch, gch, kpos).permute(0, 1, 3, 2).reshape(G, gch, kpos * gch)
-        w["pos"], w["pos_b"] = pg, st.master_view(e + "pos_conv_embed.conv.bias")
+        pg[:, :, : kpos * gch] = self._pos_weight_master().to(torch.bfloat16).view(G, gch, gch, kpos).permute(0, 1, 3, 2).reshape(G, gch, kpos * gch)
+        w["pos"], w["pos_b"] = pg, st.master_view(N.pos_b)
         w["pos_tap"] = ops.pos_conv_pack(pg, kpos)
         w["pos_adj"] = ops.pos_conv_pack_adjoint(pg, kpos)
         for i in range(cfg["hub_layers"]):
-            q = f"{e}layers.{i}."
-            off = st.offsets[q + "attention.q_proj.weight"][0]
+            off = st.offsets[N.q(i) + ".weight"][0]
             w[f"{i}.qkv"] = st.flat_bf16[off: off + 3 * d * d].view(3 * d, d)
-            boff = st.offsets[q + "attention.q_proj.bias"][0]
+            boff = st.offsets[N.q(i) + ".bias"][0]
             w[f"{i}.qkv_b"] = st.flat[boff: boff + 3 * d]
-            w[f"{i}.out"], w[f"{i}.out_b"] = st.bf16_view(q + "attention.out_proj.weight"), st.master_view(q + "attention.out_proj.bias")
-            w[f"{i}.ln1_w"], w[f"{i}.ln1_b"] = st.master_view(q + "layer_norm.weight"), st.master_view(q + "layer_norm.bias")
-            w[f"{i}.fc1"], w[f"{i}.fc1_b"] = st.bf16_view(q + "feed_forward.intermediate_dense.weight"), st.master_view(q + "feed_forward.intermediate_dense.bias")
-            w[f"{i}.fc2"], w[f"{i}.fc2_b"] = st.bf16_view(q + "feed_forward.output_dense.weight"), st.master_view(q + "feed_forward.output_dense.bias")
-            w[f"{i}.ln2_w"], w[f"{i}.ln2_b"] = st.master_view(q + "final_layer_norm.weight"), st.master_view(q + "final_layer_norm.bias")
+            w[f"{i}.out"], w[f"{i}.out_b"] = st.bf16_view(N.out(i) + ".weight"), st.master_view(N.out(i) + ".bias")
+            w[f"{i}.ln1_w"], w[f"{i}.ln1_b"] = st.master_view(N.ln1(i) + ".weight"), st.master_view(N.ln1(i) + ".bias")
+            w[f"{i}.fc1"], w[f"{i}.fc1_b"] = st.bf16_view(N.fc1(i) + ".weight"), st.master_view(N.fc1(i) + ".bias")
+            w[f"{i}.fc2"], w[f"{i}.fc2_b"] = st.bf16_view(N.fc2(i) + ".weight"), st.master_view(N.fc2(i) + ".bias")
+            w[f"{i}.ln2_w"], w[f"{i}.ln2_b"] = st.master_view(N.ln2(i) + ".weight"), st.master_view(N.ln2(i) + ".bias")
             for nme in ("qkv", "out", "fc1", "fc2"):
                 w[f"{i}.{nme}T"] = ops.transpose(w[f"{i}.{nme}"], Rp=w[f"{i}.{nme}"].shape[0])
-        w["lnp_w"], w["lnp_b"] = st.master_view(e + "layer_norm.weight"), st.master_view(e + "layer_norm.bias")
+        w["lnp_w"], w["lnp_b"] = st.master_view(N.enc_ln + ".weight"), st.master_view(N.enc_ln + ".bias")
+        self._refresh_extra()
+
+    def _refresh_extra(self):
+        """hook: compute copies of the extra trainable tensors (WavLM)"""
 
     def load(self, W: Dict[str, torch.Tensor], prefix="encoder."):
         if self.trainable:
@@ -985,13 +1021,14 @@ class HipHubertEncoder(nn.Module):
             hh, m1, r1 = ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, stats=True)
             qkv = ops.gemm_nt(hh, w[f"{i}.qkv"], bias=w[f"{i}.qkv_b"])
             vt = ops.head_rope_transpose(qkv, 2 * d, B, T, H, 64)
-            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=True)
+            rp = self._relpos(i, hh, B, T)      # WavLM: (gate [B,H,Tp], bias table, T); HuBERT: None
+            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=True, relpos=rp)
             del vt
             x1 = ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"], residual=x)
             h2, m2, r2 = ops.layernorm(x1, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], eps, stats=True)
             z = ops.gemm_nt(h2, w[f"{i}.fc1"], bias=w[f"{i}.fc1_b"])
             x2 = ops.gemm_nt(ops.gelu_fwd(z), w[f"{i}.fc2"], bias=w[f"{i}.fc2_b"], residual=x1)
-            S["blocks"].append(dict(x=x, m1=m1, r1=r1, h=hh, qkv=qkv, a=a, lse=lse, x1=x1, m2=m2, r2=r2, h2=h2, z=z))
+            S["blocks"].append(dict(x=x, m1=m1, r1=r1, h=hh, qkv=qkv, a=a, lse=lse, x1=x1, m2=m2, r2=r2, h2=h2, z=z, rp=rp))
             x = x2
         out, mo, ro = ops.layernorm(x, w["lnp_w"], w["lnp_b"], eps, stats=True)
         S.update(x_last=x, mo=mo, ro=ro)
@@ -1012,85 +1049,86 @@ class HipHubertEncoder(nn.Module):
 
     def backward_hip(self, dout: torch.Tensor, stash: dict, acc: bool):
         """dout [B*T, d] bf16 = dL/d(encoder output); deposits every encoder gradient into the flat grad buffer (hand-written adjoint of
-        the HuBERT graph of forward_train: HF HubertModel / fairseq HubertModel.extract_features as called at slam_model.py:335-341)"""
-        cfg, w, st, p = self.cfg, self.w, self.store, self.prefix
+        the graph of forward_train: HF HubertModel / fairseq HubertModel.extract_features as called at slam_model.py:335-341, WavLM
+        extract_features :333-334)"""
+        cfg, w, st, N = self.cfg, self.w, self.store, self._nm()
         S = stash.pop("encoder")
         B, T, key_mask = S["B"], S["T"], S["key_mask"]
         d, H = cfg["hub_dim"], cfg["hub_heads"]
         scale = 64 ** -0.5
         gv = st.grad_view
-        e = p + "encoder."
-        dx = ops.layernorm_bwd(S["x_last"], S["mo"], S["ro"], w["lnp_w"], dout, dgamma=gv(e + "layer_norm.weight"),
-                               dbeta=gv(e + "layer_norm.bias"), accumulate=acc)
+        dx = ops.layernorm_bwd(S["x_last"], S["mo"], S["ro"], w["lnp_w"], dout, dgamma=gv(N.enc_ln + ".weight"),
+                               dbeta=gv(N.enc_ln + ".bias"), accumulate=acc)
+        rp_state = self._relpos_backward_begin(S)
         for i in reversed(range(cfg["hub_layers"])):
             R = S["blocks"][i]
-            q = f"{e}layers.{i}."
             fo = ops.gelu_fwd(R["z"])
-            self._lin_grads(dx, fo, q + "feed_forward.output_dense.weight", acc, bias=((q + "feed_forward.output_dense.bias", 0, d),))
+            self._lin_grads(dx, fo, N.fc2(i) + ".weight", acc, bias=((N.fc2(i) + ".bias", 0, d),))
             dz = ops.gelu_bwd(R["z"], ops.gemm_nt(dx, w[f"{i}.fc2T"]))
             del fo
-            self._lin_grads(dz, R["h2"], q + "feed_forward.intermediate_dense.weight", acc,
-                            bias=((q + "feed_forward.intermediate_dense.bias", 0, cfg["hub_ffn"]),))
+            self._lin_grads(dz, R["h2"], N.fc1(i) + ".weight", acc, bias=((N.fc1(i) + ".bias", 0, cfg["hub_ffn"]),))
             dh2 = ops.gemm_nt(dz, w[f"{i}.fc1T"])
             del dz
-            dx1 = ops.layernorm_bwd(R["x1"], R["m2"], R["r2"], w[f"{i}.ln2_w"], dh2, dgamma=gv(q + "final_layer_norm.weight"),
-                                    dbeta=gv(q + "final_layer_norm.bias"), accumulate=acc)
+            dx1 = ops.layernorm_bwd(R["x1"], R["m2"], R["r2"], w[f"{i}.ln2_w"], dh2, dgamma=gv(N.ln2(i) + ".weight"),
+                                    dbeta=gv(N.ln2(i) + ".bias"), accumulate=acc)
             ops.add_(dx1, dx)
-            self._lin_grads(dx1, R["a"], q + "attention.out_proj.weight", acc, bias=((q + "attention.out_proj.bias", 0, d),))
+            self._lin_grads(dx1, R["a"], N.out(i) + ".weight", acc, bias=((N.out(i) + ".bias", 0, d),))
             da = ops.gemm_nt(dx1, w[f"{i}.outT"])
             qkv = R["qkv"]
             qt = ops.head_rope_transpose(qkv, 0, B, T, H, 64)
             kt = ops.head_rope_transpose(qkv, d, B, T, H, 64)
             dat = ops.head_rope_transpose(da, 0, B, T, H, 64)
             dqkv = torch.empty_like(qkv)
+            rp_b = self._relpos_backward_args(R, rp_state)      # WavLM: (gate, table, T, d_gate OUT, d_table ACCUMULATED)
             ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], qt, kt, R["a"], da, dat, R["lse"], dqkv[:, :d],
-                         dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask)
+                         dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask, relpos=rp_b)
             del qt, kt, dat, da
-            self._lin_grads(dqkv, R["h"], q + "attention.q_proj.weight", acc, N=3 * d, K=d,
-                            bias=((q + "attention.q_proj.bias", 0, d), (q + "attention.k_proj.bias", d, d), (q + "attention.v_proj.bias", 2 * d, d)))
+            self._lin_grads(dqkv, R["h"], N.q(i) + ".weight", acc, N=3 * d, K=d,
+                            bias=((N.q(i) + ".bias", 0, d), (N.k(i) + ".bias", d, d), (N.v(i) + ".bias", 2 * d, d)))
             dh = ops.gemm_nt(dqkv, w[f"{i}.qkvT"])
             del dqkv
-            dx = ops.layernorm_bwd(R["x"], R["m1"], R["r1"], w[f"{i}.ln1_w"], dh, dgamma=gv(q + "layer_norm.weight"),
-                                   dbeta=gv(q + "layer_norm.bias"), accumulate=acc)
+            if rp_b is not None:    # the gate is a function of the attention input too
+                ops.add_(dh, self._gate_backward(i, R, rp_b[3], acc))
+            dx = ops.layernorm_bwd(R["x"], R["m1"], R["r1"], w[f"{i}.ln1_w"], dh, dgamma=gv(N.ln1(i) + ".weight"),
+                                   dbeta=gv(N.ln1(i) + ".bias"), accumulate=acc)
             ops.add_(dx, dx1)
             S["blocks"][i] = None
+        self._relpos_backward_end(rp_state, acc)
         # ---- positional conv: x0 = h + gelu(conv(h) + b) ----
         G, kpos = cfg["hub_pos_groups"], cfg["hub_pos_k"]
         gch = d // G
         M = B * T
         Mp = round_up(M, 64)
         dpre = ops.gelu_bwd(S["pre"], dx)
-        gw = gv(e + "pos_conv_embed.conv.weight")                      # reference layout [d (co), gch (ci), kpos]
+        dw = torch.empty((d, gch, kpos), dtype=torch.float32, device=dx.device)     # reference layout [d (co), gch (ci), kpos]
         cols = torch.empty((M, self.pos_kp), dtype=torch.bfloat16, device=dx.device)
         for g in range(G):   # dW_g[co, j*gch + ci] = sum_t dpre[t, g*gch + co] * h[t + j - kpos/2, g*gch + ci]
             ops.conv1d_im2col(S["h"], B, T, g * gch, gch, kpos, 1, kpos // 2, Kp=self.pos_kp, Tout_limit=T, out=cols)
             gwg = ops.gemm_nt(ops.transpose(dpre[:, g * gch:(g + 1) * gch], Rp=Mp), ops.transpose(cols, Rp=Mp), out_dtype=torch.float32)
-            gwg = gwg[:, : kpos * gch].reshape(gch, kpos, gch).permute(0, 2, 1)
-            gw[g * gch:(g + 1) * gch].add_(gwg) if acc else gw[g * gch:(g + 1) * gch].copy_(gwg)
+            dw[g * gch:(g + 1) * gch].copy_(gwg[:, : kpos * gch].reshape(gch, kpos, gch).permute(0, 2, 1))
         del cols
-        ops.colsum(dpre, gv(e + "pos_conv_embed.conv.bias"), accumulate=acc)
+        self._deposit_pos_weight_grad(dw, acc)
+        ops.colsum(dpre, gv(N.pos_b), accumulate=acc)
         dh = ops.pos_conv_fwd(dpre, w["pos_adj"], None, B, T, residual=dx, pad=kpos - 1 - kpos // 2, act=False)
         del dpre, dx
         if S["pad_idx"] is not None:
             dh = ops.gather_rows(dh, S["pad_idx"])      # the padded frames were zero-filled in the forward: no gradient through them
         # ---- feature projection: h = Linear(LayerNorm(x6)) ----
-        f = p + "feature_projection."
-        self._lin_grads(dh, S["hN"], f + "projection.weight", acc, bias=((f + "projection.bias", 0, d),))
+        self._lin_grads(dh, S["hN"], N.fp + ".weight", acc, bias=((N.fp + ".bias", 0, d),))
         dhN = ops.gemm_nt(dh, w["fpT"])
         del dh
-        dxo = ops.layernorm_bwd(S["x6"], S["mf"], S["rf"], w["fp_lw"], dhN, dgamma=gv(f + "layer_norm.weight"), dbeta=gv(f + "layer_norm.bias"),
+        dxo = ops.layernorm_bwd(S["x6"], S["mf"], S["rf"], w["fp_lw"], dhN, dgamma=gv(N.fp_ln + ".weight"), dbeta=gv(N.fp_ln + ".bias"),
                                 accumulate=acc)
         del dhN
         # ---- conv feature extractor, last layer first: x_i = gelu(LayerNorm(conv_i(x_{i-1}))) ----
         for i in reversed(range(len(cfg["hub_conv_dim"]))):
             C_ = S["convs"][i]
             co, k, sd = cfg["hub_conv_dim"][i], cfg["hub_conv_kernel"][i], cfg["hub_conv_stride"][i]
-            c = f"{p}feature_extractor.conv_layers.{i}."
             z = ops.layernorm(C_["y"], w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5)
             dz = ops.gelu_bwd(z, dxo)
             del z, dxo
-            dy = ops.layernorm_bwd(C_["y"], C_["m"], C_["r"], w[f"c{i}_lw"], dz, dgamma=gv(c + "layer_norm.weight"), dbeta=gv(c + "layer_norm.bias"),
-                                   accumulate=acc)
+            dy = ops.layernorm_bwd(C_["y"], C_["m"], C_["r"], w[f"c{i}_lw"], dz, dgamma=gv(N.conv_ln(i) + ".weight"),
+                                   dbeta=gv(N.conv_ln(i) + ".bias"), accumulate=acc)
             del dz
             cin, Tin = C_["cin"], C_["Tin"]
             cols, Tout = ops.conv1d_im2col(C_["x_in"], B, Tin, 0, cin, k, sd, 0, Kp=w[f"c{i}"].shape[1])
@@ -1099,12 +1137,30 @@ class HipHubertEncoder(nn.Module):
             gwc = ops.gemm_nt(ops.transpose(dy, Rp=Mip), ops.transpose(cols, Rp=Mip), out_dtype=torch.float32)   # [co, kp], tap-major
             del cols
             gwc = gwc[:, : k * cin].reshape(co, k, cin).permute(0, 2, 1)
-            gv(c + "conv.weight").add_(gwc) if acc else gv(c + "conv.weight").copy_(gwc)
-            ops.colsum(dy, gv(c + "conv.bias"), accumulate=acc)
+            gv(N.conv_w(i)).add_(gwc) if acc else gv(N.conv_w(i)).copy_(gwc)
+            if N.conv_b is not None:
+                ops.colsum(dy, gv(N.conv_b(i)), accumulate=acc)
             if i > 0:
                 dxo = ops.conv1d_col2im(ops.gemm_nt(dy, w[f"c{i}T"]), B, Tin, cin, k, sd)
             del dy
             S["convs"][i] = None
+
+    # hooks of the relative-position-bias backward (WavLM overrides; HuBERT has no bias)
+    def _relpos_backward_begin(self, S: dict):
+        return None
+
+    def _relpos_backward_args(self, R: dict, state):
+        return None
+
+    def _gate_backward(self, i: int, R: dict, d_gate: torch.Tensor, acc: bool):
+        raise NotImplementedError
+
+    def _relpos_backward_end(self, state, acc: bool):
+        pass
+
+    def _deposit_pos_weight_grad(self, dw: torch.Tensor, acc: bool):
+        g = self.store.grad_view(self._nm().pos_w)
+        g.add_(dw) if acc else g.copy_(dw)
 
     def forward(self, source=None, padding_mask=None, **kw):
         return {"encoder_out": self.forward_wav(source).transpose(0, 1), "padding_mask": None}
@@ -1121,7 +1177,92 @@ class HipWavLMEncoder(HipHubertEncoder):
     layer's gate comes from slam_wavlm_gate on that layer's attention input, and the attention kernel adds gate[q] * table[k - q]
     to the scores.  Weights are read under the reference module's own state-dict names (`encoder.model.*`)."""
 
+    def __init__(self, cfg: dict, device, store: Optional["TrainableStore"] = None, prefix="encoder.model."):
+        self._tables, self._buckets = {}, {}
+        super().__init__(cfg, device, store, prefix)
+
+    # ---- trainable form: the reference module's own parameter names (WavLM.py:220-330, modules.py:330-420) -------------------
+    def _nm(self) -> SimpleNamespace:
+        p = self.prefix
+        e = p + "encoder."
+        c = lambda i: f"{p}feature_extractor.conv_layers.{i}."   # noqa: E731
+        lyr = lambda i: f"{e}layers.{i}."                        # noqa: E731
+        return SimpleNamespace(
+            conv_w=lambda i: c(i) + "0.weight", conv_b=None, conv_ln=lambda i: c(i) + "2.1",
+            fp_ln=p + "layer_norm", fp=p + "post_extract_proj",
+            pos_w=None, pos_g=e + "pos_conv.0.weight_g", pos_v=e + "pos_conv.0.weight_v", pos_b=e + "pos_conv.0.bias",
+            q=lambda i: lyr(i) + "self_attn.q_proj", k=lambda i: lyr(i) + "self_attn.k_proj", v=lambda i: lyr(i) + "self_attn.v_proj",
+            out=lambda i: lyr(i) + "self_attn.out_proj", ln1=lambda i: lyr(i) + "self_attn_layer_norm",
+            fc1=lambda i: lyr(i) + "fc1", fc2=lambda i: lyr(i) + "fc2", ln2=lambda i: lyr(i) + "final_layer_norm", enc_ln=e + "layer_norm",
+            grep_w=lambda i: lyr(i) + "self_attn.grep_linear.weight", grep_b=lambda i: lyr(i) + "self_attn.grep_linear.bias",
+            grep_a=lambda i: lyr(i) + "self_attn.grep_a", rel_bias=lyr(0) + "self_attn.relative_attention_bias.weight",
+            mask_emb=p + "mask_emb")
+
+    def _reserve_extra_layer(self, i: int):
+        cfg, r, N = self.cfg, self.store.reserve, self._nm()
+        H = cfg["hub_heads"]
+        r(N.grep_w(i), (8, 64)); r(N.grep_b(i), (8,)); r(N.grep_a(i), (1, H, 1, 1))
+        if i == 0:      # only layer 0 owns the bucket embedding (has_relative_attention_bias, WavLM.py:606-620); the others reuse its table
+            r(N.rel_bias, (cfg["wavlm_buckets"], H))
+
+    def _reserve_extra_top(self):
+        # mask_emb (WavLM.py:262-264) is a parameter of the module, so the optimizer sees it; extract_features(mask=False) never reads
+        # it: its gradient stays zero, like autograd's None
+        self.store.reserve(self._nm().mask_emb, (self.cfg["hub_dim"],))
+
+    def _load_trainable(self, W: Dict[str, torch.Tensor], prefix: str):
+        N = self._nm()
+        if prefix + N.pos_g[len(self.prefix):] not in W:     # a checkpoint saved under the parametrizations API's names
+            base = prefix + N.pos_g[len(self.prefix): -len("weight_g")]
+            W = dict(W)
+            W[base + "weight_g"], W[base + "weight_v"] = W[base + "parametrizations.weight.original0"], W[base + "parametrizations.weight.original1"]
+        if prefix + N.mask_emb[len(self.prefix):] not in W:
+            W = dict(W)
+            W[prefix + N.mask_emb[len(self.prefix):]] = torch.zeros(self.cfg["hub_dim"])
+        return super()._load_trainable(W, prefix)
+
+    def _refresh_extra(self):
+        st, w, N, H = self.store, self.w, self._nm(), self.cfg["hub_heads"]
+        for i in range(self.cfg["hub_layers"]):
+            w[f"{i}.gw"], w[f"{i}.gb"] = st.master_view(N.grep_w(i)), st.master_view(N.grep_b(i))
+            w[f"{i}.ga"] = st.master_view(N.grep_a(i)).view(H)
+        w["rel_bias"] = st.master_view(N.rel_bias)
+        self._tables = {}      # the per-length bias table is a function of the (now moving) bucket embedding
+
+    def _relpos_backward_begin(self, S: dict):
+        tab = self._tables[S["T"]]
+        return dict(tab=tab, d_tab=torch.zeros_like(tab), T=S["T"])
+
+    def _relpos_backward_args(self, R: dict, state):
+        gate = R["rp"][0]
+        return (gate, state["tab"], state["T"], torch.empty_like(gate), state["d_tab"])
+
+    def _gate_backward(self, i: int, R: dict, d_gate: torch.Tensor, acc: bool):
+        """adjoint of slam_wavlm_gate (modules.py:504-533): gate = ga * (sigmoid(sum4 a) * (sigmoid(sum4 b) * grep_a - 1) + 2) with
+        (a | b) = grep_linear(x viewed per head); deposits grep_linear / grep_a gradients, returns dL/d(attention input)"""
+        st, w, N, H = self.store, self.w, self._nm(), self.cfg["hub_heads"]
+        B, T = R["rp"][0].shape[0], R["rp"][2]
+        x = R["h"]
+        dv8, da_term, dxg = ops.wavlm_gate_bwd(x, w[f"{i}.gw"], w[f"{i}.gb"], w[f"{i}.ga"], d_gate, B, T, H)
+        ops.skinny_gram(dv8, x.view(B * T * H, 64), st.grad_view(N.grep_w(i)), 64, 1, accumulate=acc)
+        ops.colsum(dv8, st.grad_view(N.grep_b(i)), accumulate=acc)
+        tmp = torch.empty(da_term.shape[1], dtype=torch.float32, device=x.device)
+        ops.colsum(da_term, tmp)
+        ga = st.grad_view(N.grep_a(i)).view(H)
+        ga.add_(tmp[:H]) if acc else ga.copy_(tmp[:H])
+        return dxg
+
+    def _relpos_backward_end(self, state, acc: bool):
+        ops.relpos_bucket_grad(state["d_tab"], self._buckets[state["T"]], self.cfg["wavlm_buckets"],
+                               self.store.grad_view(self._nm().rel_bias), accumulate=acc)
+
+    def _deposit_pos_weight_grad(self, dw: torch.Tensor, acc: bool):
+        st, N = self.store, self._nm()
+        ops.weight_norm_bwd(dw, st.master_view(N.pos_v), st.master_view(N.pos_g), st.grad_view(N.pos_g), st.grad_view(N.pos_v), accumulate=acc)
+
     def load(self, W: Dict[str, torch.Tensor], prefix="encoder.model."):
+        if self.trainable:
+            return self._load_trainable(W, prefix)
         cfg, dev, w = self.cfg, self.device_, self.w
         bf = lambda t: t.to(device=dev, dtype=torch.bfloat16).contiguous()  # noqa: E731
         f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
@@ -1196,6 +1337,7 @@ class HipWavLMEncoder(HipHubertEncoder):
             buckets = wavlm_relative_buckets(T, self.cfg["wavlm_buckets"], self.cfg["wavlm_max_distance"]).to(self.device_)
             tab = ops.relpos_table(w["rel_bias"].index_select(0, buckets).t().contiguous())      # [H, 2T-1] (+ slack)
             self._tables = {T: tab}
+            self._buckets = {T: buckets.to(torch.int32)}
         gate = ops.wavlm_gate(attn_in, w[f"{layer}.gw"], w[f"{layer}.gb"], w[f"{layer}.ga"], B, T, H)
         return (gate, tab, T)
 
@@ -1777,9 +1919,9 @@ class SlamHipModel(nn.Module):
         self.projector_name = cfg.get("projector", "linear")
         # train_config.freeze_encoder=false (models/slam_model.py:110-113): the encoder's parameters join the trainable store
         self.train_encoder = not bool(cfg.get("freeze_encoder", True))
-        if self.train_encoder and (self.encoder_name not in ("whisper", "hubert") or cfg.get("varlen_encoder", False)):
-            raise NotImplementedError("freeze_encoder=false is implemented for the Whisper and HuBERT encoders (hand-written encoder backward) with "
-                                      "the linear / cov1d-linear / q-former projectors on padded batches; WavLM / varlen_encoder are not")
+        if self.train_encoder and (self.encoder_name not in ("whisper", "hubert", "wavlm") or cfg.get("varlen_encoder", False)):
+            raise NotImplementedError("freeze_encoder=false is implemented for the Whisper, HuBERT and WavLM encoders (hand-written encoder "
+                                      "backward) with the linear / cov1d-linear / q-former projectors on padded batches; varlen_encoder is not")
         if self.encoder_name in ("hubert", "wavlm"):
             cfg["enc_dim"] = cfg["hub_dim"]
             if not self.train_encoder:
@@ -1797,7 +1939,8 @@ class SlamHipModel(nn.Module):
         else:
             self.encoder_projector = HipProjectorConcat(cfg, self.store)  # projector last = produced last in backward
         if self.train_encoder:   # ... except a trainable encoder, after it
-            self.encoder = (HipHubertEncoder if self.encoder_name == "hubert" else HipWhisperEncoder)(cfg, self.device_, store=self.store)
+            enc_cls = {"hubert": HipHubertEncoder, "wavlm": HipWavLMEncoder, "whisper": HipWhisperEncoder}[self.encoder_name]
+            self.encoder = enc_cls(cfg, self.device_, store=self.store)
             self.encoder_projector.need_dx = True
         self.store.allocate()
         self.llm.bind()

@@ -495,6 +495,30 @@ def wavlm_gate(x2d: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, grep_a: t
     return gate
 
 
+def weight_norm_bwd(dw: torch.Tensor, v: torch.Tensor, g: torch.Tensor, dg: torch.Tensor, dv: torch.Tensor, accumulate: bool = False):
+    """dw, v, dv: fp32 [..., K] (contiguous), g, dg: fp32 with K elements -- chain rule of weight_norm(dim = last)"""
+    K = v.shape[-1]
+    call("slam_weight_norm_bwd", _p(dw), _p(v), _p(g), _p(dg), _p(dv), v.numel() // K, K, 1 if accumulate else 0, _s())
+
+
+def relpos_bucket_grad(d_table: torch.Tensor, buckets_i32: torch.Tensor, num_buckets: int, out: torch.Tensor, accumulate: bool = False):
+    """d_table: the padded table layout of relpos_table() ([H, n + 128]); out [num_buckets, H] f32"""
+    H, n = d_table.shape[0], buckets_i32.numel()
+    call("slam_relpos_bucket_grad", ctypes.c_void_p(d_table.data_ptr() + 64 * 4), d_table.shape[1], _p(buckets_i32), n, H, num_buckets, _p(out),
+         1 if accumulate else 0, _s())
+
+
+def wavlm_gate_bwd(x2d: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, grep_a: torch.Tensor, dgate: torch.Tensor, B: int, T: int, H: int):
+    """backward of wavlm_gate: returns (dv [B*T*H, 8] bf16, da_term [B*T, Hp] bf16, dx [B*T, H*64] bf16) -- see slam_wavlm_gate_bwd"""
+    M, Hp = B * T, round_up(H, 8)
+    dv = torch.empty((M * H, 8), dtype=torch.bfloat16, device=x2d.device)
+    da_term = torch.zeros((M, Hp), dtype=torch.bfloat16, device=x2d.device)
+    dx = torch.empty((M, H * 64), dtype=torch.bfloat16, device=x2d.device)
+    call("slam_wavlm_gate_bwd", _p(x2d), _ld(x2d), _p(w), _p(bias), _p(grep_a), _p(dgate), _p(dv), _p(da_term), _p(dx), _ld(dx), B, T, H,
+         dgate.shape[-1], Hp, _s())
+    return dv, da_term, dx
+
+
 def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T, Hq, Hkv, D, causal, scale,
              key_mask=None, Tk=None, rope=None, seg=None, drop=None, relpos=None):
     """rope = (cos, sin[, positions]) tables: dq/dk come out as gradients w.r.t. the pre-RoPE projections (fused

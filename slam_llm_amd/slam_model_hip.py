@@ -140,11 +140,11 @@ def build_config(train_config, model_config) -> dict:
 def check_supported(train_config, model_config):
     """what the reference's factory would do with these flags that the HIP path does not implement -> loud errors
     (src/slam_llm/models/slam_model.py:68-221)."""
-    if _get(train_config, "freeze_encoder", True) is False and _get(model_config, "encoder_name", None) not in ("whisper", "hubert"):
+    if _get(train_config, "freeze_encoder", True) is False and _get(model_config, "encoder_name", None) not in ("whisper", "hubert", "wavlm"):
         raise NotImplementedError("train_config.freeze_encoder=false (unfrozen-encoder training, slam_model.py:110-113) is implemented for "
-                                  "encoder_name=whisper and encoder_name=hubert (large / xlarge graph) -- hand-written encoder backward; linear, "
-                                  "cov1d-linear and q-former projectors; WavLM stays frozen: pass ++train_config.freeze_encoder=true as the "
-                                  "speech recipes do")
+                                  "encoder_name=whisper, hubert (large / xlarge graph) and wavlm (WavLM-Large graph) -- hand-written encoder "
+                                  "backward; linear, cov1d-linear and q-former projectors; otherwise pass ++train_config.freeze_encoder=true "
+                                  "as the speech recipes do")
     if not bool(_get(train_config, "use_peft", False)) and _get(train_config, "freeze_llm", True) is False:
         raise NotImplementedError("full LLM fine-tuning (use_peft=false, freeze_llm=false) is out of scope: the HIP LLM is frozen + LoRA")
     if bool(_get(train_config, "quantization", False)) or bool(_get(train_config, "use_fast_kernels", False)):

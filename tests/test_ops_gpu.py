@@ -1195,6 +1195,70 @@ def test_attention_fwd_gated_relative_position_bias(dev, T, masked):
     assert err < 3e-2, err
 
 
+def test_wavlm_gate_backward_matches_autograd(dev):
+    """slam_wavlm_gate_bwd (unfrozen WavLM, modules.py:522-531): dL/d(grep_linear.weight | bias), dL/d(grep_a) and dL/d(attention input)
+    against torch autograd of the same gate arithmetic on the same bf16 input, for a random dL/d(gate): cosine >= 0.9999 on the
+    parameter gradients (they are sums of bf16-rounded per-frame terms, like every Linear bias gradient of the step), dx to bf16
+    rounding."""
+    from slam_llm_amd import ops
+    B, T, H, D = 2, 333, 3, 64
+    M = B * T
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(M, H * D, generator=g) * 0.8).to(torch.bfloat16)
+    gw, gb, ga = torch.randn(8, D, generator=g) * 0.2, torch.randn(8, generator=g) * 0.2, 1 + torch.randn(H, generator=g) * 0.3
+    Tp = ops.round_up(T, 64)
+    dgate = torch.zeros(B, H, Tp)
+    dgate[..., :T] = torch.randn(B, H, T, generator=g)
+    xd = x.to(dev)
+    dv8, da_term, dx = ops.wavlm_gate_bwd(xd, gw.to(dev), gb.to(dev), ga.to(dev), dgate.to(dev), B, T, H)
+    d_w = torch.zeros(8, D, device=dev)
+    ops.skinny_gram(dv8, xd.view(M * H, D), d_w, D, 1)
+    d_b = torch.zeros(8, device=dev)
+    ops.colsum(dv8, d_b)
+    tmp = torch.zeros(da_term.shape[1], device=dev)
+    ops.colsum(da_term, tmp)
+    xr = x.float().requires_grad_(True)
+    wr, br, ar = gw.clone().requires_grad_(True), gb.clone().requires_grad_(True), ga.clone().requires_grad_(True)
+    gl = torch.sigmoid((xr.view(B, T, H, D).permute(0, 2, 1, 3) @ wr.t() + br).view(B, H, T, 2, 4).sum(-1))
+    gate = gl[..., 0] * (gl[..., 1] * ar[None, :, None] - 1.0) + 2.0
+    (gate * dgate[..., :T]).sum().backward()
+    for name, got, ref in (("grep_linear.weight", d_w, wr.grad), ("grep_linear.bias", d_b, br.grad), ("grep_a", tmp[:H], ar.grad)):
+        got = got.float().cpu()
+        cs = float((got * ref).sum() / (got.norm() * ref.norm()))
+        assert cs >= 0.9999 and abs(float(got.norm() / ref.norm()) - 1) < 5e-3, f"{name}: cosine {cs}, norms {float(got.norm())} / {float(ref.norm())}"
+    assert_close(dx, xr.grad, atol=2e-3, rtol=1e-2, what="gate dx")
+
+
+def test_weight_norm_backward_and_bucket_gradient(dev):
+    """slam_weight_norm_bwd: the chain rule of nn.utils.weight_norm(dim=2) (WavLM's positional conv, WavLM.py:378-386) vs torch autograd, fp32,
+    plain and accumulating; slam_relpos_bucket_grad: d(relative_attention_bias.weight) gathered from the gradient of the per-distance
+    table (modules.py:444-455) vs index_add_."""
+    from slam_llm_amd import ops
+    from slam_llm_amd.host_tables import wavlm_relative_buckets
+    g = torch.Generator().manual_seed(3)
+    d, gch, K = 128, 32, 16
+    v = torch.randn(d, gch, K, generator=g) * 0.1
+    gg = v.norm(dim=(0, 1), keepdim=True) * (1 + 0.1 * torch.randn(1, 1, K, generator=g))
+    dw = torch.randn(d, gch, K, generator=g)
+    vr, gr = v.clone().requires_grad_(True), gg.clone().requires_grad_(True)
+    ((gr * vr / vr.norm(dim=(0, 1), keepdim=True)) * dw).sum().backward()
+    dg, dv = torch.full((1, 1, K), 7.0, device=dev), torch.full((d, gch, K), 7.0, device=dev)
+    ops.weight_norm_bwd(dw.to(dev), v.to(dev), gg.to(dev), dg, dv)
+    assert torch.allclose(dg.cpu(), gr.grad, atol=1e-5, rtol=1e-4) and torch.allclose(dv.cpu(), vr.grad, atol=1e-5, rtol=1e-4)
+    ops.weight_norm_bwd(dw.to(dev), v.to(dev), gg.to(dev), dg, dv, accumulate=True)
+    assert torch.allclose(dg.cpu(), 2 * gr.grad, atol=2e-5, rtol=1e-4) and torch.allclose(dv.cpu(), 2 * vr.grad, atol=2e-5, rtol=1e-4)
+    T, H, nb = 200, 3, 40
+    buckets = wavlm_relative_buckets(T, nb, 24)
+    d_vals = torch.randn(H, 2 * T - 1, generator=g)
+    d_tab = ops.relpos_table(d_vals.to(dev))
+    out = torch.full((nb, H), 5.0, device=dev)
+    ops.relpos_bucket_grad(d_tab, buckets.to(torch.int32).to(dev), nb, out)
+    ref = torch.zeros(nb, H).index_add_(0, buckets, d_vals.t().contiguous())
+    assert torch.allclose(out.cpu(), ref, atol=1e-4, rtol=1e-5)
+    ops.relpos_bucket_grad(d_tab, buckets.to(torch.int32).to(dev), nb, out, accumulate=True)
+    assert torch.allclose(out.cpu(), 2 * ref, atol=2e-4, rtol=1e-5)
+
+
 @pytest.mark.parametrize("B,Tq,Tk,H,masked", [(2, 8, 8, 3, False), (2, 64, 150, 2, True), (1, 100, 100, 2, False)])
 def test_attention_probability_dropout_fwd_bwd(dev, B, Tq, Tk, H, masked):
     """slam_attn_fwd / slam_attn_bwd with drop_p > 0 (Q-Former self- and cross-attention shapes, D = 64, bidirectional) vs torch

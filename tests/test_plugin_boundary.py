@@ -180,11 +180,8 @@ def test_untouched_recipe_defaults_are_rejected_loudly():
     tc, mc, _ = recipe_configs("aispeech_asr", dict(encoder_name="beats"), dict(freeze_encoder=True))
     with pytest.raises(NotImplementedError, match="beats"):
         build_config(tc, mc)
-    # unfrozen encoders: Whisper (any projector) and HuBERT are served, WavLM is refused by name
-    tc, mc, _ = recipe_configs("aispeech_asr", dict(encoder_name="wavlm"), dict(freeze_encoder=False, use_peft=True))
-    with pytest.raises(NotImplementedError, match="freeze_encoder"):
-        check_supported(tc, mc)
-    for enc, proj in (("whisper", "q-former"), ("whisper", "cov1d-linear"), ("hubert", "linear")):
+    # unfrozen encoders: Whisper (any projector), HuBERT and WavLM are served (the base geometries refuse at model construction)
+    for enc, proj in (("whisper", "q-former"), ("whisper", "cov1d-linear"), ("hubert", "linear"), ("wavlm", "linear")):
         tc, mc, _ = recipe_configs("aispeech_asr", dict(encoder_name=enc, encoder_projector=proj), dict(freeze_encoder=False, use_peft=True))
         check_supported(tc, mc)
     tc, mc, _ = recipe_configs("aispeech_asr", dict(encoder_name="whisper"), dict(freeze_encoder=True, use_peft=True, enable_deepspeed=True))
