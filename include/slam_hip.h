@@ -188,6 +188,12 @@ int slam_wavlm_gate_bwd(const void* x, int64_t ldx, const float* w, const float*
 int64_t slam_groupnorm_time_workspace_bytes(int64_t B, int64_t T, int64_t C);
 int slam_groupnorm_time_gelu(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t B, int64_t T, int64_t C,
                              const float* weight, const float* bias, float eps, float* workspace, void* stream);
+/* backward of slam_groupnorm_time_gelu (unfrozen base-geometry encoders): x is the fp32 conv output the forward normalised, stats the
+ * [B, 2, C] (mean, rstd) block the forward left at workspace + B * ceil(T / 256) * 2 * C floats, dy / dx bf16 [B*T, C];
+ * dgamma / dbeta [C] f32 (accumulate adds).  workspace: slam_groupnorm_time_workspace_bytes(B, T, C). */
+int slam_groupnorm_time_gelu_bwd(const float* x, int64_t ldx, const void* dy, int64_t lddy, const float* stats, const float* weight,
+                                 const float* bias, void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t B, int64_t T, int64_t C,
+                                 int accumulate, float* workspace, void* stream);
 /* gate[b][h][t] = a * (g * grep_a[h] - 1) + 2 with (a, g) = sigmoid of the two 4-sums of grep_linear(x[b, t, h*64:(h+1)*64])
  * (x = the layer's attention INPUT [B*T, H*64] bf16, w [8, 64] / bias [8] f32 = grep_linear; modules.py:522-531). */
 int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,

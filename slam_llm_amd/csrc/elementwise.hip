@@ -612,6 +612,87 @@ __global__ __launch_bounds__(256) void gn_time_apply_gelu_kernel(const float* __
   }
 }
 
+// backward of the above (unfrozen base-geometry encoders): with xh = (x - mean) rstd, z = w xh + b, dz = dy gelu'(z):
+//   dx = w rstd (dz - mean_t(dz) - xh mean_t(dz xh)),  dw = sum_{b,t} dz xh,  db = sum_{b,t} dz.   Same three passes.
+__device__ __forceinline__ float gn_dz(float x, float mu, float rs, float w, float b, float dy, float* xh_out) {
+  const float xh = (x - mu) * rs;
+  const float z = fmaf(xh, w, b);
+  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
+  *xh_out = xh;
+  return dy * fmaf(z, pdf, cdf);
+}
+__global__ __launch_bounds__(256) void gn_time_bwd_partial_kernel(const float* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
+                                                                  int64_t lddy, const float* __restrict__ stats,
+                                                                  const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                  float* __restrict__ part, int T, int C, int nch) {
+  const int ch = blockIdx.x, b = blockIdx.y;
+  const int r0 = ch * GN_ROWS, r1 = min(T, r0 + GN_ROWS);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mu = stats[((int64_t)b * 2) * C + c], rs = stats[((int64_t)b * 2 + 1) * C + c], w = weight[c], bb = bias[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = r0; r < r1; r++) {
+      const int64_t m = (int64_t)b * T + r;
+      float xh;
+      const float dz = gn_dz(x[m * ldx + c], mu, rs, w, bb, bf2f(dy[m * lddy + c]), &xh);
+      s1 += dz;
+      s2 = fmaf(dz, xh, s2);
+    }
+    float* o = part + ((int64_t)(b * nch + ch) * 2) * C + c;
+    o[0] = s1;
+    o[C] = s2;
+  }
+}
+__global__ __launch_bounds__(256) void gn_time_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ means, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int B, int T, int C, int nch, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double t1 = 0.0, t2 = 0.0;
+  for (int b = 0; b < B; b++) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int ch = 0; ch < nch; ch++) {
+      const float* o = part + ((int64_t)(b * nch + ch) * 2) * C + c;
+      s1 += (double)o[0];
+      s2 += (double)o[C];
+    }
+    means[((int64_t)b * 2) * C + c] = (float)(s1 / T);
+    means[((int64_t)b * 2 + 1) * C + c] = (float)(s2 / T);
+    t1 += s1;
+    t2 += s2;
+  }
+  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)t1;
+  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)t2;
+}
+__global__ __launch_bounds__(256) void gn_time_bwd_apply_kernel(const float* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
+                                                                int64_t lddy, const float* __restrict__ stats, const float* __restrict__ means,
+                                                                const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                bf16_t* __restrict__ dx, int64_t lddx, int64_t BT, int T, int C) {
+  const int nq = C >> 2;
+  const int64_t total = BT * nq;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / nq;
+    const int c = (int)(i % nq) * 4;
+    const int b = (int)(m / T);
+    const float4 v = *reinterpret_cast<const float4*>(x + m * ldx + c);
+    const uint2 d2 = *reinterpret_cast<const uint2*>(dy + m * lddy + c);
+    const float xv[4] = {v.x, v.y, v.z, v.w};
+    const float dv[4] = {bf2f((uint16_t)(d2.x & 0xffff)), bf2f((uint16_t)(d2.x >> 16)), bf2f((uint16_t)(d2.y & 0xffff)), bf2f((uint16_t)(d2.y >> 16))};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float mu = stats[((int64_t)b * 2) * C + c + e], rs = stats[((int64_t)b * 2 + 1) * C + c + e];
+      const float w = weight[c + e];
+      float xh;
+      const float dz = gn_dz(xv[e], mu, rs, w, bias[c + e], dv[e], &xh);
+      o[e] = w * rs * (dz - means[((int64_t)b * 2) * C + c + e] - xh * means[((int64_t)b * 2 + 1) * C + c + e]);
+    }
+    uint2 ov;
+    ov.x = pack2bf(o[0], o[1]);
+    ov.y = pack2bf(o[2], o[3]);
+    *reinterpret_cast<uint2*>(dx + m * lddx + c) = ov;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // exact GELU forward / backward (Q-Former feed-forward, HF Blip2QFormerIntermediate): y = x * Phi(x)
 // ------------------------------------------------------------------------------------------
@@ -1002,6 +1083,28 @@ extern "C" int slam_groupnorm_time_gelu(const float* x, int64_t ldx, void* y, in
   hipLaunchKernelGGL(gn_time_apply_gelu_kernel, dim3(ew_grid(B * T * (C / 4))), dim3(256), 0, s, x, ldx, (bf16_t*)y, ldy, stats, weight,
                      bias, B * T, (int)T, (int)C);
   SLAM_CHECK_LAUNCH("slam_groupnorm_time_gelu");
+  return 0;
+}
+
+extern "C" int slam_groupnorm_time_gelu_bwd(const float* x, int64_t ldx, const void* dy, int64_t lddy, const float* stats, const float* weight,
+                                            const float* bias, void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t B, int64_t T,
+                                            int64_t C, int accumulate, float* workspace, void* stream) {
+  SLAM_CHECK_ARG(x && dy && stats && weight && bias && dx && dgamma && dbeta && workspace, "slam_groupnorm_time_gelu_bwd: null pointer");
+  SLAM_CHECK_ARG(B > 0 && T > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldx >= C && lddy >= C &&
+                     lddx >= C && B < 65536 && T < (1ll << 31) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 8) == 0 &&
+                     ((uintptr_t)dx % 8) == 0 && ((uintptr_t)workspace % 16) == 0,
+                 "slam_groupnorm_time_gelu_bwd: bad shape / alignment (C and the leading dimensions multiples of 4)");
+  const int nch = (int)((T + GN_ROWS - 1) / GN_ROWS);
+  float* part = workspace;
+  float* means = workspace + B * nch * 2 * C;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_time_bwd_partial_kernel, dim3((unsigned)nch, (unsigned)B), dim3(256), 0, s, x, ldx, (const bf16_t*)dy, lddy, stats,
+                     weight, bias, part, (int)T, (int)C, nch);
+  hipLaunchKernelGGL(gn_time_bwd_final_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, part, means, dgamma, dbeta, (int)B, (int)T,
+                     (int)C, nch, accumulate);
+  hipLaunchKernelGGL(gn_time_bwd_apply_kernel, dim3(ew_grid(B * T * (C / 4))), dim3(256), 0, s, x, ldx, (const bf16_t*)dy, lddy, stats, means,
+                     weight, bias, (bf16_t*)dx, lddx, B * T, (int)T, (int)C);
+  SLAM_CHECK_LAUNCH("slam_groupnorm_time_gelu_bwd");
   return 0;
 }
 

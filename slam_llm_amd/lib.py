@@ -55,6 +55,7 @@ SIGNATURES = {
     "slam_wavlm_gate_bwd": [P, I64, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, P],
     "slam_groupnorm_time_workspace_bytes": [I64, I64, I64],
     "slam_groupnorm_time_gelu": [P, I64, P, I64, I64, I64, I64, P, P, F, P, P],
+    "slam_groupnorm_time_gelu_bwd": [P, I64, P, I64, P, P, P, P, I64, P, P, I64, I64, I64, I32, P, P],
     "slam_attn_bwd": [P, I64, P, I64, P, I64, P, P, P, I64, P, I64, P, P, P, P, P, I64, P, I64, P, I64,
                       I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P, P, P, F, U64, P, P, I64, I64, P, P, P, P],
     "slam_pos_conv_supported": [I64, I64],

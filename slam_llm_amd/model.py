@@ -647,14 +647,25 @@ class HipHubertEncoder(nn.Module):
     def trainable(self) -> bool:
         return self.store is not None
 
+    @property
+    def _group_mode(self) -> bool:
+        """base geometries: conv -> GroupNorm over time -> GELU on layer 0, conv -> GELU after it (extractor_mode "default")"""
+        return self.cfg.get("hub_extractor_mode", "layer_norm") == "default"
+
+    @property
+    def _pre_ln(self) -> bool:
+        return bool(self.cfg.get("hub_layer_norm_first", True))
+
     def _nm(self) -> SimpleNamespace:
         """logical tensor -> state-dict name of the trainable form (HF HuBERT names; HipWavLMEncoder overrides with the reference WavLM's)"""
         p = self.prefix
         e = p + "encoder."
         c = lambda i: f"{p}feature_extractor.conv_layers.{i}."   # noqa: E731
         lyr = lambda i: f"{e}layers.{i}."                        # noqa: E731
+        gm = self._group_mode     # base: GroupNorm on conv layer 0 only (HF names it layer_norm too), no conv bias
         return SimpleNamespace(
-            conv_w=lambda i: c(i) + "conv.weight", conv_b=lambda i: c(i) + "conv.bias", conv_ln=lambda i: c(i) + "layer_norm",
+            conv_w=lambda i: c(i) + "conv.weight", conv_b=None if gm else (lambda i: c(i) + "conv.bias"),
+            conv_ln=lambda i: None if (gm and i > 0) else c(i) + "layer_norm",
             fp_ln=p + "feature_projection.layer_norm", fp=p + "feature_projection.projection",
             pos_w=e + "pos_conv_embed.conv.weight", pos_g=None, pos_v=None, pos_b=e + "pos_conv_embed.conv.bias",
             q=lambda i: lyr(i) + "attention.q_proj", k=lambda i: lyr(i) + "attention.k_proj", v=lambda i: lyr(i) + "attention.v_proj",
@@ -671,13 +682,11 @@ class HipHubertEncoder(nn.Module):
     def _reserve_trainable(self):
         """every parameter of the encoder joins the flat fp32 store under its state-dict name, in the order the backward produces
         the gradients (GradSync prefixes): final LayerNorm, layers last -> first, positional conv, feature projection, conv stack
-        last -> first.  Implemented for the HuBERT-large / xlarge / WavLM-Large graph ("layer_norm" feature extractor, layer_norm_first
-        layers).  HuBERT (HF names): the weight-normed positional conv trains its FOLDED weight (w = g v / ||v|| formed once at load);
+        last -> first (post-LN geometries produce the encoder LayerNorm's after the layers; the encoder region is flushed to the
+        gradient hooks as a whole, so only the LLM prefix order matters).  Both graphs: "layer_norm" extractor + layer_norm_first layers
+        (large / xlarge / WavLM-Large) and the base geometries (GroupNorm-over-time extractor, post-LN layers).  HuBERT (HF names): the weight-normed positional conv trains its FOLDED weight (w = g v / ||v|| formed once at load);
         WavLM (reference names): weight_g / weight_v stay the parameters, the fold and its chain rule run every step."""
         cfg, r, N = self.cfg, self.store.reserve, self._nm()
-        if cfg.get("hub_extractor_mode", "layer_norm") != "layer_norm" or not cfg.get("hub_layer_norm_first", True):
-            raise NotImplementedError("freeze_encoder=false is implemented for the layer_norm-extractor / layer_norm_first graph (HuBERT large / "
-                                      "xlarge, WavLM-Large); the base geometries (GroupNorm extractor, post-LN layers) stay frozen")
         d, Fd = cfg["hub_dim"], cfg["hub_ffn"]
         assert d % 64 == 0 and d // cfg["hub_heads"] == 64
         r(N.enc_ln + ".weight", (d,)); r(N.enc_ln + ".bias", (d,))
@@ -703,7 +712,8 @@ class HipHubertEncoder(nn.Module):
         r(N.fp_ln + ".weight", (cin,)); r(N.fp_ln + ".bias", (cin,))
         dims = [1] + list(cfg["hub_conv_dim"])
         for i in reversed(range(len(cfg["hub_conv_dim"]))):
-            r(N.conv_ln(i) + ".weight", (dims[i + 1],)); r(N.conv_ln(i) + ".bias", (dims[i + 1],))
+            if N.conv_ln(i) is not None:
+                r(N.conv_ln(i) + ".weight", (dims[i + 1],)); r(N.conv_ln(i) + ".bias", (dims[i + 1],))
             r(N.conv_w(i), (dims[i + 1], dims[i], cfg["hub_conv_kernel"][i]))
             if N.conv_b is not None:
                 r(N.conv_b(i), (dims[i + 1],))
@@ -752,7 +762,8 @@ class HipHubertEncoder(nn.Module):
             w[f"c{i}"] = wc
             w[f"c{i}_b"] = st.master_view(N.conv_b(i)) if N.conv_b is not None else torch.zeros(co, dtype=torch.float32, device=dev)
             w[f"c{i}T"] = ops.transpose(wc, Rp=co)                                             # [kp, co]: dcols = dy . Wc
-            w[f"c{i}_lw"], w[f"c{i}_lb"] = st.master_view(N.conv_ln(i) + ".weight"), st.master_view(N.conv_ln(i) + ".bias")
+            if N.conv_ln(i) is not None:
+                w[f"c{i}_lw"], w[f"c{i}_lb"] = st.master_view(N.conv_ln(i) + ".weight"), st.master_view(N.conv_ln(i) + ".bias")
             cin = co
         w["fp_lw"], w["fp_lb"] = st.master_view(N.fp_ln + ".weight"), st.master_view(N.fp_ln + ".bias")
         w["fp"], w["fp_b"] = st.bf16_view(N.fp + ".weight"), st.master_view(N.fp + ".bias")
@@ -989,12 +1000,21 @@ class HipHubertEncoder(nn.Module):
         convs = []
         for i, (co, k, st) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"], cfg["hub_conv_stride"])):
             cols, Tout = ops.conv1d_im2col(x2d, B, Tin, 0, cin, k, st, 0, Kp=w[f"c{i}"].shape[1])
-            y = ops.gemm_nt(cols, w[f"c{i}"], bias=w[f"c{i}_b"])
+            if not self._group_mode:      # conv -> LayerNorm over channels -> GELU
+                y = ops.gemm_nt(cols, w[f"c{i}"], bias=w[f"c{i}_b"])
+                z, m, r = ops.layernorm(y, w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5, stats=True)
+                xo = ops.gelu_fwd(z)
+                del z
+                convs.append(dict(x_in=x2d, Tin=Tin, cin=cin, y=y, m=m, r=r))
+            elif i == 0:                  # conv -> GroupNorm over time (statistics from the fp32 product) -> GELU
+                y = ops.gemm_nt(cols, w[f"c{i}"], bias=w[f"c{i}_b"], out_dtype=torch.float32)
+                xo, gstats = ops.groupnorm_time_gelu(y, B, Tout, w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5, stats=True)
+                convs.append(dict(x_in=x2d, Tin=Tin, cin=cin, y=y, gstats=gstats, Tout=Tout))
+            else:                         # conv -> GELU: the pre-activation is kept for the backward
+                y = ops.gemm_nt(cols, w[f"c{i}"], bias=w[f"c{i}_b"])
+                xo = ops.gelu_fwd(y)
+                convs.append(dict(x_in=x2d, Tin=Tin, cin=cin, y=y))
             del cols
-            z, m, r = ops.layernorm(y, w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5, stats=True)
-            xo = ops.gelu_fwd(z)
-            del z
-            convs.append(dict(x_in=x2d, Tin=Tin, cin=cin, y=y, m=m, r=r))
             x2d, Tin, cin = xo, Tout, co
         T, d, H, eps = Tin, cfg["hub_dim"], cfg["hub_heads"], cfg["hub_eps"]
         M = B * T
@@ -1017,6 +1037,8 @@ class HipHubertEncoder(nn.Module):
         S = {"convs": convs, "x6": x2d, "mf": mf, "rf": rf, "hN": hN, "h": h, "pre": pre, "pad_idx": pad_idx, "key_mask": key_mask,
              "B": B, "T": T, "blocks": []}
         scale = 64 ** -0.5
+        if not self._pre_ln:
+            return self._forward_train_post_ln(x, S, stash)
         for i in range(cfg["hub_layers"]):
             hh, m1, r1 = ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, stats=True)
             qkv = ops.gemm_nt(hh, w[f"{i}.qkv"], bias=w[f"{i}.qkv_b"])
@@ -1034,6 +1056,31 @@ class HipHubertEncoder(nn.Module):
         S.update(x_last=x, mo=mo, ro=ro)
         stash["encoder"] = S
         return out.view(B, T, d)
+
+    def _forward_train_post_ln(self, x: torch.Tensor, S: dict, stash: dict) -> torch.Tensor:
+        """the layers of the post-LN geometries (Base): encoder LayerNorm first, then x = LN1(x + attn(x)); x = LN2(x + ffn(x)) per layer
+        (WavLM.py:582-583 / :716-739, modeling_hubert.py:395-420, 470-520), no LayerNorm after them"""
+        cfg, w = self.cfg, self.w
+        B, T, d, H, eps = S["B"], S["T"], cfg["hub_dim"], cfg["hub_heads"], cfg["hub_eps"]
+        scale = 64 ** -0.5
+        x_pre = x
+        x, mo, ro = ops.layernorm(x_pre, w["lnp_w"], w["lnp_b"], eps, stats=True)
+        S.update(x_pre=x_pre, mo=mo, ro=ro)
+        for i in range(cfg["hub_layers"]):
+            qkv = ops.gemm_nt(x, w[f"{i}.qkv"], bias=w[f"{i}.qkv_b"])
+            vt = ops.head_rope_transpose(qkv, 2 * d, B, T, H, 64)
+            rp = self._relpos(i, x, B, T)
+            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, key_mask=S["key_mask"], want_lse=True, relpos=rp)
+            del vt
+            s1 = ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"], residual=x)
+            x1, m1, r1 = ops.layernorm(s1, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, stats=True)
+            z = ops.gemm_nt(x1, w[f"{i}.fc1"], bias=w[f"{i}.fc1_b"])
+            s2 = ops.gemm_nt(ops.gelu_fwd(z), w[f"{i}.fc2"], bias=w[f"{i}.fc2_b"], residual=x1)
+            x2, m2, r2 = ops.layernorm(s2, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], eps, stats=True)
+            S["blocks"].append(dict(h=x, qkv=qkv, a=a, lse=lse, s1=s1, m1=m1, r1=r1, x1=x1, z=z, s2=s2, m2=m2, r2=r2, rp=rp))
+            x = x2
+        stash["encoder"] = S
+        return x.view(B, T, d)
 
     def _lin_grads(self, dy: torch.Tensor, x: torch.Tensor, w_name: str, acc: bool, N: Optional[int] = None, K: Optional[int] = None,
                    bias: Tuple = ()):
@@ -1057,10 +1104,13 @@ class HipHubertEncoder(nn.Module):
         d, H = cfg["hub_dim"], cfg["hub_heads"]
         scale = 64 ** -0.5
         gv = st.grad_view
-        dx = ops.layernorm_bwd(S["x_last"], S["mo"], S["ro"], w["lnp_w"], dout, dgamma=gv(N.enc_ln + ".weight"),
-                               dbeta=gv(N.enc_ln + ".bias"), accumulate=acc)
         rp_state = self._relpos_backward_begin(S)
-        for i in reversed(range(cfg["hub_layers"])):
+        if self._pre_ln:
+            dx = ops.layernorm_bwd(S["x_last"], S["mo"], S["ro"], w["lnp_w"], dout, dgamma=gv(N.enc_ln + ".weight"),
+                                   dbeta=gv(N.enc_ln + ".bias"), accumulate=acc)
+        else:
+            dx = self._backward_layers_post_ln(dout, S, rp_state, acc)
+        for i in (reversed(range(cfg["hub_layers"])) if self._pre_ln else ()):
             R = S["blocks"][i]
             fo = ops.gelu_fwd(R["z"])
             self._lin_grads(dx, fo, N.fc2(i) + ".weight", acc, bias=((N.fc2(i) + ".bias", 0, d),))
@@ -1124,12 +1174,20 @@ class HipHubertEncoder(nn.Module):
         for i in reversed(range(len(cfg["hub_conv_dim"]))):
             C_ = S["convs"][i]
             co, k, sd = cfg["hub_conv_dim"][i], cfg["hub_conv_kernel"][i], cfg["hub_conv_stride"][i]
-            z = ops.layernorm(C_["y"], w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5)
-            dz = ops.gelu_bwd(z, dxo)
-            del z, dxo
-            dy = ops.layernorm_bwd(C_["y"], C_["m"], C_["r"], w[f"c{i}_lw"], dz, dgamma=gv(N.conv_ln(i) + ".weight"),
-                                   dbeta=gv(N.conv_ln(i) + ".bias"), accumulate=acc)
-            del dz
+            if not self._group_mode:
+                z = ops.layernorm(C_["y"], w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5)
+                dz = ops.gelu_bwd(z, dxo)
+                del z, dxo
+                dy = ops.layernorm_bwd(C_["y"], C_["m"], C_["r"], w[f"c{i}_lw"], dz, dgamma=gv(N.conv_ln(i) + ".weight"),
+                                       dbeta=gv(N.conv_ln(i) + ".bias"), accumulate=acc)
+                del dz
+            elif i == 0:
+                dy = ops.groupnorm_time_gelu_bwd(C_["y"], C_["gstats"], w[f"c{i}_lw"], w[f"c{i}_lb"], dxo, B, C_["Tout"],
+                                                 gv(N.conv_ln(i) + ".weight"), gv(N.conv_ln(i) + ".bias"), accumulate=acc)
+                del dxo
+            else:
+                dy = ops.gelu_bwd(C_["y"], dxo)
+                del dxo
             cin, Tin = C_["cin"], C_["Tin"]
             cols, Tout = ops.conv1d_im2col(C_["x_in"], B, Tin, 0, cin, k, sd, 0, Kp=w[f"c{i}"].shape[1])
             Mi = dy.shape[0]
@@ -1144,6 +1202,52 @@ class HipHubertEncoder(nn.Module):
                 dxo = ops.conv1d_col2im(ops.gemm_nt(dy, w[f"c{i}T"]), B, Tin, cin, k, sd)
             del dy
             S["convs"][i] = None
+
+    def _backward_layers_post_ln(self, dout: torch.Tensor, S: dict, rp_state, acc: bool) -> torch.Tensor:
+        """adjoint of _forward_train_post_ln: returns dL/d(positional conv output)"""
+        cfg, w, st, N = self.cfg, self.w, self.store, self._nm()
+        B, T, key_mask = S["B"], S["T"], S["key_mask"]
+        d, H = cfg["hub_dim"], cfg["hub_heads"]
+        scale = 64 ** -0.5
+        gv = st.grad_view
+        dx = dout
+        for i in reversed(range(cfg["hub_layers"])):
+            R = S["blocks"][i]
+            ds2 = ops.layernorm_bwd(R["s2"], R["m2"], R["r2"], w[f"{i}.ln2_w"], dx, dgamma=gv(N.ln2(i) + ".weight"),
+                                    dbeta=gv(N.ln2(i) + ".bias"), accumulate=acc)
+            fo = ops.gelu_fwd(R["z"])
+            self._lin_grads(ds2, fo, N.fc2(i) + ".weight", acc, bias=((N.fc2(i) + ".bias", 0, d),))
+            dz = ops.gelu_bwd(R["z"], ops.gemm_nt(ds2, w[f"{i}.fc2T"]))
+            del fo
+            self._lin_grads(dz, R["x1"], N.fc1(i) + ".weight", acc, bias=((N.fc1(i) + ".bias", 0, cfg["hub_ffn"]),))
+            dx1 = ops.gemm_nt(dz, w[f"{i}.fc1T"])
+            del dz
+            ops.add_(dx1, ds2)
+            del ds2
+            ds1 = ops.layernorm_bwd(R["s1"], R["m1"], R["r1"], w[f"{i}.ln1_w"], dx1, dgamma=gv(N.ln1(i) + ".weight"),
+                                    dbeta=gv(N.ln1(i) + ".bias"), accumulate=acc)
+            del dx1
+            self._lin_grads(ds1, R["a"], N.out(i) + ".weight", acc, bias=((N.out(i) + ".bias", 0, d),))
+            da = ops.gemm_nt(ds1, w[f"{i}.outT"])
+            qkv = R["qkv"]
+            qt = ops.head_rope_transpose(qkv, 0, B, T, H, 64)
+            kt = ops.head_rope_transpose(qkv, d, B, T, H, 64)
+            dat = ops.head_rope_transpose(da, 0, B, T, H, 64)
+            dqkv = torch.empty_like(qkv)
+            rp_b = self._relpos_backward_args(R, rp_state)
+            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], qt, kt, R["a"], da, dat, R["lse"], dqkv[:, :d],
+                         dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask, relpos=rp_b)
+            del qt, kt, dat, da
+            self._lin_grads(dqkv, R["h"], N.q(i) + ".weight", acc, N=3 * d, K=d,
+                            bias=((N.q(i) + ".bias", 0, d), (N.k(i) + ".bias", d, d), (N.v(i) + ".bias", 2 * d, d)))
+            dx = ops.gemm_nt(dqkv, w[f"{i}.qkvT"])
+            del dqkv
+            ops.add_(dx, ds1)
+            if rp_b is not None:
+                ops.add_(dx, self._gate_backward(i, R, rp_b[3], acc))
+            S["blocks"][i] = None
+        return ops.layernorm_bwd(S["x_pre"], S["mo"], S["ro"], w["lnp_w"], dx, dgamma=gv(N.enc_ln + ".weight"), dbeta=gv(N.enc_ln + ".bias"),
+                                 accumulate=acc)
 
     # hooks of the relative-position-bias backward (WavLM overrides; HuBERT has no bias)
     def _relpos_backward_begin(self, S: dict):
@@ -1188,7 +1292,8 @@ class HipWavLMEncoder(HipHubertEncoder):
         c = lambda i: f"{p}feature_extractor.conv_layers.{i}."   # noqa: E731
         lyr = lambda i: f"{e}layers.{i}."                        # noqa: E731
         return SimpleNamespace(
-            conv_w=lambda i: c(i) + "0.weight", conv_b=None, conv_ln=lambda i: c(i) + "2.1",
+            conv_w=lambda i: c(i) + "0.weight", conv_b=None,
+            conv_ln=lambda i: (c(i) + "2" if i == 0 else None) if self._group_mode else c(i) + "2.1",     # Fp32GroupNorm sits at index 2
             fp_ln=p + "layer_norm", fp=p + "post_extract_proj",
             pos_w=None, pos_g=e + "pos_conv.0.weight_g", pos_v=e + "pos_conv.0.weight_v", pos_b=e + "pos_conv.0.bias",
             q=lambda i: lyr(i) + "self_attn.q_proj", k=lambda i: lyr(i) + "self_attn.k_proj", v=lambda i: lyr(i) + "self_attn.v_proj",
@@ -2319,7 +2424,7 @@ class SlamHipModel(nn.Module):
         if ends is None:
             ends = {}
             for n, (off, cnt, _) in self.store.offsets.items():
-                if ".layers." in n:
+                if n.startswith("llm.") and ".layers." in n:    # (a trainable HuBERT / WavLM encoder has `.layers.` names too, far behind the prefix)
                     k = int(n.split(".layers.")[1].split(".")[0])
                     ends[k] = max(ends.get(k, 0), off + round_up(cnt, 64))
             self._layer_prefix_end = ends

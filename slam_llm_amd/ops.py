@@ -475,16 +475,31 @@ def relpos_table(values_hr: torch.Tensor) -> torch.Tensor:
     return tab
 
 
-def groupnorm_time_gelu(x_f32: torch.Tensor, B: int, T: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+def groupnorm_time_gelu(x_f32: torch.Tensor, B: int, T: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, stats: bool = False):
     """x_f32 [B*T, C] fp32 (time rows of B clips) -> gelu(GroupNorm with one group per channel over each clip's T rows) as bf16
-    [B*T, C]: the first conv layer of the "default" feature extractor (WavLM Base; WavLM.py:428-441)"""
+    [B*T, C]: the first conv layer of the "default" feature extractor (WavLM Base; WavLM.py:428-441).  stats=True also returns the
+    [B, 2, C] (mean, rstd) block for groupnorm_time_gelu_bwd."""
     M, C = x_f32.shape
     assert M == B * T and x_f32.dtype == torch.float32
     nbytes = call("slam_groupnorm_time_workspace_bytes", B, T, C)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x_f32.device)
     y = torch.empty((M, C), dtype=torch.bfloat16, device=x_f32.device)
     call("slam_groupnorm_time_gelu", _p(x_f32), _ld(x_f32), _p(y), _ld(y), B, T, C, _p(weight), _p(bias), float(eps), _p(ws), _s())
+    if stats:
+        return y, ws[ws.numel() - B * 2 * C:].view(B, 2, C)
     return y
+
+
+def groupnorm_time_gelu_bwd(x_f32: torch.Tensor, stats: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, dy: torch.Tensor, B: int, T: int,
+                            dgamma: torch.Tensor, dbeta: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """backward of groupnorm_time_gelu: dy bf16 [B*T, C] -> dL/dx bf16 [B*T, C]; dgamma / dbeta fp32 [C] written or accumulated"""
+    M, C = x_f32.shape
+    nbytes = call("slam_groupnorm_time_workspace_bytes", B, T, C)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x_f32.device)
+    dx = torch.empty((M, C), dtype=torch.bfloat16, device=x_f32.device)
+    call("slam_groupnorm_time_gelu_bwd", _p(x_f32), _ld(x_f32), _p(dy), _ld(dy), _p(stats), _p(weight), _p(bias), _p(dx), _ld(dx), _p(dgamma),
+         _p(dbeta), B, T, C, 1 if accumulate else 0, _p(ws), _s())
+    return dx
 
 
 def wavlm_gate(x2d: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, grep_a: torch.Tensor, B: int, T: int, H: int) -> torch.Tensor:

@@ -170,13 +170,8 @@ def test_unfrozen_encoder_training_matches_reference_fixture(dev):
 
 
 def test_unfrozen_encoder_rejects_unimplemented_combinations(dev):
-    from oracle.make_golden_cases import HUBERT_TINY, UNFROZEN_CASE as C, WAVLM_BASE_TINY
+    from oracle.make_golden_cases import UNFROZEN_CASE as C
     from slam_llm_amd.model import SlamHipModel
-    with pytest.raises(NotImplementedError, match="freeze_encoder"):      # the base geometries (GroupNorm extractor, post-LN) stay frozen-only
-        SlamHipModel(dict(C["cfg"], **WAVLM_BASE_TINY, freeze_encoder=False, encoder_name="wavlm", enc_dim=WAVLM_BASE_TINY["hub_dim"]), dev)
-    with pytest.raises(NotImplementedError, match="freeze_encoder"):
-        SlamHipModel(dict(C["cfg"], **HUBERT_TINY, freeze_encoder=False, encoder_name="hubert", enc_dim=HUBERT_TINY["hub_dim"],
-                          hub_extractor_mode="default", hub_layer_norm_first=False), dev)
     with pytest.raises(NotImplementedError, match="freeze_encoder"):
         SlamHipModel(dict(C["cfg"], freeze_encoder=False, varlen_encoder=True), dev)
 
@@ -218,6 +213,14 @@ def test_unfrozen_hubert_encoder_matches_oracle(dev, ragged):
     _unfrozen_wave_encoder_case(dev, "hubert", ragged)
 
 
+@pytest.mark.parametrize("which", ["hubert", "wavlm"])
+def test_unfrozen_base_geometry_encoder_matches_oracle(dev, which):
+    """row f4, base geometries (HuBERT Base, WavLM Base / Base+): conv -> GroupNorm over time -> GELU on layer 0 (adjoint:
+    slam_groupnorm_time_gelu_bwd on the fp32 conv output), conv -> GELU after it, no conv bias; post-LN layers behind the encoder
+    LayerNorm (x = LN1(x + attn(x)); x = LN2(x + ffn(x))), WavLM's gate reading the un-normalised attention input.  Ragged batch."""
+    _unfrozen_wave_encoder_case(dev, which, True, base=True)
+
+
 @pytest.mark.parametrize("ragged", [False, True])
 def test_unfrozen_wavlm_encoder_matches_oracle(dev, ragged):
     """row f4, WavLM-Large's graph (models/slam_model.py:110-113 + :333-334): HuBERT-large's adjoint plus (1) the gated relative
@@ -229,22 +232,25 @@ def test_unfrozen_wavlm_encoder_matches_oracle(dev, ragged):
     _unfrozen_wave_encoder_case(dev, "wavlm", ragged)
 
 
-def _unfrozen_wave_encoder_case(dev, which, ragged):
+def _unfrozen_wave_encoder_case(dev, which, ragged, base=False):
     """row f4: train_config.freeze_encoder=false with the HuBERT encoder (models/slam_model.py:110-113 + :335-341) -- the hand-written
     adjoint of the whole graph: 7 conv layers (LayerNorm over channels + GELU; general col2im for k 10 / 3 / 2, strides 5 / 2), feature
     LayerNorm + projection, grouped positional conv (dX = the implicit-GEMM kernel on tap-reversed, channel-transposed weights; dW per
     group), pre-LN transformer layers with key biases.  Tiny widths (conv 64, d 128, 2 layers, pos conv k 16 in 4 groups), linear
     projector, ragged variant: second clip 70 % long (fairseq frame mask, padded frames zeroed before the positional conv and masked
     as keys).  Loss and EVERY gradient against the oracle's autograd: cosine >= 0.998, norm within 4 %."""
-    from oracle.make_golden_cases import HUBERT_TINY, WAVLM_TINY
+    from oracle.make_golden_cases import HUBERT_BASE_TINY, HUBERT_TINY, WAVLM_BASE_TINY, WAVLM_TINY
     from slam_llm_amd.model import SlamHipModel
-    HUBERT_TINY = HUBERT_TINY if which == "hubert" else WAVLM_TINY
+    HUBERT_TINY = {("hubert", False): HUBERT_TINY, ("wavlm", False): WAVLM_TINY, ("hubert", True): HUBERT_BASE_TINY,
+                   ("wavlm", True): WAVLM_BASE_TINY}[(which, base)]
     cfg = dict(O.make_config(), **HUBERT_TINY, lora_dropout=0.0)
     cfg.update(encoder_name=which, enc_dim=HUBERT_TINY["hub_dim"])
     W = {k: v for k, v in O.init_weights(cfg, seed=42).items() if not k.startswith("encoder.")}
     W.update(O.init_hubert_weights(HUBERT_TINY, seed=7) if which == "hubert" else O.init_wavlm_weights(HUBERT_TINY, seed=9))
     N = 16000
-    wav = torch.nn.functional.layer_norm(O.synth_audio(2, 1.0, seed=9), (N,))
+    wav = O.synth_audio(2, 1.0, seed=9)
+    if not base:      # the large checkpoints' cfg has normalize=True (dataset-side layer norm of the waveform), the base ones have not
+        wav = torch.nn.functional.layer_norm(wav, (N,))
     n_valid = [N, 11200] if ragged else [N, N]
     if ragged:
         wav[1, n_valid[1]:] = 0.0
@@ -271,9 +277,22 @@ def _unfrozen_wave_encoder_case(dev, which, ragged):
     gb = {k: v.to(dev) for k, v in ob.items()}
     gb["audio"] = wav.to(dev)
     gb["audio_len"] = torch.tensor(n_valid, dtype=torch.int32, device=dev)
+
+    class PrefixRecorder:      # a GradSync-shaped hook: every prefix it is handed must already hold its final values
+        def __init__(self):
+            self.seen = []
+
+        def on_prefix(self, end):
+            self.seen.append((end, model.store.grad[:end].clone()))
+    rec = PrefixRecorder()
+    model.grad_hooks.append(rec)
     outputs, _ = model(**gb)
     outputs.loss.backward()
-    assert abs(float(outputs.loss.detach()) - float(loss_ref)) < 1.5e-2, (float(outputs.loss.detach()), float(loss_ref))
+    model.grad_hooks.remove(rec)
+    assert len(rec.seen) >= 2 and rec.seen[-1][0] == model.store.size
+    for end, snap in rec.seen:
+        assert torch.equal(snap, model.store.grad[:end]), f"gradient prefix [0, {end}) was announced before it was final"
+    assert abs(float(outputs.loss.detach()) - float(loss_ref.detach())) < 1.5e-2, (float(outputs.loss.detach()), float(loss_ref.detach()))
     gmax = max(float(v.norm()) for v in grads.values())
     worst, worst_name = 1.0, ""
     for n, p in model.store.params.items():
@@ -291,6 +310,11 @@ def _unfrozen_wave_encoder_case(dev, which, ragged):
         # the conv feature extractor sits under 2 transformer layers, the positional conv and up to 7 bf16 conv / LayerNorm adjoints
         # (64-channel rows at these widths): 0.995 there (measured 0.9971 on conv_layers.0), 0.998 everywhere else
         floor = 0.995 if "feature_extractor" in n else 0.998
+        if base and which == "wavlm":
+            # WavLM Base at these widths is the noisiest case of the family: the projector's linear1 gradient -- which does not pass through
+            # the encoder backward at all, only through the bf16 forward and the LLM backward -- already sits at 0.9978 here, and the
+            # encoder's own gradients follow it uniformly (measured 0.9948 worst, layer 1's key projection; norms within 4 %)
+            floor = 0.994
         if ".grep_" in n or "relative_attention_bias" in n:
             # WavLM's gate / bias-table parameters: d(gate)[q] = sum_k dS[q,k] table[k - q] is a cancelling sum (sum_k dS = 0), so the ~5 %
             # bf16 noise dS carries in this tiny end-to-end case (the same noise that puts q / k weights at 0.9985) is amplified; the
@@ -366,7 +390,7 @@ def test_unfrozen_whisper_with_cov1d_and_qformer_projectors(dev, projector):
     assert set(model.store.params) == set(names)
     outputs, _ = model(**{k: v.to(dev) for k, v in ob.items()})
     outputs.loss.backward()
-    assert abs(float(outputs.loss.detach()) - float(loss_ref)) < 1.5e-2, (float(outputs.loss.detach()), float(loss_ref))
+    assert abs(float(outputs.loss.detach()) - float(loss_ref.detach())) < 1.5e-2, (float(outputs.loss.detach()), float(loss_ref.detach()))
     gmax = max(float(v.norm()) for v in grads.values())
     worst = 1.0
     for n, p in model.store.params.items():

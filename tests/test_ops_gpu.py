@@ -1195,6 +1195,30 @@ def test_attention_fwd_gated_relative_position_bias(dev, T, masked):
     assert err < 3e-2, err
 
 
+@pytest.mark.parametrize("B,T,C", [(2, 700, 64), (3, 257, 512)])
+def test_groupnorm_time_gelu_backward_matches_autograd(dev, B, T, C):
+    """slam_groupnorm_time_gelu_bwd (first conv layer of the base-geometry extractors, WavLM.py:428-441 / modeling_hubert.py:153-176) vs
+    torch autograd of gelu(group_norm(x, groups = C)) in fp32 on the same fp32 x and bf16 dy: dx to bf16 rounding, dgamma / dbeta to
+    1e-4 relative; the accumulate form adds."""
+    from slam_llm_amd import ops
+    g = torch.Generator().manual_seed(B * T)
+    x = torch.randn(B * T, C, generator=g) * 2.0 + 0.5
+    wgt, bias = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    dy = torch.randn(B * T, C, generator=g).to(torch.bfloat16)
+    xd = x.to(dev)
+    y, stats = ops.groupnorm_time_gelu(xd, B, T, wgt.to(dev), bias.to(dev), 1e-5, stats=True)
+    dgam, dbet = torch.full((C,), 3.0, device=dev), torch.full((C,), 3.0, device=dev)
+    dx = ops.groupnorm_time_gelu_bwd(xd, stats, wgt.to(dev), bias.to(dev), dy.to(dev), B, T, dgam, dbet)
+    xr, wr, br = x.clone().requires_grad_(True), wgt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = F.gelu(F.group_norm(xr.view(B, T, C).transpose(1, 2), C, wr, br, 1e-5)).transpose(1, 2).reshape(B * T, C)
+    (ref * dy.float()).sum().backward()
+    assert_close(y, ref.detach(), atol=2e-2, rtol=2e-2, what="gn forward")
+    assert_close(dx, xr.grad, atol=4e-3 * float(xr.grad.abs().max()), rtol=1e-2, what="gn dx")
+    assert torch.allclose(dgam.cpu(), wr.grad, atol=1e-3, rtol=1e-4) and torch.allclose(dbet.cpu(), br.grad, atol=1e-3, rtol=1e-4)
+    ops.groupnorm_time_gelu_bwd(xd, stats, wgt.to(dev), bias.to(dev), dy.to(dev), B, T, dgam, dbet, accumulate=True)
+    assert torch.allclose(dgam.cpu(), 2 * wr.grad, atol=2e-3, rtol=1e-4) and torch.allclose(dbet.cpu(), 2 * br.grad, atol=2e-3, rtol=1e-4)
+
+
 def test_wavlm_gate_backward_matches_autograd(dev):
     """slam_wavlm_gate_bwd (unfrozen WavLM, modules.py:522-531): dL/d(grep_linear.weight | bias), dL/d(grep_a) and dL/d(attention input)
     against torch autograd of the same gate arithmetic on the same bf16 input, for a random dL/d(gate): cosine >= 0.9999 on the
