@@ -42,6 +42,12 @@ POS_CONV_FUSED = _os.environ.get("SLAM_POS_CONV_FUSED", "1") == "1"
 # CU) -- and it keeps a third, block-interleaved copy of every [gate ; up] weight (7.5 GB at Llama-3-8B).  Off unless
 # SLAM_FUSED_SWIGLU_FWD=1.
 FUSE_SWIGLU_FWD = _os.environ.get("SLAM_FUSED_SWIGLU_FWD", "0") == "1"
+# Training steps run the lm_head product, the cross entropy and the lm_head dX product only over the rows that carry a label: rows whose
+# (shifted) label is -100 -- the audio span, the prompt, the pad tokens: 83 % of the C3 batch -- enter neither the loss nor the accuracy
+# (utils/metric.py compute_accuracy ignores them) nor any gradient (their dL/dlogits is exactly zero), and the training forward hands
+# no logits out.  The label count reaches the host through a pinned buffer written at the START of the forward (an event wait that
+# has long completed by the time the LLM reaches its head).  SLAM_LM_HEAD_LABEL_ROWS=0 computes every row like HF does.
+LM_HEAD_LABEL_ROWS = _os.environ.get("SLAM_LM_HEAD_LABEL_ROWS", "1") == "1"
 LORA_PAD = 64  # K-extension granule (GEMM K-tile)
 
 
@@ -1722,8 +1728,9 @@ class HipLlamaLora(nn.Module):
 
     # ---- forward -------------------------------------------------------------------------------------
     def forward_hip(self, h: torch.Tensor, B: int, T: int, key_mask: torch.Tensor, targets, n_valid,
-                    train: bool, return_logits: bool, packed=None):
-        """h [B*T, d] bf16 (consumed).  Returns (out2 = [loss, acc] device tensor or None, logits or None, stash)."""
+                    train: bool, return_logits: bool, packed=None, label_count=None):
+        """h [B*T, d] bf16 (consumed).  Returns (out2 = [loss, acc] device tensor or None, logits or None, stash).
+        label_count = (event, pinned int32[1]): n_valid on its way to the host (see LM_HEAD_LABEL_ROWS)."""
         cfg, st = self.cfg, self.store
         d, Hq, Hkv, D, Fd, V = (cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"],
                                 cfg["llm_ffn"], cfg["vocab"])
@@ -1777,22 +1784,35 @@ class HipLlamaLora(nn.Module):
         logits_full = torch.empty((M, V), dtype=torch.bfloat16, device=h.device) if return_logits else None
         out2 = None
         if targets is not None:
-            row_loss = torch.empty((M,), dtype=torch.float32, device=h.device)
-            row_ok = torch.empty((M,), dtype=torch.int32, device=h.device)
-            dhN = torch.empty((M, d), dtype=torch.bfloat16, device=h.device) if train else None
-            Rc = self.lm_head_chunk_rows or max(256, min(M, ((1 << 29) // V) // 256 * 256))
-            chunk = torch.empty((min(Rc, M), V), dtype=torch.bfloat16, device=h.device)
-            for r0 in range(0, M, Rc):
-                r1 = min(M, r0 + Rc)
+            n_lab, rows, hsel, tsel = M, None, hN, targets
+            if train and not return_logits and label_count is not None:
+                label_count[0].synchronize()
+                n_host = int(label_count[1][0])
+                if 0 < n_host < M:      # labelled rows first, in their original order (host-known count: no sync on the index)
+                    n_lab = n_host
+                    rows64 = torch.argsort(targets < 0, stable=True)[:n_lab]
+                    rows = rows64.to(torch.int32)
+                    hsel, tsel = ops.gather_rows(hN, rows), targets.index_select(0, rows64)
+            row_loss = torch.empty((n_lab,), dtype=torch.float32, device=h.device)
+            row_ok = torch.empty((n_lab,), dtype=torch.int32, device=h.device)
+            dhN = torch.empty((n_lab, d), dtype=torch.bfloat16, device=h.device) if train else None
+            Rc = self.lm_head_chunk_rows or max(256, min(n_lab, ((1 << 29) // V) // 256 * 256))
+            chunk = torch.empty((min(Rc, n_lab), V), dtype=torch.bfloat16, device=h.device)
+            for r0 in range(0, n_lab, Rc):
+                r1 = min(n_lab, r0 + Rc)
                 lg = chunk[: r1 - r0]
-                ops.gemm_nt(hN[r0:r1], self.lm_head, out=lg)
+                ops.gemm_nt(hsel[r0:r1], self.lm_head, out=lg)
                 if return_logits:
                     logits_full[r0:r1].copy_(lg)
-                ops.ce_fwd_bwd(lg, targets[r0:r1], n_valid, row_loss[r0:r1], row_ok[r0:r1], write_grad=train)
+                ops.ce_fwd_bwd(lg, tsel[r0:r1], n_valid, row_loss[r0:r1], row_ok[r0:r1], write_grad=train)
                 if train:
                     ops.gemm_nt(lg, self.lm_headT, out=dhN[r0:r1])
             out2 = ops.ce_finalize(row_loss, row_ok, n_valid)
             if train:
+                if rows is not None:    # back to the [M, d] layout: the rows without a label carry a zero gradient
+                    inv = torch.full((M,), -1, dtype=torch.int32, device=h.device)
+                    inv[rows64] = torch.arange(n_lab, dtype=torch.int32, device=h.device)
+                    dhN = ops.gather_rows(dhN, inv)
                 stash["final"] = dict(h=h, rstdN=rstdN, dhN=dhN)
         elif return_logits:
             Rc = 4096
@@ -2201,6 +2221,16 @@ class SlamHipModel(nn.Module):
         B, T = input_ids.shape
         train = torch.is_grad_enabled() and labels is not None
         stash = {} if train else None
+        early_targets = label_count = None
+        if train and LM_HEAD_LABEL_ROWS:
+            # the shifted targets and their count now, the count on its way to pinned host memory: the LLM head reads it ~a forward later
+            early_targets = ops.ce_targets(labels.contiguous())
+            if getattr(self, "_label_count_host", None) is None:
+                self._label_count_host = torch.empty(1, dtype=torch.int32).pin_memory()
+            self._label_count_host.copy_(early_targets[1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            label_count = (ev, self._label_count_host)
 
         hub_pad = None
         if self.encoder_name in ("hubert", "wavlm"):
@@ -2270,8 +2300,8 @@ class SlamHipModel(nn.Module):
         embeds, spans = ops.embed_splice_fwd(input_ids, mm, self.llm.embed, proj)
         if kwargs.get("inference_mode", False):
             return embeds.view(B, T, -1), attention_mask
-        targets = n_valid = None
-        if labels is not None:
+        targets, n_valid = early_targets if early_targets is not None else (None, None)
+        if labels is not None and targets is None:
             targets, n_valid = ops.ce_targets(labels.contiguous())
         want_logits = self.return_logits if self.return_logits is not None else (not train)
         pack_idx = None
@@ -2294,7 +2324,7 @@ class SlamHipModel(nn.Module):
             h_packed = ops.gather_rows(embeds, pack_idx32)
             t_packed = targets.index_select(0, pack_idx).contiguous() if targets is not None else None
             out2, logits_p, lstash = self.llm.forward_hip(h_packed, 1, Mp, None, t_packed, n_valid, train, want_logits,
-                                                          packed=(pos, lo, hi, T))
+                                                          packed=(pos, lo, hi, T), label_count=label_count)
             logits = None
             if logits_p is not None:   # back to the padded [B*T, V] layout (pad rows zero)
                 logits = torch.zeros((B * T, logits_p.shape[1]), dtype=logits_p.dtype, device=dev)
@@ -2303,7 +2333,7 @@ class SlamHipModel(nn.Module):
             Tp = round_up(T, 64)
             key_mask = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
             key_mask[:, :T] = attention_mask.to(torch.uint8)
-            out2, logits, lstash = self.llm.forward_hip(embeds, B, T, key_mask, targets, n_valid, train, want_logits)
+            out2, logits, lstash = self.llm.forward_hip(embeds, B, T, key_mask, targets, n_valid, train, want_logits, label_count=label_count)
         loss = acc = None
         if out2 is not None:
             loss_val, acc = out2[0], out2[1]

@@ -208,6 +208,52 @@ def test_fused_swiglu_forward_step_is_bit_identical(dev, monkeypatch):
         assert torch.equal(a, b_)
 
 
+@pytest.mark.parametrize("case", ["padded", "left_pad_ragged", "varlen_packed", "chunked"])
+def test_lm_head_over_label_rows_equals_every_row(dev, monkeypatch, case):
+    """training steps run lm_head / cross entropy / lm_head dX over the labelled rows only (LM_HEAD_LABEL_ROWS): the loss equals the
+    every-row form to fp32 summation order (1e-6), the accuracy exactly, every gradient to bf16 product tiling (the same rows go
+    through the same kernels; cosine >= 0.99999, max |diff| <= 2e-3 max|g|), on padded, ragged left-padded, packed (varlen) batches
+    and with the head chunked into several row blocks.  The eval forward (labels + logits out) keeps every row."""
+    from slam_llm_amd import model as model_mod
+    cfg = dict(O.make_config(), lora_dropout=0.0, varlen=(case == "varlen_packed"))
+    W = O.init_weights(cfg, seed=42)
+    audio = O.synth_audio(3, 1.0, seed=31)
+    ob = O.synth_batch(cfg, audio, prompt_len=5, answer_lens=(4, 9, 6) if case != "padded" else (7,), seed=32,
+                       left_pad=(case == "left_pad_ragged"), pad_to_30s=False)
+    gb = {k: v.to(dev) for k, v in ob.items()}
+    n_lab = int((ob["labels"][:, 1:] != -100).sum())
+    assert 0 < n_lab < ob["labels"].numel() // 2
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(model_mod, "LM_HEAD_LABEL_ROWS", on)
+        m = model_mod.SlamHipModel(dict(cfg), dev).load_weights(W)
+        m.train()
+        if case == "chunked":
+            m.llm.lm_head_chunk_rows = 8
+        shapes = []
+        orig = model_mod.ops.ce_fwd_bwd
+
+        def spy(lg, *a, **k):
+            shapes.append(lg.shape[0])
+            return orig(lg, *a, **k)
+        monkeypatch.setattr(model_mod.ops, "ce_fwd_bwd", spy)
+        out, acc = m(**{k: v.clone() for k, v in gb.items()})
+        out.loss.backward()
+        monkeypatch.setattr(model_mod.ops, "ce_fwd_bwd", orig)
+        rows_total = ob["labels"].numel() if case != "varlen_packed" else int(ob["attention_mask"].sum())
+        assert sum(shapes) == (n_lab if on else rows_total), (shapes, n_lab)
+        res.append((float(out.loss.detach()), float(acc), m.store.grad.clone()))
+        if on:      # eval forward with labels: full logits come back, every row is computed
+            m.eval()
+            with torch.no_grad():
+                eo, _ = m(**{k: v.clone() for k, v in gb.items()})
+            assert eo.logits.shape[:2] == ob["input_ids"].shape and abs(float(eo.loss) - res[0][0]) < 1e-4
+    (l0, a0, g0), (l1, a1, g1) = res
+    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0)) and a0 == a1, (l0, l1, a0, a1)
+    cs = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
+    assert cs >= 0.99999 and float((g0 - g1).abs().max()) <= 2e-3 * float(g0.abs().max()), (cs, float((g0 - g1).abs().max()))
+
+
 @pytest.mark.parametrize("ragged", [False, True])
 def test_unfrozen_hubert_encoder_matches_oracle(dev, ragged):
     _unfrozen_wave_encoder_case(dev, "hubert", ragged)
