@@ -48,6 +48,11 @@ FUSE_SWIGLU_FWD = _os.environ.get("SLAM_FUSED_SWIGLU_FWD", "0") == "1"
 # no logits out.  The label count reaches the host through a pinned buffer written at the START of the forward (an event wait that
 # has long completed by the time the LLM reaches its head).  SLAM_LM_HEAD_LABEL_ROWS=0 computes every row like HF does.
 LM_HEAD_LABEL_ROWS = _os.environ.get("SLAM_LM_HEAD_LABEL_ROWS", "1") == "1"
+# ... and the LAST decoder layer needs its attention over every row (keys / values), but everything behind the attention -- o_proj, the
+# residual, the MLP, the final RMSNorm -- only feeds the head: those run over the labelled rows too, forward and backward (the rows
+# without a label get exactly the zero gradient they had).  Off when LoRA dropout acts on o / gate / up / down of that layer (the
+# counter-based masks are indexed by row).  SLAM_LAST_LAYER_LABEL_ROWS=0 disables.
+LAST_LAYER_LABEL_ROWS = _os.environ.get("SLAM_LAST_LAYER_LABEL_ROWS", "1") == "1"
 LORA_PAD = 64  # K-extension granule (GEMM K-tile)
 
 
@@ -1751,6 +1756,19 @@ class HipLlamaLora(nn.Module):
             self._drop_calls += 1
             return (self.lora_p, seed, self._drop_calls << 40)
 
+        n_lab, rows, rows64, inv, prune = M, None, None, None, False
+        if targets is not None and train and not return_logits and label_count is not None:
+            label_count[0].synchronize()
+            n_host = int(label_count[1][0])
+            if 0 < n_host < M:      # labelled rows first, in their original order (host-known count: no sync on the index)
+                n_lab = n_host
+                rows64 = torch.argsort(targets < 0, stable=True)[:n_lab]
+                rows = rows64.to(torch.int32)
+                LL = self.layers[-1]
+                prune = LAST_LAYER_LABEL_ROWS and not (use_drop and bool(LL.o.adapters or LL.gu.adapters or LL.down.adapters))
+                if prune:
+                    inv = torch.full((M,), -1, dtype=torch.int32, device=h.device)
+                    inv[rows64] = torch.arange(n_lab, dtype=torch.int32, device=h.device)
         for L in self.layers:
             x1 = L.qkv.new_input(M)
             _, rstd1 = ops.rmsnorm_fwd(h, L.ln1, eps, out=x1[:, :d])
@@ -1762,13 +1780,20 @@ class HipLlamaLora(nn.Module):
             o_ext = L.o.new_input(M)
             _, lse = ops.attn_fwd(qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], vt, B, T, Hq, Hkv, D, True, scale,
                                   key_mask=key_mask, want_lse=train, out=o_ext[:, : Hq * D], seg=seg)
-            h_mid = L.o.forward(o_ext, st, residual=h, drop=do_)
-            x2 = L.gu.new_input(M)
+            pruned = prune and L is self.layers[-1]
+            Mr, o_in, h_res = M, o_ext, h
+            if pruned:      # behind the last attention only the labelled rows matter
+                Mr = self._last_pruned_rows = n_lab
+                o_in = L.o.new_input(Mr)
+                ops.gather_rows(o_ext[:, : Hq * D], rows, out=o_in[:, : Hq * D])
+                h_res = ops.gather_rows(h, rows)
+            h_mid = L.o.forward(o_in, st, residual=h_res, drop=do_)
+            x2 = L.gu.new_input(Mr)
             _, rstd2 = ops.rmsnorm_fwd(h_mid, L.ln2, eps, out=x2[:, :d])
-            hh = L.down.new_input(M)
-            gu_il = train and L.gu.Wil is not None and ops.gemm_swiglu_supported(M, 2 * Fd, d, x2.stride(0), L.gu.Wil.stride(0))
+            hh = L.down.new_input(Mr)
+            gu_il = train and L.gu.Wil is not None and ops.gemm_swiglu_supported(Mr, 2 * Fd, d, x2.stride(0), L.gu.Wil.stride(0))
             if gu_il:   # one launch: [gate64 | up64]-block stash for the backward + h = silu(gate) * up
-                gu = torch.empty((M, 2 * Fd), dtype=torch.bfloat16, device=h.device)
+                gu = torch.empty((Mr, 2 * Fd), dtype=torch.bfloat16, device=h.device)
                 ops.gemm_swiglu(x2[:, :d], L.gu.Wil, gu, hh[:, :Fd])
             else:
                 gu = L.gu.forward(x2, st, drop=dg_)
@@ -1776,7 +1801,8 @@ class HipLlamaLora(nn.Module):
             h_out = L.down.forward(hh, st, residual=h_mid, drop=dd_)
             if train:
                 stash["layers"].append(dict(h=h, rstd1=rstd1, x1=x1 if L.qkv.adapters else None, qkv=qkv, qt=qt, kt=kt,
-                                            o=o_ext, lse=lse, h_mid=h_mid, rstd2=rstd2,
+                                            o=o_in, o_full=o_ext if pruned else None, inv=inv if pruned else None,
+                                            lse=lse, h_mid=h_mid, rstd2=rstd2,
                                             x2=x2 if L.gu.adapters else None, gu=gu, gu_il=gu_il,
                                             hh=hh if L.down.adapters else None, drops=(dq_, do_, dg_, dd_)))
             h = h_out
@@ -1784,15 +1810,9 @@ class HipLlamaLora(nn.Module):
         logits_full = torch.empty((M, V), dtype=torch.bfloat16, device=h.device) if return_logits else None
         out2 = None
         if targets is not None:
-            n_lab, rows, hsel, tsel = M, None, hN, targets
-            if train and not return_logits and label_count is not None:
-                label_count[0].synchronize()
-                n_host = int(label_count[1][0])
-                if 0 < n_host < M:      # labelled rows first, in their original order (host-known count: no sync on the index)
-                    n_lab = n_host
-                    rows64 = torch.argsort(targets < 0, stable=True)[:n_lab]
-                    rows = rows64.to(torch.int32)
-                    hsel, tsel = ops.gather_rows(hN, rows), targets.index_select(0, rows64)
+            hsel, tsel = hN, targets
+            if rows is not None:
+                hsel, tsel = (hN if prune else ops.gather_rows(hN, rows)), targets.index_select(0, rows64)
             row_loss = torch.empty((n_lab,), dtype=torch.float32, device=h.device)
             row_ok = torch.empty((n_lab,), dtype=torch.int32, device=h.device)
             dhN = torch.empty((n_lab, d), dtype=torch.bfloat16, device=h.device) if train else None
@@ -1809,7 +1829,7 @@ class HipLlamaLora(nn.Module):
                     ops.gemm_nt(lg, self.lm_headT, out=dhN[r0:r1])
             out2 = ops.ce_finalize(row_loss, row_ok, n_valid)
             if train:
-                if rows is not None:    # back to the [M, d] layout: the rows without a label carry a zero gradient
+                if rows is not None and not prune:    # back to the [M, d] layout: the rows without a label carry a zero gradient
                     inv = torch.full((M,), -1, dtype=torch.int32, device=h.device)
                     inv[rows64] = torch.arange(n_lab, dtype=torch.int32, device=h.device)
                     dhN = ops.gather_rows(dhN, inv)
@@ -1985,12 +2005,14 @@ class HipLlamaLora(nn.Module):
             dh_mid = ops.rmsnorm_bwd(S["h_mid"], S["rstd2"], L.ln2, dx2[:, :d], dres=dh)
             del dx2
             do_ext = L.o.backward(dh_mid, S["o"], st, accumulate, drop=do_)
-            dO = do_ext[:, : Hq * D]
+            dO, o_attn = do_ext[:, : Hq * D], S["o"]
+            if S["inv"] is not None:    # last layer ran behind its attention over the labelled rows only: back to every row (zeros elsewhere)
+                dO, dh_mid, o_attn = ops.gather_rows(dO, S["inv"]), ops.gather_rows(dh_mid, S["inv"]), S["o_full"]
             dOt = ops.head_rope_transpose(dO, 0, B, T, Hq, D)
             qkv = S["qkv"]
             q2, k2, v2 = qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
             dqkv = torch.empty_like(qkv)
-            ops.attn_bwd(q2, k2, v2, S["qt"], S["kt"], S["o"][:, : Hq * D], dO, dOt, S["lse"],
+            ops.attn_bwd(q2, k2, v2, S["qt"], S["kt"], o_attn[:, : Hq * D], dO, dOt, S["lse"],
                          dqkv[:, : Hq * D], dqkv[:, Hq * D: (Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:],
                          B, T, Hq, Hkv, D, True, scale, key_mask=key_mask, rope=rope, seg=seg)  # RoPE backward fused
             del do_ext, dO, dOt

@@ -208,14 +208,19 @@ def test_fused_swiglu_forward_step_is_bit_identical(dev, monkeypatch):
         assert torch.equal(a, b_)
 
 
-@pytest.mark.parametrize("case", ["padded", "left_pad_ragged", "varlen_packed", "chunked"])
+@pytest.mark.parametrize("case", ["padded", "left_pad_ragged", "varlen_packed", "chunked", "lora_all"])
 def test_lm_head_over_label_rows_equals_every_row(dev, monkeypatch, case):
     """training steps run lm_head / cross entropy / lm_head dX over the labelled rows only (LM_HEAD_LABEL_ROWS): the loss equals the
     every-row form to fp32 summation order (1e-6), the accuracy exactly, every gradient to bf16 product tiling (the same rows go
     through the same kernels; cosine >= 0.99999, max |diff| <= 2e-3 max|g|), on padded, ragged left-padded, packed (varlen) batches
-    and with the head chunked into several row blocks.  The eval forward (labels + logits out) keeps every row."""
+    and with the head chunked into several row blocks.  Three forms: every row, head over the labelled rows, head AND everything
+    behind the last layer's attention over the labelled rows (LAST_LAYER_LABEL_ROWS; "lora_all": adapters on all seven projections,
+    so o / gate / up / down of the last layer take their LoRA gradients from the selected rows).  The eval forward (labels + logits
+    out) keeps every row."""
     from slam_llm_amd import model as model_mod
     cfg = dict(O.make_config(), lora_dropout=0.0, varlen=(case == "varlen_packed"))
+    if case == "lora_all":
+        cfg["lora_targets"] = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
     W = O.init_weights(cfg, seed=42)
     audio = O.synth_audio(3, 1.0, seed=31)
     ob = O.synth_batch(cfg, audio, prompt_len=5, answer_lens=(4, 9, 6) if case != "padded" else (7,), seed=32,
@@ -224,8 +229,9 @@ def test_lm_head_over_label_rows_equals_every_row(dev, monkeypatch, case):
     n_lab = int((ob["labels"][:, 1:] != -100).sum())
     assert 0 < n_lab < ob["labels"].numel() // 2
     res = []
-    for on in (False, True):
+    for on, last in ((False, False), (True, False), (True, True)):
         monkeypatch.setattr(model_mod, "LM_HEAD_LABEL_ROWS", on)
+        monkeypatch.setattr(model_mod, "LAST_LAYER_LABEL_ROWS", last)
         m = model_mod.SlamHipModel(dict(cfg), dev).load_weights(W)
         m.train()
         if case == "chunked":
@@ -243,15 +249,18 @@ def test_lm_head_over_label_rows_equals_every_row(dev, monkeypatch, case):
         rows_total = ob["labels"].numel() if case != "varlen_packed" else int(ob["attention_mask"].sum())
         assert sum(shapes) == (n_lab if on else rows_total), (shapes, n_lab)
         res.append((float(out.loss.detach()), float(acc), m.store.grad.clone()))
+        if last:
+            assert m.llm._last_pruned_rows == n_lab
         if on:      # eval forward with labels: full logits come back, every row is computed
             m.eval()
             with torch.no_grad():
                 eo, _ = m(**{k: v.clone() for k, v in gb.items()})
             assert eo.logits.shape[:2] == ob["input_ids"].shape and abs(float(eo.loss) - res[0][0]) < 1e-4
-    (l0, a0, g0), (l1, a1, g1) = res
-    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0)) and a0 == a1, (l0, l1, a0, a1)
-    cs = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
-    assert cs >= 0.99999 and float((g0 - g1).abs().max()) <= 2e-3 * float(g0.abs().max()), (cs, float((g0 - g1).abs().max()))
+    l0, a0, g0 = res[0]
+    for l1, a1, g1 in res[1:]:
+        assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0)) and a0 == a1, (l0, l1, a0, a1)
+        cs = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
+        assert cs >= 0.99999 and float((g0 - g1).abs().max()) <= 2e-3 * float(g0.abs().max()), (cs, float((g0 - g1).abs().max()))
 
 
 @pytest.mark.parametrize("ragged", [False, True])
