@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void skinny_gram_reduce_kernel(const float* __
 // recomputed in registers, so x is read once and no dropout(x) copy is ever written.
 // ------------------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__((NT <= 2 ? 8 : 4) * 64) void lora_a_fwd_kernel(const bf16_t* __restrict__ X, int64_t ldx,
+__global__ __launch_bounds__((NT <= 2 ? 8 : 4) * 64, 2) void lora_a_fwd_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                          const bf16_t* __restrict__ A, int64_t lda,
                                                          bf16_t* __restrict__ U, int64_t ldu, int M, int R, int K,
                                                          unsigned thresh16, float inv_keep, unsigned long long seed,
@@ -473,39 +473,52 @@ __global__ __launch_bounds__((NT <= 2 ? 8 : 4) * 64) void lora_a_fwd_kernel(cons
   for (int mt = 0; mt < 2; mt++)
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = k_begin; k0 < k_end; k0 += 64) {
-    u16x8_t xf[2][2], af[NT][2];
+  // x is streamed in batches of LA_UNR k-steps: all 4 * LA_UNR 16-byte loads of a batch are issued before the first product waits
+  // (the kernel is latency-bound on HBM: 4 loads in flight per lane left it at 2.1 TB/s); A comes from L2
+  constexpr int LA_UNR = NT <= 2 ? 3 : 2;
+  for (int kb = k_begin; kb < k_end; kb += 64 * LA_UNR) {
+    u16x8_t xf[LA_UNR][2][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-      xf[mt][0] = *reinterpret_cast<const u16x8_t*>(xp[mt] + k0);
-      xf[mt][1] = *reinterpret_cast<const u16x8_t*>(xp[mt] + k0 + 8);
+    for (int it = 0; it < LA_UNR; it++) {
+      const int k0 = min(kb + it * 64, k_end - 64);      // (a short last batch re-reads its last step; skipped below)
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) {
+        xf[it][mt][0] = *reinterpret_cast<const u16x8_t*>(xp[mt] + k0);
+        xf[it][mt][1] = *reinterpret_cast<const u16x8_t*>(xp[mt] + k0 + 8);
+      }
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      af[nt][0] = *reinterpret_cast<const u16x8_t*>(ap[nt] + k0);
-      af[nt][1] = *reinterpret_cast<const u16x8_t*>(ap[nt] + k0 + 8);
-    }
-    if (thresh16) {
+    for (int it = 0; it < LA_UNR; it++) {
+      const int k0 = kb + it * 64;
+      if (k0 >= k_end) break;
+      u16x8_t af[NT][2];
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        af[nt][0] = *reinterpret_cast<const u16x8_t*>(ap[nt] + k0);
+        af[nt][1] = *reinterpret_cast<const u16x8_t*>(ap[nt] + k0 + 8);
+      }
+      if (thresh16) {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+          for (int hf = 0; hf < 2; hf++) {
+            const unsigned keep = slam_keep8(seed, offset + (unsigned long long)mrow[mt] * (unsigned long long)K +
+                                                       (unsigned long long)(k0 + g * 16 + hf * 8), thresh16);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+              if (!((keep >> e) & 1u)) xf[it][mt][hf][e] = 0;
+          }
+      }
 #pragma unroll
       for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-        for (int hf = 0; hf < 2; hf++) {
-          const unsigned keep = slam_keep8(seed, offset + (unsigned long long)mrow[mt] * (unsigned long long)K +
-                                                     (unsigned long long)(k0 + g * 16 + hf * 8), thresh16);
-#pragma unroll
-          for (int e = 0; e < 8; e++)
-            if (!((keep >> e) & 1u)) xf[mt][hf][e] = 0;
+        for (int nt = 0; nt < NT; nt++) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[nt][0]),
+                                                               __builtin_bit_cast(bf16x8_t, xf[it][mt][0]), acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[nt][1]),
+                                                               __builtin_bit_cast(bf16x8_t, xf[it][mt][1]), acc[mt][nt], 0, 0, 0);
         }
     }
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[nt][0]),
-                                                             __builtin_bit_cast(bf16x8_t, xf[mt][0]), acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[nt][1]),
-                                                             __builtin_bit_cast(bf16x8_t, xf[mt][1]), acc[mt][nt], 0, 0, 0);
-      }
   }
   // acc[mt][nt][i] = u[m0 + mt*16 + r][nt*16 + 4g + i]
 #pragma unroll

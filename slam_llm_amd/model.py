@@ -245,7 +245,7 @@ class FusedLinear:
             # vs 1.3 for its neighbours).  K columns = whole tiles, the extension = one narrow (N <= 64) product.
             dx_ext = out if out is not None else torch.empty((dy.shape[0], self.K + self.Rp), dtype=torch.bfloat16, device=dy.device)
             ops.gemm_nt(dy, self.WextT[: self.K], out=dx_ext[:, : self.K])
-            ops.gemm_nt(dy, self.WextT[self.K:], out=dx_ext[:, self.K:])
+            ops.gemm_nt(dy, self.WextT[self.K:], out=dx_ext[:, self.K:])    # (through the first-hop kernel instead: same step time, A/B'd)
         else:
             dx_ext = ops.gemm_nt(dy, self.WextT, out=out)
         if self.adapters:
