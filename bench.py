@@ -337,6 +337,15 @@ def main():
     value = audio_s * args.steps / elapsed
     fl = algorithmic_flops_per_clip(cfg, T, Ta, 3000)
     step_flops = fl["total"] * n_clips
+    # products the step does not execute for rows without a label (slam_llm_amd.model.LM_HEAD_LABEL_ROWS / LAST_LAYER_LABEL_ROWS): the
+    # lm_head forward + dX and, in the last decoder layer, o / gate / up / down forward + dX of those rows -- `mfu` counts what ran
+    from slam_llm_amd import model as _mm
+    rows_skipped = (T - ANSWER) if (_mm.LM_HEAD_LABEL_ROWS) else 0
+    d_, F_ = cfg["llm_dim"], cfg["llm_ffn"]
+    skipped = 2 * 2 * rows_skipped * cfg["vocab"] * d_
+    if rows_skipped and _mm.LAST_LAYER_LABEL_ROWS:
+        skipped += 2 * 2 * rows_skipped * (d_ * d_ + 3 * d_ * F_)
+    executed_flops = step_flops - skipped * n_clips
     ksum = timer.summary()
     gemm_all = [v for k, v in ksum.items() if k.startswith("gemm_nt")]
     gemm_ms = sum(v["total_ms"] for v in gemm_all)
@@ -383,10 +392,15 @@ def main():
                    # max over ranks of the mean HIP-event time of GradSync.finish() per step: tail bucket launch + waits on the compute stream
                    "comm_exposed_ms": comm_exposed_ms,
                    "grad_buffer_MB": model.store.grad.numel() * 4 / 1e6 if world > 1 else None,
-                   "logits": "full [B*T, V] lm_head computed (chunked), not materialised in fp32"},
+                   "logits": ("lm_head / cross entropy over the labelled rows only (the rows with label -100 enter neither loss, accuracy nor any "
+                              "gradient), last decoder layer behind its attention likewise; SLAM_LM_HEAD_LABEL_ROWS=0 computes every row"
+                              if rows_skipped else "full [B*T, V] lm_head computed (chunked), not materialised in fp32")},
         "loss": float(loss), "acc": float(acc),
         "model_flops_per_step_per_gpu": step_flops,
-        "mfu": step_flops / (ms_per_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
+        "executed_flops_per_step_per_gpu": executed_flops,
+        # mfu: the FLOPs the step executed; mfu_model: SURVEY 8(d)'s model (every row through the head) over the same time
+        "mfu": executed_flops / (ms_per_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
+        "mfu_model": step_flops / (ms_per_step * 1e-3) / (PEAK_BF16_TFLOPS * 1e12),
         "roofline": roof,
         "kernels": kern,
     }
