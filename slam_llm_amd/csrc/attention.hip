@@ -253,8 +253,8 @@ __device__ unsigned long long g_attn_probe[2 * 16 * 8];   // tools: cycle stamps
 // forward: 4 waves x 32 query rows per workgroup, 64-key K / V^T tiles staged through LDS
 // ------------------------------------------------------------------------------------------
 // QF = 16-row query fragments per wave (2: 128-query workgroups; 1: 64-query workgroups, fewer VGPRs -> more waves per SIMD)
-template <int D, bool CAUSAL, int QF, bool RP = false, bool DROP = false, bool PROBE = false, bool DMA = false>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+template <int D, bool CAUSAL, int QF, bool RP = false, bool DROP = false, bool PROBE = false, bool DMA = false, bool PLAIN = false>
+__global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
   constexpr int KROWB = D * 2;
@@ -278,6 +278,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int b = blk.z, h = blk.y;
   const int hk = h / (p.Hq / p.Hkv);
   const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
+  // PLAIN: no key mask, no packed segments (the Whisper encoder of a padded batch): the pointers are compile-time null, the
+  // bookkeeping of those paths leaves the register budget, and with two key fragments (not four) requested ahead and the first V^T
+  // reads issued behind the softmax the kernel fits 168 VGPRs = three waves per SIMD
+  const uint8_t* kmask_ = PLAIN ? nullptr : p.kmask;
+  const int* seg_lo_ = PLAIN ? nullptr : p.seg_lo;
+  const int* seg_hi_ = PLAIN ? nullptr : p.seg_hi;
   constexpr int QW = 16 * QF;   // query rows per wave
   const int qb0 = blk.x * (4 * QW), qw0 = qb0 + wave * QW;
 
@@ -306,11 +312,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   // packed batches (seg_lo/seg_hi over QUERY rows, both non-decreasing): query q sees keys seg_lo[q] <= k < seg_hi[q]
   // (and k <= q when causal; the bidirectional form is the ragged Whisper / HuBERT encoder: one clip = one segment).
   // Keys before the start of the block's first sequence / past the end of its last one are never visible.
-  const bool seg_both = !CAUSAL && p.seg_lo != nullptr;
-  const int kend = CAUSAL ? min(Tk, qb0 + 4 * QW) : (seg_both ? min(Tk, p.seg_hi[(int64_t)b * Tq + min(qb0 + 4 * QW - 1, Tq - 1)]) : Tk);
+  const bool seg_both = !CAUSAL && seg_lo_ != nullptr;
+  const int kend = CAUSAL ? min(Tk, qb0 + 4 * QW) : (seg_both ? min(Tk, seg_hi_[(int64_t)b * Tq + min(qb0 + 4 * QW - 1, Tq - 1)]) : Tk);
   const int ntiles = (kend + 63) / 64;
   const float sl2 = p.scale * LOG2E;
-  const int tbeg = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(qb0, Tq - 1)] / 64 : 0;
+  const int tbeg = seg_lo_ ? seg_lo_[(int64_t)b * Tq + min(qb0, Tq - 1)] / 64 : 0;
   int qlo[QF], qhi[QF];
 #pragma unroll
   for (int f = 0; f < QF; f++) {
@@ -319,14 +325,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   }
   int lo_wave_max = 0;            // largest sequence start among this wave's queries
   int hi_wave_min = 0x7fffffff;   // smallest sequence end among them
-  if (p.seg_lo) {
+  if (seg_lo_) {
 #pragma unroll
-    for (int f = 0; f < QF; f++) qlo[f] = p.seg_lo[(int64_t)b * Tq + min(qw0 + f * 16 + li, Tq - 1)];
-    lo_wave_max = p.seg_lo[(int64_t)b * Tq + min(qw0 + QW - 1, Tq - 1)];
+    for (int f = 0; f < QF; f++) qlo[f] = seg_lo_[(int64_t)b * Tq + min(qw0 + f * 16 + li, Tq - 1)];
+    lo_wave_max = seg_lo_[(int64_t)b * Tq + min(qw0 + QW - 1, Tq - 1)];
     if (seg_both) {
 #pragma unroll
-      for (int f = 0; f < QF; f++) qhi[f] = p.seg_hi[(int64_t)b * Tq + min(qw0 + f * 16 + li, Tq - 1)];
-      hi_wave_min = p.seg_hi[(int64_t)b * Tq + min(qw0, Tq - 1)];
+      for (int f = 0; f < QF; f++) qhi[f] = seg_hi_[(int64_t)b * Tq + min(qw0 + f * 16 + li, Tq - 1)];
+      hi_wave_min = seg_hi_[(int64_t)b * Tq + min(qw0, Tq - 1)];
     }
   }
 
@@ -334,12 +340,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   // path although a mask was passed (an LLM batch is padded at one end: most tiles of most rows are clean).
   unsigned long long padtiles = 0;
   bool pad_known = true;
-  if (p.kmask) {
+  if (kmask_) {
     const int ndw = Tkp >> 2;
     if (ndw > 64 * 16) {
       pad_known = false;   // more than 64 tiles: every tile takes the masked path
     } else {
-      const unsigned* m32 = reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tkp);
+      const unsigned* m32 = reinterpret_cast<const unsigned*>(kmask_ + (int64_t)b * Tkp);
       for (int c = 0; c * 64 < ndw; c++) {
         const int dw = c * 64 + lane;
         const unsigned v = dw < ndw ? m32[dw] : 0x01010101u;
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
       frag_t kfr[4][KD];
       // AHEAD key fragments are requested before the first product; fragment kf + AHEAD is requested when kf's operands have
       // landed (D = 128: two ahead = 8 reads in flight -- all four up front cost 33 more VGPRs and measured 6 % slower)
-      constexpr int AHEAD = (D == 128) ? 2 : 4;
+      constexpr int AHEAD = (D == 128 || PLAIN) ? 2 : 4;
       static_for<0, AHEAD>([&](auto kf) {
         static_for<0, KD>([&](auto kd) { kfr[kf][kd] = lds_read128<((kf >> 1) * 32 + (kf & 1) * 4) * KROWB>(ka[kd]); });
       });
@@ -524,12 +530,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int a = 0; a < 2; a++) va[a] = vbase + (unsigned)(((a * 4 + g) ^ ((li >> 1) & 7)) << 4);   // rows d = df*16 + li: (d >> 1) & 7 = (li >> 1) & 7
     frag_t vfr[2][DF];
-    static_for<0, DF>([&](auto df) { vfr[0][df] = lds_read128<df * 16 * 128>(va[0]); });
+    if constexpr (!PLAIN) static_for<0, DF>([&](auto df) { vfr[0][df] = lds_read128<df * 16 * 128>(va[0]); });
     // ---- online softmax (per query = lane&15, replicated over the 4 lane groups) ----
     // The running maximum only moves when a tile exceeds it by more than 2^8 (in the exponent's log2 units): P stays <= 256,
     // exact in fp32 / bf16, and the O / l rescale becomes a rare wave-uniform branch instead of 2 exp + 16 multiplies per tile
     // interior tiles (no padded key, fully inside [0, Tk), fully below the causal diagonal of this wave) skip all masking
-    const bool tile_pad = p.kmask != nullptr && (!pad_known || ((padtiles >> it) & 1ull) != 0);
+    const bool tile_pad = kmask_ != nullptr && (!pad_known || ((padtiles >> it) & 1ull) != 0);
     const bool tile_full = !RP && !DROP && !tile_pad && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0 &&
                            k0 + 64 <= hi_wave_min;
     float alpha[QF];
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         if constexpr (PAD) {
 #pragma unroll
           for (int kf = 0; kf < 4; kf++)
-            mk[kf] = *reinterpret_cast<const unsigned*>(p.kmask + (int64_t)b * Tkp + k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4);
+            mk[kf] = *reinterpret_cast<const unsigned*>(kmask_ + (int64_t)b * Tkp + k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4);
         }
 #pragma unroll
         for (int f = 0; f < QF; f++) {
@@ -667,6 +673,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
     stamp(it, 5);
     // ---- O^T += V^T . P^T ----
+    if constexpr (PLAIN) static_for<0, DF>([&](auto df) { vfr[0][df] = lds_read128<df * 16 * 128>(va[0]); });
     static_for<0, 2>([&](auto a) {
       frag_t pb[QF];
 #pragma unroll
@@ -1796,16 +1803,19 @@ extern "C" int slam_attn_set_bwd_variant(int variant) {   // tools: 0 = DMA-ring
   return 0;
 }
 
-extern int g_attn_fwd_dma;
+extern int g_attn_fwd_dma, g_attn_fwd_plain;
 extern "C" int slam_attn_set_fwd_qf(int qf) {   // tools: 0 = auto, 1 / 2 fragments per wave; 10 / 11 = register-staged / DMA tiles
-  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11 || qf == 20 || qf == 21,
-                 "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2; 10 / 11 = staged / DMA tiles; 20 / 21 = hardware / XCD-aware workgroup order)", qf);
-  if (qf >= 20) g_attn_xcd = qf - 20;   // (all attention kernels, forward and backward)
+  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11 || qf == 20 || qf == 21 || qf == 30 || qf == 31,
+                 "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2; 10 / 11 = staged / DMA tiles; 20 / 21 = hardware / XCD-aware workgroup order; "
+                 "30 / 31 = general / mask-free instantiation for unmasked bidirectional D = 64)", qf);
+  if (qf >= 30) g_attn_fwd_plain = qf - 30;
+  else if (qf >= 20) g_attn_xcd = qf - 20;   // (all attention kernels, forward and backward)
   else if (qf >= 10) g_attn_fwd_dma = qf - 10;
   else g_attn_fwd_qf = qf;
   return 0;
 }
 
+int g_attn_fwd_plain = 1; // 1 = unmasked bidirectional D = 64 launches (Whisper) take the instantiation without mask / segment bookkeeping
 int g_attn_fwd_dma = 1;   // 1 = K / V^T tiles by LDS-DMA ring (shipped), 0 = register-staged tiles (A/B in tools)
 
 // forward launch: the DMA form whenever the 32-bit byte offsets of its descriptors can address K and V^T
@@ -1814,6 +1824,12 @@ static void launch_fwd(const AttnParams& p, int64_t B, hipStream_t s) {
   dim3 grid((unsigned)cdiv64(p.Tq, 64 * QF), (unsigned)p.Hq, (unsigned)B);
   const int64_t lim = (int64_t)1 << 31;
   const bool fits = (B * p.Tk * p.ldk + (int64_t)p.Hkv * D) * 2 < lim && B * p.Hkv * D * p.Tkp * 2 < lim;
+  if constexpr (D == 64 && !CAUSAL && QF == 2 && !RP && !DROP && !PROBE) {
+    if (fits && g_attn_fwd_dma && !p.kmask && !p.seg_lo && g_attn_fwd_plain) {
+      attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true>), grid, 256, 0, s, p);
+      return;
+    }
+  }
   if (fits && g_attn_fwd_dma) attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true>), grid, 256, 0, s, p);
   else attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, false>), grid, 256, 0, s, p);
 }

@@ -1293,8 +1293,8 @@ class HipWavLMEncoder(HipHubertEncoder):
     to the scores.  Weights are read under the reference module's own state-dict names (`encoder.model.*`)."""
 
     def __init__(self, cfg: dict, device, store: Optional["TrainableStore"] = None, prefix="encoder.model."):
-        self._tables, self._buckets = {}, {}
         super().__init__(cfg, device, store, prefix)
+        self._tables, self._buckets = {}, {}
 
     # ---- trainable form: the reference module's own parameter names (WavLM.py:220-330, modules.py:330-420) -------------------
     def _nm(self) -> SimpleNamespace:

@@ -37,18 +37,21 @@ def timed(n=10):
 
 
 # forms timed interleaved (the clocks follow the recent load): (fragments per wave, LDS-DMA tiles)
-FORMS = [("2 fragments per wave, DMA tiles (shipped)", 2, 11), ("1 fragment per wave, DMA tiles", 1, 11),
-         ("2 fragments per wave, register-staged tiles", 2, 10), ("1 fragment per wave, register-staged tiles", 1, 10)]
-res = {n: [] for n, _, _ in FORMS}
+FORMS = [("2 fragments per wave, DMA tiles, mask-free instantiation: 3 waves / SIMD (shipped)", 2, 11, 31),
+         ("2 fragments per wave, DMA tiles, general instantiation: 2 waves / SIMD", 2, 11, 30), ("1 fragment per wave, DMA tiles", 1, 11, 30),
+         ("2 fragments per wave, register-staged tiles", 2, 10, 30), ("1 fragment per wave, register-staged tiles", 1, 10, 30)]
+res = {n: [] for n, _, _, _ in FORMS}
 for rnd in range(4):
-    for n, qf, dma in FORMS:
+    for n, qf, dma, plain in FORMS:
         call("slam_attn_set_fwd_qf", qf)
         call("slam_attn_set_fwd_qf", dma)
+        call("slam_attn_set_fwd_qf", plain)
         fwd()
         res[n].append(timed())
 call("slam_attn_set_fwd_qf", 0)
 call("slam_attn_set_fwd_qf", 11)
-for n, _, _ in FORMS:
+call("slam_attn_set_fwd_qf", 31)
+for n, _, _, _ in FORMS:
     v = sorted(res[n][1:])
     print(f"fwd, {n}: median {v[1]:.1f} us  {4.0 * B * H * T * T * D / v[1] / 1e6:.1f} TF")
 call("slam_attn_set_bwd_variant", 14)
