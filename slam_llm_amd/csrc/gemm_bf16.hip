@@ -206,8 +206,10 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const GemmParams& p, f32x4_t 
   // fragment 2*jp + (fg & 1), starting at column (fg >> 1) * 8.
   // INNER: the workgroup's whole tile lies inside [0, M) x [0, N) -- no per-lane guards (all but the last tile row / column).
   // A row's residual values are requested together, ahead of its arithmetic (one wait per row, not one per fragment).
+  // (alpha == 1 here: gemm_epilogue sends scaled products through the generic form -- as a wave-uniform `if` inside this loop the
+  // compiler turned the scaling into 4 v_pk_mul + 8 v_cndmask per 16-byte store, half the VALU of the plain path; and with ONE wave
+  // per SIMD the store tail of the 4-wave kernel is bound by exactly that dependent VALU chain, ~350 cycles per store)
   const int nbase = n0 + wn * WTN;
-  const bool scaled = p.alpha != 1.0f;
   float4 bias4[FN];
   if constexpr (BIAS) {
 #pragma unroll
@@ -216,6 +218,7 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const GemmParams& p, f32x4_t 
       bias4[j] = (INNER || n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  bf16_t* const crow0 = reinterpret_cast<bf16_t*>(p.C) + (int64_t)(m0 + wm * WTM + frow) * p.ldc + nbase + (fg & 1) * 16 + (fg >> 1) * 8;
 #pragma unroll
   for (int i = 0; i < FM; i++) {
     const int m = m0 + wm * WTM + i * 16 + frow;
@@ -229,7 +232,10 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const GemmParams& p, f32x4_t 
         else res4[j] = u16x4_t{0, 0, 0, 0};
       }
     }
-    bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nbase + (fg & 1) * 16 + (fg >> 1) * 8;
+    bf16_t* crow = crow0 + (int64_t)i * 16 * p.ldc;   // (one 64-bit add per row, not a 64-bit multiply)
+    // all packed values of the row first, then its stores back to back: with the 16 bytes of every store in the SAME four registers
+    // each conversion had to wait until the previous store had read its data out of the register file
+    uint4 outv[FN / 2];
 #pragma unroll
     for (int jp = 0; jp < FN / 2; jp++) {
       unsigned pk[2][2];
@@ -239,10 +245,6 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const GemmParams& p, f32x4_t 
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] = acc[i][j][e];
-        if (scaled) {   // wave-uniform, almost never taken (alpha = 1 everywhere but the LoRA scaling products)
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] *= p.alpha;
-        }
         if constexpr (BIAS) {
           v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w;
         }
@@ -262,17 +264,21 @@ __device__ __forceinline__ void gemm_epilogue_bf16(const GemmParams& p, f32x4_t 
       }
       swap_rows16(pk[0][0], pk[1][0]);
       swap_rows16(pk[0][1], pk[1][1]);
+      outv[jp] = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+    }
+#pragma unroll
+    for (int jp = 0; jp < FN / 2; jp++) {
       bf16_t* c = crow + jp * 32;
       if constexpr (INNER) {
-        *reinterpret_cast<uint4*>(c) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+        *reinterpret_cast<uint4*>(c) = outv[jp];
       } else {
         const int nn = nbase + (2 * jp + (fg & 1)) * 16 + (fg >> 1) * 8;
         if (nn + 8 <= p.N) {
-          *reinterpret_cast<uint4*>(c) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+          *reinterpret_cast<uint4*>(c) = outv[jp];
         } else if (nn < p.N) {   // N % 4 == 0 is enforced by the launcher
           uint2 o2;
-          o2.x = pk[0][0];
-          o2.y = pk[0][1];
+          o2.x = outv[jp].x;
+          o2.y = outv[jp].y;
           *reinterpret_cast<uint2*>(c) = o2;
         }
       }
@@ -429,7 +435,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
       gemm_epilogue_swiglu_bwd<FM, FN, WTM, WTN, false>(p, acc, m0, n0, wm, wn, frow, fg);
     return;
   }
-  if (p.out_f32 || p.accumulate || p.act == 3) {
+  if (p.out_f32 || p.accumulate || p.act == 3 || p.alpha != 1.0f) {
     gemm_epilogue_generic<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, frow, fg);
     return;
   }

@@ -17,7 +17,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslamhip.so")
+# SLAM_HIP_LIB: another build of the same library (tools: A/B of two kernel versions inside one gpurun call); never a fallback
+LIB_PATH = os.environ.get("SLAM_HIP_LIB") or os.path.join(_HERE, "libslamhip.so")
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SWIGLU_BWD = 0, 1, 2, 3
