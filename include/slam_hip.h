@@ -55,6 +55,8 @@ int slam_logmel_fwd(const float* audio, int64_t ld_audio, const int32_t* n_valid
 /* ---- GEMM: every Linear / Conv1d-as-GEMM / lm_head on the path ---------------------------------
  * C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T): +bias[N] (f32), act, +residual[(m % res_row_mod), n] (bf16),
  * optional accumulate into C, C bf16 or f32.  K % 64 == 0, N % 4 == 0, 16-byte aligned operands.
+ * lda may be SMALLER than K: the rows of A then overlap -- row t of a strided Conv1d's im2col matrix over a row-major [T, C]
+ * signal is the k * C contiguous elements from row stride * t on, i.e. A = signal, lda = stride * C, K = k * C, no copy.
  * act: 0 none, 1 GELU(erf), 2 ReLU, 3 SwiGLU backward: the product is dL/dh of h = silu(gate) * up (HF LlamaMLP), `residual`
  * holds the forward's [gate | up] ([M, 2N]); dL/dgate goes to C[:, :N] and dL/dup to C[:, N:2N] (no residual add).
  * Sites: Whisper linears/convs (src/slam_llm/models/encoder.py:18-29), projector (projector.py:24-26),

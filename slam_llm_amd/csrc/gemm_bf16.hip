@@ -1475,7 +1475,10 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
   SLAM_CHECK_ARG(ldc % 4 == 0, "slam_gemm_bf16_nt: ldc must be a multiple of 4 elements");
   SLAM_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
                  "slam_gemm_bf16_nt: operands must be 16-byte aligned");
-  SLAM_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "slam_gemm_bf16_nt: leading dimension too small");
+  // lda < K is allowed: the rows of A then OVERLAP -- a strided-convolution window over a row-major [T, C] signal is exactly such a
+  // view (row t = the k * C contiguous elements from row stride * t on), so conv layers need no im2col copy; every kernel addresses
+  // A as row * lda + k and sizes its descriptor as (M - 1) * lda + K elements
+  SLAM_CHECK_ARG(lda >= 8 && ldb >= K && ldc >= N, "slam_gemm_bf16_nt: leading dimension too small");
   SLAM_CHECK_ARG(act >= 0 && act <= 3, "slam_gemm_bf16_nt: act %d unknown", act);
   if (act == 3) {
     SLAM_CHECK_ARG(residual && ldr >= 2 * N && ldc >= 2 * N && out_dtype == SLAM_BF16 && !accumulate && !bias,

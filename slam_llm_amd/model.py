@@ -54,6 +54,10 @@ LM_HEAD_LABEL_ROWS = _os.environ.get("SLAM_LM_HEAD_LABEL_ROWS", "1") == "1"
 # counter-based masks are indexed by row).  SLAM_LAST_LAYER_LABEL_ROWS=0 disables.
 LAST_LAYER_LABEL_ROWS = _os.environ.get("SLAM_LAST_LAYER_LABEL_ROWS", "1") == "1"
 LORA_PAD = 64  # K-extension granule (GEMM K-tile)
+# HuBERT / WavLM conv layers 1-6 (k 3 / 2, stride 2, 512 channels, no padding): the im2col matrix of a row-major [T, C] signal is a VIEW
+# with overlapping rows (row t = the k * C contiguous elements from row 2 t on) -- handed to the GEMM as lda = stride * C, one launch
+# per clip, instead of 2.9 GB of materialised columns per C4 step.  SLAM_CONV_WINDOW_VIEW=0: the im2col kernel + one launch per layer.
+CONV_WINDOW_VIEW = _os.environ.get("SLAM_CONV_WINDOW_VIEW", "1") == "1"
 
 
 # ======================================================================================== presets
@@ -898,6 +902,72 @@ class HipHubertEncoder(nn.Module):
         w["lnp_w"], w["lnp_b"] = 1 + rn(d, std=0.1), rn(d, std=0.1)
         return self
 
+    def _conv_by_view(self, i: int, cin: int, k: int) -> bool:
+        return CONV_WINDOW_VIEW and i > 0 and (k * cin) % 64 == 0 and self.w[f"c{i}"].shape[1] == k * cin
+
+    def _conv_view_gemm(self, x2d: torch.Tensor, B: int, Tin: int, cin: int, k: int, st: int, i: int, act=ACT_NONE) -> torch.Tensor:
+        """conv layer i as B GEMMs over the overlapping-row window view of the [B * Tin, cin] signal (see CONV_WINDOW_VIEW)"""
+        w = self.w
+        Tout = (Tin - k) // st + 1
+        assert x2d.is_contiguous() and x2d.shape == (B * Tin, cin)
+        y = torch.empty((B * Tout, w[f"c{i}"].shape[0]), dtype=torch.bfloat16, device=x2d.device)
+        for b_ in range(B):
+            a = x2d.as_strided((Tout, k * cin), (st * cin, 1), x2d.storage_offset() + b_ * Tin * cin)
+            ops.gemm_nt(a, w[f"c{i}"], out=y[b_ * Tout:(b_ + 1) * Tout], bias=w[f"c{i}_b"], act=act)
+        return y
+
+    def _conv_stack_pitched(self, wav2d: torch.Tensor, B: int, N: int):
+        """the "layer_norm" conv stack (inference) with ONE GEMM launch per layer over the window view: layer i's rows live at a per-clip
+        pitch P_i >= T_i chosen so that P_i = stride_{i+1} * P_{i+1} -- then row r = b * P_{i+1} + t of layer i + 1 reads the k * C contiguous
+        elements from row stride * r of layer i's buffer for EVERY clip (uniform lda), the P_i - T_i rows at the end of a clip are computed from
+        whatever follows and never read by a valid row (valid row t of layer i + 1 ends at input row T_i - 1 or before).  HuBERT-large,
+        30 s: pitches 96000 / 48000 / ... / 1500 for 95999 / 47999 / ... / 1499 valid rows.  Returns (features [B * T_last, C], T_last, C)
+        or None when a layer cannot take the view (tiny channel counts)."""
+        cfg, w = self.cfg, self.w
+        ks, ss, dims = list(cfg["hub_conv_kernel"]), list(cfg["hub_conv_stride"]), list(cfg["hub_conv_dim"])
+        L = len(dims)
+        if not CONV_WINDOW_VIEW or any(not self._conv_by_view(i, dims[i - 1], ks[i]) for i in range(1, L)):
+            return None
+        Ts = [(N - ks[0]) // ss[0] + 1]
+        for i in range(1, L):
+            Ts.append((Ts[-1] - ks[i]) // ss[i] + 1)
+        P_last = Ts[-1]
+        while True:
+            P = [0] * L
+            P[-1] = P_last
+            for i in range(L - 2, -1, -1):
+                P[i] = P[i + 1] * ss[i + 1]
+            if all(P[i] >= Ts[i] for i in range(L)):
+                break
+            P_last += 1
+        dev = wav2d.device
+        slack = max(ks)
+        # layer 0 (cin = 1, k = 10: its 10-wide windows do go through im2col), LayerNorm + GELU written clip by clip at pitch P[0]
+        cols, T0 = ops.conv1d_im2col(wav2d, B, N, 0, 1, ks[0], ss[0], 0, Kp=w["c0"].shape[1])
+        y = ops.gemm_nt(cols, w["c0"], bias=w["c0_b"])
+        del cols
+        buf = torch.empty((B * P[0] + slack, dims[0]), dtype=torch.bfloat16, device=dev)
+        buf[B * P[0]:].zero_()
+        if P[0] > T0:
+            buf[: B * P[0]].view(B, P[0], dims[0])[:, T0:].zero_()
+        for b_ in range(B):
+            ops.layernorm(y[b_ * T0:(b_ + 1) * T0], w["c0_lw"], w["c0_lb"], 1e-5, out=buf[b_ * P[0]: b_ * P[0] + T0], gelu=True)
+        del y
+        for i in range(1, L):
+            cin, co = dims[i - 1], dims[i]
+            a = buf.as_strided((B * P[i], ks[i] * cin), (ss[i] * cin, 1), buf.storage_offset())
+            nxt = torch.empty((B * P[i] + slack, co), dtype=torch.bfloat16, device=dev)
+            nxt[B * P[i]:].zero_()
+            ops.gemm_nt(a, w[f"c{i}"], out=nxt[: B * P[i]], bias=w[f"c{i}_b"])
+            ops.layernorm(nxt[: B * P[i]], w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5, out=nxt[: B * P[i]], gelu=True)
+            buf = nxt
+        key = (B, P[-1], Ts[-1])
+        if getattr(self, "_pitch_idx_key", None) != key:
+            idx = (torch.arange(B, dtype=torch.int32)[:, None] * P[-1] + torch.arange(Ts[-1], dtype=torch.int32)[None, :]).reshape(-1)
+            self._pitch_idx, self._pitch_idx_key = idx.to(dev), key
+        feats = ops.gather_rows(buf[: B * P[-1]], self._pitch_idx) if P[-1] > Ts[-1] else buf[: B * P[-1]]
+        return feats, Ts[-1], dims[-1]
+
     def out_frames(self, n: int) -> int:
         for k, s_ in zip(self.cfg["hub_conv_kernel"], self.cfg["hub_conv_stride"]):
             n = (n - k) // s_ + 1
@@ -922,7 +992,16 @@ class HipHubertEncoder(nn.Module):
         x2d, Tin, cin = wav.contiguous().view(B * N, 1), N, 1
         group_mode = cfg.get("hub_extractor_mode", "layer_norm") == "default"
         pre_ln = cfg.get("hub_layer_norm_first", True)
+        pitched = None if group_mode else self._conv_stack_pitched(x2d, B, N)
         for i, (co, k, st) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"], cfg["hub_conv_stride"])):
+            if pitched is not None:     # the whole stack ran on per-clip pitches: one launch per layer (see _conv_stack_pitched)
+                x2d, Tin, cin = pitched
+                break
+            if self._conv_by_view(i, cin, k):
+                y = self._conv_view_gemm(x2d, B, Tin, cin, k, st, i, act=ACT_GELU if group_mode else ACT_NONE)
+                x2d = y if group_mode else ops.layernorm(y, w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5, out=y, gelu=True)
+                Tin, cin = (Tin - k) // st + 1, co
+                continue
             cols, Tout = ops.conv1d_im2col(x2d, B, Tin, 0, cin, k, st, 0, Kp=w[f"c{i}"].shape[1])
             if not group_mode:      # "layer_norm" extractor: conv -> LayerNorm over channels -> GELU, every layer
                 y = ops.gemm_nt(cols, w[f"c{i}"], bias=w[f"c{i}_b"])
@@ -1010,8 +1089,20 @@ class HipHubertEncoder(nn.Module):
         x2d, Tin, cin = wav.contiguous().view(B * N, 1), N, 1
         convs = []
         for i, (co, k, st) in enumerate(zip(cfg["hub_conv_dim"], cfg["hub_conv_kernel"], cfg["hub_conv_stride"])):
-            cols, Tout = ops.conv1d_im2col(x2d, B, Tin, 0, cin, k, st, 0, Kp=w[f"c{i}"].shape[1])
-            if not self._group_mode:      # conv -> LayerNorm over channels -> GELU
+            by_view = self._conv_by_view(i, cin, k)
+            Tout = (Tin - k) // st + 1
+            cols = None if by_view else ops.conv1d_im2col(x2d, B, Tin, 0, cin, k, st, 0, Kp=w[f"c{i}"].shape[1])[0]
+            if by_view and (not self._group_mode or i > 0):
+                y = self._conv_view_gemm(x2d, B, Tin, cin, k, st, i)
+                if not self._group_mode:
+                    z, m, r = ops.layernorm(y, w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5, stats=True)
+                    xo = ops.gelu_fwd(z)
+                    del z
+                    convs.append(dict(x_in=x2d, Tin=Tin, cin=cin, y=y, m=m, r=r))
+                else:
+                    xo = ops.gelu_fwd(y)
+                    convs.append(dict(x_in=x2d, Tin=Tin, cin=cin, y=y))
+            elif not self._group_mode:      # conv -> LayerNorm over channels -> GELU
                 y = ops.gemm_nt(cols, w[f"c{i}"], bias=w[f"c{i}_b"])
                 z, m, r = ops.layernorm(y, w[f"c{i}_lw"], w[f"c{i}_lb"], 1e-5, stats=True)
                 xo = ops.gelu_fwd(z)
