@@ -349,6 +349,34 @@ def test_attn_bwd_with_gated_relative_position_bias(dev, T, masked):
     assert float(d_tab[:, :64].abs().max()) == 0 and float(d_tab[:, 64 + 2 * T - 1:].abs().max()) == 0      # the slack stays untouched
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 6, 7, 11, 12])
+@pytest.mark.parametrize("k,stride,C,T", [(3, 2, 512, 4001), (2, 2, 512, 1500), (3, 2, 64, 777)])
+def test_gemm_over_the_overlapping_row_window_view_equals_im2col(dev, cfg, k, stride, C, T):
+    """lda < K (include/slam_hip.h): A = the window view of a row-major [T, C] signal (row t = the k * C contiguous elements from row
+    stride * t on) -- the product must equal, bit for bit, the product over the materialised im2col matrix with the same kernel, for
+    every GEMM kernel the auto rule can pick (HuBERT / WavLM conv layers 1-6 run this way), incl. bias + GELU and a row count that is
+    not a tile multiple; and it must equal torch's conv1d to bf16 rounding."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(k * 100 + C)
+    x = torch.randn(T + 4, C, generator=g).to(torch.bfloat16).to(dev)        # (+ slack rows: the view never reads past row T - 1)
+    Wt = (torch.randn(256, C, k, generator=g) * (C * k) ** -0.5)
+    w2 = Wt.permute(0, 2, 1).reshape(256, k * C).to(torch.bfloat16).to(dev)     # tap-major columns = the window's element order
+    bias = (torch.randn(256, generator=g) * 0.1).to(dev)
+    Tout = (T - k) // stride + 1
+    a_view = x.as_strided((Tout, k * C), (stride * C, 1), x.storage_offset())
+    cols, To2 = ops.conv1d_im2col(x[:T], 1, T, 0, C, k, stride, 0, Kp=k * C)
+    assert To2 == Tout and torch.equal(cols, a_view.contiguous())
+    ops.gemm_set_config(cfg)
+    try:
+        y_view = ops.gemm_nt(a_view, w2, bias=bias, act=ops.ACT_GELU)
+        y_cols = ops.gemm_nt(cols, w2, bias=bias, act=ops.ACT_GELU)
+    finally:
+        ops.gemm_set_config(0)
+    assert torch.equal(y_view, y_cols)
+    ref = F.gelu(F.conv1d(x[:T].float().t()[None].cpu(), Wt.to(torch.bfloat16).float(), bias.cpu(), stride=stride))[0].t()
+    assert_close(y_view, ref, atol=2e-2, rtol=2e-2, what="window-view conv vs torch")
+
+
 # ----------------------------------------------------------------------------------------- grouped positional conv
 @pytest.mark.parametrize("C,K,T", [(64, 128, 300), (48, 128, 517), (32, 16, 100), (64, 127, 256), (80, 128, 300)])
 def test_pos_conv_one_launch_matches_torch_grouped_conv(dev, C, K, T):
