@@ -640,6 +640,24 @@ class HipWhisperEncoder(nn.Module):
 
 
 
+def conv_stack_pitches(n_samples: int, kernels, strides):
+    """valid rows T_i of every conv layer (no padding) and the smallest per-clip row pitches P_i >= T_i with P_i = stride_(i+1) * P_(i+1):
+    on those pitches row b * P_(i+1) + t of layer i + 1 starts at row stride * (b * P_(i+1) + t) of layer i's buffer for every clip"""
+    L = len(kernels)
+    Ts = [(n_samples - kernels[0]) // strides[0] + 1]
+    for i in range(1, L):
+        Ts.append((Ts[-1] - kernels[i]) // strides[i] + 1)
+    P_last = Ts[-1]
+    while True:
+        P = [0] * L
+        P[-1] = P_last
+        for i in range(L - 2, -1, -1):
+            P[i] = P[i + 1] * strides[i + 1]
+        if all(P[i] >= Ts[i] for i in range(L)):
+            return Ts, P
+        P_last += 1
+
+
 # ======================================================================================== hubert encoder
 class HipHubertEncoder(nn.Module):
     """Frozen HuBERT encoder (fairseq HubertModel as called at src/slam_llm/models/slam_model.py:335-341;
@@ -928,18 +946,7 @@ class HipHubertEncoder(nn.Module):
         L = len(dims)
         if not CONV_WINDOW_VIEW or any(not self._conv_by_view(i, dims[i - 1], ks[i]) for i in range(1, L)):
             return None
-        Ts = [(N - ks[0]) // ss[0] + 1]
-        for i in range(1, L):
-            Ts.append((Ts[-1] - ks[i]) // ss[i] + 1)
-        P_last = Ts[-1]
-        while True:
-            P = [0] * L
-            P[-1] = P_last
-            for i in range(L - 2, -1, -1):
-                P[i] = P[i + 1] * ss[i + 1]
-            if all(P[i] >= Ts[i] for i in range(L)):
-                break
-            P_last += 1
+        Ts, P = conv_stack_pitches(N, ks, ss)
         dev = wav2d.device
         slack = max(ks)
         # layer 0 (cin = 1, k = 10: its 10-wide windows do go through im2col), LayerNorm + GELU written clip by clip at pitch P[0]

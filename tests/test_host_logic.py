@@ -344,3 +344,19 @@ def test_packed_aware_frame_budget():
     with pytest.raises(ValueError):
         list(batcher.dynamic_batches(samples, 3000, budget="mean"))
     assert batcher.frames_for_hbm() > 60000
+
+
+def test_conv_stack_pitches_cover_every_valid_window():
+    """HuBERT / WavLM conv layers 1-6 read layer i's [B * P_i, C] buffer as ONE overlapping-row matrix (lda = stride * C): row r of layer
+    i + 1 starts at buffer row stride * r.  For that to be clip b's window t for every b, P_i = stride * P_(i+1); every valid output
+    (t < T_(i+1)) must read only valid input rows (< T_i) of its own clip."""
+    from slam_llm_amd.model import conv_stack_pitches
+    ks, ss = (10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)
+    Ts, P = conv_stack_pitches(480000, ks, ss)
+    assert Ts == [95999, 47999, 23999, 11999, 5999, 2999, 1499] and P == [96000, 48000, 24000, 12000, 6000, 3000, 1500]
+    for n in (16000, 11200, 48000, 400, 479999, 123457):
+        Ts, P = conv_stack_pitches(n, ks, ss)
+        for i in range(1, len(ks)):
+            assert P[i - 1] == ss[i] * P[i] and P[i] >= Ts[i] and P[i - 1] >= Ts[i - 1]
+            assert ss[i] * (Ts[i] - 1) + ks[i] - 1 <= Ts[i - 1] - 1          # the last valid window ends inside the valid rows
+        assert P[-1] - Ts[-1] <= 2                                         # (the padding is a row or two per clip, not a multiple)
