@@ -189,8 +189,11 @@ def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pre
         pad = hubert_frame_padding_mask(wav.shape[1], x.shape[1], n_valid)
         x = x.masked_fill(pad[:, :, None], 0.0)
         key_bias = torch.zeros(pad.shape).masked_fill(pad, float("-inf"))[:, None, None, :]
-    pos = F.conv1d(x.transpose(1, 2), W[p + "pos_conv_embed.conv.weight"], W[p + "pos_conv_embed.conv.bias"],
-                   padding=kpos // 2, groups=cfg["hub_pos_groups"])
+    pw = W.get(p + "pos_conv_embed.conv.weight")
+    if pw is None:      # weight_norm(dim=2) kept as parameters (HF: parametrizations.weight.original0 = g [1, 1, k], original1 = v;
+        g_, v_ = W[p + "pos_conv_embed.conv.parametrizations.weight.original0"], W[p + "pos_conv_embed.conv.parametrizations.weight.original1"]
+        pw = g_ * v_ / v_.norm(dim=(0, 1), keepdim=True)   # fairseq: encoder.pos_conv.0.weight_g / weight_v -- what the reference trains)
+    pos = F.conv1d(x.transpose(1, 2), pw, W[p + "pos_conv_embed.conv.bias"], padding=kpos // 2, groups=cfg["hub_pos_groups"])
     if kpos % 2 == 0:
         pos = pos[:, :, :-1]
     x = x + F.gelu(pos).transpose(1, 2)
@@ -222,7 +225,8 @@ def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pre
     return F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], eps) if pre_ln else x
 
 
-def init_hubert_weights(cfg: dict, seed: int = 7, prefix="encoder.") -> Dict[str, torch.Tensor]:
+def init_hubert_weights(cfg: dict, seed: int = 7, prefix="encoder.", weight_norm: bool = False) -> Dict[str, torch.Tensor]:
+    """weight_norm=True: the positional conv keeps its (g, v) parametrisation (g != ||v||) instead of the folded weight"""
     g = torch.Generator().manual_seed(seed)
 
     def rn(*shape, std=0.02):
@@ -249,6 +253,10 @@ def init_hubert_weights(cfg: dict, seed: int = 7, prefix="encoder.") -> Dict[str
     gch = d // cfg["hub_pos_groups"]
     W[p + "pos_conv_embed.conv.weight"] = rn(d, gch, cfg["hub_pos_k"], std=(1.0 / (gch * cfg["hub_pos_k"])) ** 0.5)
     W[p + "pos_conv_embed.conv.bias"] = rn(d)
+    if weight_norm:
+        v_ = W.pop(p + "pos_conv_embed.conv.weight")
+        W[p + "pos_conv_embed.conv.parametrizations.weight.original1"] = v_
+        W[p + "pos_conv_embed.conv.parametrizations.weight.original0"] = v_.norm(dim=(0, 1), keepdim=True) * (1 + rn(1, 1, cfg["hub_pos_k"], std=0.2))
     for i in range(cfg["hub_layers"]):
         q_ = f"{p}layers.{i}."
         for n in ("q_proj", "k_proj", "v_proj", "out_proj"):

@@ -690,7 +690,33 @@ class HipHubertEncoder(nn.Module):
         return bool(self.cfg.get("hub_layer_norm_first", True))
 
     def _nm(self) -> SimpleNamespace:
-        """logical tensor -> state-dict name of the trainable form (HF HuBERT names; HipWavLMEncoder overrides with the reference WavLM's)"""
+        """logical tensor -> state-dict name of the trainable form.  Default: the names of the module the reference un-freezes -- fairseq's
+        HubertModel (models/slam_model.py:110-113 sets requires_grad on `self.encoder`, built at models/encoder.py:130-140 by fairseq's
+        checkpoint_utils), whose parameters are `encoder.feature_extractor.conv_layers.N.0.weight`, `encoder.post_extract_proj.*`,
+        `encoder.encoder.pos_conv.0.weight_g / weight_v`, `encoder.encoder.layers.N.self_attn.q_proj.*`, ... (the module tree that
+        src/slam_llm/models/wavlm/WavLM.py:220-330 vendors a copy of) -- so `named_parameters()` / checkpoints written from it carry the
+        reference's keys and AdamW acts on (g, v) of the weight-normed positional conv like it does there.  `hub_param_names="hf"`: the HF
+        twin's names with the positional conv FOLDED (w = g v / ||v||), for checkpoints that only exist in HF form."""
+        if self.cfg.get("hub_param_names", "fairseq") == "hf":
+            return self._nm_hf()
+        return self._nm_fairseq()
+
+    def _nm_fairseq(self) -> SimpleNamespace:
+        p = self.prefix
+        e = p + "encoder."
+        c = lambda i: f"{p}feature_extractor.conv_layers.{i}."   # noqa: E731
+        lyr = lambda i: f"{e}layers.{i}."                        # noqa: E731
+        gm = self._group_mode     # "default" extractor: Fp32GroupNorm at index 2 of layer 0 only, no conv bias
+        return SimpleNamespace(
+            conv_w=lambda i: c(i) + "0.weight", conv_b=None if (gm or not self.cfg.get("hub_conv_bias", True)) else (lambda i: c(i) + "0.bias"),
+            conv_ln=lambda i: (c(i) + "2" if i == 0 else None) if gm else c(i) + "2.1",
+            fp_ln=p + "layer_norm", fp=p + "post_extract_proj",
+            pos_w=None, pos_g=e + "pos_conv.0.weight_g", pos_v=e + "pos_conv.0.weight_v", pos_b=e + "pos_conv.0.bias",
+            q=lambda i: lyr(i) + "self_attn.q_proj", k=lambda i: lyr(i) + "self_attn.k_proj", v=lambda i: lyr(i) + "self_attn.v_proj",
+            out=lambda i: lyr(i) + "self_attn.out_proj", ln1=lambda i: lyr(i) + "self_attn_layer_norm",
+            fc1=lambda i: lyr(i) + "fc1", fc2=lambda i: lyr(i) + "fc2", ln2=lambda i: lyr(i) + "final_layer_norm", enc_ln=e + "layer_norm")
+
+    def _nm_hf(self) -> SimpleNamespace:
         p = self.prefix
         e = p + "encoder."
         c = lambda i: f"{p}feature_extractor.conv_layers.{i}."   # noqa: E731
@@ -705,6 +731,30 @@ class HipHubertEncoder(nn.Module):
             out=lambda i: lyr(i) + "attention.out_proj", ln1=lambda i: lyr(i) + "layer_norm",
             fc1=lambda i: lyr(i) + "feed_forward.intermediate_dense", fc2=lambda i: lyr(i) + "feed_forward.output_dense",
             ln2=lambda i: lyr(i) + "final_layer_norm", enc_ln=e + "layer_norm")
+
+    def key_map(self, src_style: str = "hf") -> Dict[str, str]:
+        """{name in this module's trainable store: name of the same tensor under `src_style` ("hf" | "fairseq")} for every tensor both
+        styles hold under their own key (everything but the positional conv's weight, which is (weight_g, weight_v) in fairseq form and
+        one folded `conv.weight` -- or `parametrizations.weight.original0 / original1` -- in HF form; `_load_trainable` converts it)."""
+        mine, other = self._nm(), (self._nm_hf() if src_style == "hf" else self._nm_fairseq())
+        cfg, out = self.cfg, {}
+
+        def pair(a, b, suffixes=(".weight", ".bias")):
+            if a is None or b is None:
+                return
+            for sfx in suffixes:
+                out[a + sfx] = b + sfx
+        for i in range(len(cfg["hub_conv_dim"])):
+            pair(mine.conv_w(i), other.conv_w(i), ("",))
+            if mine.conv_b is not None and other.conv_b is not None:
+                pair(mine.conv_b(i), other.conv_b(i), ("",))
+            pair(mine.conv_ln(i), other.conv_ln(i))
+        pair(mine.fp_ln, other.fp_ln); pair(mine.fp, other.fp); pair(mine.enc_ln, other.enc_ln)
+        pair(mine.pos_b, other.pos_b, ("",))
+        for i in range(cfg["hub_layers"]):
+            for f in ("q", "k", "v", "out", "ln1", "fc1", "fc2", "ln2"):
+                pair(getattr(mine, f)(i), getattr(other, f)(i))
+        return out
 
     def _reserve_extra_layer(self, i: int):
         """hook: further trainable tensors of layer i (WavLM: the gate of the relative position bias)"""
@@ -758,19 +808,39 @@ class HipHubertEncoder(nn.Module):
             if name.startswith(self.prefix):
                 _attach(self, name[len("encoder."):], prm)
 
+    def _pos_conv_sources(self, W: Dict[str, torch.Tensor], prefix: str):
+        """(g, v, folded) of the weight-normed positional conv from whichever form the checkpoint holds: fairseq `weight_g / weight_v`,
+        torch's parametrizations API (`parametrizations.weight.original0 / original1`, fairseq or HF module path), or HF's folded
+        `conv.weight` -- for which (g, v) = (||w||, w) is the parametrisation of the same function (w = g v / ||v||)."""
+        rel = lambda n: prefix + n[len(self.prefix):]   # noqa: E731
+        F_, H_ = self._nm_fairseq(), self._nm_hf()
+        fb, hb = rel(F_.pos_g)[: -len("weight_g")], rel(H_.pos_w)[: -len("weight")]
+        for base in (fb, hb):
+            if base + "weight_g" in W:
+                return W[base + "weight_g"].float(), W[base + "weight_v"].float(), None
+            if base + "parametrizations.weight.original0" in W:
+                return W[base + "parametrizations.weight.original0"].float(), W[base + "parametrizations.weight.original1"].float(), None
+        w = W[hb + "weight"].float() if hb + "weight" in W else W[fb + "weight"].float()
+        return w.norm(dim=(0, 1), keepdim=True), w, w
+
     def _load_trainable(self, W: Dict[str, torch.Tensor], prefix: str):
+        """checkpoint -> store.  Keys may be in the store's own style or in the other one (`key_map`): the reference's fairseq checkpoint
+        and an HF-converted one both load."""
         N = self._nm()
+        alt = self.key_map("hf" if self.cfg.get("hub_param_names", "fairseq") != "hf" else "fairseq") if type(self)._nm is HipHubertEncoder._nm else {}
         with torch.no_grad():
             for name, prm in self.store.params.items():
                 if not name.startswith(self.prefix):
                     continue
                 src = prefix + name[len(self.prefix):]
-                if name == N.pos_w and src not in W:   # HF checkpoint that kept the weight-norm parametrisation: fold g * v / ||v||
-                    base = src[: -len("weight")]
-                    g_, v_ = W[base + "parametrizations.weight.original0"].float(), W[base + "parametrizations.weight.original1"].float()
-                    prm.copy_((g_ * v_ / v_.norm(dim=(0, 1), keepdim=True)).to(self.device_))
-                else:
-                    prm.copy_(W[src].to(self.device_).reshape(prm.shape))
+                if name in (N.pos_w, N.pos_g, N.pos_v) and src not in W:
+                    g_, v_, folded = self._pos_conv_sources(W, prefix)
+                    val = {N.pos_g: g_, N.pos_v: v_}.get(name) if name != N.pos_w else (folded if folded is not None else g_ * v_ / v_.norm(dim=(0, 1), keepdim=True))
+                    prm.copy_(val.to(self.device_).reshape(prm.shape))
+                    continue
+                if src not in W and name in alt:
+                    src = prefix + alt[name][len(self.prefix):]
+                prm.copy_(W[src].to(self.device_).reshape(prm.shape))
         return self
 
     def _pos_weight_master(self) -> torch.Tensor:
@@ -1372,7 +1442,11 @@ class HipHubertEncoder(nn.Module):
         pass
 
     def _deposit_pos_weight_grad(self, dw: torch.Tensor, acc: bool):
-        g = self.store.grad_view(self._nm().pos_w)
+        st, N = self.store, self._nm()
+        if N.pos_w is None:     # weight_norm(dim=2) kept as (g, v): chain rule of w = g v / ||v|| (fairseq / reference WavLM names)
+            ops.weight_norm_bwd(dw, st.master_view(N.pos_v), st.master_view(N.pos_g), st.grad_view(N.pos_g), st.grad_view(N.pos_v), accumulate=acc)
+            return
+        g = st.grad_view(N.pos_w)
         g.add_(dw) if acc else g.copy_(dw)
 
     def forward(self, source=None, padding_mask=None, **kw):
@@ -1396,21 +1470,16 @@ class HipWavLMEncoder(HipHubertEncoder):
 
     # ---- trainable form: the reference module's own parameter names (WavLM.py:220-330, modules.py:330-420) -------------------
     def _nm(self) -> SimpleNamespace:
+        N = self._nm_fairseq()      # WavLM.py vendors fairseq's module tree: same names, no conv bias, plus the gate / bucket table / mask_emb
         p = self.prefix
-        e = p + "encoder."
-        c = lambda i: f"{p}feature_extractor.conv_layers.{i}."   # noqa: E731
-        lyr = lambda i: f"{e}layers.{i}."                        # noqa: E731
-        return SimpleNamespace(
-            conv_w=lambda i: c(i) + "0.weight", conv_b=None,
-            conv_ln=lambda i: (c(i) + "2" if i == 0 else None) if self._group_mode else c(i) + "2.1",     # Fp32GroupNorm sits at index 2
-            fp_ln=p + "layer_norm", fp=p + "post_extract_proj",
-            pos_w=None, pos_g=e + "pos_conv.0.weight_g", pos_v=e + "pos_conv.0.weight_v", pos_b=e + "pos_conv.0.bias",
-            q=lambda i: lyr(i) + "self_attn.q_proj", k=lambda i: lyr(i) + "self_attn.k_proj", v=lambda i: lyr(i) + "self_attn.v_proj",
-            out=lambda i: lyr(i) + "self_attn.out_proj", ln1=lambda i: lyr(i) + "self_attn_layer_norm",
-            fc1=lambda i: lyr(i) + "fc1", fc2=lambda i: lyr(i) + "fc2", ln2=lambda i: lyr(i) + "final_layer_norm", enc_ln=e + "layer_norm",
-            grep_w=lambda i: lyr(i) + "self_attn.grep_linear.weight", grep_b=lambda i: lyr(i) + "self_attn.grep_linear.bias",
-            grep_a=lambda i: lyr(i) + "self_attn.grep_a", rel_bias=lyr(0) + "self_attn.relative_attention_bias.weight",
-            mask_emb=p + "mask_emb")
+        lyr = lambda i: f"{p}encoder.layers.{i}."                # noqa: E731
+        N.conv_b = None
+        N.grep_w = lambda i: lyr(i) + "self_attn.grep_linear.weight"
+        N.grep_b = lambda i: lyr(i) + "self_attn.grep_linear.bias"
+        N.grep_a = lambda i: lyr(i) + "self_attn.grep_a"
+        N.rel_bias = lyr(0) + "self_attn.relative_attention_bias.weight"
+        N.mask_emb = p + "mask_emb"
+        return N
 
     def _reserve_extra_layer(self, i: int):
         cfg, r, N = self.cfg, self.store.reserve, self._nm()
@@ -1469,10 +1538,6 @@ class HipWavLMEncoder(HipHubertEncoder):
     def _relpos_backward_end(self, state, acc: bool):
         ops.relpos_bucket_grad(state["d_tab"], self._buckets[state["T"]], self.cfg["wavlm_buckets"],
                                self.store.grad_view(self._nm().rel_bias), accumulate=acc)
-
-    def _deposit_pos_weight_grad(self, dw: torch.Tensor, acc: bool):
-        st, N = self.store, self._nm()
-        ops.weight_norm_bwd(dw, st.master_view(N.pos_v), st.master_view(N.pos_g), st.grad_view(N.pos_g), st.grad_view(N.pos_v), accumulate=acc)
 
     def load(self, W: Dict[str, torch.Tensor], prefix="encoder.model."):
         if self.trainable:

@@ -1,0 +1,289 @@
+"""GPU: parity at the geometries of the OTHER BASELINE configs and of the ragged large-scale path.
+
+* C1 (configs[0]) at its TRUE geometry, every layer: Whisper-tiny (d 384, 6 heads, 4 layers) -> TinyLlama-1.1B (d 2048, 32 q / 4 kv heads of
+  64 = GQA group 8, ffn 5632, V 32000, 22 layers), LoRA r 8, one 10 s clip padded to 30 s by the recipe: whole step vs the fp32 oracle;
+* C4 (configs[3]) at the BENCH geometry: 6 x 30 s waveforms (T_e = 1499: six time blocks of the positional conv with a ragged last one,
+  conv layers 1-6 as one launch on per-clip pitches, attention at T = 1499 x 16 heads), true widths, 2 HuBERT layers + 2 Q-Former layers +
+  1 Vicuna layer;
+* C5-style (configs[4]): ragged multitask batch (clips of 30 / 12.3 / 21.7 / 4.1 / 8 s, prompts of different lengths, right-padded
+  collator), `varlen` + `varlen_encoder` + labelled rows, Whisper-large-v3 x 1 -> Llama-3-8B x 1 at true widths, vs the per-clip oracle;
+* unfrozen encoders at TRUE widths (Whisper-large-v3 x 1 layer, HuBERT-large x 1 layer): every gradient vs the oracle's autograd.
+Tolerances are written at each assert."""
+import os
+
+import pytest
+import torch
+
+from oracle import slam_oracle as O
+from tests import golden_util as G
+from tests.test_headline_gpu import _check_grads, _oracle_grads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(2400)
+def test_c1_true_geometry_step_matches_oracle(dev):
+    """BASELINE configs[0] as bench.py --workload c1 builds it, all 4 + 22 layers: loss abs <= 1e-2, accuracy within one token, every
+    trainable gradient cosine >= 0.999 / norm within 3 % of the fp32 oracle.  Exercises what no other test does at true widths: GQA group 8
+    (32 q heads on 4 kv heads of 64) through the D = 64 causal attention kernels, ffn 5632 (= 22 x 256: the 128-wide tile rule), r = 8
+    adapters in the 64-column K-extension, a 22-layer bf16 residual stream."""
+    from slam_llm_amd.model import SlamHipModel, make_config
+    cfg = make_config("whisper-tiny", "tinyllama-1.1b", lora_r=8, lora_alpha=32, lora_targets=("q_proj", "v_proj"), lora_dropout=0.0)
+    assert (cfg["enc_dim"], cfg["enc_heads"], cfg["enc_layers"], cfg["llm_dim"], cfg["llm_heads"], cfg["llm_kv_heads"], cfg["llm_head_dim"],
+            cfg["llm_ffn"], cfg["vocab"], cfg["llm_layers"]) == (384, 6, 4, 2048, 32, 4, 64, 5632, 32000, 22)
+    W = O.init_weights(cfg, seed=42)
+    audio = O.synth_audio(1, 10.0, seed=1234)
+    ob = O.synth_batch(cfg, audio, prompt_len=16, answer_lens=(64,), seed=1236, left_pad=False, pad_to_30s=True)
+    assert ob["input_ids"].shape == (1, 380) and ob["audio_mel"].shape == (1, 3000, 80)
+
+    def fwd():
+        with torch.no_grad():
+            enc = O.whisper_encoder(W, cfg, ob["audio_mel"].permute(0, 2, 1))
+        proj = O.projector_concat(W, enc, cfg["ds_rate"])
+        emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+        loss, logits = O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
+        acc = O.compute_accuracy(torch.argmax(logits, -1)[:, :-1], ob["labels"][:, 1:], -100)
+        return loss, acc
+
+    loss_ref, acc_ref, grads = _oracle_grads(W, cfg, ob, fwd)
+    model = SlamHipModel(dict(cfg), dev).load_weights(W)
+    del W
+    model.train()
+    gb = {k: v.to(dev) for k, v in ob.items() if k != "audio_mel"}
+    gb["audio"] = audio.to(dev)                                   # GPU log-mel (pads the 10 s clip to 30 s like whisper.pad_or_trim)
+    outputs, acc = model(**gb)
+    outputs.loss.backward()
+    n_valid = int((ob["labels"][:, 1:] != -100).sum())
+    got = float(outputs.loss)
+    assert abs(got - loss_ref) <= 1e-2, (got, loss_ref)
+    assert abs(float(acc) - acc_ref) <= 1.0 / n_valid + 1e-6
+    worst = _check_grads(model, grads)
+    print(f"C1 true geometry: loss {got:.4f} vs {loss_ref:.4f}, acc {float(acc):.4f} vs {acc_ref:.4f}, worst gradient cosine {worst:.6f}")
+
+
+@pytest.mark.timeout(2400)
+def test_c4_bench_geometry_step_matches_oracle(dev):
+    """BASELINE configs[3] at the geometry bench.py --workload c4 runs: six 30 s waveforms, true widths, 2 + 2 + 1 layers.  The frozen
+    HuBERT-large front end takes the per-clip-pitch conv stack (one launch per conv layer over all clips), the positional conv runs six
+    256-step time blocks per (clip, group) with a ragged last block (1499 = 5 x 256 + 219), the encoder attention runs T = 1499 x 16
+    heads, the Q-Former cross-attends 32 queries to 1499 frames.  Loss abs <= 1e-2, accuracy within one token, gradients cosine >= 0.998 /
+    norm 3 % (the Q-Former fixtures' tolerance)."""
+    from slam_llm_amd.model import SlamHipModel
+    from slam_llm_amd.slam_model_hip import build_config
+    mc = dict(encoder_name="hubert", encoder_path="hubert_large_ll60k.pt", llm_name="vicuna-7b-v1.5", encoder_dim=1024,
+              encoder_projector="q-former", qformer_layers=2, query_len=32)
+    cfg = build_config(dict(use_peft=True, peft_config=dict(r=32, lora_alpha=32, target_modules=["q_proj", "v_proj"], lora_dropout=0.0),
+                            seed=42, freeze_encoder=True), mc)
+    cfg = dict(cfg, hub_layers=2, llm_layers=1, lora_dropout=0.0, qf_dropout=0.0)
+    c = dict(cfg)
+    W = {k: v for k, v in O.init_weights(c, seed=42).items() if not k.startswith(("encoder.", "encoder_projector."))}
+    W.update(O.init_hubert_weights(c, seed=7))
+    W.update(O.init_qformer_weights(c, c["enc_dim"], c["llm_dim"], seed=11))
+    B = 6
+    audio = O.synth_audio(B, 30.0, seed=77)
+    wav = torch.nn.functional.layer_norm(audio, (audio.shape[1],))   # dataset_config.normalize (speech_dataset.py:96-97)
+    Q = c["qf_queries"]
+    g = torch.Generator().manual_seed(1236)
+    samples = [O.make_sample(Q, torch.randint(3, c["vocab"], (16,), generator=g).tolist(),
+                             torch.randint(3, c["vocab"], (63,), generator=g).tolist(), 2) for _ in range(B)]
+    ob = O.collate_right_pad(samples, pad_id=2)
+    assert ob["input_ids"].shape == (B, 32 + 16 + 64)
+
+    def fwd():
+        with torch.no_grad():
+            enc = O.hubert_encoder(W, c, wav)
+        assert enc.shape[1] == 1499
+        proj = O.projector_qformer(W, c, enc, None)
+        emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+        loss, logits = O.llama_forward(W, c, emb, ob["attention_mask"], ob["labels"])
+        acc = O.compute_accuracy(torch.argmax(logits, -1)[:, :-1], ob["labels"][:, 1:], -100)
+        return loss, acc
+
+    loss_ref, acc_ref, grads = _oracle_grads(W, c, ob, fwd)
+    model = SlamHipModel(dict(cfg), dev).load_weights(W)
+    del W
+    model.train()
+    gb = {k: v.to(dev) for k, v in ob.items()}
+    gb["audio"] = wav.to(dev)
+    from slam_llm_amd import ops
+    ops.TIMER = ops.KernelTimer()
+    try:
+        outputs, acc = model(**gb)
+        outputs.loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        used = set(ops.TIMER.rec)
+        ops.TIMER = None
+    assert any("pos_conv" in k for k in used), sorted(used)          # the one-launch positional conv ran (not 16 x im2col + GEMM)
+    n_valid = int((ob["labels"][:, 1:] != -100).sum())
+    got = float(outputs.loss)
+    assert abs(got - loss_ref) <= 1e-2, (got, loss_ref)
+    assert abs(float(acc) - acc_ref) <= 1.0 / n_valid + 1e-6
+    worst = _check_grads(model, grads, cos_min=0.998)
+    print(f"C4 bench geometry: loss {got:.4f} vs {loss_ref:.4f}, worst gradient cosine {worst:.6f}")
+
+
+@pytest.mark.timeout(2400)
+def test_c5_style_ragged_multitask_step_matches_per_clip_oracle(dev):
+    """BASELINE configs[4] style (aispeech_asr: multitask dataset, dynamic prompts, right-padded collator) on the large-scale batching path:
+    five clips of 30 / 12.3 / 21.7 / 4.1 / 8 s with prompts of 5 / 23 / 9 / 16 / 12 tokens and answers of 40 / 7 / 22 / 3 / 15,
+    `varlen_encoder` (no pad frames through the encoder) + `varlen` (no pad tokens through the LLM) + the labelled-rows head, Whisper-large-v3
+    x 1 layer -> Llama-3-8B x 1 layer at true widths.  Oracle: every clip alone through the reference's variable-length encoder and the
+    projector, then splice / LLM / loss on the right-padded batch.  Loss abs <= 1e-2, accuracy within one token, every gradient cosine >=
+    0.999 / norm 3 %."""
+    from slam_llm_amd import batcher
+    from slam_llm_amd.model import SlamHipModel, make_config
+    cfg = make_config("whisper-large-v3", "llama-3-8b", enc_layers=1, llm_layers=1, lora_r=16, lora_alpha=32,
+                      lora_targets=("q_proj", "v_proj"), lora_dropout=0.0)
+    W = O.init_weights(cfg, seed=42)
+    g = torch.Generator().manual_seed(21)
+    lens = [480000, int(12.3 * 16000), int(21.7 * 16000), int(4.1 * 16000), 128000]
+    prompts, answers = [5, 23, 9, 16, 12], [40, 7, 22, 3, 15]
+    audio = [(torch.randn(n, generator=g) * 0.1).clamp(-1, 1) for n in lens]
+    samples = []
+    for a, pl, al in zip(audio, prompts, answers):
+        alen = batcher.whisper_audio_length(len(a), 5, pad_to_30s=False)
+        samples.append(batcher.make_sample(a, torch.randint(3, cfg["vocab"], (pl,), generator=g).tolist(),
+                                           torch.randint(3, cfg["vocab"], (al,), generator=g).tolist(), 2, alen))
+    batch = batcher.collate(samples, 0, left_pad_prompt=False)
+    ob = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
+
+    def fwd():
+        projs = []
+        with torch.no_grad():
+            encs = []
+            for a in audio:
+                n = a.shape[0] // O.HOP * O.HOP
+                mel = O.log_mel_spectrogram(a[:n], cfg["n_mels"]).permute(1, 0)[None]
+                encs.append(O.whisper_encoder(W, cfg, mel.permute(0, 2, 1)))
+        for enc in encs:
+            projs.append(O.projector_concat(W, enc, cfg["ds_rate"])[0])
+        Tam = max(p.shape[0] for p in projs)
+        proj = torch.stack([torch.cat([p, p.new_zeros(Tam - p.shape[0], p.shape[1])]) for p in projs])
+        emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+        loss, logits = O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
+        acc = O.compute_accuracy(torch.argmax(logits, -1)[:, :-1], ob["labels"][:, 1:], -100)
+        return loss, acc
+
+    loss_ref, acc_ref, grads = _oracle_grads(W, cfg, ob, fwd)
+    model = SlamHipModel(dict(cfg, pad_or_trim=False, varlen_encoder=True, varlen=True), dev).load_weights(W)
+    del W
+    model.train()
+    gb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    outputs, acc = model(**gb)
+    outputs.loss.backward()
+    n_valid = int((ob["labels"][:, 1:] != -100).sum())
+    got = float(outputs.loss)
+    assert abs(got - loss_ref) <= 1e-2, (got, loss_ref)
+    assert abs(float(acc) - acc_ref) <= 1.0 / n_valid + 1e-6
+    worst = _check_grads(model, grads)
+    print(f"C5-style ragged step: loss {got:.4f} vs {loss_ref:.4f}, worst gradient cosine {worst:.6f}")
+
+
+@pytest.mark.timeout(2400)
+def test_unfrozen_whisper_large_true_width_matches_oracle(dev):
+    """train_config.freeze_encoder=false at Whisper-large-v3's true widths (d 1280, 20 heads, 128 mels, T_e = 1500 from two 30 s clips),
+    one encoder layer, under a toy LLM: every gradient (conv stem, positional path, LayerNorms, attention, MLP, projector, LoRA) vs the
+    oracle's autograd.  At true widths the bf16 noise that the toy-width cases carry averages out: cosine >= 0.999 / norm 3 % throughout
+    (key projections included), loss abs <= 1e-2."""
+    from slam_llm_amd.model import SlamHipModel, make_config
+    cfg = make_config("whisper-large-v3", None, enc_layers=1, lora_dropout=0.0)
+    W = O.init_weights(cfg, seed=42)
+    audio = O.synth_audio(2, 30.0, seed=99)
+    ob = O.synth_batch(cfg, audio, prompt_len=6, answer_lens=(9, 5), seed=1236, left_pad=True, pad_to_30s=True)
+    names = O.trainable_names(W) + [n for n in W if n.startswith("encoder.") and not n.endswith("positional_embedding")]
+    for n in names:
+        W[n].requires_grad_(True)
+    torch.set_num_threads(min(64, os.cpu_count()))
+    enc = O.whisper_encoder(W, cfg, ob["audio_mel"].permute(0, 2, 1))
+    proj = O.projector_concat(W, enc, cfg["ds_rate"])
+    emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+    loss_ref, _ = O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
+    loss_ref.backward()
+    grads = {n: W[n].grad.detach().clone() for n in names}
+    for n in names:
+        W[n].requires_grad_(False)
+        W[n].grad = None
+    model = SlamHipModel(dict(cfg, freeze_encoder=False), dev).load_weights(W)
+    model.train()
+    assert set(model.store.params) == set(names)
+    outputs, _ = model(**{k: v.to(dev) for k, v in ob.items()})
+    outputs.loss.backward()
+    assert abs(float(outputs.loss.detach()) - float(loss_ref.detach())) <= 1e-2, (float(outputs.loss.detach()), float(loss_ref.detach()))
+    worst = _check_grads(model, grads)
+    print(f"unfrozen whisper-large-v3 x 1 layer: worst gradient cosine {worst:.6f}")
+
+
+@pytest.mark.timeout(2400)
+@pytest.mark.parametrize("which", ["hubert", "wavlm"])
+def test_unfrozen_wave_encoder_large_true_width_matches_oracle(dev, which):
+    """train_config.freeze_encoder=false at HuBERT-large's / WavLM-Large's true widths (conv 512 x 7, d 1024, 16 heads, positional conv k 128
+    in 16 groups, ffn 4096), one transformer layer, ragged pair of 2 s clips, toy LLM: every gradient vs the oracle's autograd.  The floors the
+    toy-width cases need (0.995 feature extractor, 0.99 gate / bias table) are bf16 noise on 64-channel rows; here: cosine >= 0.998, norm
+    within 4 %, the cancelling-sum parameters of WavLM's gate (grep_a, grep_linear.bias: a handful of elements) bounded against their
+    layer's grep_linear.weight gradient like in the toy case."""
+    from slam_llm_amd.model import SlamHipModel
+    HC = O.hubert_config(hub_layers=1) if which == "hubert" else O.wavlm_config(hub_layers=1)
+    cfg = dict(O.make_config(), **HC, lora_dropout=0.0)
+    cfg.update(encoder_name=which, enc_dim=HC["hub_dim"])
+    assert (HC["hub_dim"], HC["hub_conv_dim"][0], HC["hub_heads"], HC["hub_ffn"]) == (1024, 512, 16, 4096)
+    W = {k: v for k, v in O.init_weights(cfg, seed=42).items() if not k.startswith("encoder.")}
+    W.update(O.init_hubert_weights(HC, seed=7, weight_norm=True) if which == "hubert" else O.init_wavlm_weights(HC, seed=9))
+    N = 32000
+    wav = torch.nn.functional.layer_norm(O.synth_audio(2, 2.0, seed=9), (N,))
+    n_valid = [N, 22400]
+    wav[1, n_valid[1]:] = 0.0
+    alen = [n // 320 // 5 for n in n_valid]
+    samples = [O.make_sample(alen[0], [5, 6, 7], [9, 10, 11, 12], 2), O.make_sample(alen[1], [5, 6], [9, 10], 2)]
+    ob = O.collate_left_pad(samples, pad_id=2)
+    names = O.trainable_names(W) + [n for n in W if n.startswith("encoder.")]
+    for n in names:
+        W[n].requires_grad_(True)
+    torch.set_num_threads(min(64, os.cpu_count()))
+    enc = (O.hubert_encoder if which == "hubert" else O.wavlm_encoder)(W, cfg, wav, n_valid=torch.tensor(n_valid))
+    proj = O.projector_concat(W, enc, cfg["ds_rate"])
+    emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+    loss_ref, _ = O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
+    loss_ref.backward()
+    unused = [n for n in names if W[n].grad is None]
+    grads = {n: (W[n].grad.detach().clone() if W[n].grad is not None else torch.zeros_like(W[n])) for n in names}
+    for n in names:
+        W[n].requires_grad_(False)
+        W[n].grad = None
+    model = SlamHipModel(dict(cfg, freeze_encoder=False), dev).load_weights(W)
+    model.train()
+    kmap = dict(model.encoder.key_map("hf")) if which == "hubert" else {}      # fairseq names (the module the reference trains) -> the oracle's HF names
+    if which == "hubert":
+        kmap["encoder.encoder.pos_conv.0.weight_g"] = "encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original0"
+        kmap["encoder.encoder.pos_conv.0.weight_v"] = "encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original1"
+    grads = {n: grads[kmap.get(n, n)] for n in model.store.params}
+    assert len(grads) == len(names)
+    unused = [n for n in model.store.params if kmap.get(n, n) in unused]
+    gb = {k: v.to(dev) for k, v in ob.items()}
+    gb["audio"] = wav.to(dev)
+    gb["audio_len"] = torch.tensor(n_valid, dtype=torch.int32, device=dev)
+    outputs, _ = model(**gb)
+    outputs.loss.backward()
+    assert abs(float(outputs.loss.detach()) - float(loss_ref.detach())) <= 1e-2, (float(outputs.loss.detach()), float(loss_ref.detach()))
+    gmax = max(float(v.norm()) for v in grads.values())
+    worst, worst_name = 1.0, ""
+    for n, p in model.store.params.items():
+        gn, mine = float(grads[n].norm()), p.grad.float().cpu()
+        if n in unused:
+            assert float(mine.abs().max()) == 0.0, n
+            continue
+        if n.endswith("k_proj.bias") and gn < 1e-4 * gmax:
+            assert float(mine.abs().max()) < 3e-2, n
+            continue
+        if (".grep_" in n) and mine.numel() <= 16:
+            wn = float(grads[n.rsplit(".grep_", 1)[0] + ".grep_linear.weight"].norm())
+            err = float((mine - grads[n]).norm())
+            assert err <= 5e-2 * wn, f"grad {n}: error {err} vs 5 % of the layer's grep_linear.weight gradient norm {wn}"
+            continue
+        cs = G.cosine(grads[n].numpy(), mine.numpy())
+        if cs < worst:
+            worst, worst_name = cs, n
+        print(f"  {n:80s} cos {cs:.5f}  norm {float(mine.norm()):.4e} vs {gn:.4e}")
+        assert cs >= 0.998, f"grad {n}: cosine {cs}"
+        assert abs(float(mine.norm()) - gn) <= 4e-2 * gn + 1e-7, f"grad {n}: norm {float(mine.norm())} vs {gn}"
+    print(f"unfrozen {which}-large x 1 layer: worst gradient cosine {worst:.6f} ({worst_name})")

@@ -301,7 +301,7 @@ def _unfrozen_wave_encoder_case(dev, which, ragged, base=False):
     cfg = dict(O.make_config(), **HUBERT_TINY, lora_dropout=0.0)
     cfg.update(encoder_name=which, enc_dim=HUBERT_TINY["hub_dim"])
     W = {k: v for k, v in O.init_weights(cfg, seed=42).items() if not k.startswith("encoder.")}
-    W.update(O.init_hubert_weights(HUBERT_TINY, seed=7) if which == "hubert" else O.init_wavlm_weights(HUBERT_TINY, seed=9))
+    W.update(O.init_hubert_weights(HUBERT_TINY, seed=7, weight_norm=True) if which == "hubert" else O.init_wavlm_weights(HUBERT_TINY, seed=9))
     N = 16000
     wav = O.synth_audio(2, 1.0, seed=9)
     if not base:      # the large checkpoints' cfg has normalize=True (dataset-side layer norm of the waveform), the base ones have not
@@ -328,7 +328,16 @@ def _unfrozen_wave_encoder_case(dev, which, ragged, base=False):
         W[n].grad = None
     model = SlamHipModel(dict(cfg, freeze_encoder=False), dev).load_weights(W)
     model.train()
-    assert set(model.store.params) == set(names), set(model.store.params) ^ set(names)
+    # HuBERT trains under the names of the module the reference un-freezes (fairseq's HubertModel: ...conv_layers.N.0.weight, post_extract_proj,
+    # encoder.pos_conv.0.weight_g / weight_v, self_attn.q_proj, ...); the oracle restates the HF twin: compare through the key map
+    kmap = dict(model.encoder.key_map("hf")) if which == "hubert" else {}
+    if which == "hubert":
+        kmap["encoder.encoder.pos_conv.0.weight_g"] = "encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original0"
+        kmap["encoder.encoder.pos_conv.0.weight_v"] = "encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original1"
+        assert "encoder.post_extract_proj.weight" in model.store.params and "encoder.encoder.layers.0.self_attn.q_proj.bias" in model.store.params
+    grads = {n: grads[kmap.get(n, n)] for n in model.store.params if kmap.get(n, n) in grads}
+    assert len(grads) == len(names) and set(model.store.params) == set(grads), set(model.store.params) ^ set(grads)
+    unused = [n for n in model.store.params if kmap.get(n, n) in unused]
     gb = {k: v.to(dev) for k, v in ob.items()}
     gb["audio"] = wav.to(dev)
     gb["audio_len"] = torch.tensor(n_valid, dtype=torch.int32, device=dev)
@@ -385,9 +394,8 @@ def _unfrozen_wave_encoder_case(dev, which, ragged, base=False):
                 assert err <= 5e-2 * wn, f"grad {n}: error {err} vs 5 % of the layer's grep_linear.weight gradient norm {wn}"
                 continue
             floor = 0.99
-        if os.environ.get("SLAM_TEST_VERBOSE"):
+        if os.environ.get("SLAM_TEST_VERBOSE"):     # prints only: the asserts below run either way
             print(f"  {n:80s} cos {cs:.5f}  norm {float(mine.norm()):.4e} vs {gn:.4e}")
-            continue
         assert cs >= floor, f"grad {n}: cosine {cs}"
         assert abs(float(mine.norm()) - gn) <= 5e-2 * gn + 1e-7, f"grad {n}: norm {float(mine.norm())} vs {gn}"
     print(f"unfrozen {which} (ragged={ragged}): worst gradient cosine {worst:.6f} ({worst_name})")
@@ -398,7 +406,13 @@ def _unfrozen_wave_encoder_case(dev, which, ragged, base=False):
     opt.step()
     opt.zero_grad()
     assert float((model.store.flat - before).abs().max()) > 0
-    assert ("encoder.feature_extractor.conv_layers.0.conv.weight" if which == "hubert" else "encoder.model.encoder.pos_conv.0.weight_g") in model.state_dict()
+    sd = model.state_dict()
+    assert ("encoder.feature_extractor.conv_layers.0.0.weight" if which == "hubert" else "encoder.model.encoder.pos_conv.0.weight_g") in sd
+    if which == "hubert":      # a checkpoint written from named_parameters (save_model_checkpoint_peft) loads back, and so does the HF-named W
+        assert "encoder.encoder.pos_conv.0.weight_v" in sd and not any("pos_conv_embed" in k for k in sd)
+        again = SlamHipModel(dict(cfg, freeze_encoder=False), dev).load_weights({**{k: v for k, v in W.items() if not k.startswith("encoder.")},
+                                                                                  **{k: v.detach().cpu() for k, v in sd.items() if k.startswith("encoder.")}})
+        assert torch.equal(again.store.flat, model.store.flat)
     out2, _ = model(**gb)
     assert bool(torch.isfinite(out2.loss))
 
