@@ -139,7 +139,7 @@ int slam_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int
                         int64_t Rp, void* stream);
 
 /* ---- attention (Whisper blocks: bidirectional, no mask; Llama: causal ^ key padding, GQA) -----------
- * Q/K/V/O/dO row-major [B*T, ld] with head h at column h*D; Vt/Kt/Qt/dOt = [B,H,D,Tp] transposed copies;
+ * Q/K/V/O/dO row-major [B*T, ld] with head h at column h*D; Vt/Kt/Qt/dOt = [B,H,D,Tp] transposed copies (optional since round 4, see below);
  * LSE/Delta [B,Hq,Tqp] f32; key_mask [B,Tkp] uint8 (1 = attend, zero padded) or NULL; D in {64,128}.
  * Query rows are (b*Tq + t), key/value rows (b*Tk + t): Tq != Tk is cross-attention (Q-Former, projector.py:69-80);
  * Tqp/Tkp are the 64-padded lengths used by the transposed copies, LSE/Delta and the mask.
@@ -150,10 +150,16 @@ int slam_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int
  * seg_lo[q] = first row of q's sequence, seg_hi[k] = one past the last row of k's sequence (int32, non-decreasing,
  * nullable): query q attends keys seg_lo[q] <= k <= q only.  Equals the right-padded batch of the reference's
  * MultiTaskDataset collator (speech_dataset_large.py:180-233) on every valid token. */
-int slam_attn_set_fwd_qf(int qf);   /* tools: 0 = auto, 1 / 2 = query fragments per wave of the forward kernel; 10 / 11 = register-staged / LDS-DMA tiles; 20 / 21 = hardware round-robin / XCD-aware (shipped) workgroup numbering of ALL attention kernels */
+int slam_attn_set_fwd_qf(int qf);   /* tools: 0 = auto, 1 / 2 = query fragments per wave of the forward kernel; 10 / 11 = register-staged / LDS-DMA tiles; 20 / 21 = hardware round-robin / XCD-aware (shipped) workgroup numbering of ALL attention kernels; 30 / 31 = general / mask-free Whisper instantiation; 40 / 41 = round-3 kernels on the transposed copies / transposed-read kernels (shipped) */
 int slam_attn_debug_clock(unsigned long long* out256);   /* tools: cycle stamps written by the probe form of the dQ kernel (variant 14): [wave 0|3][tile < 16][8] */
 int slam_attn_set_bwd_variant(int variant);   /* tools: 0 = DMA-ring backward kernels (shipped), 1 = the round-1 register-staged kernels, 2 = ring dK/dV with the register-staged dQ, 14 = dQ kernel with cycle stamps, 11/12/15 = timing ablations (wrong results) */
-int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, void* O,
+/* Round 4: the kernels read their transposed MFMA operands with ds_read_b64_tr_b16 from the ROW-MAJOR tiles, so the [B,H,D,Tp] copies are
+ * optional: slam_attn_fwd takes V row-major (V, ldv; like K) and / or Vt -- with V given it never reads Vt; slam_attn_bwd reads Qt / Kt / dOt
+ * only in the configurations slam_attn_needs_transposed reports (bit 1: <= 64 queries, attention dropout, the relative position bias,
+ * tensors beyond 2 GiB, the tools' variants), NULL otherwise.  flags: bit 0 = dropout, bit 1 = relative position bias. */
+int slam_attn_needs_transposed(int64_t B, int64_t Tq, int64_t Tk, int64_t Hq, int64_t Hkv, int64_t D, int64_t ldq, int64_t ldk,
+                               int64_t ldv, int64_t lddo, int flags);
+int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, const void* V, int64_t ldv, void* O,
                   int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B, int64_t Tq, int64_t Tk,
                   int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
                   const int32_t* seg_lo, const int32_t* seg_hi, const float* rp_gate, const float* rp_tab, int64_t rp_T,

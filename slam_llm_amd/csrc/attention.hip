@@ -248,12 +248,54 @@ __device__ __forceinline__ void bufdma16_asm(__amdgpu_buffer_rsrc_t srd, unsigne
                : "memory");
 }
 
+// ------------------------------------------------------------------------------------------
+// Transposed MFMA operands straight from the ROW-MAJOR tiles (round 4): ds_read_b64_tr_b16.  Inside every 16-lane group, result lane i,
+// element j = element (i & 3) of the 8 bytes addressed by lane 4 j + (i >> 2) (tools/probes/tr_probe.py checks this on random addresses).
+// With lane i pointing at row 8 g + 4 half + (i >> 2), columns 16 df + 4 (i & 3) .. + 3 of a row-major [rows][D] tile, lane i receives
+// rows 8 g + 4 half .. + 3 of COLUMN 16 df + i: two such reads (half = 0, 1) are the A operand "row = head-dim element 16 df + li,
+// k-slots = tile rows 8 g .. 8 g + 7" that the second products of all three kernels (O^T += V^T P^T, dQ^T += K^T dS^T, dV^T += dO^T P,
+// dK^T += Q^T dS) used to read from transposed copies ([B, H, D, Tp] in HBM, written by slam_head_rope_transpose: three launches per
+// layer, and half of the backward kernels' LDS-DMA pieces).
+// Swizzle: the 16-byte chunks of tile row `row` are XOR-ed with tr_swz<D>(row); the same key keeps the b128 fragment reads of the FIRST
+// products (16 rows 8 (i / 4) + 4 f + i % 4 per fragment) and these reads (8 rows x 32 bytes per half-wave) free of bank conflicts
+// (measured: 333 cycles per 16 reads and wave = the conflict-free floor; the round-2/3 keys cost 512, no swizzle 1707).
+template <int D>
+__device__ __forceinline__ int tr_swz(int row) {
+  return D == 128 ? (((row & 3) << 1) | (((row >> 3) & 1) << 3)) : ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2) | (row & 1));
+}
+template <int OFF>
+__device__ __forceinline__ u32x2_t lds_read_tr(unsigned addr) {
+  u32x2_t r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+struct TrFrag {   // the two halves of one transposed A operand (k-slots 0-3 | 4-7 of the lane's group)
+  u32x2_t lo, hi;
+};
+__device__ __forceinline__ frag_t tr_join(const TrFrag& t) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  u32x4_t w;
+  w[0] = t.lo[0]; w[1] = t.lo[1]; w[2] = t.hi[0]; w[3] = t.hi[1];
+  return __builtin_bit_cast(frag_t, w);
+}
+__device__ __forceinline__ void lds_landed(TrFrag& r) { asm volatile("" : "+v"(r.lo), "+v"(r.hi)); }
+// per-lane byte offset (inside a row-major [rows][D] tile) of the first transposed read: row 8 g + (li >> 2), the 8-byte half li & 1 of
+// logical chunk (li & 3) >> 1; df enters as XOR (df << 5) (it shares the chunk bits with the key), half / tile row blocks as immediates
+template <int D>
+__device__ __forceinline__ unsigned tr_lane_off(int g, int li) {
+  const int row = 8 * g + (li >> 2);
+  return (unsigned)(row * (D * 2) + (((((li & 3) >> 1)) ^ tr_swz<D>(row)) << 4) + (li & 1) * 8);
+}
+
+
 __device__ unsigned long long g_attn_probe[2 * 16 * 8];   // tools: cycle stamps of two waves of one workgroup (PROBE forms)
 
 // forward: 4 waves x 32 query rows per workgroup, 64-key K / V^T tiles staged through LDS
 // ------------------------------------------------------------------------------------------
 // QF = 16-row query fragments per wave (2: 128-query workgroups; 1: 64-query workgroups, fewer VGPRs -> more waves per SIMD)
-template <int D, bool CAUSAL, int QF, bool RP = false, bool DROP = false, bool PROBE = false, bool DMA = false, bool PLAIN = false>
+// TRV (round 4, shipped): the V tile is staged ROW-MAJOR ([64 keys][D], straight from the fused QKV buffer: no [B,H,D,Tp] copy of V) and
+// the V^T operand of O^T += V^T P^T is read with ds_read_b64_tr_b16 (two 8-byte reads per fragment instead of one 16-byte read)
+template <int D, bool CAUSAL, int QF, bool RP = false, bool DROP = false, bool PROBE = false, bool DMA = false, bool PLAIN = false, bool TRV = false>
 __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnParams p) {
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
@@ -375,8 +417,14 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
 #pragma unroll
     for (int i = 0; i < VI; i++) {
       const int item = tid + i * 256;
-      const int d = item >> 3, c = item & 7;
-      vreg[i] = *reinterpret_cast<const frag_t*>(p.Vt + ((int64_t)(b * p.Hkv + hk) * D + d) * Tkp + k0 + c * 8);
+      if constexpr (TRV) {
+        const int row = item / KCH, c = item % KCH;
+        const int key = k0 + row;
+        vreg[i] = (key < Tk) ? *reinterpret_cast<const frag_t*>(p.V + ((int64_t)b * Tk + key) * p.ldv + hk * D + c * 8) : zero_frag();
+      } else {
+        const int d = item >> 3, c = item & 7;
+        vreg[i] = *reinterpret_cast<const frag_t*>(p.Vt + ((int64_t)(b * p.Hkv + hk) * D + d) * Tkp + k0 + c * 8);
+      }
     }
   };
   auto lstore = [&]() {
@@ -389,8 +437,13 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
 #pragma unroll
     for (int i = 0; i < VI; i++) {
       const int item = tid + i * 256;
-      const int d = item >> 3, c = item & 7;
-      *reinterpret_cast<frag_t*>(ldsV + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = vreg[i];
+      if constexpr (TRV) {
+        const int row = item / KCH, c = item % KCH;
+        *reinterpret_cast<frag_t*>(ldsV + row * KROWB + ((c ^ tr_swz<D>(row)) << 4)) = vreg[i];
+      } else {
+        const int d = item >> 3, c = item & 7;
+        *reinterpret_cast<frag_t*>(ldsV + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = vreg[i];
+      }
     }
   };
 
@@ -409,19 +462,25 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
   // rows, which only tiles on the masked path (k0 + 64 > Tk) can contain. ----
   unsigned voff[NPW], dsto[NPW];
   __amdgpu_buffer_rsrc_t srd_k, srd_vt;
-  unsigned lds0 = 0, ldk2 = 0;
+  unsigned lds0 = 0, ldk2 = 0, ldv2 = 0;
   if constexpr (DMA) {
     lds0 = __builtin_amdgcn_readfirstlane(lds_offset_of(lds));
     ldk2 = (unsigned)p.ldk * 2u;
+    ldv2 = TRV ? (unsigned)p.ldv * 2u : 0u;
     const int nB = p.gz;
     srd_k = __builtin_amdgcn_make_buffer_rsrc((void*)p.K, 0, (unsigned)((((int64_t)nB * Tk - 1) * p.ldk + (int64_t)p.Hkv * D) * 2), 0x00020000);
-    srd_vt = __builtin_amdgcn_make_buffer_rsrc((void*)p.Vt, 0, (unsigned)((int64_t)nB * p.Hkv * D * Tkp * 2), 0x00020000);
+    if constexpr (TRV) srd_vt = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, (unsigned)((((int64_t)nB * Tk - 1) * p.ldv + (int64_t)p.Hkv * D) * 2), 0x00020000);
+    else srd_vt = __builtin_amdgcn_make_buffer_rsrc((void*)p.Vt, 0, (unsigned)((int64_t)nB * p.Hkv * D * Tkp * 2), 0x00020000);
 #pragma unroll
     for (int u = 0; u < NPW; u++) {
       const int j = u * 4 + wave;                 // piece of the stage
       if (u < NPW / 2) {                          // K: [64][D] row-major
         const int row = j * (1024 / KROWB) + lane / KCH, c = lane % KCH;
         voff[u] = (unsigned)(((int64_t)b * Tk + row) * p.ldk + hk * D + ((c ^ fwd_swz<D>(row)) << 3)) * 2u;
+      } else if constexpr (TRV) {                 // V: [64][D] row-major like K, swizzled for the transposed reads
+        const int jv = j - NPW * 2;
+        const int row = jv * (1024 / KROWB) + lane / KCH, c = lane % KCH;
+        voff[u] = (unsigned)(((int64_t)b * Tk + row) * p.ldv + hk * D + ((c ^ tr_swz<D>(row)) << 3)) * 2u;
       } else {                                    // V^T: [D][64 keys], 128-byte rows
         const int jv = j - NPW * 2;               // piece inside the V^T sub-tile
         const int d = jv * 8 + (lane >> 3), c = lane & 7;
@@ -445,7 +504,7 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
 #pragma unroll
       for (int u = 0; u < NPW; u++) {
         const unsigned dst = __builtin_amdgcn_readfirstlane(st + dsto[u]);
-        const unsigned so = (u < NPW / 2) ? (unsigned)k0 * ldk2 : (unsigned)k0 * 2u;
+        const unsigned so = (u < NPW / 2) ? (unsigned)k0 * ldk2 : (TRV ? (unsigned)k0 * ldv2 : (unsigned)k0 * 2u);
         bufdma16_asm(u < NPW / 2 ? srd_k : srd_vt, voff[u] + __builtin_amdgcn_readfirstlane(so), dst);
       }
     }
@@ -530,7 +589,24 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
 #pragma unroll
     for (int a = 0; a < 2; a++) va[a] = vbase + (unsigned)(((a * 4 + g) ^ ((li >> 1) & 7)) << 4);   // rows d = df*16 + li: (d >> 1) & 7 = (li >> 1) & 7
     frag_t vfr[2][DF];
-    if constexpr (!PLAIN) static_for<0, DF>([&](auto df) { vfr[0][df] = lds_read128<df * 16 * 128>(va[0]); });
+    // TRV: fragment t = a * DF + df of the V^T operand = two transposed 8-byte reads of V-tile rows 32 a + 8 g + 4 half + (li >> 2);
+    // TPRE fragments are requested before the softmax (12 reads at most: the LDS counter holds 15), TAH ahead of their products after it
+    constexpr int NT = 2 * DF;
+    constexpr int TPRE = PLAIN ? 0 : (DF < 6 ? DF : 6);
+    constexpr int TAH = DF < 6 ? DF : 6;
+    TrFrag vtr[TRV ? NT : 1];
+    unsigned vta[TRV ? DF : 1];
+    if constexpr (TRV) {
+      const unsigned t0 = lds_offset_of(ldsV) + tr_lane_off<D>(g, li);
+#pragma unroll
+      for (int df = 0; df < DF; df++) vta[df] = t0 ^ (unsigned)(df << 5);   // (the stage base is a multiple of 1 KiB)
+      static_for<0, TPRE>([&](auto t) {
+        vtr[t].lo = lds_read_tr<((t / DF) * 32) * KROWB>(vta[t % DF]);
+        vtr[t].hi = lds_read_tr<((t / DF) * 32 + 4) * KROWB>(vta[t % DF]);
+      });
+    } else {
+      if constexpr (!PLAIN) static_for<0, DF>([&](auto df) { vfr[0][df] = lds_read128<df * 16 * 128>(va[0]); });
+    }
     // ---- online softmax (per query = lane&15, replicated over the 4 lane groups) ----
     // The running maximum only moves when a tile exceeds it by more than 2^8 (in the exponent's log2 units): P stays <= 256,
     // exact in fp32 / bf16, and the O / l rescale becomes a rare wave-uniform branch instead of 2 exp + 16 multiplies per tile
@@ -673,6 +749,28 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
     }
     stamp(it, 5);
     // ---- O^T += V^T . P^T ----
+    if constexpr (TRV) {
+      frag_t pb[2][QF];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int f = 0; f < QF; f++) pb[a][f] = pack_frag(s[f][2 * a], s[f][2 * a + 1]);
+      static_for<TPRE, TAH>([&](auto t) {      // (PLAIN: nothing was requested before the softmax)
+        vtr[t].lo = lds_read_tr<((t / DF) * 32) * KROWB>(vta[t % DF]);
+        vtr[t].hi = lds_read_tr<((t / DF) * 32 + 4) * KROWB>(vta[t % DF]);
+      });
+      static_for<0, NT>([&](auto t) {
+        constexpr int inflight = (NT - t < TAH ? NT - t : TAH);   // fragments requested and not yet waited for, incl. t
+        lds_wait<2 * (inflight - 1)>(vtr[t]);
+        if constexpr (t + TAH < NT) {
+          vtr[t + TAH].lo = lds_read_tr<(((t + TAH) / DF) * 32) * KROWB>(vta[(t + TAH) % DF]);
+          vtr[t + TAH].hi = lds_read_tr<(((t + TAH) / DF) * 32 + 4) * KROWB>(vta[(t + TAH) % DF]);
+        }
+        const frag_t av = tr_join(vtr[t]);
+#pragma unroll
+        for (int f = 0; f < QF; f++) o[f][t % DF] = mfma16(av, pb[t / DF][f], o[f][t % DF]);
+      });
+    } else {
     if constexpr (PLAIN) static_for<0, DF>([&](auto df) { vfr[0][df] = lds_read128<df * 16 * 128>(va[0]); });
     static_for<0, 2>([&](auto a) {
       frag_t pb[QF];
@@ -685,6 +783,7 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
         for (int f = 0; f < QF; f++) o[f][df] = mfma16(vfr[a][df], pb[f], o[f][df]);
       });
     });
+    }
     stamp(it, 6);
   }
   if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMAs still target this workgroup's LDS
@@ -1401,6 +1500,251 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ring_kernel(AttnParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// backward dK/dV, transposed-read form (round 4, shipped): attn_bwd_dkdv_ring_kernel without the Q^T / dO^T sub-tiles.  A stage is
+// Q | dO | LSE,Delta (17 KiB at D = 128, was 33): half the LDS-DMA pieces per wave and tile, and the [B, H, D, Tp] copies of Q and dO
+// are no longer read (or written).  dO^T / Q^T operands of the second products: two ds_read_b64_tr_b16 per fragment from the row-major
+// sub-tiles the first products read with ds_read_b128.  Same arithmetic, masks, RoPE / GQA epilogue and ring discipline (4 stages, three
+// tiles in flight, counted vmcnt, one raw barrier per tile) as the ring kernel.
+// ------------------------------------------------------------------------------------------
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(512) void attn_bwd_dkdv_tr_kernel(AttnParams p) {
+  constexpr int KD = D / 32;
+  constexpr int DF = D / 16;
+  constexpr int ROWB = D * 2;
+  constexpr int KCH = D / 8;
+  constexpr int NS = 4;                       // ring stages
+  constexpr int SUB = 32 * ROWB;              // bytes of one row-major sub-tile [32][D]
+  constexpr int STG = 2 * SUB + 1024;         // Q | dO | LSE[32] Delta[32] (+ the rest of that DMA piece)
+  constexpr int NI = SUB / 1024;              // 1 KiB DMA instructions per sub-tile (8 for D = 128, 4 for D = 64)
+  constexpr int NU = 2 * NI / 8;              // tile DMA instructions per wave and stage: 2 (D = 128: piece `wave` of Q and of dO) | 1
+  constexpr int RPI = 1024 / ROWB;            // rows per DMA instruction (4 | 8)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const AttnBlk blk = attn_blk(p);
+  const int b = blk.z, hk = blk.y;
+  const int G = p.Hq / p.Hkv;
+  const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
+  const int kb0 = blk.x * 128, kw0 = kb0 + wave * 16;
+  const int key = kw0 + li;
+  const bool kok = key < Tk && (!p.kmask || p.kmask[(int64_t)b * Tkp + min(key, Tkp - 1)] != 0);
+
+  frag_t kf[KD], vf[KD];
+#pragma unroll
+  for (int kd = 0; kd < KD; kd++) {
+    const bool inb = key < Tk;
+    kf[kd] = inb ? *reinterpret_cast<const frag_t*>(p.K + ((int64_t)b * Tk + key) * p.ldk + hk * D + kd * 32 + g * 8) : zero_frag();
+    vf[kd] = inb ? *reinterpret_cast<const frag_t*>(p.V + ((int64_t)b * Tk + key) * p.ldv + hk * D + kd * 32 + g * 8) : zero_frag();
+  }
+  f32x4_t dk[DF], dv[DF];
+#pragma unroll
+  for (int df = 0; df < DF; df++) {
+    dk[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    dv[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const float sl2 = p.scale * LOG2E;
+  const int qstart = CAUSAL ? (kb0 / 32) * 32 : 0;
+  const int qend = p.seg_hi ? min(Tq, p.seg_hi[(int64_t)b * Tk + min(kb0 + 127, Tk - 1)]) : Tq;
+  int khi = p.seg_hi ? p.seg_hi[(int64_t)b * Tk + min(key, Tk - 1)] : 0x7fffffff;
+  // every ordinary load above must have RETURNED before the first asm DMA is issued (see attn_bwd_dkdv_ring_kernel)
+#pragma unroll
+  for (int kd = 0; kd < KD; kd++) asm volatile("" : "+v"(kf[kd]), "+v"(vf[kd]));
+  asm volatile("" : "+v"(khi));
+  const bool wave_all_keys = __builtin_amdgcn_readfirstlane(__all(kok ? 1 : 0));
+  const int qlim = min(Tq, __builtin_amdgcn_readfirstlane(khi));
+  const int nq = max(0, (qend - qstart + 31) / 32);
+  const int ntiles = G * nq;
+
+  // ---- DMA issue: D = 128: this wave owns piece j = wave (rows 4 wave .. + 3) of Q (u = 0) and of dO (u = 1); D = 64: waves 0-3 own
+  // piece wave (rows 8 wave .. + 7) of Q, waves 4-7 piece wave - 4 of dO.  Lane -> (row, 16-byte chunk); the swizzle goes on the SOURCE chunk.
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_offset_of(lds));
+  const int nB = p.gz;
+  const __amdgpu_buffer_rsrc_t srd_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, (unsigned)((((int64_t)nB * Tq - 1) * p.ldq + (int64_t)p.Hq * D) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_do = __builtin_amdgcn_make_buffer_rsrc((void*)p.dO, 0, (unsigned)((((int64_t)nB * Tq - 1) * p.lddo + (int64_t)p.Hq * D) * 2), 0x00020000);
+  const bool second = (D == 64) && wave >= 4;
+  const int jpiece = (D == 128) ? wave : (wave & 3);
+  __amdgpu_buffer_rsrc_t srd_u[NU];
+  unsigned voff[NU], ldu[NU], dsto[NU];
+#pragma unroll
+  for (int u = 0; u < NU; u++) {
+    const bool isdo = (D == 128) ? (u == 1) : second;
+    const int row = jpiece * RPI + lane / KCH, c = lane % KCH;
+    ldu[u] = (unsigned)(isdo ? p.lddo : p.ldq);
+    srd_u[u] = isdo ? srd_do : srd_q;
+    voff[u] = (unsigned)(((int64_t)b * Tq + row) * ldu[u] + ((c ^ tr_swz<D>(row)) << 3)) * 2u;
+    dsto[u] = (unsigned)((isdo ? SUB : 0) + jpiece * 1024);
+  }
+  const float* ld_src = (lane < 16 && lane >= 8 ? p.Delta + (lane - 8) * 4 : p.LSE + (lane < 8 ? lane * 4 : 0));
+  int i_hh = 0, i_qi = 0;
+  auto issue = [&](int s) {
+    const int h = hk * G + i_hh, q0 = qstart + i_qi * 32;
+    const unsigned st = lds0 + (unsigned)(s * STG);
+    const unsigned s_row = (unsigned)q0 * 2u;
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(st + dsto[u]);
+      const unsigned so = s_row * ldu[u] + (unsigned)(h * D) * 2u;
+      bufdma16_asm(srd_u[u], voff[u] + __builtin_amdgcn_readfirstlane(so), dst);
+    }
+    if (wave == 0) {
+      const int64_t e = ((int64_t)b * p.Hq + h) * Tqp + q0;
+      glds16_asm(ld_src + e, __builtin_amdgcn_readfirstlane(st + (unsigned)(2 * SUB)));
+    }
+    if (i_hh * nq + i_qi + 1 < ntiles) {
+      if (++i_qi == nq) {
+        i_qi = 0;
+        ++i_hh;
+      }
+    }
+  };
+
+  // per-lane LDS read addresses (stage 0): first products = fragment rows 8 (li / 4) + 4 f + li % 4, chunk (4 kd + g) ^ key;
+  // second products = transposed reads (tr_lane_off)
+  unsigned aA0[KD];
+  {
+    const int row = 8 * (li >> 2) + (li & 3);   // + 4 f through the instruction offset (the key ignores bit 2 of the row)
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) aA0[kd] = lds0 + (unsigned)(row * ROWB + (((kd * 4 + g) ^ tr_swz<D>(row)) << 4));
+  }
+  const unsigned aL0 = lds0 + (unsigned)(32 * g);
+  const unsigned aT0 = lds0 + tr_lane_off<D>(g, li);
+
+  if (ntiles > 0) {
+    issue(0);
+    issue(1);
+    issue(2);
+  }
+  int c_qi = 0;
+  constexpr int AH = 3;        // transposed fragments (4 reads each) requested ahead of their products
+  for (int it = 0; it < ntiles; it++) {
+    const int q0 = qstart + c_qi * 32;
+    if (++c_qi == nq) c_qi = 0;
+    const int s = it & (NS - 1);
+    // tile `it` has landed when at most the two younger tiles' DMA of this wave are outstanding
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NU + 2) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NU) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue((it + 3) & (NS - 1));
+    if (kw0 >= Tk || (CAUSAL && q0 + 31 < kw0)) continue;
+    const unsigned so = (unsigned)(s * STG);
+    unsigned aA[KD];
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) aA[kd] = aA0[kd] + so;
+    const unsigned aL = aL0 + so;
+    unsigned aT[DF];
+#pragma unroll
+    for (int df = 0; df < DF; df++) aT[df] = (aT0 + so) ^ (unsigned)(df << 5);   // (so is a multiple of 1 KiB: the XOR commutes with it)
+    frag_t q0f[KD], d0f[KD], q1f[KD], d1f[KD], lse0, lse1, del0, del1;
+    TrFrag bq[DF], bd[DF];
+    static_for<0, KD>([&](auto kd) {
+      q0f[kd] = lds_read128<0>(aA[kd]);
+      d0f[kd] = lds_read128<SUB>(aA[kd]);
+    });
+    lse0 = lds_read128<2 * SUB>(aL);
+    lse1 = lds_read128<2 * SUB + 16>(aL);
+    del0 = lds_read128<2 * SUB + 128>(aL);
+    del1 = lds_read128<2 * SUB + 144>(aL);
+    f32x4_t sacc[2], dp[2];
+    sacc[0] = sacc[1] = dp[0] = dp[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // fragment 0 products while fragment 1's operands are fetched (2 KD + 4 reads outstanding at every wait)
+    static_for<0, KD>([&](auto kd) {
+      lds_wait<2 * KD + 2>(q0f[kd], d0f[kd]);
+      q1f[kd] = lds_read128<4 * ROWB>(aA[kd]);
+      d1f[kd] = lds_read128<SUB + 4 * ROWB>(aA[kd]);
+      sacc[0] = mfma16(q0f[kd], kf[kd], sacc[0]);
+      dp[0] = mfma16(d0f[kd], vf[kd], dp[0]);
+    });
+    // fragment 1 products while the first AH transposed fragments of dO / Q are fetched (four 8-byte reads each; the LDS counter
+    // holds 15, so at most 12 of them are requested before the softmax)
+    static_for<0, KD>([&](auto kd) {
+      constexpr int before = 2 * (KD - 1 - kd) + 4 * (kd < AH ? kd : AH);   // reads younger than (q1f[kd], d1f[kd]) at this point
+      if constexpr (kd == 0) lds_wait<before>(lse0, lse1, del0, del1, q1f[kd], d1f[kd]);
+      else lds_wait<before>(q1f[kd], d1f[kd]);
+      if constexpr (kd < AH) {
+        bd[kd].lo = lds_read_tr<SUB>(aT[kd]);
+        bd[kd].hi = lds_read_tr<SUB + 4 * ROWB>(aT[kd]);
+        bq[kd].lo = lds_read_tr<0>(aT[kd]);
+        bq[kd].hi = lds_read_tr<4 * ROWB>(aT[kd]);
+      }
+      sacc[1] = mfma16(q1f[kd], kf[kd], sacc[1]);
+      dp[1] = mfma16(d1f[kd], vf[kd], dp[1]);
+    });
+    static_assert(KD >= 2 && AH <= DF, "read-ahead bookkeeping below");
+    // softmax arithmetic (covers the latency of those reads).  Element (f, r) of this lane is query q0 + 8g + 4f + r.
+    f32x4_t pm[2], ds[2];
+    const f32x4_t l4[2] = {__builtin_bit_cast(f32x4_t, lse0), __builtin_bit_cast(f32x4_t, lse1)};
+    const f32x4_t e4[2] = {__builtin_bit_cast(f32x4_t, del0), __builtin_bit_cast(f32x4_t, del1)};
+    const bool interior = wave_all_keys && q0 + 32 <= qlim && (!CAUSAL || kw0 + 15 <= q0);
+    if (interior) {
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float pv = fast_exp2(__builtin_fmaf(sacc[f][r], sl2, -LOG2E * l4[f][r]));
+          pm[f][r] = pv;
+          ds[f][r] = pv * (dp[f][r] - e4[f][r]) * p.scale;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int q = q0 + 8 * g + 4 * f + r;
+          const bool ok = kok && q < Tq && (!CAUSAL || key <= q) && q < khi;
+          const float pv = ok ? fast_exp2(__builtin_fmaf(sacc[f][r], sl2, -LOG2E * l4[f][r])) : 0.f;
+          pm[f][r] = pv;
+          ds[f][r] = ok ? pv * (dp[f][r] - e4[f][r]) * p.scale : 0.f;
+        }
+      }
+    }
+    const frag_t pb = pack_frag(pm[0], pm[1]);
+    const frag_t dsb = pack_frag(ds[0], ds[1]);
+    // dV / dK products, operands AH fragments ahead (wait for fragment df, then request df + AH, then its two products)
+    constexpr int PRE = KD < AH ? KD : AH;      // fragments requested above
+    static_for<0, DF>([&](auto df) {
+      if constexpr (df >= PRE && df < AH) {     // (KD < AH: top up to AH fragments in flight)
+        bd[df].lo = lds_read_tr<SUB>(aT[df]);
+        bd[df].hi = lds_read_tr<SUB + 4 * ROWB>(aT[df]);
+        bq[df].lo = lds_read_tr<0>(aT[df]);
+        bq[df].hi = lds_read_tr<4 * ROWB>(aT[df]);
+      }
+      constexpr int inflight = (df < PRE ? PRE : (df < AH ? df + 1 : (DF - df < AH ? DF - df : AH)));   // fragments requested and not yet waited for, incl. df
+      lds_wait<4 * (inflight - 1)>(bd[df], bq[df]);
+      if constexpr (df + AH < DF && df + AH >= PRE) {
+        if constexpr (df + AH >= AH) {
+          bd[df + AH].lo = lds_read_tr<SUB>(aT[df + AH]);
+          bd[df + AH].hi = lds_read_tr<SUB + 4 * ROWB>(aT[df + AH]);
+          bq[df + AH].lo = lds_read_tr<0>(aT[df + AH]);
+          bq[df + AH].hi = lds_read_tr<4 * ROWB>(aT[df + AH]);
+        }
+      }
+      dv[df] = mfma16(tr_join(bd[df]), pb, dv[df]);
+      dk[df] = mfma16(tr_join(bq[df]), dsb, dk[df]);
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMAs still target this workgroup's LDS
+  if (key >= Tk) return;
+  if (p.rope_cos) rope_grad_inplace<DF>(dk, p.rope_cos, p.rope_sin, p.rope_pos ? p.rope_pos[(int64_t)b * Tk + key] : key, D, g);
+  bf16_t* krow = p.dK + ((int64_t)b * Tk + key) * p.lddk + hk * D;
+  bf16_t* vrow = p.dV + ((int64_t)b * Tk + key) * p.lddv + hk * D;
+#pragma unroll
+  for (int df = 0; df < DF; df++) {
+    uint2 w;
+    w.x = pack2bf(dk[df][0], dk[df][1]);
+    w.y = pack2bf(dk[df][2], dk[df][3]);
+    *reinterpret_cast<uint2*>(krow + df * 16 + 4 * g) = w;
+    w.x = pack2bf(dv[df][0], dv[df][1]);
+    w.y = pack2bf(dv[df][2], dv[df][3]);
+    *reinterpret_cast<uint2*>(vrow + df * 16 + 4 * g) = w;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // backward dQ, ring form: the arithmetic of attn_bwd_dq_kernel<D, CAUSAL, false, QF> (same fragment mapping, same masks),
 // with the 32-key K | V | K^T tiles DMA'd HBM -> LDS into a ring of 3 stages (two tiles in flight while one is consumed),
@@ -1690,6 +2034,271 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AttnParams p) 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward dQ, transposed-read form (round 4, shipped): attn_bwd_dq_ring_kernel without the K^T sub-tile.  A stage is K | V | mask
+// (17 KiB at D = 128, was 25); the K^T operand of the dQ product is read with ds_read_b64_tr_b16 from the row-major K sub-tile that the S
+// product reads with ds_read_b128 (tr_swz keeps both conflict-free).  Same arithmetic / masks / epilogue as the ring kernel.
+// ------------------------------------------------------------------------------------------
+template <int D, bool CAUSAL, int QF>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_tr_kernel(AttnParams p) {
+  constexpr int KD = D / 32;
+  constexpr int DF = D / 16;
+  constexpr int ROWB = D * 2;
+  constexpr int KCH = D / 8;
+  constexpr int NS = 3;                       // ring stages
+  constexpr int SUB = 32 * ROWB;              // bytes of one row-major sub-tile [32][D]
+  constexpr int STG = 2 * SUB + 1024;         // K | V | mask[32] (+ the rest of that DMA piece)
+  constexpr int NI = SUB / 1024;              // 1 KiB DMA instructions per sub-tile (8 for D = 128, 4 for D = 64)
+  constexpr int PS = NI / 4;                  // ... per wave and sub-tile
+  constexpr int NU = 2 * PS;                  // tile DMA instructions per wave and stage (wave 0: + 1, the mask line)
+  constexpr int RPI = 1024 / ROWB;            // rows per DMA instruction (4 | 8)
+  constexpr int QB = 64 * QF;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const AttnBlk blk = attn_blk(p);
+  const int b = blk.z, h = blk.y;
+  const int hk = h / (p.Hq / p.Hkv);
+  const int Tq = p.Tq, Tk = p.Tk, Tqp = p.Tqp, Tkp = p.Tkp;
+  const int qb0 = blk.x * QB, qw0 = qb0 + wave * 16 * QF;
+
+  frag_t qf[QF][KD], dof[QF][KD];
+  float lse2[QF], delta[QF];
+  int qlo[QF];
+#pragma unroll
+  for (int f = 0; f < QF; f++) {
+    const int q = qw0 + f * 16 + li;
+    const bool qok = q < Tq;
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) {
+      qf[f][kd] = qok ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * Tq + q) * p.ldq + h * D + kd * 32 + g * 8) : zero_frag();
+      dof[f][kd] = qok ? *reinterpret_cast<const frag_t*>(p.dO + ((int64_t)b * Tq + q) * p.lddo + h * D + kd * 32 + g * 8) : zero_frag();
+    }
+    lse2[f] = qok ? p.LSE[((int64_t)b * p.Hq + h) * Tqp + q] * LOG2E : INFINITY;
+    float dl = 0.f;   // Delta[q] = sum_d dO[q,d] O[q,d], written out for the dK/dV kernel that runs next on the stream
+    if (qok) {
+#pragma unroll
+      for (int kd = 0; kd < KD; kd++) {
+        const frag_t of = *reinterpret_cast<const frag_t*>(p.O + ((int64_t)b * Tq + q) * p.ldo + h * D + kd * 32 + g * 8);
+        const u16x8_t ov = __builtin_bit_cast(u16x8_t, of), dv = __builtin_bit_cast(u16x8_t, dof[f][kd]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) dl = fmaf(bf2f(ov[e]), bf2f(dv[e]), dl);
+      }
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (qok && g == 0) p.Delta[((int64_t)b * p.Hq + h) * Tqp + q] = dl;
+    delta[f] = dl;
+    qlo[f] = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(q, Tq - 1)] : 0;
+  }
+  const float sl2 = p.scale * LOG2E;
+  int qlo_hi = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(qw0 + 16 * QF - 1, Tq - 1)] : 0;
+  f32x4_t dq[QF][DF];
+#pragma unroll
+  for (int f = 0; f < QF; f++)
+#pragma unroll
+    for (int df = 0; df < DF; df++) dq[f][df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int kend = CAUSAL ? min(Tk, qb0 + QB) : Tk;
+  const int ntiles = (kend + 31) / 32;
+  const int tbeg = p.seg_lo ? p.seg_lo[(int64_t)b * Tq + min(qb0, Tq - 1)] / 32 : 0;
+  // every ordinary load above must have RETURNED before the first asm DMA is issued (see attn_bwd_dkdv_ring_kernel)
+#pragma unroll
+  for (int f = 0; f < QF; f++) {
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) asm volatile("" : "+v"(qf[f][kd]), "+v"(dof[f][kd]));
+    asm volatile("" : "+v"(lse2[f]), "+v"(delta[f]), "+v"(qlo[f]));
+  }
+  int tb = tbeg;
+  asm volatile("" : "+s"(tb), "+s"(qlo_hi));
+
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_offset_of(lds));
+  const int nB = p.gz;
+  const __amdgpu_buffer_rsrc_t srd_k = __builtin_amdgcn_make_buffer_rsrc((void*)p.K, 0, (unsigned)((((int64_t)nB * Tk - 1) * p.ldk + (int64_t)p.Hkv * D) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_v = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, (unsigned)((((int64_t)nB * Tk - 1) * p.ldv + (int64_t)p.Hkv * D) * 2), 0x00020000);
+  unsigned voff[NU], dsto[NU];
+#pragma unroll
+  for (int u = 0; u < NU; u++) {
+    const int sub = u / PS, j = (u % PS) * 4 + wave;
+    const int row = j * RPI + lane / KCH, c = lane % KCH;
+    const int64_t ld = sub ? p.ldv : p.ldk;
+    voff[u] = (unsigned)(((int64_t)b * Tk + row) * ld + hk * D + ((c ^ tr_swz<D>(row)) << 3)) * 2u;
+    dsto[u] = (unsigned)(sub * SUB + j * 1024);
+  }
+  const uint8_t* mk_src = p.kmask ? p.kmask + (int64_t)b * Tkp + (lane == 1 ? 16 : 0) : reinterpret_cast<const uint8_t*>(p.K);
+  const unsigned ldk2 = (unsigned)p.ldk * 2u, ldv2 = (unsigned)p.ldv * 2u;
+  auto issue = [&](int tile, int s) {
+    const int k0 = min(tile, ntiles - 1) * 32;   // past the end: the last tile again, into a stage nobody reads
+    const unsigned st = lds0 + (unsigned)(s * STG);
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      const int sub = u / PS;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(st + dsto[u]);
+      const unsigned so = sub == 0 ? (unsigned)k0 * ldk2 : (unsigned)k0 * ldv2;
+      bufdma16_asm(sub == 0 ? srd_k : srd_v, voff[u] + __builtin_amdgcn_readfirstlane(so), dst);
+    }
+    if (wave == 0) glds16_asm(mk_src + (p.kmask ? k0 : 0), __builtin_amdgcn_readfirstlane(st + (unsigned)(2 * SUB)));
+  };
+
+  int aA[KD];
+  {
+    const int row = 8 * (li >> 2) + (li & 3);
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) aA[kd] = row * ROWB + (((kd * 4 + g) ^ tr_swz<D>(row)) << 4);
+  }
+  const int aT0 = (int)tr_lane_off<D>(g, li);
+  const int aM = 2 * SUB + 8 * g;
+
+  if (ntiles > tb) {
+    issue(tb, 0);
+    issue(tb + 1, 1);
+  }
+  int s = 0;
+  constexpr int NPAIR = (DF >= 8) ? 3 : KD;   // k-steps of the fragment-1 products that each request two transposed fragments (4 reads)
+  constexpr int AH = 2 * NPAIR;               // transposed fragments in flight through the softmax (12 reads at D = 128: the LDS counter holds 15)
+  for (int it = tb; it < ntiles; it++) {
+    const int k0 = it * 32;
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NU + 1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NU) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int sc = s;
+    {
+      const int s2 = s == 0 ? NS - 1 : s - 1;   // (s + 2) % 3
+      issue(it + 2, s2);
+    }
+    s = s == NS - 1 ? 0 : s + 1;
+    if (qw0 >= Tq || (CAUSAL && k0 > qw0 + 16 * QF - 1)) continue;
+
+    const unsigned so = lds0 + (unsigned)(sc * STG);
+    unsigned rA[KD];
+#pragma unroll
+    for (int kd = 0; kd < KD; kd++) rA[kd] = so + (unsigned)aA[kd];
+    const unsigned rM = so + (unsigned)aM;
+    unsigned rT[DF];
+#pragma unroll
+    for (int df = 0; df < DF; df++) rT[df] = (so + (unsigned)aT0) ^ (unsigned)(df << 5);
+    frag_t k0f[KD], v0f[KD], k1f[KD], v1f[KD];
+    TrFrag ktf[DF];
+    u32x2_t mk;
+    static_for<0, KD>([&](auto kd) {
+      k0f[kd] = lds_read128<0>(rA[kd]);
+      v0f[kd] = lds_read128<SUB>(rA[kd]);
+    });
+    mk = lds_read64<0>(rM);
+    f32x4_t st[QF][2], dpt[QF][2];
+#pragma unroll
+    for (int f = 0; f < QF; f++)
+#pragma unroll
+      for (int kf = 0; kf < 2; kf++) {
+        st[f][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dpt[f][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    static_for<0, KD>([&](auto kd) {
+      lds_wait<2 * KD - 1>(k0f[kd], v0f[kd]);
+      k1f[kd] = lds_read128<4 * ROWB>(rA[kd]);
+      v1f[kd] = lds_read128<SUB + 4 * ROWB>(rA[kd]);
+#pragma unroll
+      for (int f = 0; f < QF; f++) {
+        st[f][0] = mfma16(k0f[kd], qf[f][kd], st[f][0]);
+        dpt[f][0] = mfma16(v0f[kd], dof[f][kd], dpt[f][0]);
+      }
+    });
+    static_for<0, KD>([&](auto kd) {
+      constexpr int younger = 2 * (KD - 1 - kd) + 4 * (kd < NPAIR ? kd : NPAIR);
+      if constexpr (kd == 0) {
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger) : "memory");
+        asm volatile("" : "+v"(mk));
+        lds_landed(k1f[kd]);
+        lds_landed(v1f[kd]);
+      } else {
+        lds_wait<younger>(k1f[kd], v1f[kd]);
+      }
+      if constexpr (kd < NPAIR) {
+        ktf[2 * kd].lo = lds_read_tr<0>(rT[2 * kd]);
+        ktf[2 * kd].hi = lds_read_tr<4 * ROWB>(rT[2 * kd]);
+        ktf[2 * kd + 1].lo = lds_read_tr<0>(rT[2 * kd + 1]);
+        ktf[2 * kd + 1].hi = lds_read_tr<4 * ROWB>(rT[2 * kd + 1]);
+      }
+#pragma unroll
+      for (int f = 0; f < QF; f++) {
+        st[f][1] = mfma16(k1f[kd], qf[f][kd], st[f][1]);
+        dpt[f][1] = mfma16(v1f[kd], dof[f][kd], dpt[f][1]);
+      }
+    });
+    static_assert(DF == 2 * KD && AH <= DF, "two K^T fragments are requested per k-step above");
+    if (!p.kmask) mk = u32x2_t{0x01010101u, 0x01010101u};
+    frag_t dsb[QF];
+    const bool all_keys = __all(mk[0] == 0x01010101u && mk[1] == 0x01010101u);
+    const bool interior = all_keys && k0 + 32 <= Tk && (!CAUSAL || k0 + 31 <= qw0) && k0 >= qlo_hi;
+    if (interior) {
+#pragma unroll
+      for (int f = 0; f < QF; f++) {
+#pragma unroll
+        for (int kf = 0; kf < 2; kf++) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float pv = fast_exp2(__builtin_fmaf(st[f][kf][r], sl2, -lse2[f]));
+            st[f][kf][r] = pv * (dpt[f][kf][r] - delta[f]) * p.scale;
+          }
+        }
+        dsb[f] = pack_frag(st[f][0], st[f][1]);
+      }
+    } else {
+      const int kbase = k0 + 8 * g;
+#pragma unroll
+      for (int f = 0; f < QF; f++) {
+        const int q = qw0 + f * 16 + li;
+        const int hi = q < Tq ? (CAUSAL ? min(q, Tk - 1) : Tk - 1) : qlo[f] - 1;
+        const unsigned span = (unsigned)(hi - qlo[f]);
+        const bool any = hi >= qlo[f];
+        const int rel = kbase - qlo[f];
+#pragma unroll
+        for (int kf = 0; kf < 2; kf++) {
+          const unsigned m4 = kf ? mk[1] : mk[0];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const bool ok = any && (unsigned)(rel + 4 * kf + r) <= span && (m4 & (0xffu << (8 * r))) != 0;
+            const float pv = ok ? fast_exp2(__builtin_fmaf(st[f][kf][r], sl2, -lse2[f])) : 0.f;
+            st[f][kf][r] = pv * (dpt[f][kf][r] - delta[f]) * p.scale;
+          }
+        }
+        dsb[f] = pack_frag(st[f][0], st[f][1]);
+      }
+    }
+    static_for<0, DF>([&](auto df) {
+      constexpr int inflight = (DF - df < AH ? DF - df : AH);   // fragments requested and not yet waited for, incl. df
+      lds_wait<2 * (inflight - 1)>(ktf[df]);
+      if constexpr (df + AH < DF) {
+        ktf[df + AH].lo = lds_read_tr<0>(rT[df + AH]);
+        ktf[df + AH].hi = lds_read_tr<4 * ROWB>(rT[df + AH]);
+      }
+      const frag_t a = tr_join(ktf[df]);
+#pragma unroll
+      for (int f = 0; f < QF; f++) dq[f][df] = mfma16(a, dsb[f], dq[f][df]);
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMAs still target this workgroup's LDS
+  int li_e = li;
+  asm volatile("" : "+v"(li_e));
+#pragma unroll
+  for (int f = 0; f < QF; f++) {
+    const int q = qw0 + f * 16 + li_e;
+    if (q >= Tq) continue;
+    if (p.rope_cos) rope_grad_inplace<DF>(dq[f], p.rope_cos, p.rope_sin, p.rope_pos ? p.rope_pos[(int64_t)b * Tq + q] : q, D, g);
+    bf16_t* orow = p.dQ + ((int64_t)b * Tq + q) * p.lddq + h * D;
+#pragma unroll
+    for (int df = 0; df < DF; df++) {
+      uint2 w;
+      w.x = pack2bf(dq[f][df][0], dq[f][df][1]);
+      w.y = pack2bf(dq[f][df][2], dq[f][df][3]);
+      *reinterpret_cast<uint2*>(orow + df * 16 + 4 * g) = w;
+    }
+  }
+}
+
 // ---- gradients of WavLM's gated relative position bias from dL/d(score) (written by attn_bwd_dq_kernel<..., RP>) ----
 // score(b, h, q, k) += gate[b, h, q] * tab[h][k - q + T - 1]  (src/slam_llm/models/wavlm/modules.py:504-533)
 //   d gate[b, h, q] = sum_k ds[b, h, q, k] * tab[h][k - q + T - 1]                      one wave per row, fixed-order lane sums
@@ -1729,6 +2338,7 @@ __global__ __launch_bounds__(256) void relpos_dtab_kernel(const float* __restric
   dtab[(int64_t)h * rp_ld + r] += acc;
 }
 
+int g_attn_tr = 1;    // 1 = transposed operands by ds_read_b64_tr_b16 from the row-major tiles (shipped), 0 = round-3 kernels on the [B,H,D,Tp] copies
 int g_attn_xcd = 1;   // 1 = XCD-aware workgroup numbering (shipped), 0 = hardware round-robin order (A/B in tools)
 
 // every attention kernel is launched through this: logical 3-D grid -> 1-D launch + the geometry attn_blk() needs
@@ -1760,6 +2370,38 @@ int launch_dkdv_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr int lds = 4 * (4 * 32 * D * 2 + 1024);
   static bool attr_set = false;
   auto kern = attn_bwd_dkdv_ring_kernel<D, CAUSAL, ABL>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      slam_set_error("slam_attn_bwd: cannot raise the LDS limit to %d", lds);
+      return -2;
+    }
+    attr_set = true;
+  }
+  attn_launch(kern, grid, 512, lds, s, p);
+  return 0;
+}
+
+template <int D, bool CAUSAL, int QF>
+int launch_dq_tr(const AttnParams& p, dim3 grid, hipStream_t s) {
+  constexpr int lds = 3 * (2 * 32 * D * 2 + 1024);
+  static bool attr_set = false;
+  auto kern = attn_bwd_dq_tr_kernel<D, CAUSAL, QF>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      slam_set_error("slam_attn_bwd: cannot raise the LDS limit to %d", lds);
+      return -2;
+    }
+    attr_set = true;
+  }
+  attn_launch(kern, grid, 256, lds, s, p);
+  return 0;
+}
+
+template <int D, bool CAUSAL>
+int launch_dkdv_tr(const AttnParams& p, dim3 grid, hipStream_t s) {
+  constexpr int lds = 4 * (2 * 32 * D * 2 + 1024);
+  static bool attr_set = false;
+  auto kern = attn_bwd_dkdv_tr_kernel<D, CAUSAL>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       slam_set_error("slam_attn_bwd: cannot raise the LDS limit to %d", lds);
@@ -1805,10 +2447,11 @@ extern "C" int slam_attn_set_bwd_variant(int variant) {   // tools: 0 = DMA-ring
 
 extern int g_attn_fwd_dma, g_attn_fwd_plain;
 extern "C" int slam_attn_set_fwd_qf(int qf) {   // tools: 0 = auto, 1 / 2 fragments per wave; 10 / 11 = register-staged / DMA tiles
-  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11 || qf == 20 || qf == 21 || qf == 30 || qf == 31,
+  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11 || qf == 20 || qf == 21 || qf == 30 || qf == 31 || qf == 40 || qf == 41,
                  "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2; 10 / 11 = staged / DMA tiles; 20 / 21 = hardware / XCD-aware workgroup order; "
-                 "30 / 31 = general / mask-free instantiation for unmasked bidirectional D = 64)", qf);
-  if (qf >= 30) g_attn_fwd_plain = qf - 30;
+                 "30 / 31 = general / mask-free instantiation for unmasked bidirectional D = 64; 40 / 41 = transposed-copy / transposed-read kernels)", qf);
+  if (qf >= 40) g_attn_tr = qf - 40;
+  else if (qf >= 30) g_attn_fwd_plain = qf - 30;
   else if (qf >= 20) g_attn_xcd = qf - 20;   // (all attention kernels, forward and backward)
   else if (qf >= 10) g_attn_fwd_dma = qf - 10;
   else g_attn_fwd_qf = qf;
@@ -1823,7 +2466,23 @@ template <int D, bool CAUSAL, int QF, bool RP = false, bool DROP = false, bool P
 static void launch_fwd(const AttnParams& p, int64_t B, hipStream_t s) {
   dim3 grid((unsigned)cdiv64(p.Tq, 64 * QF), (unsigned)p.Hq, (unsigned)B);
   const int64_t lim = (int64_t)1 << 31;
-  const bool fits = (B * p.Tk * p.ldk + (int64_t)p.Hkv * D) * 2 < lim && B * p.Hkv * D * p.Tkp * 2 < lim;
+  // row-major V whenever the caller passed it (and the [B,H,D,Tp] copy only when it did not, or for the A/B knob)
+  const bool trv = p.V != nullptr && (g_attn_tr || p.Vt == nullptr);
+  const bool fits = (B * p.Tk * p.ldk + (int64_t)p.Hkv * D) * 2 < lim &&
+                    (trv ? (B * p.Tk * p.ldv + (int64_t)p.Hkv * D) * 2 < lim : B * p.Hkv * D * p.Tkp * 2 < lim);
+  if constexpr (!PROBE) {
+    if (trv) {
+      if constexpr (D == 64 && !CAUSAL && QF == 2 && !RP && !DROP) {
+        if (fits && g_attn_fwd_dma && !p.kmask && !p.seg_lo && g_attn_fwd_plain) {
+          attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true, true>), grid, 256, 0, s, p);
+          return;
+        }
+      }
+      if (fits && g_attn_fwd_dma) attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, false, true>), grid, 256, 0, s, p);
+      else attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, false, false, true>), grid, 256, 0, s, p);
+      return;
+    }
+  }
   if constexpr (D == 64 && !CAUSAL && QF == 2 && !RP && !DROP && !PROBE) {
     if (fits && g_attn_fwd_dma && !p.kmask && !p.seg_lo && g_attn_fwd_plain) {
       attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true>), grid, 256, 0, s, p);
@@ -1834,12 +2493,29 @@ static void launch_fwd(const AttnParams& p, int64_t B, hipStream_t s) {
   else attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, false>), grid, 256, 0, s, p);
 }
 
-extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt,
+// which transposed [B,H,D,Tp] copies a call with these arguments reads (bit 0: slam_attn_fwd needs Vt; bit 1: slam_attn_bwd needs Qt / Kt /
+// dOt).  0 for everything the transposed-read kernels cover; the host side builds the copies (slam_head_rope_transpose) only when asked
+// to.  flags: bit 0 = attention-probability dropout, bit 1 = gated relative position bias (WavLM).
+extern "C" int slam_attn_needs_transposed(int64_t B, int64_t Tq, int64_t Tk, int64_t Hq, int64_t Hkv, int64_t D, int64_t ldq, int64_t ldk,
+                                          int64_t ldv, int64_t lddo, int flags) {
+  int need = 0;
+  if (!g_attn_tr) return 3;
+  const int64_t lim = (int64_t)1 << 31;
+  const bool fits_kv = (B * Tk * ldk + Hkv * D) * 2 < lim && (B * Tk * ldv + Hkv * D) * 2 < lim;
+  const bool fits_q = (B * Tq * ldq + Hq * D) * 2 < lim && (B * Tq * lddo + Hq * D) * 2 < lim;
+  // backward: the transposed-read kernels are the ring forms; <= 64 queries, dropout, the relative position bias, the non-default
+  // variants and tensors beyond the descriptors' 2 GiB stay on the register-staged kernels, which read the copies
+  if (flags != 0 || Tq <= 64 || !fits_kv || !fits_q || g_attn_bwd_variant != 0) need |= 2;
+  return need;   // (the forward kernel has a transposed-read form of every instantiation, register-staged ones included)
+}
+
+extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, const void* V, int64_t ldv,
                              void* O, int64_t ldo, float* LSE, const uint8_t* key_mask, int64_t B,
                              int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D,
                              int causal, float scale, const int32_t* seg_lo, const int32_t* seg_hi, const float* rp_gate,
                              const float* rp_tab, int64_t rp_T, int64_t rp_ld, float drop_p, uint64_t drop_seed, void* stream) {
-  SLAM_CHECK_ARG(Q && K && Vt && O, "slam_attn_fwd: null pointer");
+  SLAM_CHECK_ARG(Q && K && (Vt || V) && O, "slam_attn_fwd: null pointer (V row-major and / or its [B,H,D,Tp] copy Vt must be given)");
+  SLAM_CHECK_ARG(!V || ldv % 8 == 0, "slam_attn_fwd: ldv must be a multiple of 8");
   SLAM_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "slam_attn_fwd: drop_p=%f must be in [0, 1)", (double)drop_p);
   SLAM_CHECK_ARG(drop_p == 0.f || (D == 64 && !causal && !seg_lo && !rp_gate),
                  "slam_attn_fwd: attention-probability dropout is implemented for head_dim 64, bidirectional, unpacked batches");
@@ -1853,6 +2529,7 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   SLAM_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "slam_attn_fwd: leading dims must be multiples of 8");
   AttnParams p = {};
   p.Q = (const bf16_t*)Q; p.ldq = ldq; p.K = (const bf16_t*)K; p.ldk = ldk; p.Vt = (const bf16_t*)Vt;
+  p.V = (const bf16_t*)V; p.ldv = ldv;
   p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = LSE; p.kmask = key_mask;
   p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
   p.seg_lo = seg_lo;
@@ -1900,7 +2577,7 @@ static int launch_dq(const AttnParams& p, int64_t B, hipStream_t s) {
     if (fits && g_attn_bwd_variant == 14) {
       if constexpr (D == 128 && CAUSAL) return launch_dq_ring<D, CAUSAL, 2, true>(p, g2, s);
     }
-    if (fits && g_attn_bwd_variant != 2) return launch_dq_ring<D, CAUSAL, 2>(p, g2, s);
+    if (fits && g_attn_bwd_variant != 2) return g_attn_tr ? launch_dq_tr<D, CAUSAL, 2>(p, g2, s) : launch_dq_ring<D, CAUSAL, 2>(p, g2, s);
     attn_launch((attn_bwd_dq_kernel<D, CAUSAL, false, 2>), g2, 256, 0, s, p);
   } else {
     dim3 g1((unsigned)cdiv64(p.Tq, 64), (unsigned)p.Hq, (unsigned)B);
@@ -1918,7 +2595,12 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
                              const float* rope_cos, const float* rope_sin, const int32_t* rope_pos,
                              const int32_t* seg_lo, const int32_t* seg_hi, float drop_p, uint64_t drop_seed, const float* rp_gate,
                              const float* rp_tab, int64_t rp_T, int64_t rp_ld, float* rp_ds, float* d_gate, float* d_tab, void* stream) {
-  SLAM_CHECK_ARG(Q && K && V && Qt && Kt && O && dO && dOt && LSE && Delta && dQ && dK && dV, "slam_attn_bwd: null pointer");
+  SLAM_CHECK_ARG(Q && K && V && O && dO && LSE && Delta && dQ && dK && dV, "slam_attn_bwd: null pointer");
+  {
+    const int need = slam_attn_needs_transposed(B, Tq, Tk, Hq, Hkv, D, ldq, ldk, ldv, lddo, (drop_p > 0.f ? 1 : 0) | (rp_gate ? 2 : 0));
+    SLAM_CHECK_ARG(!(need & 2) || (Qt && Kt && dOt), "slam_attn_bwd: this configuration runs the kernels that read the transposed copies: "
+                   "Qt / Kt / dOt must be given (slam_attn_needs_transposed says when)");
+  }
   SLAM_CHECK_ARG(!rp_gate || (rp_tab && rp_ds && d_gate && d_tab && D == 64 && !causal && !seg_lo && !rope_cos && drop_p == 0.f && Hq == Hkv &&
                               rp_T >= Tq && rp_T >= Tk && rp_ld >= 2 * rp_T - 1),
                  "slam_attn_bwd: the gated relative position bias needs rp_tab / rp_ds / d_gate / d_tab, head_dim 64, bidirectional unpacked MHA "
@@ -1986,18 +2668,18 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   if (D == 64) {
     if (causal) {
       if ((rc = launch_dq<64, true>(p, B, s))) return rc;
-      if (ring) rc = launch_dkdv_ring<64, true>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<64, true>), gk, 256, 0, s, p);
+      if (ring) rc = g_attn_tr ? launch_dkdv_tr<64, true>(p, gk2, s) : launch_dkdv_ring<64, true>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<64, true>), gk, 256, 0, s, p);
     } else {
       if ((rc = launch_dq<64, false>(p, B, s))) return rc;
-      if (ring) rc = launch_dkdv_ring<64, false>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<64, false>), gk, 256, 0, s, p);
+      if (ring) rc = g_attn_tr ? launch_dkdv_tr<64, false>(p, gk2, s) : launch_dkdv_ring<64, false>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<64, false>), gk, 256, 0, s, p);
     }
   } else {
     if (causal) {
       if ((rc = launch_dq<128, true>(p, B, s))) return rc;
-      if (ring) rc = launch_dkdv_ring<128, true>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<128, true>), gk, 256, 0, s, p);
+      if (ring) rc = g_attn_tr ? launch_dkdv_tr<128, true>(p, gk2, s) : launch_dkdv_ring<128, true>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<128, true>), gk, 256, 0, s, p);
     } else {
       if ((rc = launch_dq<128, false>(p, B, s))) return rc;
-      if (ring) rc = launch_dkdv_ring<128, false>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<128, false>), gk, 256, 0, s, p);
+      if (ring) rc = g_attn_tr ? launch_dkdv_tr<128, false>(p, gk2, s) : launch_dkdv_ring<128, false>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<128, false>), gk, 256, 0, s, p);
     }
   }
   if (rc) return rc;

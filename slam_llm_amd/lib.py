@@ -49,7 +49,8 @@ SIGNATURES = {
     "slam_rmsnorm_bwd": [P, I64, P, P, P, I64, P, I64, P, I64, P, I64, I64, P],
     "slam_head_rope_transpose": [P, I64, I64, P, P, I32, P, I64, I64, I64, I64, I64, P, P],
     "slam_transpose_bf16": [P, I64, P, I64, I64, I64, I64, P],
-    "slam_attn_fwd": [P, I64, P, I64, P, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P, P, I64, I64, F, U64, P],
+    "slam_attn_needs_transposed": [I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I32],
+    "slam_attn_fwd": [P, I64, P, I64, P, P, I64, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I32, F, P, P, P, P, I64, I64, F, U64, P],
     "slam_wavlm_gate": [P, I64, P, P, P, P, I64, I64, I64, I64, P],
     "slam_weight_norm_bwd": [P, P, P, P, P, I64, I64, I32, P],
     "slam_relpos_bucket_grad": [P, I64, P, I64, I64, I64, P, I32, P],

@@ -427,8 +427,7 @@ class HipWhisperEncoder(nn.Module):
         for i in range(cfg["enc_layers"]):
             ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], out=hbuf)
             ops.gemm_nt(hbuf, w[f"{i}.qkv"], out=qkv, bias=w[f"{i}.qkv_b"])
-            vt = ops.head_rope_transpose(qkv, 2 * d, B, T2, H, 64)
-            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T2, H, H, 64, False, scale, want_lse=False, out=obuf)
+            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T2, H, H, 64, False, scale, want_lse=False, out=obuf)
             ops.gemm_nt(obuf, w[f"{i}.out"], out=x, bias=w[f"{i}.out_b"], residual=x)
             ops.layernorm(x, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], out=hbuf)
             ops.gemm_nt(hbuf, w[f"{i}.fc1"], out=fbuf, bias=w[f"{i}.fc1_b"], act=ACT_GELU)
@@ -491,9 +490,7 @@ class HipWhisperEncoder(nn.Module):
         for i in range(cfg["enc_layers"]):
             h, m1, r1 = ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], stats=True)
             qkv = ops.gemm_nt(h, w[f"{i}.qkv"], bias=w[f"{i}.qkv_b"])
-            vt = ops.head_rope_transpose(qkv, 2 * d, B, T2, H, 64)
-            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T2, H, H, 64, False, scale, want_lse=True)
-            del vt
+            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T2, H, H, 64, False, scale, want_lse=True)
             x1 = ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"], residual=x)
             h2, m2, r2 = ops.layernorm(x1, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], stats=True)
             z = ops.gemm_nt(h2, w[f"{i}.fc1"], bias=w[f"{i}.fc1_b"])
@@ -548,13 +545,10 @@ class HipWhisperEncoder(nn.Module):
             self._lin_grads(dx1, R["a"], b + "attn.out.weight", acc, bias=((b + "attn.out.bias", 0, d),))
             da = ops.gemm_nt(dx1, w[f"{i}.outT"])
             qkv = R["qkv"]
-            qt = ops.head_rope_transpose(qkv, 0, B, T2, H, 64)
-            kt = ops.head_rope_transpose(qkv, d, B, T2, H, 64)
-            dat = ops.head_rope_transpose(da, 0, B, T2, H, 64)
             dqkv = torch.empty_like(qkv)
-            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], qt, kt, R["a"], da, dat, R["lse"], dqkv[:, :d],
+            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], R["a"], da, R["lse"], dqkv[:, :d],
                          dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T2, H, H, 64, False, scale)
-            del qt, kt, dat, da
+            del da
             self._lin_grads(dqkv, R["h"], b + "attn.query.weight", acc, N=3 * d, K=d,
                             bias=((b + "attn.query.bias", 0, d), (b + "attn.value.bias", 2 * d, d)))
             dh = ops.gemm_nt(dqkv, w[f"{i}.qkvT"])
@@ -629,8 +623,7 @@ class HipWhisperEncoder(nn.Module):
         for i in range(cfg["enc_layers"]):
             ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], out=hbuf)
             ops.gemm_nt(hbuf, w[f"{i}.qkv"], out=qkv, bias=w[f"{i}.qkv_b"])
-            vt = ops.head_rope_transpose(qkv, 2 * d, 1, M, H, 64)
-            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, 1, M, H, H, 64, False, scale, want_lse=False, out=obuf, seg=seg)
+            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], 1, M, H, H, 64, False, scale, want_lse=False, out=obuf, seg=seg)
             ops.gemm_nt(obuf, w[f"{i}.out"], out=x, bias=w[f"{i}.out_b"], residual=x)
             ops.layernorm(x, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], out=hbuf)
             ops.gemm_nt(hbuf, w[f"{i}.fc1"], out=fbuf, bias=w[f"{i}.fc1_b"], act=ACT_GELU)
@@ -1135,8 +1128,7 @@ class HipHubertEncoder(nn.Module):
                 ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, out=hbuf)
             attn_in = hbuf if pre_ln else x
             ops.gemm_nt(attn_in, w[f"{i}.qkv"], out=qkv, bias=w[f"{i}.qkv_b"])
-            vt = ops.head_rope_transpose(qkv, 2 * d, B, T, H, 64)
-            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=False, out=obuf,
+            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=False, out=obuf,
                          relpos=self._relpos(i, attn_in, B, T))
             if pre_ln:      # x += attn(LN1(x)); x += ffn(LN2(x))
                 ops.gemm_nt(obuf, w[f"{i}.out"], out=x, bias=w[f"{i}.out_b"], residual=x)
@@ -1221,10 +1213,8 @@ class HipHubertEncoder(nn.Module):
         for i in range(cfg["hub_layers"]):
             hh, m1, r1 = ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, stats=True)
             qkv = ops.gemm_nt(hh, w[f"{i}.qkv"], bias=w[f"{i}.qkv_b"])
-            vt = ops.head_rope_transpose(qkv, 2 * d, B, T, H, 64)
             rp = self._relpos(i, hh, B, T)      # WavLM: (gate [B,H,Tp], bias table, T); HuBERT: None
-            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=True, relpos=rp)
-            del vt
+            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=True, relpos=rp)
             x1 = ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"], residual=x)
             h2, m2, r2 = ops.layernorm(x1, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], eps, stats=True)
             z = ops.gemm_nt(h2, w[f"{i}.fc1"], bias=w[f"{i}.fc1_b"])
@@ -1247,10 +1237,8 @@ class HipHubertEncoder(nn.Module):
         S.update(x_pre=x_pre, mo=mo, ro=ro)
         for i in range(cfg["hub_layers"]):
             qkv = ops.gemm_nt(x, w[f"{i}.qkv"], bias=w[f"{i}.qkv_b"])
-            vt = ops.head_rope_transpose(qkv, 2 * d, B, T, H, 64)
             rp = self._relpos(i, x, B, T)
-            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, T, H, H, 64, False, scale, key_mask=S["key_mask"], want_lse=True, relpos=rp)
-            del vt
+            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=S["key_mask"], want_lse=True, relpos=rp)
             s1 = ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"], residual=x)
             x1, m1, r1 = ops.layernorm(s1, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, stats=True)
             z = ops.gemm_nt(x1, w[f"{i}.fc1"], bias=w[f"{i}.fc1_b"])
@@ -1304,14 +1292,11 @@ class HipHubertEncoder(nn.Module):
             self._lin_grads(dx1, R["a"], N.out(i) + ".weight", acc, bias=((N.out(i) + ".bias", 0, d),))
             da = ops.gemm_nt(dx1, w[f"{i}.outT"])
             qkv = R["qkv"]
-            qt = ops.head_rope_transpose(qkv, 0, B, T, H, 64)
-            kt = ops.head_rope_transpose(qkv, d, B, T, H, 64)
-            dat = ops.head_rope_transpose(da, 0, B, T, H, 64)
             dqkv = torch.empty_like(qkv)
             rp_b = self._relpos_backward_args(R, rp_state)      # WavLM: (gate, table, T, d_gate OUT, d_table ACCUMULATED)
-            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], qt, kt, R["a"], da, dat, R["lse"], dqkv[:, :d],
+            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], R["a"], da, R["lse"], dqkv[:, :d],
                          dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask, relpos=rp_b)
-            del qt, kt, dat, da
+            del da
             self._lin_grads(dqkv, R["h"], N.q(i) + ".weight", acc, N=3 * d, K=d,
                             bias=((N.q(i) + ".bias", 0, d), (N.k(i) + ".bias", d, d), (N.v(i) + ".bias", 2 * d, d)))
             dh = ops.gemm_nt(dqkv, w[f"{i}.qkvT"])
@@ -1409,14 +1394,11 @@ class HipHubertEncoder(nn.Module):
             self._lin_grads(ds1, R["a"], N.out(i) + ".weight", acc, bias=((N.out(i) + ".bias", 0, d),))
             da = ops.gemm_nt(ds1, w[f"{i}.outT"])
             qkv = R["qkv"]
-            qt = ops.head_rope_transpose(qkv, 0, B, T, H, 64)
-            kt = ops.head_rope_transpose(qkv, d, B, T, H, 64)
-            dat = ops.head_rope_transpose(da, 0, B, T, H, 64)
             dqkv = torch.empty_like(qkv)
             rp_b = self._relpos_backward_args(R, rp_state)
-            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], qt, kt, R["a"], da, dat, R["lse"], dqkv[:, :d],
+            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], R["a"], da, R["lse"], dqkv[:, :d],
                          dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask, relpos=rp_b)
-            del qt, kt, dat, da
+            del da
             self._lin_grads(dqkv, R["h"], N.q(i) + ".weight", acc, N=3 * d, K=d,
                             bias=((N.q(i) + ".bias", 0, d), (N.k(i) + ".bias", d, d), (N.v(i) + ".bias", 2 * d, d)))
             dx = ops.gemm_nt(dqkv, w[f"{i}.qkvT"])
@@ -1937,11 +1919,9 @@ class HipLlamaLora(nn.Module):
             _, rstd1 = ops.rmsnorm_fwd(h, L.ln1, eps, out=x1[:, :d])
             dq_, do_, dg_, dd_ = drop_for(L.qkv), drop_for(L.o), drop_for(L.gu), drop_for(L.down)
             qkv = L.qkv.forward(x1, st, drop=dq_)
-            qt = ops.head_rope_transpose(qkv, 0, B, T, Hq, D, cos=cos, sin=sin, want_t=train, positions=positions)
-            kt = ops.head_rope_transpose(qkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, want_t=train, positions=positions)
-            vt = ops.head_rope_transpose(qkv, (Hq + Hkv) * D, B, T, Hkv, D)
+            ops.rope_inplace(qkv, 0, B, T, Hq + Hkv, D, cos, sin, positions=positions)     # q and k heads: adjacent columns, one launch
             o_ext = L.o.new_input(M)
-            _, lse = ops.attn_fwd(qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], vt, B, T, Hq, Hkv, D, True, scale,
+            _, lse = ops.attn_fwd(qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:], B, T, Hq, Hkv, D, True, scale,
                                   key_mask=key_mask, want_lse=train, out=o_ext[:, : Hq * D], seg=seg)
             pruned = prune and L is self.layers[-1]
             Mr, o_in, h_res = M, o_ext, h
@@ -1963,7 +1943,7 @@ class HipLlamaLora(nn.Module):
                 ops.swiglu_fwd(gu, out=hh[:, :Fd])
             h_out = L.down.forward(hh, st, residual=h_mid, drop=dd_)
             if train:
-                stash["layers"].append(dict(h=h, rstd1=rstd1, x1=x1 if L.qkv.adapters else None, qkv=qkv, qt=qt, kt=kt,
+                stash["layers"].append(dict(h=h, rstd1=rstd1, x1=x1 if L.qkv.adapters else None, qkv=qkv,
                                             o=o_in, o_full=o_ext if pruned else None, inv=inv if pruned else None,
                                             lse=lse, h_mid=h_mid, rstd2=rstd2,
                                             x2=x2 if L.gu.adapters else None, gu=gu, gu_il=gu_il,
@@ -2057,13 +2037,11 @@ class HipLlamaLora(nn.Module):
             x1 = L.qkv.new_input(M)
             ops.rmsnorm_fwd(h, L.ln1, eps, out=x1[:, :d])
             qkv = L.qkv.forward(x1, st)
-            ops.head_rope_transpose(qkv, 0, B, T, Hq, D, cos=cos, sin=sin, want_t=False, positions=positions)
-            ops.head_rope_transpose(qkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, want_t=False, positions=positions)
-            vt = ops.head_rope_transpose(qkv, (Hq + Hkv) * D, B, T, Hkv, D)
+            ops.rope_inplace(qkv, 0, B, T, Hq + Hkv, D, cos, sin, positions=positions)
             cache.Kp[li].copy_(qkv[:, Hq * D:(Hq + Hkv) * D].view(B, T, Hkv * D))
             cache.Vp[li].copy_(qkv[:, (Hq + Hkv) * D:].view(B, T, Hkv * D))
             o_ext = L.o.new_input(M)
-            ops.attn_fwd(qkv[:, : Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], vt, B, T, Hq, Hkv, D, True, D ** -0.5,
+            ops.attn_fwd(qkv[:, : Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:], B, T, Hq, Hkv, D, True, D ** -0.5,
                          key_mask=key_mask, want_lse=False, out=o_ext[:, : Hq * D])
             h = self._mlp_block(L, L.o.forward(o_ext, st, residual=h))
         last = h.view(B, T, -1)[:, T - 1].contiguous()
@@ -2171,14 +2149,13 @@ class HipLlamaLora(nn.Module):
             dO, o_attn = do_ext[:, : Hq * D], S["o"]
             if S["inv"] is not None:    # last layer ran behind its attention over the labelled rows only: back to every row (zeros elsewhere)
                 dO, dh_mid, o_attn = ops.gather_rows(dO, S["inv"]), ops.gather_rows(dh_mid, S["inv"]), S["o_full"]
-            dOt = ops.head_rope_transpose(dO, 0, B, T, Hq, D)
             qkv = S["qkv"]
             q2, k2, v2 = qkv[:, : Hq * D], qkv[:, Hq * D: (Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
             dqkv = torch.empty_like(qkv)
-            ops.attn_bwd(q2, k2, v2, S["qt"], S["kt"], o_attn[:, : Hq * D], dO, dOt, S["lse"],
+            ops.attn_bwd(q2, k2, v2, o_attn[:, : Hq * D], dO, S["lse"],
                          dqkv[:, : Hq * D], dqkv[:, Hq * D: (Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:],
                          B, T, Hq, Hkv, D, True, scale, key_mask=key_mask, rope=rope, seg=seg)  # RoPE backward fused
-            del do_ext, dO, dOt
+            del do_ext, dO
             dx1 = L.qkv.backward(dqkv, S["x1"], st, accumulate, drop=dq_)
             del dqkv
             dh = ops.rmsnorm_bwd(S["h"], S["rstd1"], L.ln1, dx1[:, :d], dres=dh_mid)

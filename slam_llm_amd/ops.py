@@ -444,20 +444,38 @@ def transpose(x2d, Rp=None, out=None):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def attn_fwd(q2d, k2d, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_lse=True, out=None, Tk=None, seg=None,
+def rope_inplace(src2d, col0, B, T, H, D, cos, sin, positions=None, inverse=False):
+    """HF apply_rotary_pos_emb on columns [col0, col0 + H*D) of src2d [B*T, ld], in place (q and k heads are adjacent columns of the fused
+    QKV buffer: one launch with H = Hq + Hkv rotates both).  No transposed copy is written: the attention kernels read their transposed
+    operands from the row-major tiles (ds_read_b64_tr_b16)."""
+    head_rope_transpose(src2d, col0, B, T, H, D, cos=cos, sin=sin, inverse=inverse, want_t=False, positions=positions)
+
+
+def attn_needs_transposed(q2d, k2d, v2d, do2d, B, T, Tk, Hq, Hkv, D, drop=None, relpos=None) -> int:
+    """bit 1: slam_attn_bwd reads Qt / Kt / dOt for this configuration (<= 64 queries, dropout, relative position bias, > 2 GiB)"""
+    flags = (1 if drop else 0) | (2 if relpos else 0)
+    return lib.raw().slam_attn_needs_transposed(B, T, Tk, Hq, Hkv, D, _ld(q2d), _ld(k2d), _ld(v2d), _ld(do2d) if do2d is not None else _ld(q2d), flags)
+
+
+def attn_fwd(q2d, k2d, v, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_lse=True, out=None, Tk=None, seg=None,
              relpos=None, drop=None):
-    """self-attention: q/k rows (b*T + t).  Cross-attention: pass Tk (key rows b*Tk + t); vt is [B,Hkv,D,Tkp].
+    """self-attention: q/k/v rows (b*T + t), head h at column h*D.  Cross-attention: pass Tk (key / value rows b*Tk + t).
+    v: the ROW-MAJOR values [B*Tk, ld] (a column slice of the fused QKV buffer) -- the kernel reads V^T with transposing LDS reads -- or,
+    for the round-3 kernels (tools, A/B), the [B,Hkv,D,Tkp] transposed copy written by head_rope_transpose (a 4-D tensor).
     seg = (lo, hi) int32 [B*T]: packed sequences (B = 1), query q sees keys lo[q] <= k <= q (causal) or
     lo[q] <= k < hi[q] (bidirectional: the ragged encoder, one clip per segment).
     relpos = (gate [B,Hq,Tqp] f32, table from relpos_table(), rp_T): WavLM's gated relative position bias.
     drop = (p, seed): dropout on the attention probabilities (counter-based mask; attn_bwd with the same pair recomputes it)."""
     Tk = Tk or T
-    Tkp, Tqp = vt.shape[-1], round_up(T, 64)
+    vt, v2d = (v, None) if v.dim() == 4 else (None, v)
+    Tkp, Tqp = (vt.shape[-1] if vt is not None else round_up(Tk, 64)), round_up(T, 64)
+    assert key_mask is None or key_mask.shape[-1] == Tkp
     if out is None:
         out = torch.empty((B * T, Hq * D), dtype=torch.bfloat16, device=q2d.device)
     lse = torch.empty((B, Hq, Tqp), dtype=torch.float32, device=q2d.device) if want_lse else None
     _timed("attn_fwd", 4.0 * B * Hq * T * Tk * D * (0.5 if causal else 1.0),
-           lambda: call("slam_attn_fwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(vt), _p(out), _ld(out), _p(lse),
+           lambda: call("slam_attn_fwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(vt), _p(v2d), _ld(v2d) if v2d is not None else 0,
+                        _p(out), _ld(out), _p(lse),
                         _p(key_mask), B, T, Tk, Tqp, Tkp, Hq, Hkv, D, 1 if causal else 0, scale, _p(seg[0]) if seg else None,
                         _p(seg[1]) if seg else None, _p(relpos[0]) if relpos else None,
                         (relpos[1].data_ptr() + 64 * 4) if relpos else None, relpos[2] if relpos else 0,
@@ -534,12 +552,22 @@ def wavlm_gate_bwd(x2d: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, grep_
     return dv, da_term, dx
 
 
-def attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq2d, dk2d, dv2d, B, T, Hq, Hkv, D, causal, scale,
-             key_mask=None, Tk=None, rope=None, seg=None, drop=None, relpos=None):
+def attn_bwd(q2d, k2d, v2d, o2d, do2d, lse, dq2d, dk2d, dv2d, B, T, Hq, Hkv, D, causal, scale,
+             key_mask=None, Tk=None, rope=None, seg=None, drop=None, relpos=None, qt=None, kt=None, dot=None):
     """rope = (cos, sin[, positions]) tables: dq/dk come out as gradients w.r.t. the pre-RoPE projections (fused
-    epilogue; explicit int32 positions for packed batches).  seg = (lo, hi): packed sequences, see attn_fwd."""
+    epilogue; explicit int32 positions for packed batches).  seg = (lo, hi): packed sequences, see attn_fwd.
+    qt / kt / dot: the [B,H,D,Tp] transposed copies of q / k / dO.  The shipped kernels do not read them (transposing LDS reads from the
+    row-major tiles); the configurations that still run the round-2/3 kernels (slam_attn_needs_transposed: <= 64 queries, attention
+    dropout, WavLM's relative position bias, tensors beyond 2 GiB, the tools' variants) get them built here when the caller passes none."""
     Tk = Tk or T
-    Tqp, Tkp = qt.shape[-1], kt.shape[-1]
+    Tqp, Tkp = round_up(T, 64), round_up(Tk, 64)
+    if attn_needs_transposed(q2d, k2d, v2d, do2d, B, T, Tk, Hq, Hkv, D, drop, relpos) & 2:
+        if qt is None:
+            qt = head_rope_transpose(q2d, 0, B, T, Hq, D)
+        if kt is None:
+            kt = head_rope_transpose(k2d, 0, B, Tk, Hkv, D)
+        if dot is None:
+            dot = head_rope_transpose(do2d, 0, B, T, Hq, D)
     delta = torch.empty((B, Hq, Tqp), dtype=torch.float32, device=q2d.device)
     # relpos = (gate [B,Hq,Tqp] f32, table from relpos_table(), rp_T, d_gate [B,Hq,Tqp] f32 OUT, d_table (same layout as the table, ACCUMULATED)):
     # WavLM's gated relative position bias in the backward (unfrozen WavLM); dL/d(score) goes through a scratch buffer

@@ -165,30 +165,24 @@ class HipProjectorQFormer(nn.Module):
             Lp = f"{P}encoder.layer.{l}."
             A = Lp + "attention."
             qkv = ops.gemm_nt(h, self._fused(A + "attention.query.weight", 3 * d, d), bias=self._fused(A + "attention.query.bias", 1, 3 * d, master=True).view(-1))
-            qt = ops.head_rope_transpose(qkv, 0, B, Q, H, 64) if train else None
-            kt = ops.head_rope_transpose(qkv, d, B, Q, H, 64) if train else None
-            vt = ops.head_rope_transpose(qkv, 2 * d, B, Q, H, 64)
             ad = attn_drop()
-            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], vt, B, Q, H, H, 64, False, scale, want_lse=train, drop=ad)
+            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, Q, H, H, 64, False, scale, want_lse=train, drop=ad)
             k1 = drop_key()
             s1 = out_proj(a, A + "output.dense.weight", A + "output.dense.bias", h, k1)
             h1, m1, r1 = ops.layernorm(s1, f32(A + "output.LayerNorm.weight"), f32(A + "output.LayerNorm.bias"), self.eps, stats=True)
-            rec = dict(h=h, qkv=qkv, qt=qt, kt=kt, a=a, lse=lse, s1=s1, m1=m1, r1=r1, h1=h1, cross=None, k1=k1, ad=ad)
+            rec = dict(h=h, qkv=qkv, a=a, lse=lse, s1=s1, m1=m1, r1=r1, h1=h1, cross=None, k1=k1, ad=ad)
             hx = h1
             if l % self.cross_freq == 0:
                 C = Lp + "crossattention."
                 qc = ops.gemm_nt(h1, st.bf16_view(C + "attention.query.weight"), bias=f32(C + "attention.query.bias"))
                 kvc = ops.gemm_nt(enc2d, self._fused(C + "attention.key.weight", 2 * d, self.d_enc),
                                   bias=self._fused(C + "attention.key.bias", 1, 2 * d, master=True).view(-1))
-                vtc = ops.head_rope_transpose(kvc, d, B, Tk, H, 64)
-                ktc = ops.head_rope_transpose(kvc, 0, B, Tk, H, 64) if train else None
-                qtc = ops.head_rope_transpose(qc, 0, B, Q, H, 64) if train else None
                 adc = attn_drop()
-                c, lsec = ops.attn_fwd(qc, kvc[:, :d], vtc, B, Q, H, H, 64, False, scale, key_mask=km, want_lse=train, Tk=Tk, drop=adc)
+                c, lsec = ops.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, Q, H, H, 64, False, scale, key_mask=km, want_lse=train, Tk=Tk, drop=adc)
                 k2 = drop_key()
                 s2 = out_proj(c, C + "output.dense.weight", C + "output.dense.bias", h1, k2)
                 hx, mc, rc = ops.layernorm(s2, f32(C + "output.LayerNorm.weight"), f32(C + "output.LayerNorm.bias"), self.eps, stats=True)
-                rec["cross"] = dict(qc=qc, kvc=kvc, ktc=ktc, qtc=qtc, c=c, lse=lsec, s2=s2, mc=mc, rc=rc, hx=hx, k2=k2, ad=adc)
+                rec["cross"] = dict(qc=qc, kvc=kvc, c=c, lse=lsec, s2=s2, mc=mc, rc=rc, hx=hx, k2=k2, ad=adc)
             z = ops.gemm_nt(hx, st.bf16_view(Lp + "intermediate_query.dense.weight"), bias=f32(Lp + "intermediate_query.dense.bias"))
             f = ops.gelu_fwd(z)
             k3 = drop_key()
@@ -240,10 +234,10 @@ class HipProjectorQFormer(nn.Module):
                 C = Lp + "crossattention."
                 ds2 = ln_bwd(X["s2"], X["mc"], X["rc"], C + "output.LayerNorm", dhx)
                 dc = self._lin_bwd(undrop(ds2, X["k2"]), X["c"], C + "output.dense.weight", C + "output.dense.bias", d, d, acc, C + "output.dense.weight")
-                dct = ops.head_rope_transpose(dc, 0, B, Q, H, 64)
                 dqc = torch.empty_like(X["qc"])
                 dkvc = torch.empty_like(X["kvc"])
-                ops.attn_bwd(X["qc"], X["kvc"][:, :d], X["kvc"][:, d:], X["qtc"], X["ktc"], X["c"], dc, dct, X["lse"], dqc,
+                # (32 queries: the <= 64-query backward kernels read transposed copies of q / k / dO; ops.attn_bwd builds them)
+                ops.attn_bwd(X["qc"], X["kvc"][:, :d], X["kvc"][:, d:], X["c"], dc, X["lse"], dqc,
                              dkvc[:, :d], dkvc[:, d:], B, Q, H, H, 64, False, scale, key_mask=km, Tk=Tk, drop=X["ad"])
                 dh1 = self._lin_bwd(dqc, R["h1"], C + "attention.query.weight", C + "attention.query.bias", d, d, acc,
                                     C + "attention.query.weight")
@@ -258,10 +252,9 @@ class HipProjectorQFormer(nn.Module):
             A = Lp + "attention."
             ds1 = ln_bwd(R["s1"], R["m1"], R["r1"], A + "output.LayerNorm", dh1)
             da = self._lin_bwd(undrop(ds1, R["k1"]), R["a"], A + "output.dense.weight", A + "output.dense.bias", d, d, acc, A + "output.dense.weight")
-            dat = ops.head_rope_transpose(da, 0, B, Q, H, 64)
             qkv = R["qkv"]
             dqkv = torch.empty_like(qkv)
-            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], R["qt"], R["kt"], R["a"], da, dat, R["lse"], dqkv[:, :d],
+            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], R["a"], da, R["lse"], dqkv[:, :d],
                          dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, Q, H, H, 64, False, scale, drop=R["ad"])
             dh = self._lin_bwd(dqkv, R["h"], A + "attention.query.weight", A + "attention.query.bias", 3 * d, d, acc,
                                A + "attention.qkv")

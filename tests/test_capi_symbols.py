@@ -46,7 +46,9 @@ def test_errors_are_reported_not_swallowed():
     with pytest.raises(lib.SlamHipError, match="multiple of 64"):
         lib.call("slam_gemm_bf16_nt", one, 40, one, 40, one, 8, 8, 8, 40, None, None, 0, 0, 0, 1.0, 0, 0, None)
     with pytest.raises(lib.SlamHipError, match="head_dim"):
-        lib.call("slam_attn_fwd", one, 64, one, 64, one, one, 64, None, None, 1, 8, 8, 64, 64, 1, 1, 32, 0, 1.0, None, None, None, None, 0, 0, 0.0, 0, None)
+        lib.call("slam_attn_fwd", one, 64, one, 64, None, one, 64, one, 64, None, None, 1, 8, 8, 64, 64, 1, 1, 32, 0, 1.0, None, None, None, None, 0, 0, 0.0, 0, None)
+    with pytest.raises(lib.SlamHipError, match="Vt must be given"):      # neither the row-major V nor its transposed copy
+        lib.call("slam_attn_fwd", one, 64, one, 64, None, None, 0, one, 64, None, None, 1, 8, 8, 64, 64, 1, 1, 64, 0, 1.0, None, None, None, None, 0, 0, 0.0, 0, None)
 
 
 def test_product_never_imports_the_oracle():

@@ -321,7 +321,7 @@ def test_attn_bwd_with_gated_relative_position_bias(dev, T, masked):
     d_gate = torch.zeros_like(gate_p)
     d_tab = torch.zeros_like(tab)
     for _ in range(2):
-        ops.attn_bwd(q2d, k2d, v2d, qt, kt, o2d, do2d, dot, lse, dq, dk, dv, B, T, H, H, D, False, scale, key_mask=km,
+        ops.attn_bwd(q2d, k2d, v2d, o2d, do2d, lse, dq, dk, dv, B, T, H, H, D, False, scale, key_mask=km,
                      relpos=(gate_p, tab, T, d_gate, d_tab))
     # fp32 reference
     qf = q2d.float().view(B, T, H, D).transpose(1, 2).detach().requires_grad_(True)
@@ -505,14 +505,24 @@ def _attn_ref(q, k, v, causal, kmask, scale):
     return (p @ vh).permute(0, 2, 1, 3)
 
 
-def _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed):
+@pytest.fixture(params=["tr", "copies"])
+def attn_form(request):
+    """the attention tests below run twice: on the shipped kernels (transposed MFMA operands by ds_read_b64_tr_b16 from the row-major
+    tiles: V is passed row-major, no [B,H,D,Tp] copy exists) and on the round-3 kernels (slam_attn_set_fwd_qf 40: V^T passed as a copy,
+    ops.attn_bwd builds Q^T / K^T / dO^T)"""
+    from slam_llm_amd.lib import call
+    call("slam_attn_set_fwd_qf", 41 if request.param == "tr" else 40)
+    yield request.param
+    call("slam_attn_set_fwd_qf", 41)
+
+
+def _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed, form="tr"):
+    """-> qkv, q2, k2, v2, Tp, v_arg: v_arg is what attn_fwd gets for V (row-major view | transposed copy)"""
     ld = (Hq + 2 * Hkv) * D
     qkv = rnd((B * T, ld), dev, seed=seed, std=1.0)
-    qt = ops.head_rope_transpose(qkv, 0, B, T, Hq, D)
-    kt = ops.head_rope_transpose(qkv, Hq * D, B, T, Hkv, D)
-    vt = ops.head_rope_transpose(qkv, (Hq + Hkv) * D, B, T, Hkv, D)
     q2, k2, v2 = qkv[:, : Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D], qkv[:, (Hq + Hkv) * D:]
-    return qkv, q2, k2, v2, qt, kt, vt
+    vt = ops.head_rope_transpose(qkv, (Hq + Hkv) * D, B, T, Hkv, D) if form == "copies" else None
+    return qkv, q2, k2, v2, ops.round_up(T, 64), (vt if form == "copies" else v2)
 
 
 @pytest.mark.parametrize("B,T,Hq,Hkv,D,causal,masked", [
@@ -522,10 +532,9 @@ def _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed):
     (2, 380, 4, 1, 128, True, True),      # Llama-3 head_dim, T of the C3 workload
     (1, 64, 2, 2, 128, True, False),
 ])
-def test_attention_fwd(dev, B, T, Hq, Hkv, D, causal, masked):
+def test_attention_fwd(dev, attn_form, B, T, Hq, Hkv, D, causal, masked):
     ops = _ops()
-    qkv, q2, k2, v2, qt, kt, vt = _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed=11)
-    Tp = vt.shape[-1]
+    qkv, q2, k2, v2, Tp, vt = _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed=11, form=attn_form)
     km = None
     km_ref = None
     if masked:
@@ -547,10 +556,9 @@ def test_attention_fwd(dev, B, T, Hq, Hkv, D, causal, masked):
     (2, 380, 4, 1, 128, True),
     (1, 70, 2, 2, 128, False),
 ])
-def test_attention_bwd(dev, B, T, Hq, Hkv, D, masked):
+def test_attention_bwd(dev, attn_form, B, T, Hq, Hkv, D, masked):
     ops = _ops()
-    qkv, q2, k2, v2, qt, kt, vt = _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed=12)
-    Tp = vt.shape[-1]
+    qkv, q2, k2, v2, Tp, vt = _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed=12, form=attn_form)
     km = None
     if masked:
         km = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
@@ -561,10 +569,9 @@ def test_attention_bwd(dev, B, T, Hq, Hkv, D, masked):
     do = rnd((B * T, Hq * D), dev, seed=13)
     if masked:
         do.view(B, T, Hq * D)[0, :9] = 0  # pad query rows never receive gradient (labels = -100, never attended)
-    dot = ops.head_rope_transpose(do, 0, B, T, Hq, D)
     dqkv = torch.zeros_like(qkv)
     dq2, dk2, dv2 = dqkv[:, : Hq * D], dqkv[:, Hq * D:(Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:]
-    ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, dq2, dk2, dv2, B, T, Hq, Hkv, D, True, scale, key_mask=km)
+    ops.attn_bwd(q2, k2, v2, o, do, lse, dq2, dk2, dv2, B, T, Hq, Hkv, D, True, scale, key_mask=km)
     qf = q2.float().view(B, T, Hq, D).clone().requires_grad_(True)
     kf = k2.float().view(B, T, Hkv, D).clone().requires_grad_(True)
     vf = v2.float().view(B, T, Hkv, D).clone().requires_grad_(True)
@@ -580,7 +587,7 @@ def test_attention_bwd(dev, B, T, Hq, Hkv, D, masked):
     from slam_llm_amd.host_tables import rope_tables
     cos, sin = (t.to(dev) for t in rope_tables(T, D, 10000.0))
     fused = torch.zeros_like(qkv)
-    ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, fused[:, : Hq * D], fused[:, Hq * D:(Hq + Hkv) * D],
+    ops.attn_bwd(q2, k2, v2, o, do, lse, fused[:, : Hq * D], fused[:, Hq * D:(Hq + Hkv) * D],
                  fused[:, (Hq + Hkv) * D:], B, T, Hq, Hkv, D, True, scale, key_mask=km, rope=(cos, sin))
     ops.head_rope_transpose(dqkv, 0, B, T, Hq, D, cos=cos, sin=sin, inverse=True, want_t=False)
     ops.head_rope_transpose(dqkv, Hq * D, B, T, Hkv, D, cos=cos, sin=sin, inverse=True, want_t=False)
@@ -589,14 +596,13 @@ def test_attention_bwd(dev, B, T, Hq, Hkv, D, masked):
 
 
 @pytest.mark.parametrize("B,T,Hq,Hkv,D", [(2, 380, 8, 2, 128), (1, 200, 4, 1, 64), (2, 130, 4, 4, 64), (1, 97, 2, 1, 128)])
-def test_attention_bwd_dq_forms_agree(dev, B, T, Hq, Hkv, D):
+def test_attention_bwd_dq_forms_agree(dev, attn_form, B, T, Hq, Hkv, D):
     """the dQ launch forms (DMA ring, register-staged tiles with 32 / 16 queries per wave) are the same arithmetic in the
     same order: their dQ must agree to rounding noise, with left padding and RoPE"""
     ops = _ops()
     from slam_llm_amd.lib import call
     from slam_llm_amd.host_tables import rope_tables
-    qkv, q2, k2, v2, qt, kt, vt = _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed=31)
-    Tp = vt.shape[-1]
+    qkv, q2, k2, v2, Tp, vt = _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed=31, form=attn_form)
     km = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
     km[:, :T] = 1
     km[0, :5] = 0
@@ -605,13 +611,12 @@ def test_attention_bwd_dq_forms_agree(dev, B, T, Hq, Hkv, D):
     o, lse = ops.attn_fwd(q2, k2, vt, B, T, Hq, Hkv, D, True, scale, key_mask=km)
     do = rnd((B * T, Hq * D), dev, seed=32)
     do.view(B, T, Hq * D)[0, :5] = 0
-    dot = ops.head_rope_transpose(do, 0, B, T, Hq, D)
     outs = {}
     try:
         for v in (0, 2, 1):
             call("slam_attn_set_bwd_variant", v)
             g = torch.zeros_like(qkv)
-            ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, g[:, : Hq * D], g[:, Hq * D:(Hq + Hkv) * D], g[:, (Hq + Hkv) * D:],
+            ops.attn_bwd(q2, k2, v2, o, do, lse, g[:, : Hq * D], g[:, Hq * D:(Hq + Hkv) * D], g[:, (Hq + Hkv) * D:],
                          B, T, Hq, Hkv, D, True, scale, key_mask=km, rope=(cos, sin))
             outs[v] = g[:, : Hq * D].float()
     finally:
@@ -625,14 +630,14 @@ def test_attention_bwd_dq_forms_agree(dev, B, T, Hq, Hkv, D):
 
 
 @pytest.mark.parametrize("lens,Hq,Hkv,D", [((70, 133, 37), 4, 2, 128), ((5, 64, 1, 200, 63), 2, 2, 64), ((380, 380), 4, 1, 128)])
-def test_packed_sequences_attention_equals_per_sequence(dev, lens, Hq, Hkv, D):
+def test_packed_sequences_attention_equals_per_sequence(dev, attn_form, lens, Hq, Hkv, D):
     """packed ("varlen") causal attention: sequences concatenated along T with seg_lo / seg_hi == attention run on every
     sequence alone (torch fp32 reference + autograd), forward and all three gradients, incl. the fused RoPE backward
     with explicit per-token positions"""
     ops = _ops()
     from slam_llm_amd.host_tables import rope_tables
     T = sum(lens)
-    qkv, q2, k2, v2, qt, kt, vt = _prep_attn(ops, dev, 1, T, Hq, Hkv, D, seed=17)
+    qkv, q2, k2, v2, _, vt = _prep_attn(ops, dev, 1, T, Hq, Hkv, D, seed=17, form=attn_form)
     starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
     lo = torch.tensor(np.repeat(starts, lens), dtype=torch.int32, device=dev)
     hi = torch.tensor(np.repeat(starts + np.array(lens), lens), dtype=torch.int32, device=dev)
@@ -640,9 +645,8 @@ def test_packed_sequences_attention_equals_per_sequence(dev, lens, Hq, Hkv, D):
     scale = D ** -0.5
     o, lse = ops.attn_fwd(q2, k2, vt, 1, T, Hq, Hkv, D, True, scale, seg=(lo, hi))
     do = rnd((T, Hq * D), dev, seed=18)
-    dot = ops.head_rope_transpose(do, 0, 1, T, Hq, D)
     dqkv = torch.zeros_like(qkv)
-    ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, dqkv[:, : Hq * D], dqkv[:, Hq * D:(Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:],
+    ops.attn_bwd(q2, k2, v2, o, do, lse, dqkv[:, : Hq * D], dqkv[:, Hq * D:(Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:],
                  1, T, Hq, Hkv, D, True, scale, seg=(lo, hi))
     ref_o = torch.empty(T, Hq, D, device=dev)
     ref_g = [torch.empty(T, Hq, D, device=dev), torch.empty(T, Hkv, D, device=dev), torch.empty(T, Hkv, D, device=dev)]
@@ -664,24 +668,22 @@ def test_packed_sequences_attention_equals_per_sequence(dev, lens, Hq, Hkv, D):
     # fused RoPE backward with per-token positions == separate inverse rotation with the same positions
     cos, sin = (t.to(dev) for t in rope_tables(max(lens), D, 10000.0))
     fused = torch.zeros_like(qkv)
-    ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, fused[:, : Hq * D], fused[:, Hq * D:(Hq + Hkv) * D], fused[:, (Hq + Hkv) * D:],
+    ops.attn_bwd(q2, k2, v2, o, do, lse, fused[:, : Hq * D], fused[:, Hq * D:(Hq + Hkv) * D], fused[:, (Hq + Hkv) * D:],
                  1, T, Hq, Hkv, D, True, scale, rope=(cos, sin, pos), seg=(lo, hi))
     ops.head_rope_transpose(dqkv, 0, 1, T, Hq, D, cos=cos, sin=sin, inverse=True, want_t=False, positions=pos)
     ops.head_rope_transpose(dqkv, Hq * D, 1, T, Hkv, D, cos=cos, sin=sin, inverse=True, want_t=False, positions=pos)
     assert_close(fused, dqkv.float(), atol=2e-2 * float(dqkv.float().abs().max()), rtol=2e-2, what="packed fused rope grad")
 
 
-def test_cross_attention_fwd_bwd(dev):
+def test_cross_attention_fwd_bwd(dev, attn_form):
     """Tq != Tk (Q-Former cross-attention: 32 queries over 150 encoder frames, key padding mask), D = 64"""
     ops = _ops()
     B, Tq, Tk, H, D = 2, 32, 150, 3, 64
     q2 = rnd((B * Tq, H * D), dev, seed=21)
     kv = rnd((B * Tk, 2 * H * D), dev, seed=22)
     k2, v2 = kv[:, : H * D], kv[:, H * D:]
-    qt = ops.head_rope_transpose(q2, 0, B, Tq, H, D)
-    kt = ops.head_rope_transpose(kv, 0, B, Tk, H, D)
-    vt = ops.head_rope_transpose(kv, H * D, B, Tk, H, D)
-    km = torch.zeros((B, vt.shape[-1]), dtype=torch.uint8, device=dev)
+    vt = ops.head_rope_transpose(kv, H * D, B, Tk, H, D) if attn_form == "copies" else v2
+    km = torch.zeros((B, ops.round_up(Tk, 64)), dtype=torch.uint8, device=dev)
     km[0, :Tk] = 1
     km[1, :100] = 1
     scale = D ** -0.5
@@ -694,10 +696,9 @@ def test_cross_attention_fwd_bwd(dev):
     ref = (torch.softmax(s, -1) @ vf.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
     assert_close(o.view(B, Tq, H, D), ref.detach(), atol=2e-2, rtol=2e-2, what="cross attn fwd")
     do = rnd((B * Tq, H * D), dev, seed=23)
-    dot = ops.head_rope_transpose(do, 0, B, Tq, H, D)
     dq2 = torch.zeros_like(q2)
     dkv = torch.zeros_like(kv)
-    ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, dq2, dkv[:, : H * D], dkv[:, H * D:], B, Tq, H, H, D, False, scale,
+    ops.attn_bwd(q2, k2, v2, o, do, lse, dq2, dkv[:, : H * D], dkv[:, H * D:], B, Tq, H, H, D, False, scale,
                  key_mask=km, Tk=Tk)
     ref.backward(do.float().view(B, Tq, H, D))
     for nme, got, r in (("dq", dq2, qf.grad), ("dk", dkv[:, : H * D], kf.grad), ("dv", dkv[:, H * D:], vf.grad)):
@@ -708,13 +709,13 @@ def test_cross_attention_fwd_bwd(dev):
 
 
 @pytest.mark.parametrize("lens,H,D", [((70, 133, 37), 4, 64), ((5, 64, 1, 200, 63), 2, 64), ((1500, 431, 1500), 2, 64), ((130, 70), 2, 128)])
-def test_packed_bidirectional_attention_equals_per_clip(dev, lens, H, D):
+def test_packed_bidirectional_attention_equals_per_clip(dev, attn_form, lens, H, D):
     """the ragged encoder's attention: clips concatenated along T (B = 1), query q sees keys seg_lo[q] <= k < seg_hi[q] and
     nothing else == bidirectional attention run on every clip alone (fp32 torch reference).  Covers clips shorter than one
     64-key tile, boundaries in the middle of tiles and of 16-row fragments, and full 1500-frame clips."""
     ops = _ops()
     T = sum(lens)
-    qkv, q2, k2, v2, qt, kt, vt = _prep_attn(ops, dev, 1, T, H, H, D, seed=31)
+    qkv, q2, k2, v2, _, vt = _prep_attn(ops, dev, 1, T, H, H, D, seed=31, form=attn_form)
     starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
     lo = torch.tensor(np.repeat(starts, lens), dtype=torch.int32, device=dev)
     hi = torch.tensor(np.repeat(starts + np.array(lens), lens), dtype=torch.int32, device=dev)
@@ -1338,7 +1339,7 @@ def test_attention_probability_dropout_fwd_bwd(dev, B, Tq, Tk, H, masked):
                           drop=(pdrop, seed))
     dq = torch.empty_like(qd)
     dkv = torch.empty_like(kvd)
-    ops.attn_bwd(qd, kvd[:, : H * D], kvd[:, H * D:], qt, kt, o, dod, dot, lse, dq, dkv[:, : H * D], dkv[:, H * D:], B, Tq, H, H, D,
+    ops.attn_bwd(qd, kvd[:, : H * D], kvd[:, H * D:], o, dod, lse, dq, dkv[:, : H * D], dkv[:, H * D:], B, Tq, H, H, D,
                  False, scale, key_mask=km.to(dev) if masked else None, Tk=Tk, drop=(pdrop, seed))
     keep = torch.from_numpy(G.attn_keep_mask(seed, pdrop, B, H, Tq, Tk, Tqp, Tkp))
     assert abs(float(keep.mean()) - (1 - pdrop)) < 0.03

@@ -31,7 +31,7 @@ dqkv = torch.empty_like(qkv)
 WHICH = sys.argv[1] if len(sys.argv) > 1 else "dq"   # dq | dkdv
 call("slam_attn_set_bwd_variant", 14 if WHICH == "dq" else 19)
 for _ in range(5):
-    ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, dqkv[:, : Hq * D], dqkv[:, Hq * D:(Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:],
+    ops.attn_bwd(q2, k2, v2, o, do, lse, dqkv[:, : Hq * D], dqkv[:, Hq * D:(Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:],
                  B, T, Hq, Hkv, D, True, scale, key_mask=km)
 torch.cuda.synchronize()
 call("slam_attn_set_bwd_variant", 0)

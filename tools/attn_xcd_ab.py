@@ -46,7 +46,7 @@ def llama():
         ops.attn_fwd(q2, k2, vt, B, T, Hq, Hkv, D, True, scale, key_mask=km, out=o)
 
     def bwd():
-        ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, dqkv[:, : Hq * D], dqkv[:, Hq * D:(Hq + Hkv) * D],
+        ops.attn_bwd(q2, k2, v2, o, do, lse, dqkv[:, : Hq * D], dqkv[:, Hq * D:(Hq + Hkv) * D],
                      dqkv[:, (Hq + Hkv) * D:], B, T, Hq, Hkv, D, True, scale, key_mask=km, rope=(cos, sin))
     return {"llama_fwd": fwd, "llama_bwd(dq+dkdv)": bwd}
 

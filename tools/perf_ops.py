@@ -67,7 +67,7 @@ def attn_cases():
             dot = ops.head_rope_transpose(do, 0, B, T, Hq, D)
             dqkv = torch.empty_like(qkv)
             dq2, dk2, dv2 = dqkv[:, :Hq * D], dqkv[:, Hq * D:(Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:]
-            t = timeit(lambda: ops.attn_bwd(q2, k2, v2, qt, kt, o, do, dot, lse, dq2, dk2, dv2, B, T, Hq, Hkv, D, causal, scale))
+            t = timeit(lambda: ops.attn_bwd(q2, k2, v2, o, do, lse, dq2, dk2, dv2, B, T, Hq, Hkv, D, causal, scale))
             res.append({"op": "attn_bwd", "B": B, "T": T, "ms": t * 1e3, "TF": 2.5 * fl / t / 1e12})
             print(res[-1], flush=True)
 
