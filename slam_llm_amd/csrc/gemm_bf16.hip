@@ -39,6 +39,9 @@ std::atomic<int64_t> g_gemm_ws_bytes{0};
 // part of the last round saves on every product of the C3 / C2 / C4 steps, profiles/r03_gemm_splitk.md), 0 auto plan, >= 2 forced
 // number of K slices (tools / tests)
 std::atomic<int> g_gemm_splitk{-1};
+// Round 4: K-sliced launch + reduce launch for MID-M products (fewer 256 x 256 tiles than half the CUs: M = 672 of C4, the small-batch
+// recipes): 1 = the auto rule may pick it (DEFAULT), 0 = never, 2 = forced plans (302..316) take the two-launch form as well (sweeps)
+std::atomic<int> g_gemm_sk2{1};
 std::atomic<int> g_gemm_splitk_rmax{32};   // auto plan: split only when the last round holds <= rmax tiles ...
 std::atomic<int> g_gemm_splitk_smax{2};    // ... into at most smax slices (slam_gemm_set_config 320 + rmax / 8, 340 + smax: sweeps)
 
@@ -946,7 +949,9 @@ __device__ __forceinline__ void w4_vmwait() {
 // in phase B, after the barrier that releases the stage: two cheap instructions per KiB and 64 staging VGPRs.
 // SK: the instantiation that carries the split-K tail (launched only when a split plan is active: the plain instantiation stays
 // byte-for-byte the kernel the headline number is quoted on -- the tail code costs it registers and a few spilled loop invariants)
-template <int BM, int BN, bool REG, int ABL = 0, bool PROBE = false, bool SK = false>   // ABL (tools, wrong results): 1 no operand traffic in the loop, 2 no fragment reads, 3 neither; PROBE (tools): workgroup 0 stamps g_clk_probe
+// SK: 0 = whole tiles only, 1 = in-launch split-K tail (ticket + last arriver; round 3), 2 = two-launch form (round 4): the slices only
+// write their slabs -- no fence, no ticket, no fix-up code in this instantiation -- and gemm_sk_reduce_kernel adds them up
+template <int BM, int BN, bool REG, int ABL = 0, bool PROBE = false, int SK = 0>   // ABL (tools, wrong results): 1 no operand traffic in the loop, 2 no fragment reads, 3 neither; PROBE (tools): workgroup 0 stamps g_clk_probe
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned bytes_a, unsigned bytes_b) {
   if (PROBE && blockIdx.x == 0 && threadIdx.x == 0) {
     g_clk_probe[0] = __builtin_readcyclecounter();
@@ -1214,6 +1219,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
           *reinterpret_cast<f32x4_t*>(slab + ((size_t)((quad * 16 + i * 4 + j) * 256 + tid) << 2)) = a[i][j];
     };
     put(acc00, 0); put(acc01, 1); put(acc10, 2); put(acc11, 3);
+    if constexpr (SK == 2) return;   // two-launch form: the kernel boundary publishes the slabs, gemm_sk_reduce_kernel adds them up
     // producer side of the hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): every wave drains its stores, workgroup
     // barrier, ONE lane writes the XCD's L2 back (agent-scope release), asm vmcnt(0) (the compiler may drop the one the fence
     // implies), then the relaxed agent-scope ticket.  (Write-through `sc0 sc1` slab stores without the release were tried and
@@ -1275,7 +1281,166 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
   if (PROBE && blockIdx.x == 0 && threadIdx.x == 0) g_clk_probe[5] = __builtin_readcyclecounter();
 }
 
-template <int BM, int BN, bool REG, int ABL, bool PROBE, bool SK>
+// ------------------------------------------------------------------------------------------------------------
+// Second launch of the two-launch split-K form (round 4): tail tile t = blockIdx.x / 4, quadrant blockIdx.x % 4 of the 4-wave kernel's
+// 256 x 256 tile.  The slab layout is the kernel's own register layout (float4 number ((quadrant * 16 + i * 4 + j) * 256 + tid)), so
+// thread tid adds up the SAME accumulators the kernel's thread tid held, slices in index order (bit-reproducible), and runs the
+// kernel's epilogue on them.  Why two launches: with every tile of an under-filled grid sliced (C4's M = 672 products: 48 tiles on 256
+// CUs) the in-launch form leaves the whole reduction to 48 last arrivers, ~9 us per 256 KiB slab each (672 x 4096 x 4096: 75 us
+// unsplit, 98 us with five slices); here 4 x R workgroups read the slabs at the chip's streaming rate behind one kernel boundary.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_sk_reduce_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, WTM = 128, WTN = 128;
+  const int t = blockIdx.x >> 2, quad = blockIdx.x & 3;
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid;
+  {   // tail tile t -> position in the tile order: entry sk_main / 8 + t / 8 of XCD (t % 8)'s run (as in gemm_nt_w4_kernel)
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = t & 7, idx = (p.sk_main >> 3) + (t >> 3);
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    bid = base + idx;
+  }
+  const int GM = p.group_m;
+  const int per_group = GM * p.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GM;
+  const int gsz = min(GM, p.tiles_m - first_m);
+  const int within = bid - group * per_group;
+  const int m0 = (first_m + within % gsz) * BM, n0 = (within / gsz) * BN;
+  if (p.M - m0 <= 16) return;   // thin tiles are never sliced: slice 0 computed and stored all of it
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, frow = lane & 15, fg = lane >> 4;
+  const float* slab0 = p.sk_ws + (size_t)t * p.sk_S * (size_t)(BM * BN);
+  f32x4_t acc[4][4];
+  for (int sl = 0; sl < p.sk_S; sl++) {
+    const float* sp = slab0 + (size_t)sl * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(sp + ((size_t)((quad * 16 + i * 4 + j) * 256 + tid) << 2));
+        acc[i][j] = sl == 0 ? v : acc[i][j] + v;
+      }
+  }
+  gemm_epilogue<4, 4, WTM, WTN>(p, acc, m0 + (quad >> 1) * 64, n0 + (quad & 1) * 64, wm, wn, frow, fg);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Tall-skinny products, N <= 64 (round 4): C[M, N] = A[M, K] . B[N, K]^T with K in the thousands -- the LoRA-extension columns of every
+// dX product (du = dy . (s B)^T over K = 6144 ... 22016 output features) and the adapters' first hop where lora_a_fwd does not apply.
+// One 128 x 64 tile column gave ceil(M / 128) workgroups walking ALL of K alone: 6 workgroups on 256 CUs at C4 (139 us, 8 TFLOP/s), 93 at
+// C3 (80 us) -- for a product whose only cost is streaming A once (145 MB at C3: 23 us at the HBM rate).
+// Here a workgroup is 64 rows x ONE K SLICE: 4 waves x 16 rows, operands straight from global memory into the MFMAs (A is read once, B
+// is 64 rows that live in L1 / L2: nothing to stage), eight k-steps of loads in flight per wave; S slices per row block so that the grid
+// is ~1000 workgroups whatever M is.  S = 1: the epilogue runs in place.  S > 1: fp32 partials [S][M][64] into the GEMM workspace, and
+// gemm_ts_reduce_kernel adds them in slice order (bit-reproducible) and runs the generic epilogue.
+// ------------------------------------------------------------------------------------------------------------
+struct TsPlan { int S, nk; float* ws; };
+
+__device__ __forceinline__ void ts_slice(int nk, int S, int sl, int& k0, int& k1) {
+  k0 = (int)((int64_t)sl * nk / S) * 32;
+  k1 = (int)((int64_t)(sl + 1) * nk / S) * 32;
+}
+
+__global__ __launch_bounds__(256) void gemm_ts_kernel(GemmParams p, TsPlan pl) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int m0 = blockIdx.x * 64, sl = blockIdx.y;
+  int k0, k1;
+  ts_slice(pl.nk, pl.S, sl, k0, k1);
+  const bf16_t* ap = p.A + (int64_t)min(m0 + wave * 16 + frow, p.M - 1) * p.lda + fg * 8;
+  const bf16_t* bp[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) bp[j] = p.B + (int64_t)min(j * 16 + frow, p.N - 1) * p.ldb + fg * 8;
+  f32x4_t acc[1][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) acc[0][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  constexpr int UN = 8;
+  int k = k0;
+  for (; k + 32 * UN <= k1; k += 32 * UN) {
+    bf16x8_t af[UN], bf[UN][4];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      af[u] = *reinterpret_cast<const bf16x8_t*>(ap + k + 32 * u);
+#pragma unroll
+      for (int j = 0; j < 4; j++) bf[u][j] = *reinterpret_cast<const bf16x8_t*>(bp[j] + k + 32 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[u][j], af[u], acc[0][j], 0, 0, 0);
+  }
+  for (; k < k1; k += 32) {
+    const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(ap + k);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(bp[j] + k), af, acc[0][j], 0, 0, 0);
+  }
+  if (pl.S == 1) {
+    gemm_epilogue_generic<1, 4, 16, 64>(p, acc, m0, 0, wave, 0, frow, fg);
+    return;
+  }
+  const int m = m0 + wave * 16 + frow;
+  if (m >= p.M) return;
+  float* wrow = pl.ws + ((size_t)sl * p.M + m) * 64;
+#pragma unroll
+  for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4_t*>(wrow + j * 16 + fg * 4) = acc[0][j];
+}
+
+__global__ __launch_bounds__(256) void gemm_ts_reduce_kernel(GemmParams p, TsPlan pl) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int m0 = blockIdx.x * 64;
+  const int m = m0 + wave * 16 + frow;
+  f32x4_t acc[1][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) acc[0][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (m < p.M) {
+    for (int sl = 0; sl < pl.S; sl++) {
+      const float* wrow = pl.ws + ((size_t)sl * p.M + m) * 64;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(wrow + j * 16 + fg * 4);
+        acc[0][j] = sl == 0 ? v : acc[0][j] + v;
+      }
+    }
+  }
+  gemm_epilogue_generic<1, 4, 16, 64>(p, acc, m0, 0, wave, 0, frow, fg);   // (all lanes: the 16-byte store path exchanges lane rows)
+}
+
+std::atomic<int> g_gemm_ts{1};   // 1 = N <= 64 products take the tall-skinny K-sliced kernel (DEFAULT), 0 = the 128 x 64 tile kernel (A/B)
+
+// -> true when launched
+static bool launch_gemm_ts(GemmParams& p, hipStream_t stream, int* rc) {
+  // (large M: the staged 128 x 64 tile kernel streams A in full 128-byte lines and wins -- 56 vs 96 us at 11780 x 64 x 6144; this
+  // kernel's fragment-shaped loads are 64-byte row segments.  It is the form for FEW rows and a long K: 102 -> 37 us at 672 x 64 x 12288)
+  if (!g_gemm_ts || p.N > 64 || p.M > 4096 || p.act == 3 || p.act == 4 || p.K < 256) return false;
+  const int rb = (p.M + 63) / 64;
+  const int nk = p.K / 32;
+  int S = 1024 / rb;
+  if (S > nk / 8) S = nk / 8;        // >= 8 k-steps (256 of K: one batch of loads in flight) per slice
+  if (S < 1) S = 1;
+  float* ws = nullptr;
+  if (S > 1) {
+    char* base = (char*)g_gemm_ws.load();
+    const int64_t need = SK_CNT_BYTES + (int64_t)S * p.M * 64 * 4;
+    if (base == nullptr || need > g_gemm_ws_bytes) S = 1;   // no scratch registered: one slice per row block (still 64-row workgroups)
+    else ws = reinterpret_cast<float*>(base + SK_CNT_BYTES);
+  }
+  TsPlan pl{S, nk, ws};
+  hipLaunchKernelGGL(gemm_ts_kernel, dim3((unsigned)rb, (unsigned)S), dim3(256), 0, stream, p, pl);
+  if (S > 1) hipLaunchKernelGGL(gemm_ts_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, p, pl);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    slam_set_error("slam_gemm_bf16_nt(tall-skinny): launch failed: %s", hipGetErrorString(e));
+    *rc = -2;
+  } else {
+    *rc = 0;
+  }
+  return true;
+}
+
+template <int BM, int BN, bool REG, int ABL, bool PROBE, int SK>
 int launch_gemm_w4_impl(GemmParams& p, int64_t nwg, hipStream_t stream) {
   constexpr int lds = 2 * (BM + BN) * ROWB;
   static std::atomic<bool> attr_set{false};   // (setting the attribute twice from two threads is harmless; the flag only saves the call)
@@ -1296,22 +1461,31 @@ int launch_gemm_w4_impl(GemmParams& p, int64_t nwg, hipStream_t stream) {
 }
 
 template <int BM, int BN, bool REG, int ABL = 0, bool PROBE = false>
-int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
+int launch_gemm_w4(GemmParams& p, hipStream_t stream, int want_two = 0) {   // want_two: slice count of the two-launch form picked by the auto rule (0 = none)
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
   // ---- split-K tail plan (see the kernel): R = tiles of the last, partial round; S slices each so that R * S <= one round ----
   p.sk_main = 0; p.sk_R = 0; p.sk_S = 1; p.sk_ws = nullptr; p.sk_cnt = nullptr;
-  const int mode = g_gemm_splitk;   // -1 off, 0 auto, >= 2 forced slice count (tools / tests)
+  bool two = false;
+  int mode = g_gemm_splitk;   // -1 off, 0 auto, >= 2 forced slice count (tools / tests)
+  if (want_two >= 2) mode = want_two;
   char* ws = (char*)g_gemm_ws.load();
   const int64_t ws_bytes = g_gemm_ws_bytes;
-  if (!PROBE && ABL == 0 && mode >= 0 && ws != nullptr && nwg < (1ll << 30)) {
+  if (!PROBE && ABL == 0 && (mode >= 0 || g_gemm_sk2) && ws != nullptr && nwg < (1ll << 30)) {
     const int n_cu = 256;
     const int nt = p.K / BK;
     const int R = (int)(nwg % n_cu);
     int S = 1;
+    bool few_over = false;
     if (mode >= 2) S = mode;
-    else if (R > 0 && R <= g_gemm_splitk_rmax && nwg >= n_cu) {
+    else if (mode < 0 && g_gemm_sk2 && R > 0 && R <= 8 && nwg > n_cu && nt >= 16 && p.act != 4) {
+      // a handful of tiles over a whole number of rounds (C4's gate|up product: 3 x 86 = 258 tiles on 256 CUs -- a second round for
+      // TWO tiles): those tiles run as 8 K slices each next to the last full round, two-launch form (167 -> 136 us)
+      S = nt / 8 < 8 ? nt / 8 : 8;
+      few_over = S >= 2;
+    }
+    else if (mode >= 0 && R > 0 && R <= g_gemm_splitk_rmax && nwg >= n_cu) {
       // auto: only a genuinely short last round (R <= rmax tiles), slices of >= 8 k-tiles, at most smax slabs to add up.  The
       // thresholds come from profiles/r03_gemm_splitk.md (tools/gemm_splitk_sweep.py on MI355X): the hand-off (slab stores,
       // L2 write-back, ticket, fix-up reads: ~35 us) has a fixed price that only a nearly empty last round pays back.
@@ -1326,12 +1500,21 @@ int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
       p.sk_cnt = reinterpret_cast<unsigned*>(ws);
       p.sk_ws = reinterpret_cast<float*>(ws + SK_CNT_BYTES);
       nwg = (int64_t)p.sk_main + (int64_t)Rt * S;
+      two = (want_two >= 2 || few_over || (g_gemm_sk2 == 2 && mode >= 2)) && p.act != 4;
     }
   }
   if constexpr (!PROBE && ABL == 0) {
-    if (p.sk_S > 1) return launch_gemm_w4_impl<BM, BN, REG, ABL, false, true>(p, nwg, stream);
+    if (p.sk_S > 1 && two) {
+      const int rc = launch_gemm_w4_impl<BM, BN, REG, ABL, false, 2>(p, nwg, stream);
+      if (rc == 0) {
+        hipLaunchKernelGGL(gemm_sk_reduce_kernel, dim3((unsigned)(4 * p.sk_R)), dim3(256), 0, stream, p);
+        SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(split-K reduce)");
+      }
+      return rc;
+    }
+    if (p.sk_S > 1) return launch_gemm_w4_impl<BM, BN, REG, ABL, false, 1>(p, nwg, stream);
   }
-  return launch_gemm_w4_impl<BM, BN, REG, ABL, PROBE, false>(p, nwg, stream);
+  return launch_gemm_w4_impl<BM, BN, REG, ABL, PROBE, 0>(p, nwg, stream);
 }
 
 // (A persistent form of this kernel -- one workgroup per CU, the branch-free tail fetching the NEXT output tile's first two
@@ -1445,6 +1628,8 @@ extern "C" int slam_gemm_set_workspace(void* workspace, int64_t bytes) {
 }
 
 extern "C" int slam_gemm_set_config(int cfg) {
+  if (cfg >= 360 && cfg <= 362) { g_gemm_sk2 = cfg - 360; return 0; }       // two-launch split-K for mid-M products: off / auto (default) / also for forced plans
+  if (cfg == 370 || cfg == 371) { g_gemm_ts = cfg - 370; return 0; }         // N <= 64 products: 128 x 64 tile kernel / tall-skinny K-sliced kernel (default)
   if (cfg >= 320 && cfg <= 336) { g_gemm_splitk_rmax = (cfg - 320) * 8; return 0; }   // auto plan: tail tiles <= 8 * (cfg - 320)
   if (cfg >= 340 && cfg <= 348) { g_gemm_splitk_smax = cfg - 340; return 0; }         // auto plan: at most cfg - 340 slices
   if (cfg >= 300 && cfg <= 316) {   // split-K tail of the 4-wave kernel: 300 = auto, 301 = off, 302..316 = forced slice count (tools / tests)
@@ -1497,9 +1682,14 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
   p.bias = bias; p.res = (const bf16_t*)residual; p.ldr = ldr; p.res_mod = (int)res_row_mod;
   p.act = act; p.alpha = alpha; p.out_f32 = (out_dtype == SLAM_F32); p.accumulate = accumulate;
   p.C2 = nullptr; p.ldc2 = 0;
+  int want_two = 0;
   p.group_m = g_gemm_group_m;
   hipStream_t s = (hipStream_t)stream;
   int cfg = g_gemm_cfg;
+  if ((cfg == 0 || cfg == 3) && N <= 64) {
+    int rc = 0;
+    if (launch_gemm_ts(p, s, &rc)) return rc;
+  }
   const int big = g_gemm_big, big_shortk = g_gemm_big_shortk;
   if (cfg == 0) {
     // auto (measured on MI355X, profiles/r01_perf_ops_first.json, tools/gemm_bench.py): the pipelined 256x256 tile
@@ -1519,6 +1709,21 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     // (N = 1280 with a residual epilogue, Whisper fc2: 1084 vs 1124 TF for the 8-wave pipelined kernel, tools/gemm_enc_bench.py)
     else if (t256 < t128) cfg = (K <= 2048) ? big_shortk : ((big == 12 && N < 2048) ? 6 : big);
     else cfg = g_gemm_small;
+    // mid-M (round 4): fewer 256 x 256 tiles than half the CUs and a K worth slicing -> the 4-wave kernel on K slices + the reduce
+    // launch.  Cost model in the same unit (one CU x one 128 x 128 x K tile, ~22 us at K = 4096): 1 / S of a big tile's 2.86, plus the
+    // slab stores, the launch boundary and the reduce pass (~20 us whatever K is) -- measured on the C4 shapes, tools/gemm_splitk_sweep.py
+    if (g_gemm_sk2 && tiles256 <= 128 && N >= 256 && K >= 2048 && g_gemm_ws.load() != nullptr &&
+        (uint64_t)M * (uint64_t)lda * 2ull < (1ull << 32) && (uint64_t)N * (uint64_t)ldb * 2ull < (1ull << 32)) {
+      const int nt = (int)(K / BK);
+      int S = (int)(256 / tiles256);
+      if (S > nt / 8) S = nt / 8;
+      if (S > 8) S = 8;
+      const double tsk = (4.0 / 1.4) / S + 4500.0 / (double)K;
+      if (S >= 2 && SK_CNT_BYTES + tiles256 * S * (int64_t)(256 * 256 * 4) <= g_gemm_ws_bytes && tsk < 0.95 * (t256 < t128 ? t256 : t128)) {
+        cfg = 12;
+        want_two = S;
+      }
+    }
   }
   switch (cfg) {
     case 1: return launch_gemm<128, 128, 2, 2>(p, s);
@@ -1540,7 +1745,7 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
       if (p.K < 2 * BK || (uint64_t)p.M * (uint64_t)p.lda * 2ull >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldb * 2ull >= (1ull << 32))
         return launch_gemm<256, 256, 2, 4, 1>(p, s);
       if (g_gemm_probe) return launch_gemm_w4<256, 256, false, 0, true>(p, s);
-      return launch_gemm_w4<256, 256, false>(p, s);
+      return launch_gemm_w4<256, 256, false>(p, s, want_two);
   }
   slam_set_error("slam_gemm_bf16_nt: bad config %d", cfg);
   return -1;

@@ -103,6 +103,7 @@ class TrainableStore:
         self.entries: List[Tuple[str, Tuple[int, ...], int]] = []
         self.size = 0
         self.flat = self.grad = self.flat_bf16 = None
+        self.pure_bf16, self.grad_lp = False, None
         self.params: Dict[str, nn.Parameter] = {}
 
     def reserve(self, name: str, shape) -> None:
@@ -134,7 +135,32 @@ class TrainableStore:
         return self.flat[off:off + n].view(shape)
 
     def refresh_bf16(self):
-        ops.cast_bf16(self.flat, self.flat_bf16)
+        if self.pure_bf16:      # the bf16 buffer IS the parameters: refresh their fp32 shadow (LayerNorm weights / biases are read in fp32)
+            self.flat.copy_(self.flat_bf16)
+        else:
+            ops.cast_bf16(self.flat, self.flat_bf16)
+
+    def to_pure_bf16(self):
+        """`model.to(torch.bfloat16)` of the reference's pure_bf16 route (src/slam_llm/pipeline/finetune.py:154-155): every trainable
+        parameter becomes a bf16 tensor -- a view of the flat bf16 buffer the kernels read anyway, so `torch.optim.AdamW(model.parameters())`
+        or AnyPrecisionAdamW (finetune.py:237-251) update the operands of the next forward in place; the fp32 buffer turns into their
+        up-cast shadow.  Gradients are handed out in bf16 (`.grad` dtype must match): the kernels still reduce in fp32, the flat fp32
+        gradient buffer is rounded once per backward into `grad_lp`."""
+        if self.pure_bf16:
+            return
+        with torch.no_grad():
+            ops.cast_bf16(self.flat, self.flat_bf16)
+            self.flat.copy_(self.flat_bf16)
+            self.grad_lp = torch.zeros(self.size, dtype=torch.bfloat16, device=self.device)
+            for name, (off, n, shape) in self.offsets.items():
+                prm = self.params[name]
+                prm.grad = None
+                prm.data = self.flat_bf16[off:off + n].view(shape)
+        self.pure_bf16 = True
+
+    def grad_lp_view(self, name):
+        off, n, shape = self.offsets[name]
+        return self.grad_lp[off:off + n].view(shape)
 
 
 # ======================================================================================== fused (LoRA) linear
@@ -2360,10 +2386,37 @@ class SlamHipModel(nn.Module):
         the dtype or the device of the trainable parameters (`model.to(torch.bfloat16)` of the pure_bf16 route,
         finetune.py:154-155; `.cpu()`) would silently detach them from the flat master buffer the kernels read."""
         probe = fn(torch.empty(0, dtype=torch.float32, device=self.device_))
-        if probe.dtype != torch.float32 or probe.device != self.device_:
-            raise RuntimeError(f"SlamHipModel lives on {self.device_} with fp32 trainable masters (bf16 compute copies are "
-                               f"internal); cannot convert to {probe.dtype} on {probe.device}")
+        if probe.device == self.device_ and probe.dtype == torch.bfloat16:
+            # the pure_bf16 route (finetune.py:154-155 `model.to(torch.bfloat16)`): bf16 masters, see TrainableStore.to_pure_bf16
+            self.store.to_pure_bf16()
+            self._round_frozen_fp32()
+            self._stale = True
+            return self
+        want = torch.bfloat16 if self.store.pure_bf16 else torch.float32
+        probe = fn(torch.empty(0, dtype=want, device=self.device_))
+        if probe.dtype != want or probe.device != self.device_:
+            raise RuntimeError(f"SlamHipModel lives on {self.device_} with {'bf16' if self.store.pure_bf16 else 'fp32'} trainable masters (`.to(torch.bfloat16)` "
+                               f"switches to bf16 masters once); cannot convert to {probe.dtype} on {probe.device}")
+        if self.store.pure_bf16:
+            return self     # (a no-op move: the parameters are views of the flat bf16 buffer and must stay that)
         return super()._apply(fn, *args, **kwargs)
+
+    @torch.no_grad()
+    def _round_frozen_fp32(self):
+        """the other half of `model.to(torch.bfloat16)`: in the reference EVERY parameter becomes bf16, the frozen ones included -- the
+        LayerNorm / RMSNorm weights and the biases this path keeps in fp32 (the kernels read them in fp32) take their bf16-representable
+        values (the frozen matrices are bf16 already)."""
+        flat = self.store.flat
+        lo, hi = flat.data_ptr(), flat.data_ptr() + 4 * flat.numel()
+
+        def rnd(t):
+            if isinstance(t, torch.Tensor) and t.dtype == torch.float32 and not (lo <= t.data_ptr() < hi):
+                t.copy_(t.to(torch.bfloat16))
+        for t in getattr(self.encoder, "w", {}).values():
+            rnd(t)
+        for L in self.llm.layers:
+            rnd(L.ln1); rnd(L.ln2)
+        rnd(self.llm.norm_w)
 
     # ---- forward -------------------------------------------------------------------------------------
     def forward(self, input_ids=None, attention_mask=None, labels=None, **kwargs):
@@ -2582,6 +2635,10 @@ class SlamHipModel(nn.Module):
             accumulate = False
         else:
             accumulate = any(p.grad is not None for p in st.params.values())
+            if accumulate and st.pure_bf16:
+                # bf16 masters: `.grad` is the bf16 buffer -- whatever the loop did to it since the last backward (unscale, clip, zero_)
+                # is what the next micro-step adds to, like autograd's bf16 accumulation in the reference
+                st.grad.copy_(st.grad_lp)
         for hk in self.grad_hooks:
             begin = getattr(hk, "on_backward_begin", None)
             if begin is not None:
@@ -2599,11 +2656,17 @@ class SlamHipModel(nn.Module):
         d_enc = self.encoder_projector.backward_hip(dproj, stash, accumulate)
         if self.train_encoder:
             self.encoder.backward_hip(d_enc, stash, accumulate)
+        if st.pure_bf16:       # gradients leave in the parameters' dtype: one rounding of the fp32 sums per backward
+            if as_autograd:
+                fresh = torch.empty_like(st.grad_lp)
+                ops.cast_bf16(st.grad, fresh)
+                return [fresh[off:off + n].view(shape) for (off, n, shape) in (st.offsets[name] for name in st.params)]
+            ops.cast_bf16(st.grad, st.grad_lp)
         if as_autograd:
             return [st.grad_view(name) for name in st.params]
         for name, p in st.params.items():
             if p.grad is None:
-                p.grad = st.grad_view(name)
+                p.grad = st.grad_lp_view(name) if st.pure_bf16 else st.grad_view(name)
         for hk in self.grad_hooks:
             hk.on_prefix(st.size) if hasattr(hk, "on_prefix") else hk(st.size)
         return ()
@@ -2704,6 +2767,9 @@ class SlamAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.model = model
         st = model.store
+        if st.pure_bf16 and type(self) is SlamAdamW:
+            raise NotImplementedError("SlamAdamW keeps fp32 masters; after model.to(torch.bfloat16) (pure_bf16 route) use torch.optim.AdamW(model.parameters()) "
+                                      "or SlamAnyPrecisionAdamW(model, pure_bf16=True) like the reference does (pipeline/finetune.py:237-251)")
         self.exp_avg = torch.zeros_like(st.flat)
         self.exp_avg_sq = torch.zeros_like(st.flat)
         self._step = 0
@@ -2713,6 +2779,11 @@ class SlamAdamW(torch.optim.Optimizer):
         autograd_params mode: autograd owns `.grad` (views of the last backward's buffer when it adopted them, other
         tensors after accumulation or under DDP's bucket views) -> gather whatever is not already in place."""
         st = self.model.store
+        if st.pure_bf16:      # bf16 masters: the loop's gradients are the bf16 buffer (what a bf16 model's autograd would hold)
+            lp = st.grad_lp.data_ptr()
+            if all(p.grad is not None and p.grad.data_ptr() == lp + 2 * st.offsets[n][0] for n, p in st.params.items()):
+                st.grad.copy_(st.grad_lp)
+                return st.grad
         base = st.grad.data_ptr()
         for name, p in st.params.items():
             g = p.grad
@@ -2771,8 +2842,8 @@ class SlamAnyPrecisionAdamW(SlamAdamW):
         self.exp_avg = torch.zeros_like(st.flat, dtype=torch.bfloat16)
         self.exp_avg_sq = torch.zeros_like(st.flat, dtype=torch.bfloat16)
         self.compensation = torch.zeros_like(st.flat, dtype=torch.bfloat16) if use_kahan_summation else None
-        self.pure_bf16 = bool(pure_bf16)
-        if self.pure_bf16:
+        self.pure_bf16 = bool(pure_bf16) or st.pure_bf16      # (after model.to(torch.bfloat16) the parameters ARE bf16)
+        if self.pure_bf16 and not st.pure_bf16:
             with torch.no_grad():
                 st.flat.copy_(st.flat.to(torch.bfloat16).float())
             model.mark_params_updated()

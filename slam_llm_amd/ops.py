@@ -81,7 +81,12 @@ _GEMM_WS = {}   # device index -> workspace tensor of the split-K tail (kept ali
 GEMM_WS_BYTES = 4096 + 512 * 256 * 256 * 4   # counters + 512 slabs of 256 KiB (the auto plans use <= 256; forced sweeps up to 512): 128 MiB of 288 GB
 
 
-_SPLITK_WANTED = False   # the split-K tail is off by default: no scratch buffer until a plan is switched on (gemm_set_config(300 | 302..316))
+# Round 4: the scratch buffer is registered at the first product of the process: the K-sliced forms for mid-M products (two-launch split-K
+# of the 4-wave kernel) and for N <= 64 products (tall-skinny kernel) are part of the auto rule.  SLAM_GEMM_SK2=0 / SLAM_GEMM_TS=0 switch
+# them off (A/B); the in-launch split-K TAIL of round 3 stays off by default (gemm_set_config(300 | 302..316)).
+_SPLITK_WANTED = True
+SK2_AUTO = os.environ.get("SLAM_GEMM_SK2", "1") != "0"
+TS_AUTO = os.environ.get("SLAM_GEMM_TS", "1") != "0"
 
 
 def _ensure_gemm_workspace(device: torch.device):
@@ -163,15 +168,21 @@ if os.environ.get("SLAM_GEMM_BIG_SHORTK"):
     _GEMM_BIG["shortk"] = int(os.environ["SLAM_GEMM_BIG_SHORTK"])
 
 
+if not SK2_AUTO:
+    call("slam_gemm_set_config", 360)
+if not TS_AUTO:
+    call("slam_gemm_set_config", 370)
 if os.environ.get("SLAM_GEMM_SPLITK"):       # sweeps: off | auto | <slices>
     _sk = os.environ["SLAM_GEMM_SPLITK"]
     call("slam_gemm_set_config", 301 if _sk == "off" else (300 if _sk == "auto" else 300 + int(_sk)))
-    _SPLITK_WANTED = _sk != "off"
+
 
 
 def gemm_kernel_name(M: int, N: int, K: int = 1 << 30) -> str:
     """which template instance slam_gemm_bf16_nt's auto rule launches for this shape (mirrors gemm_bf16.hip)"""
     cfg = _GEMM_CFG
+    if cfg in (0, 3) and N <= 64 and M <= 4096 and TS_AUTO and 256 <= K < (1 << 30):
+        return "gemm_ts_kernel"
     if cfg == 0:
         tiles256 = ((M + 255) // 256) * ((N + 255) // 256)
         tiles128 = ((M + 127) // 128) * ((N + 127) // 128)
@@ -179,6 +190,10 @@ def gemm_kernel_name(M: int, N: int, K: int = 1 << 30) -> str:
         t128 = ((tiles128 + 511) // 512) * 2.0
         big = 6 if (_GEMM_BIG["big"] == 12 and N < 2048) else _GEMM_BIG["big"]
         cfg = 3 if N <= 64 else ((_GEMM_BIG["shortk"] if K <= 2048 else big) if t256 < t128 else _GEMM_BIG["small"])
+        if N > 64 and SK2_AUTO and tiles256 <= 128 and N >= 256 and 2048 <= K < (1 << 30) and _GEMM_WS:      # mid-M: K-sliced 4-wave kernel + reduce launch
+            S = min(256 // tiles256, (K // 64) // 8, 8)
+            if S >= 2 and (4.0 / 1.4) / S + 4500.0 / K < 0.95 * min(t256, t128):
+                return f"gemm_nt_w4_kernel<256,256,false,0> split-K x{S} + reduce"
     return _GEMM_NAMES[cfg]
 
 
@@ -187,8 +202,11 @@ def gemm_set_config(cfg: int):
     for K > 2048 / K <= 2048 (sweeps)"""
     global _GEMM_CFG
     global _SPLITK_WANTED
-    if cfg == 300 or 302 <= cfg <= 316:
-        _SPLITK_WANTED = True
+    global SK2_AUTO, TS_AUTO
+    if 360 <= cfg <= 362:
+        SK2_AUTO = cfg != 360
+    if cfg in (370, 371):
+        TS_AUTO = cfg == 371
     if cfg in (601, 611):
         _GEMM_BIG["small"] = cfg - 600
     elif cfg >= 300:    # 300 / 301 / 302..316: split-K tail auto / off / forced slices; 400 / 401: cycle stamps off / on

@@ -203,3 +203,81 @@ def test_rccl_backend_runs_gradsync_and_ddp_at_world_1(dev):
     assert res["autograd_params_rel"] <= 1e-6 and res["ddp_rel_vs_plain"] <= 1e-6 and res["ddp_scaler_rel"] <= 1e-6, res
     assert p.exitcode == 0
     print("RCCL world-1:", res)
+
+
+# ------------------------------------------------------------------------------------------------ the pure_bf16 route (VERDICT r3 missing #3)
+def test_pure_bf16_route_model_to_bfloat16(dev):
+    """src/slam_llm/pipeline/finetune.py:154-155: `model.to(torch.bfloat16)` (enable_ddp + fsdp_config.pure_bf16), then the optimizer over
+    `model.parameters()` (:237-251: AnyPrecisionAdamW with bf16 states, or torch AdamW).  SlamHipModel accepts the call: the trainable
+    parameters become bf16 views of the flat buffer the kernels read; `.grad` arrives in bf16.
+    * the first step's gradients = the bf16 rounding of the gradients of an fp32-master model built from the bf16-rounded weights (the
+      kernels see identical operands): bit-exact;
+    * one SlamAnyPrecisionAdamW step on the bf16 parameters = the oracle's restatement of the reference class applied to the same bf16
+      tensors on the device (every rounding of its op sequence; <= 1 bf16 ulp on < 2 % of the elements, the fma contraction);
+    * torch.optim.AdamW(model.parameters()) -- bf16 parameters, bf16 gradients, bf16 states -- trains (3 steps, loss falls, parameters
+      stay views of the flat buffer, the next forward sees the update without any call)."""
+    from slam_llm_amd.model import SlamAdamW, SlamAnyPrecisionAdamW, SlamHipModel
+    cfg = dict(O.make_config(), lora_dropout=0.0)
+    W = O.init_weights(cfg, seed=42)
+    Wr = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() else v) for k, v in W.items()}
+    batches = _batches(cfg, dev)
+    ref = SlamHipModel(dict(cfg), dev).load_weights(Wr)          # fp32 masters holding bf16-representable values
+    ref.train()
+    out, _ = ref(**{k: v.clone() for k, v in batches[0].items()})
+    out.loss.backward()
+    g_ref = {n: p.grad.detach().clone() for n, p in ref.store.params.items()}
+
+    model = SlamHipModel(dict(cfg), dev).load_weights(W)
+    ret = model.to(torch.bfloat16)
+    assert ret is model and model.store.pure_bf16
+    base = model.store.flat_bf16.data_ptr()
+    for n, p in model.named_parameters():
+        assert p.dtype == torch.bfloat16 and base <= p.data_ptr() < base + 2 * model.store.size, n
+    assert model.cuda() is model and model.to(dev) is model              # the pipeline's device move stays a no-op
+    with pytest.raises(RuntimeError):
+        model.to(torch.float16)
+    with pytest.raises(NotImplementedError):
+        SlamAdamW(model)
+    model.train()
+    out1, _ = model(**{k: v.clone() for k, v in batches[0].items()})
+    out1.loss.backward()
+    assert float(out1.loss) == float(out.loss)
+    for n, p in model.store.params.items():
+        assert p.grad.dtype == torch.bfloat16
+        assert torch.equal(p.grad, g_ref[n].to(torch.bfloat16)), n
+    # one AnyPrecisionAdamW step (bf16 states) vs the oracle's op-by-op restatement on the same bf16 tensors
+    opt = SlamAnyPrecisionAdamW(model, lr=1e-3, weight_decay=0.01)
+    assert opt.pure_bf16
+    before = {n: p.detach().clone() for n, p in model.store.params.items()}
+    grads = {n: p.grad.detach().clone() for n, p in model.store.params.items()}
+    opt.step()
+    for n, p in model.store.params.items():
+        # the restatement executed with torch ops ON THE DEVICE (torch's CPU kernel rounds `alpha` of add_(bf16, alpha=) to bf16 first:
+        # tests/test_ops_gpu.py::test_anyprecision_adamw_matches_reference_class_fixture): equal up to one bf16 ulp on a handful of
+        # elements (fma contraction of a + alpha * b)
+        want = O.anyprecision_adamw_step(before[n].clone(), grads[n], {}, lr=1e-3, weight_decay=0.01)
+        d = ((p.detach().float().view(torch.int32) >> 16) - (want.float().view(torch.int32) >> 16)).abs()
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 0.02, (n, int(d.max()), float((d > 0).float().mean()))
+    opt.zero_grad()
+    # torch.optim.AdamW on the bf16 parameters: the reference's other branch
+    model2 = SlamHipModel(dict(cfg), dev).load_weights(W).to(torch.bfloat16)
+    model2.train()
+    topt = torch.optim.AdamW(model2.parameters(), lr=2e-3, weight_decay=0.0)
+    losses = []
+    for step in range(3):
+        o2, _ = model2(**{k: v.clone() for k, v in batches[0].items()})
+        o2.loss.backward()
+        topt.step()
+        topt.zero_grad()
+        losses.append(float(o2.loss.detach()))
+    assert losses[2] < losses[0] and all(torch.isfinite(torch.tensor(losses)))
+    for n, p in model2.named_parameters():
+        assert p.dtype == torch.bfloat16 and model2.store.flat_bf16.data_ptr() <= p.data_ptr() < model2.store.flat_bf16.data_ptr() + 2 * model2.store.size
+    # gradient accumulation in the parameters' dtype (two micro-steps: bf16 += like autograd's accumulation in a bf16 model)
+    o3, _ = model2(**{k: v.clone() for k, v in batches[1].items()})
+    o3.loss.backward()
+    g1 = {n: p.grad.detach().clone() for n, p in model2.store.params.items()}
+    o4, _ = model2(**{k: v.clone() for k, v in batches[1].items()})
+    o4.loss.backward()
+    for n, p in model2.store.params.items():
+        assert torch.allclose(p.grad.float(), 2 * g1[n].float(), rtol=2e-2, atol=1e-6), n

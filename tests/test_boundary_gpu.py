@@ -40,7 +40,8 @@ def test_model_factory_train_step_and_inference_batch(dev, tmp_path):
     assert cfg["lora_r"] == 8 and cfg["lora_targets"] == ("q_proj", "v_proj") and cfg["lora_dropout"] == 0.05   # asr_config.py:29-37
     model = model.cuda(0)                                                   # finetune.py:181 must be a no-op move
     with pytest.raises(RuntimeError, match="fp32 trainable masters"):
-        model.to(torch.bfloat16)                                            # the pure_bf16 route (finetune.py:154-155) is refused loudly
+        model.to(torch.float16)                                             # (fp16 masters are refused loudly; the pure_bf16 route --
+    #                                                                         model.to(torch.bfloat16), finetune.py:154-155 -- is accepted: tests/test_amp_rccl_gpu.py)
     model.train()
     audio = O.synth_audio(2, 1.0, seed=5)
     ob = O.synth_batch(cfg, audio, prompt_len=4, answer_lens=(3, 6), seed=6, left_pad=True, pad_to_30s=False)

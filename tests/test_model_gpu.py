@@ -412,7 +412,9 @@ def _unfrozen_wave_encoder_case(dev, which, ragged, base=False):
         assert "encoder.encoder.pos_conv.0.weight_v" in sd and not any("pos_conv_embed" in k for k in sd)
         again = SlamHipModel(dict(cfg, freeze_encoder=False), dev).load_weights({**{k: v for k, v in W.items() if not k.startswith("encoder.")},
                                                                                   **{k: v.detach().cpu() for k, v in sd.items() if k.startswith("encoder.")}})
-        assert torch.equal(again.store.flat, model.store.flat)
+        for k_, v_ in again.store.params.items():      # (the optimizer step above moved the adapters / projector too: W still holds their old values)
+            if k_.startswith("encoder."):
+                assert torch.equal(v_, model.store.params[k_]), k_
     out2, _ = model(**gb)
     assert bool(torch.isfinite(out2.loss))
 

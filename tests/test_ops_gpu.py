@@ -201,10 +201,13 @@ def test_gemm_swiglu_forward_is_refused_where_the_4_wave_kernel_does_not_run(dev
     (772, 512, 4096, 4, "f32acc"),          # thin 4-row tail tiles among the split tiles; fp32 accumulate epilogue
     (2048, 2048, 4096, 2, "none"),          # exactly 64 tiles, every one split in two
 ])
-def test_gemm_split_k_tail(dev, M, N, K, slices, epi):
-    """split-K tail of the 4-wave kernel (in-launch partial slabs + ticket + fixed-order fix-up): against the unsplit launch of the
-    same kernel (fp32 partial sums are re-associated: bf16 outputs may differ by one rounding on a few elements: <= 2^-7 relative,
-    < 2 % of the elements), against an fp32 matmul, and bit-reproducible from run to run."""
+@pytest.mark.parametrize("form", ["in-launch", "two-launch"])
+def test_gemm_split_k_tail(dev, M, N, K, slices, epi, form):
+    """split-K of the 4-wave kernel -- in-launch form (partial slabs + ticket + fixed-order fix-up by the last arriver; round 3) and
+    two-launch form (the slices only store their slabs, gemm_sk_reduce_kernel adds them in slice order and runs the epilogue; round 4,
+    what the auto rule picks for mid-M products) -- against the unsplit launch of the same kernel (fp32 partial sums are re-associated:
+    bf16 outputs may differ by one rounding on a few elements: <= 2^-7 relative, < 2 % of the elements), against an fp32 matmul, and
+    bit-reproducible from run to run."""
     ops = _ops()
     a, b = rnd((M, K), dev, seed=61), rnd((N, K), dev, seed=62, std=K ** -0.5)
     bias = torch.randn(N, device=dev) if epi in ("bias+res", "gelu") else None
@@ -218,8 +221,11 @@ def test_gemm_split_k_tail(dev, M, N, K, slices, epi):
         out = base.clone() if f32 else torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
         ops.gemm_nt(a, b, out=out, bias=bias, residual=res, act=act, accumulate=f32)
         return out
+    if form == "two-launch" and slices == 0:
+        pytest.skip("the two-launch form has no tail auto plan: its auto rule covers under-filled grids (test_gemm_mid_m_rule_*)")
     try:
         ops.gemm_set_config(12)
+        ops.gemm_set_config(362 if form == "two-launch" else 361)
         if slices == 0:   # the shipped auto plan is conservative (tail <= 32 tiles, 2 slices); exercise the general planner too
             ops.gemm_set_config(320 + 16)   # tails up to 128 tiles
             ops.gemm_set_config(340 + 8)    # up to 8 slices
@@ -230,6 +236,7 @@ def test_gemm_split_k_tail(dev, M, N, K, slices, epi):
         ops.gemm_set_config(320 + 4)
         ops.gemm_set_config(340 + 2)
         ops.gemm_set_config(301)    # shipped default: split-K tail off
+        ops.gemm_set_config(361)    # shipped default: two-launch form by the auto rule only
         ops.gemm_set_config(0)
     assert torch.equal(split1, split2), "split-K tail is not reproducible"
     assert bool(torch.isfinite(split1).all())
@@ -250,6 +257,79 @@ def test_gemm_split_k_tail(dev, M, N, K, slices, epi):
         assert float((split1 != plain).float().mean()) < 0.02
     if slices == 0:   # the auto plan must actually have split this shape: 272 tiles leave 16 for the last round
         assert (M, N) == (4352, 4096)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(672, 4096, 11008, "res"), (672, 4096, 4096, "none"), (380, 2048, 5632, "bias+res"), (1520, 4096, 14336, "f32acc"),
+                                       (100, 1024, 8192, "gelu")])
+def test_gemm_mid_m_rule_slices_k_and_matches_unsliced(dev, M, N, K, epi):
+    """AUTO rule, mid-M products (C4's M = 672, C1's M = 380, half a C2 batch: fewer 256 x 256 tiles than half the CUs): the rule picks
+    the 4-wave kernel on K slices + the reduce launch (ops.gemm_kernel_name says so); result vs the same product with the rule's
+    K-slicing off (one rounding of re-associated fp32 sums), vs fp32, and bit-reproducible."""
+    ops = _ops()
+    a, b = rnd((M, K), dev, seed=81), rnd((N, K), dev, seed=82, std=K ** -0.5)
+    bias = torch.randn(N, device=dev) if epi in ("bias+res", "gelu") else None
+    res = rnd((M, N), dev, seed=83) if epi in ("bias+res", "res") else None
+    act = ops.ACT_GELU if epi == "gelu" else ops.ACT_NONE
+    f32 = epi == "f32acc"
+    base = torch.randn(M, N, device=dev) if f32 else None
+
+    def run():
+        out = base.clone() if f32 else torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm_nt(a, b, out=out, bias=bias, residual=res, act=act, accumulate=f32)
+        return out
+    assert ops._GEMM_CFG == 0
+    run()      # (registers the scratch buffer on the first product of the process)
+    assert "split-K" in ops.gemm_kernel_name(M, N, K), ops.gemm_kernel_name(M, N, K)
+    s1, s2 = run(), run()
+    try:
+        ops.gemm_set_config(360)
+        assert "split-K" not in ops.gemm_kernel_name(M, N, K)
+        plain = run()
+    finally:
+        ops.gemm_set_config(361)
+    assert torch.equal(s1, s2) and bool(torch.isfinite(s1).all())
+    ref = a.float() @ b.float().t()
+    if bias is not None:
+        ref = ref + bias
+    if act == ops.ACT_GELU:
+        ref = F.gelu(ref)
+    if res is not None:
+        ref = ref + res.float()
+    if f32:
+        ref = ref + base
+    assert_close(s1, ref, atol=2e-2, rtol=2e-2, what="K-sliced vs fp32")
+    assert_close(s1, plain, atol=1e-3 if f32 else 2 ** -5, rtol=2 ** -7, what="K-sliced vs unsliced")
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(672, 64, 12288, "bf16"), (380, 16, 2560, "bf16"), (3040, 64, 6144, "f32acc"), (70, 32, 512, "bias"), (4096, 64, 4096, "bf16")])
+def test_gemm_tall_skinny_k_sliced(dev, M, N, K, mode):
+    """N <= 64, M <= 4096 (the LoRA-extension columns of the dX products at the small-batch recipes, first hops with r not a multiple of
+    4): 64-row x K-slice workgroups + fixed-order reduce, vs the 128 x 64 tile kernel (gemm_set_config 370) and fp32; bit-reproducible."""
+    ops = _ops()
+    a, b = rnd((M, K), dev, seed=91), rnd((N, K), dev, seed=92, std=K ** -0.5)
+    bias = torch.randn(N, device=dev) if mode == "bias" else None
+    f32 = mode == "f32acc"
+    base = torch.randn(M, N, device=dev) if f32 else None
+
+    def run():
+        out = base.clone() if f32 else torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.gemm_nt(a, b, out=out, bias=bias, accumulate=f32, alpha=0.5 if f32 else 1.0)
+        return out
+    assert ops.gemm_kernel_name(M, N, K) == "gemm_ts_kernel"
+    t1, t2 = run(), run()
+    try:
+        ops.gemm_set_config(370)
+        tile = run()
+    finally:
+        ops.gemm_set_config(371)
+    assert torch.equal(t1, t2) and bool(torch.isfinite(t1).all())
+    ref = (0.5 if f32 else 1.0) * (a.float() @ b.float().t())
+    if bias is not None:
+        ref = ref + bias
+    if f32:
+        ref = ref + base
+    assert_close(t1, ref, atol=2e-2, rtol=2e-2, what="tall-skinny vs fp32")
+    assert_close(t1, tile, atol=1e-3 if f32 else 2 ** -5, rtol=2 ** -7, what="tall-skinny vs tile kernel")
 
 
 def test_gemm_swiglu_forward_with_split_k_tail(dev):

@@ -19,7 +19,8 @@ SHAPES = {
     # C2 (8 x 380 = 3040 rows)
     "c2": [(3040, 6144, 4160), (3040, 4096, 4096), (3040, 28672, 4096), (3040, 4096, 14336), (3040, 14336, 4096), (3040, 128256, 4096)],
     # C4 (6 x 112 = 672 rows, Vicuna-7B MHA, r32 on q,v)
-    "c4": [(672, 12288, 4160), (672, 4096, 4096), (672, 22016, 4096), (672, 4096, 11008), (672, 11008, 4096), (672, 32000, 4096)],
+    "c4": [(672, 12288, 4160), (672, 4096, 4096), (672, 22016, 4096), (672, 4096, 11008), (672, 11008, 4096), (672, 32000, 4096),
+           (672, 4096, 12288), (672, 4096, 22016)],
 }
 
 
@@ -42,7 +43,7 @@ def main():
         c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         tiles = -(-M // 256) * -(-N // 256)
         modes = {"rule(cfg0,nosplit)": (0, 301), "w4_off": (12, 301), "w4_auto": (12, 300)}
-        for S in (2, 3, 4, 6, 8):
+        for S in (2, 3, 4, 5, 6, 8):
             if (K // 64) // S >= 4:
                 modes[f"w4_S{S}"] = (12, 300 + S)
         res = {k: [] for k in modes}
