@@ -252,6 +252,63 @@ def traffic_for(kernel_name):
     return None, table.get("source")
 
 
+def pmc_for(kernel_name):
+    """MFMA utilisation and effective clock of the dominant kernel from the committed PMC summary (profiles/pmc.json: rocprofv3 --pmc
+    SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE ... over tools/pmc_gemm.py; the counters cannot be read inside this process)."""
+    path = os.path.join(ROOT, "profiles", "pmc.json")
+    if not os.path.exists(path):
+        return None
+    table = json.load(open(path))
+    want = kernel_name.rstrip(">")
+    rows = {k: v for k, v in table.get("kernels", {}).items() if k.split(" @ ")[0].rstrip(">").startswith(want) or want.startswith(k.split(" @ ")[0].rstrip(">"))}
+    if not rows:
+        return None
+    return dict(source=table.get("source"), units=table.get("units"),
+                per_shape={k.split(" @ ")[-1]: dict(mfma_util=v["mfma_util"], effective_clock_GHz=v["effective_clock_GHz"], duration_us=v["duration_us"],
+                                                    wave_cycles_share=v["wave_cycles_share"], l2_hit_rate=v["l2_hit_rate"]) for k, v in rows.items()})
+
+
+def rank_seed(rank: int) -> int:
+    """every rank draws its own synthetic batch (weak scaling: per-GPU work fixed, data different)"""
+    return 1234 + rank
+
+
+def measure(step, steps: int, warmup: int, world: int, dist, sync, device, comm_ms_fn=None):
+    """The timed region of the contract, the same on every rank: W untimed steps, sync + barrier, EXACTLY K steps, sync + barrier; the
+    elapsed time and the exposed-communication time are the MAX over ranks (one all-reduce of two doubles).  `sync` = the device
+    synchronisation (torch.cuda.synchronize; a no-op for the CPU / gloo test of this logic), `comm_ms_fn` = this rank's mean exposed
+    communication per step (GradSync) or None.  Returns (last step's result, elapsed seconds, comm_exposed_ms | None)."""
+    import time as _time
+    import torch
+    res = None
+    for _ in range(warmup):
+        res = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = _time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    elapsed = _time.perf_counter() - t0
+    comm = comm_ms_fn() if comm_ms_fn is not None else None
+    if world > 1:
+        te = torch.tensor([elapsed, comm or 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te[0].item())
+        if comm is not None:
+            comm = float(te[1].item())
+    return res, elapsed, comm
+
+
+def throughput(world: int, n_clips: int, clip_s: float, steps: int, elapsed: float):
+    """WHOLE-JOB audio-seconds/sec over all ranks and ms per step"""
+    return world * n_clips * clip_s * steps / elapsed, elapsed / steps * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,43 +355,25 @@ def main():
     opt = SlamAdamW(model, lr=1e-4, weight_decay=0.0)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: lr_lambda(s, 1000, 100000))
     clip_s = wl.get("clip_seconds", CLIP_SECONDS)
-    batch, T, Ta = make_batch(cfg, n_clips, dev, seed=1234 + rank, clip_seconds=clip_s)
+    batch, T, Ta = make_batch(cfg, n_clips, dev, seed=rank_seed(rank), clip_seconds=clip_s)
 
     def step():
         return train_step(step_model, batch, opt, sched, gsync)
 
-    for _ in range(args.warmup):
-        loss, acc = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    # warm-up outside the kernel timer, then the timed region (measure(): barrier + synchronize on both sides, MAX over ranks)
+    measure(step, 0, args.warmup, world, dist, torch.cuda.synchronize, dev)
     ops.TIMER = ops.KernelTimer()
     if gsync is not None:
         gsync.time_finish = True    # HIP events around finish(): the part of the gradient exchange the backward did not hide
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, acc = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    (loss, acc), elapsed, comm_exposed_ms = measure(step, args.steps, 0, world, dist, torch.cuda.synchronize, dev,
+                                                    comm_ms_fn=(gsync.exposed_ms_per_step if gsync is not None else None))
     timer, ops.TIMER = ops.TIMER, None
-    comm_exposed_ms = gsync.exposed_ms_per_step() if gsync is not None else None
-    if world > 1:
-        te = torch.tensor([elapsed, comm_exposed_ms or 0.0], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te[0].item())
-        if comm_exposed_ms is not None:
-            comm_exposed_ms = float(te[1].item())
     if rank != 0:
         if world > 1:
             dist.barrier()
         return
 
-    ms_per_step = elapsed / args.steps * 1e3
-    audio_s = world * n_clips * clip_s
-    value = audio_s * args.steps / elapsed
+    value, ms_per_step = throughput(world, n_clips, clip_s, args.steps, elapsed)
     fl = algorithmic_flops_per_clip(cfg, T, Ta, 3000)
     step_flops = fl["total"] * n_clips
     # products the step does not execute for rows without a label (slam_llm_amd.model.LM_HEAD_LABEL_ROWS / LAST_LAYER_LABEL_ROWS): the
@@ -364,6 +403,14 @@ def main():
             "share_of_step": g["total_ms"] / args.steps / ms_per_step,
             "algorithmic_bytes_per_launch": g["bytes"] / g["launches"] if g.get("bytes") else None,
             "all_gemm_instances": {"achieved": gemm_tf_all, "share_of_step": gemm_ms / args.steps / ms_per_step}}
+    pmc = pmc_for(dom) if args.workload == "c3" else None
+    if pmc is not None:
+        # MFMA-busy cycles / (active cycles x 256 CUs x 4 SIMDs) of the dominant kernel, longest-running shape first; at the clock the
+        # chip sustained under that kernel (power-limited: 1.55-1.78 GHz of 2.4), the same kernel's TFLOP/s = mfma_util x 2.5 PF x clock / 2.4
+        big = max(pmc["per_shape"].values(), key=lambda v: v["duration_us"])
+        roof["mfma_util"] = big["mfma_util"]
+        roof["effective_clock_GHz"] = big["effective_clock_GHz"]
+        roof["pmc_detail"] = pmc
     if traffic is not None:
         hbm = traffic["fetch_bytes_per_launch"] + traffic["write_bytes_per_launch"]
         roof["traffic"] = hbm
@@ -392,6 +439,9 @@ def main():
                    # max over ranks of the mean HIP-event time of GradSync.finish() per step: tail bucket launch + waits on the compute stream
                    "comm_exposed_ms": comm_exposed_ms,
                    "grad_buffer_MB": model.store.grad.numel() * 4 / 1e6 if world > 1 else None,
+                   # whether the last decoder layer really ran behind its attention over the labelled rows only in this run (it does not
+                   # when LoRA dropout acts on o / gate / up / down of that layer)
+                   "last_layer_label_rows_active": bool(getattr(model.llm, "_last_pruned_rows", 0)),
                    "logits": ("lm_head / cross entropy over the labelled rows only (the rows with label -100 enter neither loss, accuracy nor any "
                               "gradient), last decoder layer behind its attention likewise; SLAM_LM_HEAD_LABEL_ROWS=0 computes every row"
                               if rows_skipped else "full [B*T, V] lm_head computed (chunked), not materialised in fp32")},

@@ -1587,8 +1587,10 @@ int launch_gemm_persist2(GemmParams& p, hipStream_t stream) {
 }
 
 // the descriptor form addresses every byte of a (row-padded) operand with 32 bits
-static inline bool fits_descriptor(int64_t rows, int64_t ld, int tile) {
-  return (uint64_t)(rows + tile) * (uint64_t)ld * 2ull < (1ull << 32);
+// (extent of a row view whose rows may OVERLAP -- lda < K, the conv window views: (rows - 1) * ld + K elements -- plus one tile of rows
+// past the end that the kernels address before the range check zeroes them)
+static inline bool fits_descriptor(int64_t rows, int64_t ld, int tile, int64_t K) {
+  return ((uint64_t)(rows + tile - 1) * (uint64_t)ld + (uint64_t)K) * 2ull < (1ull << 32);
 }
 
 // tuning state (tools / sweeps set it between launches; relaxed atomics: a launch reads each knob once, whole)
@@ -1713,7 +1715,7 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     // launch.  Cost model in the same unit (one CU x one 128 x 128 x K tile, ~22 us at K = 4096): 1 / S of a big tile's 2.86, plus the
     // slab stores, the launch boundary and the reduce pass (~20 us whatever K is) -- measured on the C4 shapes, tools/gemm_splitk_sweep.py
     if (g_gemm_sk2 && tiles256 <= 128 && N >= 256 && K >= 2048 && g_gemm_ws.load() != nullptr &&
-        (uint64_t)M * (uint64_t)lda * 2ull < (1ull << 32) && (uint64_t)N * (uint64_t)ldb * 2ull < (1ull << 32)) {
+        fits_descriptor(M, lda, 1, K) && fits_descriptor(N, ldb, 1, K)) {
       const int nt = (int)(K / BK);
       int S = (int)(256 / tiles256);
       if (S > nt / 8) S = nt / 8;
@@ -1737,12 +1739,12 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
       if (g_gemm_probe) return launch_gemm<256, 256, 2, 4, 1, true>(p, s);
       return launch_gemm<256, 256, 2, 4, 1>(p, s);
     case 7:                                                // persistent pipelined, descriptor DMA (auto: short-K products)
-      if (p.K < 2 * BK || !fits_descriptor(p.M, p.lda, 256) || !fits_descriptor(p.N, p.ldb, 256)) return launch_gemm<256, 256, 2, 4, 1>(p, s);
+      if (p.K < 2 * BK || !fits_descriptor(p.M, p.lda, 256, p.K) || !fits_descriptor(p.N, p.ldb, 256, p.K)) return launch_gemm<256, 256, 2, 4, 1>(p, s);
       return launch_gemm_persist2<256, 256, 2, 4>(p, s);
     // (cfg 5 = compiler-placed barrier, 8-11 = timing ablations of the pipelined loop, 13 = register-staged 4-wave form,
     //  14-16 = ablations of the 4-wave loop: measured, recorded in profiles/r02_gemm_experiments.md, removed to keep the build short)
     case 12:                                               // 4 waves, hand-ordered k-loop
-      if (p.K < 2 * BK || (uint64_t)p.M * (uint64_t)p.lda * 2ull >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldb * 2ull >= (1ull << 32))
+      if (p.K < 2 * BK || !fits_descriptor(p.M, p.lda, 1, p.K) || !fits_descriptor(p.N, p.ldb, 1, p.K))
         return launch_gemm<256, 256, 2, 4, 1>(p, s);
       if (g_gemm_probe) return launch_gemm_w4<256, 256, false, 0, true>(p, s);
       return launch_gemm_w4<256, 256, false>(p, s, want_two);

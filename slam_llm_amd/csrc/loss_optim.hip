@@ -23,8 +23,12 @@ __global__ __launch_bounds__(1024) void ce_targets_kernel(const int64_t* __restr
   for (int64_t r = threadIdx.x; r < M; r += 1024) {
     const int t = (int)(r % T);
     int64_t l = (t + 1 < T) ? labels[r + 1] : (int64_t)ignore_index;
-    if (l != ignore_index) cnt++;
-    tgt[r] = (l == ignore_index) ? -1 : (int32_t)l;
+    // a row carries a label iff its target is a class index: `ignore_index` and any other negative value (which torch's
+    // CrossEntropyLoss rejects with a device assert) both become -1 -- the count, the loss rows and the labelled-rows selection of
+    // the model (targets >= 0) are then the same predicate
+    const bool valid = l != ignore_index && l >= 0;
+    if (valid) cnt++;
+    tgt[r] = valid ? (int32_t)l : -1;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);

@@ -40,17 +40,20 @@ PRESET_ALIASES = {"xtralarge": "xlarge", "extralarge": "xlarge", "x-large": "xla
 
 
 def _guess_preset(name: str, table) -> str:
-    """architecture preset from a checkpoint name.  Only the BASENAME votes (a directory such as `/hubert-large-models/` must not
+    """architecture preset from a checkpoint name.  The BASENAME votes first (a directory such as `/hubert-large-models/` must not
     pick the geometry of `hubert_base_ls960.pt` inside it); the reference recipes' spellings are normalised first
     (`hubert_xtralarge_ll60k_finetune_ls960.pt`, examples/asr_librispeech/scripts/finetune_hubert_xtralarge_linear_vicuna_7b.sh)."""
-    import os as _os
-    n = _os.path.basename((name or "").rstrip("/")).lower().replace("_", "-")
-    for a, b in PRESET_ALIASES.items():
-        n = n.replace(a, b)
-    for k in sorted(table, key=len, reverse=True):
-        if k in n or k.replace("-", "") in n.replace("-", ""):
-            return k
-    raise ValueError(f"cannot map '{name}' to a known architecture preset {sorted(table)}; pass model_config.arch_*")
+    parts = [c for c in (name or "").replace("\\", "/").rstrip("/").split("/") if c]
+    # the basename votes first; a generic file name (`checkpoint_best.pt`, `model.safetensors` of an HF snapshot) falls back to its parent
+    # directories, nearest first (`/ckpt/hubert_large_ll60k/checkpoint_best.pt`)
+    for comp in reversed(parts or [""]):
+        n = comp.lower().replace("_", "-")
+        for a, b in PRESET_ALIASES.items():
+            n = n.replace(a, b)
+        for k in sorted(table, key=len, reverse=True):
+            if k in n or k.replace("-", "") in n.replace("-", ""):
+                return k
+    raise ValueError(f"cannot map '{name}' to a known architecture preset {sorted(table)}; pass model_config.arch_encoder / arch_llm explicitly")
 
 
 HUBERT_PRESETS = {

@@ -4,9 +4,10 @@ The k-loop of gemm_nt_w4_kernel, the tile loops of attn_fwd_kernel, attn_bwd_dkd
 MFMAs as `asm volatile` statements whose result registers are "ready" for the compiler at once.  If hipcc ever SPILLS such a
 register (stores it to scratch before the data has landed) the kernel computes garbage -- it happened once with three
 instantiations of the GEMM tile body (876 bytes of scratch, wrong results).  Zero scratch is therefore a build invariant of the
-attention kernels and the pipelined GEMM.  The 4-wave GEMM (512 registers, split-K tail + fused epilogues around its loop) is allowed
-to park loop-INVARIANT values in scratch outside its hand-ordered region: the invariant there is that no scratch STORE
-appears between the first inline-asm LDS read and the last inline-asm MFMA (prologue reads + the whole k-loop)."""
+attention kernels, the pipelined GEMM and the whole-tile instantiation (SK = 0) of the 4-wave GEMM.  Its split-K instantiations (512
+registers, slab / ticket code around the loop) are allowed to park loop-INVARIANT values in scratch outside the hand-ordered region: the
+invariant there is that no scratch STORE appears between the first inline-asm LDS read and the last inline-asm MFMA (prologue reads +
+the whole k-loop)."""
 import os
 import re
 import subprocess
@@ -21,7 +22,8 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # its tile loop: harmless, not part of the invariant)
 REGION_RULE = ("gemm_nt_w4_kernel",)   # kernels checked by region instead of by total scratch size
 FILES = {"gemm_bf16.hip": ([], ("gemm_nt_w4_kernel", "gemm_nt_pipe_kernel")),
-         "attention.hip": (["-mllvm", "-amdgpu-mfma-vgpr-form"], ("attn_fwd_kernel", "attn_bwd_dkdv_ring_kernel", "attn_bwd_dq_ring_kernel"))}
+         "attention.hip": (["-mllvm", "-amdgpu-mfma-vgpr-form"], ("attn_fwd_kernel", "attn_bwd_dkdv_ring_kernel", "attn_bwd_dq_ring_kernel",
+                                                                  "attn_bwd_dkdv_tr_kernel", "attn_bwd_dq_tr_kernel"))}
 
 
 def _scratch_by_kernel(src, extra):
@@ -34,9 +36,18 @@ def _scratch_by_kernel(src, extra):
     for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
         res[m.group(1)] = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
     for name in list(res):
-        if res[name] and any(r in name for r in REGION_RULE):
+        if res[name] and any(r in name for r in REGION_RULE) and _w4_split_k_form(name) != 0:
             res[name] = _scratch_in_asm_region(text, name)
     return res
+
+
+def _w4_split_k_form(mangled):
+    """last template argument (SK) of a gemm_nt_w4_kernel instantiation: 0 = the whole-tile kernel the headline number is quoted on --
+    it must not touch scratch AT ALL (a spilled asm result in its prologue / epilogue, outside the region rule, once produced wrong
+    results); 1 / 2 = the split-K instantiations, which park loop invariants in scratch outside the hand-ordered region"""
+    m = re.search(r"gemm_nt_w4_kernelILi\d+ELi\d+ELb[01]ELi\d+ELb[01]ELi(\d+)EE", mangled)
+    assert m, f"cannot parse the template arguments of {mangled}"
+    return int(m.group(1))
 
 
 def _scratch_in_asm_region(text, name):

@@ -83,3 +83,74 @@ def test_gradsync_world2_gloo():
     for rank, ok, flags in res:
         assert ok, f"rank {rank}: averaged gradients wrong"
         assert flags == [True, True, False]
+
+
+# ------------------------------------------------------------------------------------------------ bench.py's rank logic at world 8
+def _bench_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import time
+    import bench
+    from slam_llm_amd.train import GradSync, setup_distributed
+    r, lr, w = setup_distributed("cpu")
+    assert (r, w) == (rank, world)
+    dev = torch.device("cpu")
+    # a stub step whose duration depends on the rank: rank r sleeps (r + 1) x 4 ms, and "exposes" (r + 1) ms of communication
+    calls = []
+
+    def step():
+        calls.append(time.perf_counter())
+        time.sleep(0.004 * (rank + 1))
+        return float(rank), 0.0
+    steps, warmup = 5, 2
+    res, elapsed, comm = bench.measure(step, steps, warmup, world, dist, lambda: None, dev, comm_ms_fn=lambda: float(rank + 1))
+    # the flat-buffer exchange itself at world 8: mean over ranks, prefix buckets, projector tail
+    n = 50_000
+    flat = torch.full((n,), float(rank))
+
+    class FakeModel:
+        grad_hooks = []
+    gs = GradSync(flat, bucket_bytes=32 * 1024).attach(FakeModel)
+    for end in (8_000, 8_001, 33_000, n):
+        for hk in FakeModel.grad_hooks:
+            hk(end)
+    gs.finish()
+    mean_ok = bool(torch.allclose(flat, torch.full((n,), (world - 1) / 2.0)))
+    q.put((rank, len(calls), res, elapsed, comm, bench.rank_seed(rank), mean_ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bench_rank_logic_world8_gloo():
+    """bench.py --gpus 8 without GPUs: eight gloo ranks drive bench.measure() with a stub step (rank r takes (r + 1) x 4 ms).  Checked:
+    every rank runs exactly W + K steps; the elapsed time every rank ends up with is the SAME number = the slowest rank's (MAX over
+    ranks, >= K x 32 ms); comm_exposed_ms is the MAX over ranks (8.0); the per-rank data seeds differ; the throughput formula is the
+    whole-job aggregate (world x clips); and the flat-buffer mean all-reduce of GradSync is right at world 8."""
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    elapsed = {round(e, 9) for _, _, _, e, _, _, _ in res}
+    assert len(elapsed) == 1, f"ranks disagree on the elapsed time: {elapsed}"
+    e = res[0][3]
+    assert e >= 5 * 0.004 * world * 0.98, e                       # the slowest rank's five steps
+    assert e < 5 * 0.004 * world * 3 + 1.0, e                     # ... and not the SUM over ranks
+    for rank, n_calls, last, _, comm, seed, mean_ok in res:
+        assert n_calls == 7 and last == (float(rank), 0.0)
+        assert comm == float(world)                               # MAX over ranks of the per-rank exposed time
+        assert mean_ok
+    assert len({seed for *_, seed, _ in res}) == world and res[3][5] == bench.rank_seed(3)
+    value, ms = bench.throughput(world, 31, 30.0, 5, e)
+    assert abs(value - world * 31 * 30.0 * 5 / e) < 1e-9 and abs(ms - e / 5 * 1e3) < 1e-9

@@ -206,7 +206,7 @@ def test_wavlm_and_unfrozen_whisper_recipes_build():
     assert build_config(tc, mc)["freeze_encoder"] is False
 
 
-def test_preset_guess_uses_the_basename_and_the_recipes_spellings():
+def test_preset_guess_uses_the_basename_first_and_the_recipes_spellings():
     """the reference HuBERT recipe's checkpoint is `hubert_xtralarge_ll60k_finetune_ls960.pt` (xtralarge = xlarge), and a
     directory component must not outvote the file name; find_unused_parameters=true is refused loudly (DDP cannot see through the
     one autograd node that produces every gradient)."""
@@ -215,8 +215,12 @@ def test_preset_guess_uses_the_basename_and_the_recipes_spellings():
     assert _guess_preset("/hubert-large-models/hubert_base_ls960.pt", HUBERT_PRESETS) == "hubert-base"
     assert _guess_preset("/ckpt/hubert_large_ll60k.pt", HUBERT_PRESETS) == "hubert-large"
     assert _guess_preset("/wavlm-large/WavLM-Base+.pt", WAVLM_PRESETS) == "wavlm-base"
-    with pytest.raises(ValueError, match="cannot map"):
-        _guess_preset("/hubert-large/model.pt", HUBERT_PRESETS)
+    # a generic file name falls back to its parent directories, nearest first: fairseq work dirs, HF snapshot dirs
+    assert _guess_preset("/hubert-large/model.pt", HUBERT_PRESETS) == "hubert-large"
+    assert _guess_preset("/ckpt/hubert_large_ll60k/checkpoint_best.pt", HUBERT_PRESETS) == "hubert-large"
+    assert _guess_preset("/hub/models--facebook--hubert-base-ls960/snapshots/abc/model.safetensors", HUBERT_PRESETS) == "hubert-base"
+    with pytest.raises(ValueError, match="arch_encoder"):
+        _guess_preset("/data/run17/checkpoint_best.pt", HUBERT_PRESETS)
     with pytest.raises(NotImplementedError, match="find_unused_parameters"):
         check_supported(dict(use_peft=True, freeze_encoder=True, find_unused_parameters=True), dict(encoder_name="whisper"))
 
