@@ -279,6 +279,13 @@ int slam_skinny_gram(const void* S, int64_t lds, const void* X, int64_t ldx, flo
 int slam_lora_a_fwd(const void* X, int64_t ldx, const void* A, int64_t lda, void* U, int64_t ldu, int64_t M, int64_t R,
                     int64_t K, float drop_p, uint64_t seed, uint64_t offset, void* stream);
 
+/* LoRA backward, second hop under lora_dropout (peft 0.6.0 Linear: lora_B(lora_A(lora_dropout(x)))): dx[M, K] += mask . (du[M, R] . At[K, R]^T) / (1 - p)
+ * in ONE pass over dx -- du = dL/d(lora_A output) (R = 32 | 64 columns incl. zero padding), At = the adapters' A matrices stacked and transposed
+ * ([K, R]), mask = slam_dropout_bf16's at index offset + m * K + k (what the forward's slam_lora_a_fwd applied to x).  Bit-identical to
+ * slam_gemm_bf16_nt into a scratch buffer + slam_dropout_bf16(accumulate). */
+int slam_lora_hop_dropout(const void* DU, int64_t lddu, const void* At, int64_t ldat, void* DX, int64_t lddx, int64_t M, int64_t K,
+                          int64_t R, float drop_p, uint64_t seed, uint64_t offset, void* stream);
+
 /* ---- embed + audio splice (src/slam_llm/models/slam_model.py:370-392) and its backward --------------
  * input_ids int64 [B,T] (-1 -> 0 in place), modality_mask uint8 [B,T], enc = projector output [B,Ta,ldenc],
  * out [B*T, ldo]; spans int32 [B,2] (start,len) is produced by fwd and consumed by bwd. No host sync. */

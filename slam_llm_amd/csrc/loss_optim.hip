@@ -550,6 +550,111 @@ __global__ __launch_bounds__((NT <= 2 ? 8 : 4) * 64, 2) void lora_a_fwd_kernel(c
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// LoRA backward, second hop with lora_dropout live (round 4): dx[M, K] += mask . (du[M, R] . A[R, K]) / (1 - p), the mask of
+// slam_dropout_bf16 at index offset + m * K + k.  Was two launches -- the rank-R product into a separate [M, K] buffer, then
+// slam_dropout_bf16(accumulate) over it (96 + 290 MB of traffic per Llama layer at the C3 shape for a 193 MB update) -- now one pass over
+// dx: the product on the MFMA (R / 32 k-steps, operands straight from global memory: A^T fragments stay in registers, du is L2-resident),
+// fp32 values exchanged between lane rows (v_permlane16_swap, v_permlane32_swap) so that a lane owns SIXTEEN consecutive columns = two
+// 16-byte loads + stores of dx and two slam_keep8 mask words.  Measured 50.6 us against 70.4 us for the two launches at [11780, 4096]
+// (3.8 TB/s of algorithmic traffic); what bounds it now is the mask itself -- three 64-bit multiplies per four elements, quarter-rate
+// VALU -- which is shared with every other kernel that applies or rebuilds the mask and with the oracle, so it stays.  Rounding
+// reproduces the two-launch form bit for
+// bit: the product is rounded to bf16 before the mask / scale, the sum once more.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hop_swap_rows16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+
+__device__ __forceinline__ void hop_swap_half32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+
+template <int KS>   // KS = R / 32 k-steps (R <= 64, zero-padded to a multiple of 32 by the caller's buffers)
+__global__ __launch_bounds__(256) void lora_hop_drop_kernel(const bf16_t* __restrict__ DU, int64_t lddu, const bf16_t* __restrict__ AT, int64_t ldat,
+                                                            bf16_t* __restrict__ DX, int64_t lddx, int M, int K, int nrb, float inv_keep,
+                                                            unsigned thresh, unsigned long long seed, unsigned long long offset) {
+  // workgroup = one 64-column block of dx (its four fragments of A^T stay in registers), walking row blocks blockIdx.y, + gridDim.y, ...;
+  // the next row block's du and dx pieces are requested before the current one is computed.  (The first form -- a 64 x 256 tile per
+  // workgroup with all sixteen A^T fragments preloaded -- used ~200 VGPRs, ran 2 waves / SIMD and reached 2.3 TB/s.)
+  typedef __attribute__((ext_vector_type(8))) __bf16 bfrag_t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int n0 = blockIdx.x * 64;
+  const int nn = n0 + fg * 16;                       // this lane's 16 consecutive columns after the two exchange levels
+  bfrag_t bf[4][KS];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int n = min(n0 + j * 16 + frow, K - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) bf[j][ks] = *reinterpret_cast<const bfrag_t*>(AT + (int64_t)n * ldat + ks * 32 + fg * 8);
+  }
+  bfrag_t af_n[2][KS];                              // two row blocks requested ahead (one: 3.7 TB/s)
+  u16x8_t old_n[2][2];
+  const int G = gridDim.y;
+  auto request = [&](bfrag_t (&a)[KS], u16x8_t (&o)[2], int rb) {
+    const int m = rb * 64 + wave * 16 + frow;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) a[ks] = *reinterpret_cast<const bfrag_t*>(DU + (int64_t)min(m, M - 1) * lddu + ks * 32 + fg * 8);
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if (m < M && nn + 8 * h < K) o[h] = *reinterpret_cast<const u16x8_t*>(DX + (int64_t)m * lddx + nn + 8 * h);
+  };
+  auto compute = [&](const bfrag_t (&af)[KS], const u16x8_t (&old)[2], int rb) {
+    const int m = rb * 64 + wave * 16 + frow;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int hh = 0; hh < 4; hh++) {
+      acc[hh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++)
+        acc[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[hh][ks], af[ks], acc[hh], 0, 0, 0);   // lane: row frow, columns 4 fg .. + 3 of the fragment
+    }
+    // two exchange levels turn "4 columns of each of four fragments" into "16 consecutive columns of fragment fg": 16-lane rows first
+    // (odd rows of fragment 2 i <-> even rows of 2 i + 1: columns (fg >> 1) * 8 .. + 7 of fragment 2 i + (fg & 1)), then the 32-lane halves
+    // of the two pairs.  The four lanes of a matrix row then cover 128 contiguous bytes of dx.
+    float v[4][4];
+#pragma unroll
+    for (int hh = 0; hh < 4; hh++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[hh][e] = acc[hh][e];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { hop_swap_rows16(v[0][e], v[1][e]); hop_swap_rows16(v[2][e], v[3][e]); }
+#pragma unroll
+    for (int e = 0; e < 4; e++) { hop_swap_half32(v[0][e], v[2][e]); hop_swap_half32(v[1][e], v[3][e]); }
+    // v[0]: columns 0-3, v[1]: 4-7, v[2]: 8-11, v[3]: 12-15 of fragment fg
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      if (m < M && nn + 8 * h < K) {                // K % 8 == 0 (launcher)
+        const unsigned keep8 = slam_keep8(seed, offset + (unsigned long long)m * (unsigned long long)K + (unsigned long long)(nn + 8 * h), thresh);
+        u16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float hop = bf2f(f2bf(v[2 * h + (e >> 2)][e & 3]));        // the [M, K] bf16 buffer of the two-launch form
+          const float val = ((keep8 >> e) & 1u) ? hop * inv_keep : 0.f;
+          o[e] = f2bf(bf2f(old[h][e]) + val);
+        }
+        *reinterpret_cast<u16x8_t*>(DX + (int64_t)m * lddx + nn + 8 * h) = o;
+      }
+    }
+  };
+  int rb = blockIdx.y;
+  if (rb < nrb) request(af_n[0], old_n[0], rb);
+  if (rb + G < nrb) request(af_n[1], old_n[1], rb + G);
+  for (; rb < nrb; rb += 2 * G) {
+    bfrag_t af[KS];
+    u16x8_t old[2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) af[ks] = af_n[0][ks];
+    old[0] = old_n[0][0]; old[1] = old_n[0][1];
+    if (rb + 2 * G < nrb) request(af_n[0], old_n[0], rb + 2 * G);
+    compute(af, old, rb);
+    if (rb + G >= nrb) break;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) af[ks] = af_n[1][ks];
+    old[0] = old_n[1][0]; old[1] = old_n[1][1];
+    if (rb + 3 * G < nrb) request(af_n[1], old_n[1], rb + 3 * G);
+    compute(af, old, rb + G);
+  }
+}
+
 }  // namespace
 
 extern "C" int slam_lora_a_fwd(const void* X, int64_t ldx, const void* A, int64_t lda, void* U, int64_t ldu, int64_t M,
@@ -571,6 +676,29 @@ extern "C" int slam_lora_a_fwd(const void* X, int64_t ldx, const void* A, int64_
   else SLAM_LAUNCH_LA(4);
 #undef SLAM_LAUNCH_LA
   SLAM_CHECK_LAUNCH("slam_lora_a_fwd");
+  return 0;
+}
+
+extern "C" int slam_lora_hop_dropout(const void* DU, int64_t lddu, const void* AT, int64_t ldat, void* DX, int64_t lddx, int64_t M, int64_t K,
+                                     int64_t R, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
+  SLAM_CHECK_ARG(DU && AT && DX, "slam_lora_hop_dropout: null pointer");
+  SLAM_CHECK_ARG(M > 0 && K > 0 && K % 8 == 0 && (R == 32 || R == 64), "slam_lora_hop_dropout: need K %% 8 == 0 and R (columns of du, zero padded) in {32, 64}");
+  SLAM_CHECK_ARG(lddu % 8 == 0 && ldat % 8 == 0 && lddx % 8 == 0 && lddu >= R && ldat >= R && lddx >= K, "slam_lora_hop_dropout: leading dimensions");
+  SLAM_CHECK_ARG(((uintptr_t)DU % 16) == 0 && ((uintptr_t)AT % 16) == 0 && ((uintptr_t)DX % 16) == 0, "slam_lora_hop_dropout: operands must be 16-byte aligned");
+  SLAM_CHECK_ARG(drop_p > 0.f && drop_p < 1.f && offset % 8 == 0, "slam_lora_hop_dropout: drop_p in (0, 1), offset %% 8 == 0");
+  const unsigned th = slam_drop_thresh16(drop_p);
+  const float inv_keep = 1.0f / (1.0f - drop_p);
+  const int nrb = (int)cdiv64(M, 64), ncb = (int)cdiv64(K, 64);
+  const int chunks = (int)std::min<int64_t>(nrb, std::max<int64_t>(1, cdiv64(2048, ncb)));   // >= 8 workgroups per CU when M allows
+  dim3 grid((unsigned)ncb, (unsigned)chunks);
+  hipStream_t s = (hipStream_t)stream;
+  if (R == 32)
+    hipLaunchKernelGGL(lora_hop_drop_kernel<1>, grid, dim3(256), 0, s, (const bf16_t*)DU, lddu, (const bf16_t*)AT, ldat, (bf16_t*)DX, lddx, (int)M, (int)K,
+                       nrb, inv_keep, th, (unsigned long long)seed, (unsigned long long)offset);
+  else
+    hipLaunchKernelGGL(lora_hop_drop_kernel<2>, grid, dim3(256), 0, s, (const bf16_t*)DU, lddu, (const bf16_t*)AT, ldat, (bf16_t*)DX, lddx, (int)M, (int)K,
+                       nrb, inv_keep, th, (unsigned long long)seed, (unsigned long long)offset);
+  SLAM_CHECK_LAUNCH("slam_lora_hop_dropout");
   return 0;
 }
 

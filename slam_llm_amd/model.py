@@ -53,6 +53,9 @@ LM_HEAD_LABEL_ROWS = _os.environ.get("SLAM_LM_HEAD_LABEL_ROWS", "1") == "1"
 # without a label get exactly the zero gradient they had).  Off when LoRA dropout acts on o / gate / up / down of that layer (the
 # counter-based masks are indexed by row).  SLAM_LAST_LAYER_LABEL_ROWS=0 disables.
 LAST_LAYER_LABEL_ROWS = _os.environ.get("SLAM_LAST_LAYER_LABEL_ROWS", "1") == "1"
+# LoRA backward under lora_dropout: second hop + mask + accumulate as ONE pass over dx (slam_lora_hop_dropout) instead of product -> scratch
+# [M, K] -> slam_dropout_bf16(accumulate); bit-identical; SLAM_FUSED_LORA_HOP=0 restores the two launches (A/B)
+FUSE_LORA_HOP = _os.environ.get("SLAM_FUSED_LORA_HOP", "1") == "1"
 LORA_PAD = 64  # K-extension granule (GEMM K-tile)
 # HuBERT / WavLM conv layers 1-6 (k 3 / 2, stride 2, 512 channels, no padding): the im2col matrix of a row-major [T, C] signal is a VIEW
 # with overlapping rows (row t = the k * C contiguous elements from row 2 t on) -- handed to the GEMM as lda = stride * C, one launch
@@ -283,6 +286,9 @@ class FusedLinear:
             xin = x_ext[:, : self.K]
             if drop is None:
                 ops.gemm_nt(dx_ext[:, self.K:], self.AcatT, out=dx_ext[:, : self.K], accumulate=True)
+            elif FUSE_LORA_HOP and self.Rp in (32, 64):
+                # dL/dx += mask . (du . A) / (1 - p): the rank-Rp product, the mask (recomputed) and the accumulate in one pass over dx
+                ops.lora_hop_dropout(dx_ext[:, self.K:], self.AcatT, dx_ext[:, : self.K], drop)
             else:
                 hop = ops.gemm_nt(dx_ext[:, self.K:], self.AcatT)           # dL/d(dropout(x))
                 ops.dropout(hop, *drop, out=dx_ext[:, : self.K], accumulate=True)  # same mask, recomputed

@@ -755,6 +755,17 @@ def lora_a_fwd(x2d, a_cat, out, drop=None):
     return out
 
 
+def lora_hop_dropout(du, a_t, dx, drop):
+    """dx[M, K] += mask(drop) . (du[M, R] @ a_t[K, R]^T) / (1 - p) in one pass over dx (R = 32 | 64 incl. zero padding)"""
+    M, R = du.shape
+    K = a_t.shape[0]
+    p_, seed, off = drop
+    _timed("lora_hop_dropout", 2.0 * M * K * R, lambda: call("slam_lora_hop_dropout", _p(du), _ld(du), _p(a_t), _ld(a_t), _p(dx), _ld(dx), M, K, R, float(p_),
+                                                             int(seed) & (2 ** 64 - 1), int(off) & (2 ** 64 - 1), _s()),
+           nbytes=4.0 * M * K)
+    return dx
+
+
 def skinny_gram(S2d, X2d, out, out_ld_r, out_ld_c, alpha=1.0, accumulate=False, drop=None):
     """out[r*ld_r + c*ld_c] (+)= alpha * sum_m S[m,r] X'[m,c]   (LoRA dA / dB); out is an fp32 tensor (any view);
     drop = (p, seed, offset): X' = dropout(X) recomputed from the counter-based mask, else X' = X"""

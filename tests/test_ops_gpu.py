@@ -1028,6 +1028,30 @@ def test_lora_first_hop_and_gram_recompute_the_dropout_mask(dev, M, K, R, p):
         assert_close(g1, ref, atol=2e-2 * float(ref.abs().max()), rtol=2e-2, what="dA with recomputed mask")
 
 
+@pytest.mark.parametrize("M,K,R,sr", [(700, 512, 64, 32), (11780, 4096, 64, 32), (100, 256, 64, 8), (380, 2048, 64, 16)])
+def test_lora_hop_dropout_equals_the_two_launch_form(dev, M, K, R, sr):
+    """slam_lora_hop_dropout (second hop of the LoRA backward + recomputed dropout mask + accumulate, one pass over dx) is BIT-identical to
+    the product into a scratch buffer followed by slam_dropout_bf16(accumulate) -- same MFMA order, same two bf16 roundings, same mask"""
+    ops = _ops()
+    du = torch.zeros((M, R), dtype=torch.bfloat16, device=dev)
+    du[:, :sr] = rnd((M, sr), dev, seed=101)
+    a_t = torch.zeros((K, R), dtype=torch.bfloat16, device=dev)
+    a_t[:, :sr] = rnd((K, sr), dev, seed=102, std=0.05)
+    dx0 = rnd((M, K), dev, seed=103)
+    drop = (0.05, 1234567, 5 << 40)
+    ref = dx0.clone()
+    ops.dropout(ops.gemm_nt(du, a_t), *drop, out=ref, accumulate=True)
+    got = dx0.clone()
+    ops.lora_hop_dropout(du, a_t, got, drop)
+    assert torch.equal(got, ref)
+    assert not torch.equal(got, dx0)
+    # a column view with a larger leading dimension (how FusedLinear.backward calls it: du and dx are column blocks of dx_ext)
+    ext = torch.zeros((M, K + R), dtype=torch.bfloat16, device=dev)
+    ext[:, :K], ext[:, K:] = dx0, du
+    ops.lora_hop_dropout(ext[:, K:], a_t, ext[:, :K], drop)
+    assert torch.equal(ext[:, :K], ref)
+
+
 def test_lora_fused_linear_with_dropout_matches_autograd(dev):
     """peft semantics y = x W^T + s * (dropout(x) A^T) B^T, forward and every gradient, with the kernel's own mask"""
     ops = _ops()
