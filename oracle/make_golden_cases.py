@@ -37,6 +37,11 @@ UNFROZEN_CASE = dict(cfg=O.make_config(), clip_seconds=1.77, answer_lens=(5, 9),
 # inside ~50 frames
 WAVLM_TINY = O.wavlm_config(hub_conv_dim=(64,) * 7, hub_dim=128, hub_heads=2, hub_layers=2, hub_ffn=256, hub_pos_k=16,
                             hub_pos_groups=4, wavlm_buckets=40, wavlm_max_distance=24)
+# the same module left in TRAIN mode (freeze_encoder=false, slam_model.py:317-318): three layers so that layerdrop can skip one and leave
+# two, every regulariser of WavLM.py:180-185 non-zero (the released cfg's activation_dropout / dropout_input are 0; 0.1 here so that
+# their placement is pinned too)
+WAVLM_TRAIN_TINY = dict(WAVLM_TINY, hub_layers=3)
+WAVLM_TRAIN_REG = dict(dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, dropout_input=0.1, encoder_layerdrop=0.4)
 # HuBERT-base structure (HF: feat_extract_norm="group", do_stable_layer_norm=False, conv_bias=False) at toy widths
 HUBERT_BASE_TINY = O.hubert_base_config(hub_conv_dim=(64,) * 7, hub_dim=128, hub_heads=2, hub_layers=2, hub_ffn=256, hub_pos_k=16,
                                         hub_pos_groups=4)

@@ -151,8 +151,13 @@ def hubert_frame_padding_mask(n_samples: int, n_frames: int, n_valid: torch.Tens
     return torch.arange(n_frames)[None, :] >= keep[:, None]
 
 
+def _mul(x, m):
+    """multiplicative dropout mask (0 or 1/(1-p)) handed in by the caller, None = identity"""
+    return x if m is None else x * m
+
+
 def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, prefix="encoder.",
-                   n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   n_valid: Optional[torch.Tensor] = None, train: Optional[dict] = None) -> torch.Tensor:
     """The HuBERT branch of slam_model.forward (src/slam_llm/models/slam_model.py:335-341: fairseq
     `self.encoder(source=audio, padding_mask=...)["encoder_out"]`), restated from the HF twin of fairseq's model
     (transformers/models/hubert/modeling_hubert.py: HubertFeatureEncoder with LayerNorm conv layers :127-151,
@@ -163,7 +168,13 @@ def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pre
     over the padded waveform, the frame mask follows fairseq (hubert_frame_padding_mask), padded frames are zeroed before the
     positional conv (fairseq TransformerEncoder.extract_features: `x = index_put(x, padding_mask, 0)`; HF :571-575 the same) and
     masked as attention KEYS in every layer; their own output rows are garbage (never read: the splice takes the clip's first
-    len//320//5 projector frames)."""
+    len//320//5 projector frames).
+    train (un-frozen encoder in train mode; fairseq wav2vec2 TransformerEncoder / TransformerSentenceEncoderLayer -- the module tree the
+    reference's WavLM.py vendors, see wavlm_encoder): the masks the regularisers drew, as inputs (torch's RNG stream cannot be shared
+    with a device kernel): {"input": after the feature projection, "x": after the positional conv (+ the encoder LayerNorm of post-LN
+    models), "layers": per layer None (dropped by layerdrop) or {"attn": [B,H,T,T] on the attention probabilities, "d1" / "d3": on the
+    attention / feed-forward output projections before the residual add, "d2": after the GELU}}; each mask 0 or 1/(1-p), None = off."""
+    tr = train or {}
     x = wav[:, None, :]
     group_mode = cfg.get("hub_extractor_mode", "layer_norm") == "default"
     pre_ln = cfg.get("hub_layer_norm_first", True)
@@ -181,7 +192,7 @@ def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pre
     eps = cfg["hub_eps"]
     p = prefix + "feature_projection."
     x = F.layer_norm(x, (x.shape[-1],), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], eps)
-    x = F.linear(x, W[p + "projection.weight"], W[p + "projection.bias"])
+    x = _mul(F.linear(x, W[p + "projection.weight"], W[p + "projection.bias"]), tr.get("input"))
     p = prefix + "encoder."
     kpos = cfg["hub_pos_k"]
     key_bias = None
@@ -202,8 +213,12 @@ def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pre
     hd = d // H
     if not pre_ln:      # HubertEncoder (post-LN, modeling_hubert.py:470-520): the encoder LayerNorm precedes the layers
         x = F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], eps)
+    x = _mul(x, tr.get("x"))
     for i in range(cfg["hub_layers"]):
         q_ = f"{p}layers.{i}."
+        lm = tr["layers"][i] if "layers" in tr else {}
+        if lm is None:      # layerdrop
+            continue
         h = F.layer_norm(x, (d,), W[q_ + "layer_norm.weight"], W[q_ + "layer_norm.bias"], eps) if pre_ln else x
         q = F.linear(h, W[q_ + "attention.q_proj.weight"], W[q_ + "attention.q_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
         k = F.linear(h, W[q_ + "attention.k_proj.weight"], W[q_ + "attention.k_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
@@ -211,15 +226,15 @@ def hubert_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pre
         sc = (q @ k.transpose(2, 3)) * hd ** -0.5
         if key_bias is not None:
             sc = sc + key_bias
-        a = F.softmax(sc, dim=-1) @ v
+        a = _mul(F.softmax(sc, dim=-1), lm.get("attn")) @ v
         a = a.transpose(1, 2).reshape(B, T, d)
-        x = x + F.linear(a, W[q_ + "attention.out_proj.weight"], W[q_ + "attention.out_proj.bias"])
+        x = x + _mul(F.linear(a, W[q_ + "attention.out_proj.weight"], W[q_ + "attention.out_proj.bias"]), lm.get("d1"))
         if not pre_ln:  # HubertEncoderLayer (:395-420): x = LN(x + attn(x)); x = LN_final(x + ffn(x))
             x = F.layer_norm(x, (d,), W[q_ + "layer_norm.weight"], W[q_ + "layer_norm.bias"], eps)
         h = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], eps) if pre_ln else x
-        h = F.linear(F.gelu(F.linear(h, W[q_ + "feed_forward.intermediate_dense.weight"], W[q_ + "feed_forward.intermediate_dense.bias"])),
+        h = F.linear(_mul(F.gelu(F.linear(h, W[q_ + "feed_forward.intermediate_dense.weight"], W[q_ + "feed_forward.intermediate_dense.bias"])), lm.get("d2")),
                      W[q_ + "feed_forward.output_dense.weight"], W[q_ + "feed_forward.output_dense.bias"])
-        x = x + h
+        x = x + _mul(h, lm.get("d3"))
         if not pre_ln:
             x = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], eps)
     return F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], eps) if pre_ln else x
@@ -301,7 +316,7 @@ def wavlm_relative_buckets(rel: torch.Tensor, num_buckets: int, max_distance: in
 
 
 def wavlm_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, prefix="encoder.model.",
-                  n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  n_valid: Optional[torch.Tensor] = None, train: Optional[dict] = None) -> torch.Tensor:
     """The WavLM branch of slam_model.forward (src/slam_llm/models/slam_model.py:333-334:
     `self.encoder.extract_features(audio, 1 - audio_mask)` -> models/encoder.py:126-127 -> WavLM.extract_features,
     models/wavlm/WavLM.py:323-376) in eval mode.  wav [B, N] (layer-normed by the dataset when cfg.normalize) -> [B, T', d].
@@ -312,7 +327,13 @@ def wavlm_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pref
     * attention (modules.py:504-562): scores = q.k / sqrt(hd) + gate[b,h,q] * position_bias[h,q,k], where position_bias is
       layer 0's `relative_attention_bias` embedding of the bucketed distance k - q (compute_bias :444-455, shared by ALL
       layers) and gate = a * (g * grep_a - 1) + 2 with (a, g) = sigmoid of the two 4-sums of grep_linear(per-head slice of the
-      attention INPUT) (:522-531); key padding mask -> -inf."""
+      attention INPUT) (:522-531); key padding mask -> -inf.
+    train (the module is left in train mode when un-frozen, slam_model.py:317-318): the masks of WavLM's regularisers as inputs, same
+    dict as hubert_encoder -- "input" = dropout_input (:353), "x" = F.dropout after the positional conv (+ LayerNorm) (:582-584),
+    per layer None = skipped by layerdrop (:596-597) or "attn" (attention_dropout on the probabilities, modules.py F.dropout on
+    attn_probs), "d1" / "d2" / "d3" (:702-726).  With layer 0 skipped, position_bias is never created (it is computed inside layer 0's
+    attention and handed down, :593-599): the other layers then run without the bias and the gate."""
+    tr = train or {}
     x = wav[:, None, :]
     group_mode = cfg.get("hub_extractor_mode", "layer_norm") == "default"
     pre_ln = cfg.get("hub_layer_norm_first", True)
@@ -330,7 +351,7 @@ def wavlm_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pref
             x = F.gelu(x.transpose(-2, -1))
     x = x.transpose(1, 2)
     x = F.layer_norm(x, (x.shape[-1],), W[prefix + "layer_norm.weight"], W[prefix + "layer_norm.bias"], 1e-5)
-    x = F.linear(x, W[prefix + "post_extract_proj.weight"], W[prefix + "post_extract_proj.bias"])
+    x = _mul(F.linear(x, W[prefix + "post_extract_proj.weight"], W[prefix + "post_extract_proj.bias"]), tr.get("input"))
     B, T, d = x.shape
     key_bias = None
     if n_valid is not None:
@@ -347,13 +368,18 @@ def wavlm_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pref
     x = x + F.gelu(pos).transpose(1, 2)
     if not pre_ln:      # post-LN encoders normalise HERE (WavLM.py:582-583) and not after the layers (:567-568)
         x = F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5)
+    x = _mul(x, tr.get("x"))
     H = cfg["hub_heads"]
     hd = d // H
     rel = torch.arange(T)[None, :] - torch.arange(T)[:, None]                 # memory - context = k - q
     buckets = wavlm_relative_buckets(rel, cfg["wavlm_buckets"], cfg["wavlm_max_distance"])
     pos_bias = F.embedding(buckets, W[p + "layers.0.self_attn.relative_attention_bias.weight"]).permute(2, 0, 1)   # [H, T, T]
+    biased = not ("layers" in tr and tr["layers"][0] is None)
     for i in range(cfg["hub_layers"]):
         q_ = f"{p}layers.{i}."
+        lm = tr["layers"][i] if "layers" in tr else {}
+        if lm is None:
+            continue
         # attention input: LN(x) in layer_norm_first layers (:690-703), x itself in post-LN layers (:716-725)
         h = F.layer_norm(x, (d,), W[q_ + "self_attn_layer_norm.weight"], W[q_ + "self_attn_layer_norm.bias"], 1e-5) if pre_ln else x
         hh = h.view(B, T, H, hd).permute(0, 2, 1, 3)                           # per-head slices of the attention input
@@ -363,17 +389,21 @@ def wavlm_encoder(W: Dict[str, torch.Tensor], cfg: dict, wav: torch.Tensor, pref
         q = F.linear(h, W[q_ + "self_attn.q_proj.weight"], W[q_ + "self_attn.q_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
         k = F.linear(h, W[q_ + "self_attn.k_proj.weight"], W[q_ + "self_attn.k_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
         v = F.linear(h, W[q_ + "self_attn.v_proj.weight"], W[q_ + "self_attn.v_proj.bias"]).view(B, T, H, hd).transpose(1, 2)
-        sc = (q @ k.transpose(2, 3)) * hd ** -0.5 + gate * pos_bias[None]
+        sc = (q @ k.transpose(2, 3)) * hd ** -0.5
+        if biased:
+            sc = sc + gate * pos_bias[None]
         if key_bias is not None:
             sc = sc + key_bias
-        a = (F.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(B, T, d)
-        x = x + F.linear(a, W[q_ + "self_attn.out_proj.weight"], W[q_ + "self_attn.out_proj.bias"])
+        a = (_mul(F.softmax(sc, dim=-1), lm.get("attn")) @ v).transpose(1, 2).reshape(B, T, d)
+        x = x + _mul(F.linear(a, W[q_ + "self_attn.out_proj.weight"], W[q_ + "self_attn.out_proj.bias"]), lm.get("d1"))
+        ffn = lambda t: _mul(F.linear(_mul(F.gelu(F.linear(t, W[q_ + "fc1.weight"], W[q_ + "fc1.bias"])), lm.get("d2")),    # noqa: E731
+                                      W[q_ + "fc2.weight"], W[q_ + "fc2.bias"]), lm.get("d3"))
         if pre_ln:
             h = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], 1e-5)
-            x = x + F.linear(F.gelu(F.linear(h, W[q_ + "fc1.weight"], W[q_ + "fc1.bias"])), W[q_ + "fc2.weight"], W[q_ + "fc2.bias"])
+            x = x + ffn(h)
         else:           # post-LN (:726-739): x = LN1(x + attn(x)); x = LN2(x + ffn(x))
             x = F.layer_norm(x, (d,), W[q_ + "self_attn_layer_norm.weight"], W[q_ + "self_attn_layer_norm.bias"], 1e-5)
-            x = x + F.linear(F.gelu(F.linear(x, W[q_ + "fc1.weight"], W[q_ + "fc1.bias"])), W[q_ + "fc2.weight"], W[q_ + "fc2.bias"])
+            x = x + ffn(x)
             x = F.layer_norm(x, (d,), W[q_ + "final_layer_norm.weight"], W[q_ + "final_layer_norm.bias"], 1e-5)
     return F.layer_norm(x, (d,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5) if pre_ln else x
 

@@ -2517,7 +2517,7 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   SLAM_CHECK_ARG(Q && K && (Vt || V) && O, "slam_attn_fwd: null pointer (V row-major and / or its [B,H,D,Tp] copy Vt must be given)");
   SLAM_CHECK_ARG(!V || ldv % 8 == 0, "slam_attn_fwd: ldv must be a multiple of 8");
   SLAM_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "slam_attn_fwd: drop_p=%f must be in [0, 1)", (double)drop_p);
-  SLAM_CHECK_ARG(drop_p == 0.f || (D == 64 && !causal && !seg_lo && !rp_gate),
+  SLAM_CHECK_ARG(drop_p == 0.f || (D == 64 && !causal && !seg_lo),
                  "slam_attn_fwd: attention-probability dropout is implemented for head_dim 64, bidirectional, unpacked batches");
   SLAM_CHECK_ARG((rp_gate == nullptr) == (rp_tab == nullptr), "slam_attn_fwd: rp_gate / rp_tab must both be set or both null");
   SLAM_CHECK_ARG(!rp_gate || (D == 64 && !causal && !seg_lo && rp_T >= Tq && rp_T >= Tk && rp_ld >= 2 * rp_T - 1),
@@ -2539,7 +2539,9 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.drop_scale = 1.0f / (1.0f - drop_p);
   p.drop_seed = drop_seed;
   hipStream_t s = (hipStream_t)stream;
-  if (drop_p > 0.f) {
+  if (drop_p > 0.f && rp_gate) {   // un-frozen WavLM in train mode: attention_dropout on top of the gated bias (WavLM.py:181, modules.py:504-562)
+    launch_fwd<64, false, 2, true, true>(p, B, s);
+  } else if (drop_p > 0.f) {
     launch_fwd<64, false, 2, false, true>(p, B, s);
   } else if (rp_gate) {
     launch_fwd<64, false, 2, true>(p, B, s);
@@ -2601,10 +2603,10 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
     SLAM_CHECK_ARG(!(need & 2) || (Qt && Kt && dOt), "slam_attn_bwd: this configuration runs the kernels that read the transposed copies: "
                    "Qt / Kt / dOt must be given (slam_attn_needs_transposed says when)");
   }
-  SLAM_CHECK_ARG(!rp_gate || (rp_tab && rp_ds && d_gate && d_tab && D == 64 && !causal && !seg_lo && !rope_cos && drop_p == 0.f && Hq == Hkv &&
+  SLAM_CHECK_ARG(!rp_gate || (rp_tab && rp_ds && d_gate && d_tab && D == 64 && !causal && !seg_lo && !rope_cos && Hq == Hkv &&
                               rp_T >= Tq && rp_T >= Tk && rp_ld >= 2 * rp_T - 1),
                  "slam_attn_bwd: the gated relative position bias needs rp_tab / rp_ds / d_gate / d_tab, head_dim 64, bidirectional unpacked MHA "
-                 "without dropout or fused RoPE, and a table covering the sequence");
+                 "without fused RoPE, and a table covering the sequence");
   SLAM_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "slam_attn_bwd: drop_p=%f must be in [0, 1)", (double)drop_p);
   SLAM_CHECK_ARG(drop_p == 0.f || (D == 64 && !causal && !seg_lo && !rope_cos),
                  "slam_attn_bwd: attention-probability dropout is implemented for head_dim 64, bidirectional, unpacked batches");
@@ -2631,8 +2633,13 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   hipStream_t s = (hipStream_t)stream;
   if (rp_gate) {   // WavLM (unfrozen): the bias joins the recomputed scores; dL/d(score) is materialised once and reduced twice
     dim3 gq_((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B), gk_((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);
-    attn_launch((attn_bwd_dq_kernel<64, false, false, 1, true>), gq_, 256, 0, s, p);
-    attn_launch((attn_bwd_dkdv_kernel<64, false, false, true>), gk_, 256, 0, s, p);
+    if (drop_p > 0.f) {     // train-mode attention_dropout: the same mask as the forward, recomputed; dL/d(score) already carries it
+      attn_launch((attn_bwd_dq_kernel<64, false, true, 1, true>), gq_, 256, 0, s, p);
+      attn_launch((attn_bwd_dkdv_kernel<64, false, true, true>), gk_, 256, 0, s, p);
+    } else {
+      attn_launch((attn_bwd_dq_kernel<64, false, false, 1, true>), gq_, 256, 0, s, p);
+      attn_launch((attn_bwd_dkdv_kernel<64, false, false, true>), gk_, 256, 0, s, p);
+    }
     const int64_t rows = B * Hq * Tq;
     hipLaunchKernelGGL(relpos_dgate_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(rows, 4), 65535 * 4)), dim3(256), 0, s, rp_ds, rp_tab, d_gate, (int)B,
                        (int)Hq, (int)Tq, (int)Tk, (int)Tkp, (int)Tqp, (int)rp_T, (int)rp_ld);

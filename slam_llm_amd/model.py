@@ -21,6 +21,8 @@ from __future__ import annotations
 
 import math
 from types import SimpleNamespace
+
+import numpy as np
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -695,6 +697,7 @@ class HipHubertEncoder(nn.Module):
 
     def __init__(self, cfg: dict, device, store: Optional["TrainableStore"] = None, prefix="encoder."):
         super().__init__()
+        self._drop_calls = 0
         self.cfg, self.device_, self.w = cfg, device, {}
         self.store, self.prefix = store, prefix
         if store is not None:
@@ -713,6 +716,47 @@ class HipHubertEncoder(nn.Module):
     @property
     def _pre_ln(self) -> bool:
         return bool(self.cfg.get("hub_layer_norm_first", True))
+
+    def _regularisers(self) -> SimpleNamespace:
+        """the train-mode regularisers of the UN-FROZEN encoder (the reference leaves it in train mode, slam_model.py:317-318 calls .eval()
+        only when frozen): WavLM.py:180-185 / fairseq HubertConfig -- `dropout` (after the positional conv, WavLM.py:584, and after the
+        attention / feed-forward output projections, :702-726 dropout1 / dropout3), `attention_dropout` (on the attention probabilities),
+        `activation_dropout` (after the GELU, dropout2), `dropout_input` (after post_extract_proj, :353) and `encoder_layerdrop` (:597).
+        cfg keys hub_dropout / hub_attention_dropout / hub_activation_dropout / hub_dropout_input / hub_layerdrop; absent = 0 (plain
+        geometry configs), the factory fills in the reference's defaults (slam_model_hip.build_config).  All zero in eval mode or when
+        the encoder is frozen."""
+        c, on = self.cfg, bool(self.trainable and self.training)
+        f = (lambda k: float(c.get(k, 0.0) or 0.0)) if on else (lambda k: 0.0)
+        R = SimpleNamespace(p=f("hub_dropout"), p_attn=f("hub_attention_dropout"), p_act=f("hub_activation_dropout"),
+                            p_in=f("hub_dropout_input"), layerdrop=f("hub_layerdrop"))
+        R.on = on and max(R.p, R.p_attn, R.p_act, R.p_in, R.layerdrop) > 0.0
+        seed = (torch.initial_seed() ^ 0xE7C0DE) if R.on else 0
+
+        def key(p):
+            """(p, seed, offset) of the next hidden dropout (slam_dropout_bf16's counter-based mask; the backward recomputes it)"""
+            if not (R.on and p > 0.0):
+                return None
+            self._drop_calls += 1
+            return (p, seed, ((self._drop_calls & 0xFFFFF) | 0x100000) << 40)
+
+        def attn_key(p):
+            """(p, seed) of the next attention-probability dropout (applied inside the attention kernels)"""
+            if not (R.on and p > 0.0):
+                return None
+            self._drop_calls += 1
+            return (p, (seed * 0x9E3779B1 + self._drop_calls) & (2 ** 63 - 1))
+
+        def keep_layer():
+            """encoder_layerdrop: `np.random.random() > layerdrop` keeps the layer (WavLM.py:596-597: numpy's global stream, one draw per
+            layer, drawn in train mode only here)"""
+            return (not R.on) or bool(np.random.random() > R.layerdrop)
+        R.key, R.attn_key, R.keep_layer = key, attn_key, keep_layer
+        return R
+
+    @staticmethod
+    def _drop_add(t: torch.Tensor, residual: torch.Tensor, key) -> torch.Tensor:
+        """residual + dropout(t) (the output projections' dropout1 / dropout3 sit BEFORE the residual add)"""
+        return ops.dropout(t, *key, out=residual.clone(), accumulate=True)
 
     def _nm(self) -> SimpleNamespace:
         """logical tensor -> state-dict name of the trainable form.  Default: the names of the module the reference un-freezes -- fairseq's
@@ -1235,30 +1279,55 @@ class HipHubertEncoder(nn.Module):
             h = ops.gather_rows(h, pad_idx)                        # padded frames -> zero rows
             key_mask = km.to(wav.device, non_blocking=True)
         kpos = cfg["hub_pos_k"]
+        RG = self._regularisers()                      # all-None keys in eval mode / frozen / p = 0: the deterministic graph
+        k_in = RG.key(RG.p_in)
+        if k_in is not None:                           # dropout_input (WavLM.py:353), before the padded frames are zeroed: same result
+            h = ops.dropout(h, *k_in)
         pre = torch.empty((M, d), dtype=torch.bfloat16, device=wav.device)
         x = ops.pos_conv_fwd(h, w["pos_tap"], w["pos_b"], B, T, pre=pre)
         S = {"convs": convs, "x6": x2d, "mf": mf, "rf": rf, "hN": hN, "h": h, "pre": pre, "pad_idx": pad_idx, "key_mask": key_mask,
-             "B": B, "T": T, "blocks": []}
+             "B": B, "T": T, "blocks": [], "k_in": k_in, "k_x": None}
         scale = 64 ** -0.5
         if not self._pre_ln:
-            return self._forward_train_post_ln(x, S, stash)
+            return self._forward_train_post_ln(x, S, stash, RG)
+        S["k_x"] = RG.key(RG.p)                        # F.dropout after the positional conv (WavLM.py:584; layer_norm_first: no LayerNorm here)
+        if S["k_x"] is not None:
+            x = ops.dropout(x, *S["k_x"])
         for i in range(cfg["hub_layers"]):
+            if not RG.keep_layer():                    # layerdrop: the layer is the identity this step
+                S["blocks"].append(None)
+                continue
+            ka, k1, k2, k3 = RG.attn_key(RG.p_attn), RG.key(RG.p), RG.key(RG.p_act), RG.key(RG.p)
             hh, m1, r1 = ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, stats=True)
             qkv = ops.gemm_nt(hh, w[f"{i}.qkv"], bias=w[f"{i}.qkv_b"])
-            rp = self._relpos(i, hh, B, T)      # WavLM: (gate [B,H,Tp], bias table, T); HuBERT: None
-            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=True, relpos=rp)
-            x1 = ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"], residual=x)
+            # WavLM: (gate [B,H,Tp], bias table, T); HuBERT: None.  The bias is created by layer 0's attention and handed down
+            # (WavLM.py:593-599): with layer 0 dropped by layerdrop the reference runs the other layers without it -- so does this
+            rp = self._relpos(i, hh, B, T) if i == 0 or S["blocks"][0] is not None else None
+            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask, want_lse=True,
+                                  relpos=rp, drop=ka)
+            if k1 is None:
+                x1 = ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"], residual=x)
+            else:
+                x1 = self._drop_add(ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"]), x, k1)
             h2, m2, r2 = ops.layernorm(x1, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], eps, stats=True)
             z = ops.gemm_nt(h2, w[f"{i}.fc1"], bias=w[f"{i}.fc1_b"])
-            x2 = ops.gemm_nt(ops.gelu_fwd(z), w[f"{i}.fc2"], bias=w[f"{i}.fc2_b"], residual=x1)
-            S["blocks"].append(dict(x=x, m1=m1, r1=r1, h=hh, qkv=qkv, a=a, lse=lse, x1=x1, m2=m2, r2=r2, h2=h2, z=z, rp=rp))
+            fo = ops.gelu_fwd(z)
+            if k2 is not None:
+                fo = ops.dropout(fo, *k2)
+            if k3 is None:
+                x2 = ops.gemm_nt(fo, w[f"{i}.fc2"], bias=w[f"{i}.fc2_b"], residual=x1)
+            else:
+                x2 = self._drop_add(ops.gemm_nt(fo, w[f"{i}.fc2"], bias=w[f"{i}.fc2_b"]), x1, k3)
+            del fo
+            S["blocks"].append(dict(x=x, m1=m1, r1=r1, h=hh, qkv=qkv, a=a, lse=lse, x1=x1, m2=m2, r2=r2, h2=h2, z=z, rp=rp,
+                                    ka=ka, k1=k1, k2=k2, k3=k3))
             x = x2
         out, mo, ro = ops.layernorm(x, w["lnp_w"], w["lnp_b"], eps, stats=True)
         S.update(x_last=x, mo=mo, ro=ro)
         stash["encoder"] = S
         return out.view(B, T, d)
 
-    def _forward_train_post_ln(self, x: torch.Tensor, S: dict, stash: dict) -> torch.Tensor:
+    def _forward_train_post_ln(self, x: torch.Tensor, S: dict, stash: dict, RG: SimpleNamespace) -> torch.Tensor:
         """the layers of the post-LN geometries (Base): encoder LayerNorm first, then x = LN1(x + attn(x)); x = LN2(x + ffn(x)) per layer
         (WavLM.py:582-583 / :716-739, modeling_hubert.py:395-420, 470-520), no LayerNorm after them"""
         cfg, w = self.cfg, self.w
@@ -1267,16 +1336,35 @@ class HipHubertEncoder(nn.Module):
         x_pre = x
         x, mo, ro = ops.layernorm(x_pre, w["lnp_w"], w["lnp_b"], eps, stats=True)
         S.update(x_pre=x_pre, mo=mo, ro=ro)
+        S["k_x"] = RG.key(RG.p)                        # F.dropout after the encoder LayerNorm (WavLM.py:582-584)
+        if S["k_x"] is not None:
+            x = ops.dropout(x, *S["k_x"])
         for i in range(cfg["hub_layers"]):
+            if not RG.keep_layer():
+                S["blocks"].append(None)
+                continue
+            ka, k1, k2, k3 = RG.attn_key(RG.p_attn), RG.key(RG.p), RG.key(RG.p_act), RG.key(RG.p)
             qkv = ops.gemm_nt(x, w[f"{i}.qkv"], bias=w[f"{i}.qkv_b"])
-            rp = self._relpos(i, x, B, T)
-            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=S["key_mask"], want_lse=True, relpos=rp)
-            s1 = ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"], residual=x)
+            rp = self._relpos(i, x, B, T) if i == 0 or S["blocks"][0] is not None else None
+            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=S["key_mask"], want_lse=True,
+                                  relpos=rp, drop=ka)
+            if k1 is None:
+                s1 = ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"], residual=x)
+            else:
+                s1 = self._drop_add(ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"]), x, k1)
             x1, m1, r1 = ops.layernorm(s1, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], eps, stats=True)
             z = ops.gemm_nt(x1, w[f"{i}.fc1"], bias=w[f"{i}.fc1_b"])
-            s2 = ops.gemm_nt(ops.gelu_fwd(z), w[f"{i}.fc2"], bias=w[f"{i}.fc2_b"], residual=x1)
+            fo = ops.gelu_fwd(z)
+            if k2 is not None:
+                fo = ops.dropout(fo, *k2)
+            if k3 is None:
+                s2 = ops.gemm_nt(fo, w[f"{i}.fc2"], bias=w[f"{i}.fc2_b"], residual=x1)
+            else:
+                s2 = self._drop_add(ops.gemm_nt(fo, w[f"{i}.fc2"], bias=w[f"{i}.fc2_b"]), x1, k3)
+            del fo
             x2, m2, r2 = ops.layernorm(s2, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], eps, stats=True)
-            S["blocks"].append(dict(h=x, qkv=qkv, a=a, lse=lse, s1=s1, m1=m1, r1=r1, x1=x1, z=z, s2=s2, m2=m2, r2=r2, rp=rp))
+            S["blocks"].append(dict(h=x, qkv=qkv, a=a, lse=lse, s1=s1, m1=m1, r1=r1, x1=x1, z=z, s2=s2, m2=m2, r2=r2, rp=rp,
+                                    ka=ka, k1=k1, k2=k2, k3=k3))
             x = x2
         stash["encoder"] = S
         return x.view(B, T, d)
@@ -1311,23 +1399,36 @@ class HipHubertEncoder(nn.Module):
             dx = self._backward_layers_post_ln(dout, S, rp_state, acc)
         for i in (reversed(range(cfg["hub_layers"])) if self._pre_ln else ()):
             R = S["blocks"][i]
+            if R is None:                              # layerdrop: identity this step -- its parameters get no gradient (zero-filled below)
+                self._zero_layer_grads(i, acc)
+                continue
             fo = ops.gelu_fwd(R["z"])
-            self._lin_grads(dx, fo, N.fc2(i) + ".weight", acc, bias=((N.fc2(i) + ".bias", 0, d),))
-            dz = ops.gelu_bwd(R["z"], ops.gemm_nt(dx, w[f"{i}.fc2T"]))
-            del fo
+            if R["k2"] is not None:
+                fo = ops.dropout(fo, *R["k2"])
+            dt = dx if R["k3"] is None else ops.dropout(dx, *R["k3"])         # dL/d(fc2 output): the residual branch keeps the undropped dx
+            self._lin_grads(dt, fo, N.fc2(i) + ".weight", acc, bias=((N.fc2(i) + ".bias", 0, d),))
+            dfo = ops.gemm_nt(dt, w[f"{i}.fc2T"])
+            if R["k2"] is not None:
+                dfo = ops.dropout(dfo, *R["k2"])
+            dz = ops.gelu_bwd(R["z"], dfo)
+            del fo, dfo, dt
             self._lin_grads(dz, R["h2"], N.fc1(i) + ".weight", acc, bias=((N.fc1(i) + ".bias", 0, cfg["hub_ffn"]),))
             dh2 = ops.gemm_nt(dz, w[f"{i}.fc1T"])
             del dz
             dx1 = ops.layernorm_bwd(R["x1"], R["m2"], R["r2"], w[f"{i}.ln2_w"], dh2, dgamma=gv(N.ln2(i) + ".weight"),
                                     dbeta=gv(N.ln2(i) + ".bias"), accumulate=acc)
             ops.add_(dx1, dx)
-            self._lin_grads(dx1, R["a"], N.out(i) + ".weight", acc, bias=((N.out(i) + ".bias", 0, d),))
-            da = ops.gemm_nt(dx1, w[f"{i}.outT"])
+            dt = dx1 if R["k1"] is None else ops.dropout(dx1, *R["k1"])
+            self._lin_grads(dt, R["a"], N.out(i) + ".weight", acc, bias=((N.out(i) + ".bias", 0, d),))
+            da = ops.gemm_nt(dt, w[f"{i}.outT"])
+            del dt
             qkv = R["qkv"]
             dqkv = torch.empty_like(qkv)
-            rp_b = self._relpos_backward_args(R, rp_state)      # WavLM: (gate, table, T, d_gate OUT, d_table ACCUMULATED)
+            rp_b = self._relpos_backward_args(R, rp_state) if R["rp"] is not None else None   # WavLM: (gate, table, T, d_gate OUT, d_table ACCUMULATED)
+            if R["rp"] is None:
+                self._zero_gate_grads(i, acc)
             ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], R["a"], da, R["lse"], dqkv[:, :d],
-                         dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask, relpos=rp_b)
+                         dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask, relpos=rp_b, drop=R["ka"])
             del da
             self._lin_grads(dqkv, R["h"], N.q(i) + ".weight", acc, N=3 * d, K=d,
                             bias=((N.q(i) + ".bias", 0, d), (N.k(i) + ".bias", d, d), (N.v(i) + ".bias", 2 * d, d)))
@@ -1341,6 +1442,8 @@ class HipHubertEncoder(nn.Module):
             S["blocks"][i] = None
         self._relpos_backward_end(rp_state, acc)
         # ---- positional conv: x0 = h + gelu(conv(h) + b) ----
+        if self._pre_ln and S["k_x"] is not None:
+            dx = ops.dropout(dx, *S["k_x"])
         G, kpos = cfg["hub_pos_groups"], cfg["hub_pos_k"]
         gch = d // G
         M = B * T
@@ -1359,6 +1462,8 @@ class HipHubertEncoder(nn.Module):
         del dpre, dx
         if S["pad_idx"] is not None:
             dh = ops.gather_rows(dh, S["pad_idx"])      # the padded frames were zero-filled in the forward: no gradient through them
+        if S["k_in"] is not None:
+            dh = ops.dropout(dh, *S["k_in"])
         # ---- feature projection: h = Linear(LayerNorm(x6)) ----
         self._lin_grads(dh, S["hN"], N.fp + ".weight", acc, bias=((N.fp + ".bias", 0, d),))
         dhN = ops.gemm_nt(dh, w["fpT"])
@@ -1409,12 +1514,21 @@ class HipHubertEncoder(nn.Module):
         dx = dout
         for i in reversed(range(cfg["hub_layers"])):
             R = S["blocks"][i]
+            if R is None:
+                self._zero_layer_grads(i, acc)
+                continue
             ds2 = ops.layernorm_bwd(R["s2"], R["m2"], R["r2"], w[f"{i}.ln2_w"], dx, dgamma=gv(N.ln2(i) + ".weight"),
                                     dbeta=gv(N.ln2(i) + ".bias"), accumulate=acc)
             fo = ops.gelu_fwd(R["z"])
-            self._lin_grads(ds2, fo, N.fc2(i) + ".weight", acc, bias=((N.fc2(i) + ".bias", 0, d),))
-            dz = ops.gelu_bwd(R["z"], ops.gemm_nt(ds2, w[f"{i}.fc2T"]))
-            del fo
+            if R["k2"] is not None:
+                fo = ops.dropout(fo, *R["k2"])
+            dt = ds2 if R["k3"] is None else ops.dropout(ds2, *R["k3"])
+            self._lin_grads(dt, fo, N.fc2(i) + ".weight", acc, bias=((N.fc2(i) + ".bias", 0, d),))
+            dfo = ops.gemm_nt(dt, w[f"{i}.fc2T"])
+            if R["k2"] is not None:
+                dfo = ops.dropout(dfo, *R["k2"])
+            dz = ops.gelu_bwd(R["z"], dfo)
+            del fo, dfo, dt
             self._lin_grads(dz, R["x1"], N.fc1(i) + ".weight", acc, bias=((N.fc1(i) + ".bias", 0, cfg["hub_ffn"]),))
             dx1 = ops.gemm_nt(dz, w[f"{i}.fc1T"])
             del dz
@@ -1423,13 +1537,17 @@ class HipHubertEncoder(nn.Module):
             ds1 = ops.layernorm_bwd(R["s1"], R["m1"], R["r1"], w[f"{i}.ln1_w"], dx1, dgamma=gv(N.ln1(i) + ".weight"),
                                     dbeta=gv(N.ln1(i) + ".bias"), accumulate=acc)
             del dx1
-            self._lin_grads(ds1, R["a"], N.out(i) + ".weight", acc, bias=((N.out(i) + ".bias", 0, d),))
-            da = ops.gemm_nt(ds1, w[f"{i}.outT"])
+            dt = ds1 if R["k1"] is None else ops.dropout(ds1, *R["k1"])
+            self._lin_grads(dt, R["a"], N.out(i) + ".weight", acc, bias=((N.out(i) + ".bias", 0, d),))
+            da = ops.gemm_nt(dt, w[f"{i}.outT"])
+            del dt
             qkv = R["qkv"]
             dqkv = torch.empty_like(qkv)
-            rp_b = self._relpos_backward_args(R, rp_state)
+            rp_b = self._relpos_backward_args(R, rp_state) if R["rp"] is not None else None
+            if R["rp"] is None:
+                self._zero_gate_grads(i, acc)
             ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], R["a"], da, R["lse"], dqkv[:, :d],
-                         dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask, relpos=rp_b)
+                         dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T, H, H, 64, False, scale, key_mask=key_mask, relpos=rp_b, drop=R["ka"])
             del da
             self._lin_grads(dqkv, R["h"], N.q(i) + ".weight", acc, N=3 * d, K=d,
                             bias=((N.q(i) + ".bias", 0, d), (N.k(i) + ".bias", d, d), (N.v(i) + ".bias", 2 * d, d)))
@@ -1439,6 +1557,8 @@ class HipHubertEncoder(nn.Module):
             if rp_b is not None:
                 ops.add_(dx, self._gate_backward(i, R, rp_b[3], acc))
             S["blocks"][i] = None
+        if S["k_x"] is not None:
+            dx = ops.dropout(dx, *S["k_x"])
         return ops.layernorm_bwd(S["x_pre"], S["mo"], S["ro"], w["lnp_w"], dx, dgamma=gv(N.enc_ln + ".weight"), dbeta=gv(N.enc_ln + ".bias"),
                                  accumulate=acc)
 
@@ -1454,6 +1574,19 @@ class HipHubertEncoder(nn.Module):
 
     def _relpos_backward_end(self, state, acc: bool):
         pass
+
+    def _zero_gate_grads(self, i: int, acc: bool):
+        pass
+
+    def _zero_layer_grads(self, i: int, acc: bool):
+        """a layer skipped by layerdrop contributes no gradient: with acc=False its slots of the flat buffer still hold the previous
+        step's values and are cleared (autograd would leave .grad = None)"""
+        if acc:
+            return
+        pre = self._nm().fc1(i).split(f"layers.{i}.")[0] + f"layers.{i}."
+        for name in self.store.offsets:
+            if name.startswith(pre):
+                self.store.grad_view(name).zero_()
 
     def _deposit_pos_weight_grad(self, dw: torch.Tensor, acc: bool):
         st, N = self.store, self._nm()
@@ -1527,8 +1660,16 @@ class HipWavLMEncoder(HipHubertEncoder):
         self._tables = {}      # the per-length bias table is a function of the (now moving) bucket embedding
 
     def _relpos_backward_begin(self, S: dict):
-        tab = self._tables[S["T"]]
+        tab = self._tables.get(S["T"])
+        if tab is None:         # layer 0 dropped on the first step at this length: no layer used the bias
+            tab = self._table(S["T"])
         return dict(tab=tab, d_tab=torch.zeros_like(tab), T=S["T"])
+
+    def _zero_gate_grads(self, i: int, acc: bool):
+        if not acc:
+            N = self._nm()
+            for name in (N.grep_w(i), N.grep_b(i), N.grep_a(i)):
+                self.store.grad_view(name).zero_()
 
     def _relpos_backward_args(self, R: dict, state):
         gate = R["rp"][0]
@@ -1622,15 +1763,19 @@ class HipWavLMEncoder(HipHubertEncoder):
         self._tables = {}
         return self
 
-    def _relpos(self, layer: int, attn_in: torch.Tensor, B: int, T: int):
-        w, H = self.w, self.cfg["hub_heads"]
+    def _table(self, T: int) -> torch.Tensor:
         tab = self._tables.get(T)
         if tab is None:
             from .host_tables import wavlm_relative_buckets
             buckets = wavlm_relative_buckets(T, self.cfg["wavlm_buckets"], self.cfg["wavlm_max_distance"]).to(self.device_)
-            tab = ops.relpos_table(w["rel_bias"].index_select(0, buckets).t().contiguous())      # [H, 2T-1] (+ slack)
+            tab = ops.relpos_table(self.w["rel_bias"].index_select(0, buckets).t().contiguous())      # [H, 2T-1] (+ slack)
             self._tables = {T: tab}
             self._buckets = {T: buckets.to(torch.int32)}
+        return tab
+
+    def _relpos(self, layer: int, attn_in: torch.Tensor, B: int, T: int):
+        w, H = self.w, self.cfg["hub_heads"]
+        tab = self._table(T)
         gate = ops.wavlm_gate(attn_in, w[f"{layer}.gw"], w[f"{layer}.gb"], w[f"{layer}.ga"], B, T, H)
         return (gate, tab, T)
 

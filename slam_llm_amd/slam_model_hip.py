@@ -120,6 +120,15 @@ def build_config(train_config, model_config) -> dict:
         enc = None
     else:
         enc = _get(model_config, "arch_encoder") or _guess_preset("whisper-" + str(_get(model_config, "encoder_path", "")).split("/")[-1].replace(".pt", ""), enc_presets)
+    if enc_name in ("hubert", "wavlm"):
+        # train-mode regularisers of the UN-FROZEN wave encoder (no effect when frozen or in eval mode): the reference module's own
+        # defaults -- WavLMConfig (models/wavlm/WavLM.py:180-185; a raw WavLM checkpoint's `cfg` overrides them in model_factory) and
+        # fairseq's HubertConfig carry the same numbers
+        extra.update(hub_dropout=float(_get(model_config, "encoder_dropout", 0.1)),
+                     hub_attention_dropout=float(_get(model_config, "encoder_attention_dropout", 0.1)),
+                     hub_activation_dropout=float(_get(model_config, "encoder_activation_dropout", 0.0)),
+                     hub_dropout_input=float(_get(model_config, "encoder_dropout_input", 0.0)),
+                     hub_layerdrop=float(_get(model_config, "encoder_layerdrop", 0.0)))
     if projector == "q-former":
         extra.update(qf_dim=768, qf_heads=12, qf_ffn=3072, qf_eps=1e-12, qf_cross_freq=2,
                      qf_layers=int(_get(model_config, "qformer_layers", 8)), qf_queries=int(_get(model_config, "query_len", 64)),
@@ -269,7 +278,17 @@ def model_factory(train_config, model_config, **kwargs):
         for key in ("encoder_state", "llm_state"):
             p = _get(model_config, key, None)
             if p:
-                W.update(_load_state(str(p)))
+                st = _load_state(str(p))
+                if key == "encoder_state" and isinstance(st, dict) and "cfg" in st and "model" in st:
+                    # a raw WavLM checkpoint {"cfg": ..., "model": state_dict} as models/encoder.py:118-121 reads it: its cfg carries the
+                    # dropout / layerdrop values the module is built with
+                    for mine, theirs in (("hub_dropout", "dropout"), ("hub_attention_dropout", "attention_dropout"),
+                                         ("hub_activation_dropout", "activation_dropout"), ("hub_dropout_input", "dropout_input"),
+                                         ("hub_layerdrop", "encoder_layerdrop")):
+                        if theirs in st["cfg"] and _get(model_config, "encoder_" + theirs.replace("encoder_", ""), None) is None:
+                            cfg[mine] = float(st["cfg"][theirs])
+                    st = {"encoder.model." + k: v for k, v in st["model"].items()}
+                W.update(st)
         if not W:
             raise FileNotFoundError("no weights given: set model_config.encoder_state / llm_state (state dicts in the "
                                     "reference's key names) or model_config.random_init=true")

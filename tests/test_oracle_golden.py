@@ -162,6 +162,39 @@ def test_wavlm_encoder_matches_the_reference_module():
         assert int(wavlm_relative_buckets(T, nb, md).max()) < nb
 
 
+@pytest.mark.parametrize("tag", ["A", "B", "C"])
+def test_wavlm_train_mode_regularisers_match_the_reference_module(tag):
+    """the un-frozen WavLM is left in train mode (slam_model.py:317-318): dropout_input, the dropout after the positional conv, per
+    layer attention_dropout / dropout1 / dropout2 / dropout3 and layerdrop, with the masks the reference module drew handed to the
+    oracle (fixture written by oracle/make_golden_wavlm_train.py from the reference's own WavLM in .train()).  A: layer 1 skipped on a
+    ragged batch; B: layer 0 skipped -- no position bias is ever created, the other layers run without bias and gate; C: all kept.
+    Output and every parameter gradient."""
+    from oracle.make_golden_cases import WAVLM_TRAIN_TINY as C
+    fx = G.load("wavlm_train_tiny")
+    W = {k: v.requires_grad_(True) for k, v in O.init_wavlm_weights(C, seed=9).items()}
+    tr = G.wavlm_train_masks(fx, tag, C["hub_layers"])
+    nv = torch.from_numpy(fx[tag + ".n_valid"])
+    wav = torch.from_numpy(fx[tag + ".wav"])
+    ragged = bool((nv != wav.shape[1]).any())
+    out = O.wavlm_encoder(W, C, wav, n_valid=nv if ragged else None, train=tr)
+    pad = O.hubert_frame_padding_mask(wav.shape[1], out.shape[1], nv)
+    G.check_packed(fx, tag + ".out", out.detach().masked_fill(pad[:, :, None], 0.0).numpy(), atol=3e-5, rtol=1e-4)
+    (out * torch.from_numpy(fx[tag + ".cot"])).sum().backward()
+    gmax = max(float(fx[f"{tag}.grad.{k}.__norm"]) for k in W if f"{tag}.grad.{k}.__norm" in fx)
+    n_none = 0
+    for k in W:
+        if f"{tag}.grad.{k}.__none" in fx:          # parameters of the skipped layer, mask_emb; in B also every gate and the bucket table
+            assert W[k].grad is None or float(W[k].grad.abs().max()) == 0.0, k
+            n_none += 1
+            continue
+        gn = float(fx[f"{tag}.grad.{k}.__norm"])
+        if k.endswith("k_proj.bias") and gn < 1e-5 * gmax:
+            continue
+        G.check_packed(fx, f"{tag}.grad.{k}", W[k].grad.numpy(), atol=1e-6 * gmax, rtol=2e-3)
+    kept = [bool(x) for x in fx[tag + ".kept"]]
+    assert n_none >= 1 + 19 * kept.count(False) and (tag != "B" or n_none >= 1 + 19 + 1 + 3 * 2)
+
+
 def test_wavlm_base_encoder_matches_the_reference_module():
     """the Base / Base+ structure (extractor_mode "default": GroupNorm over time after the first conv only; post-LN layers with the
     encoder-level LayerNorm in front of them): oracle == the reference's own WavLM on the fixture it wrote, equal-length and ragged"""

@@ -200,6 +200,15 @@ def test_wavlm_and_unfrozen_whisper_recipes_build():
     cfg = build_config(tc, mc)
     assert cfg["encoder_name"] == "wavlm" and cfg["enc_dim"] == 1024 and cfg["hub_layers"] == 24 and cfg["wavlm_buckets"] == 320 \
         and cfg["wavlm_max_distance"] == 800 and cfg["freeze_encoder"] is True
+    # the train-mode regularisers of the un-frozen wave encoder arrive with the reference module's defaults (WavLMConfig, WavLM.py:180-185)
+    # and are overridable per knob
+    assert (cfg["hub_dropout"], cfg["hub_attention_dropout"], cfg["hub_activation_dropout"], cfg["hub_dropout_input"], cfg["hub_layerdrop"]) == \
+        (0.1, 0.1, 0.0, 0.0, 0.0)
+    tc2, mc2, _ = recipe_configs("aispeech_asr", dict(encoder_name="wavlm", encoder_path="/ckpt/WavLM-Large.pt", encoder_dim=1024, llm_name="vicuna-7b-v1.5",
+                                                       llm_dim=4096, encoder_projector="linear", normalize=True, encoder_dropout=0.0,
+                                                       encoder_layerdrop=0.05), dict(freeze_encoder=False, use_peft=True))
+    cfg2 = build_config(tc2, mc2)
+    assert cfg2["hub_dropout"] == 0.0 and cfg2["hub_layerdrop"] == 0.05 and cfg2["hub_attention_dropout"] == 0.1
     tc, mc, _ = recipe_configs("asr_librispeech", dict(encoder_name="whisper", encoder_path="/ckpt/large-v3.pt", encoder_dim=1280, llm_name="llama-3-8b",
                                                         llm_dim=4096, encoder_projector="linear"), dict(freeze_encoder=False, use_peft=True))
     check_supported(tc, mc)
