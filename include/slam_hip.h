@@ -43,13 +43,15 @@ const char* slam_target_arch(void); /* "gfx950" */
  * src/slam_llm/datasets/speech_dataset_large.py:102-104.
  * audio [B, ld_audio] f32; n_valid[b] (nullable) = samples of clip b that are real (rest treated as the
  * zero padding of pad_or_trim); n_samples = padded length (480000); window400 = periodic Hann;
- * twiddle_400x416 = [n][0..207]=cos(2*pi*n*k/400), [n][208..415]=sin; mel_filters_T [201, n_mels];
+ * twiddle_folded = the folded real DFT's twiddles, fp32 [13 bin tiles][cos | sin][13 k-quads][64 lanes][4]: lane 16 g + li, k-step
+ * ks = 4 kq + j -> bin 16 tile + li at sample index n = 4 ks + g: cos(2 pi bin n / 400) for n <= 200 / sin for n < 200, zero beyond and
+ * for bins > 200 (slam_llm_amd/ops.py logmel_twiddle_table builds it); mel_filters_T [201, n_mels];
  * out_mel [B, n_samples/160, n_mels] f32; workspace: slam_logmel_workspace_bytes(B) bytes.
  * per_clip != 0: pad_or_trim OFF (speech_dataset_large.py:102-104 with pad_or_trim=false): each clip's STFT runs over its own
  * n_valid[b] samples, it owns n_valid[b]/160 frames, the remaining rows are the collator's mel-space zeros. */
 int slam_logmel_workspace_bytes(int64_t B);
 int slam_logmel_fwd(const float* audio, int64_t ld_audio, const int32_t* n_valid, int64_t n_samples,
-                    const float* window400, const float* twiddle_400x416, const float* mel_filters_T,
+                    const float* window400, const float* twiddle_folded, const float* mel_filters_T,
                     int64_t n_mels, float* out_mel, int32_t* workspace, int64_t B, int per_clip, void* stream);
 
 /* ---- GEMM: every Linear / Conv1d-as-GEMM / lm_head on the path ---------------------------------

@@ -253,17 +253,27 @@ def mel_filterbank(n_mels: int, n_fft: int = 400, sr: int = 16000):
     return (w * enorm[:, None]).astype(np.float32)
 
 
+def logmel_twiddle_table():
+    """the folded DFT's twiddles in the layout slam_logmel_fwd streams (csrc/logmel.hip): [13 bin tiles][cos | sin][13 k-quads][64 lanes][4]
+    fp32; lane = 16 * g + li holds, for k-step ks = 4 * kq + j, the value for bin 16 * tile + li at sample index n = 4 * ks + g:
+    cos(2 pi bin n / 400) for n <= 200, sin(2 pi bin n / 400) for n < 200, zero beyond (and for the 7 pad bins 201..207)"""
+    import numpy as np
+    t, p, kq, g, li, j = np.meshgrid(np.arange(13), np.arange(2), np.arange(13), np.arange(4), np.arange(16), np.arange(4), indexing="ij")
+    n = 4 * (4 * kq + j) + g
+    k = 16 * t + li
+    ang = 2.0 * np.pi * (k * n % 400).astype(np.float64) / 400.0
+    val = np.where(p == 0, np.where(n <= 200, np.cos(ang), 0.0), np.where(n < 200, np.sin(ang), 0.0))
+    val = np.where(k <= 200, val, 0.0)
+    return np.ascontiguousarray(val.astype(np.float32)).reshape(13, 2, 13, 64, 4)
+
+
 def _mel_tables(n_mels: int, device):
     key = (n_mels, str(device))
     if key not in _MEL_TABLES:
         import numpy as np
         n = np.arange(400, dtype=np.float64)
         window = (0.5 - 0.5 * np.cos(2 * np.pi * n / 400)).astype(np.float32)
-        k = np.arange(208, dtype=np.float64)
-        ang = 2 * np.pi * np.outer(n, k) / 400.0
-        tw = np.zeros((400, 416), dtype=np.float32)
-        tw[:, :201] = np.cos(ang[:, :201])
-        tw[:, 208:208 + 201] = np.sin(ang[:, :201])
+        tw = logmel_twiddle_table()
         melT = np.ascontiguousarray(mel_filterbank(n_mels).T)  # [201, n_mels]
         _MEL_TABLES[key] = tuple(torch.from_numpy(x).to(device) for x in (window, tw, melT))
     return _MEL_TABLES[key]
@@ -282,7 +292,7 @@ def logmel(audio: torch.Tensor, n_mels: int, n_samples: int = 480000, n_valid: O
         n_valid = n_valid.to(device=audio.device, dtype=torch.int32)
     window, tw, melT = _mel_tables(n_mels, audio.device)
     out = torch.empty((B, n_samples // 160, n_mels), dtype=torch.float32, device=audio.device)
-    ws = torch.empty((B,), dtype=torch.int32, device=audio.device)
+    ws = torch.empty((lib.raw().slam_logmel_workspace_bytes(B) + 3) // 4, dtype=torch.int32, device=audio.device)
     call("slam_logmel_fwd", _p(audio), audio.stride(0), _p(n_valid), n_samples, _p(window), _p(tw), _p(melT),
          n_mels, _p(out), _p(ws), B, 1 if per_clip else 0, _s())
     return out
