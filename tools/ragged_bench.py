@@ -4,7 +4,11 @@ dynamic-frame batcher, four ways on the SAME clips:
   packed_llm      ++model_config.varlen=true: pad rows dropped before the LLM (seg_lo/seg_hi attention, per-token RoPE)
   ragged          + ++model_config.varlen_encoder=true: per-clip frame counts through the encoder (no pad frames)
   ragged_sum36k   ragged, batches formed by the packed-aware budget (sum of real tokens <= 36 000 instead of B * T_max <= 12 000)
-Prints audio-seconds/sec (true clip durations, SURVEY 8d metric) for each."""
+  c5              BASELINE configs[4] style (aispeech_asr multi-task ASR + ST): the same clips with DYNAMIC PROMPTS (one of several task
+                  prompts per sample, 6 .. 40 tokens), the recipe's default LoRA (r 64, alpha 16, all seven projections, dropout 0.05),
+                  ragged encoder + packed LLM, dynamic-frame batcher
+Prints audio-seconds/sec (true clip durations, SURVEY 8d metric) for each, and one bench-style JSON line per variant whose
+config.workload names it."""
 import json
 import os
 import sys
@@ -29,21 +33,41 @@ def main():
         A = int(torch.randint(8, 129, (1,), generator=g))
         samples.append(batcher.make_sample(torch.zeros(n), torch.randint(3, 128000, (16,), generator=g).tolist(),
                                            torch.randint(3, 128000, (A - 1,), generator=g).tolist(), 2, alen))
+    # C5: a multi-task stream -- each sample draws one of eight task prompts (ASR / translation into several languages, with and
+    # without a hot-word list): prompt lengths 6 .. 40 tokens, translation answers ~1.3x as long
+    task_len = [6, 9, 12, 17, 22, 28, 34, 40]
+    samples_c5 = []
+    for s_, smp in zip(secs.tolist(), samples):
+        n = int(s_ * 16000) // 160 * 160
+        alen = batcher.whisper_audio_length(n, 5, pad_to_30s=False)
+        task = int(torch.randint(0, 8, (1,), generator=g))
+        A = int(torch.randint(8, 129, (1,), generator=g))
+        A = int(A * (1.3 if task >= 4 else 1.0))
+        samples_c5.append(batcher.make_sample(torch.zeros(n), torch.randint(3, 128000, (task_len[task],), generator=g).tolist(),
+                                              torch.randint(3, 128000, (A - 1,), generator=g).tolist(), 2, alen))
     res = {}
+    lora7 = dict(lora_r=64, lora_alpha=16, lora_targets=("q_proj", "k_proj", "v_proj", "o_proj", "up_proj", "gate_proj", "down_proj"))
     variants = [("padded", dict(), 12000, "padded"), ("packed_llm", dict(varlen=True), 12000, "padded"),
                 ("ragged", dict(varlen=True, varlen_encoder=True), 12000, "padded"),
-                ("ragged_sum36k", dict(varlen=True, varlen_encoder=True), 36000, "sum")]
+                ("ragged_sum36k", dict(varlen=True, varlen_encoder=True), 36000, "sum"),
+                ("c5", dict(varlen=True, varlen_encoder=True, **lora7), 12000, "padded")]
+    describe = {"padded": "padded (reference semantics: zero-padded mel batch, padded [B, T_max] LLM pass)",
+                "packed_llm": "model_config.varlen=true (pad rows dropped before the LLM)",
+                "ragged": "varlen + varlen_encoder (no pad frames through the encoder, packed LLM pass)",
+                "ragged_sum36k": "varlen + varlen_encoder, dataset_config.frame_budget=sum, train_max_frame_length=36000",
+                "c5": "C5 style: multi-task dynamic prompts (6..40 tokens), LoRA r64 alpha16 on all seven projections, varlen + varlen_encoder"}
     only = sys.argv[1].split(",") if len(sys.argv) > 1 else None
     for name, extra, mfl, budget in variants:
         if only and name not in only:
             continue
-        groups = list(batcher.dynamic_batches(iter(samples), mfl, budget=budget))[:-1]
+        groups = list(batcher.dynamic_batches(iter(samples_c5 if name == "c5" else samples), mfl, budget=budget))[:-1]
         if budget == "padded":
             groups = groups[:5]
         else:
             groups = groups[:3]
-        cfg = make_config("whisper-large-v3", "llama-3-8b", lora_r=16, lora_alpha=32, lora_targets=("q_proj", "v_proj"),
-                          lora_dropout=0.05, pad_or_trim=False, **extra)
+        kw = dict(lora_r=16, lora_alpha=32, lora_targets=("q_proj", "v_proj"), lora_dropout=0.05, pad_or_trim=False)
+        kw.update(extra)
+        cfg = make_config("whisper-large-v3", "llama-3-8b", **kw)
         model = SlamHipModel(cfg, dev).init_random(42)
         model.train()
         opt = SlamAdamW(model, lr=1e-4)
@@ -70,6 +94,13 @@ def main():
                          encoder_rows_real=enc_rows_real, encoder_rows_padded=enc_rows_padded,
                          peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
         print(name, res[name], flush=True)
+        print(json.dumps({"metric": "audio-seconds/sec (true clip durations; ragged set, not the headline workload)",
+                          "value": res[name]["audio_s_per_s"], "unit": "audio-s/s", "n_gpus": 1, "ms_per_step": res[name]["ms_per_batch"],
+                          "steps": len(batches), "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": f"RAGGED C3 set (clip durations ~U(2 s, 30 s), seed 1235, pad_or_trim off, answers ~U{{8..128}}, "
+                                                 f"dynamic-frame batcher): {describe[name]}; whisper-large-v3 -> llama-3-8b, full optimizer "
+                                                 f"step, GPU log-mel in the step", **{k: res[name][k] for k in ("batches", "clips", "llm_tokens_valid",
+                                                 "llm_tokens_padded", "encoder_rows_real", "encoder_rows_padded", "peak_hbm_gb")}}}), flush=True)
         del model, opt, batches
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
