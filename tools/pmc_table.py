@@ -34,7 +34,7 @@ def main():
                  "timestamps (profiled passes run ~2-3 % slower than un-profiled ones).\n\n")
         fh.write("| kernel | grid | n | us | " + " | ".join(counters) + " |\n|---|---|---|---|" + "---|" * len(counters) + "\n")
         for k in sorted(acc, key=lambda k: (-max(len(v) for v in acc[k].values()), k)):
-            if not any(s in k[0] for s in ("gemm", "attn")):
+            if not any(s in k[0] for s in ("gemm", "attn", "logmel", "lora_hop")):
                 continue
             ds = [x for (kk, d), v in dur.items() if kk == k for x in (v[1:] if len(v) > 2 else v)]
             cells = []
