@@ -1289,9 +1289,12 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
 // CUs) the in-launch form leaves the whole reduction to 48 last arrivers, ~9 us per 256 KiB slab each (672 x 4096 x 4096: 75 us
 // unsplit, 98 us with five slices); here 4 x R workgroups read the slabs at the chip's streaming rate behind one kernel boundary.
 // ------------------------------------------------------------------------------------------------------------
+// (grid 16 x R since late round 4: a workgroup adds ONE 16-row fragment strip of a quadrant -- 4 float4 per thread and slice -- with the
+// loads of up to eight slices in flight together; the 4 x R form walked the slices one dependent round trip at a time: 14 us per
+// launch, 197 launches per C4 step)
 __global__ __launch_bounds__(256) void gemm_sk_reduce_kernel(GemmParams p) {
   constexpr int BM = 256, BN = 256, WTM = 128, WTN = 128;
-  const int t = blockIdx.x >> 2, quad = blockIdx.x & 3;
+  const int t = blockIdx.x >> 4, quad = (blockIdx.x >> 2) & 3, strip = blockIdx.x & 3;
   const int nwg = p.tiles_m * p.tiles_n;
   int bid;
   {   // tail tile t -> position in the tile order: entry sk_main / 8 + t / 8 of XCD (t % 8)'s run (as in gemm_nt_w4_kernel)
@@ -1311,18 +1314,24 @@ __global__ __launch_bounds__(256) void gemm_sk_reduce_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, frow = lane & 15, fg = lane >> 4;
   const float* slab0 = p.sk_ws + (size_t)t * p.sk_S * (size_t)(BM * BN);
-  f32x4_t acc[4][4];
-  for (int sl = 0; sl < p.sk_S; sl++) {
-    const float* sp = slab0 + (size_t)sl * (BM * BN);
+  f32x4_t acc[1][4];
+  const float* sp0 = slab0 + ((size_t)((quad * 16 + strip * 4) * 256 + tid) << 2);
+  for (int s0 = 0; s0 < p.sk_S; s0 += 8) {
+    f32x4_t v[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int u = 0; u < 8; u++)
+      if (s0 + u < p.sk_S) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(sp + ((size_t)((quad * 16 + i * 4 + j) * 256 + tid) << 2));
-        acc[i][j] = sl == 0 ? v : acc[i][j] + v;
+        for (int j = 0; j < 4; j++) v[u][j] = *reinterpret_cast<const f32x4_t*>(sp0 + (size_t)(s0 + u) * (BM * BN) + ((size_t)(j * 256) << 2));
+      }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (s0 + u < p.sk_S) {       // slices in index order, as before: the same bits
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[0][j] = (s0 + u == 0) ? v[u][j] : acc[0][j] + v[u][j];
       }
   }
-  gemm_epilogue<4, 4, WTM, WTN>(p, acc, m0 + (quad >> 1) * 64, n0 + (quad & 1) * 64, wm, wn, frow, fg);
+  gemm_epilogue<1, 4, WTM, WTN>(p, acc, m0 + (quad >> 1) * 64 + strip * 16, n0 + (quad & 1) * 64, wm, wn, frow, fg);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1396,13 +1405,23 @@ __global__ __launch_bounds__(256) void gemm_ts_reduce_kernel(GemmParams p, TsPla
 #pragma unroll
   for (int j = 0; j < 4; j++) acc[0][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (m < p.M) {
-    for (int sl = 0; sl < pl.S; sl++) {
-      const float* wrow = pl.ws + ((size_t)sl * p.M + m) * 64;
+    // eight slices' loads in flight together (one dependent round trip per slice: 25 us for the 48 slices of the C4 shape, more than the
+    // product itself); the sums stay in slice order
+    for (int s0 = 0; s0 < pl.S; s0 += 8) {
+      f32x4_t v[8][4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(wrow + j * 16 + fg * 4);
-        acc[0][j] = sl == 0 ? v : acc[0][j] + v;
-      }
+      for (int u = 0; u < 8; u++)
+        if (s0 + u < pl.S) {
+          const float* wrow = pl.ws + ((size_t)(s0 + u) * p.M + m) * 64;
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[u][j] = *reinterpret_cast<const f32x4_t*>(wrow + j * 16 + fg * 4);
+        }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (s0 + u < pl.S) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[0][j] = (s0 + u == 0) ? v[u][j] : acc[0][j] + v[u][j];
+        }
     }
   }
   gemm_epilogue_generic<1, 4, 16, 64>(p, acc, m0, 0, wave, 0, frow, fg);   // (all lanes: the 16-byte store path exchanges lane rows)
@@ -1507,7 +1526,7 @@ int launch_gemm_w4(GemmParams& p, hipStream_t stream, int want_two = 0) {   // w
     if (p.sk_S > 1 && two) {
       const int rc = launch_gemm_w4_impl<BM, BN, REG, ABL, false, 2>(p, nwg, stream);
       if (rc == 0) {
-        hipLaunchKernelGGL(gemm_sk_reduce_kernel, dim3((unsigned)(4 * p.sk_R)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(gemm_sk_reduce_kernel, dim3((unsigned)(16 * p.sk_R)), dim3(256), 0, stream, p);
         SLAM_CHECK_LAUNCH("slam_gemm_bf16_nt(split-K reduce)");
       }
       return rc;
