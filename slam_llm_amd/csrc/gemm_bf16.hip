@@ -1399,8 +1399,8 @@ __global__ __launch_bounds__(256) void gemm_ts_kernel(GemmParams p, TsPlan pl) {
 __global__ __launch_bounds__(256) void gemm_ts_reduce_kernel(GemmParams p, TsPlan pl) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fg = lane >> 4;
-  const int m0 = blockIdx.x * 64;
-  const int m = m0 + wave * 16 + frow;
+  const int m0 = blockIdx.x * (16 * (blockDim.x >> 6));   // launched with ONE wave per workgroup: 16 rows each, so that M / 16 CUs pull the slabs
+  const int m = m0 + wave * 16 + frow;                    // (64-row workgroups: 11 CUs for the 672-row C4 products, each bound by its own fill rate)
   f32x4_t acc[1][4];
 #pragma unroll
   for (int j = 0; j < 4; j++) acc[0][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -1448,7 +1448,7 @@ static bool launch_gemm_ts(GemmParams& p, hipStream_t stream, int* rc) {
   }
   TsPlan pl{S, nk, ws};
   hipLaunchKernelGGL(gemm_ts_kernel, dim3((unsigned)rb, (unsigned)S), dim3(256), 0, stream, p, pl);
-  if (S > 1) hipLaunchKernelGGL(gemm_ts_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, p, pl);
+  if (S > 1) hipLaunchKernelGGL(gemm_ts_reduce_kernel, dim3((unsigned)((p.M + 15) / 16)), dim3(64), 0, stream, p, pl);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     slam_set_error("slam_gemm_bf16_nt(tall-skinny): launch failed: %s", hipGetErrorString(e));
