@@ -979,6 +979,23 @@ def test_logmel_vs_golden_and_oracle(dev, n_mels):
     assert_close(mel, full, atol=1e-4, rtol=0, what="logmel vs oracle")
 
 
+@pytest.mark.parametrize("n_mels,secs", [(20, 1.0), (100, 2.3), (256, 1.5), (128, 30.0)])
+def test_logmel_other_filter_counts_and_lengths(dev, n_mels, secs):
+    """the round-4 kernel's thread -> (filter, frames) mapping at filter counts that do not divide its 512 threads (100), need two
+    8-frame passes per thread (256) or leave most of a frame group idle (20), on clips whose frame count is not a multiple of the
+    32-frame block, and one full 30 s clip (94 blocks walked by one workgroup chain); against the oracle, same 1e-4 tolerance"""
+    ops = _ops()
+    from oracle import slam_oracle as O
+    n = int(secs * 16000) // 160 * 160
+    g = torch.Generator().manual_seed(n_mels)
+    audio = (torch.randn(3, n, generator=g) * 0.1).clamp(-1, 1)
+    audio[1, n // 2:] = 0.0                      # a silent tail: the clamp at 1e-10 and the max - 8 floor are live
+    mel = ops.logmel(audio.to(dev), n_mels, n_samples=n).cpu()
+    ref = torch.stack([O.log_mel_spectrogram(a, n_mels) for a in audio]).permute(0, 2, 1)
+    assert mel.shape == ref.shape == (3, n // 160, n_mels)
+    assert_close(mel, ref, atol=1e-4, rtol=0, what=f"logmel n_mels={n_mels}")
+
+
 def test_logmel_per_clip_ragged(dev):
     """pad_or_trim off: each clip's own STFT/floor, mel-space zero padding to the batch maximum (speech_dataset_large.py)"""
     ops = _ops()
@@ -1037,7 +1054,7 @@ def test_lora_first_hop_and_gram_recompute_the_dropout_mask(dev, M, K, R, p):
         assert_close(g1, ref, atol=2e-2 * float(ref.abs().max()), rtol=2e-2, what="dA with recomputed mask")
 
 
-@pytest.mark.parametrize("M,K,R,sr", [(700, 512, 64, 32), (11780, 4096, 64, 32), (100, 256, 64, 8), (380, 2048, 64, 16)])
+@pytest.mark.parametrize("M,K,R,sr", [(700, 512, 64, 32), (11780, 4096, 64, 32), (100, 256, 64, 8), (380, 2048, 64, 16), (130, 264, 64, 16), (3000, 1096, 64, 64)])
 def test_lora_hop_dropout_equals_the_two_launch_form(dev, M, K, R, sr):
     """slam_lora_hop_dropout (second hop of the LoRA backward + recomputed dropout mask + accumulate, one pass over dx) is BIT-identical to
     the product into a scratch buffer followed by slam_dropout_bf16(accumulate) -- same MFMA order, same two bf16 roundings, same mask"""
