@@ -61,17 +61,17 @@ def find_seed(pattern, layerdrop):
     raise RuntimeError("no seed")
 
 
-def build(c):
+def build(c, seed=9):
     from slam_llm.models.encoder import WavLMEncoder
     from slam_llm.models.wavlm.WavLM import WavLM, WavLMConfig
     layers = "[" + ", ".join(f"({co},{k},{s})" for co, k, s in zip(c["hub_conv_dim"], c["hub_conv_kernel"], c["hub_conv_stride"])) + "]"
     cfg = WavLMConfig(dict(extractor_mode=c["hub_extractor_mode"], encoder_layers=c["hub_layers"], encoder_embed_dim=c["hub_dim"],
                            encoder_ffn_embed_dim=c["hub_ffn"], encoder_attention_heads=c["hub_heads"], layer_norm_first=c["hub_layer_norm_first"],
-                           conv_feature_layers=layers, conv_bias=False, normalize=True, conv_pos=c["hub_pos_k"],
+                           conv_feature_layers=layers, conv_bias=False, normalize=c["hub_layer_norm_first"], conv_pos=c["hub_pos_k"],
                            conv_pos_groups=c["hub_pos_groups"], relative_position_embedding=True, num_buckets=c["wavlm_buckets"],
                            max_distance=c["wavlm_max_distance"], gru_rel_pos=True, **WAVLM_TRAIN_REG))
     model = WavLM(cfg)
-    W = O.init_wavlm_weights(c, seed=9)
+    W = O.init_wavlm_weights(c, seed=seed)
     model.load_state_dict({k[len("encoder.model."):]: v for k, v in W.items()}, strict=True)
     return WavLMEncoder(cfg, model), W
 
@@ -86,12 +86,13 @@ def train_dict(masks, kept, n_layers):
     return tr
 
 
-def one_case(fx, tag, pattern, ragged):
-    c = WAVLM_TRAIN_TINY
-    enc, W = build(c)
+def one_case(fx, tag, pattern, ragged, c=WAVLM_TRAIN_TINY, seed=9):
+    enc, W = build(c, seed)
     enc.train()
     N = 16000
-    wav = torch.nn.functional.layer_norm(O.synth_audio(2, 1.0, seed=31), (N,))
+    wav = O.synth_audio(2, 1.0, seed=31)
+    if c["hub_layer_norm_first"]:       # the large checkpoints' cfg has normalize=True (dataset-side layer norm), the base ones have not
+        wav = torch.nn.functional.layer_norm(wav, (N,))
     nv = torch.tensor([N, 11200] if ragged else [N, N])
     if ragged:
         wav[1, int(nv[1]):] = 0.0
@@ -169,6 +170,12 @@ def main():
     one_case(fx, "A", (True, False, True), ragged=True)        # layer 1 skipped, ragged batch
     one_case(fx, "B", (False, True, True), ragged=False)       # layer 0 skipped: no position bias at all
     one_case(fx, "C", (True, True, True), ragged=False)
+    # Base / Base+ structure (group-norm extractor, post-LN layers: the dropout after the positional conv sits behind the encoder LayerNorm,
+    # WavLM.py:582-584; dropout1 / dropout3 before the residual adds that the LayerNorms follow, :716-739)
+    from oracle.make_golden_cases import WAVLM_BASE_TINY
+    fx["base.weights_sha256"] = np.array(wsum(O.init_wavlm_weights(WAVLM_BASE_TINY, seed=10)))
+    one_case(fx, "D", (True, True), ragged=True, c=WAVLM_BASE_TINY, seed=10)
+    one_case(fx, "E", (True, False), ragged=False, c=WAVLM_BASE_TINY, seed=10)
     np.savez_compressed(os.path.join(GOLD, "wavlm_train_tiny.npz"), **fx)
     print("wavlm_train_tiny.npz written", os.path.getsize(os.path.join(GOLD, "wavlm_train_tiny.npz")), "bytes")
 

@@ -287,7 +287,7 @@ def test_unfrozen_wavlm_encoder_matches_oracle(dev, ragged):
     _unfrozen_wave_encoder_case(dev, "wavlm", ragged)
 
 
-@pytest.mark.parametrize("tag", ["A", "B", "C"])
+@pytest.mark.parametrize("tag", ["A", "B", "C", "D", "E"])
 def test_unfrozen_wavlm_train_mode_regularisers_match_oracle_with_the_same_masks(dev, tag):
     """VERDICT r3 missing #4: the un-frozen WavLM is left in TRAIN mode by the reference (slam_model.py:317-318): dropout_input, the
     dropout after the positional conv, attention_dropout inside the attention kernels (on top of the gated bias), dropout1 / 2 / 3 of
@@ -295,26 +295,57 @@ def test_unfrozen_wavlm_train_mode_regularisers_match_oracle_with_the_same_masks
     numpy-stream layerdrop decisions; the masks it drew are rebuilt from their keys / seeds, the kept-layer pattern is read from its
     stash, both go to the fp32 oracle (itself pinned against the reference module in .train(), tests/golden/wavlm_train_tiny.npz), and
     output + every parameter gradient must agree.  A: layer 1 skipped, ragged batch; B: layer 0 skipped (no position bias anywhere,
-    the gates' and the bucket table's gradients are exactly zero); C: nothing skipped.  Then eval mode: no key is drawn and the output
-    equals the deterministic graph's; p = 0 in train mode: bit-identical to eval."""
-    from oracle.make_golden_cases import WAVLM_TRAIN_TINY as C
-    from slam_llm_amd import ops
-    from slam_llm_amd.model import HipWavLMEncoder, TrainableStore
+    the gates' and the bucket table's gradients are exactly zero); C: nothing skipped; D / E: the Base structure (post-LN layers: the
+    dropout after the positional conv sits behind the encoder LayerNorm, dropout1 / 3 in front of the LayerNorms), ragged batch all
+    kept / layer 1 skipped.  Then eval mode: no key is drawn and the output equals the deterministic graph's; p = 0 in train mode:
+    bit-identical to eval."""
+    from oracle.make_golden_cases import WAVLM_BASE_TINY, WAVLM_TRAIN_TINY
+    from slam_llm_amd.model import HipWavLMEncoder
+    C, wseed = (WAVLM_TRAIN_TINY, 9) if tag in "ABC" else (WAVLM_BASE_TINY, 10)
     fx = G.load("wavlm_train_tiny")
     pattern = tuple(bool(k) for k in fx[tag + ".kept"])
+    _wave_train_mode_case(dev, tag, HipWavLMEncoder, C, O.init_wavlm_weights(C, seed=wseed), O.wavlm_encoder, torch.from_numpy(fx[tag + ".wav"]),
+                          [int(x) for x in fx[tag + ".n_valid"]], pattern, torch.from_numpy(fx[tag + ".cot"]), {}, True, 1 + 19 * pattern.count(False))
+
+
+@pytest.mark.parametrize("pattern,ragged", [((True, True), True), ((True, False), False)])
+def test_unfrozen_hubert_train_mode_regularisers_match_oracle_with_the_same_masks(dev, pattern, ragged):
+    """the same regularisers on the un-frozen HuBERT (fairseq's wav2vec2 TransformerEncoder: the module tree WavLM.py vendors, minus the
+    position bias): fairseq parameter names and (g, v) of the positional conv in the store, the oracle's HF-named twin reached through the
+    key map; masks rebuilt from the keys, kept-layer pattern from numpy's stream (the reference module itself is un-vendored fairseq:
+    the sites are the ones pinned for WavLM)"""
+    from oracle.make_golden_cases import HUBERT_TINY as C
+    from slam_llm_amd.model import HipHubertEncoder
+    W = O.init_hubert_weights(C, seed=7, weight_norm=True)
+    N = 16000
+    wav = torch.nn.functional.layer_norm(O.synth_audio(2, 1.0, seed=33), (N,))
+    nv = [N, 11200] if ragged else [N, N]
+    if ragged:
+        wav[1, nv[1]:] = 0.0
+    T = O.hubert_encoder(W, C, wav[:1, :N]).shape[1]
+    cot = torch.randn((2, T, C["hub_dim"]), generator=torch.Generator().manual_seed(5)) * 0.1
+    cot = cot.masked_fill(O.hubert_frame_padding_mask(N, T, torch.tensor(nv))[:, :, None], 0.0)
+    probe = HipHubertEncoder(dict(C), dev, store=__import__("slam_llm_amd.model", fromlist=["TrainableStore"]).TrainableStore(dev))
+    kmap = {hf: fs for fs, hf in probe.key_map("hf").items()}       # oracle (HF) name -> store (fairseq) name
+    kmap["encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = "encoder.encoder.pos_conv.0.weight_g"
+    kmap["encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = "encoder.encoder.pos_conv.0.weight_v"
+    _wave_train_mode_case(dev, f"hubert {pattern}", HipHubertEncoder, C, W, O.hubert_encoder, wav, nv, pattern, cot, kmap, False,
+                          16 * pattern.count(False))
+
+
+def _wave_train_mode_case(dev, tag, enc_cls, C, W, oracle_fn, wav, nv, pattern, cot, kmap, has_relpos, min_zero):
+    from slam_llm_amd import ops
+    from slam_llm_amd.model import TrainableStore
     reg = dict(hub_dropout=0.1, hub_attention_dropout=0.1, hub_activation_dropout=0.1, hub_dropout_input=0.1, hub_layerdrop=0.4)
-    W = O.init_wavlm_weights(C, seed=9)
     store = TrainableStore(dev)
     cfg = dict(C, **reg)
-    enc = HipWavLMEncoder(cfg, dev, store=store)
+    enc = enc_cls(cfg, dev, store=store)
     store.allocate()
     enc.bind()
     enc.load(W)
     store.refresh_bf16()
     enc.refresh()
     enc.train()
-    wav = torch.from_numpy(fx[tag + ".wav"])
-    nv = [int(x) for x in fx[tag + ".n_valid"]]
     ragged = any(n != wav.shape[1] for n in nv)
     np.random.seed(G.layerdrop_seed(pattern, 0.4))
     stash = {}
@@ -335,22 +366,21 @@ def test_unfrozen_wavlm_train_mode_regularisers_match_oracle_with_the_same_masks
             continue
         am = torch.from_numpy(G.attn_keep_mask(R["ka"][1], 0.1, B, H, T, T, Tp, Tp)) / 0.9
         tr["layers"].append(dict(attn=am, d1=hid(R["k1"]), d2=hid(R["k2"], C["hub_ffn"]), d3=hid(R["k3"])))
-        assert (R["rp"] is None) == (not pattern[0])
+        assert (R["rp"] is None) == (not pattern[0] or not has_relpos)
     frac = torch.cat([m.reshape(-1) for m in [tr["input"], tr["x"]] + [v for lm in tr["layers"] if lm for v in lm.values()]]).ne(0).float().mean()
     assert abs(float(frac) - 0.9) < 0.01, float(frac)
     Wg = {k: v.clone().requires_grad_(True) for k, v in W.items()}
-    ref = O.wavlm_encoder(Wg, C, wav, n_valid=torch.tensor(nv) if ragged else None, train=tr)
+    ref = oracle_fn(Wg, C, wav, n_valid=torch.tensor(nv) if ragged else None, train=tr)
     pad = O.hubert_frame_padding_mask(wav.shape[1], T, torch.tensor(nv))
     a = out.float().cpu().masked_fill(pad[:, :, None], 0.0).numpy()
     g = ref.detach().masked_fill(pad[:, :, None], 0.0).numpy()
     assert rel_err(a, g) < 3e-2 and G.cosine(g, a) > 0.9995, (rel_err(a, g), G.cosine(g, a))
-    cot = torch.from_numpy(fx[tag + ".cot"])
     (ref * cot).sum().backward()
     enc.backward_hip(cot.to(dev).to(torch.bfloat16).reshape(B * T, d).contiguous(), stash, acc=False)
     gmax = max(float(v.grad.norm()) for v in Wg.values() if v.grad is not None)
     worst, n_zero, bad = (1.0, ""), 0, []
     for n in W:
-        mine = store.grad_view(n).float().cpu().reshape(W[n].shape)
+        mine = store.grad_view(kmap.get(n, n)).float().cpu().reshape(W[n].shape)
         if Wg[n].grad is None or float(Wg[n].grad.abs().max()) == 0.0:     # the skipped layer, mask_emb, in B every gate + the bucket table
             assert float(mine.abs().max()) == 0.0, n
             n_zero += 1
@@ -375,9 +405,9 @@ def test_unfrozen_wavlm_train_mode_regularisers_match_oracle_with_the_same_masks
         if cs <= floor or nr >= 6e-2:
             bad.append((n, round(cs, 5), round(nr, 4)))
     assert not bad, bad
-    assert n_zero >= 1 + 19 * pattern.count(False)
+    assert n_zero >= min_zero
     if os.environ.get("SLAM_TEST_VERBOSE"):
-        print(f"wavlm train-mode {tag}: worst gradient cosine {worst}")
+        print(f"train-mode {tag}: worst gradient cosine {worst}")
     # eval mode: nothing drawn; train mode at p = 0: the deterministic graph, bit for bit
     calls = enc._drop_calls
     enc.eval()

@@ -162,16 +162,18 @@ def test_wavlm_encoder_matches_the_reference_module():
         assert int(wavlm_relative_buckets(T, nb, md).max()) < nb
 
 
-@pytest.mark.parametrize("tag", ["A", "B", "C"])
+@pytest.mark.parametrize("tag", ["A", "B", "C", "D", "E"])
 def test_wavlm_train_mode_regularisers_match_the_reference_module(tag):
     """the un-frozen WavLM is left in train mode (slam_model.py:317-318): dropout_input, the dropout after the positional conv, per
     layer attention_dropout / dropout1 / dropout2 / dropout3 and layerdrop, with the masks the reference module drew handed to the
     oracle (fixture written by oracle/make_golden_wavlm_train.py from the reference's own WavLM in .train()).  A: layer 1 skipped on a
-    ragged batch; B: layer 0 skipped -- no position bias is ever created, the other layers run without bias and gate; C: all kept.
+    ragged batch; B: layer 0 skipped -- no position bias is ever created, the other layers run without bias and gate; C: all kept;
+    D / E: the Base structure (group-norm extractor, post-LN layers), all kept on a ragged batch / layer 1 skipped.
     Output and every parameter gradient."""
-    from oracle.make_golden_cases import WAVLM_TRAIN_TINY as C
+    from oracle.make_golden_cases import WAVLM_BASE_TINY, WAVLM_TRAIN_TINY
+    C, wseed = (WAVLM_TRAIN_TINY, 9) if tag in "ABC" else (WAVLM_BASE_TINY, 10)
     fx = G.load("wavlm_train_tiny")
-    W = {k: v.requires_grad_(True) for k, v in O.init_wavlm_weights(C, seed=9).items()}
+    W = {k: v.requires_grad_(True) for k, v in O.init_wavlm_weights(C, seed=wseed).items()}
     tr = G.wavlm_train_masks(fx, tag, C["hub_layers"])
     nv = torch.from_numpy(fx[tag + ".n_valid"])
     wav = torch.from_numpy(fx[tag + ".wav"])
@@ -193,6 +195,7 @@ def test_wavlm_train_mode_regularisers_match_the_reference_module(tag):
         G.check_packed(fx, f"{tag}.grad.{k}", W[k].grad.numpy(), atol=1e-6 * gmax, rtol=2e-3)
     kept = [bool(x) for x in fx[tag + ".kept"]]
     assert n_none >= 1 + 19 * kept.count(False) and (tag != "B" or n_none >= 1 + 19 + 1 + 3 * 2)
+    assert len(kept) == C["hub_layers"]
 
 
 def test_wavlm_base_encoder_matches_the_reference_module():
