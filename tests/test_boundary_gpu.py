@@ -125,6 +125,58 @@ def test_fresh_finetune_initialises_projector_and_lora_like_the_reference(dev, t
     assert min(nz_b) > 0, "dB must be non-zero when A is initialised (B = 0 only zeroes dA on the first step)"
 
 
+def test_raw_wavlm_checkpoint_supplies_its_regularisers_and_trains(dev, tmp_path):
+    """models/encoder.py:118-121 reads a WavLM checkpoint as {"cfg": ..., "model": state_dict} and builds the module from that cfg.  Given
+    as `encoder_state` with train_config.freeze_encoder=false, the factory unwraps it (keys gain the `encoder.model.` prefix), takes
+    dropout / attention_dropout / activation_dropout / dropout_input / encoder_layerdrop from ITS cfg (a model_config.encoder_* value
+    would win), and the un-frozen encoder then runs in train mode with them: masks are drawn (the counter moves), eval mode draws none,
+    every encoder parameter outside a skipped layer gets a gradient."""
+    from oracle.make_golden_cases import WAVLM_TINY
+    from slam_llm_amd.slam_model_hip import model_factory
+    cfg = dict(O.make_config(), **WAVLM_TINY)
+    cfg.update(encoder_name="wavlm", enc_dim=WAVLM_TINY["hub_dim"])
+    W = O.init_weights(cfg, seed=42)
+    enc_sd = {k[len("encoder.model."):]: v for k, v in O.init_wavlm_weights(WAVLM_TINY, seed=9).items()}
+    torch.save({"cfg": {"dropout": 0.2, "attention_dropout": 0.05, "activation_dropout": 0.0, "encoder_layerdrop": 0.0, "dropout_input": 0.1,
+                        "encoder_layers": WAVLM_TINY["hub_layers"]}, "model": enc_sd}, tmp_path / "WavLM-Tiny.pt")
+    torch.save({k: v for k, v in W.items() if k.startswith("llm.") and k not in O.trainable_names(W)}, tmp_path / "llm.pt")
+    arch = dict(TINY_ARCH, **{k: (list(v) if isinstance(v, tuple) else v) for k, v in WAVLM_TINY.items()}, enc_dim=WAVLM_TINY["hub_dim"])
+    tc, mc, _ = recipe_configs("asr_librispeech",
+                               model=dict(encoder_name="wavlm", encoder_path="/ckpt/WavLM-Large.pt", llm_name="tinyllama-1.1b",
+                                          encoder_dim=WAVLM_TINY["hub_dim"], llm_dim=128, arch_overrides=arch, normalize=True,
+                                          encoder_state=str(tmp_path / "WavLM-Tiny.pt"), llm_state=str(tmp_path / "llm.pt"),
+                                          encoder_attention_dropout=0.15),
+                               train=dict(use_peft=True, freeze_encoder=False, freeze_llm=True, seed=7))
+    model, _ = model_factory(tc, mc)
+    c = model.encoder.cfg
+    assert (c["hub_dropout"], c["hub_dropout_input"], c["hub_layerdrop"], c["hub_activation_dropout"]) == (0.2, 0.1, 0.0, 0.0)
+    assert c["hub_attention_dropout"] == 0.15                      # the recipe's own value wins over the checkpoint's 0.05
+    assert "encoder.model.encoder.layers.0.self_attn.grep_a" in model.store.params
+    got = model.store.params["encoder.model.post_extract_proj.weight"].detach().cpu()
+    assert torch.equal(got, enc_sd["post_extract_proj.weight"])
+    model.train()
+    N = 16000
+    wav = torch.nn.functional.layer_norm(O.synth_audio(2, 1.0, seed=9), (N,))
+    alen = N // 320 // 5
+    ob = O.collate_left_pad([O.make_sample(alen, [5, 6, 7], [9, 10, 11], 2), O.make_sample(alen, [5, 6], [9, 10], 2)], pad_id=2)
+    gb = {k: v.to(dev) for k, v in ob.items()}
+    gb["audio"] = wav.to(dev)
+    gb["audio_len"] = torch.tensor([N, N], dtype=torch.int32, device=dev)
+    calls = model.encoder._drop_calls
+    out, _ = model(**{k: v.clone() for k, v in gb.items()})
+    out.loss.backward()
+    assert model.encoder._drop_calls > calls                       # train mode: masks were drawn
+    assert float(model.store.grad_view("encoder.model.encoder.layers.1.fc1.weight").abs().max()) > 0
+    assert float(model.store.grad_view("encoder.model.feature_extractor.conv_layers.0.0.weight").abs().max()) > 0
+    l_train = float(out.loss.detach())
+    model.eval()
+    calls = model.encoder._drop_calls
+    with torch.no_grad():
+        e1, _ = model(**{k: v.clone() for k, v in gb.items()})
+        e2, _ = model(**{k: v.clone() for k, v in gb.items()})
+    assert model.encoder._drop_calls == calls and float(e1.loss) == float(e2.loss) and np.isfinite(l_train)
+
+
 def test_slam_adamw_state_dict_round_trip(dev):
     """moments + step survive state_dict()/load_state_dict(): a resumed run continues bit for bit."""
     from slam_llm_amd.model import SlamAdamW, SlamHipModel
