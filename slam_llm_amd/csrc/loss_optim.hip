@@ -557,9 +557,11 @@ __global__ __launch_bounds__((NT <= 2 ? 8 : 4) * 64, 2) void lora_a_fwd_kernel(c
 // slam_dropout_bf16(accumulate) over it (96 + 290 MB of traffic per Llama layer at the C3 shape for a 193 MB update) -- now one pass over
 // dx: the product on the MFMA (R / 32 k-steps, operands straight from global memory: A^T fragments stay in registers, du is L2-resident),
 // fp32 values exchanged between lane rows (v_permlane16_swap, v_permlane32_swap) so that a lane owns SIXTEEN consecutive columns = two
-// 16-byte loads + stores of dx and two slam_keep8 mask words.  Measured 50.6 us against 70.4 us for the two launches at [11780, 4096]
-// (3.8 TB/s of algorithmic traffic); what bounds it now is the mask itself -- three 64-bit multiplies per four elements, quarter-rate
-// VALU -- which is shared with every other kernel that applies or rebuilds the mask and with the oracle, so it stays.  Rounding
+// 16-byte loads + stores of dx and two slam_keep8 mask words.  Measured 48 us against 71 us for the two launches at [11780, 4096]
+// (4.0 TB/s of algorithmic traffic).  What bounds it is instruction issue, ~1500 cycles per 16 x 64 block and wave (conversions, the
+// mask's compares / selects, eight exchanges, address arithmetic): 47 k blocks on 1024 SIMDs = 33 us at 2.1 GHz.  NOT the mask hash (a
+// three-multiply 32-bit hash was built, validated and measured: 51.2 -> 51.2 us, reverted) and not the width of the row segments
+// (four waves on neighbouring column blocks = 512 contiguous bytes per row: 51 -> 50 us, kept); the grid is one residency round.  Rounding
 // reproduces the two-launch form bit for
 // bit: the product is rounded to bf16 before the mask / scale, the sum once more.
 // ------------------------------------------------------------------------------------------------------------
@@ -571,13 +573,14 @@ template <int KS>   // KS = R / 32 k-steps (R <= 64, zero-padded to a multiple o
 __global__ __launch_bounds__(256) void lora_hop_drop_kernel(const bf16_t* __restrict__ DU, int64_t lddu, const bf16_t* __restrict__ AT, int64_t ldat,
                                                             bf16_t* __restrict__ DX, int64_t lddx, int M, int K, int nrb, float inv_keep,
                                                             unsigned thresh, unsigned long long seed, unsigned long long offset) {
-  // workgroup = one 64-column block of dx (its four fragments of A^T stay in registers), walking row blocks blockIdx.y, + gridDim.y, ...;
+  // workgroup = 256 columns of dx (one 64-column block per wave, its four fragments of A^T in registers) x 16-row blocks blockIdx.y, + gridDim.y, ...
+  // (a wave per 16 ROWS of one 64-column block -- 128-byte row segments at an 8 KiB pitch -- held 3.8 TB/s whatever the mask cost);
   // the next row block's du and dx pieces are requested before the current one is computed.  (The first form -- a 64 x 256 tile per
   // workgroup with all sixteen A^T fragments preloaded -- used ~200 VGPRs, ran 2 waves / SIMD and reached 2.3 TB/s.)
   typedef __attribute__((ext_vector_type(8))) __bf16 bfrag_t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int frow = lane & 15, fg = lane >> 4;
-  const int n0 = blockIdx.x * 64;
+  const int n0 = (blockIdx.x * 4 + wave) * 64;     // the four waves take NEIGHBOURING 64-column blocks of the same 16 rows: 512 contiguous bytes per row
   const int nn = n0 + fg * 16;                       // this lane's 16 consecutive columns after the two exchange levels
   bfrag_t bf[4][KS];
 #pragma unroll
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(256) void lora_hop_drop_kernel(const bf16_t* __rest
   u16x8_t old_n[2][2];
   const int G = gridDim.y;
   auto request = [&](bfrag_t (&a)[KS], u16x8_t (&o)[2], int rb) {
-    const int m = rb * 64 + wave * 16 + frow;
+    const int m = rb * 16 + frow;
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) a[ks] = *reinterpret_cast<const bfrag_t*>(DU + (int64_t)min(m, M - 1) * lddu + ks * 32 + fg * 8);
 #pragma unroll
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(256) void lora_hop_drop_kernel(const bf16_t* __rest
       if (m < M && nn + 8 * h < K) o[h] = *reinterpret_cast<const u16x8_t*>(DX + (int64_t)m * lddx + nn + 8 * h);
   };
   auto compute = [&](const bfrag_t (&af)[KS], const u16x8_t (&old)[2], int rb) {
-    const int m = rb * 64 + wave * 16 + frow;
+    const int m = rb * 16 + frow;
     f32x4_t acc[4];
 #pragma unroll
     for (int hh = 0; hh < 4; hh++) {
@@ -688,8 +691,8 @@ extern "C" int slam_lora_hop_dropout(const void* DU, int64_t lddu, const void* A
   SLAM_CHECK_ARG(drop_p > 0.f && drop_p < 1.f && offset % 8 == 0, "slam_lora_hop_dropout: drop_p in (0, 1), offset %% 8 == 0");
   const unsigned th = slam_drop_thresh16(drop_p);
   const float inv_keep = 1.0f / (1.0f - drop_p);
-  const int nrb = (int)cdiv64(M, 64), ncb = (int)cdiv64(K, 64);
-  const int chunks = (int)std::min<int64_t>(nrb, std::max<int64_t>(1, cdiv64(2048, ncb)));   // >= 8 workgroups per CU when M allows
+  const int nrb = (int)cdiv64(M, 16), ncb = (int)cdiv64(K, 256);
+  const int chunks = (int)std::min<int64_t>(nrb, std::max<int64_t>(1, 1024 / ncb));   // 4 workgroups per CU are resident (128 VGPRs): exactly one round
   dim3 grid((unsigned)ncb, (unsigned)chunks);
   hipStream_t s = (hipStream_t)stream;
   if (R == 32)

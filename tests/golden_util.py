@@ -35,21 +35,29 @@ def cosine(a, b):
     return float((a * b).sum() / (np.sqrt((a * a).sum() * (b * b).sum()) + 1e-30))
 
 
+def mix64(seed: int, q):
+    """host restatement of the mask hash of csrc/common.h: slam_mix64(seed ^ (q * 0xD1342543DE82EF95)) -- the splitmix64 finaliser over the
+    group index q = element index >> 2; q = uint64 array"""
+    q = np.asarray(q, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & (2 ** 64 - 1)) ^ (q * np.uint64(0xD1342543DE82EF95))
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
 def attn_keep_mask(seed: int, p: float, B: int, H: int, Tq: int, Tk: int, Tqp: int, Tkp: int):
     """host restatement of the attention kernels' counter-based dropout mask (csrc/attention.hip attn_keep4 over
     csrc/common.h slam_mix64): element (b, h, q, k) lives at index ((b*H + h)*Tqp + q)*Tkp + k; one splitmix64 word per group of
-    4 consecutive indices, 16 bits each, keep = bits >= round(p * 65536).  Returns float32 [B, H, Tq, Tk] of 0 / 1."""
+    4 consecutive indices (mix64 below), 16 bits each, keep = bits >= round(p * 65536).  Returns float32 [B, H, Tq, Tk] of 0 / 1."""
     import numpy as np
     thresh = min(65535, int(p * 65536.0 + 0.5))
     b, h, q, k = np.meshgrid(np.arange(B, dtype=np.uint64), np.arange(H, dtype=np.uint64), np.arange(Tq, dtype=np.uint64),
                              np.arange(Tk, dtype=np.uint64), indexing="ij")
     idx = ((b * np.uint64(H) + h) * np.uint64(Tqp) + q) * np.uint64(Tkp) + k
-    with np.errstate(over="ignore"):
-        z = np.uint64(seed & (2 ** 64 - 1)) ^ ((idx >> np.uint64(2)) * np.uint64(0xD1342543DE82EF95))
-        z = z + np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
+    z = mix64(seed, idx >> np.uint64(2))
     bits = (z >> (np.uint64(16) * (idx & np.uint64(3)))) & np.uint64(0xFFFF)
     return (bits >= np.uint64(thresh)).astype(np.float32)
 

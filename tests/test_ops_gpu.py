@@ -1025,6 +1025,16 @@ def test_dropout_mask_properties(dev):
     assert torch.equal(y1, y2) and not torch.equal(y1, y3)          # pure function of (seed, offset, index)
     ones = torch.ones((M, N), dtype=torch.bfloat16, device=dev)
     mask = ops.dropout(ones, p, seed=123, offset=1 << 40).float()
+    # the device mask IS the host restatement of the hash (tests/golden_util.mix64), bit for bit, also for a seed with high bits set and an
+    # offset whose group index crosses 2^32
+    from tests import golden_util as G
+    for seed_, off_ in ((123, 1 << 40), (2 ** 63 + 99, (7 << 40) + 8), (0, (1 << 34) - 64)):
+        dm = ops.dropout(ones, p, seed=seed_, offset=off_).float().cpu().ne(0)
+        idx = np.uint64(off_) + np.arange(M * N, dtype=np.uint64)
+        z = G.mix64(seed_, idx >> np.uint64(2))
+        bits = (z >> (np.uint64(16) * (idx & np.uint64(3)))) & np.uint64(0xFFFF)
+        host = torch.from_numpy((bits >= np.uint64(min(65535, int(p * 65536.0 + 0.5)))).reshape(M, N))
+        assert torch.equal(dm, host), (seed_, off_)
     keep = (mask > 0).float().mean().item()
     assert abs(keep - (1 - p)) < 0.01, keep
     assert torch.allclose(mask[mask > 0], torch.tensor(1 / (1 - p)), rtol=1e-2)
