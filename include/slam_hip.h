@@ -49,7 +49,7 @@ const char* slam_target_arch(void); /* "gfx950" */
  * out_mel [B, n_samples/160, n_mels] f32; workspace: slam_logmel_workspace_bytes(B) bytes.
  * per_clip != 0: pad_or_trim OFF (speech_dataset_large.py:102-104 with pad_or_trim=false): each clip's STFT runs over its own
  * n_valid[b] samples, it owns n_valid[b]/160 frames, the remaining rows are the collator's mel-space zeros. */
-int slam_logmel_workspace_bytes(int64_t B);
+int64_t slam_logmel_workspace_bytes(int64_t B);
 int slam_logmel_fwd(const float* audio, int64_t ld_audio, const int32_t* n_valid, int64_t n_samples,
                     const float* window400, const float* twiddle_folded, const float* mel_filters_T,
                     int64_t n_mels, float* out_mel, int32_t* workspace, int64_t B, int per_clip, void* stream);

@@ -927,6 +927,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     if (tid < 8) ldsMask[tid] = mreg;
   };
 
+  // RP (WavLM's gated bias, un-frozen encoder): d(gate)[q] = sum_k dS[q,k] table[k - q] is a CANCELLING sum (sum_k dS = 0 exactly), so
+  // a Delta that is not the one the recomputed P implies -- sum_d dO O carries the bf16 rounding of O -- leaks Delta_err * sum_k P table
+  // straight into it.  The RP form therefore walks the key tiles twice: pass 0 only accumulates sum_k P dP and sum_k P from the SAME
+  // recomputed values pass 1 uses (same instructions, same bits), Delta := their quotient replaces the prologue's value (for this
+  // kernel, and through p.Delta for the dK / dV kernel), and sum_k dS of pass 1 is zero to fp32 rounding.  Non-RP forms: one pass.
+  float dsum[QF], psum[QF];
+#pragma unroll
+  for (int f = 0; f < QF; f++) dsum[f] = psum[f] = 0.f;
+  for (int pass = RP ? 0 : 1; pass < 2; pass++) {
   if (ntiles > tbeg) gload(tbeg * 32);
   for (int it = tbeg; it < ntiles; it++) {
     const int k0 = it * 32;
@@ -977,6 +986,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
           if constexpr (RP) bias = rp_g[f] * p.rp_tab[(int64_t)h * p.rp_ld + (key - min(q, Tq - 1) + p.rp_T - 1)];
           const float pv = ok ? fast_exp2(fmaf(st[f][kf][r], sl2, bias) - lse2[f]) : 0.f;
           const float dpm = DROP ? (((keep >> r) & 1u) ? dpt[f][kf][r] * p.drop_scale : 0.f) : dpt[f][kf][r];   // d(dropped P) -> dP
+          if constexpr (RP) {
+            if (pass == 0) {
+              dsum[f] = fmaf(pv, dpm, dsum[f]);
+              psum[f] += pv;
+              continue;
+            }
+          }
           const float ds0 = pv * (dpm - delta[f]);      // dL/d(score) of (q, key)
           if constexpr (RP) {
             if (qok && key < Tkp) p.rp_ds[(((int64_t)b * p.Hq + h) * Tq + q) * Tkp + key] = ds0;
@@ -986,6 +1002,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
       }
       dsb[f] = pack_frag(st[f][0], st[f][1]);
     }
+    if constexpr (RP) {
+      if (pass == 0) continue;
+    }
 #pragma unroll
     for (int df = 0; df < DF; df++) {
       const int d = df * 16 + li;
@@ -993,6 +1012,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
       for (int f = 0; f < QF; f++) dq[f][df] = mfma16(ktf, dsb[f], dq[f][df]);
     }
+  }
+  if constexpr (RP) {
+    if (pass == 0) {     // the four lane groups of a query row hold disjoint key subsets: fixed-order combine, then Delta := sum P dP / sum P
+      __syncthreads();   // (every wave is done reading the last tile before pass 1 re-stages tile tbeg)
+#pragma unroll
+      for (int f = 0; f < QF; f++) {
+        float a = dsum[f], s1 = psum[f];
+        a += __shfl_xor(a, 16, 64);  s1 += __shfl_xor(s1, 16, 64);
+        a += __shfl_xor(a, 32, 64);  s1 += __shfl_xor(s1, 32, 64);
+        delta[f] = s1 > 0.f ? a / s1 : 0.f;
+        const int q = qw0 + f * 16 + li;
+        if (q < Tq && g == 0) p.Delta[((int64_t)b * p.Hq + h) * Tqp + q] = delta[f];
+      }
+    }
+  }
   }
 #pragma unroll
   for (int f = 0; f < QF; f++) {
@@ -2493,6 +2527,21 @@ static void launch_fwd(const AttnParams& p, int64_t B, hipStream_t s) {
   else attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, false>), grid, 256, 0, s, p);
 }
 
+// what the 32-bit byte offsets of the DMA descriptors can address: the row-major operands (Q / dO and K / V live inside fused buffers:
+// ld = 3 H D for a QKV buffer, so the range is exhausted ~3x sooner than H D would suggest), and the [B,H,D,Tp] copies of the round-3
+// ring kernels.  ONE predicate for slam_attn_needs_transposed and for every backward launch (they used to differ, and the
+// dK / dV launch did not look at all -- beyond 2 GiB its descriptor reads would have returned zeros, silently).
+struct AttnFits { bool rowmajor, copies; };
+static AttnFits attn_fits(int64_t B, int64_t Tq, int64_t Tk, int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int64_t ldq,
+                          int64_t ldk, int64_t ldv, int64_t lddo) {
+  const int64_t lim = (int64_t)1 << 31;
+  AttnFits f;
+  f.rowmajor = (B * Tk * ldk + Hkv * D) * 2 < lim && (B * Tk * ldv + Hkv * D) * 2 < lim &&
+               (B * Tq * ldq + Hq * D) * 2 < lim && (B * Tq * lddo + Hq * D) * 2 < lim;
+  f.copies = B * Hkv * D * Tkp * 2 < lim && B * Hq * D * Tqp * 2 < lim;
+  return f;
+}
+
 // which transposed [B,H,D,Tp] copies a call with these arguments reads (bit 0: slam_attn_fwd needs Vt; bit 1: slam_attn_bwd needs Qt / Kt /
 // dOt).  0 for everything the transposed-read kernels cover; the host side builds the copies (slam_head_rope_transpose) only when asked
 // to.  flags: bit 0 = attention-probability dropout, bit 1 = gated relative position bias (WavLM).
@@ -2500,12 +2549,9 @@ extern "C" int slam_attn_needs_transposed(int64_t B, int64_t Tq, int64_t Tk, int
                                           int64_t ldv, int64_t lddo, int flags) {
   int need = 0;
   if (!g_attn_tr) return 3;
-  const int64_t lim = (int64_t)1 << 31;
-  const bool fits_kv = (B * Tk * ldk + Hkv * D) * 2 < lim && (B * Tk * ldv + Hkv * D) * 2 < lim;
-  const bool fits_q = (B * Tq * ldq + Hq * D) * 2 < lim && (B * Tq * lddo + Hq * D) * 2 < lim;
   // backward: the transposed-read kernels are the ring forms; <= 64 queries, dropout, the relative position bias, the non-default
   // variants and tensors beyond the descriptors' 2 GiB stay on the register-staged kernels, which read the copies
-  if (flags != 0 || Tq <= 64 || !fits_kv || !fits_q || g_attn_bwd_variant != 0) need |= 2;
+  if (flags != 0 || Tq <= 64 || !attn_fits(B, Tq, Tk, 0, 0, Hq, Hkv, D, ldq, ldk, ldv, lddo).rowmajor || g_attn_bwd_variant != 0) need |= 2;
   return need;   // (the forward kernel has a transposed-read form of every instantiation, register-staged ones included)
 }
 
@@ -2567,24 +2613,38 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   return 0;
 }
 
-// dQ launch: 32 queries per wave (128 per workgroup) once there is more than one 64-query block; the ring form whenever the
-// 32-bit byte offsets of its DMA descriptors can address the tensors (variant 2: register-staged form, for A/B in tools)
+// dQ launch: 32 queries per wave (128 per workgroup) once there is more than one 64-query block; the descriptor (DMA ring) forms
+// whenever attn_fits says their descriptors reach (variant 2: register-staged form, for A/B in tools)
 template <int D, bool CAUSAL>
-static int launch_dq(const AttnParams& p, int64_t B, hipStream_t s) {
+static int launch_dq(const AttnParams& p, int64_t B, hipStream_t s, AttnFits fits) {
   if (p.Tq > 64 && g_attn_bwd_variant != 1) {
     dim3 g2((unsigned)cdiv64(p.Tq, 128), (unsigned)p.Hq, (unsigned)B);
-    const int64_t lim = (int64_t)1 << 31;
-    const bool fits = (B * p.Tk * p.ldk + (int64_t)p.Hkv * D) * 2 < lim && (B * p.Tk * p.ldv + (int64_t)p.Hkv * D) * 2 < lim &&
-                      B * p.Hkv * D * p.Tkp * 2 < lim;
-    if (fits && g_attn_bwd_variant == 14) {
+    if (fits.rowmajor && fits.copies && g_attn_bwd_variant == 14) {
       if constexpr (D == 128 && CAUSAL) return launch_dq_ring<D, CAUSAL, 2, true>(p, g2, s);
     }
-    if (fits && g_attn_bwd_variant != 2) return g_attn_tr ? launch_dq_tr<D, CAUSAL, 2>(p, g2, s) : launch_dq_ring<D, CAUSAL, 2>(p, g2, s);
-    attn_launch((attn_bwd_dq_kernel<D, CAUSAL, false, 2>), g2, 256, 0, s, p);
+    if (g_attn_bwd_variant != 2) {
+      if (g_attn_tr && fits.rowmajor) return launch_dq_tr<D, CAUSAL, 2>(p, g2, s);
+      if (!g_attn_tr && fits.rowmajor && fits.copies) return launch_dq_ring<D, CAUSAL, 2>(p, g2, s);
+    }
+    attn_launch((attn_bwd_dq_kernel<D, CAUSAL, false, 2>), g2, 256, 0, s, p);      // (reads Kt: slam_attn_needs_transposed asked for it)
   } else {
     dim3 g1((unsigned)cdiv64(p.Tq, 64), (unsigned)p.Hq, (unsigned)B);
     attn_launch((attn_bwd_dq_kernel<D, CAUSAL, false, 1>), g1, 256, 0, s, p);
   }
+  return 0;
+}
+
+// dK / dV launch: transposing-read ring kernel, round-3 ring kernel on the copies (tools: slam_attn_set_fwd_qf 40), or the register-staged
+// round-1 kernel (variant 1, and every tensor the descriptors cannot address)
+template <int D, bool CAUSAL>
+static int launch_dkdv(const AttnParams& p, int64_t B, hipStream_t s, AttnFits fits) {
+  dim3 gk((unsigned)cdiv64(p.Tk, 64), (unsigned)p.Hkv, (unsigned)B);
+  dim3 gk2((unsigned)cdiv64(p.Tk, 128), (unsigned)p.Hkv, (unsigned)B);
+  if (g_attn_bwd_variant != 1) {
+    if (g_attn_tr && fits.rowmajor) return launch_dkdv_tr<D, CAUSAL>(p, gk2, s);
+    if (!g_attn_tr && fits.rowmajor && fits.copies) return launch_dkdv_ring<D, CAUSAL>(p, gk2, s);
+  }
+  attn_launch((attn_bwd_dkdv_kernel<D, CAUSAL>), gk, 256, 0, s, p);
   return 0;
 }
 
@@ -2631,6 +2691,7 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.drop_seed = drop_seed;
   p.rp_gate = rp_gate; p.rp_tab = rp_tab; p.rp_T = (int)rp_T; p.rp_ld = (int)rp_ld; p.rp_ds = rp_ds;
   hipStream_t s = (hipStream_t)stream;
+  const AttnFits fits = attn_fits(B, Tq, Tk, Tqp, Tkp, Hq, Hkv, D, ldq, ldk, ldv, lddo);
   if (rp_gate) {   // WavLM (unfrozen): the bias joins the recomputed scores; dL/d(score) is materialised once and reduced twice
     dim3 gq_((unsigned)cdiv64(Tq, 64), (unsigned)Hq, (unsigned)B), gk_((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);
     if (drop_p > 0.f) {     // train-mode attention_dropout: the same mask as the forward, recomputed; dL/d(score) already carries it
@@ -2655,12 +2716,11 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
     SLAM_CHECK_LAUNCH("slam_attn_bwd");
     return 0;
   }
-  dim3 gk((unsigned)cdiv64(Tk, 64), (unsigned)Hkv, (unsigned)B);
   dim3 gk2((unsigned)cdiv64(Tk, 128), (unsigned)Hkv, (unsigned)B);
-  const bool ring = g_attn_bwd_variant != 1;
   int rc = 0;
   if (g_attn_bwd_variant > 10 && D == 128 && causal) {   // timing ablations of the D = 128 causal ring kernel (tools only)
-    if ((rc = launch_dq<128, true>(p, B, s))) return rc;
+    SLAM_CHECK_ARG(fits.rowmajor && fits.copies, "slam_attn_bwd: the timing-ablation variants need tensors within the descriptors' 2 GiB");
+    if ((rc = launch_dq<128, true>(p, B, s, fits))) return rc;
     switch (g_attn_bwd_variant) {
       case 11: rc = launch_dkdv_ring<128, true, 1>(p, gk2, s); break;
       case 12: rc = launch_dkdv_ring<128, true, 2>(p, gk2, s); break;
@@ -2674,19 +2734,19 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   }
   if (D == 64) {
     if (causal) {
-      if ((rc = launch_dq<64, true>(p, B, s))) return rc;
-      if (ring) rc = g_attn_tr ? launch_dkdv_tr<64, true>(p, gk2, s) : launch_dkdv_ring<64, true>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<64, true>), gk, 256, 0, s, p);
+      if ((rc = launch_dq<64, true>(p, B, s, fits))) return rc;
+      rc = launch_dkdv<64, true>(p, B, s, fits);
     } else {
-      if ((rc = launch_dq<64, false>(p, B, s))) return rc;
-      if (ring) rc = g_attn_tr ? launch_dkdv_tr<64, false>(p, gk2, s) : launch_dkdv_ring<64, false>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<64, false>), gk, 256, 0, s, p);
+      if ((rc = launch_dq<64, false>(p, B, s, fits))) return rc;
+      rc = launch_dkdv<64, false>(p, B, s, fits);
     }
   } else {
     if (causal) {
-      if ((rc = launch_dq<128, true>(p, B, s))) return rc;
-      if (ring) rc = g_attn_tr ? launch_dkdv_tr<128, true>(p, gk2, s) : launch_dkdv_ring<128, true>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<128, true>), gk, 256, 0, s, p);
+      if ((rc = launch_dq<128, true>(p, B, s, fits))) return rc;
+      rc = launch_dkdv<128, true>(p, B, s, fits);
     } else {
-      if ((rc = launch_dq<128, false>(p, B, s))) return rc;
-      if (ring) rc = g_attn_tr ? launch_dkdv_tr<128, false>(p, gk2, s) : launch_dkdv_ring<128, false>(p, gk2, s); else attn_launch((attn_bwd_dkdv_kernel<128, false>), gk, 256, 0, s, p);
+      if ((rc = launch_dq<128, false>(p, B, s, fits))) return rc;
+      rc = launch_dkdv<128, false>(p, B, s, fits);
     }
   }
   if (rc) return rc;

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void logmel_finish_kernel(float* __restrict__ 
 
 }  // namespace
 
-extern "C" int slam_logmel_workspace_bytes(int64_t B) { return (int)(melpack_offset(B) + (int64_t)sizeof(MelPack)); }
+extern "C" int64_t slam_logmel_workspace_bytes(int64_t B) { return melpack_offset(B) + (int64_t)sizeof(MelPack); }
 
 extern "C" int slam_logmel_fwd(const float* audio, int64_t ld_audio, const int32_t* n_valid,
                                int64_t n_samples, const float* window400, const float* twiddle_folded,

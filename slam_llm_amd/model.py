@@ -737,7 +737,11 @@ class HipHubertEncoder(nn.Module):
             if not (R.on and p > 0.0):
                 return None
             self._drop_calls += 1
-            return (p, seed, ((self._drop_calls & 0xFFFFF) | 0x100000) << 40)
+            # the offset carries 20 bits of the call counter (an encoder draws ~100 keys per step: 2^20 keys = ~10 k steps); the bits above
+            # go into the seed, so a long run never re-uses a (seed, offset) pair (the counter used to wrap onto old masks)
+            epoch = self._drop_calls >> 20
+            s = seed if epoch == 0 else (seed ^ (epoch * 0x9E3779B97F4A7C15)) & (2 ** 64 - 1)
+            return (p, s, ((self._drop_calls & 0xFFFFF) | 0x100000) << 40)
 
         def attn_key(p):
             """(p, seed) of the next attention-probability dropout (applied inside the attention kernels)"""

@@ -280,19 +280,34 @@ def model_factory(train_config, model_config, **kwargs):
             if p:
                 st = _load_state(str(p))
                 if key == "encoder_state" and isinstance(st, dict) and "cfg" in st and "model" in st:
-                    # a raw WavLM checkpoint {"cfg": ..., "model": state_dict} as models/encoder.py:118-121 reads it: its cfg carries the
-                    # dropout / layerdrop values the module is built with
+                    # a raw checkpoint {"cfg": ..., "model": state_dict}: WavLM's as models/encoder.py:118-121 reads it (flat cfg, the module
+                    # sits under `encoder.model.`), or fairseq's HuBERT as load_model_ensemble_and_task reads it (models/encoder.py:130-140:
+                    # the module values are nested under cfg["model"], and the fairseq model IS `self.encoder`: prefix `encoder.`).  Its cfg
+                    # carries the dropout / layerdrop values the reference builds the module with; explicit recipe values win.
+                    enc_kind = cfg.get("encoder_name")
+                    ck_cfg = st["cfg"]
+                    if enc_kind == "hubert" and isinstance(ck_cfg, dict) and isinstance(ck_cfg.get("model"), dict):
+                        ck_cfg = ck_cfg["model"]
                     for mine, theirs in (("hub_dropout", "dropout"), ("hub_attention_dropout", "attention_dropout"),
                                          ("hub_activation_dropout", "activation_dropout"), ("hub_dropout_input", "dropout_input"),
                                          ("hub_layerdrop", "encoder_layerdrop")):
-                        if theirs in st["cfg"] and _get(model_config, "encoder_" + theirs.replace("encoder_", ""), None) is None:
-                            cfg[mine] = float(st["cfg"][theirs])
-                    st = {"encoder.model." + k: v for k, v in st["model"].items()}
+                        if theirs in ck_cfg and _get(model_config, "encoder_" + theirs.replace("encoder_", ""), None) is None:
+                            cfg[mine] = float(ck_cfg[theirs])
+                    cfg["hub_regularisers_from"] = "checkpoint cfg"
+                    prefix = "encoder." if enc_kind == "hubert" else "encoder.model."
+                    st = {prefix + k: v for k, v in st["model"].items()}
                 W.update(st)
         if not W:
             raise FileNotFoundError("no weights given: set model_config.encoder_state / llm_state (state dicts in the "
                                     "reference's key names) or model_config.random_init=true")
         model.load_weights(W, seed=seed)   # projector / LoRA tensors absent from W get the reference's fresh-module init
+    if cfg.get("encoder_name") in ("hubert", "wavlm") and not cfg.get("freeze_encoder", True):
+        # the reference builds the un-frozen module from its checkpoint's own cfg (the published Large checkpoints carry 0.0 for several of
+        # these); a plain state dict has no cfg, so say which values the train-mode regularisers run with
+        logger.warning("un-frozen %s encoder: train-mode regularisers from %s: dropout=%s attention_dropout=%s activation_dropout=%s "
+                       "dropout_input=%s encoder_layerdrop=%s (override with ++model_config.encoder_dropout=... etc.)", cfg["encoder_name"],
+                       cfg.get("hub_regularisers_from", "the module defaults / recipe (no checkpoint cfg seen)"), cfg.get("hub_dropout"),
+                       cfg.get("hub_attention_dropout"), cfg.get("hub_activation_dropout"), cfg.get("hub_dropout_input"), cfg.get("hub_layerdrop"))
     if peft_state is not None:
         own = set(model.state_dict().keys())
         unknown = [k for k in peft_state if k not in own]

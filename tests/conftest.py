@@ -7,9 +7,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Collection order of the GPU suite: the driver runs `pytest -x`, so the cheapest, most fundamental tests go
+# FIRST -- every kernel against its fp32 reference, then the module-level fixtures, the boundary, the multi-process paths, and the
+# whole-step geometry / headline comparisons last.  One model-level assert can then no longer hide the per-kernel parity tests.
+_FILE_ORDER = ["test_capi_symbols", "test_build_invariants", "test_oracle_golden", "test_host_logic", "test_plugin_boundary", "test_dist_gloo",
+               "test_ops_gpu", "test_determinism_gpu", "test_model_gpu", "test_boundary_gpu", "test_amp_rccl_gpu", "test_dist_gpu",
+               "test_geometry_gpu", "test_ragged_hbm_gpu", "test_headline_gpu"]
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        stem = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _FILE_ORDER.index(stem) if stem in _FILE_ORDER else len(_FILE_ORDER)
+    items.sort(key=rank)      # stable: the order inside a file stays the file's own
 
 
 @pytest.fixture(scope="session")
@@ -18,3 +32,22 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _isolated_gpu_test(request):
+    """every GPU test starts from the same process state whatever ran before it: torch / numpy seeds fixed (the counter-based dropout
+    masks of the train-mode paths derive from torch.initial_seed(): without this a mask draw depends on which tests were selected and
+    in which order -- the round-4 driver failure), and every process-global tuning knob of the library at its shipped default (a test
+    that fails between `gemm_set_config(x)` and its own restore must not change what the tests behind it run)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import numpy as np
+    import torch
+    torch.manual_seed(20240924)
+    np.random.seed(20240924)
+    if torch.cuda.is_available():
+        from slam_llm_amd import ops
+        ops.reset_tuning()
+    yield

@@ -299,13 +299,18 @@ def test_unfrozen_wavlm_train_mode_regularisers_match_oracle_with_the_same_masks
     dropout after the positional conv sits behind the encoder LayerNorm, dropout1 / 3 in front of the LayerNorms), ragged batch all
     kept / layer 1 skipped.  Then eval mode: no key is drawn and the output equals the deterministic graph's; p = 0 in train mode:
     bit-identical to eval."""
+    _wavlm_train_mode_case(dev, tag)
+
+
+def _wavlm_train_mode_case(dev, tag, mask_seed=None, report=None):
     from oracle.make_golden_cases import WAVLM_BASE_TINY, WAVLM_TRAIN_TINY
     from slam_llm_amd.model import HipWavLMEncoder
     C, wseed = (WAVLM_TRAIN_TINY, 9) if tag in "ABC" else (WAVLM_BASE_TINY, 10)
     fx = G.load("wavlm_train_tiny")
     pattern = tuple(bool(k) for k in fx[tag + ".kept"])
     _wave_train_mode_case(dev, tag, HipWavLMEncoder, C, O.init_wavlm_weights(C, seed=wseed), O.wavlm_encoder, torch.from_numpy(fx[tag + ".wav"]),
-                          [int(x) for x in fx[tag + ".n_valid"]], pattern, torch.from_numpy(fx[tag + ".cot"]), {}, True, 1 + 19 * pattern.count(False))
+                          [int(x) for x in fx[tag + ".n_valid"]], pattern, torch.from_numpy(fx[tag + ".cot"]), {}, True, 1 + 19 * pattern.count(False),
+                          mask_seed=mask_seed, report=report)
 
 
 @pytest.mark.parametrize("pattern,ragged", [((True, True), True), ((True, False), False)])
@@ -333,9 +338,21 @@ def test_unfrozen_hubert_train_mode_regularisers_match_oracle_with_the_same_mask
                           16 * pattern.count(False))
 
 
-def _wave_train_mode_case(dev, tag, enc_cls, C, W, oracle_fn, wav, nv, pattern, cot, kmap, has_relpos, min_zero):
+# grep_linear.bias [8] and grep_a [H] of a WavLM layer are CANCELLING sums (sum_k dS = 0): their error is bounded against the norm of the
+# layer's grep_linear.weight gradient.  Round 5: the RP dQ kernel derives Delta from the recomputed P (csrc/attention.hip, two passes), so
+# sum_k dS is zero to fp32 rounding and what is left is the bf16 noise of the individual terms.  The bound is >= 2x the worst ratio
+# measured over 5 mask seeds x cases A..E on the GPU (tools/wavlm_trainmode_seeds.py -> profiles/r05_wavlm_trainmode_seeds.md).
+SMALL_GATE_BOUND = 1.0e-1
+
+
+def _wave_train_mode_case(dev, tag, enc_cls, C, W, oracle_fn, wav, nv, pattern, cot, kmap, has_relpos, min_zero, mask_seed=None, report=None):
+    """mask_seed: torch seed the counter-based masks derive from (None: the suite-wide seed tests/conftest.py sets before every GPU
+    test -- the draw no longer depends on which tests ran before).  report: a dict to fill with the measured errors instead of
+    asserting the gradient bounds (tools/wavlm_trainmode_seeds.py: the bounds below are set from its table)."""
     from slam_llm_amd import ops
     from slam_llm_amd.model import TrainableStore
+    if mask_seed is not None:
+        torch.manual_seed(mask_seed)
     reg = dict(hub_dropout=0.1, hub_attention_dropout=0.1, hub_activation_dropout=0.1, hub_dropout_input=0.1, hub_layerdrop=0.4)
     store = TrainableStore(dev)
     cfg = dict(C, **reg)
@@ -397,13 +414,22 @@ def _wave_train_mode_case(dev, tag, enc_cls, C, W, oracle_fn, wav, nv, pattern, 
         # 8-element bias from one mask draw to the next -- not a statistic)
         if ".grep_" in n and mine.numel() <= 16:
             wn = float(Wg[n.rsplit(".grep_", 1)[0] + ".grep_linear.weight"].grad.norm())
-            if float((mine - gold).norm()) > 5e-2 * wn:
+            ratio = float((mine - gold).norm()) / wn
+            if report is not None:
+                report.setdefault("small_gate_err_over_weight_grad_norm", {})[n] = ratio
+            if ratio > SMALL_GATE_BOUND:
                 bad.append((n, "err", float((mine - gold).norm()), "weight-grad norm", wn))
             continue
         floor = 0.99 if ("feature_extractor" in n or "grep_" in n) else 0.995
         nr = abs(float(mine.norm()) - float(gold.norm())) / float(gold.norm())
+        if report is not None:
+            report.setdefault("cos_norm", {})[n] = (cs, nr)
         if cs <= floor or nr >= 6e-2:
             bad.append((n, round(cs, 5), round(nr, 4)))
+    if report is not None:
+        report["bad"] = bad
+        report["worst"] = worst
+        return
     assert not bad, bad
     assert n_zero >= min_zero
     if os.environ.get("SLAM_TEST_VERBOSE"):
@@ -525,7 +551,7 @@ def _unfrozen_wave_encoder_case(dev, which, ragged, base=False):
                 err = float((mine - grads[n]).norm())
                 if os.environ.get("SLAM_TEST_VERBOSE"):
                     print(f"  {n:80s} err {err:.3e} vs weight-grad norm {wn:.3e}")
-                assert err <= 5e-2 * wn, f"grad {n}: error {err} vs 5 % of the layer's grep_linear.weight gradient norm {wn}"
+                assert err <= SMALL_GATE_BOUND * wn, f"grad {n}: error {err} vs {SMALL_GATE_BOUND} of the layer's grep_linear.weight gradient norm {wn}"
                 continue
             floor = 0.99
         if os.environ.get("SLAM_TEST_VERBOSE"):     # prints only: the asserts below run either way
