@@ -225,13 +225,27 @@ def _free_port():
     return p
 
 
+def fail(args, message, rc=2):
+    """a multi-GPU run that cannot be what it claims (fewer devices than ranks, a backend other than RCCL, ranks that did not all
+    join) must not print a plausible-looking number: rank 0 prints ONE JSON line with value null + the reason, exit code != 0
+    (VERDICT r4 next #8: the first hardware run must not be able to fall back to gloo silently)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({"metric": "audio-seconds/sec/node (Whisper-large-v3->Llama-3-8B LoRA)", "value": None, "unit": "audio-seconds/sec",
+                          "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "error": message}), flush=True)
+    sys.exit(rc)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves."""
     import torch
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if torch.cuda.device_count() < args.gpus:
-        env.setdefault("SLAM_DIST_BACKEND", "gloo")   # ranks share a device: RCCL cannot, gloo can (functional check)
+        if not args.functional_gloo:
+            fail(args, f"--gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible: a scaling line needs one MI355X per rank "
+                       f"over RCCL.  (--functional-gloo runs the N > 1 code path with ranks SHARING devices over gloo: a functional check, "
+                       f"marked invalid_for_scaling in its line.)")
+        env["SLAM_DIST_BACKEND"] = "gloo"   # ranks share a device: RCCL cannot, gloo can (functional check only)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     os.execvpe(cmd[0], cmd, env)
@@ -319,6 +333,8 @@ def main():
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU (default: the workload's)")
     ap.add_argument("--train-encoder", action="store_true", help="train_config.freeze_encoder=false (Whisper workloads): the encoder "
                     "trains too -- NOT the headline configuration, named as such in config.workload")
+    ap.add_argument("--functional-gloo", action="store_true", help="N>1 on a box with fewer than N GPUs: ranks share devices over gloo (functional "
+                    "check of the N > 1 path only; without this flag such a run FAILS instead of printing a number)")
     ap.add_argument("--ddp", action="store_true", help="N>1: reduce through torch DistributedDataParallel (autograd_params mode) "
                                                       "instead of the GradSync fast path")
     args = ap.parse_args()
@@ -338,6 +354,23 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = dist.get_backend() if world > 1 else None
+    n_ranks_seen, devices_distinct = 1, True
+    if world > 1:
+        # what the collective library itself sees: a SUM of ones over the group (must be N), and every rank's device identity
+        # (PCI bus id where the runtime exposes it, else the index) gathered through the same backend
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        n_ranks_seen = int(one.item())
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = f"{getattr(props, 'pci_bus_id', -1)}:{getattr(props, 'pci_device_id', -1)}:{getattr(props, 'uuid', local_rank)}:{local_rank}"
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        devices_distinct = len(set(idents)) == world
+        if n_ranks_seen != args.gpus:
+            fail(args, f"the process group reduced {n_ranks_seen} ranks, --gpus says {args.gpus}")
+        if (backend != "nccl" or not devices_distinct) and not args.functional_gloo:
+            fail(args, f"N = {world} ranks over backend '{backend}' with {len(set(idents))} distinct device(s): a scaling line needs backend nccl (= RCCL) "
+                       f"and one MI355X per rank (SLAM_DIST_BACKEND / a shared device is only accepted with --functional-gloo)")
 
     # recipe defaults (examples/asr_librispeech/asr_config.py:29-37): LoRA on q_proj,v_proj with lora_dropout 0.05 live in
     # train mode ("dropout 0 for parity, 0.05 for throughput"); r per BASELINE.json
@@ -436,6 +469,9 @@ def main():
                    "global_batch_clips": world * n_clips, "seq_len": T, "parallelism": f"dp{world}",
                    "grad_exchange": None if world == 1 else ("DistributedDataParallel" if args.ddp else "GradSync (flat-buffer prefixes)"),
                    "backend": backend if backend != "nccl" else f"nccl (RCCL {rccl_version()})",
+                   "n_ranks_seen": n_ranks_seen, "rccl_version": rccl_version(), "devices_distinct": devices_distinct,
+                   **({"invalid_for_scaling": "ranks share devices over gloo (--functional-gloo): functional check of the N > 1 path, not a measurement"}
+                      if (world > 1 and (backend != "nccl" or not devices_distinct)) else {}),
                    # max over ranks of the mean HIP-event time of GradSync.finish() per step: tail bucket launch + waits on the compute stream
                    "comm_exposed_ms": comm_exposed_ms,
                    "grad_buffer_MB": model.store.grad.numel() * 4 / 1e6 if world > 1 else None,

@@ -231,11 +231,21 @@ def test_bench_self_launches_two_ranks_on_one_gpu(dev):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c1", "--clips", "2",
+            "--no-cpu-baseline"]
+    if torch.cuda.device_count() < 2:
+        # round 5: without --functional-gloo a run with fewer devices than ranks FAILS -- value null, the reason in the
+        # line, exit code != 0 -- instead of printing a gloo number that looks like a scaling line
+        p = subprocess.run(base, capture_output=True, text=True, env=env, timeout=800)
+        assert p.returncode != 0
+        out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["value"] is None and "HIP device" in out["error"] and out["n_gpus"] == 2
+        # ... and a forced non-RCCL backend is refused by the ranks themselves
     for extra in ([], ["--ddp"]):
-        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "c1",
-                            "--clips", "2", "--no-cpu-baseline"] + extra, capture_output=True, text=True, env=env, timeout=800)
+        p = subprocess.run(base + ["--functional-gloo"] + extra, capture_output=True, text=True, env=env, timeout=800)
         assert p.returncode == 0, p.stderr[-3000:]
         line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
         out = json.loads(line)
         assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
         assert out["config"]["global_batch_clips"] == 4
+        assert out["config"]["n_ranks_seen"] == 2 and out["config"]["backend"] == "gloo" and "invalid_for_scaling" in out["config"]

@@ -60,10 +60,26 @@ def test_headline_geometry_step_matches_oracle(dev, encoder, B):
     8 x 30 s clips), T = 380, true widths, 1 + 1 layers, raw audio in: loss abs <= 1e-2, accuracy within one token, every trainable
     gradient cosine >= 0.999 and norm within 3 % of the fp32 oracle; the auto GEMM rule must have picked the kernels the bench lines
     are quoted on (4-wave hand-ordered kernel for the LLM products, persistent descriptor-DMA kernel for the K <= 2048 encoder products)."""
+    _headline_case(dev, encoder, B, 1, 1)
+
+
+@pytest.mark.timeout(2400)
+def test_c3_full_depth_step_matches_oracle(dev):
+    """VERDICT r4 missing #5: the headline model at FULL depth -- all 32 Whisper-large-v3 layers and all 32 Llama-3-8B layers at true
+    widths (the bf16 residual stream at d 4096 through 32 layers has otherwise only met the oracle at C1's widths), B = 2 clips x 30 s,
+    T = 380, raw audio in, LoRA r16 on q, v: loss abs <= 1e-2, accuracy within one token, every gradient cosine >= 0.999 / norm 3 %.
+    The fp32 oracle holds 8.6 G parameters (34 GB) on the host: skipped on a box with less than 160 GB of free RAM."""
+    import psutil
+    if psutil.virtual_memory().available < 160 * 2 ** 30:
+        pytest.skip("needs 160 GB of host RAM for the fp32 oracle at full depth")
+    _headline_case(dev, "whisper-large-v3", 2, 32, 32)
+
+
+def _headline_case(dev, encoder, B, enc_layers, llm_layers):
     from slam_llm_amd import ops
     from slam_llm_amd.model import SlamHipModel, make_config
     PROMPT, ANSWER = 16, 64
-    cfg = make_config(encoder, "llama-3-8b", enc_layers=1, llm_layers=1, lora_r=16, lora_alpha=32,
+    cfg = make_config(encoder, "llama-3-8b", enc_layers=enc_layers, llm_layers=llm_layers, lora_r=16, lora_alpha=32,
                       lora_targets=("q_proj", "v_proj"), lora_dropout=0.0)
     W = O.init_weights(cfg, seed=42)
     audio = O.synth_audio(B, 30.0, seed=1234)
@@ -96,16 +112,21 @@ def test_headline_geometry_step_matches_oracle(dev, encoder, B):
         ops.TIMER = None
     M = B * 380
     assert model.llm.lm_head_chunk_rows is None and ((1 << 29) // cfg["vocab"]) // 256 * 256 == 4096   # default chunking: lm_head chunks of 4096 rows
-    assert -(-M // 4096) == (3 if B == 31 else 1)
-    assert "w4" in ops.gemm_kernel_name(M, 4096, 4096) and "w4" in ops.gemm_kernel_name(M, 6144, 4160)
-    assert "persist2" in ops.gemm_kernel_name(B * 1500, 3 * cfg["enc_dim"], cfg["enc_dim"])
-    assert any("gemm_nt_w4_kernel" in k for k in used) and any("gemm_nt_persist2_kernel" in k for k in used), sorted(used)
+    if B >= 8:      # the bench batch sizes: the auto rule must have picked the kernels the bench lines are quoted on
+        assert -(-M // 4096) == (3 if B == 31 else 1)
+        assert "w4" in ops.gemm_kernel_name(M, 4096, 4096) and "w4" in ops.gemm_kernel_name(M, 6144, 4160)
+        assert "persist2" in ops.gemm_kernel_name(B * 1500, 3 * cfg["enc_dim"], cfg["enc_dim"])
+        assert any("gemm_nt_w4_kernel" in k for k in used) and any("gemm_nt_persist2_kernel" in k for k in used), sorted(used)
     n_valid = int((ob["labels"][:, 1:] != -100).sum())
     got = float(outputs.loss)
     assert abs(got - loss_ref) <= 1e-2, (got, loss_ref)
     assert abs(float(acc) - acc_ref) <= 1.0 / n_valid + 1e-6
     worst = _check_grads(model, grads)
-    print(f"{encoder} x {B}: loss {got:.4f} vs {loss_ref:.4f}, acc {float(acc):.4f} vs {acc_ref:.4f}, worst gradient cosine {worst:.6f}")
+    print(f"{encoder} x {B} ({enc_layers} + {llm_layers} layers): loss {got:.4f} vs {loss_ref:.4f}, acc {float(acc):.4f} vs {acc_ref:.4f}, worst gradient cosine {worst:.6f}")
+    if os.environ.get("SLAM_TEST_REPORT"):      # (tools: append the measured numbers to a file that is committed under profiles/)
+        with open(os.environ["SLAM_TEST_REPORT"], "a") as f:
+            f.write(f"{encoder} x {B}, {enc_layers} + {llm_layers} layers, T = 380: loss {got:.5f} vs oracle {loss_ref:.5f}; accuracy {float(acc):.4f} vs "
+                    f"{acc_ref:.4f}; worst gradient cosine {worst:.6f} over {len(grads)} tensors\n")
 
 
 @pytest.mark.timeout(1500)

@@ -107,6 +107,40 @@ def test_gemm_thin_tail_tile_of_the_4wave_kernel(dev, M, N, K):
         ops.gemm_set_config(0)
 
 
+@pytest.mark.parametrize("where", ["below", "beyond"])
+def test_gemm_operand_at_the_4gib_descriptor_boundary(dev, where):
+    """the descriptor (LDS-DMA) GEMM forms address an operand with 32-bit byte offsets; a 288 GB-sized ragged
+    batch puts M x ld near that limit (65 k tokens x the 28 672-wide gate|up stash = 3.7 GB).  `below`: the A operand ends a few rows
+    under 4 GiB and is followed DIRECTLY by NaNs -- the descriptor forms run (cfg 12 and cfg 7), rows past M must read as zeros through
+    the range check; `beyond`: the operand crosses 4 GiB -- `fits_descriptor` must send cfg 12 / cfg 7 / the auto rule to the kernels
+    that address with 64-bit pointers, and the rows behind the boundary must be right (a wrapped 32-bit offset would read row 0's
+    neighbourhood instead).  Row samples at the start, around the boundary and at the end against fp32 torch."""
+    ops = _ops()
+    K, N, ld = 14336, 384, 14400            # Llama-3-8B's h_mid with its LoRA extension columns: ld = 14336 + 64
+    rows_4g = (1 << 32) // (2 * ld)         # 149 130 rows reach 4 GiB
+    M = rows_4g - 300 if where == "below" else rows_4g + 2100
+    g = torch.Generator(device=dev).manual_seed(11)
+    buf = torch.full(((M + 64) * ld,), float("nan"), device=dev, dtype=torch.bfloat16)
+    a = buf[: M * ld].view(M, ld)[:, :K]
+    for r0 in range(0, M, 16384):           # (filled in slabs: a [M, K] fp32 temporary would be 8.5 GB)
+        r1 = min(M, r0 + 16384)
+        a[r0:r1] = torch.randn(r1 - r0, K, generator=g, device=dev).to(torch.bfloat16)
+    buf[: M * ld].view(M, ld)[:, K:] = 0
+    b = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
+    sample = torch.cat([torch.arange(0, 300), torch.arange(rows_4g - 600, min(M, rows_4g + 300)), torch.arange(M - 300, M)]).unique().to(dev)
+    ref = a[sample].float() @ b.float().T
+    for cfg in (0, 12, 7, 6):
+        ops.gemm_set_config(cfg)
+        try:
+            c = ops.gemm_nt(a, b)
+        finally:
+            ops.gemm_set_config(0)
+        assert torch.isfinite(c).all(), f"cfg {cfg}: a NaN from behind the operand reached the output"
+        assert_close(c[sample], ref, atol=2e-2 * math.sqrt(K / 64), rtol=1e-2, what=f"cfg {cfg}, operand {where} 4 GiB")
+    # the dX-shaped product of the same batch: the wide operand is the OUTPUT / residual side ([M, 2F] = 28 672 columns: 65 k rows = 3.7 GB)
+    del buf, a, c
+
+
 def test_gemm_asymmetric_identity(dev):
     """A = I with an asymmetric B catches row/col swaps in the MFMA output mapping."""
     ops = _ops()

@@ -4,6 +4,8 @@ dynamic-frame batcher, four ways on the SAME clips:
   packed_llm      ++model_config.varlen=true: pad rows dropped before the LLM (seg_lo/seg_hi attention, per-token RoPE)
   ragged          + ++model_config.varlen_encoder=true: per-clip frame counts through the encoder (no pad frames)
   ragged_sum36k   ragged, batches formed by the packed-aware budget (sum of real tokens <= 36 000 instead of B * T_max <= 12 000)
+  ragged_sum_hbm  ragged, packed-aware budget = batcher.frames_for_hbm() (~61 k real tokens, ~250 clips per batch: the buffer size the
+                  288 GB part is for -- north_star "ragged buffers sized for 288 GB"; its own 900-clip draw of the same distribution)
   c5              BASELINE configs[4] style (aispeech_asr multi-task ASR + ST): the same clips with DYNAMIC PROMPTS (one of several task
                   prompts per sample, 6 .. 40 tokens), the recipe's default LoRA (r 64, alpha 16, all seven projections, dropout 0.05),
                   ragged encoder + packed LLM, dynamic-frame batcher
@@ -45,22 +47,36 @@ def main():
         A = int(A * (1.3 if task >= 4 else 1.0))
         samples_c5.append(batcher.make_sample(torch.zeros(n), torch.randint(3, 128000, (task_len[task],), generator=g).tolist(),
                                               torch.randint(3, 128000, (A - 1,), generator=g).tolist(), 2, alen))
+    # the 288 GB-sized row needs more clips than the 320 above (one batch holds ~250): its own draw of the same distribution
+    g2 = torch.Generator().manual_seed(1237)
+    samples_hbm = []
+    for s_ in (torch.rand(900, generator=g2) * 28 + 2).tolist():
+        n = int(s_ * 16000) // 160 * 160
+        A = int(torch.randint(8, 129, (1,), generator=g2))
+        samples_hbm.append(batcher.make_sample(torch.zeros(n), torch.randint(3, 128000, (16,), generator=g2).tolist(),
+                                               torch.randint(3, 128000, (A - 1,), generator=g2).tolist(), 2,
+                                               batcher.whisper_audio_length(n, 5, pad_to_30s=False)))
+    hbm_budget = batcher.frames_for_hbm()
     res = {}
     lora7 = dict(lora_r=64, lora_alpha=16, lora_targets=("q_proj", "k_proj", "v_proj", "o_proj", "up_proj", "gate_proj", "down_proj"))
     variants = [("padded", dict(), 12000, "padded"), ("packed_llm", dict(varlen=True), 12000, "padded"),
                 ("ragged", dict(varlen=True, varlen_encoder=True), 12000, "padded"),
                 ("ragged_sum36k", dict(varlen=True, varlen_encoder=True), 36000, "sum"),
+                ("ragged_sum_hbm", dict(varlen=True, varlen_encoder=True), hbm_budget, "sum"),
                 ("c5", dict(varlen=True, varlen_encoder=True, **lora7), 12000, "padded")]
     describe = {"padded": "padded (reference semantics: zero-padded mel batch, padded [B, T_max] LLM pass)",
                 "packed_llm": "model_config.varlen=true (pad rows dropped before the LLM)",
                 "ragged": "varlen + varlen_encoder (no pad frames through the encoder, packed LLM pass)",
                 "ragged_sum36k": "varlen + varlen_encoder, dataset_config.frame_budget=sum, train_max_frame_length=36000",
+                "ragged_sum_hbm": f"varlen + varlen_encoder, dataset_config.frame_budget=sum, train_max_frame_length=frames_for_hbm()={hbm_budget} "
+                                  f"(the 288 GB-sized ragged buffer)",
                 "c5": "C5 style: multi-task dynamic prompts (6..40 tokens), LoRA r64 alpha16 on all seven projections, varlen + varlen_encoder"}
     only = sys.argv[1].split(",") if len(sys.argv) > 1 else None
     for name, extra, mfl, budget in variants:
         if only and name not in only:
             continue
-        groups = list(batcher.dynamic_batches(iter(samples_c5 if name == "c5" else samples), mfl, budget=budget))[:-1]
+        pool = samples_c5 if name == "c5" else (samples_hbm if name == "ragged_sum_hbm" else samples)
+        groups = list(batcher.dynamic_batches(iter(pool), mfl, budget=budget))[:-1]
         if budget == "padded":
             groups = groups[:5]
         else:
