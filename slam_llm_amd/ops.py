@@ -153,6 +153,7 @@ def gemm_skinny(a, b, out, residual=None, b2=None, swiglu=False):
 _GEMM_CFG = 0
 _GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 11: "gemm_nt_pipe_kernel<128,128,2,2,1>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
                4: "gemm_nt_kernel<256,256,2,4>", 6: "gemm_nt_pipe_kernel<256,256,2,4,1>", 7: "gemm_nt_persist2_kernel<256,256,2,4>",
+               8: "gemm_nt_p3_kernel<128,256> (two workgroups per CU)",
                12: "gemm_nt_w4_kernel<256,256,false,0>"}
 
 

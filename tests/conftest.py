@@ -51,3 +51,16 @@ def _isolated_gpu_test(request):
         from slam_llm_amd import ops
         ops.reset_tuning()
     yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """SLAM_TEST_MARGINS=<path>: every cosine floor the suite checked, with the share of its allowed deviation the measurement used
+    (tests/golden_util.floor_check): tools/margins_report.py turns the file into profiles/r05_margins.md"""
+    path = os.environ.get("SLAM_TEST_MARGINS")
+    if not path:
+        return
+    from tests import golden_util as G
+    with open(path, "w") as f:
+        f.write("test\twhat\tmeasured_1_minus_cos\tallowed_1_minus_cos\n")
+        for t, what, dev_, allowed in G.MARGINS:
+            f.write(f"{t}\t{what}\t{dev_:.3e}\t{allowed:.3e}\n")

@@ -29,6 +29,19 @@ def check_packed(fx, name, arr, atol, rtol, norm_rtol=None):
         assert abs(n - gn) <= norm_rtol * max(gn, 1e-12), f"{name}: norm {n} vs golden {gn}"
 
 
+MARGINS = []      # (test id, what, measured deviation, allowed deviation): written by tests/conftest.py when SLAM_TEST_MARGINS is set
+
+
+def floor_check(cs, floor, what=""):
+    """assert a cosine against its floor AND record how much of the allowed deviation (1 - floor) the measured one (1 - cs) uses: the
+    suite-wide rule of VERDICT r4 next #5c -- no bound within 2x of a measured value -- is checked from these records
+    (tools/margins_report.py, profiles/r05_margins.md)"""
+    import os
+    cs, floor = float(cs), float(floor)
+    MARGINS.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], str(what)[:120], 1.0 - cs, 1.0 - floor))
+    assert cs >= floor, f"{what}: cosine {cs} below the floor {floor}"
+
+
 def cosine(a, b):
     a = np.asarray(a, dtype=np.float64).reshape(-1)
     b = np.asarray(b, dtype=np.float64).reshape(-1)

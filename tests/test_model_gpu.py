@@ -95,7 +95,7 @@ def test_gradients_and_training_steps_match_reference(dev, name, chunk):
                 g = p.grad.float().cpu().numpy()
                 gold, mine = G.sub(fx, "grad." + n, g)
                 cs = G.cosine(gold, mine)
-                assert cs > 0.999, f"grad {n}: cosine {cs}"
+                G.floor_check(cs, 0.999, f"grad {n}: cosine {cs}")
                 gn = float(fx["grad." + n + ".__norm"])
                 mn = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
                 assert abs(mn - gn) < 3e-2 * gn + 1e-7, f"grad {n}: norm {mn} vs {gn}"
@@ -139,7 +139,7 @@ def test_unfrozen_encoder_training_matches_reference_fixture(dev):
                 # 0.999 like the frozen-encoder cases, except the encoder's key projections (measured 0.9988 on blocks.0): softmax is
                 # invariant to a per-query constant of the scores, so dK is what is left after that part cancels -- the smallest and
                 # (from bf16 dS tiles) noisiest gradient of the block
-                assert cs > (0.998 if n.endswith("attn.key.weight") else 0.999), f"grad {n}: cosine {cs}"
+                G.floor_check(cs, (0.998 if n.endswith("attn.key.weight") else 0.999), f"grad {n}: cosine {cs}")
                 gn = float(fx["grad." + n + ".__norm"])
                 mn = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
                 assert abs(mn - gn) < 3e-2 * gn + 1e-7, f"grad {n}: norm {mn} vs {gn}"
@@ -340,9 +340,12 @@ def test_unfrozen_hubert_train_mode_regularisers_match_oracle_with_the_same_mask
 
 # grep_linear.bias [8] and grep_a [H] of a WavLM layer are CANCELLING sums (sum_k dS = 0): their error is bounded against the norm of the
 # layer's grep_linear.weight gradient.  Round 5: the RP dQ kernel derives Delta from the recomputed P (csrc/attention.hip, two passes), so
-# sum_k dS is zero to fp32 rounding and what is left is the bf16 noise of the individual terms.  The bound is >= 2x the worst ratio
-# measured over 5 mask seeds x cases A..E on the GPU (tools/wavlm_trainmode_seeds.py -> profiles/r05_wavlm_trainmode_seeds.md).
-SMALL_GATE_BOUND = 1.0e-1
+# sum_k dS is zero to fp32 rounding and what is left is the bf16 noise of the individual terms.  Measured over cases A..E x 6 mask draws
+# on the GPU (tools/wavlm_trainmode_seeds.py -> profiles/r05_wavlm_trainmode_seeds.md): worst ratio 0.0262 (round 4, Delta from the
+# bf16 O: 0.0505 at ONE draw against a bound of 0.05 -- the driver failure); worst cosine of a tensor-sized gate gradient 0.99587, worst
+# norm deviation 0.0529.  Bounds = at least 2x the worst measured value: 0.06 / cosine floor 0.99 (1 - cos <= 2.4x) / norm 0.11.
+SMALL_GATE_BOUND = 6.0e-2
+TRAIN_MODE_NORM_TOL = 1.1e-1
 
 
 def _wave_train_mode_case(dev, tag, enc_cls, C, W, oracle_fn, wav, nv, pattern, cot, kmap, has_relpos, min_zero, mask_seed=None, report=None):
@@ -424,7 +427,7 @@ def _wave_train_mode_case(dev, tag, enc_cls, C, W, oracle_fn, wav, nv, pattern, 
         nr = abs(float(mine.norm()) - float(gold.norm())) / float(gold.norm())
         if report is not None:
             report.setdefault("cos_norm", {})[n] = (cs, nr)
-        if cs <= floor or nr >= 6e-2:
+        if cs <= floor or nr >= TRAIN_MODE_NORM_TOL:
             bad.append((n, round(cs, 5), round(nr, 4)))
     if report is not None:
         report["bad"] = bad
@@ -556,7 +559,7 @@ def _unfrozen_wave_encoder_case(dev, which, ragged, base=False):
             floor = 0.99
         if os.environ.get("SLAM_TEST_VERBOSE"):     # prints only: the asserts below run either way
             print(f"  {n:80s} cos {cs:.5f}  norm {float(mine.norm()):.4e} vs {gn:.4e}")
-        assert cs >= floor, f"grad {n}: cosine {cs}"
+        G.floor_check(cs, floor, f"grad {n}: cosine {cs}")
         assert abs(float(mine.norm()) - gn) <= 5e-2 * gn + 1e-7, f"grad {n}: norm {float(mine.norm())} vs {gn}"
     print(f"unfrozen {which} (ragged={ragged}): worst gradient cosine {worst:.6f} ({worst_name})")
     # one optimizer step moves the encoder, and the state_dict carries it under the reference's names
@@ -631,7 +634,7 @@ def test_unfrozen_whisper_with_cov1d_and_qformer_projectors(dev, projector):
             continue
         cs = G.cosine(grads[n].numpy(), mine.numpy())
         worst = min(worst, cs)
-        assert cs >= 0.998, f"grad {n}: cosine {cs}"
+        G.floor_check(cs, 0.998, f"grad {n}: cosine {cs}")
         assert abs(float(mine.norm()) - gn) <= 4e-2 * gn + 1e-7, f"grad {n}: norm {float(mine.norm())} vs {gn}"
     assert sum(1 for n in model.store.params if n.startswith("encoder.")) == 4 + 15 * cfg["enc_layers"] + 2
     print(f"unfrozen whisper + {projector}: worst gradient cosine {worst:.6f}")
@@ -872,7 +875,7 @@ def test_qformer_projector_matches_reference_fixture(dev):
             continue
         cs = G.cosine(gold, mine)
         worst = min(worst, cs)
-        assert cs > 0.998, f"grad {n}: cosine {cs}"
+        G.floor_check(cs, 0.998, f"grad {n}: cosine {cs}")
         mn = float(np.sqrt((store.grad_view(n).float().cpu().numpy().astype(np.float64) ** 2).sum()))
         assert abs(mn - gn) < 4e-2 * gn, f"grad {n}: norm {mn} vs {gn}"
     # state-dict keys equal the reference module's
@@ -1318,7 +1321,7 @@ def test_edge_shapes_match_oracle(dev, case):
         mine = model.store.grad_view(n).float().cpu()
         cs = float(F.cosine_similarity(mine.flatten(), gref.flatten(), dim=0))
         worst = min(worst, cs)
-        assert cs > 0.998, f"{case}: grad {n} cosine {cs}"
+        G.floor_check(cs, 0.998, f"{case}: grad {n} cosine {cs}")
         assert abs(float(mine.norm()) - float(gref.norm())) < 4e-2 * float(gref.norm()) + 1e-6, n
     print(case, "T =", batch["input_ids"].shape[1], "worst grad cosine", worst)
 
@@ -1376,7 +1379,7 @@ def test_ragged_encoder_step_matches_per_clip_oracle(dev, varlen_llm):
     assert abs(float(acc) - float(acc_ref)) <= 1.0 / int((ob["labels"][:, 1:] != -100).sum()) + 1e-6
     for n, p in model.store.params.items():
         cs = G.cosine(W[n].grad.numpy(), p.grad.float().cpu().numpy())
-        assert cs > 0.999, f"grad {n}: cosine {cs}"
+        G.floor_check(cs, 0.999, f"grad {n}: cosine {cs}")
 
 
 def test_ragged_encoder_equals_padded_path_when_nothing_is_ragged(dev):
