@@ -78,6 +78,8 @@ struct AttnParams {
   // launch geometry (set by attn_launch): the logical grid is (gx sequence blocks, gy heads, gz batches), launched 1-D
   int gx, gy, gz;
   int xcd;   // 1: undo the hardware's round-robin workgroup -> XCD placement (attn_blk)
+  int heavy; // causal, unpacked launches: +1 = sequence block 0 is the heaviest (dK / dV: key block 0 meets every query), -1 = the last one is
+             // (forward, dQ: the last query block meets every key); attn_blk starts each XCD's heaviest blocks first.  0 = plain order
 };
 
 // Workgroup -> (sequence block, head, batch).  The hardware deals consecutive workgroups round-robin over the 8 XCDs (workgroup L
@@ -92,7 +94,30 @@ __device__ __forceinline__ AttnBlk attn_blk(const AttnParams& p) {
   int bid = blockIdx.x;
   if (p.xcd) {
     const int n = gridDim.x, xcd = bid & 7, q = n >> 3, r = n & 7;
-    bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int a = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;   // this XCD's run of logical ids: [a, a + cnt)
+    int i = bid >> 3;
+    bid = a + i;
+    if (p.heavy != 0 && p.gx > 1) {
+      // Round 5: longest block first.  Under a causal mask the sequence blocks of one (batch, head) differ 3 : 2 : 1 in work at T = 380
+      // (12 : 8 : 4 tiles), the hardware starts an XCD's workgroups in id order and ids run sequence block fastest, so light and heavy
+      // blocks alternated and whichever heavy block happened to start last set the launch's tail (744 dK / dV workgroups on 256 CUs:
+      // ~3 waves of workgroups, the last one up to half a launch long).  The i-th workgroup an XCD starts now takes the i-th id of its
+      // run in the order (heaviest sequence block first, ascending id inside a class): same ids, same XCD (L2 reuse across the blocks
+      // of a head is what the run is for), every workgroup computes what it computed before -- results bit-identical.
+      const int cnt = (xcd < r) ? q + 1 : q;
+      const int gx = p.gx;
+      for (int j = 0; j < gx; j++) {
+        const int sb = p.heavy > 0 ? j : gx - 1 - j;
+        int f = (sb - a) % gx;             // first id >= a with id % gx == sb is a + f
+        if (f < 0) f += gx;
+        const int c = f < cnt ? (cnt - f - 1) / gx + 1 : 0;
+        if (i < c) {
+          bid = a + f + i * gx;
+          break;
+        }
+        i -= c;
+      }
+    }
   }
   AttnBlk o;
   o.x = bid % p.gx;
@@ -2374,12 +2399,14 @@ __global__ __launch_bounds__(256) void relpos_dtab_kernel(const float* __restric
 
 int g_attn_tr = 1;    // 1 = transposed operands by ds_read_b64_tr_b16 from the row-major tiles (shipped), 0 = round-3 kernels on the [B,H,D,Tp] copies
 int g_attn_xcd = 1;   // 1 = XCD-aware workgroup numbering (shipped), 0 = hardware round-robin order (A/B in tools)
+int g_attn_heavy = 1; // 1 = causal launches start each XCD's heaviest sequence blocks first (round 5), 0 = id order (A/B: slam_attn_set_fwd_qf 50 / 51)
 
 // every attention kernel is launched through this: logical 3-D grid -> 1-D launch + the geometry attn_blk() needs
 template <class Kern>
-static void attn_launch(Kern kern, dim3 grid, unsigned threads, int lds, hipStream_t s, AttnParams p) {
+static void attn_launch(Kern kern, dim3 grid, unsigned threads, int lds, hipStream_t s, AttnParams p, int heavy = 0) {
   p.gx = (int)grid.x; p.gy = (int)grid.y; p.gz = (int)grid.z;
   p.xcd = g_attn_xcd;
+  p.heavy = (g_attn_heavy && !p.seg_lo) ? heavy : 0;   // (packed batches: a block's work follows its segment, not its index)
   hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(threads), lds, s, p);
 }
 
@@ -2388,6 +2415,7 @@ int launch_dq_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr int lds = 3 * (3 * 32 * D * 2 + 1024);
   static bool attr_set = false;
   auto kern = attn_bwd_dq_ring_kernel<D, CAUSAL, QF, PROBE>;
+  constexpr int heavy = CAUSAL ? -1 : 0;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       slam_set_error("slam_attn_bwd: cannot raise the LDS limit to %d", lds);
@@ -2395,7 +2423,7 @@ int launch_dq_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
     }
     attr_set = true;
   }
-  attn_launch(kern, grid, 256, lds, s, p);
+  attn_launch(kern, grid, 256, lds, s, p, heavy);
   return 0;
 }
 
@@ -2404,6 +2432,7 @@ int launch_dkdv_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr int lds = 4 * (4 * 32 * D * 2 + 1024);
   static bool attr_set = false;
   auto kern = attn_bwd_dkdv_ring_kernel<D, CAUSAL, ABL>;
+  constexpr int heavy = CAUSAL ? 1 : 0;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       slam_set_error("slam_attn_bwd: cannot raise the LDS limit to %d", lds);
@@ -2411,7 +2440,7 @@ int launch_dkdv_ring(const AttnParams& p, dim3 grid, hipStream_t s) {
     }
     attr_set = true;
   }
-  attn_launch(kern, grid, 512, lds, s, p);
+  attn_launch(kern, grid, 512, lds, s, p, heavy);
   return 0;
 }
 
@@ -2420,6 +2449,7 @@ int launch_dq_tr(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr int lds = 3 * (2 * 32 * D * 2 + 1024);
   static bool attr_set = false;
   auto kern = attn_bwd_dq_tr_kernel<D, CAUSAL, QF>;
+  constexpr int heavy = CAUSAL ? -1 : 0;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       slam_set_error("slam_attn_bwd: cannot raise the LDS limit to %d", lds);
@@ -2427,7 +2457,7 @@ int launch_dq_tr(const AttnParams& p, dim3 grid, hipStream_t s) {
     }
     attr_set = true;
   }
-  attn_launch(kern, grid, 256, lds, s, p);
+  attn_launch(kern, grid, 256, lds, s, p, heavy);
   return 0;
 }
 
@@ -2436,6 +2466,7 @@ int launch_dkdv_tr(const AttnParams& p, dim3 grid, hipStream_t s) {
   constexpr int lds = 4 * (2 * 32 * D * 2 + 1024);
   static bool attr_set = false;
   auto kern = attn_bwd_dkdv_tr_kernel<D, CAUSAL>;
+  constexpr int heavy = CAUSAL ? 1 : 0;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       slam_set_error("slam_attn_bwd: cannot raise the LDS limit to %d", lds);
@@ -2443,7 +2474,7 @@ int launch_dkdv_tr(const AttnParams& p, dim3 grid, hipStream_t s) {
     }
     attr_set = true;
   }
-  attn_launch(kern, grid, 512, lds, s, p);
+  attn_launch(kern, grid, 512, lds, s, p, heavy);
   return 0;
 }
 
@@ -2481,10 +2512,12 @@ extern "C" int slam_attn_set_bwd_variant(int variant) {   // tools: 0 = DMA-ring
 
 extern int g_attn_fwd_dma, g_attn_fwd_plain;
 extern "C" int slam_attn_set_fwd_qf(int qf) {   // tools: 0 = auto, 1 / 2 fragments per wave; 10 / 11 = register-staged / DMA tiles
-  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11 || qf == 20 || qf == 21 || qf == 30 || qf == 31 || qf == 40 || qf == 41,
+  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11 || qf == 20 || qf == 21 || qf == 30 || qf == 31 || qf == 40 || qf == 41 || qf == 50 || qf == 51,
                  "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2; 10 / 11 = staged / DMA tiles; 20 / 21 = hardware / XCD-aware workgroup order; "
-                 "30 / 31 = general / mask-free instantiation for unmasked bidirectional D = 64; 40 / 41 = transposed-copy / transposed-read kernels)", qf);
-  if (qf >= 40) g_attn_tr = qf - 40;
+                 "30 / 31 = general / mask-free instantiation for unmasked bidirectional D = 64; 40 / 41 = transposed-copy / transposed-read kernels; "
+                 "50 / 51 = id order / heaviest sequence block first in causal launches)", qf);
+  if (qf >= 50) g_attn_heavy = qf - 50;
+  else if (qf >= 40) g_attn_tr = qf - 40;
   else if (qf >= 30) g_attn_fwd_plain = qf - 30;
   else if (qf >= 20) g_attn_xcd = qf - 20;   // (all attention kernels, forward and backward)
   else if (qf >= 10) g_attn_fwd_dma = qf - 10;
@@ -2508,23 +2541,23 @@ static void launch_fwd(const AttnParams& p, int64_t B, hipStream_t s) {
     if (trv) {
       if constexpr (D == 64 && !CAUSAL && QF == 2 && !RP && !DROP) {
         if (fits && g_attn_fwd_dma && !p.kmask && !p.seg_lo && g_attn_fwd_plain) {
-          attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true, true>), grid, 256, 0, s, p);
+          attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true, true>), grid, 256, 0, s, p, CAUSAL ? -1 : 0);
           return;
         }
       }
-      if (fits && g_attn_fwd_dma) attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, false, true>), grid, 256, 0, s, p);
-      else attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, false, false, true>), grid, 256, 0, s, p);
+      if (fits && g_attn_fwd_dma) attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, false, true>), grid, 256, 0, s, p, CAUSAL ? -1 : 0);
+      else attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, false, false, true>), grid, 256, 0, s, p, CAUSAL ? -1 : 0);
       return;
     }
   }
   if constexpr (D == 64 && !CAUSAL && QF == 2 && !RP && !DROP && !PROBE) {
     if (fits && g_attn_fwd_dma && !p.kmask && !p.seg_lo && g_attn_fwd_plain) {
-      attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true>), grid, 256, 0, s, p);
+      attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true>), grid, 256, 0, s, p, CAUSAL ? -1 : 0);
       return;
     }
   }
-  if (fits && g_attn_fwd_dma) attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true>), grid, 256, 0, s, p);
-  else attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, false>), grid, 256, 0, s, p);
+  if (fits && g_attn_fwd_dma) attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true>), grid, 256, 0, s, p, CAUSAL ? -1 : 0);
+  else attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, false>), grid, 256, 0, s, p, CAUSAL ? -1 : 0);
 }
 
 // what the 32-bit byte offsets of the DMA descriptors can address: the row-major operands (Q / dO and K / V live inside fused buffers:
@@ -2626,10 +2659,10 @@ static int launch_dq(const AttnParams& p, int64_t B, hipStream_t s, AttnFits fit
       if (g_attn_tr && fits.rowmajor) return launch_dq_tr<D, CAUSAL, 2>(p, g2, s);
       if (!g_attn_tr && fits.rowmajor && fits.copies) return launch_dq_ring<D, CAUSAL, 2>(p, g2, s);
     }
-    attn_launch((attn_bwd_dq_kernel<D, CAUSAL, false, 2>), g2, 256, 0, s, p);      // (reads Kt: slam_attn_needs_transposed asked for it)
+    attn_launch((attn_bwd_dq_kernel<D, CAUSAL, false, 2>), g2, 256, 0, s, p, CAUSAL ? -1 : 0);      // (reads Kt: slam_attn_needs_transposed asked for it)
   } else {
     dim3 g1((unsigned)cdiv64(p.Tq, 64), (unsigned)p.Hq, (unsigned)B);
-    attn_launch((attn_bwd_dq_kernel<D, CAUSAL, false, 1>), g1, 256, 0, s, p);
+    attn_launch((attn_bwd_dq_kernel<D, CAUSAL, false, 1>), g1, 256, 0, s, p, CAUSAL ? -1 : 0);
   }
   return 0;
 }
@@ -2644,7 +2677,7 @@ static int launch_dkdv(const AttnParams& p, int64_t B, hipStream_t s, AttnFits f
     if (g_attn_tr && fits.rowmajor) return launch_dkdv_tr<D, CAUSAL>(p, gk2, s);
     if (!g_attn_tr && fits.rowmajor && fits.copies) return launch_dkdv_ring<D, CAUSAL>(p, gk2, s);
   }
-  attn_launch((attn_bwd_dkdv_kernel<D, CAUSAL>), gk, 256, 0, s, p);
+  attn_launch((attn_bwd_dkdv_kernel<D, CAUSAL>), gk, 256, 0, s, p, CAUSAL ? 1 : 0);
   return 0;
 }
 

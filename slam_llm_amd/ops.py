@@ -240,7 +240,7 @@ def reset_tuning():
     gemm_set_config(400)         # cycle stamps off
     call("slam_gemm_set_group_m", 8)
     call("slam_attn_set_bwd_variant", 0)
-    for knob in (0, 11, 21, 31, 41):   # forward: auto fragments, DMA tiles, XCD-aware numbering, mask-free instantiation, transposing reads
+    for knob in (0, 11, 21, 31, 41, 51):   # auto fragments, DMA tiles, XCD-aware numbering, mask-free instantiation, transposing reads, heaviest block first
         call("slam_attn_set_fwd_qf", knob)
 
 

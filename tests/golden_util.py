@@ -29,6 +29,19 @@ def check_packed(fx, name, arr, atol, rtol, norm_rtol=None):
         assert abs(n - gn) <= norm_rtol * max(gn, 1e-12), f"{name}: norm {n} vs golden {gn}"
 
 
+# Gradient-cosine floors of the model-level GPU tests.  SURVEY 8(c) states >= 0.999 for the frozen-encoder path (LoRA + projector
+# gradients): kept.  Every other entry is a stated DEVIATION (DESIGN.md section 7 lists them with the reasons), set to at least 2x the
+# worst deviation measured on MI355X over the whole suite (tools/margins_report.py -> profiles/r05_margins.md): VERDICT r4 next #5b / #5c.
+FLOORS = dict(
+    frozen=0.999,               # worst measured 1 - cos: 3.4e-4 (projector linear1, toy widths); 6.7e-5 at the headline geometry
+    c1_full_depth=0.9965,       # 1.59e-3: layer 21 q_proj lora_A under 22 layers of bf16 residual stream (dQ is a cancelling sum over keys)
+    unfrozen_fixture=0.9975,    # 9.8e-4 / 1.2e-3: Whisper blocks.0 query / key weights at toy widths vs the reference fixture
+    unfrozen=0.996,             # 1.96e-3 (HuBERT-base pos_conv weight_g), 1.5e-3 (k_proj) at toy widths; 1.2e-3 Whisper + cov1d / Q-Former
+    unfrozen_fe=0.993,          # 3.5e-3: conv_layers.0 under seven bf16 conv / LayerNorm adjoints at 64-channel widths
+    unfrozen_wavlm_base=0.989,  # 5.2e-3: WavLM Base at toy widths, the noisiest member of the family
+    unfrozen_gate=0.983,        # 8.2e-3: grep_linear.weight / relative_attention_bias (cancelling sums of dS)
+)
+
 MARGINS = []      # (test id, what, measured deviation, allowed deviation): written by tests/conftest.py when SLAM_TEST_MARGINS is set
 
 

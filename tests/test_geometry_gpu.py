@@ -60,8 +60,9 @@ def test_c1_true_geometry_step_matches_oracle(dev):
     # 22 layers of bf16 residual stream under an fp32 oracle: the adapters of the LAST layers see a forward that has drifted by 22 x bf16
     # roundings.  Measured worst cosine (layers.21.self_attn.q_proj.lora_A) over equally valid kernel choices on MI355X: 0.99907 with the
     # mid-M products unsliced, 0.99855 with the round-4 K-sliced form (different summation order of the same fp32 products; every GEMM form
-    # is held to the fp32 product and to each other in tests/test_ops_gpu.py).  Floor 0.998 here, 0.999 at the 1-layer geometries.
-    worst = _check_grads(model, grads, cos_min=0.998)
+    # is held to the fp32 product and to each other in tests/test_ops_gpu.py).  Round 5: 0.99841 at the suite's fixed seeds; floor = 2x that
+    # deviation (tests/golden_util.FLOORS), 0.999 at the 1-layer geometries.
+    worst = _check_grads(model, grads, cos_min=G.FLOORS["c1_full_depth"])
     print(f"C1 true geometry: loss {got:.4f} vs {loss_ref:.4f}, acc {float(acc):.4f} vs {acc_ref:.4f}, worst gradient cosine {worst:.6f}")
 
 

@@ -344,3 +344,28 @@ def test_attn_xcd_order_is_bit_identical_to_hardware_order(dev):
         call("slam_attn_set_fwd_qf", 21)
     for a, b_ in zip(*res):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("B,T,Hq,Hkv,D", [(3, 380, 8, 2, 128), (2, 200, 6, 2, 64), (1, 1100, 4, 4, 128)])
+def test_attn_heaviest_block_first_order_is_bit_identical_to_id_order(dev, B, T, Hq, Hkv, D):
+    """Round 5: causal launches start each XCD's heaviest sequence blocks first (attn_blk: the i-th workgroup an XCD starts takes the
+    i-th id of its run sorted by block weight).  A pure renumbering: forward output, LSE and dQ / dK / dV must be bit-identical with the
+    knob off (slam_attn_set_fwd_qf 50) and on (51), for grids of 3, 4 and 9 / 18 sequence blocks whose sizes are not multiples of 8."""
+    from slam_llm_amd import ops
+    from slam_llm_amd.host_tables import rope_tables
+    from slam_llm_amd.lib import call
+    q2d, k2d, v2d, do2d = (_rand_bf16((B * T, H * D), dev, s) for s, H in ((41, Hq), (42, Hkv), (43, Hkv), (44, Hq)))
+    cos, sin = (t.to(dev) for t in rope_tables(T, D, 10000.0))
+    res = []
+    try:
+        for knob in (50, 51):
+            call("slam_attn_set_fwd_qf", knob)
+            o, lse = ops.attn_fwd(q2d, k2d, v2d, B, T, Hq, Hkv, D, True, D ** -0.5)
+            dq, dk, dv = torch.empty_like(q2d), torch.empty_like(k2d), torch.empty_like(v2d)
+            ops.attn_bwd(q2d, k2d, v2d, o, do2d, lse, dq, dk, dv, B, T, Hq, Hkv, D, True, D ** -0.5, rope=(cos, sin))
+            torch.cuda.synchronize()
+            res.append((o.clone(), lse[..., :T].clone(), dq, dk, dv))
+    finally:
+        call("slam_attn_set_fwd_qf", 51)
+    for a, b_ in zip(*res):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b_)

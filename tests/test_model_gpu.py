@@ -139,7 +139,7 @@ def test_unfrozen_encoder_training_matches_reference_fixture(dev):
                 # 0.999 like the frozen-encoder cases, except the encoder's key projections (measured 0.9988 on blocks.0): softmax is
                 # invariant to a per-query constant of the scores, so dK is what is left after that part cancels -- the smallest and
                 # (from bf16 dS tiles) noisiest gradient of the block
-                G.floor_check(cs, (0.998 if n.endswith("attn.key.weight") else 0.999), f"grad {n}: cosine {cs}")
+                G.floor_check(cs, (G.FLOORS["unfrozen_fixture"] if n.startswith("encoder.") else G.FLOORS["frozen"]), f"grad {n}: cosine {cs}")
                 gn = float(fx["grad." + n + ".__norm"])
                 mn = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
                 assert abs(mn - gn) < 3e-2 * gn + 1e-7, f"grad {n}: norm {mn} vs {gn}"
@@ -536,12 +536,12 @@ def _unfrozen_wave_encoder_case(dev, which, ragged, base=False):
             worst, worst_name = cs, n
         # the conv feature extractor sits under 2 transformer layers, the positional conv and up to 7 bf16 conv / LayerNorm adjoints
         # (64-channel rows at these widths): 0.995 there (measured 0.9971 on conv_layers.0), 0.998 everywhere else
-        floor = 0.995 if "feature_extractor" in n else 0.998
+        floor = G.FLOORS["unfrozen_fe"] if "feature_extractor" in n else G.FLOORS["unfrozen"]
         if base and which == "wavlm":
             # WavLM Base at these widths is the noisiest case of the family: the projector's linear1 gradient -- which does not pass through
             # the encoder backward at all, only through the bf16 forward and the LLM backward -- already sits at 0.9978 here, and the
             # encoder's own gradients follow it uniformly (measured 0.9948 worst, layer 1's key projection; norms within 4 %)
-            floor = 0.994
+            floor = G.FLOORS["unfrozen_wavlm_base"]
         if ".grep_" in n or "relative_attention_bias" in n:
             # WavLM's gate / bias-table parameters: d(gate)[q] = sum_k dS[q,k] table[k - q] is a cancelling sum (sum_k dS = 0), so the ~5 %
             # bf16 noise dS carries in this tiny end-to-end case (the same noise that puts q / k weights at 0.9985) is amplified; the
@@ -556,7 +556,7 @@ def _unfrozen_wave_encoder_case(dev, which, ragged, base=False):
                     print(f"  {n:80s} err {err:.3e} vs weight-grad norm {wn:.3e}")
                 assert err <= SMALL_GATE_BOUND * wn, f"grad {n}: error {err} vs {SMALL_GATE_BOUND} of the layer's grep_linear.weight gradient norm {wn}"
                 continue
-            floor = 0.99
+            floor = G.FLOORS["unfrozen_gate"]
         if os.environ.get("SLAM_TEST_VERBOSE"):     # prints only: the asserts below run either way
             print(f"  {n:80s} cos {cs:.5f}  norm {float(mine.norm()):.4e} vs {gn:.4e}")
         G.floor_check(cs, floor, f"grad {n}: cosine {cs}")
@@ -634,7 +634,7 @@ def test_unfrozen_whisper_with_cov1d_and_qformer_projectors(dev, projector):
             continue
         cs = G.cosine(grads[n].numpy(), mine.numpy())
         worst = min(worst, cs)
-        G.floor_check(cs, 0.998, f"grad {n}: cosine {cs}")
+        G.floor_check(cs, G.FLOORS["unfrozen"], f"grad {n}: cosine {cs}")
         assert abs(float(mine.norm()) - gn) <= 4e-2 * gn + 1e-7, f"grad {n}: norm {float(mine.norm())} vs {gn}"
     assert sum(1 for n in model.store.params if n.startswith("encoder.")) == 4 + 15 * cfg["enc_layers"] + 2
     print(f"unfrozen whisper + {projector}: worst gradient cosine {worst:.6f}")

@@ -495,7 +495,6 @@ def test_attn_bwd_with_gated_relative_position_bias(dev, T, masked, drop_p):
         sc = sc.masked_fill(km[:, None, None, :T] == 0, float("-inf"))
     pr = torch.softmax(sc, -1)
     if drop is not None:
-        from tests import golden_util as G
         keep = torch.from_numpy(G.attn_keep_mask(drop[1], drop_p, B, H, T, T, Tp, Tp)).to(dev)
         assert abs(float(keep.mean()) - (1 - drop_p)) < 0.01
         pr = pr * keep / (1 - drop_p)
@@ -1047,7 +1046,6 @@ def test_adamw_matches_torch(dev):
 def test_logmel_vs_golden_and_oracle(dev, n_mels):
     ops = _ops()
     from oracle import slam_oracle as O
-    from tests import golden_util as G
     fx = G.load("logmel")
     audio = torch.from_numpy(fx["audio"]).to(dev)  # 3.7 s clips, padded to 30 s inside the kernel
     mel = ops.logmel(audio, n_mels).cpu()  # [2, 3000, n_mels]
@@ -1107,7 +1105,6 @@ def test_dropout_mask_properties(dev):
     mask = ops.dropout(ones, p, seed=123, offset=1 << 40).float()
     # the device mask IS the host restatement of the hash (tests/golden_util.mix64), bit for bit, also for a seed with high bits set and an
     # offset whose group index crosses 2^32
-    from tests import golden_util as G
     for seed_, off_ in ((123, 1 << 40), (2 ** 63 + 99, (7 << 40) + 8), (0, (1 << 34) - 64)):
         dm = ops.dropout(ones, p, seed=seed_, offset=off_).float().cpu().ne(0)
         idx = np.uint64(off_) + np.arange(M * N, dtype=np.uint64)
@@ -1538,7 +1535,6 @@ def test_attention_probability_dropout_fwd_bwd(dev, B, Tq, Tk, H, masked):
     """slam_attn_fwd / slam_attn_bwd with drop_p > 0 (Q-Former self- and cross-attention shapes, D = 64, bidirectional) vs torch
     autograd through softmax(q.k) * mask / (1-p) @ v with the SAME mask, rebuilt on the host from the seed (tests/golden_util.py)"""
     from slam_llm_amd import ops
-    from tests import golden_util as G
     D, pdrop, seed = 64, 0.1, 0x1234567
     g = torch.Generator().manual_seed(Tq * 31 + Tk)
     q = torch.randn(B * Tq, H * D, generator=g).to(torch.bfloat16)
