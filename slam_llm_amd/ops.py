@@ -219,6 +219,9 @@ def gemm_set_config(cfg: int):
     call("slam_gemm_set_config", cfg)
 
 
+ATTN_HEAVY_FIRST = os.environ.get("SLAM_ATTN_HEAVY", "1") != "0"     # A/B: SLAM_ATTN_HEAVY=0 python bench.py (id order of causal attention workgroups)
+if not ATTN_HEAVY_FIRST:
+    call("slam_attn_set_fwd_qf", 50)
 _ENV_DEFAULTS = dict(_GEMM_BIG, sk2=SK2_AUTO, ts=TS_AUTO, splitk=os.environ.get("SLAM_GEMM_SPLITK", "off"))
 
 
@@ -240,7 +243,7 @@ def reset_tuning():
     gemm_set_config(400)         # cycle stamps off
     call("slam_gemm_set_group_m", 8)
     call("slam_attn_set_bwd_variant", 0)
-    for knob in (0, 11, 21, 31, 41, 51):   # auto fragments, DMA tiles, XCD-aware numbering, mask-free instantiation, transposing reads, heaviest block first
+    for knob in (0, 11, 21, 31, 41, 51 if ATTN_HEAVY_FIRST else 50):   # auto fragments, DMA tiles, XCD-aware numbering, mask-free instantiation, transposing reads, heaviest block first
         call("slam_attn_set_fwd_qf", knob)
 
 
