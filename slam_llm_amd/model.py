@@ -504,27 +504,44 @@ class HipWhisperEncoder(nn.Module):
                 w[f"{i}.{nme}T"] = ops.transpose(w[f"{i}.{nme}"], Rp=w[f"{i}.{nme}"].shape[0])
         w["lnp_w"], w["lnp_b"] = st.master_view(p + "ln_post.weight"), st.master_view(p + "ln_post.bias")
 
-    def forward_train(self, mel: torch.Tensor, stash: dict) -> torch.Tensor:
-        """forward_btc that keeps the activations backward_hip() needs in stash["encoder"] (GELU pre-activations instead of
-        fused-epilogue outputs; GELU outputs, im2col matrices and head transposes are recomputed in the backward).
-        Stash size: 11 [M, d]-sized bf16 tensors per block (M = B * T2): 42 GB for 31 x 30 s through Whisper-large-v3."""
-        cfg, w = self.cfg, self.w
-        B, T, nm = mel.shape
-        d, H = cfg["enc_dim"], cfg["enc_heads"]
-        T2 = (T + 1) // 2
-        assert T2 <= w["pos"].shape[0], "audio longer than the encoder's positional table"
-        M = B * T2
+    def _attn_fwd_geom(self, qkv: torch.Tensor, geom):
+        """bidirectional self-attention of the blocks for the two row layouts of the trainable encoder: ("batch", B, T2) = B equal-length
+        clips in one launch; ("clips", [(first row, rows), ...]) = the packed ragged layout, one launch per clip on row slices of the
+        packed buffers (each clip attends to its own frames only, exactly as if alone in the batch).  Returns (a [M, d], lse handle)."""
+        d, H = self.cfg["enc_dim"], self.cfg["enc_heads"]
         scale = 64 ** -0.5
-        z1 = ops.gemm_nt(ops.conv1d_k3_im2col(mel, 1, self.kp1), w["conv1"], bias=w["conv1_b"])
-        h1 = ops.gelu_fwd(z1)
-        z2 = ops.gemm_nt(ops.conv1d_k3_im2col(h1.view(B, T, d), 2, 3 * d), w["conv2"], bias=w["conv2_b"])
-        del h1
-        x = (ops.gelu_fwd(z2).view(B, T2, d) + w["pos"][:T2]).view(M, d)
-        S = {"mel": mel, "z1": z1, "z2": z2, "B": B, "T": T, "T2": T2, "blocks": []}
+        if geom[0] == "batch":
+            _, B, T2 = geom
+            return ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T2, H, H, 64, False, scale, want_lse=True)
+        a = torch.empty((qkv.shape[0], d), dtype=torch.bfloat16, device=qkv.device)
+        lses = []
+        for r0, n in geom[1]:
+            q = qkv[r0: r0 + n]
+            _, lse = ops.attn_fwd(q[:, :d], q[:, d: 2 * d], q[:, 2 * d:], 1, n, H, H, 64, False, scale, want_lse=True, out=a[r0: r0 + n])
+            lses.append(lse)
+        return a, lses
+
+    def _attn_bwd_geom(self, qkv, a, da, lse, dqkv, geom):
+        d, H = self.cfg["enc_dim"], self.cfg["enc_heads"]
+        scale = 64 ** -0.5
+        if geom[0] == "batch":
+            _, B, T2 = geom
+            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], a, da, lse, dqkv[:, :d], dqkv[:, d: 2 * d], dqkv[:, 2 * d:],
+                         B, T2, H, H, 64, False, scale)
+            return
+        for (r0, n), lse_c in zip(geom[1], lse):
+            q, dq = qkv[r0: r0 + n], dqkv[r0: r0 + n]
+            ops.attn_bwd(q[:, :d], q[:, d: 2 * d], q[:, 2 * d:], a[r0: r0 + n], da[r0: r0 + n], lse_c, dq[:, :d], dq[:, d: 2 * d], dq[:, 2 * d:],
+                         1, n, H, H, 64, False, scale)
+
+    def _blocks_train(self, x: torch.Tensor, S: dict, geom):
+        """the transformer blocks + ln_post on rows x [M, d], keeping what _blocks_backward needs in S"""
+        cfg, w = self.cfg, self.w
+        S["blocks"], S["geom"] = [], geom
         for i in range(cfg["enc_layers"]):
             h, m1, r1 = ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], stats=True)
             qkv = ops.gemm_nt(h, w[f"{i}.qkv"], bias=w[f"{i}.qkv_b"])
-            a, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T2, H, H, 64, False, scale, want_lse=True)
+            a, lse = self._attn_fwd_geom(qkv, geom)
             x1 = ops.gemm_nt(a, w[f"{i}.out"], bias=w[f"{i}.out_b"], residual=x)
             h2, m2, r2 = ops.layernorm(x1, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], stats=True)
             z = ops.gemm_nt(h2, w[f"{i}.fc1"], bias=w[f"{i}.fc1_b"])
@@ -533,8 +550,62 @@ class HipWhisperEncoder(nn.Module):
             x = x2
         out, mo, ro = ops.layernorm(x, w["lnp_w"], w["lnp_b"], stats=True)
         S.update(x_last=x, mo=mo, ro=ro)
+        return out
+
+    def forward_train(self, mel: torch.Tensor, stash: dict) -> torch.Tensor:
+        """forward_btc that keeps the activations backward_hip() needs in stash["encoder"] (GELU pre-activations instead of
+        fused-epilogue outputs; GELU outputs, im2col matrices and head transposes are recomputed in the backward).
+        Stash size: 11 [M, d]-sized bf16 tensors per block (M = B * T2): 42 GB for 31 x 30 s through Whisper-large-v3."""
+        cfg, w = self.cfg, self.w
+        B, T, nm = mel.shape
+        d = cfg["enc_dim"]
+        T2 = (T + 1) // 2
+        assert T2 <= w["pos"].shape[0], "audio longer than the encoder's positional table"
+        M = B * T2
+        z1 = ops.gemm_nt(ops.conv1d_k3_im2col(mel, 1, self.kp1), w["conv1"], bias=w["conv1_b"])
+        h1 = ops.gelu_fwd(z1)
+        z2 = ops.gemm_nt(ops.conv1d_k3_im2col(h1.view(B, T, d), 2, 3 * d), w["conv2"], bias=w["conv2_b"])
+        del h1
+        x = (ops.gelu_fwd(z2).view(B, T2, d) + w["pos"][:T2]).view(M, d)
+        S = {"mel": mel, "z1": z1, "z2": z2, "B": B, "T": T, "T2": T2}
+        out = self._blocks_train(x, S, ("batch", B, T2))
         stash["encoder"] = S
         return out.view(B, T2, d)
+
+    def forward_packed_train(self, mel: torch.Tensor, n_frames: List[int], stash: dict):
+        """forward_packed with the encoder UN-frozen (round 5: `train_config.freeze_encoder=false` + `++model_config.varlen_encoder=true`,
+        which SlamHipModel used to refuse): same arithmetic as forward_packed -- every clip encoded as if alone in the batch -- keeping
+        what backward_hip needs.  Attention runs one launch per clip on row slices of the packed buffers (the backward kernels take
+        packed segments only under a causal mask); everything else runs on the packed rows.  Returns (packed output [sum T2_b, d], T2)."""
+        cfg, w = self.cfg, self.w
+        B, T, nm = mel.shape
+        d, dev = cfg["enc_dim"], mel.device
+        assert len(n_frames) == B and max(n_frames) <= T
+        T2 = [(n + 1) // 2 for n in n_frames]
+        T2max = (T + 1) // 2
+        assert max(T2) <= w["pos"].shape[0], "audio longer than the encoder's positional table"
+        nf = torch.tensor(n_frames, dtype=torch.int32).to(dev, non_blocking=True)
+        z1 = ops.gemm_nt(ops.conv1d_k3_im2col(mel, 1, self.kp1, n_valid=nf), w["conv1"], bias=w["conv1_b"])
+        h1 = ops.gelu_fwd(z1)
+        z2 = ops.gemm_nt(ops.conv1d_k3_im2col(h1.view(B, T, d), 2, 3 * d, n_valid=nf), w["conv2"], bias=w["conv2_b"])   # frames past a clip's own read as zero
+        del h1
+        xpad = (ops.gelu_fwd(z2).view(B, T2max, d) + w["pos"][:T2max]).view(B * T2max, d)     # the positional embedding restarts at every clip
+        idx, clips, inv2, valid1 = [], [], torch.full((B * T2max,), -1, dtype=torch.int32), torch.full((B * T,), -1, dtype=torch.int32)
+        acc = 0
+        for b_, (t2, n1) in enumerate(zip(T2, n_frames)):
+            idx.append(torch.arange(b_ * T2max, b_ * T2max + t2, dtype=torch.int32))
+            inv2[b_ * T2max: b_ * T2max + t2] = torch.arange(acc, acc + t2, dtype=torch.int32)   # padded conv2 row -> packed row
+            valid1[b_ * T: b_ * T + n1] = torch.arange(b_ * T, b_ * T + n1, dtype=torch.int32)    # conv1 frames conv2 really read
+            clips.append((acc, t2))
+            acc += t2
+        meta = torch.cat(idx).to(dev, non_blocking=True)
+        x = ops.gather_rows(xpad, meta)
+        del xpad
+        S = {"mel": mel, "z1": z1, "z2": z2, "B": B, "T": T, "T2": T2max, "nf": nf, "inv2": inv2.to(dev, non_blocking=True),
+             "valid1": valid1.to(dev, non_blocking=True)}
+        out = self._blocks_train(x, S, ("clips", clips))
+        stash["encoder"] = S
+        return out, T2
 
     def _lin_grads(self, dy: torch.Tensor, x: torch.Tensor, w_name: str, acc: bool, N: Optional[int] = None,
                    K: Optional[int] = None, bias: Tuple = ()):
@@ -550,14 +621,15 @@ class HipWhisperEncoder(nn.Module):
             ops.colsum(dy[:, c0: c0 + n], st.grad_view(name), accumulate=acc)
 
     def backward_hip(self, dout: torch.Tensor, stash: dict, acc: bool):
-        """dout [B*T2, d] bf16 = dL/d(encoder output); deposits every encoder gradient into the flat grad buffer
-        (hand-written adjoint of extract_variable_length_features, models/encoder.py:13-30)"""
+        """dout [M, d] bf16 = dL/d(encoder output) on the rows the forward returned (B * T2 padded rows, or the packed rows of
+        forward_packed_train); deposits every encoder gradient into the flat grad buffer (hand-written adjoint of
+        extract_variable_length_features, models/encoder.py:13-30)"""
         cfg, w, st, p = self.cfg, self.w, self.store, self.prefix
         S = stash.pop("encoder")
         B, T, T2 = S["B"], S["T"], S["T2"]
-        d, H, nm = cfg["enc_dim"], cfg["enc_heads"], cfg["n_mels"]
+        d, nm = cfg["enc_dim"], cfg["n_mels"]
         M = B * T2
-        scale = 64 ** -0.5
+        nf, geom = S.get("nf"), S["geom"]
         gv = st.grad_view
         dx = ops.layernorm_bwd(S["x_last"], S["mo"], S["ro"], w["lnp_w"], dout, dgamma=gv(p + "ln_post.weight"),
                                dbeta=gv(p + "ln_post.bias"), accumulate=acc)
@@ -580,8 +652,7 @@ class HipWhisperEncoder(nn.Module):
             da = ops.gemm_nt(dx1, w[f"{i}.outT"])
             qkv = R["qkv"]
             dqkv = torch.empty_like(qkv)
-            ops.attn_bwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], R["a"], da, R["lse"], dqkv[:, :d],
-                         dqkv[:, d: 2 * d], dqkv[:, 2 * d:], B, T2, H, H, 64, False, scale)
+            self._attn_bwd_geom(qkv, R["a"], da, R["lse"], dqkv, geom)
             del da
             self._lin_grads(dqkv, R["h"], b + "attn.query.weight", acc, N=3 * d, K=d,
                             bias=((b + "attn.query.bias", 0, d), (b + "attn.value.bias", 2 * d, d)))
@@ -592,9 +663,11 @@ class HipWhisperEncoder(nn.Module):
             ops.add_(dx, dx1)
             S["blocks"][i] = None
         # conv stem: x0 = gelu(conv2(gelu(conv1(mel)))) + pos  (pos is a fixed buffer)
+        if nf is not None:      # packed rows -> the padded conv2 layout (rows past a clip's own frames carry no gradient)
+            dx = ops.gather_rows(dx, S["inv2"])
         dz2 = ops.gelu_bwd(S["z2"], dx)
         h1 = ops.gelu_fwd(S["z1"])
-        cols2 = ops.conv1d_k3_im2col(h1.view(B, T, d), 2, 3 * d)
+        cols2 = ops.conv1d_k3_im2col(h1.view(B, T, d), 2, 3 * d, n_valid=nf)
         del h1
         Mp = round_up(M, 64)
         g2 = ops.gemm_nt(ops.transpose(dz2, Rp=Mp), ops.transpose(cols2, Rp=Mp), out_dtype=torch.float32)   # [d, 3d], tap-major
@@ -603,8 +676,10 @@ class HipWhisperEncoder(nn.Module):
         gv(p + "conv2.weight").add_(g2) if acc else gv(p + "conv2.weight").copy_(g2)
         ops.colsum(dz2, gv(p + "conv2.bias"), accumulate=acc)
         dh1 = ops.conv1d_k3_col2im(ops.gemm_nt(dz2, w["conv2T"]), B, T, d, 2)
+        if nf is not None:      # conv2 read ZEROS (not conv1's output) past a clip's own frames: no gradient flows to those conv1 rows
+            dh1 = ops.gather_rows(dh1.view(B * T, d), S["valid1"]).view(B, T, d)
         dz1 = ops.gelu_bwd(S["z1"], dh1.view(B * T, d))
-        cols1 = ops.conv1d_k3_im2col(S["mel"], 1, self.kp1)
+        cols1 = ops.conv1d_k3_im2col(S["mel"], 1, self.kp1, n_valid=nf)
         M1p = round_up(B * T, 64)
         g1 = ops.gemm_nt(ops.transpose(dz1, Rp=M1p), ops.transpose(cols1, Rp=M1p), out_dtype=torch.float32)  # [d, kp1]
         g1 = g1[:, : 3 * nm].reshape(d, 3, nm).permute(0, 2, 1)
@@ -1857,7 +1932,8 @@ class HipProjectorConcat(nn.Module):
         ops.gemm_nt(dhT, xT, out=s.grad_view(p + "linear1.weight"), accumulate=accumulate)
         ops.colsum(dh, s.grad_view(p + "linear1.bias"), accumulate=accumulate)
         if self.need_dx:
-            return self._unstack(ops.gemm_nt(dh, self.w1T), stash)
+            dxp = ops.gemm_nt(dh, self.w1T)
+            return self._unstack(dxp, stash) if "proj_shape" in stash else dxp     # (forward_rows: the caller owns the row layout)
         stash.pop("proj_shape", None)
         return None
 
@@ -1946,7 +2022,8 @@ class HipProjectorCov1d(nn.Module):
             g.copy_(dwc)
         ops.colsum(dc, s.grad_view(p + "conv1d.bias"), accumulate=accumulate)
         if self.need_dx:
-            return self._unstack(ops.gemm_nt(dc, self.wcT), stash)
+            dxp = ops.gemm_nt(dc, self.wcT)
+            return self._unstack(dxp, stash) if "proj_shape" in stash else dxp     # (forward_rows: the caller owns the row layout)
         stash.pop("proj_shape", None)
         return None
 
@@ -2387,9 +2464,9 @@ class SlamHipModel(nn.Module):
         self.projector_name = cfg.get("projector", "linear")
         # train_config.freeze_encoder=false (models/slam_model.py:110-113): the encoder's parameters join the trainable store
         self.train_encoder = not bool(cfg.get("freeze_encoder", True))
-        if self.train_encoder and (self.encoder_name not in ("whisper", "hubert", "wavlm") or cfg.get("varlen_encoder", False)):
+        if self.train_encoder and self.encoder_name not in ("whisper", "hubert", "wavlm"):
             raise NotImplementedError("freeze_encoder=false is implemented for the Whisper, HuBERT and WavLM encoders (hand-written encoder "
-                                      "backward) with the linear / cov1d-linear / q-former projectors on padded batches; varlen_encoder is not")
+                                      "backward) with the linear / cov1d-linear / q-former projectors")
         if self.encoder_name in ("hubert", "wavlm"):
             cfg["enc_dim"] = cfg["hub_dim"]
             if not self.train_encoder:
@@ -2744,7 +2821,11 @@ class SlamHipModel(nn.Module):
         """packed encoder -> projector -> padded [B, Ta_max, dl] for the splice (rows past a clip's own audio tokens are zero,
         which is what the splice's clamp `min(sum(mask), Ta)` never reads anyway)."""
         dev = self.device_
-        enc, T2 = self.encoder.forward_packed(audio_mel, n_frames)
+        enc_train = self.train_encoder and stash is not None      # round 5: un-frozen Whisper on the ragged layout
+        if enc_train:
+            enc, T2 = self.encoder.forward_packed_train(audio_mel, n_frames, stash)
+        else:
+            enc, T2 = self.encoder.forward_packed(audio_mel, n_frames)
         B, d = len(T2), enc.shape[1]
         if self.projector_name == "q-former":   # cross-attends over the frames under a key mask: hand it the padded layout
             T2max = max(T2)
@@ -2753,6 +2834,8 @@ class SlamHipModel(nn.Module):
             for b_, t2 in enumerate(T2):
                 inv[b_, :t2] = torch.arange(acc, acc + t2, dtype=torch.int32)
                 acc += t2
+            if enc_train:      # dL/d(padded layout) -> packed rows: row i of the packed output sits at padded row enc_rows[i]
+                stash["ragged_enc_rows"] = torch.nonzero(inv.view(-1) >= 0).view(-1).to(torch.int32).to(dev, non_blocking=True)
             inv = inv.to(dev, non_blocking=True)
             encp = ops.gather_rows(enc, inv.view(-1)).view(B, T2max, d)
             return self.encoder_projector.forward_hip(encp, (inv >= 0).to(torch.float32), stash)
@@ -2769,6 +2852,13 @@ class SlamHipModel(nn.Module):
             valid.append(b_ * Tam + torch.arange(ta, dtype=torch.int32))
             acc += t2
             row += ta
+        if enc_train:
+            # adjoint of the window gather below: packed encoder row r = win[i] + j is row i * k + j of dL/d(xp) viewed as [sum Ta * k, d];
+            # the t2 % k last frames of a clip belong to no window (the reference's view(B, T // k, k * d) drops them): zero gradient
+            unwin = torch.full((sum(T2),), -1, dtype=torch.int32)
+            for i, r0 in enumerate(torch.cat(win).tolist()):
+                unwin[r0: r0 + k] = torch.arange(i * k, (i + 1) * k, dtype=torch.int32)
+            stash["ragged_unwindow"] = unwin.to(dev, non_blocking=True)
         win = torch.cat(win).to(dev, non_blocking=True)
         inv = inv.view(-1).to(dev, non_blocking=True)
         xp = ops.gather_rows(enc, win, width=k * d)                        # [sum Ta, k*d]: the reference's view(B, T//k, k*d) per clip
@@ -2810,6 +2900,10 @@ class SlamHipModel(nn.Module):
             dproj = ops.gather_rows(dproj, stash["proj_valid_rows"])
         d_enc = self.encoder_projector.backward_hip(dproj, stash, accumulate)
         if self.train_encoder:
+            if stash.get("ragged_unwindow") is not None:      # ragged encoder, stacked-row projectors: dL/d(k-frame windows) -> packed encoder rows
+                d_enc = ops.gather_rows(d_enc.reshape(-1, self.cfg["enc_dim"]), stash.pop("ragged_unwindow"))
+            elif stash.get("ragged_enc_rows") is not None:    # ragged encoder, Q-Former: padded [B * T2max, d] -> packed rows
+                d_enc = ops.gather_rows(d_enc.reshape(-1, self.cfg["enc_dim"]), stash.pop("ragged_enc_rows"))
             self.encoder.backward_hip(d_enc, stash, accumulate)
         if st.pure_bf16:       # gradients leave in the parameters' dtype: one rounding of the fp32 sums per backward
             if as_autograd:
