@@ -193,6 +193,11 @@ __device__ __forceinline__ unsigned lds_offset_of(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
+template <bool FIRST, class A, class B>
+__device__ __forceinline__ auto& pick_ref(A& a, B& b) {
+  if constexpr (FIRST) return a;
+  else return b;
+}
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -320,8 +325,12 @@ __device__ unsigned long long g_attn_probe[2 * 16 * 8];   // tools: cycle stamps
 // QF = 16-row query fragments per wave (2: 128-query workgroups; 1: 64-query workgroups, fewer VGPRs -> more waves per SIMD)
 // TRV (round 4, shipped): the V tile is staged ROW-MAJOR ([64 keys][D], straight from the fused QKV buffer: no [B,H,D,Tp] copy of V) and
 // the V^T operand of O^T += V^T P^T is read with ds_read_b64_tr_b16 (two 8-byte reads per fragment instead of one 16-byte read)
-template <int D, bool CAUSAL, int QF, bool RP = false, bool DROP = false, bool PROBE = false, bool DMA = false, bool PLAIN = false, bool TRV = false>
+// QS (round 5; inference-only launches of the PLAIN form: the frozen Whisper encoder, no LSE wanted): the Q fragments are multiplied by
+// scale * log2(e) once, when they are loaded (one more bf16 rounding of Q), and interior tiles start the S^T accumulators at -m (the
+// running maximum): the first product then delivers s * scale * log2(e) - m and P = exp2 of it -- no v_fma per score in the softmax.
+template <int D, bool CAUSAL, int QF, bool RP = false, bool DROP = false, bool PROBE = false, bool DMA = false, bool PLAIN = false, bool TRV = false, bool QS = false>
 __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnParams p) {
+  static_assert(!QS || (PLAIN && !CAUSAL && !RP && !DROP), "QS is a variant of the mask-free bidirectional form");
   constexpr int KD = D / 32;
   constexpr int DF = D / 16;
   constexpr int KROWB = D * 2;
@@ -354,6 +363,8 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
   constexpr int QW = 16 * QF;   // query rows per wave
   const int qb0 = blk.x * (4 * QW), qw0 = qb0 + wave * QW;
 
+  const float sl2 = p.scale * LOG2E;
+  const float ksc = QS ? 1.0f : sl2;   // what turns a score of the first product into log2 units
   frag_t qf[QF][KD];
 #pragma unroll
   for (int f = 0; f < QF; f++) {
@@ -362,6 +373,10 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
     for (int kd = 0; kd < KD; kd++) {
       qf[f][kd] = (q < Tq) ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * Tq + q) * p.ldq + h * D + kd * 32 + g * 8)
                           : zero_frag();
+      if constexpr (QS) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) qf[f][kd][e] = f2bf(bf2f(qf[f][kd][e]) * sl2);
+      }
     }
   }
   f32x4_t o[QF][DF];
@@ -382,7 +397,6 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
   const bool seg_both = !CAUSAL && seg_lo_ != nullptr;
   const int kend = CAUSAL ? min(Tk, qb0 + 4 * QW) : (seg_both ? min(Tk, seg_hi_[(int64_t)b * Tq + min(qb0 + 4 * QW - 1, Tq - 1)]) : Tk);
   const int ntiles = (kend + 63) / 64;
-  const float sl2 = p.scale * LOG2E;
   const int tbeg = seg_lo_ ? seg_lo_[(int64_t)b * Tq + min(qb0, Tq - 1)] / 64 : 0;
   int qlo[QF], qhi[QF];
 #pragma unroll
@@ -578,8 +592,13 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
     // 16-byte LDS read (it was two 8-byte reads and a register shuffle).  LDS reads are asm with counted waits: all K fragments
     // are requested up front, products start as they land; the V^T reads of the first pair are requested before the softmax
     // arithmetic and land behind it.
+    // QS (a PLAIN form: no mask, no segments): a tile behind the first one (every row has a finite maximum by then) starts its
+    // accumulators at -m; the keys past Tk of the last tile start theirs at -inf (P = 0 on every path: the QS form has no masked path)
+    const bool pre = QS && it > tb;
+    const bool tail = QS && k0 + 64 > Tk;
     f32x4_t s[QF][4];
-    {
+    auto s_product = [&](const bool from_minus_m, auto tail_c, const int li, const int g) {   // (li, g: see the second call)
+      constexpr bool TAIL = decltype(tail_c)::value;
       const int i4 = (li >> 2) * 8 + (li & 3);
       const unsigned kbase = lds_offset_of(ldsK) + (unsigned)(i4 * KROWB);
       unsigned ka[KD];
@@ -601,13 +620,21 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
           });
 #pragma unroll
         for (int f = 0; f < QF; f++) {
-          f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          const float a0 = (QS && from_minus_m) ? -mrow[f] : 0.f;
+          f32x4_t acc = f32x4_t{a0, a0, a0, a0};
+          if constexpr (TAIL) {   // element r of fragment kf is key k0 + 32 (kf / 2) + 8 g + 4 (kf % 2) + r
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              if (k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4 + r >= Tk) acc[r] = -INFINITY;
+          }
 #pragma unroll
           for (int kd = 0; kd < KD; kd++) acc = mfma16(kfr[kf][kd], qf[f][kd], acc);
           s[f][kf] = acc;
         }
       });
-    }
+    };
+    if (QS && tail) s_product(pre, std::true_type{}, li, g);
+    else s_product(pre, std::false_type{}, li, g);
     stamp(it, 4);
     const unsigned vbase = lds_offset_of(ldsV) + (unsigned)(li * 128);
     unsigned va[2];
@@ -637,8 +664,8 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
     // exact in fp32 / bf16, and the O / l rescale becomes a rare wave-uniform branch instead of 2 exp + 16 multiplies per tile
     // interior tiles (no padded key, fully inside [0, Tk), fully below the causal diagonal of this wave) skip all masking
     const bool tile_pad = kmask_ != nullptr && (!pad_known || ((padtiles >> it) & 1ull) != 0);
-    const bool tile_full = !RP && !DROP && !tile_pad && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0 &&
-                           k0 + 64 <= hi_wave_min;
+    const bool tile_full = QS || (!RP && !DROP && !tile_pad && (k0 + 64 <= Tk) && (!CAUSAL || k0 + 63 <= qw0) && lo_wave_max <= k0 &&
+                                  k0 + 64 <= hi_wave_min);
     float alpha[QF];
     bool moved = false;
     // interior tiles first try the running maximum as it is: P = exp2(s * sl2 - m) with no tile maximum at all (32 v_max and
@@ -646,23 +673,32 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
     // tile, where m = -inf) sends the whole wave through the ordinary path below, which moves the maximum.
     // (bidirectional kernels only: a causal wave of the LLM shape sees three or four tiles, the first of them always slow)
     bool fast_done = false;
-    if (!CAUSAL && tile_full) {
-      f32x4_t pt[QF][4];
+    // P of this tile.  Every path below writes it here and the second product packs it from here: the raw scores `s` stay intact for
+    // the ordinary path when the attempt fails, and a successful attempt costs no register copies (round 5: the former `s = pt` merge
+    // was 32 v_mov per tile in the Whisper loop, a quarter of its VALU instructions)
+    // (kernels without the attempt, and the QS form, which computes the scores again when it fails, keep P in the registers of s)
+    constexpr bool PSEP = !CAUSAL && !QS;
+    f32x4_t pt_own[PSEP ? QF : 1][4];
+    auto& pt = pick_ref<PSEP>(pt_own, s);
+    if (!CAUSAL && tile_full && (!QS || pre)) {
       float rs[QF];
       bool over = false;
 #pragma unroll
       for (int f = 0; f < QF; f++) {
-        float acc = 0.f;
+        float acc0 = 0.f, acc1 = 0.f;   // two chains (the translation unit is built without SLP packing: v_pk_add_f32 beside MFMAs is slower than two v_add_f32)
 #pragma unroll
         for (int kf = 0; kf < 4; kf++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const float pv = fast_exp2(fmaf(s[f][kf][r], sl2, -mrow[f]));
-            pt[f][kf][r] = pv;
-            acc += pv;
+          for (int r = 0; r < 4; r += 2) {
+            const float pv0 = fast_exp2(QS ? s[f][kf][r] : fmaf(s[f][kf][r], sl2, -mrow[f]));
+            const float pv1 = fast_exp2(QS ? s[f][kf][r + 1] : fmaf(s[f][kf][r + 1], sl2, -mrow[f]));
+            pt[f][kf][r] = pv0;
+            pt[f][kf][r + 1] = pv1;
+            acc0 += pv0;
+            acc1 += pv1;
           }
-        rs[f] = acc;
-        over |= !(acc <= 64.0f);
+        rs[f] = acc0 + acc1;
+        over |= !(rs[f] <= 64.0f);
       }
       if (!__any(over)) {
         fast_done = true;
@@ -670,9 +706,16 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
         for (int f = 0; f < QF; f++) {
           alpha[f] = 1.0f;
           lrow[f] += rs[f];
-#pragma unroll
-          for (int kf = 0; kf < 4; kf++) s[f][kf] = pt[f][kf];
         }
+      } else if constexpr (QS) {
+        // rare (a row's maximum grew by more than 2^6 inside one tile): the ordinary path below wants the scores themselves.  They are
+        // computed again from the K tile (still in its stage; no LDS read is outstanding here) instead of being kept alive beside P
+        // through every successful attempt: that cost 32 VGPRs of the 168 three waves per SIMD allow
+        // (its LDS addresses are derived from an opaque copy of the thread id: one register less carried through the loop for this path)
+        int t2 = threadIdx.x;
+        asm volatile("" : "+v"(t2));
+        if (tail) s_product(false, std::true_type{}, t2 & 15, (t2 >> 4) & 3);
+        else s_product(false, std::false_type{}, t2 & 15, (t2 >> 4) & 3);
       }
     }
     if (fast_done) {
@@ -685,7 +728,7 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
 #pragma unroll
           for (int r = 0; r < 4; r++) mt = fmaxf(mt, s[f][kf][r]);
         mt = max_across_groups(mt);
-        mt *= sl2;
+        mt *= ksc;
         const bool mv = mt > mrow[f] + 8.0f;
         const float mnew = mv ? mt : mrow[f];
         alpha[f] = mv ? fast_exp2(mrow[f] - mnew) : 1.0f;
@@ -696,8 +739,8 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
         for (int kf = 0; kf < 4; kf++)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const float pv = fast_exp2(fmaf(s[f][kf][r], sl2, -mnew));
-            s[f][kf][r] = pv;
+            const float pv = fast_exp2(fmaf(s[f][kf][r], ksc, -mnew));
+            pt[f][kf][r] = pv;
             rs += pv;
           }
         lrow[f] = lrow[f] * alpha[f] + rs;
@@ -734,7 +777,7 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
             for (int r = 0; r < 4; r++) {
               bool ok = any && (unsigned)(rel + ko + r) <= span;
               if constexpr (PAD) ok = ok && (mk[kf] & (0xffu << (8 * r))) != 0;
-              const float x = ok ? fmaf(s[f][kf][r], sl2, bias[r]) : -INFINITY;
+              const float x = ok ? fmaf(s[f][kf][r], ksc, bias[r]) : -INFINITY;
               s[f][kf][r] = x;
               mt = fmaxf(mt, x);
             }
@@ -755,7 +798,7 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
             for (int r = 0; r < 4; r++) {
               const float pv = fast_exp2(s[f][kf][r] - muse);
               rs += pv;                                    // the row sum is over the UNdropped probabilities
-              s[f][kf][r] = DROP ? (((keep >> r) & 1u) ? pv * p.drop_scale : 0.f) : pv;
+              pt[f][kf][r] = DROP ? (((keep >> r) & 1u) ? pv * p.drop_scale : 0.f) : pv;
             }
           }
           lrow[f] = lrow[f] * alpha[f] + rs;
@@ -779,7 +822,7 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int f = 0; f < QF; f++) pb[a][f] = pack_frag(s[f][2 * a], s[f][2 * a + 1]);
+        for (int f = 0; f < QF; f++) pb[a][f] = pack_frag(pt[f][2 * a], pt[f][2 * a + 1]);
       static_for<TPRE, TAH>([&](auto t) {      // (PLAIN: nothing was requested before the softmax)
         vtr[t].lo = lds_read_tr<((t / DF) * 32) * KROWB>(vta[t % DF]);
         vtr[t].hi = lds_read_tr<((t / DF) * 32 + 4) * KROWB>(vta[t % DF]);
@@ -800,7 +843,7 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
     static_for<0, 2>([&](auto a) {
       frag_t pb[QF];
 #pragma unroll
-      for (int f = 0; f < QF; f++) pb[f] = pack_frag(s[f][2 * a], s[f][2 * a + 1]);
+      for (int f = 0; f < QF; f++) pb[f] = pack_frag(pt[f][2 * a], pt[f][2 * a + 1]);
       if constexpr (a == 0) static_for<0, DF>([&](auto df) { vfr[1][df] = lds_read128<df * 16 * 128>(va[1]); });
       static_for<0, DF>([&](auto df) {
         lds_wait<(a == 0 ? DF : 0) + (DF - 1 - df)>(vfr[a][df]);
@@ -814,12 +857,22 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
   if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail DMAs still target this workgroup's LDS
 
   // ---- epilogue ----
+  // (QS: the lane's row / column indices are derived again from an opaque copy of the thread id, so that the output addresses are
+  // computed here instead of being carried -- spilled, at the 168 registers of three waves per SIMD -- from the prologue through the loop)
+  int e_li = li, e_g = g, e_qw0 = qw0;
+  if constexpr (QS) {
+    int t2 = threadIdx.x;
+    asm volatile("" : "+v"(t2));
+    e_li = t2 & 15;
+    e_g = (t2 >> 4) & 3;
+    e_qw0 = qb0 + __builtin_amdgcn_readfirstlane(t2 >> 6) * QW;
+  }
 #pragma unroll
   for (int f = 0; f < QF; f++) {
     float lt = lrow[f];
     lt = sum_across_groups(lt);
     const float inv = lt > 0.f ? 1.0f / lt : 0.f;
-    const int q = qw0 + f * 16 + li;
+    const int q = e_qw0 + f * 16 + e_li;
     if (q >= Tq) continue;
     bf16_t* orow = p.O + ((int64_t)b * Tq + q) * p.ldo + h * D;
 #pragma unroll
@@ -827,9 +880,9 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
       uint2 w;
       w.x = pack2bf(o[f][df][0] * inv, o[f][df][1] * inv);
       w.y = pack2bf(o[f][df][2] * inv, o[f][df][3] * inv);
-      *reinterpret_cast<uint2*>(orow + df * 16 + 4 * g) = w;
+      *reinterpret_cast<uint2*>(orow + df * 16 + 4 * e_g) = w;
     }
-    if (p.LSE && g == 0)
+    if (p.LSE && e_g == 0)
       p.LSE[((int64_t)b * p.Hq + h) * Tqp + q] = lt > 0.f ? (mrow[f] * LN2 + __logf(lt)) : INFINITY;
   }
 }
@@ -2510,13 +2563,15 @@ extern "C" int slam_attn_set_bwd_variant(int variant) {   // tools: 0 = DMA-ring
   return 0;
 }
 
-extern int g_attn_fwd_dma, g_attn_fwd_plain;
+extern int g_attn_fwd_dma, g_attn_fwd_plain, g_attn_fwd_qs;
 extern "C" int slam_attn_set_fwd_qf(int qf) {   // tools: 0 = auto, 1 / 2 fragments per wave; 10 / 11 = register-staged / DMA tiles
-  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11 || qf == 20 || qf == 21 || qf == 30 || qf == 31 || qf == 40 || qf == 41 || qf == 50 || qf == 51,
+  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11 || qf == 20 || qf == 21 || qf == 30 || qf == 31 || qf == 40 || qf == 41 || qf == 50 || qf == 51 || qf == 60 || qf == 61,
                  "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2; 10 / 11 = staged / DMA tiles; 20 / 21 = hardware / XCD-aware workgroup order; "
                  "30 / 31 = general / mask-free instantiation for unmasked bidirectional D = 64; 40 / 41 = transposed-copy / transposed-read kernels; "
-                 "50 / 51 = id order / heaviest sequence block first in causal launches)", qf);
-  if (qf >= 50) g_attn_heavy = qf - 50;
+                 "50 / 51 = id order / heaviest sequence block first in causal launches; 60 / 61 = scores scaled in the softmax / Q pre-scaled "
+                 "and accumulators started at -m in LSE-less mask-free launches)", qf);
+  if (qf >= 60) g_attn_fwd_qs = qf - 60;
+  else if (qf >= 50) g_attn_heavy = qf - 50;
   else if (qf >= 40) g_attn_tr = qf - 40;
   else if (qf >= 30) g_attn_fwd_plain = qf - 30;
   else if (qf >= 20) g_attn_xcd = qf - 20;   // (all attention kernels, forward and backward)
@@ -2525,6 +2580,7 @@ extern "C" int slam_attn_set_fwd_qf(int qf) {   // tools: 0 = auto, 1 / 2 fragme
   return 0;
 }
 
+int g_attn_fwd_qs = 1;    // 1 = LSE-less launches of the mask-free form run with Q pre-scaled by scale * log2(e) (attn_fwd_kernel<..., QS>)
 int g_attn_fwd_plain = 1; // 1 = unmasked bidirectional D = 64 launches (Whisper) take the instantiation without mask / segment bookkeeping
 int g_attn_fwd_dma = 1;   // 1 = K / V^T tiles by LDS-DMA ring (shipped), 0 = register-staged tiles (A/B in tools)
 
@@ -2541,7 +2597,9 @@ static void launch_fwd(const AttnParams& p, int64_t B, hipStream_t s) {
     if (trv) {
       if constexpr (D == 64 && !CAUSAL && QF == 2 && !RP && !DROP) {
         if (fits && g_attn_fwd_dma && !p.kmask && !p.seg_lo && g_attn_fwd_plain) {
-          attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true, true>), grid, 256, 0, s, p, CAUSAL ? -1 : 0);
+          // no LSE wanted = nobody will recompute P from the unscaled Q (the frozen encoder's forward): the pre-scaled-Q form
+          if (!p.LSE && g_attn_fwd_qs) attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true, true, true>), grid, 256, 0, s, p, 0);
+          else attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true, true>), grid, 256, 0, s, p, CAUSAL ? -1 : 0);
           return;
         }
       }

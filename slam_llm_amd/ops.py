@@ -243,7 +243,8 @@ def reset_tuning():
     gemm_set_config(400)         # cycle stamps off
     call("slam_gemm_set_group_m", 8)
     call("slam_attn_set_bwd_variant", 0)
-    for knob in (0, 11, 21, 31, 41, 51 if ATTN_HEAVY_FIRST else 50):   # auto fragments, DMA tiles, XCD-aware numbering, mask-free instantiation, transposing reads, heaviest block first
+    # auto fragments, DMA tiles, XCD-aware numbering, mask-free instantiation, transposing reads, heaviest block first, pre-scaled Q in LSE-less launches
+    for knob in (0, 11, 21, 31, 41, 51 if ATTN_HEAVY_FIRST else 50, 61):
         call("slam_attn_set_fwd_qf", knob)
 
 

@@ -22,7 +22,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # its tile loop: harmless, not part of the invariant)
 REGION_RULE = ("gemm_nt_w4_kernel",)   # kernels checked by region instead of by total scratch size
 FILES = {"gemm_bf16.hip": ([], ("gemm_nt_w4_kernel", "gemm_nt_pipe_kernel")),
-         "attention.hip": (["-mllvm", "-amdgpu-mfma-vgpr-form"], ("attn_fwd_kernel", "attn_bwd_dkdv_ring_kernel", "attn_bwd_dq_ring_kernel",
+         "attention.hip": (["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"], ("attn_fwd_kernel", "attn_bwd_dkdv_ring_kernel", "attn_bwd_dq_ring_kernel",
                                                                   "attn_bwd_dkdv_tr_kernel", "attn_bwd_dq_tr_kernel"))}
 
 

@@ -215,7 +215,7 @@ def test_fused_swiglu_forward_step_is_bit_identical(dev, monkeypatch):
 def test_lm_head_over_label_rows_equals_every_row(dev, monkeypatch, case):
     """training steps run lm_head / cross entropy / lm_head dX over the labelled rows only (LM_HEAD_LABEL_ROWS): the loss equals the
     every-row form to fp32 summation order (1e-6), the accuracy exactly, every gradient to bf16 product tiling (the same rows go
-    through the same kernels; cosine >= 0.99999, max |diff| <= 2e-3 max|g|), on padded, ragged left-padded, packed (varlen) batches
+    through the same kernels; cosine >= 0.99999, max |diff| <= 4.5e-3 max|g|), on padded, ragged left-padded, packed (varlen) batches
     and with the head chunked into several row blocks.  Three forms: every row, head over the labelled rows, head AND everything
     behind the last layer's attention over the labelled rows (LAST_LAYER_LABEL_ROWS; "lora_all": adapters on all seven projections,
     so o / gate / up / down of the last layer take their LoRA gradients from the selected rows).  The eval forward (labels + logits
@@ -263,7 +263,12 @@ def test_lm_head_over_label_rows_equals_every_row(dev, monkeypatch, case):
     for l1, a1, g1 in res[1:]:
         assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0)) and a0 == a1, (l0, l1, a0, a1)
         cs = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
-        assert cs >= 0.99999 and float((g0 - g1).abs().max()) <= 2e-3 * float(g0.abs().max()), (cs, float((g0 - g1).abs().max()))
+        rel = float((g0 - g1).abs().max()) / float(g0.abs().max())
+        print(f"label-rows vs every-row [{case}]: 1 - cos {1 - cs:.2e}, max |diff| / max |g| {rel:.2e}")
+        # measured on MI355X (round 5, `pytest -s`): rel 0 (packed, chunked head alone), 1.2e-3 .. 2.1e-3 where the last layer runs behind
+        # its attention over the labelled rows only (other row counts -> other GEMM forms -> another fp32 summation order; ONE bf16 ulp of
+        # the largest gradient element is 3.9e-3 of it).  Bound = 2 x the largest measured value and ~1 ulp; 1 - cos measured <= 2.9e-6.
+        assert cs >= 0.99999 and rel <= 4.5e-3, (cs, rel)
 
 
 @pytest.mark.parametrize("ragged", [False, True])
@@ -1459,8 +1464,9 @@ def test_unfrozen_whisper_ragged_encoder_step_matches_per_clip_oracle(dev, proje
 
 
 def test_ragged_encoder_equals_padded_path_when_nothing_is_ragged(dev):
-    """B = 1: the ragged encoder is bit-identical to the reference-padded path; equal-length batches: equal to rounding, and the
-    model does not even enter it (the deviation only exists where the reference lets real frames attend to pad frames)"""
+    """equal-length batches (and B = 1): the ragged encoder equals the reference-padded path to rounding (bit for bit at B = 1 when both
+    run the same attention form), and the model does not even enter it (the deviation only exists where the reference lets real frames
+    attend to pad frames)"""
     from slam_llm_amd.model import SlamHipModel
     cfg = CASES["step_tiny"]["cfg"]
     W = O.init_weights(cfg, seed=42)
@@ -1472,10 +1478,18 @@ def test_ragged_encoder_equals_padded_path_when_nothing_is_ragged(dev):
         enc_pad = m_pad.encoder.forward_btc(mel)
         enc_rag, T2 = m_rag.encoder.forward_packed(mel, [n // 160] * n_clips)
         assert T2 == [enc_pad.shape[1]] * n_clips
+        # same mathematics; equal to bf16 rounding: the padded path's LSE-less launches run the pre-scaled-Q form of the attention
+        # forward (round 5: one more bf16 rounding of Q, accumulators started at -m), the packed rows the segment form, whose online
+        # softmax also meets the keys at another tile alignment when there are several clips.  (Through round 4 the two were the same
+        # kernel at B = 1 and bit-identical; with slam_attn_set_fwd_qf(60) they still are -- checked below.)
+        assert rel_err(enc_rag.view(enc_pad.shape).float().cpu().numpy(), enc_pad.float().cpu().numpy()) < 1e-2
         if n_clips == 1:
-            assert torch.equal(enc_rag.view(enc_pad.shape), enc_pad)
-        else:   # same mathematics, different key-tile alignment of the online softmax (packed rows): equal to bf16 rounding
-            assert rel_err(enc_rag.view(enc_pad.shape).float().cpu().numpy(), enc_pad.float().cpu().numpy()) < 1e-2
+            from slam_llm_amd.lib import call
+            call("slam_attn_set_fwd_qf", 60)
+            try:
+                assert torch.equal(enc_rag.view(enc_pad.shape), m_pad.encoder.forward_btc(mel))
+            finally:
+                call("slam_attn_set_fwd_qf", 61)
         # the model itself takes the reference-padded path when no clip is shorter than the batch (bit-equal to the reference)
         assert m_rag._ragged_frames(mel, {"audio_len_list": [n] * n_clips}) is None
     assert m_rag._ragged_frames(mel, {"audio_len_list": [n, n - 1600, n]}) == [n // 160, (n - 1600) // 160, n // 160]

@@ -719,6 +719,56 @@ def test_attention_fwd(dev, attn_form, B, T, Hq, Hkv, D, causal, masked):
     assert torch.isfinite(o.float()).all()
 
 
+@pytest.mark.parametrize("B,T,H,grow", [
+    (2, 150, 2, 0.0),      # T not a multiple of the tile: the keys past T of the last tile start their accumulators at -inf
+    (1, 1500, 2, 0.0),     # Whisper context length (23 whole tiles + 28 keys)
+    (3, 40, 2, 0.0),       # one tile that is both the first (ordinary path, zero start) and the partial last one
+    (2, 64, 1, 0.0),       # exactly one whole tile
+    (2, 128, 2, 0.0),      # whole tiles only
+    (2, 700, 2, 13.0),     # spike keys whose scores exceed the running maximum by ~2^7, then ~2^14, ...: the attempt "P = exp2(S')"
+    (1, 1500, 1, 13.0),    #   fails there and the scores are computed again (the fallback s_product); the maximum moves at every second spike
+])
+def test_attention_fwd_prescaled_q_form(dev, B, T, H, grow):
+    """round 5: LSE-less launches of the mask-free bidirectional D = 64 form (the frozen Whisper encoder) run attn_fwd_kernel<..., QS>:
+    Q pre-multiplied by scale * log2(e) (one more bf16 rounding), accumulators of the first product started at -m (at -inf for the
+    keys past T), P = exp2 of the product.  vs the fp32 reference at the tolerance of the other forward tests, and vs the form it
+    replaces (knob 60: scores scaled inside the softmax) at the size of the extra rounding."""
+    ops = _ops()
+    from slam_llm_amd.lib import call
+    D = 64
+    qkv = rnd((B * T, 3 * H * D), dev, seed=31, std=1.0)
+    if grow:
+        # every query has a component 3 along a fixed unit direction; spike key i (t = 70 + 130 i) has a component grow * (i + 1) along
+        # it: its score stands out by 3 * grow * (i + 1) / 8 * log2(e) = ~7 (i + 1) in the exponent's log2 units
+        dirn = torch.nn.functional.normalize(torch.randn(D, generator=torch.Generator().manual_seed(5)), dim=0).to(dev)
+        k3 = qkv[:, H * D: 2 * H * D].float().view(B, T, H, D).clone()
+        for i, t in enumerate(range(70, T, 130)):
+            k3[:, t] += grow * (i + 1) * dirn
+        q3 = qkv[:, : H * D].float().view(B, T, H, D) + 3.0 * dirn
+        qkv[:, H * D: 2 * H * D] = k3.reshape(B * T, H * D).to(torch.bfloat16)
+        qkv[:, : H * D] = q3.reshape(B * T, H * D).to(torch.bfloat16)
+    q2, k2, v2 = qkv[:, : H * D], qkv[:, H * D: 2 * H * D], qkv[:, 2 * H * D:]
+    scale = D ** -0.5
+    o_qs, lse = ops.attn_fwd(q2, k2, v2, B, T, H, H, D, False, scale, want_lse=False)
+    assert lse is None
+    call("slam_attn_set_fwd_qf", 60)
+    try:
+        o_old, _ = ops.attn_fwd(q2, k2, v2, B, T, H, H, D, False, scale, want_lse=False)
+    finally:
+        call("slam_attn_set_fwd_qf", 61)
+    ref = _attn_ref(q2.float().view(B, T, H, D), k2.float().view(B, T, H, D), v2.float().view(B, T, H, D), False, None, scale)
+    assert torch.isfinite(o_qs.float()).all()
+    assert_close(o_old.view(B, T, H, D), ref, atol=2e-2, rtol=2e-2, what="attn fwd (scores scaled in the softmax)")
+    # sharply peaked rows (spikes) amplify the extra 2^-9 rounding of Q by the score magnitude (up to ~80 log2 units here)
+    tol = 2e-2 if not grow else 6e-2
+    assert_close(o_qs.view(B, T, H, D), ref, atol=tol, rtol=tol, what="attn fwd (pre-scaled Q)")
+    assert_close(o_qs.view(B, T, H, D), o_old.view(B, T, H, D).float(), atol=tol, rtol=tol, what="pre-scaled Q vs scaled scores")
+    # and it is a deterministic function of its inputs (poisoned output buffer, second launch)
+    o2 = torch.full_like(o_qs, float("nan"))
+    ops.attn_fwd(q2, k2, v2, B, T, H, H, D, False, scale, want_lse=False, out=o2)
+    assert torch.equal(o2, o_qs)
+
+
 @pytest.mark.parametrize("B,T,Hq,Hkv,D,masked", [
     (2, 100, 4, 2, 64, True),
     (2, 380, 4, 1, 128, True),
