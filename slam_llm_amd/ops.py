@@ -220,6 +220,12 @@ def gemm_set_config(cfg: int):
 
 
 ATTN_HEAVY_FIRST = os.environ.get("SLAM_ATTN_HEAVY", "1") != "0"     # A/B: SLAM_ATTN_HEAVY=0 python bench.py (id order of causal attention workgroups)
+ATTN_QS = os.environ.get("SLAM_ATTN_QS", "1") != "0"                 # A/B: SLAM_ATTN_QS=0 (scores scaled inside the softmax in LSE-less mask-free launches)
+ATTN_DKDV32 = os.environ.get("SLAM_ATTN_DKDV32", "0") != "0"         # A/B: SLAM_ATTN_DKDV32=1 (4 waves x 32 keys in the D = 128 dK / dV kernel: bit-identical, slower)
+if not ATTN_QS:
+    call("slam_attn_set_fwd_qf", 60)
+if ATTN_DKDV32:
+    call("slam_attn_set_fwd_qf", 71)
 if not ATTN_HEAVY_FIRST:
     call("slam_attn_set_fwd_qf", 50)
 _ENV_DEFAULTS = dict(_GEMM_BIG, sk2=SK2_AUTO, ts=TS_AUTO, splitk=os.environ.get("SLAM_GEMM_SPLITK", "off"))
@@ -244,7 +250,7 @@ def reset_tuning():
     call("slam_gemm_set_group_m", 8)
     call("slam_attn_set_bwd_variant", 0)
     # auto fragments, DMA tiles, XCD-aware numbering, mask-free instantiation, transposing reads, heaviest block first, pre-scaled Q in LSE-less launches
-    for knob in (0, 11, 21, 31, 41, 51 if ATTN_HEAVY_FIRST else 50, 61):
+    for knob in (0, 11, 21, 31, 41, 51 if ATTN_HEAVY_FIRST else 50, 61 if ATTN_QS else 60, 71 if ATTN_DKDV32 else 70):   # ..., 32 keys per wave in the D = 128 dK / dV kernel
         call("slam_attn_set_fwd_qf", knob)
 
 

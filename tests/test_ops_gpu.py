@@ -813,6 +813,58 @@ def test_attention_bwd(dev, attn_form, B, T, Hq, Hkv, D, masked):
     assert torch.equal(fused[:, (Hq + Hkv) * D:], dqkv[:, (Hq + Hkv) * D:])  # dV untouched by RoPE
 
 
+@pytest.mark.parametrize("B,T,Hq,Hkv,causal,packed", [
+    (3, 380, 8, 2, True, False),     # the C3 shape (GQA 4:1, T = 2 whole key blocks + 124 keys), left padding
+    (2, 380, 4, 4, True, False),     # MHA (Vicuna)
+    (2, 97, 2, 1, True, False),      # one partial key block: waves 3 has no key at all
+    (1, 257, 2, 2, True, False),     # a key block with a single key
+    (2, 200, 2, 1, False, False),    # bidirectional with a key mask
+    (1, 0, 4, 2, True, True),        # packed sequences (seg_lo / seg_hi, explicit rotary positions)
+])
+def test_attention_bwd_dkdv32_is_bit_identical(dev, B, T, Hq, Hkv, causal, packed):
+    """round 5: the D = 128 dK / dV kernel with 32 keys per wave (4 waves, accumulators in AGPRs, every Q / dO fragment read from the LDS
+    feeds two MFMAs; csrc/attention_dkdv32.hip; selectable with knob 71, NOT the default: measured 11 % slower) runs the same MFMAs on
+    the same operands in the same order as the shipped 16-keys-per-wave kernel (knob 70): dK, dV (and the dQ written by the same call)
+    are bit-identical, with left padding, fused RoPE, GQA, partial key blocks and packed sequences."""
+    ops = _ops()
+    from slam_llm_amd.lib import call
+    from slam_llm_amd.host_tables import rope_tables
+    D = 128
+    seg = pos = None
+    if packed:
+        lens = (70, 133, 37, 260)
+        T, B = sum(lens), 1
+        lo = torch.cat([torch.full((n,), s0, dtype=torch.int32) for n, s0 in zip(lens, [0, 70, 203, 240])]).to(dev)
+        hi = torch.cat([torch.full((n,), s0 + n, dtype=torch.int32) for n, s0 in zip(lens, [0, 70, 203, 240])]).to(dev)
+        seg = (lo, hi)
+        pos = torch.cat([torch.arange(n, dtype=torch.int32) for n in lens]).to(dev)
+    qkv, q2, k2, v2, Tp, vt = _prep_attn(ops, dev, B, T, Hq, Hkv, D, seed=41)
+    km = None
+    if not packed:
+        km = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
+        km[:, :T] = 1
+        km[0, :6] = 0
+    scale = D ** -0.5
+    cos, sin = (t.to(dev) for t in rope_tables(max(T, 300), D, 500000.0))
+    rope = (cos, sin, pos) if packed else (cos, sin)
+    o, lse = ops.attn_fwd(q2, k2, vt, B, T, Hq, Hkv, D, causal, scale, key_mask=km, seg=seg)
+    do = rnd((B * T, Hq * D), dev, seed=42)
+    outs = {}
+    try:
+        for knob in (71, 70, 71):
+            call("slam_attn_set_fwd_qf", knob)
+            g = torch.full_like(qkv, float("nan"))     # every element of dQ | dK | dV is written by the launch
+            ops.attn_bwd(q2, k2, v2, o, do, lse, g[:, : Hq * D], g[:, Hq * D:(Hq + Hkv) * D], g[:, (Hq + Hkv) * D:],
+                         B, T, Hq, Hkv, D, causal, scale, key_mask=km, rope=rope, seg=seg)
+            if knob in outs:
+                assert torch.equal(outs[knob].view(torch.int16), g.view(torch.int16)), "second launch of the same form differs"
+            outs[knob] = g
+    finally:
+        call("slam_attn_set_fwd_qf", 70)
+    assert torch.isfinite(outs[71].float()).all()
+    assert torch.equal(outs[71].view(torch.int16), outs[70].view(torch.int16))
+
+
 @pytest.mark.parametrize("B,T,Hq,Hkv,D", [(2, 380, 8, 2, 128), (1, 200, 4, 1, 64), (2, 130, 4, 4, 64), (1, 97, 2, 1, 128)])
 def test_attention_bwd_dq_forms_agree(dev, attn_form, B, T, Hq, Hkv, D):
     """the dQ launch forms (DMA ring, register-staged tiles with 32 / 16 queries per wave) are the same arithmetic in the
