@@ -166,6 +166,11 @@ int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
                   int64_t Tqp, int64_t Tkp, int64_t Hq, int64_t Hkv, int64_t D, int causal, float scale,
                   const int32_t* seg_lo, const int32_t* seg_hi, const float* rp_gate, const float* rp_tab, int64_t rp_T,
                   int64_t rp_ld, float drop_p, uint64_t drop_seed, void* stream);
+/* scale < 0 (forward only, round 5): Q arrives multiplied by |scale| * log2(e) -- the caller folded the softmax scale and the base change
+ * of the exponent into a FROZEN query projection (W_q, b_q scaled in fp32 when the checkpoint is loaded: Q is still rounded to bf16 once,
+ * Whisper blocks of models/encoder.py:26-27); the kernels then take the scores of the first product as they are, and LSE-less launches of
+ * the mask-free bidirectional D = 64 form start their score accumulators at -max (no multiply-add per score in the softmax).  LSE, when
+ * requested, keeps its meaning (natural-log units of the scaled scores).  Not with rp_gate or drop_p. */
 /* drop_p > 0 (forward and backward, D = 64 bidirectional): dropout on the attention PROBABILITIES (HF Blip2QFormer
  * attention_probs_dropout_prob inside EncoderProjectorQFormer, models/projector.py:51-67, train mode): P keeps its full-row
  * normalisation, element (b, h, q, k) is kept with slam_dropout_bf16's counter-based mask at index ((b*Hq + h)*Tqp + q)*Tkp + k

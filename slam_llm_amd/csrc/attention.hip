@@ -36,9 +36,10 @@ __device__ unsigned long long g_attn_probe[2 * 16 * 8];   // tools: cycle stamps
 // QF = 16-row query fragments per wave (2: 128-query workgroups; 1: 64-query workgroups, fewer VGPRs -> more waves per SIMD)
 // TRV (round 4, shipped): the V tile is staged ROW-MAJOR ([64 keys][D], straight from the fused QKV buffer: no [B,H,D,Tp] copy of V) and
 // the V^T operand of O^T += V^T P^T is read with ds_read_b64_tr_b16 (two 8-byte reads per fragment instead of one 16-byte read)
-// QS (round 5; inference-only launches of the PLAIN form: the frozen Whisper encoder, no LSE wanted): the Q fragments are multiplied by
-// scale * log2(e) once, when they are loaded (one more bf16 rounding of Q), and interior tiles start the S^T accumulators at -m (the
-// running maximum): the first product then delivers s * scale * log2(e) - m and P = exp2 of it -- no v_fma per score in the softmax.
+// QS (round 5; LSE-less launches of the PLAIN form with p.qpre: the frozen Whisper encoder, whose query projection carries
+// scale * log2(e) -- folded into W_q, b_q in fp32 when the checkpoint is loaded, so Q is rounded to bf16 once, like the unscaled Q of the
+// reference path): every tile behind the first starts the S^T accumulators at -m (the running maximum): the first product then delivers
+// s * scale * log2(e) - m and P = exp2 of it -- no v_fma per score in the softmax.
 template <int D, bool CAUSAL, int QF, bool RP = false, bool DROP = false, bool PROBE = false, bool DMA = false, bool PLAIN = false, bool TRV = false, bool QS = false>
 __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnParams p) {
   static_assert(!QS || (PLAIN && !CAUSAL && !RP && !DROP), "QS is a variant of the mask-free bidirectional form");
@@ -74,8 +75,8 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
   constexpr int QW = 16 * QF;   // query rows per wave
   const int qb0 = blk.x * (4 * QW), qw0 = qb0 + wave * QW;
 
-  const float sl2 = p.scale * LOG2E;
-  const float ksc = QS ? 1.0f : sl2;   // what turns a score of the first product into log2 units
+  const float sl2 = p.qpre ? 1.0f : p.scale * LOG2E;   // what turns a score of the first product into the exponent's log2 units
+  const float ksc = QS ? 1.0f : sl2;
   frag_t qf[QF][KD];
 #pragma unroll
   for (int f = 0; f < QF; f++) {
@@ -84,10 +85,6 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
     for (int kd = 0; kd < KD; kd++) {
       qf[f][kd] = (q < Tq) ? *reinterpret_cast<const frag_t*>(p.Q + ((int64_t)b * Tq + q) * p.ldq + h * D + kd * 32 + g * 8)
                           : zero_frag();
-      if constexpr (QS) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) qf[f][kd][e] = f2bf(bf2f(qf[f][kd][e]) * sl2);
-      }
     }
   }
   f32x4_t o[QF][DF];
@@ -2295,7 +2292,7 @@ extern "C" int slam_attn_set_fwd_qf(int qf) {   // tools: 0 = auto, 1 / 2 fragme
   SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11 || qf == 20 || qf == 21 || qf == 30 || qf == 31 || qf == 40 || qf == 41 || qf == 50 || qf == 51 || qf == 60 || qf == 61 || qf == 70 || qf == 71,
                  "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2; 10 / 11 = staged / DMA tiles; 20 / 21 = hardware / XCD-aware workgroup order; "
                  "30 / 31 = general / mask-free instantiation for unmasked bidirectional D = 64; 40 / 41 = transposed-copy / transposed-read kernels; "
-                 "50 / 51 = id order / heaviest sequence block first in causal launches; 60 / 61 = scores scaled in the softmax / Q pre-scaled "
+                 "50 / 51 = id order / heaviest sequence block first in causal launches; 60 / 61 = general softmax / Q pre-scaled by the caller "
                  "and accumulators started at -m in LSE-less mask-free launches; 70 / 71 = 8 waves x 16 keys / 4 waves x 32 keys in the D = 128 dK / dV kernel)", qf);
   if (qf >= 70) g_attn_dkdv32 = qf - 70;
   else if (qf >= 60) g_attn_fwd_qs = qf - 60;
@@ -2308,7 +2305,7 @@ extern "C" int slam_attn_set_fwd_qf(int qf) {   // tools: 0 = auto, 1 / 2 fragme
   return 0;
 }
 
-int g_attn_fwd_qs = 1;    // 1 = LSE-less launches of the mask-free form run with Q pre-scaled by scale * log2(e) (attn_fwd_kernel<..., QS>)
+int g_attn_fwd_qs = 1;    // 1 = LSE-less launches of the mask-free form whose Q arrives pre-scaled (negative scale) run attn_fwd_kernel<..., QS>
 int g_attn_fwd_plain = 1; // 1 = unmasked bidirectional D = 64 launches (Whisper) take the instantiation without mask / segment bookkeeping
 int g_attn_fwd_dma = 1;   // 1 = K / V^T tiles by LDS-DMA ring (shipped), 0 = register-staged tiles (A/B in tools)
 
@@ -2325,8 +2322,8 @@ static void launch_fwd(const AttnParams& p, int64_t B, hipStream_t s) {
     if (trv) {
       if constexpr (D == 64 && !CAUSAL && QF == 2 && !RP && !DROP) {
         if (fits && g_attn_fwd_dma && !p.kmask && !p.seg_lo && g_attn_fwd_plain) {
-          // no LSE wanted = nobody will recompute P from the unscaled Q (the frozen encoder's forward): the pre-scaled-Q form
-          if (!p.LSE && g_attn_fwd_qs) attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true, true, true>), grid, 256, 0, s, p, 0);
+          // Q pre-scaled by the caller and no LSE wanted (the frozen encoder's forward): accumulators start at -m
+          if (!p.LSE && p.qpre && g_attn_fwd_qs) attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true, true, true>), grid, 256, 0, s, p, 0);
           else attn_launch((attn_fwd_kernel<D, CAUSAL, QF, RP, DROP, PROBE, true, true, true>), grid, 256, 0, s, p, CAUSAL ? -1 : 0);
           return;
         }
@@ -2396,7 +2393,11 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.Q = (const bf16_t*)Q; p.ldq = ldq; p.K = (const bf16_t*)K; p.ldk = ldk; p.Vt = (const bf16_t*)Vt;
   p.V = (const bf16_t*)V; p.ldv = ldv;
   p.O = (bf16_t*)O; p.ldo = ldo; p.LSE = LSE; p.kmask = key_mask;
-  p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv; p.scale = scale;
+  p.Tq = (int)Tq; p.Tk = (int)Tk; p.Tqp = (int)Tqp; p.Tkp = (int)Tkp; p.Hq = (int)Hq; p.Hkv = (int)Hkv;
+  // scale < 0: Q was produced multiplied by |scale| * log2(e) (a frozen query projection with the factor folded into its weights)
+  p.qpre = scale < 0.f ? 1 : 0;
+  p.scale = scale < 0.f ? -scale : scale;
+  SLAM_CHECK_ARG(!p.qpre || (!rp_gate && drop_p == 0.f), "slam_attn_fwd: a pre-scaled Q (negative scale) is for the plain forward (no relative position bias, no dropout)");
   p.seg_lo = seg_lo;
   p.seg_hi = causal ? nullptr : seg_hi;   // (the causal forward only needs the sequence starts)
   p.rp_gate = rp_gate; p.rp_tab = rp_tab; p.rp_T = (int)rp_T; p.rp_ld = (int)rp_ld;

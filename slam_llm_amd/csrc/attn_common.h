@@ -28,6 +28,8 @@ struct AttnParams {
   const uint8_t* kmask;             // [B, Tp] 1 = attend (zero padded) or null
   int Tq, Tk, Tqp, Tkp, Hq, Hkv;  // query / key lengths and their 64-padded strides (Tq == Tk for self-attention)
   float scale;                      // softmax scale (1/sqrt(D))
+  int qpre;                         // forward only: 1 = Q arrives multiplied by scale * log2(e) (slam_attn_fwd with a negative scale: the caller folded
+                                    // the factor into a frozen query projection): the scores of the first product already are in the exponent's log2 units
   const float* rope_cos;            // backward only, nullable: [T, D/2] RoPE tables; when set dQ and dK are rotated back
   const float* rope_sin;            //   (d/dx of the forward rotation, position = row index) before they are stored
   const int* rope_pos;              // nullable [B*T]: explicit rotary position per row (packed / varlen batches)

@@ -323,6 +323,8 @@ class HipWhisperEncoder(nn.Module):
     sinusoidal `positional_embedding` is a buffer there and stays fixed), forward_train() keeps what the hand-written
     backward_hip() needs, and the bf16 compute copies (`self.w`) are rebuilt from the store by refresh() after each step."""
 
+    QFOLD = ops.qscale(64 ** -0.5)   # what the FROZEN encoder's query projection is multiplied by at load time (head_dim 64)
+
     def __init__(self, cfg: dict, device, store: Optional["TrainableStore"] = None, prefix="encoder."):
         super().__init__()
         self.cfg = cfg
@@ -381,8 +383,11 @@ class HipWhisperEncoder(nn.Module):
         w["pos"] = bf(W[prefix + "positional_embedding"])
         for i in range(cfg["enc_layers"]):
             p = f"{prefix}blocks.{i}."
-            w[f"{i}.qkv"] = bf(torch.cat([W[p + "attn.query.weight"], W[p + "attn.key.weight"], W[p + "attn.value.weight"]], 0))
-            w[f"{i}.qkv_b"] = f32(torch.cat([W[p + "attn.query.bias"], torch.zeros(d), W[p + "attn.value.bias"]], 0))
+            # the frozen query projection carries the softmax scale and the exponent's base change (QFOLD = d_head^-1/2 * log2 e, folded in
+            # fp32 BEFORE the one rounding to bf16): attn_fwd(..., q_prescaled=True) then takes the scores as they come out of the product
+            # (an un-frozen encoder keeps the reference's own weights: its eval forward passes q_prescaled=False)
+            w[f"{i}.qkv"] = bf(torch.cat([W[p + "attn.query.weight"].float() * self.QFOLD, W[p + "attn.key.weight"], W[p + "attn.value.weight"]], 0))
+            w[f"{i}.qkv_b"] = f32(torch.cat([W[p + "attn.query.bias"].float() * self.QFOLD, torch.zeros(d), W[p + "attn.value.bias"]], 0))
             w[f"{i}.out"], w[f"{i}.out_b"] = bf(W[p + "attn.out.weight"]), f32(W[p + "attn.out.bias"])
             w[f"{i}.ln1_w"], w[f"{i}.ln1_b"] = f32(W[p + "attn_ln.weight"]), f32(W[p + "attn_ln.bias"])
             w[f"{i}.fc1"], w[f"{i}.fc1_b"] = bf(W[p + "mlp.0.weight"]), f32(W[p + "mlp.0.bias"])
@@ -421,8 +426,12 @@ class HipWhisperEncoder(nn.Module):
         from .host_tables import sinusoids
         w["pos"] = sinusoids(cfg["enc_ctx"], d).to(device=dev, dtype=torch.bfloat16)
         for i in range(cfg["enc_layers"]):
-            w[f"{i}.qkv"] = rn(3 * d, d, std=d ** -0.5).to(torch.bfloat16)
+            wq = rn(3 * d, d, std=d ** -0.5)
+            wq[:d] *= self.QFOLD            # (see load(): the frozen query projection carries scale * log2 e)
+            w[f"{i}.qkv"] = wq.to(torch.bfloat16)
+            del wq
             qb = rn(3 * d)
+            qb[:d] *= self.QFOLD
             qb[d: 2 * d] = 0
             w[f"{i}.qkv_b"] = qb
             w[f"{i}.out"], w[f"{i}.out_b"] = rn(d, d, std=d ** -0.5).to(torch.bfloat16), rn(d)
@@ -461,7 +470,7 @@ class HipWhisperEncoder(nn.Module):
         for i in range(cfg["enc_layers"]):
             ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], out=hbuf)
             ops.gemm_nt(hbuf, w[f"{i}.qkv"], out=qkv, bias=w[f"{i}.qkv_b"])
-            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T2, H, H, 64, False, scale, want_lse=False, out=obuf)
+            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], B, T2, H, H, 64, False, scale, want_lse=False, out=obuf, q_prescaled=not self.trainable)
             ops.gemm_nt(obuf, w[f"{i}.out"], out=x, bias=w[f"{i}.out_b"], residual=x)
             ops.layernorm(x, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], out=hbuf)
             ops.gemm_nt(hbuf, w[f"{i}.fc1"], out=fbuf, bias=w[f"{i}.fc1_b"], act=ACT_GELU)
@@ -732,7 +741,7 @@ class HipWhisperEncoder(nn.Module):
         for i in range(cfg["enc_layers"]):
             ops.layernorm(x, w[f"{i}.ln1_w"], w[f"{i}.ln1_b"], out=hbuf)
             ops.gemm_nt(hbuf, w[f"{i}.qkv"], out=qkv, bias=w[f"{i}.qkv_b"])
-            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], 1, M, H, H, 64, False, scale, want_lse=False, out=obuf, seg=seg)
+            ops.attn_fwd(qkv[:, :d], qkv[:, d: 2 * d], qkv[:, 2 * d:], 1, M, H, H, 64, False, scale, want_lse=False, out=obuf, seg=seg, q_prescaled=not self.trainable)
             ops.gemm_nt(obuf, w[f"{i}.out"], out=x, bias=w[f"{i}.out_b"], residual=x)
             ops.layernorm(x, w[f"{i}.ln2_w"], w[f"{i}.ln2_b"], out=hbuf)
             ops.gemm_nt(hbuf, w[f"{i}.fc1"], out=fbuf, bias=w[f"{i}.fc1_b"], act=ACT_GELU)

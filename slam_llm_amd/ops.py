@@ -220,7 +220,7 @@ def gemm_set_config(cfg: int):
 
 
 ATTN_HEAVY_FIRST = os.environ.get("SLAM_ATTN_HEAVY", "1") != "0"     # A/B: SLAM_ATTN_HEAVY=0 python bench.py (id order of causal attention workgroups)
-ATTN_QS = os.environ.get("SLAM_ATTN_QS", "1") != "0"                 # A/B: SLAM_ATTN_QS=0 (scores scaled inside the softmax in LSE-less mask-free launches)
+ATTN_QS = os.environ.get("SLAM_ATTN_QS", "1") != "0"                 # A/B: SLAM_ATTN_QS=0 (general softmax also for the LSE-less mask-free launches with a pre-scaled Q)
 ATTN_DKDV32 = os.environ.get("SLAM_ATTN_DKDV32", "0") != "0"         # A/B: SLAM_ATTN_DKDV32=1 (4 waves x 32 keys in the D = 128 dK / dV kernel: bit-identical, slower)
 if not ATTN_QS:
     call("slam_attn_set_fwd_qf", 60)
@@ -522,14 +522,16 @@ def attn_needs_transposed(q2d, k2d, v2d, do2d, B, T, Tk, Hq, Hkv, D, drop=None, 
 
 
 def attn_fwd(q2d, k2d, v, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_lse=True, out=None, Tk=None, seg=None,
-             relpos=None, drop=None):
+             relpos=None, drop=None, q_prescaled=False):
     """self-attention: q/k/v rows (b*T + t), head h at column h*D.  Cross-attention: pass Tk (key / value rows b*Tk + t).
     v: the ROW-MAJOR values [B*Tk, ld] (a column slice of the fused QKV buffer) -- the kernel reads V^T with transposing LDS reads -- or,
     for the round-3 kernels (tools, A/B), the [B,Hkv,D,Tkp] transposed copy written by head_rope_transpose (a 4-D tensor).
     seg = (lo, hi) int32 [B*T]: packed sequences (B = 1), query q sees keys lo[q] <= k <= q (causal) or
     lo[q] <= k < hi[q] (bidirectional: the ragged encoder, one clip per segment).
     relpos = (gate [B,Hq,Tqp] f32, table from relpos_table(), rp_T): WavLM's gated relative position bias.
-    drop = (p, seed): dropout on the attention probabilities (counter-based mask; attn_bwd with the same pair recomputes it)."""
+    drop = (p, seed): dropout on the attention probabilities (counter-based mask; attn_bwd with the same pair recomputes it).
+    q_prescaled: q2d was produced multiplied by scale * log2(e) (QSCALE(scale): a frozen query projection with the factor folded into
+    its weights -- the frozen Whisper encoder); handed to the C ABI as a negative scale."""
     Tk = Tk or T
     vt, v2d = (v, None) if v.dim() == 4 else (None, v)
     Tkp, Tqp = (vt.shape[-1] if vt is not None else round_up(Tk, 64)), round_up(T, 64)
@@ -540,12 +542,17 @@ def attn_fwd(q2d, k2d, v, B, T, Hq, Hkv, D, causal, scale, key_mask=None, want_l
     _timed("attn_fwd", 4.0 * B * Hq * T * Tk * D * (0.5 if causal else 1.0),
            lambda: call("slam_attn_fwd", _p(q2d), _ld(q2d), _p(k2d), _ld(k2d), _p(vt), _p(v2d), _ld(v2d) if v2d is not None else 0,
                         _p(out), _ld(out), _p(lse),
-                        _p(key_mask), B, T, Tk, Tqp, Tkp, Hq, Hkv, D, 1 if causal else 0, scale, _p(seg[0]) if seg else None,
+                        _p(key_mask), B, T, Tk, Tqp, Tkp, Hq, Hkv, D, 1 if causal else 0, (-scale if q_prescaled else scale), _p(seg[0]) if seg else None,
                         _p(seg[1]) if seg else None, _p(relpos[0]) if relpos else None,
                         (relpos[1].data_ptr() + 64 * 4) if relpos else None, relpos[2] if relpos else 0,
                         relpos[1].shape[1] if relpos else 0, float(drop[0]) if drop else 0.0,
                         (int(drop[1]) & (2 ** 64 - 1)) if drop else 0, _s()))
     return out, lse
+
+
+def qscale(scale: float) -> float:
+    """the factor a frozen query projection carries for attn_fwd(..., q_prescaled=True): softmax scale x log2(e)"""
+    return float(scale) * 1.4426950408889634
 
 
 def relpos_table(values_hr: torch.Tensor) -> torch.Tensor:

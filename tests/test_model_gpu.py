@@ -158,7 +158,9 @@ def test_unfrozen_encoder_training_matches_reference_fixture(dev):
     out2, _ = model(**{k: v.clone() for k, v in b.items()})
     out2.loss.backward()
     assert torch.allclose(model.store.grad, 2 * g1, rtol=2e-2, atol=2e-6)
-    # eval-mode forward of the trainable encoder == the frozen encoder built from the same weights
+    # eval-mode forward of the trainable encoder == the frozen encoder built from the same weights, to the rounding of ONE operand: the
+    # frozen encoder's query projection carries d_head^-1/2 * log2(e) (folded in fp32 at load time, round 5), so its W_q / Q are the
+    # bf16 roundings of scaled values (measured 3.7e-4 on this fixture; through round 4 the two were the same kernels: < 1e-5)
     model.eval()
     frozen = SlamHipModel(dict(cfg, lora_dropout=0.0), dev).load_weights({k: v.detach().clone() for k, v in
                                                                           dict(W, **{n: p.detach().cpu() for n, p in model.store.params.items()}).items()})
@@ -166,7 +168,7 @@ def test_unfrozen_encoder_training_matches_reference_fixture(dev):
     with torch.no_grad():
         l1, _ = model(**{k: v.clone() for k, v in b.items()})
         l2, _ = frozen(**{k: v.clone() for k, v in b.items()})
-    assert abs(float(l1.loss) - float(l2.loss)) < 1e-5
+    assert abs(float(l1.loss) - float(l2.loss)) < 2e-3
 
 
 def test_unfrozen_encoder_rejects_unimplemented_combinations(dev):
