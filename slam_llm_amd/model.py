@@ -354,6 +354,16 @@ class HipWhisperEncoder(nn.Module):
     def trainable(self) -> bool:
         return self.store is not None
 
+    @torch.no_grad()
+    def refold_query_bias(self):
+        """frozen encoder: rebuild the scaled query bias from the unscaled one (after `model.to(torch.bfloat16)` rounded the frozen fp32
+        tensors: the reference's cast rounds the bias ITSELF, the scale is then applied to the rounded value in fp32)"""
+        if self.trainable:
+            return
+        d = self.cfg["enc_dim"]
+        for i in range(self.cfg["enc_layers"]):
+            self.w[f"{i}.qkv_b"][:d] = self.w[f"{i}.q_b_raw"] * self.QFOLD
+
     def bind(self):
         for name, prm in self.store.params.items():
             if name.startswith(self.prefix):
@@ -388,6 +398,7 @@ class HipWhisperEncoder(nn.Module):
             # (an un-frozen encoder keeps the reference's own weights: its eval forward passes q_prescaled=False)
             w[f"{i}.qkv"] = bf(torch.cat([W[p + "attn.query.weight"].float() * self.QFOLD, W[p + "attn.key.weight"], W[p + "attn.value.weight"]], 0))
             w[f"{i}.qkv_b"] = f32(torch.cat([W[p + "attn.query.bias"].float() * self.QFOLD, torch.zeros(d), W[p + "attn.value.bias"]], 0))
+            w[f"{i}.q_b_raw"] = f32(W[p + "attn.query.bias"])     # (the unscaled bias: refold_query_bias)
             w[f"{i}.out"], w[f"{i}.out_b"] = bf(W[p + "attn.out.weight"]), f32(W[p + "attn.out.bias"])
             w[f"{i}.ln1_w"], w[f"{i}.ln1_b"] = f32(W[p + "attn_ln.weight"]), f32(W[p + "attn_ln.bias"])
             w[f"{i}.fc1"], w[f"{i}.fc1_b"] = bf(W[p + "mlp.0.weight"]), f32(W[p + "mlp.0.bias"])
@@ -431,6 +442,7 @@ class HipWhisperEncoder(nn.Module):
             w[f"{i}.qkv"] = wq.to(torch.bfloat16)
             del wq
             qb = rn(3 * d)
+            w[f"{i}.q_b_raw"] = qb[:d].clone()
             qb[:d] *= self.QFOLD
             qb[d: 2 * d] = 0
             w[f"{i}.qkv_b"] = qb
@@ -2655,6 +2667,8 @@ class SlamHipModel(nn.Module):
                 t.copy_(t.to(torch.bfloat16))
         for t in getattr(self.encoder, "w", {}).values():
             rnd(t)
+        if hasattr(self.encoder, "refold_query_bias"):
+            self.encoder.refold_query_bias()
         for L in self.llm.layers:
             rnd(L.ln1); rnd(L.ln2)
         rnd(self.llm.norm_w)

@@ -219,9 +219,10 @@ def test_pure_bf16_route_model_to_bfloat16(dev):
     from slam_llm_amd.model import SlamAdamW, SlamAnyPrecisionAdamW, SlamHipModel
     cfg = dict(O.make_config(), lora_dropout=0.0)
     W = O.init_weights(cfg, seed=42)
-    # (the frozen encoder's query projection is NOT pre-rounded: it is rounded to bf16 once, AFTER the softmax scale is folded into it at
-    # load time -- HipWhisperEncoder.load, round 5 -- so both models below must be handed the same fp32 values for it)
-    Wr = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() and ".attn.query." not in k else v) for k, v in W.items()}
+    # (the frozen encoder's query WEIGHT is not pre-rounded: it is rounded to bf16 once, AFTER the softmax scale is folded into it at load
+    # time -- HipWhisperEncoder.load, round 5 -- so both models below must be handed the same fp32 values for it; the query bias stays
+    # fp32 in the kernels: `.to(torch.bfloat16)` rounds the bias itself and the scale multiplies the rounded value, like here)
+    Wr = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() and not k.endswith(".attn.query.weight") else v) for k, v in W.items()}
     batches = _batches(cfg, dev)
     ref = SlamHipModel(dict(cfg), dev).load_weights(Wr)          # fp32 masters holding bf16-representable values
     ref.train()
