@@ -86,8 +86,11 @@ def test_c3_full_depth_step_matches_oracle(dev):
 # keys that share a large common component at depth under random-init weights (token representations of a deep random transformer
 # collapse towards each other), so the bf16 rounding of the dS operand (and of Delta = sum dO O) is amplified by |mean key| / |key spread|.
 # A property of bf16 attention backward in this regime (torch SDPA in bf16 has it too), not of depth bookkeeping: dV = P^T dO has no such
-# structure and stays at 0.9998.  Floors = 2x the worst measured deviation: 1 - cos 0.0056 -> 0.988, norm 0.033 -> 0.07.
-FULL_DEPTH_COS, FULL_DEPTH_NORM = 0.988, 7e-2
+# structure and stays at 0.9998.  The worst q_proj adapter is a noisy quantity: three builds of round 5 whose attention arithmetic differs
+# only in roundings (score scale applied in the softmax / folded into Q in the kernel / folded into the frozen query projection) measured
+# 1 - cos 0.0056, 0.0054 and 0.0067 (layer 30 lora_A each time), norm deviations 0.033 .. 0.037.  Floors = 2x the worst measured:
+# 1 - cos 0.0067 -> 0.985 (rounded down), norm 0.037 -> 0.08.
+FULL_DEPTH_COS, FULL_DEPTH_NORM = 0.985, 8e-2
 
 
 def _headline_case(dev, encoder, B, enc_layers, llm_layers):
