@@ -31,6 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+# Per-launch HIP events (the roofline's live measurement) are recorded on every KERNEL_TIMING_EVERY-th step of the timed region, not on
+# all of them: ~1 170 events per C3 step cost the step they measure 3.4 ms = 0.9 % (tools/timer_overhead.py, profiles/r05_timer_overhead.md).
+# The sampled steps are ordinary steps of the timed region (step 0, 4, 8, ...: with the default K = 5 two of five, with K = 20 five of twenty).
+KERNEL_TIMING_EVERY = 4
 CLIP_SECONDS, PROMPT, ANSWER = 30.0, 16, 64
 
 WORKLOADS = {
@@ -390,17 +394,27 @@ def main():
     clip_s = wl.get("clip_seconds", CLIP_SECONDS)
     batch, T, Ta = make_batch(cfg, n_clips, dev, seed=rank_seed(rank), clip_seconds=clip_s)
 
+    timer = ops.KernelTimer()
+    sampled = {"on": False, "i": 0, "n": 0}
+
     def step():
-        return train_step(step_model, batch, opt, sched, gsync)
+        on = sampled["on"] and sampled["i"] % KERNEL_TIMING_EVERY == 0
+        sampled["i"] += 1
+        sampled["n"] += 1 if on else 0
+        ops.TIMER = timer if on else None       # (per-launch events on the sampled steps only: see KERNEL_TIMING_EVERY)
+        try:
+            return train_step(step_model, batch, opt, sched, gsync)
+        finally:
+            ops.TIMER = None
 
     # warm-up outside the kernel timer, then the timed region (measure(): barrier + synchronize on both sides, MAX over ranks)
     measure(step, 0, args.warmup, world, dist, torch.cuda.synchronize, dev)
-    ops.TIMER = ops.KernelTimer()
+    sampled.update(on=True, i=0, n=0)
     if gsync is not None:
         gsync.time_finish = True    # HIP events around finish(): the part of the gradient exchange the backward did not hide
     (loss, acc), elapsed, comm_exposed_ms = measure(step, args.steps, 0, world, dist, torch.cuda.synchronize, dev,
                                                     comm_ms_fn=(gsync.exposed_ms_per_step if gsync is not None else None))
-    timer, ops.TIMER = ops.TIMER, None
+    n_timed = max(1, sampled["n"])           # steps of the timed region that carried per-launch events
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -425,17 +439,19 @@ def main():
     dom = max((k for k in ksum if k.startswith("gemm_nt")), key=lambda k: ksum[k]["total_ms"])
     g = ksum[dom]  # the dominant kernel (largest share of the step): one template instance of the bf16 GEMM
     gemm_tf = g["work"] / (g["total_ms"] * 1e-3) / 1e12
-    kern = {k: dict(launches_per_step=v["launches"] / args.steps, ms_per_step=v["total_ms"] / args.steps,
+    kern = {k: dict(launches_per_step=v["launches"] / n_timed, ms_per_step=v["total_ms"] / n_timed,
                     avg_ms=v["avg_ms"], TFLOPs=v["work"] / (v["total_ms"] * 1e-3) / 1e12,
                     **({"algorithmic_GB_per_launch": v["bytes"] / v["launches"] / 1e9} if v.get("bytes") else {}))
             for k, v in ksum.items()}
     traffic, traffic_src = (traffic_for(dom) if args.workload == "c3" else (None, None))
     roof = {"bound": "mfma", "kernel": dom + " (slam_gemm_bf16_nt)", "achieved": gemm_tf,
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS, "traffic": None,
-            "avg_launch_ms": g["avg_ms"], "launches_per_step": g["launches"] / args.steps,
-            "share_of_step": g["total_ms"] / args.steps / ms_per_step,
+            "avg_launch_ms": g["avg_ms"], "launches_per_step": g["launches"] / n_timed,
+            "share_of_step": g["total_ms"] / n_timed / ms_per_step,
+            "timing": f"HIP events around every launch on {n_timed} of the {args.steps} timed steps (every {KERNEL_TIMING_EVERY}th, from the first): "
+                      f"~1 170 events per step cost it 0.9 %, so they are not recorded on every step",
             "algorithmic_bytes_per_launch": g["bytes"] / g["launches"] if g.get("bytes") else None,
-            "all_gemm_instances": {"achieved": gemm_tf_all, "share_of_step": gemm_ms / args.steps / ms_per_step}}
+            "all_gemm_instances": {"achieved": gemm_tf_all, "share_of_step": gemm_ms / n_timed / ms_per_step}}
     pmc = pmc_for(dom) if args.workload == "c3" else None
     if pmc is not None:
         # MFMA-busy cycles / (active cycles x 256 CUs x 4 SIMDs) of the dominant kernel, longest-running shape first; at the clock the
