@@ -282,9 +282,11 @@ int slam_skinny_gram(const void* S, int64_t lds, const void* X, int64_t ldx, flo
 
 /* LoRA first hop u[M, R] = lora_dropout(x)[M, K] . A[R, K]^T (peft 0.6.0 Linear.forward: lora_A(lora_dropout(x))), R <= 64
  * = all adapters sharing x stacked.  drop_p > 0 applies the counter-based mask of slam_dropout_bf16 (same seed / offset /
- * element index -> same mask) in registers; slam_skinny_gram's drop_p does the same to X for dA = du^T dropout(x). */
+ * element index -> same mask) in registers; slam_skinny_gram's drop_p does the same to X for dA = du^T dropout(x).
+ * Rpad >= R (round 5): columns [R, Rpad) of U -- the zero padding of the K-extension the frozen GEMM runs over -- are written as
+ * zeros by the same launch (Rpad = R: none). */
 int slam_lora_a_fwd(const void* X, int64_t ldx, const void* A, int64_t lda, void* U, int64_t ldu, int64_t M, int64_t R,
-                    int64_t K, float drop_p, uint64_t seed, uint64_t offset, void* stream);
+                    int64_t Rpad, int64_t K, float drop_p, uint64_t seed, uint64_t offset, void* stream);
 
 /* LoRA backward, second hop under lora_dropout (peft 0.6.0 Linear: lora_B(lora_A(lora_dropout(x)))): dx[M, K] += mask . (du[M, R] . At[K, R]^T) / (1 - p)
  * in ONE pass over dx -- du = dL/d(lora_A output) (R = 32 | 64 columns incl. zero padding), At = the adapters' A matrices stacked and transposed

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void skinny_gram_reduce_kernel(const float* __
 template <int NT>
 __global__ __launch_bounds__((NT <= 2 ? 8 : 4) * 64, 2) void lora_a_fwd_kernel(const bf16_t* __restrict__ X, int64_t ldx,
                                                          const bf16_t* __restrict__ A, int64_t lda,
-                                                         bf16_t* __restrict__ U, int64_t ldu, int M, int R, int K,
+                                                         bf16_t* __restrict__ U, int64_t ldu, int M, int R, int Rpad, int K,
                                                          unsigned thresh16, float inv_keep, unsigned long long seed,
                                                          unsigned long long offset) {
   constexpr int NWV = NT <= 2 ? 8 : 4;   // waves splitting K (8 when the LDS reduction buffer allows: more loads in flight)
@@ -547,6 +547,13 @@ __global__ __launch_bounds__((NT <= 2 ? 8 : 4) * 64, 2) void lora_a_fwd_kernel(c
     o.x = pack2bf(v[0] * inv_keep, v[1] * inv_keep);
     o.y = pack2bf(v[2] * inv_keep, v[3] * inv_keep);
     *reinterpret_cast<uint2*>(U + (int64_t)m * ldu + j) = o;
+  }
+  // columns [R, Rpad) of the K-extension are padding (zero rows of the extended weight meet them): zeroed here, by the kernel that
+  // writes their neighbours, instead of by a strided fill launch per layer (round 5: 32 launches x 16 us per C3 step)
+  const int pq = (Rpad - R) >> 2;
+  for (int idx = tid; idx < 32 * pq; idx += NWV * 64) {
+    const int m = m0 + idx / pq, j = R + (idx % pq) * 4;
+    if (m < M) *reinterpret_cast<uint2*>(U + (int64_t)m * ldu + j) = make_uint2(0u, 0u);
   }
 }
 
@@ -661,9 +668,10 @@ __global__ __launch_bounds__(256) void lora_hop_drop_kernel(const bf16_t* __rest
 }  // namespace
 
 extern "C" int slam_lora_a_fwd(const void* X, int64_t ldx, const void* A, int64_t lda, void* U, int64_t ldu, int64_t M,
-                               int64_t R, int64_t K, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
+                               int64_t R, int64_t Rpad, int64_t K, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
   SLAM_CHECK_ARG(X && A && U, "slam_lora_a_fwd: null pointer");
   SLAM_CHECK_ARG(M > 0 && R > 0 && R <= 64 && R % 4 == 0 && K > 0 && K % 64 == 0, "slam_lora_a_fwd: need R %% 4 == 0, R <= 64, K %% 64 == 0");
+  SLAM_CHECK_ARG(Rpad >= R && Rpad % 4 == 0 && Rpad <= ldu && Rpad <= 4096, "slam_lora_a_fwd: Rpad (columns of U to define: R results + zero padding) must be a multiple of 4 in [R, ldu]");
   SLAM_CHECK_ARG(ldx % 8 == 0 && lda % 8 == 0 && ldu % 4 == 0 && ((uintptr_t)U % 8) == 0, "slam_lora_a_fwd: misaligned operands");
   SLAM_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && offset % 8 == 0, "slam_lora_a_fwd: bad dropout arguments");
   const unsigned th = drop_p > 0.f ? slam_drop_thresh16(drop_p) : 0u;
@@ -672,7 +680,7 @@ extern "C" int slam_lora_a_fwd(const void* X, int64_t ldx, const void* A, int64_
   hipStream_t s = (hipStream_t)stream;
   const int nt = (int)cdiv64(R, 16);
 #define SLAM_LAUNCH_LA(NT_) hipLaunchKernelGGL(lora_a_fwd_kernel<NT_>, grid, dim3((NT_ <= 2 ? 8 : 4) * 64), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)A, lda, \
-                                              (bf16_t*)U, ldu, (int)M, (int)R, (int)K, th, inv_keep, (unsigned long long)seed, (unsigned long long)offset)
+                                              (bf16_t*)U, ldu, (int)M, (int)R, (int)Rpad, (int)K, th, inv_keep, (unsigned long long)seed, (unsigned long long)offset)
   if (nt == 1) SLAM_LAUNCH_LA(1);
   else if (nt == 2) SLAM_LAUNCH_LA(2);
   else if (nt == 3) SLAM_LAUNCH_LA(3);

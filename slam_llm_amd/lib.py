@@ -71,7 +71,7 @@ SIGNATURES = {
     "slam_colsum_bf16": [P, I64, P, I64, I64, I32, P],
     "slam_skinny_gram_workspace_bytes": [I64, I64, I64],
     "slam_skinny_gram": [P, I64, P, I64, P, I64, I64, I64, I64, I64, F, I32, F, U64, U64, P, P],
-    "slam_lora_a_fwd": [P, I64, P, I64, P, I64, I64, I64, I64, F, U64, U64, P],
+    "slam_lora_a_fwd": [P, I64, P, I64, P, I64, I64, I64, I64, I64, F, U64, U64, P],
     "slam_lora_hop_dropout": [P, I64, P, I64, P, I64, I64, I64, I64, F, U64, U64, P],
     "slam_lora_pack_b": [P, F, P, I64, P, I64, I64, I64, P],
     "slam_gemm_skinny_workspace_bytes": [I64, I64, I64, I64, I32],

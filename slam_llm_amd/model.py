@@ -241,10 +241,16 @@ class FusedLinear:
         off, _, _ = store.offsets[first["A"]]
         return store.grad[off: off + self.sum_r * self.K].view(self.sum_r, self.K)
 
-    def new_input(self, M: int) -> torch.Tensor:
-        """[M, K + Rp] activation buffer; the caller fills [:, :K]."""
+    @property
+    def hop_fills_pad(self) -> bool:
+        """forward() runs the first hop through slam_lora_a_fwd, which also zeroes the padding columns of the K-extension"""
+        return bool(self.adapters) and self.sum_r <= 64 and self.sum_r % 4 == 0
+
+    def new_input(self, M: int, for_forward: bool = False) -> torch.Tensor:
+        """[M, K + Rp] activation buffer; the caller fills [:, :K].  for_forward: the buffer goes straight into forward(), whose first-hop
+        kernel defines every extension column (results + zero padding) -- no fill launch here (round 5: 32 strided fills per C3 step)."""
         buf = torch.empty((M, self.K + self.Rp), dtype=torch.bfloat16, device=self.device)
-        if self.Rp:
+        if self.Rp and self.Rp > self.sum_r and not (for_forward and self.hop_fills_pad):
             buf[:, self.K + self.sum_r:].zero_()  # padding columns of the K-extension
         return buf
 
@@ -255,8 +261,8 @@ class FusedLinear:
         deviation); None = no dropout (eval mode / p = 0)."""
         if self.adapters:
             sr = self.sum_r
-            if sr <= 64 and sr % 4 == 0:   # one pass over x, dropout mask applied in registers
-                ops.lora_a_fwd(x_ext[:, : self.K], self.a_cat(store), x_ext[:, self.K: self.K + sr], drop)
+            if self.hop_fills_pad:   # one pass over x, dropout mask applied in registers; the padding columns zeroed by the same launch
+                ops.lora_a_fwd(x_ext[:, : self.K], self.a_cat(store), x_ext[:, self.K: self.K + sr], drop, pad_to=self.Rp)
             else:
                 xin = x_ext[:, : self.K]
                 if drop is not None:
@@ -2194,7 +2200,7 @@ class HipLlamaLora(nn.Module):
                     inv = torch.full((M,), -1, dtype=torch.int32, device=h.device)
                     inv[rows64] = torch.arange(n_lab, dtype=torch.int32, device=h.device)
         for L in self.layers:
-            x1 = L.qkv.new_input(M)
+            x1 = L.qkv.new_input(M, for_forward=True)
             _, rstd1 = ops.rmsnorm_fwd(h, L.ln1, eps, out=x1[:, :d])
             dq_, do_, dg_, dd_ = drop_for(L.qkv), drop_for(L.o), drop_for(L.gu), drop_for(L.down)
             qkv = L.qkv.forward(x1, st, drop=dq_)

@@ -797,13 +797,14 @@ def colsum(x2d, out_f32, accumulate=False):
 _GRAM_WS = {}
 
 
-def lora_a_fwd(x2d, a_cat, out, drop=None):
-    """out[M, R] = dropout(x)[M, K] @ a_cat[R, K]^T; drop = (p, seed, offset) or None (x is read once, mask in registers)"""
+def lora_a_fwd(x2d, a_cat, out, drop=None, pad_to=None):
+    """out[M, R] = dropout(x)[M, K] @ a_cat[R, K]^T; drop = (p, seed, offset) or None (x is read once, mask in registers).
+    pad_to: columns [R, pad_to) behind `out` (same rows, same leading dimension: the K-extension's padding) are zeroed by the launch."""
     M, K = x2d.shape
     R = a_cat.shape[0]
     p_, seed, off = drop if drop is not None else (0.0, 0, 0)
     _timed("lora_a_fwd", 2.0 * M * K,
-           lambda: call("slam_lora_a_fwd", _p(x2d), _ld(x2d), _p(a_cat), _ld(a_cat), _p(out), _ld(out), M, R, K, float(p_),
+           lambda: call("slam_lora_a_fwd", _p(x2d), _ld(x2d), _p(a_cat), _ld(a_cat), _p(out), _ld(out), M, R, int(pad_to or R), K, float(p_),
                         int(seed) & (2 ** 64 - 1), int(off) & (2 ** 64 - 1), _s()))
     return out
 

@@ -1246,6 +1246,12 @@ def test_lora_first_hop_and_gram_recompute_the_dropout_mask(dev, M, K, R, p):
     u = torch.empty((M, R + 8), dtype=torch.bfloat16, device=dev)
     ops.lora_a_fwd(x, A, u[:, :R], drop)
     assert_close(u[:, :R], xd.float() @ A.float().T, atol=2e-2, rtol=2e-2, what="lora first hop")
+    # pad_to (round 5): the padding columns of the K-extension behind the results are zeroed by the same launch -- and nothing else moves
+    Rp = ops.round_up(R, 64)
+    up = torch.full((M, Rp + 8), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.lora_a_fwd(x, A, up[:, :R], drop, pad_to=Rp)
+    assert torch.equal(up[:, :R], u[:, :R])
+    assert torch.all(up[:, R:Rp] == 0) and torch.isnan(up[:, Rp:].float()).all()
     if R in (8, 16, 32, 64):
         du = rnd((M, R), dev, seed=33)
         g1 = torch.zeros((R, K), dtype=torch.float32, device=dev)
