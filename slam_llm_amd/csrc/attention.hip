@@ -305,8 +305,25 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
     const bool pre = QS && it > tb;
     const bool tail = QS && k0 + 64 > Tk;
     f32x4_t s[QF][4];
-    auto s_product = [&](const bool from_minus_m, auto tail_c, const int li, const int g) {   // (li, g: see the second call)
+    // FUSE (QS attempts): the exponentials (and row-sum adds) of key fragment kf - 1 are placed between the MFMAs of fragment kf -- a SIMD
+    // runs its waves' MFMA and VALU phases one after the other unless they alternate inside one instruction stream (profiles/r05_attention_isa.md:
+    // 512 cycles of MFMA + 512 of v_exp_f32 + 280 of other VALU per wave and tile = the measured tile time); sched_group_barrier pins the pattern
+    float fz[QF];   // FUSE: the row sum per query fragment (one chain: its adds sit between MFMAs, their latency is covered)
+    auto s_product = [&](const bool from_minus_m, auto tail_c, const int li, const int g, auto fuse_c) {   // (li, g: see the second call)
       constexpr bool TAIL = decltype(tail_c)::value;
+      constexpr bool FUSE = decltype(fuse_c)::value;
+      auto exp_pair = [&](auto kfe, int f, int r) {   // P of elements r, r + 1 of fragment kfe in place of their scores, row-sum chains updated
+        const float pv0 = fast_exp2(s[f][kfe][r]);
+        const float pv1 = fast_exp2(s[f][kfe][r + 1]);
+        s[f][kfe][r] = pv0;
+        s[f][kfe][r + 1] = pv1;
+        fz[f] += pv0;
+        fz[f] += pv1;
+      };
+      if constexpr (FUSE) {
+#pragma unroll
+        for (int f = 0; f < QF; f++) fz[f] = 0.f;
+      }
       const int i4 = (li >> 2) * 8 + (li & 3);
       const unsigned kbase = lds_offset_of(ldsK) + (unsigned)(i4 * KROWB);
       unsigned ka[KD];
@@ -336,13 +353,39 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
               if (k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4 + r >= Tk) acc[r] = -INFINITY;
           }
 #pragma unroll
-          for (int kd = 0; kd < KD; kd++) acc = mfma16(kfr[kf][kd], qf[f][kd], acc);
+          for (int kd = 0; kd < KD; kd++) {
+            acc = mfma16(kfr[kf][kd], qf[f][kd], acc);
+            if constexpr (FUSE && kf >= 1) {
+              // behind every MFMA of fragment kf: one pair of exponentials (+ two adds) of fragment kf - 1 (QF * KD MFMAs, QF * 2 pairs),
+              // fenced so that the order in the instruction stream IS this order
+              static_assert(KD == 2, "one pair of fragment kf - 1 per MFMA of fragment kf");
+              __builtin_amdgcn_sched_barrier(0);
+              exp_pair(std::integral_constant<int, (kf >= 1 ? kf - 1 : 0)>{}, f, 2 * kd);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
           s[f][kf] = acc;
         }
       });
+      if constexpr (FUSE) {
+#pragma unroll
+        for (int f = 0; f < QF; f++)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) exp_pair(std::integral_constant<int, 3>{}, f, r);
+      }
     };
-    if (QS && tail) s_product(pre, std::true_type{}, li, g);
-    else s_product(pre, std::false_type{}, li, g);
+    if constexpr (QS) {
+      if (pre) {
+        if (tail) s_product(true, std::true_type{}, li, g, std::true_type{});
+        else s_product(true, std::false_type{}, li, g, std::true_type{});
+      } else if (tail) {
+        s_product(false, std::true_type{}, li, g, std::false_type{});
+      } else {
+        s_product(false, std::false_type{}, li, g, std::false_type{});
+      }
+    } else {
+      s_product(false, std::false_type{}, li, g, std::false_type{});
+    }
     stamp(it, 4);
     const unsigned vbase = lds_offset_of(ldsV) + (unsigned)(li * 128);
     unsigned va[2];
@@ -394,17 +437,21 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
 #pragma unroll
       for (int f = 0; f < QF; f++) {
         float acc0 = 0.f, acc1 = 0.f;   // two chains (the translation unit is built without SLP packing: v_pk_add_f32 beside MFMAs is slower than two v_add_f32)
+        if constexpr (QS) {             // P and the two chains were produced between the MFMAs of the first product (FUSE)
+          acc0 = fz[f];
+        } else {
 #pragma unroll
-        for (int kf = 0; kf < 4; kf++)
+          for (int kf = 0; kf < 4; kf++)
 #pragma unroll
-          for (int r = 0; r < 4; r += 2) {
-            const float pv0 = fast_exp2(QS ? s[f][kf][r] : fmaf(s[f][kf][r], sl2, -mrow[f]));
-            const float pv1 = fast_exp2(QS ? s[f][kf][r + 1] : fmaf(s[f][kf][r + 1], sl2, -mrow[f]));
-            pt[f][kf][r] = pv0;
-            pt[f][kf][r + 1] = pv1;
-            acc0 += pv0;
-            acc1 += pv1;
-          }
+            for (int r = 0; r < 4; r += 2) {
+              const float pv0 = fast_exp2(fmaf(s[f][kf][r], sl2, -mrow[f]));
+              const float pv1 = fast_exp2(fmaf(s[f][kf][r + 1], sl2, -mrow[f]));
+              pt[f][kf][r] = pv0;
+              pt[f][kf][r + 1] = pv1;
+              acc0 += pv0;
+              acc1 += pv1;
+            }
+        }
         rs[f] = acc0 + acc1;
         over |= !(rs[f] <= 64.0f);
       }
@@ -422,8 +469,8 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
         // (its LDS addresses are derived from an opaque copy of the thread id: one register less carried through the loop for this path)
         int t2 = threadIdx.x;
         asm volatile("" : "+v"(t2));
-        if (tail) s_product(false, std::true_type{}, t2 & 15, (t2 >> 4) & 3);
-        else s_product(false, std::false_type{}, t2 & 15, (t2 >> 4) & 3);
+        if (tail) s_product(false, std::true_type{}, t2 & 15, (t2 >> 4) & 3, std::false_type{});
+        else s_product(false, std::false_type{}, t2 & 15, (t2 >> 4) & 3, std::false_type{});
       }
     }
     if (fast_done) {

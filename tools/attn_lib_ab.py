@@ -32,7 +32,11 @@ def main():
     qkv = torch.randn(B * T, 3 * H * D, device=dev).to(torch.bfloat16)
     q2, k2, v2 = qkv[:, : H * D], qkv[:, H * D: 2 * H * D], qkv[:, 2 * H * D:]
     o = torch.empty(B * T, H * D, device=dev, dtype=torch.bfloat16)
-    fns["whisper_fwd_no_lse"] = lambda: ops.attn_fwd(q2, k2, v2, B, T, H, H, D, False, D ** -0.5, want_lse=False, out=o)
+    pre = hasattr(ops, "qscale")   # (builds from the folded-scale form on: the frozen encoder's launch hands over a pre-scaled Q)
+    if pre:
+        qkv[:, : H * D] = (qkv[:, : H * D].float() * ops.qscale(D ** -0.5)).to(torch.bfloat16)
+    fns["whisper_fwd_no_lse"] = ((lambda: ops.attn_fwd(q2, k2, v2, B, T, H, H, D, False, D ** -0.5, want_lse=False, out=o, q_prescaled=True)) if pre
+                                 else (lambda: ops.attn_fwd(q2, k2, v2, B, T, H, H, D, False, D ** -0.5, want_lse=False, out=o)))
     fns["whisper_fwd_lse"] = lambda: ops.attn_fwd(q2, k2, v2, B, T, H, H, D, False, D ** -0.5, want_lse=True, out=o)
     Bl, Tl, Hq, Hkv, Dl = 31, 380, 32, 8, 128
     qkvl = torch.randn(Bl * Tl, (Hq + 2 * Hkv) * Dl, device=dev).to(torch.bfloat16)
