@@ -37,6 +37,15 @@ extern "C" {
 const char* slam_last_error(void);
 int slam_abi_version(void);
 const char* slam_target_arch(void); /* "gfx950" */
+/* every process-global tuning knob (slam_gemm_set_config / _set_group_m, slam_attn_set_fwd_qf / _set_bwd_variant) back to the default
+ * it is defined with: the defaults live in the library, not in its callers (tests reset between cases; no reference counterpart:
+ * the reference has no kernel-selection state) */
+int slam_reset_tuning(void);
+/* dropout masks under hipGraph replay: every dropout-aware kernel (slam_dropout_bf16, slam_lora_a_fwd, slam_lora_hop_dropout,
+ * slam_skinny_gram, the DROP attention kernels) XORs *device_word into its seed when one is registered; a captured step bumps the word
+ * at its end so that each replay draws fresh masks (torch's dropout under CUDA graphs does the same through its philox offset).
+ * null (default) detaches: seeds are used as passed.  Reference: peft lora_dropout / Blip2QFormer dropout draw from torch's RNG. */
+int slam_set_dropout_salt(const unsigned long long* device_word);
 
 /* ---- a1: log-mel front end ------------------------------------------------------------------
  * whisper.pad_or_trim + whisper.log_mel_spectrogram, src/slam_llm/datasets/speech_dataset.py:101-103,
@@ -308,6 +317,12 @@ int slam_embed_splice_bwd(const int32_t* spans, const void* dX, int64_t lddx, vo
  * targets[b*T+t] = labels[b,t+1] (or -1 when ignored / t = T-1); n_valid = #valid targets (device int). */
 int slam_ce_targets(const int64_t* labels, int32_t* targets, int32_t* n_valid, int64_t B, int64_t T,
                     int64_t ignore_index, void* stream);
+/* device-side selection of the labelled rows (replaces a host read-back of the label count + a torch argsort; the reference runs
+ * lm_head and CrossEntropyLoss(ignore_index=-100) over every row, src/slam_llm/models/slam_model.py:400-405): rows[i] / tsel[i] =
+ * index / target of the i-th row with targets >= 0 (row order), -1 beyond the count up to `cap`; inv[r] = position of row r in rows or
+ * -1; count[0] = number of labelled rows (a count above cap means the caller's bound was too small). */
+int slam_label_rows(const int32_t* targets, int64_t M, int64_t cap, int32_t* rows, int32_t* tsel, int32_t* inv, int32_t* count,
+                    void* stream);
 /* per row: loss, argmax==target; when write_grad, logits are overwritten by dlogits = (softmax-onehot)/n_valid */
 int slam_ce_fwd_bwd(void* logits, int64_t ld, const int32_t* targets, const int32_t* n_valid,
                     float* row_loss, int32_t* row_correct, int64_t rows, int64_t V, int write_grad,
@@ -321,6 +336,12 @@ int slam_ce_finalize(const float* row_loss, const int32_t* row_correct, const in
 int slam_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                     int64_t step, float grad_scale, void* stream);
+
+/* the same update with lr, 1 - beta1^step, sqrt(1 - beta2^step) read from device memory (hyper[0..2]): for a training step captured
+ * in a hipGraph, whose kernel arguments are frozen at capture (the LambdaLR value of pipeline/finetune.py:253-260 changes every step) */
+int slam_adamw_hyper(float lr, float beta1, float beta2, int64_t step, float* out3_host);   /* the three words, as slam_adamw_step forms them */
+int slam_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16, int64_t n,
+                        const float* hyper, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
 /* AnyPrecisionAdamW (src/slam_llm/policies/anyprecision_optimizer.py:73-178, selected at pipeline/finetune.py:237-245): bf16
  * momentum / variance (and optional bf16 Kahan compensation: non-null), every tensor op of the reference rounded to its tensor's

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
     // are requested up front, products start as they land; the V^T reads of the first pair are requested before the softmax
     // arithmetic and land behind it.
     // QS (a PLAIN form: no mask, no segments): a tile behind the first one (every row has a finite maximum by then) starts its
-    // accumulators at -m; the keys past Tk of the last tile start theirs at -inf (P = 0 on every path: the QS form has no masked path)
+    // accumulators at -m; the scores of keys past Tk of the last tile are replaced by -inf behind the product (P = 0 on every path: the QS form has no masked path)
     const bool pre = QS && it > tb;
     const bool tail = QS && k0 + 64 > Tk;
     f32x4_t s[QF][4];
@@ -347,11 +347,6 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
         for (int f = 0; f < QF; f++) {
           const float a0 = (QS && from_minus_m) ? -mrow[f] : 0.f;
           f32x4_t acc = f32x4_t{a0, a0, a0, a0};
-          if constexpr (TAIL) {   // element r of fragment kf is key k0 + 32 (kf / 2) + 8 g + 4 (kf % 2) + r
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-              if (k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4 + r >= Tk) acc[r] = -INFINITY;
-          }
 #pragma unroll
           for (int kd = 0; kd < KD; kd++) {
             acc = mfma16(kfr[kf][kd], qf[f][kd], acc);
@@ -363,6 +358,14 @@ __global__ __launch_bounds__(256, (PLAIN ? 3 : 1)) void attn_fwd_kernel(AttnPara
               exp_pair(std::integral_constant<int, (kf >= 1 ? kf - 1 : 0)>{}, f, 2 * kd);
               __builtin_amdgcn_sched_barrier(0);
             }
+          }
+          if constexpr (TAIL) {   // element r of fragment kf is key k0 + 32 (kf / 2) + 8 g + 4 (kf % 2) + r
+            // keys past Tk: the score is DISCARDED (a select behind the product, last tile only), not "-inf + whatever the LDS rows past
+            // the tile hold" -- those rows are the next batch item's K (or descriptor zeros), and an Inf / NaN there must stay that
+            // item's problem (-inf + NaN = NaN reached this item's row sums)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              if (k0 + (kf >> 1) * 32 + 8 * g + (kf & 1) * 4 + r >= Tk) acc[r] = -INFINITY;
           }
           s[f][kf] = acc;
         }
@@ -2270,22 +2273,12 @@ int launch_dq_tr(const AttnParams& p, dim3 grid, hipStream_t s) {
 }
 
 }  // namespace
-// attention_dkdv32.hip (its own translation unit: built without -amdgpu-mfma-vgpr-form): the 32-keys-per-wave form of the kernel below
-extern "C" __attribute__((visibility("hidden"))) int slam_attn_launch_dkdv32(const void* attn_params, int causal, unsigned nblocks, void* stream);
-int g_attn_dkdv32 = 0;   // 1 = D = 128 launches of the transposed-read dK / dV kernel take the 4-wave x 32-key form (round 5: bit-identical, measured 11 % SLOWER -- kept selectable, not shipped); 0 = 8 waves x 16 keys (A/B: slam_attn_set_fwd_qf 70 / 71)
+// (round 5's 4-wave x 32-key form of the kernel below -- half the LDS bytes per MFMA, bit-identical, 11 % slower, profiles/r05_attention_dkdv32.md --
+// was removed in round 6 with its translation unit; git history keeps it)
 namespace {
 
 template <int D, bool CAUSAL>
 int launch_dkdv_tr(const AttnParams& p, dim3 grid, hipStream_t s) {
-  if constexpr (D == 128) {
-    if (g_attn_dkdv32) {
-      AttnParams q = p;   // (what attn_launch does, for a kernel that lives in the other translation unit)
-      q.gx = (int)grid.x; q.gy = (int)grid.y; q.gz = (int)grid.z;
-      q.xcd = g_attn_xcd;
-      q.heavy = (g_attn_heavy && !p.seg_lo) ? (CAUSAL ? 1 : 0) : 0;
-      return slam_attn_launch_dkdv32(&q, CAUSAL ? 1 : 0, grid.x * grid.y * grid.z, s);
-    }
-  }
   constexpr int lds = 4 * (2 * 32 * D * 2 + 1024);
   static bool attr_set = false;
   auto kern = attn_bwd_dkdv_tr_kernel<D, CAUSAL>;
@@ -2334,15 +2327,13 @@ extern "C" int slam_attn_set_bwd_variant(int variant) {   // tools: 0 = DMA-ring
 }
 
 extern int g_attn_fwd_dma, g_attn_fwd_plain, g_attn_fwd_qs;
-extern int g_attn_dkdv32;
 extern "C" int slam_attn_set_fwd_qf(int qf) {   // tools: 0 = auto, 1 / 2 fragments per wave; 10 / 11 = register-staged / DMA tiles
-  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11 || qf == 20 || qf == 21 || qf == 30 || qf == 31 || qf == 40 || qf == 41 || qf == 50 || qf == 51 || qf == 60 || qf == 61 || qf == 70 || qf == 71,
+  SLAM_CHECK_ARG((qf >= 0 && qf <= 2) || qf == 10 || qf == 11 || qf == 20 || qf == 21 || qf == 30 || qf == 31 || qf == 40 || qf == 41 || qf == 50 || qf == 51 || qf == 60 || qf == 61,
                  "slam_attn_set_fwd_qf: %d (0 = auto, 1 or 2; 10 / 11 = staged / DMA tiles; 20 / 21 = hardware / XCD-aware workgroup order; "
                  "30 / 31 = general / mask-free instantiation for unmasked bidirectional D = 64; 40 / 41 = transposed-copy / transposed-read kernels; "
                  "50 / 51 = id order / heaviest sequence block first in causal launches; 60 / 61 = general softmax / Q pre-scaled by the caller "
-                 "and accumulators started at -m in LSE-less mask-free launches; 70 / 71 = 8 waves x 16 keys / 4 waves x 32 keys in the D = 128 dK / dV kernel)", qf);
-  if (qf >= 70) g_attn_dkdv32 = qf - 70;
-  else if (qf >= 60) g_attn_fwd_qs = qf - 60;
+                 "and accumulators started at -m in LSE-less mask-free launches)", qf);
+  if (qf >= 60) g_attn_fwd_qs = qf - 60;
   else if (qf >= 50) g_attn_heavy = qf - 50;
   else if (qf >= 40) g_attn_tr = qf - 40;
   else if (qf >= 30) g_attn_fwd_plain = qf - 30;
@@ -2350,6 +2341,12 @@ extern "C" int slam_attn_set_fwd_qf(int qf) {   // tools: 0 = auto, 1 / 2 fragme
   else if (qf >= 10) g_attn_fwd_dma = qf - 10;
   else g_attn_fwd_qf = qf;
   return 0;
+}
+
+// every attention tuning knob back to the value it is DEFINED with (slam_reset_tuning)
+void slam_attn_reset_tuning_() {
+  g_attn_tr = 1; g_attn_xcd = 1; g_attn_heavy = 1; g_attn_bwd_variant = 0; g_attn_fwd_qf = 0;
+  g_attn_fwd_qs = 1; g_attn_fwd_plain = 1; g_attn_fwd_dma = 1;
 }
 
 int g_attn_fwd_qs = 1;    // 1 = LSE-less launches of the mask-free form whose Q arrives pre-scaled (negative scale) run attn_fwd_kernel<..., QS>
@@ -2451,6 +2448,7 @@ extern "C" int slam_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.drop_thresh = drop_p > 0.f ? slam_drop_thresh16(drop_p) : 0u;
   p.drop_scale = 1.0f / (1.0f - drop_p);
   p.drop_seed = drop_seed;
+  p.drop_salt = g_slam_drop_salt;
   hipStream_t s = (hipStream_t)stream;
   if (drop_p > 0.f && rp_gate) {   // un-frozen WavLM in train mode: attention_dropout on top of the gated bias (WavLM.py:181, modules.py:504-562)
     launch_fwd<64, false, 2, true, true>(p, B, s);
@@ -2556,6 +2554,7 @@ extern "C" int slam_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t 
   p.drop_thresh = drop_p > 0.f ? slam_drop_thresh16(drop_p) : 0u;
   p.drop_scale = 1.0f / (1.0f - drop_p);
   p.drop_seed = drop_seed;
+  p.drop_salt = g_slam_drop_salt;
   p.rp_gate = rp_gate; p.rp_tab = rp_tab; p.rp_T = (int)rp_T; p.rp_ld = (int)rp_ld; p.rp_ds = rp_ds;
   hipStream_t s = (hipStream_t)stream;
   const AttnFits fits = attn_fits(B, Tq, Tk, Tqp, Tkp, Hq, Hkv, D, ldq, ldk, ldv, lddo);

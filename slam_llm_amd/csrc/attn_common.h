@@ -1,4 +1,4 @@
-// Shared by the attention translation units (attention.hip, attention_dkdv32.hip): launch parameters, the workgroup -> (block, head,
+// Shared by the attention code (attention.hip; round 5 had a second translation unit): launch parameters, the workgroup -> (block, head,
 // batch) numbering, MFMA / LDS / LDS-DMA helpers.  Everything lives in an anonymous namespace (one copy per translation unit); AttnParams
 // crosses the boundary between them only as an opaque pointer (same header, same layout).
 #pragma once
@@ -54,6 +54,7 @@ struct AttnParams {
   unsigned drop_thresh;
   float drop_scale;
   unsigned long long drop_seed;
+  const unsigned long long* drop_salt;   // null, or the device word of slam_set_dropout_salt (XORed into drop_seed: captured steps)
   // launch geometry (set by attn_launch): the logical grid is (gx sequence blocks, gy heads, gz batches), launched 1-D
   int gx, gy, gz;
   int xcd;   // 1: undo the hardware's round-robin workgroup -> XCD placement (attn_blk)
@@ -109,7 +110,7 @@ __device__ __forceinline__ AttnBlk attn_blk(const AttnParams& p) {
 // keep bits (bit r) of keys kb .. kb+3 (kb % 4 == 0) for query q of flattened (batch, head) bh
 __device__ __forceinline__ unsigned attn_keep4(const AttnParams& p, int bh, int q, int kb) {
   const unsigned long long idx = ((unsigned long long)bh * (unsigned)p.Tqp + (unsigned)q) * (unsigned)p.Tkp + (unsigned)kb;
-  const unsigned long long h64 = slam_mix64(p.drop_seed ^ ((idx >> 2) * 0xD1342543DE82EF95ull));
+  const unsigned long long h64 = slam_mix64(slam_salted(p.drop_seed, p.drop_salt) ^ ((idx >> 2) * 0xD1342543DE82EF95ull));
   unsigned bits = 0;
 #pragma unroll
   for (int e = 0; e < 4; e++) bits |= ((unsigned)((h64 >> (16 * e)) & 0xFFFFull) >= p.drop_thresh ? 1u : 0u) << e;

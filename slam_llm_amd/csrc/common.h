@@ -122,6 +122,16 @@ __device__ __forceinline__ unsigned long long slam_mix64(unsigned long long z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
+// Dropout "salt" (round 6, for captured training steps): a captured hipGraph replays its kernel arguments, so a mask seed passed by value
+// would repeat the SAME masks on every replay.  slam_set_dropout_salt(dev_ptr) registers one device-resident 64-bit word; every
+// dropout-aware kernel XORs *dev_ptr into its seed when the pointer is non-null, and the captured step bumps the word at its end (forward
+// and backward of one step read the same value).  null (default, eager mode): seeds are used as passed -- the masks the tests rebuild on
+// the host.  Defined in capi_core.hip.
+extern const unsigned long long* g_slam_drop_salt;
+__device__ __forceinline__ unsigned long long slam_salted(unsigned long long seed, const unsigned long long* salt) {
+  return salt ? (seed ^ *salt) : seed;
+}
+
 __device__ __forceinline__ unsigned slam_keep8(unsigned long long seed, unsigned long long base, unsigned thresh16) {
   unsigned bits = 0;
 #pragma unroll

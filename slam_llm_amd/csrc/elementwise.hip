@@ -745,7 +745,9 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out,
                                                       int64_t ldo, int64_t M, int N, float inv_keep, unsigned thresh,
-                                                      unsigned long long seed, unsigned long long offset, int accumulate) {
+                                                      unsigned long long seed, unsigned long long offset, int accumulate,
+                                                      const unsigned long long* salt) {
+  seed = slam_salted(seed, salt);
   const int nch = N >> 3;
   const int64_t total = M * nch;
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -1253,7 +1255,7 @@ extern "C" int slam_dropout_bf16(const void* x, int64_t ldx, void* out, int64_t 
   const unsigned thresh = slam_drop_thresh16(p);
   hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(M * (N / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
                      (bf16_t*)out, ldo, M, (int)N, 1.0f / (1.0f - p), thresh, (unsigned long long)seed,
-                     (unsigned long long)offset, accumulate);
+                     (unsigned long long)offset, accumulate, g_slam_drop_salt);
   SLAM_CHECK_LAUNCH("slam_dropout_bf16");
   return 0;
 }

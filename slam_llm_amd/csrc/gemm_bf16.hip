@@ -24,9 +24,6 @@
 #include <atomic>
 #include <type_traits>
 
-// cfg 8, two workgroups per CU: csrc/gemm_p3.hip
-int launch_gemm_p3(GemmParams& p, hipStream_t stream, int stagger_mode);
-
 namespace {
 
 // tools only: shader-clock / real-time stamps of workgroup 0 (effective clock of a launch = d(shader cycles) / d(100 MHz ticks))
@@ -1165,7 +1162,6 @@ std::atomic<int> g_gemm_big{12};       // which 256x256 kernel the auto rule use
 std::atomic<int> g_gemm_big_shortk{7}; // ... and for K <= 2048
 std::atomic<int> g_gemm_small{1};      // the 128x128 kernel of the auto rule: 1 = two-stage loop, 11 = register-double-buffered pipeline
 std::atomic<int> g_gemm_group_m{8};
-std::atomic<int> g_gemm_p3_stagger{1}; // cfg 8: second-slot workgroups start half a tile late (slam_gemm_set_config 380 / 381: off / on)
 std::atomic<int> g_gemm_probe{0};      // 1: cfg 6 / 12 launch their PROBE instantiation (workgroup 0 stamps g_clk_probe; tools/gemm_epi_probe.py)
 
 }  // namespace
@@ -1196,9 +1192,14 @@ extern "C" int slam_gemm_set_workspace(void* workspace, int64_t bytes) {
   return 0;
 }
 
+// every GEMM tuning knob back to the value it is DEFINED with above (slam_reset_tuning: one place for the defaults)
+void slam_gemm_reset_tuning_() {
+  g_gemm_splitk = -1; g_gemm_sk2 = 1; g_gemm_splitk_rmax = 32; g_gemm_splitk_smax = 2; g_gemm_ts = 1;
+  g_gemm_cfg = 0; g_gemm_big = 12; g_gemm_big_shortk = 7; g_gemm_small = 1; g_gemm_group_m = 8; g_gemm_probe = 0;
+}
+
 extern "C" int slam_gemm_set_config(int cfg) {
   if (cfg >= 360 && cfg <= 362) { g_gemm_sk2 = cfg - 360; return 0; }       // two-launch split-K for mid-M products: off / auto (default) / also for forced plans
-  if (cfg == 380 || cfg == 381) { g_gemm_p3_stagger = cfg - 380; return 0; }   // cfg 8: stagger of the second-slot workgroups off / on (default)
   if (cfg == 370 || cfg == 371) { g_gemm_ts = cfg - 370; return 0; }         // N <= 64 products: 128 x 64 tile kernel / tall-skinny K-sliced kernel (default)
   if (cfg >= 320 && cfg <= 336) { g_gemm_splitk_rmax = (cfg - 320) * 8; return 0; }   // auto plan: tail tiles <= 8 * (cfg - 320)
   if (cfg >= 340 && cfg <= 348) { g_gemm_splitk_smax = cfg - 340; return 0; }         // auto plan: at most cfg - 340 slices
@@ -1209,9 +1210,9 @@ extern "C" int slam_gemm_set_config(int cfg) {
   // 100 + v / 200 + v (v in 6, 7, 12): the 256x256 kernel the AUTO rule picks for K > 2048 / K <= 2048 (tools/step sweeps)
   if (cfg == 400 || cfg == 401) { g_gemm_probe = cfg - 400; return 0; }   // tools: cycle stamps of workgroup 0 (slam_gemm_debug_clock)
   if (cfg == 106 || cfg == 107 || cfg == 112) { g_gemm_big = cfg - 100; return 0; }
-  if (cfg == 206 || cfg == 207 || cfg == 208 || cfg == 212) { g_gemm_big_shortk = cfg - 200; return 0; }
+  if (cfg == 206 || cfg == 207 || cfg == 212) { g_gemm_big_shortk = cfg - 200; return 0; }
   if (cfg == 601 || cfg == 611) { g_gemm_small = cfg - 600; return 0; }   // which 128x128 kernel the auto rule uses when small tiles win (1 | 11)
-  SLAM_CHECK_ARG(cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 11 || cfg == 12, "slam_gemm_set_config: cfg %d (0 auto | 1 2 3 4 6 7 8 11 12)", cfg);
+  SLAM_CHECK_ARG(cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 6 || cfg == 7 || cfg == 11 || cfg == 12, "slam_gemm_set_config: cfg %d (0 auto | 1 2 3 4 6 7 11 12)", cfg);
   g_gemm_cfg = cfg;
   return 0;
 }
@@ -1306,12 +1307,11 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
     case 6:                                                // pipelined, phase A pinned before the barrier (shipped)
       if (g_gemm_probe) return launch_gemm<256, 256, 2, 4, 1, true>(p, s);
       return launch_gemm<256, 256, 2, 4, 1>(p, s);
-    case 8:                                                // 128 x 256 tiles, two workgroups per CU (round 5; csrc/gemm_p3.hip)
-      if (p.K < 128 || p.K % 64 || !fits_descriptor(p.M, p.lda, 128, p.K) || !fits_descriptor(p.N, p.ldb, 256, p.K)) return launch_gemm<256, 256, 2, 4, 1>(p, s);
-      return launch_gemm_p3(p, s, g_gemm_p3_stagger);
     case 7:                                                // persistent pipelined, descriptor DMA (auto: short-K products)
       if (p.K < 2 * BK || !fits_descriptor(p.M, p.lda, 256, p.K) || !fits_descriptor(p.N, p.ldb, 256, p.K)) return launch_gemm<256, 256, 2, 4, 1>(p, s);
       return launch_gemm_persist2<256, 256, 2, 4>(p, s);
+    // (round 5's cfg 8 -- 128 x 256 tiles, two workgroups per CU, hand-ordered, bit-identical to cfg 7 -- measured 26 % slower
+    //  (profiles/r05_gemm_two_wg.md) and was removed in round 6 with its translation unit; git history keeps it)
     // (cfg 5 = compiler-placed barrier, 8-11 = timing ablations of the pipelined loop, 13 = register-staged 4-wave form,
     //  14-16 = ablations of the 4-wave loop: measured, recorded in profiles/r02_gemm_experiments.md, removed to keep the build short)
     case 12:                                               // 4 waves, hand-ordered k-loop

@@ -1,4 +1,4 @@
-// Shared by the bf16 GEMM translation units (gemm_bf16.hip, gemm_p3.hip): launch parameters, LDS-DMA helpers and the epilogues.
+// Shared by the bf16 GEMM code (gemm_bf16.hip; round 5 had a second translation unit): launch parameters, LDS-DMA helpers and the epilogues.
 // Split out of gemm_bf16.hip in round 5 so that a new kernel form compiles in its own (short) translation unit.
 #pragma once
 #include "common.h"
@@ -428,7 +428,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4_t (&acc
 }
 
 
-// ---- hand-ordered loops (gemm_nt_w4_kernel, gemm_nt_p3_kernel): every instruction of the k-loop is an `asm volatile` statement ----
+// ---- hand-ordered loops (gemm_nt_w4_kernel): every instruction of the k-loop is an `asm volatile` statement ----
 template <int I, int N, class F>
 __device__ __forceinline__ void gemm_static_for(F&& f) {
   if constexpr (I < N) {

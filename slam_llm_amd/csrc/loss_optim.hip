@@ -41,6 +41,53 @@ __global__ __launch_bounds__(1024) void ce_targets_kernel(const int64_t* __restr
   }
 }
 
+// Device-side selection of the rows that carry a label (round 6: takes the host out of the training step -- the label count used
+// to be read back through pinned memory and the row list came from a torch argsort, which blocked hipGraph capture).
+//   rows[i]   (i < cap)  = index of the i-th row with targets >= 0, in row order; -1 for i >= count (slam_gather_rows_bf16 turns a
+//                          negative index into a zero row: padding rows are zero activations with an ignored target)
+//   tsel[i]   (i < cap)  = targets[rows[i]], -1 for the padding
+//   inv[r]    (r < M)    = position of row r in `rows`, -1 when row r carries no label (or did not fit below cap)
+//   count[0]             = number of rows with a label (may exceed cap: the caller's bound was too small -- its problem to detect)
+// One workgroup: M is a few 10^4, the scan is chunked 1024 rows at a time with a wave-level prefix + an LDS prefix over the 16 waves.
+__global__ __launch_bounds__(1024) void label_rows_kernel(const int32_t* __restrict__ tgt, int M, int cap, int32_t* __restrict__ rows,
+                                                          int32_t* __restrict__ tsel, int32_t* __restrict__ inv,
+                                                          int32_t* __restrict__ count) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < M; r0 += 1024) {
+    const int r = r0 + tid;
+    const int t = r < M ? tgt[r] : -1;
+    const bool has = t >= 0;
+    const unsigned long long ball = __ballot(has);
+    const int before = __popcll(ball & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(ball);
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+      const int c = wsum[w];
+      if (w < wave) wbase += c;
+      tot += c;
+    }
+    const int base = base_s;
+    const int pos = base + wbase + before;
+    if (r < M) {
+      const bool fits = has && pos < cap;
+      inv[r] = fits ? pos : -1;
+      if (fits) { rows[pos] = r; tsel[pos] = t; }
+    }
+    __syncthreads();
+    if (tid == 0) base_s = base + tot;
+    __syncthreads();
+  }
+  const int n = base_s;
+  for (int i = n + tid; i < cap; i += 1024) { rows[i] = -1; tsel[i] = -1; }
+  if (tid == 0) *count = n;
+}
+
 struct MaxSum {
   float m, s;
   int idx;
@@ -177,7 +224,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     bf16_t* __restrict__ p_bf16, int64_t n, float lr,
                                                     float beta1, float beta2, float eps, float wd,
-                                                    float bc1, float bc2_sqrt, float gscale) {
+                                                    float bc1, float bc2_sqrt, float gscale, const float* __restrict__ hyper) {
+  if (hyper) {     // slam_adamw_step_dev: lr and the two bias corrections come from device memory (a captured step replays its arguments)
+    lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2];
+  }
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = g[i] * gscale;
     float pi = p[i];
@@ -271,6 +321,15 @@ extern "C" int slam_ce_targets(const int64_t* labels, int32_t* targets, int32_t*
   return 0;
 }
 
+extern "C" int slam_label_rows(const int32_t* targets, int64_t M, int64_t cap, int32_t* rows, int32_t* tsel, int32_t* inv, int32_t* count,
+                               void* stream) {
+  SLAM_CHECK_ARG(targets && rows && tsel && inv && count, "slam_label_rows: null pointer");
+  SLAM_CHECK_ARG(M > 0 && M < (1ll << 31) && cap > 0 && cap <= M, "slam_label_rows: need 0 < cap <= M < 2^31 (M=%ld cap=%ld)", (long)M, (long)cap);
+  hipLaunchKernelGGL(label_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, targets, (int)M, (int)cap, rows, tsel, inv, count);
+  SLAM_CHECK_LAUNCH("slam_label_rows");
+  return 0;
+}
+
 extern "C" int slam_ce_fwd_bwd(void* logits, int64_t ld, const int32_t* targets, const int32_t* n_valid,
                                float* row_loss, int32_t* row_correct, int64_t rows, int64_t V,
                                int write_grad, void* stream) {
@@ -302,8 +361,32 @@ extern "C" int slam_adamw_step(float* param, const float* grad, float* exp_avg, 
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, param, grad,
                      exp_avg, exp_avg_sq, (bf16_t*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1,
-                     sqrtf(bc2), grad_scale);
+                     sqrtf(bc2), grad_scale, (const float*)nullptr);
   SLAM_CHECK_LAUNCH("slam_adamw_step");
+  return 0;
+}
+
+// host-side helper: the three words slam_adamw_step_dev reads, formed exactly like slam_adamw_step forms them (float powf / sqrtf), so that
+// a captured step is bit-identical to the eager one; `out3` is HOST memory (the caller copies it to the device buffer)
+extern "C" int slam_adamw_hyper(float lr, float beta1, float beta2, int64_t step, float* out3) {
+  SLAM_CHECK_ARG(out3 && step >= 1, "slam_adamw_hyper: need a host buffer of 3 floats and step >= 1");
+  out3[0] = lr;
+  out3[1] = 1.0f - powf(beta1, (float)step);
+  out3[2] = sqrtf(1.0f - powf(beta2, (float)step));
+  return 0;
+}
+
+// the same kernel with lr, 1 - beta1^step and sqrt(1 - beta2^step) read from device memory (hyper[0..2], fp32): what a step captured in a
+// hipGraph needs -- the host (LambdaLR, the step counter) writes the three words before each replay
+extern "C" int slam_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16, int64_t n,
+                                   const float* hyper, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                   void* stream) {
+  SLAM_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && hyper && n > 0, "slam_adamw_step_dev: bad arguments");
+  int64_t g = cdiv64(n, 256);
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
+                     (bf16_t*)param_bf16, n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_scale, hyper);
+  SLAM_CHECK_LAUNCH("slam_adamw_step_dev");
   return 0;
 }
 
@@ -327,7 +410,8 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const bf16_t* __restrict
                                                         const bf16_t* __restrict__ X, int64_t ldx,
                                                         float* __restrict__ ws, int M, int R, int C, int rows_per_split,
                                                         unsigned thresh16, unsigned long long seed,
-                                                        unsigned long long offset) {
+                                                        unsigned long long offset, const unsigned long long* salt) {
+  seed = slam_salted(seed, salt);
   constexpr int SLD = NT == 1 ? 16 : (NT == 2 ? 48 : 80);   // dword strides 8 / 24 / 40: 4 consecutive rows -> disjoint banks
   constexpr int SCH = NT * 2;                               // 16-byte chunks per S row
   __shared__ __attribute__((aligned(16))) bf16_t xs[32 * GM_XLD];
@@ -454,7 +538,8 @@ __global__ __launch_bounds__((NT <= 2 ? 8 : 4) * 64, 2) void lora_a_fwd_kernel(c
                                                          const bf16_t* __restrict__ A, int64_t lda,
                                                          bf16_t* __restrict__ U, int64_t ldu, int M, int R, int Rpad, int K,
                                                          unsigned thresh16, float inv_keep, unsigned long long seed,
-                                                         unsigned long long offset) {
+                                                         unsigned long long offset, const unsigned long long* salt) {
+  seed = slam_salted(seed, salt);
   constexpr int NWV = NT <= 2 ? 8 : 4;   // waves splitting K (8 when the LDS reduction buffer allows: more loads in flight)
   __shared__ float red[NWV][2 * NT][256 + 4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -579,7 +664,9 @@ __device__ __forceinline__ void hop_swap_half32(float& a, float& b) { asm volati
 template <int KS>   // KS = R / 32 k-steps (R <= 64, zero-padded to a multiple of 32 by the caller's buffers)
 __global__ __launch_bounds__(256) void lora_hop_drop_kernel(const bf16_t* __restrict__ DU, int64_t lddu, const bf16_t* __restrict__ AT, int64_t ldat,
                                                             bf16_t* __restrict__ DX, int64_t lddx, int M, int K, int nrb, float inv_keep,
-                                                            unsigned thresh, unsigned long long seed, unsigned long long offset) {
+                                                            unsigned thresh, unsigned long long seed, unsigned long long offset,
+                                                            const unsigned long long* salt) {
+  seed = slam_salted(seed, salt);
   // workgroup = 256 columns of dx (one 64-column block per wave, its four fragments of A^T in registers) x 16-row blocks blockIdx.y, + gridDim.y, ...
   // (a wave per 16 ROWS of one 64-column block -- 128-byte row segments at an 8 KiB pitch -- held 3.8 TB/s whatever the mask cost);
   // the next row block's du and dx pieces are requested before the current one is computed.  (The first form -- a 64 x 256 tile per
@@ -680,7 +767,7 @@ extern "C" int slam_lora_a_fwd(const void* X, int64_t ldx, const void* A, int64_
   hipStream_t s = (hipStream_t)stream;
   const int nt = (int)cdiv64(R, 16);
 #define SLAM_LAUNCH_LA(NT_) hipLaunchKernelGGL(lora_a_fwd_kernel<NT_>, grid, dim3((NT_ <= 2 ? 8 : 4) * 64), 0, s, (const bf16_t*)X, ldx, (const bf16_t*)A, lda, \
-                                              (bf16_t*)U, ldu, (int)M, (int)R, (int)Rpad, (int)K, th, inv_keep, (unsigned long long)seed, (unsigned long long)offset)
+                                              (bf16_t*)U, ldu, (int)M, (int)R, (int)Rpad, (int)K, th, inv_keep, (unsigned long long)seed, (unsigned long long)offset, g_slam_drop_salt)
   if (nt == 1) SLAM_LAUNCH_LA(1);
   else if (nt == 2) SLAM_LAUNCH_LA(2);
   else if (nt == 3) SLAM_LAUNCH_LA(3);
@@ -705,10 +792,10 @@ extern "C" int slam_lora_hop_dropout(const void* DU, int64_t lddu, const void* A
   hipStream_t s = (hipStream_t)stream;
   if (R == 32)
     hipLaunchKernelGGL(lora_hop_drop_kernel<1>, grid, dim3(256), 0, s, (const bf16_t*)DU, lddu, (const bf16_t*)AT, ldat, (bf16_t*)DX, lddx, (int)M, (int)K,
-                       nrb, inv_keep, th, (unsigned long long)seed, (unsigned long long)offset);
+                       nrb, inv_keep, th, (unsigned long long)seed, (unsigned long long)offset, g_slam_drop_salt);
   else
     hipLaunchKernelGGL(lora_hop_drop_kernel<2>, grid, dim3(256), 0, s, (const bf16_t*)DU, lddu, (const bf16_t*)AT, ldat, (bf16_t*)DX, lddx, (int)M, (int)K,
-                       nrb, inv_keep, th, (unsigned long long)seed, (unsigned long long)offset);
+                       nrb, inv_keep, th, (unsigned long long)seed, (unsigned long long)offset, g_slam_drop_salt);
   SLAM_CHECK_LAUNCH("slam_lora_hop_dropout");
   return 0;
 }
@@ -736,7 +823,7 @@ extern "C" int slam_skinny_gram(const void* S, int64_t lds_, const void* X, int6
   dim3 grid((unsigned)cdiv64(C, GM_CB), (unsigned)nsplit);
   hipStream_t s = (hipStream_t)stream;
 #define SLAM_LAUNCH_GM(NT_) hipLaunchKernelGGL(gram_mfma_kernel<NT_>, grid, dim3(256), 0, s, (const bf16_t*)S, lds_, (const bf16_t*)X, ldx, \
-                                              workspace, (int)M, (int)R, (int)C, rows_per_split, th, (unsigned long long)seed, (unsigned long long)offset)
+                                              workspace, (int)M, (int)R, (int)C, rows_per_split, th, (unsigned long long)seed, (unsigned long long)offset, g_slam_drop_salt)
   if (R <= 16) SLAM_LAUNCH_GM(1);
   else if (R <= 32) SLAM_LAUNCH_GM(2);
   else SLAM_LAUNCH_GM(4);

@@ -20,6 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SLAM_HIP_LIB: another build of the same library (tools: A/B of two kernel versions inside one gpurun call); never a fallback
 LIB_PATH = os.environ.get("SLAM_HIP_LIB") or os.path.join(_HERE, "libslamhip.so")
 
+ABI_VERSION = 2      # what SIGNATURES below was written for; _load() refuses any other library (include/slam_hip.h, csrc/capi_core.hip)
 BF16, F32 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SWIGLU_BWD = 0, 1, 2, 3
 
@@ -27,6 +28,11 @@ P, I64, I32, F, U64 = c_void_p, c_int64, c_int, c_float, ctypes.c_uint64
 
 # name -> argtypes; every symbol of include/slam_hip.h (tests/test_capi_symbols.py checks the two agree)
 SIGNATURES = {
+    "slam_reset_tuning": [],
+    "slam_set_dropout_salt": [P],
+    "slam_label_rows": [P, I64, I64, P, P, P, P, P],
+    "slam_adamw_hyper": [F, F, F, I64, P],
+    "slam_adamw_step_dev": [P, P, P, P, P, I64, P, F, F, F, F, F, P],
     "slam_logmel_workspace_bytes": [I64],
     "slam_logmel_fwd": [P, I64, P, I64, P, P, P, I64, P, P, I64, I32, P],
     "slam_gemm_bf16_nt": [P, I64, P, I64, P, I64, I64, I64, I64, P, P, I64, I64, I32, F, I32, I32, P],
@@ -107,6 +113,10 @@ def _load():
     lib.slam_last_error.argtypes = []
     lib.slam_abi_version.restype = c_int
     lib.slam_target_arch.restype = c_char_p
+    got = lib.slam_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} reports C-ABI version {got}; this binding was written for version {ABI_VERSION} (argument lists differ "
+                          "between versions: rebuild the library from this tree's csrc/)")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so and the header ever diverge
         fn.argtypes = argtypes

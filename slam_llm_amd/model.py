@@ -28,7 +28,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, trace
 from .ops import ACT_GELU, ACT_NONE, ACT_RELU, round_up
 
 import os as _os
@@ -2083,6 +2083,11 @@ class HipLlamaLora(nn.Module):
         self.lora_p = float(cfg.get("lora_dropout", 0.0) or 0.0)
         self._drop_calls = 0
         self.lm_head_chunk_rows = None   # None: rows per lm_head/CE chunk derived from a 1 GB bf16 logits buffer (tests override)
+        # static upper bound on the rows that carry a label (None: the exact count is read back from the device each step): with it the
+        # training forward has no host round trip and static shapes -- train.GraphedTrainStep sets it; `last_label_count` (device int32)
+        # is the real count of the last forward, for the caller's overflow check
+        self.label_rows_cap = None
+        self.last_label_count = None
         self.layers = []
         targets = tuple(cfg.get("lora_targets") or ())
         r, alpha = cfg["lora_r"], cfg["lora_alpha"]
@@ -2186,19 +2191,25 @@ class HipLlamaLora(nn.Module):
             self._drop_calls += 1
             return (self.lora_p, seed, self._drop_calls << 40)
 
-        n_lab, rows, rows64, inv, prune = M, None, None, None, False
-        if targets is not None and train and not return_logits and label_count is not None:
-            label_count[0].synchronize()
-            n_host = int(label_count[1][0])
-            if 0 < n_host < M:      # labelled rows first, in their original order (host-known count: no sync on the index)
-                n_lab = n_host
-                rows64 = torch.argsort(targets < 0, stable=True)[:n_lab]
-                rows = rows64.to(torch.int32)
+        n_lab, rows, tsel_rows, inv, prune = M, None, None, None, False
+        self.last_label_count = None
+        if targets is not None and train and not return_logits and (label_count is not None or self.label_rows_cap):
+            # which rows carry a label: a device-side selection (slam_label_rows: row list, their targets, the inverse map, the count).
+            # Its size is either the caller's STATIC bound (`label_rows_cap`: no host round trip at all -- what a captured step needs;
+            # positions past the real count are zero rows with an ignored target, which change nothing) or the exact count read
+            # back through pinned memory (an event wait that completed long ago: the count left at the start of the forward).
+            cap = None
+            if self.label_rows_cap:
+                cap = min(int(self.label_rows_cap), M)
+            else:
+                label_count[0].synchronize()
+                n_host = int(label_count[1][0])
+                cap = n_host if 0 < n_host < M else None
+            if cap is not None:
+                n_lab = cap
+                rows, tsel_rows, inv, self.last_label_count = ops.label_rows(targets, cap)
                 LL = self.layers[-1]
                 prune = LAST_LAYER_LABEL_ROWS and not (use_drop and bool(LL.o.adapters or LL.gu.adapters or LL.down.adapters))
-                if prune:
-                    inv = torch.full((M,), -1, dtype=torch.int32, device=h.device)
-                    inv[rows64] = torch.arange(n_lab, dtype=torch.int32, device=h.device)
         for L in self.layers:
             x1 = L.qkv.new_input(M, for_forward=True)
             _, rstd1 = ops.rmsnorm_fwd(h, L.ln1, eps, out=x1[:, :d])
@@ -2240,7 +2251,7 @@ class HipLlamaLora(nn.Module):
         if targets is not None:
             hsel, tsel = hN, targets
             if rows is not None:
-                hsel, tsel = (hN if prune else ops.gather_rows(hN, rows)), targets.index_select(0, rows64)
+                hsel, tsel = (hN if prune else ops.gather_rows(hN, rows)), tsel_rows
             row_loss = torch.empty((n_lab,), dtype=torch.float32, device=h.device)
             row_ok = torch.empty((n_lab,), dtype=torch.int32, device=h.device)
             dhN = torch.empty((n_lab, d), dtype=torch.bfloat16, device=h.device) if train else None
@@ -2258,8 +2269,6 @@ class HipLlamaLora(nn.Module):
             out2 = ops.ce_finalize(row_loss, row_ok, n_valid)
             if train:
                 if rows is not None and not prune:    # back to the [M, d] layout: the rows without a label carry a zero gradient
-                    inv = torch.full((M,), -1, dtype=torch.int32, device=h.device)
-                    inv[rows64] = torch.arange(n_lab, dtype=torch.int32, device=h.device)
                     dhN = ops.gather_rows(dhN, inv)
                 stash["final"] = dict(h=h, rstdN=rstdN, dhN=dhN)
         elif return_logits:
@@ -2698,7 +2707,9 @@ class SlamHipModel(nn.Module):
         train = torch.is_grad_enabled() and labels is not None
         stash = {} if train else None
         early_targets = label_count = None
-        if train and LM_HEAD_LABEL_ROWS:
+        if train and LM_HEAD_LABEL_ROWS and self.llm.label_rows_cap:
+            early_targets = ops.ce_targets(labels.contiguous())     # static bound: nothing goes to the host
+        elif train and LM_HEAD_LABEL_ROWS:
             # the shifted targets and their count now, the count on its way to pinned host memory: the LLM head reads it ~a forward later
             early_targets = ops.ce_targets(labels.contiguous())
             if getattr(self, "_label_count_host", None) is None:
@@ -2726,10 +2737,8 @@ class SlamHipModel(nn.Module):
                 nvi = [int(n) for n in nv]
                 enc = self.encoder.forward_train(audio.float(), stash, nvi) if hub_train else self.encoder.forward_wav(audio.float(), nvi)
                 keep = self.encoder.valid_frames(audio.shape[1], nv)
-                hub_pad = torch.zeros((len(keep), enc.shape[1]), dtype=torch.float32)
-                for b_, kf in enumerate(keep):
-                    hub_pad[b_, kf:] = 1.0     # fairseq's frame padding mask: 1 = PADDING
-                hub_pad = hub_pad.to(dev, non_blocking=True)
+                # fairseq's frame padding mask: 1 = PADDING (frames kf .. of clip b)
+                hub_pad = (torch.arange(enc.shape[1])[None, :] >= torch.tensor(keep)[:, None]).to(torch.float32).to(dev, non_blocking=True)
             else:
                 enc = self.encoder.forward_train(audio.float(), stash) if hub_train else self.encoder.forward_wav(audio.float())
         else:
@@ -2738,7 +2747,8 @@ class SlamHipModel(nn.Module):
                     raise RuntimeError("batch carries neither audio_mel nor audio")
                 # GPU log-mel front end (replaces the CPU DataLoader mel of speech_dataset.py:101-103)
                 if self.cfg.get("pad_or_trim", True):   # reference default (aispeech_asr_config.py:106; unconditional in speech_dataset.py:101)
-                    audio_mel = ops.logmel(audio.float(), self.cfg["n_mels"], n_valid=kwargs.get("audio_len", None))
+                    with trace.phase("mel"):
+                        audio_mel = ops.logmel(audio.float(), self.cfg["n_mels"], n_valid=kwargs.get("audio_len", None))
                 else:                                   # ragged clips: mel over each clip's own length, zero padded to the batch max
                     alen = kwargs.get("audio_len", None)
                     nmax = min(480000, round_up(int(audio.shape[1]), 160))
@@ -2749,7 +2759,8 @@ class SlamHipModel(nn.Module):
                 enc = None
             else:
                 mel_c = audio_mel.float().contiguous()
-                enc = self.encoder.forward_train(mel_c, stash) if (self.train_encoder and train) else self.encoder.forward_btc(mel_c)
+                with trace.phase("encoder"):
+                    enc = self.encoder.forward_train(mel_c, stash) if (self.train_encoder and train) else self.encoder.forward_btc(mel_c)
         if enc is None:
             pass
         elif self.projector_name == "q-former":
@@ -2766,9 +2777,11 @@ class SlamHipModel(nn.Module):
                 # padded clip cross-attends to its padding frames only; a clip without padding has an all-zero mask, which HF
                 # turns into one constant additive bias = ordinary attention over all frames.
                 pmask = torch.where(hub_pad.sum(1, keepdim=True) > 0, hub_pad, torch.ones_like(hub_pad))
-            proj = self.encoder_projector.forward_hip(enc, pmask, stash)
+            with trace.phase("projector"):
+                proj = self.encoder_projector.forward_hip(enc, pmask, stash)
         else:
-            proj = self.encoder_projector.forward_hip(enc, stash)  # [B, Ta, dl]
+            with trace.phase("projector"):
+                proj = self.encoder_projector.forward_hip(enc, stash)  # [B, Ta, dl]
         Ta = proj.shape[1]
         if modality_mask is None:
             raise RuntimeError("modality_mask is required (speech recipes always provide it)")
@@ -2799,8 +2812,9 @@ class SlamHipModel(nn.Module):
             pack_idx32 = pack_idx.to(torch.int32)
             h_packed = ops.gather_rows(embeds, pack_idx32)
             t_packed = targets.index_select(0, pack_idx).contiguous() if targets is not None else None
-            out2, logits_p, lstash = self.llm.forward_hip(h_packed, 1, Mp, None, t_packed, n_valid, train, want_logits,
-                                                          packed=(pos, lo, hi, T), label_count=label_count)
+            with trace.phase("llm_fwd"):
+                out2, logits_p, lstash = self.llm.forward_hip(h_packed, 1, Mp, None, t_packed, n_valid, train, want_logits,
+                                                              packed=(pos, lo, hi, T), label_count=label_count)
             logits = None
             if logits_p is not None:   # back to the padded [B*T, V] layout (pad rows zero)
                 logits = torch.zeros((B * T, logits_p.shape[1]), dtype=logits_p.dtype, device=dev)
@@ -2809,7 +2823,8 @@ class SlamHipModel(nn.Module):
             Tp = round_up(T, 64)
             key_mask = torch.zeros((B, Tp), dtype=torch.uint8, device=dev)
             key_mask[:, :T] = attention_mask.to(torch.uint8)
-            out2, logits, lstash = self.llm.forward_hip(embeds, B, T, key_mask, targets, n_valid, train, want_logits, label_count=label_count)
+            with trace.phase("llm_fwd"):
+                out2, logits, lstash = self.llm.forward_hip(embeds, B, T, key_mask, targets, n_valid, train, want_logits, label_count=label_count)
         loss = acc = None
         if out2 is not None:
             loss_val, acc = out2[0], out2[1]
@@ -2885,8 +2900,8 @@ class SlamHipModel(nn.Module):
             # adjoint of the window gather below: packed encoder row r = win[i] + j is row i * k + j of dL/d(xp) viewed as [sum Ta * k, d];
             # the t2 % k last frames of a clip belong to no window (the reference's view(B, T // k, k * d) drops them): zero gradient
             unwin = torch.full((sum(T2),), -1, dtype=torch.int32)
-            for i, r0 in enumerate(torch.cat(win).tolist()):
-                unwin[r0: r0 + k] = torch.arange(i * k, (i + 1) * k, dtype=torch.int32)
+            w0 = torch.cat(win).to(torch.int64)                               # one scatter for all windows (was a slice assignment per window)
+            unwin[(w0[:, None] + torch.arange(k)).flatten()] = torch.arange(w0.numel() * k, dtype=torch.int32)
             stash["ragged_unwindow"] = unwin.to(dev, non_blocking=True)
         win = torch.cat(win).to(dev, non_blocking=True)
         inv = inv.view(-1).to(dev, non_blocking=True)
@@ -2918,7 +2933,8 @@ class SlamHipModel(nn.Module):
             if begin is not None:
                 begin()
         gs = grad_out.reshape(1).to(torch.float32).contiguous()
-        dh0 = self.llm.backward_hip(stash, gs, accumulate, on_layer_done=self._on_layer_done)
+        with trace.phase("llm_bwd"):
+            dh0 = self.llm.backward_hip(stash, gs, accumulate, on_layer_done=self._on_layer_done)
         if stash.get("pack_idx") is not None:   # packed rows -> padded [B*T, d] layout (pad rows carry no gradient)
             n_rows = stash["batch_B"] * stash["batch_T"]
             inv = torch.full((n_rows,), -1, dtype=torch.int32, device=dh0.device)
@@ -2927,13 +2943,15 @@ class SlamHipModel(nn.Module):
         dproj = ops.embed_splice_bwd(stash["spans"], dh0, stash["batch_B"], stash["batch_T"], stash["Ta"], self.cfg["llm_dim"])
         if stash.get("proj_valid_rows") is not None:   # ragged encoder: the projector ran on the clips' own rows only
             dproj = ops.gather_rows(dproj, stash["proj_valid_rows"])
-        d_enc = self.encoder_projector.backward_hip(dproj, stash, accumulate)
+        with trace.phase("projector_bwd"):
+            d_enc = self.encoder_projector.backward_hip(dproj, stash, accumulate)
         if self.train_encoder:
             if stash.get("ragged_unwindow") is not None:      # ragged encoder, stacked-row projectors: dL/d(k-frame windows) -> packed encoder rows
                 d_enc = ops.gather_rows(d_enc.reshape(-1, self.cfg["enc_dim"]), stash.pop("ragged_unwindow"))
             elif stash.get("ragged_enc_rows") is not None:    # ragged encoder, Q-Former: padded [B * T2max, d] -> packed rows
                 d_enc = ops.gather_rows(d_enc.reshape(-1, self.cfg["enc_dim"]), stash.pop("ragged_enc_rows"))
-            self.encoder.backward_hip(d_enc, stash, accumulate)
+            with trace.phase("encoder_bwd"):
+                self.encoder.backward_hip(d_enc, stash, accumulate)
         if st.pure_bf16:       # gradients leave in the parameters' dtype: one rounding of the fp32 sums per backward
             if as_autograd:
                 fresh = torch.empty_like(st.grad_lp)
@@ -2949,10 +2967,8 @@ class SlamHipModel(nn.Module):
             hk.on_prefix(st.size) if hasattr(hk, "on_prefix") else hk(st.size)
         return ()
 
-    def _on_layer_done(self, li: int):
-        if not self.grad_hooks:
-            return
-        # LoRA grads of layers >= li are final: they occupy the prefix of the flat buffer (reserved last layer first)
+    def layer_prefix_ends(self) -> Dict[int, int]:
+        """{LLM layer index: end offset of its LoRA gradients in the flat buffer} (reserved last layer first: a prefix per layer)"""
         ends = getattr(self, "_layer_prefix_end", None)
         if ends is None:
             ends = {}
@@ -2961,6 +2977,26 @@ class SlamHipModel(nn.Module):
                     k = int(n.split(".layers.")[1].split(".")[0])
                     ends[k] = max(ends.get(k, 0), off + round_up(cnt, 64))
             self._layer_prefix_end = ends
+        return ends
+
+    def prefix_plan(self) -> List[int]:
+        """the sequence of `on_prefix(end)` announcements one backward makes (layers last to first, then the whole buffer): what an
+        exhausted rank replays over a zero buffer (train.GradSync.shadow_backward, the `Join` policy)"""
+        ends = self.layer_prefix_ends()
+        return [ends[li] for li in reversed(range(len(self.llm.layers))) if li in ends] + [self.store.size]
+
+    def attach_grad_views(self):
+        """`.grad` of every trainable parameter = its view of the flat gradient buffer (what a backward leaves behind)"""
+        st = self.store
+        for name, p in st.params.items():
+            if p.grad is None:
+                p.grad = st.grad_lp_view(name) if st.pure_bf16 else st.grad_view(name)
+
+    def _on_layer_done(self, li: int):
+        if not self.grad_hooks:
+            return
+        # LoRA grads of layers >= li are final: they occupy the prefix of the flat buffer (reserved last layer first)
+        ends = self.layer_prefix_ends()
         end = ends.get(li)
         if end is None:
             return
@@ -3077,9 +3113,10 @@ class SlamAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         st = self.model.store
         self._step += 1
-        ops.adamw_step(st.flat, self._flat_grad(), self.exp_avg, self.exp_avg_sq, st.flat_bf16, float(g["lr"]), g["betas"][0],
-                       g["betas"][1], g["eps"], g["weight_decay"], self._step)
-        self.model.refresh_derived()
+        with trace.phase("optimizer"):
+            ops.adamw_step(st.flat, self._flat_grad(), self.exp_avg, self.exp_avg_sq, st.flat_bf16, float(g["lr"]), g["betas"][0],
+                           g["betas"][1], g["eps"], g["weight_decay"], self._step)
+            self.model.refresh_derived()
         self.model._always_refresh = False
 
     def zero_grad(self, set_to_none: bool = True):

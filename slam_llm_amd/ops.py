@@ -153,7 +153,6 @@ def gemm_skinny(a, b, out, residual=None, b2=None, swiglu=False):
 _GEMM_CFG = 0
 _GEMM_NAMES = {1: "gemm_nt_kernel<128,128,2,2>", 11: "gemm_nt_pipe_kernel<128,128,2,2,1>", 2: "gemm_nt_kernel<256,128,4,2>", 3: "gemm_nt_kernel<128,64,2,2>",
                4: "gemm_nt_kernel<256,256,2,4>", 6: "gemm_nt_pipe_kernel<256,256,2,4,1>", 7: "gemm_nt_persist2_kernel<256,256,2,4>",
-               8: "gemm_nt_p3_kernel<128,256> (two workgroups per CU)",
                12: "gemm_nt_w4_kernel<256,256,false,0>"}
 
 
@@ -221,11 +220,8 @@ def gemm_set_config(cfg: int):
 
 ATTN_HEAVY_FIRST = os.environ.get("SLAM_ATTN_HEAVY", "1") != "0"     # A/B: SLAM_ATTN_HEAVY=0 python bench.py (id order of causal attention workgroups)
 ATTN_QS = os.environ.get("SLAM_ATTN_QS", "1") != "0"                 # A/B: SLAM_ATTN_QS=0 (general softmax also for the LSE-less mask-free launches with a pre-scaled Q)
-ATTN_DKDV32 = os.environ.get("SLAM_ATTN_DKDV32", "0") != "0"         # A/B: SLAM_ATTN_DKDV32=1 (4 waves x 32 keys in the D = 128 dK / dV kernel: bit-identical, slower)
 if not ATTN_QS:
     call("slam_attn_set_fwd_qf", 60)
-if ATTN_DKDV32:
-    call("slam_attn_set_fwd_qf", 71)
 if not ATTN_HEAVY_FIRST:
     call("slam_attn_set_fwd_qf", 50)
 _ENV_DEFAULTS = dict(_GEMM_BIG, sk2=SK2_AUTO, ts=TS_AUTO, splitk=os.environ.get("SLAM_GEMM_SPLITK", "off"))
@@ -237,6 +233,8 @@ def reset_tuning():
     before every GPU test so that a test which dies between `gemm_set_config(x)` and its own restore cannot change what the tests
     behind it measure (VERDICT r4 weak #1c)."""
     d = _ENV_DEFAULTS
+    call("slam_reset_tuning")    # the library's own defaults (one place: csrc), then this process's environment overrides on top
+    call("slam_set_dropout_salt", None)
     gemm_set_config(0)
     gemm_set_config(100 + d["big"])
     gemm_set_config(200 + d["shortk"])
@@ -250,7 +248,7 @@ def reset_tuning():
     call("slam_gemm_set_group_m", 8)
     call("slam_attn_set_bwd_variant", 0)
     # auto fragments, DMA tiles, XCD-aware numbering, mask-free instantiation, transposing reads, heaviest block first, pre-scaled Q in LSE-less launches
-    for knob in (0, 11, 21, 31, 41, 51 if ATTN_HEAVY_FIRST else 50, 61 if ATTN_QS else 60, 71 if ATTN_DKDV32 else 70):   # ..., 32 keys per wave in the D = 128 dK / dV kernel
+    for knob in (0, 11, 21, 31, 41, 51 if ATTN_HEAVY_FIRST else 50, 61 if ATTN_QS else 60):
         call("slam_attn_set_fwd_qf", knob)
 
 
@@ -740,6 +738,21 @@ def ce_targets(labels, ignore_index=-100):
     return tgt, nv
 
 
+def label_rows(targets: torch.Tensor, cap: int):
+    """device-side selection of the rows that carry a label (targets >= 0), in row order: returns (rows int32 [cap], tsel int32 [cap],
+    inv int32 [M], count int32 [1]); positions >= count hold -1 (gather_rows turns those into zero rows, the CE kernel ignores a
+    target of -1).  No host round trip: `cap` is the caller's static bound (the exact count when the host knows it)."""
+    M = targets.numel()
+    assert targets.dtype == torch.int32 and 0 < cap <= M
+    dev = targets.device
+    rows = torch.empty((cap,), dtype=torch.int32, device=dev)
+    tsel = torch.empty((cap,), dtype=torch.int32, device=dev)
+    inv = torch.empty((M,), dtype=torch.int32, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    call("slam_label_rows", _p(targets), M, cap, _p(rows), _p(tsel), _p(inv), _p(cnt), _s())
+    return rows, tsel, inv, cnt
+
+
 def ce_fwd_bwd(logits2d, targets, n_valid, row_loss, row_correct, write_grad=True):
     rows, V = logits2d.shape
     call("slam_ce_fwd_bwd", _p(logits2d), _ld(logits2d), _p(targets), _p(n_valid), _p(row_loss),
@@ -755,6 +768,26 @@ def ce_finalize(row_loss, row_correct, n_valid):
 def adamw_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     call("slam_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), lr, beta1, beta2, eps, wd, step,
          grad_scale, _s())
+
+
+def adamw_step_dev(p, g, m, v, p_bf16, hyper, beta1, beta2, eps, wd, grad_scale=1.0):
+    """adamw_step with lr, 1 - beta1^step, sqrt(1 - beta2^step) read from the device tensor `hyper` (fp32 [3]): captured steps"""
+    assert hyper.dtype == torch.float32 and hyper.numel() >= 3 and hyper.is_cuda
+    call("slam_adamw_step_dev", _p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), _p(hyper), beta1, beta2, eps, wd, grad_scale, _s())
+
+
+def adamw_hyper(lr, beta1, beta2, step, out_host: torch.Tensor):
+    """fills the pinned host tensor `out_host` (fp32 [3]) with lr, 1 - beta1^step, sqrt(1 - beta2^step) as slam_adamw_step computes them"""
+    assert out_host.dtype == torch.float32 and out_host.numel() >= 3 and not out_host.is_cuda
+    call("slam_adamw_hyper", float(lr), float(beta1), float(beta2), int(step), ctypes.c_void_p(out_host.data_ptr()))
+
+
+def set_dropout_salt(word: Optional[torch.Tensor]):
+    """register (or, with None, detach) the device-resident int64 word every dropout-aware kernel XORs into its seed -- see
+    include/slam_hip.h:slam_set_dropout_salt.  The caller keeps the tensor alive while it is registered."""
+    if word is not None:
+        assert word.dtype == torch.int64 and word.numel() == 1 and word.is_cuda
+    call("slam_set_dropout_salt", _p(word) if word is not None else None)
 
 
 def adamw_anyprecision_step(p, g, m_bf16, v_bf16, comp_bf16, p_bf16, lr, beta1, beta2, eps, wd, step, params_are_bf16=False):

@@ -138,6 +138,8 @@ class GradSync:
 
     def finish(self):
         """flush the tail and wait for all buckets (call before optimizer.step())."""
+        from . import trace
+        trace.push("allreduce")
         ev = None
         if self.time_finish and self.flat.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -149,6 +151,20 @@ class GradSync:
             ev[1].record()
             self._finish_events = getattr(self, "_finish_events", [])
             self._finish_events.append(ev)
+        trace.pop()
+
+    def shadow_backward(self, prefix_ends):
+        """`Join` for the fast path (reference: `with Join([model])`, utils/train_utils.py:91; torch's default
+        `divide_by_initial_world_size=True`): a rank whose shard is exhausted stands in for one armed backward by posting the SAME
+        sequence of prefix all-reduces over a ZERO gradient buffer, so the ranks that still have data finish their step instead of
+        hanging in a collective nobody else joins.  `prefix_ends` = the prefix sequence a real backward announces
+        (`SlamHipModel.prefix_plan()`: the layers' LoRA prefixes, last layer first, then the whole buffer).  The buffer then holds the
+        mean over ALL ranks of the active ranks' gradients (the divisor stays the world size, like DDP's Join), so the shadowing rank
+        can apply the same optimizer step and its replica stays in sync.  Follow with finish()."""
+        self.on_backward_begin()
+        self.flat.zero_()
+        for end in prefix_ends:
+            self.on_prefix(int(end))
 
     def exposed_ms_per_step(self) -> Optional[float]:
         """mean HIP-event time of finish() over the calls timed so far (time_finish=True): tail launch + waits on the compute
@@ -170,7 +186,18 @@ def all_ranks_have_data(has_batch: bool, device) -> bool:
     return bool(flag.item())
 
 
-def train_step(model, batch: dict, optimizer, scheduler=None, grad_sync: Optional[GradSync] = None,
+def ranks_with_data(has_batch: bool, device) -> int:
+    """how many ranks still hold a batch this iteration (one SUM all-reduce of a flag).  With it a loop can follow either policy for
+    uneven shards: stop as soon as the number drops below the world size (`all_ranks_have_data`, this build's default), or keep going
+    until it is 0 with the exhausted ranks shadowing (`train_step(model, None, ...)`, the reference's DDP `Join`, train_utils.py:91)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1 if has_batch else 0
+    flag = torch.tensor([1 if has_batch else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+    return int(flag.item())
+
+
+def train_step(model, batch: Optional[dict], optimizer, scheduler=None, grad_sync: Optional[GradSync] = None,
                gradient_accumulation_steps: int = 1, do_step: bool = True, scaler=None):
     """One iteration of train_utils.py:112-169.  Returns (loss, acc) as device tensors (no host sync).
     With gradient accumulation the caller passes do_step=False on all but the last micro-step (the reference's
@@ -179,6 +206,20 @@ def train_step(model, batch: dict, optimizer, scheduler=None, grad_sync: Optiona
     forward under `torch.cuda.amp.autocast`, `scaler.scale(loss).backward()`, `scaler.step(optimizer)`, `scaler.update()`.
     The HIP path computes in bf16 with fp32 masters whatever the autocast state says; the scale factor reaches the kernels as the
     backward's incoming gradient (a power of two: exact in bf16 and fp32) and GradScaler unscales the flat gradient views in place."""
+    if batch is None:
+        # this rank's shard is exhausted while others still train (the `Join` policy, see GradSync.shadow_backward): zero gradients
+        # through the same collectives, then the same optimizer step on the averaged buffer -- the replicas stay identical
+        if grad_sync is None or scaler is not None or gradient_accumulation_steps != 1 or not do_step:
+            raise ValueError("train_step(batch=None) shadows one plain optimizer step of the GradSync fast path (no GradScaler, no accumulation)")
+        grad_sync.arm(True)
+        grad_sync.shadow_backward(model.prefix_plan())
+        grad_sync.finish()
+        model.attach_grad_views()
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+        optimizer.zero_grad()
+        return None, None
     if grad_sync is not None:
         grad_sync.arm(do_step)   # one reduction of the accumulated buffer instead of one per micro-step (same result)
     if scaler is not None:
@@ -205,6 +246,138 @@ def train_step(model, batch: dict, optimizer, scheduler=None, grad_sync: Optiona
             scheduler.step()
         optimizer.zero_grad()
     return loss.detach(), acc
+
+
+class GraphedTrainStep:
+    """`train_step` captured ONCE in a HIP graph (torch.cuda.CUDAGraph) and replayed: one graph launch instead of the ~1 200 (C3) to
+    ~2 300 (C4) kernel launches of the loop body of utils/train_utils.py:112-169.  The launch-bound BASELINE configurations (C1: 69 % of
+    the step idle between kernels, C4: ~30 %) are where it pays; the result is bit-identical to the eager step (same kernels, same
+    arguments, same order -- tests/test_graph_gpu.py).
+
+    What had to leave the host for this (round 6):
+      * the label-row selection runs on the device against a STATIC bound (`label_rows_cap`: HipLlamaLora.label_rows_cap; default = the
+        first batch's own count rounded up to a multiple of 64; batches are checked against it one step late, without a sync);
+      * the fused AdamW reads lr and the bias corrections from device memory (`slam_adamw_step_dev`): LambdaLR stays a host object,
+        its value is written into a 3-float device buffer before every replay;
+      * LoRA / Q-Former dropout masks: every dropout-aware kernel XORs a device-resident word into its seed (`slam_set_dropout_salt`),
+        and the captured step bumps that word at its end, so each replay draws fresh masks.
+    Scope: fixed-shape batches (the padded layouts; `varlen` / `varlen_encoder` batches have data-dependent shapes), SlamAdamW, no
+    GradScaler, world size 1 or an un-armed GradSync -- anything else runs the eager `train_step` (same semantics, `self.eager_steps`
+    counts them).  The first `warmup` calls also run eagerly (they are real training steps: workspaces, tables and LDS attributes
+    of the library are set up by them, outside the capture)."""
+
+    SALT_STEP = 0x9E3779B97F4A7C15 - (1 << 64)      # the golden-ratio increment as a signed int64
+
+    def __init__(self, model, optimizer, scheduler=None, label_rows_cap: Optional[int] = None, warmup: int = 2, grad_sync: Optional[GradSync] = None):
+        from .model import SlamAdamW
+        if type(optimizer) is not SlamAdamW:
+            raise TypeError("GraphedTrainStep captures the fused SlamAdamW step (device-side lr / bias corrections)")
+        self.model, self.opt, self.sched, self.gsync = model, optimizer, scheduler, grad_sync
+        self.cap_arg, self.warmup = label_rows_cap, int(warmup)
+        self.graph = None
+        self.key = None
+        self.static = None
+        self.out = None
+        self.calls = self.eager_steps = self.replays = 0
+        dev = model.device_
+        self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+        self.salt = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._count_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._count_ev = None
+
+    # ---- helpers ----
+    @staticmethod
+    def _signature(batch: dict):
+        return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in batch.items() if isinstance(v, torch.Tensor)))
+
+    def _capturable(self, batch: dict) -> bool:
+        m = self.model
+        if m.cfg.get("varlen", False) or m.cfg.get("varlen_encoder", False) or m.autograd_params or m.store.pure_bf16:
+            return False
+        if self.gsync is not None and (self.gsync.world > 1 or self.gsync.force):
+            return False        # (collectives stay outside the graph: the eager step overlaps them with the backward)
+        if any(not isinstance(v, torch.Tensor) for v in batch.values()):
+            return False        # python-side batch entries (length lists of the ragged collators)
+        from . import ops
+        return ops.TIMER is None
+
+    def _write_hyper(self):
+        g = self.opt.param_groups[0]
+        step = self.opt._step + 1
+        from . import ops
+        b1, b2 = g["betas"]
+        ops.adamw_hyper(g["lr"], b1, b2, step, self.hyper_host)      # (formed in C exactly like the eager kernel's arguments)
+        self.hyper.copy_(self.hyper_host, non_blocking=True)
+
+    def _check_label_cap(self):
+        """the count of the PREVIOUS replay (copied to pinned memory behind it): a batch with more labelled rows than the bound lost
+        rows -- that step is wrong and says so, one step late, instead of costing every step a sync"""
+        if self._count_ev is not None and self._count_ev.query():
+            n, cap = int(self._count_host[0]), int(self.model.llm.label_rows_cap)
+            self._count_ev = None
+            if n > cap:
+                raise RuntimeError(f"GraphedTrainStep: a batch carried {n} labelled rows, more than label_rows_cap = {cap}: the previous step dropped "
+                                   "rows; construct GraphedTrainStep(label_rows_cap=...) with the collator's bound (B x longest answer)")
+
+    def _body(self):
+        from . import ops
+        m = self.model
+        outputs, acc = m(**self.static)
+        loss = outputs.loss
+        loss.backward()
+        st, g = m.store, self.opt.param_groups[0]
+        ops.adamw_step_dev(st.flat, self.opt._flat_grad(), self.opt.exp_avg, self.opt.exp_avg_sq, st.flat_bf16, self.hyper,
+                           g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"])
+        m.refresh_derived()
+        m._always_refresh = False
+        self.opt.zero_grad()
+        self.salt.add_(self.SALT_STEP)
+        return loss.detach(), acc
+
+    # ---- the step ----
+    def __call__(self, batch: dict):
+        from . import ops
+        self.calls += 1
+        self._check_label_cap()
+        m = self.model
+        if self.calls <= self.warmup or not self._capturable(batch) or (self.key is not None and self._signature(batch) != self.key):
+            if m.llm.label_rows_cap is None and self.cap_arg:
+                m.llm.label_rows_cap = int(self.cap_arg)
+            self.eager_steps += 1
+            return train_step(m, batch, self.opt, self.sched, self.gsync)
+        if self.graph is None:
+            if m.llm.label_rows_cap is None:
+                if self.cap_arg:
+                    m.llm.label_rows_cap = int(self.cap_arg)
+                elif batch.get("labels") is not None:      # (one sync, once: the capture batch's own count, rounded up)
+                    n = int((batch["labels"][:, 1:] >= 0).sum())
+                    m.llm.label_rows_cap = max(64, -(-n // 64) * 64)
+            self.key = self._signature(batch)
+            self.static = {k: v.clone() for k, v in batch.items()}
+            self._write_hyper()
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            ops.set_dropout_salt(self.salt)
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.out = self._body()
+            finally:
+                ops.set_dropout_salt(None)       # (the pointer is a kernel argument of the captured launches; eager code keeps its plain seeds)
+        else:
+            for k, v in batch.items():
+                self.static[k].copy_(v, non_blocking=True)
+            self._write_hyper()
+        self.graph.replay()
+        self.replays += 1
+        self.opt._step += 1
+        if self.sched is not None:
+            self.sched.step()
+        if m.llm.last_label_count is not None:
+            self._count_host.copy_(m.llm.last_label_count, non_blocking=True)
+            self._count_ev = torch.cuda.Event()
+            self._count_ev.record()
+        return self.out
 
 
 def lr_lambda(step: int, warmup_steps: int, total_steps: int) -> float:

@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 # FIRST -- every kernel against its fp32 reference, then the module-level fixtures, the boundary, the multi-process paths, and the
 # whole-step geometry / headline comparisons last.  One model-level assert can then no longer hide the per-kernel parity tests.
 _FILE_ORDER = ["test_capi_symbols", "test_build_invariants", "test_oracle_golden", "test_host_logic", "test_plugin_boundary", "test_dist_gloo",
-               "test_ops_gpu", "test_determinism_gpu", "test_model_gpu", "test_boundary_gpu", "test_amp_rccl_gpu", "test_dist_gpu",
+               "test_ops_gpu", "test_determinism_gpu", "test_graph_gpu", "test_model_gpu", "test_boundary_gpu", "test_amp_rccl_gpu", "test_dist_gpu",
                "test_geometry_gpu", "test_ragged_hbm_gpu", "test_headline_gpu"]
 
 

@@ -42,6 +42,13 @@ FLOORS = dict(
     unfrozen_gate=0.983,        # 8.2e-3: grep_linear.weight / relative_attention_bias (cancelling sums of dS)
 )
 
+# the deviation (1 - cosine) measured on MI355X behind each relaxed floor: _check_grads() warns (drift alarm, never a failure) when the worst
+# tensor of a run leaves [0.5, 1.5] x this value -- a 1.9x regression no longer passes silently under a 2x-wide floor
+EXPECT = dict(
+    c1_full_depth=1.59e-3, c3_full_depth=5.6e-3, unfrozen_fixture=1.2e-3, unfrozen=1.96e-3, unfrozen_fe=3.5e-3,
+    unfrozen_wavlm_base=5.2e-3, unfrozen_gate=8.2e-3,
+)
+
 MARGINS = []      # (test id, what, measured deviation, allowed deviation): written by tests/conftest.py when SLAM_TEST_MARGINS is set
 
 
@@ -53,6 +60,72 @@ def floor_check(cs, floor, what=""):
     cs, floor = float(cs), float(floor)
     MARGINS.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], str(what)[:120], 1.0 - cs, 1.0 - floor))
     assert cs >= floor, f"{what}: cosine {cs} below the floor {floor}"
+
+
+# "Expected" deviations (1 - cosine) behind the relaxed floors: the value measured on MI355X when the floor was set.  floor_check()
+# raises a WARNING (not a failure) when a measured deviation leaves [0.5, 1.5] x its expected value: a drift alarm that fires long
+# before the 2x-wide floor does.  Keys: substrings of the `what` argument.
+EXPECTED = {}
+
+
+def expect(key, deviation):
+    EXPECTED[key] = float(deviation)
+
+
+def drift_check(what, measured, expected, lo=0.5, hi=1.5):
+    """warn (never fail) when `measured` leaves [lo, hi] x `expected`; returns True when inside"""
+    import warnings
+    ok = lo * expected <= measured <= hi * expected
+    if not ok:
+        warnings.warn(f"DRIFT {what}: measured deviation {measured:.3e} vs expected {expected:.3e} (alarm band x{lo}..x{hi})")
+    return ok
+
+
+def check_logits(hip_logits, ref_logits, attention_mask, labels, what, atol=6e-2, rtol=2e-2, other_stride=5, min_top1=None):
+    """VERDICT r5 missing #1 / SURVEY 8(c) "logits compared on a sampled subset": the every-row eval forward's logits
+    (`outputs.logits`, [B, T, V] bf16 on the device) against the oracle's ([B, T, V] fp32, CPU) on EVERY row that carries a label
+    (shifted: row t predicts labels[t + 1]) plus every `other_stride`-th other non-pad row, all V columns:
+      * |hip - ref| <= atol + rtol * max|ref|  (the bf16 bound the reference fixtures use, tests/test_model_gpu.py:63-71);
+      * top-1 on the label rows: the oracle's arg-max token must be HIP's arg-max or within the same bound of it (two near-tied logits
+        may swap under bf16), and the plain agreement rate is returned (asserted >= min_top1 when given).
+    Pad rows are garbage by design and skipped.  Returns a dict of the measured numbers."""
+    import torch
+    B, T, V = ref_logits.shape
+    assert tuple(hip_logits.shape) == (B, T, V), (tuple(hip_logits.shape), (B, T, V))
+    am = attention_mask.bool().reshape(-1).cpu()
+    lab = torch.nn.functional.pad(labels, (0, 1), value=-100)[:, 1:].reshape(-1).cpu() != -100
+    lab &= am
+    other = am & ~lab
+    idx_other = torch.nonzero(other).flatten()[::other_stride]
+    idx_lab = torch.nonzero(lab).flatten()
+    rows = torch.cat([idx_lab, idx_other])
+    dev = hip_logits.device
+    ref = ref_logits.reshape(B * T, V)[rows].to(dev, torch.float32)
+    got = hip_logits.reshape(B * T, V)[rows.to(dev)].float()
+    assert bool(torch.isfinite(got).all()), f"{what}: non-finite logits on valid rows"
+    err = (got - ref).abs()
+    bound = atol + rtol * float(ref.abs().max())
+    worst = float(err.max())
+    rms = float((err.double() ** 2).mean().sqrt())
+    assert worst <= bound, f"{what}: logits max |err| {worst:.4f} > {bound:.4f} (rms {rms:.4f}) over {rows.numel()} rows x {V}"
+    nl = idx_lab.numel()
+    stats = dict(rows=int(rows.numel()), label_rows=int(nl), max_err=worst, rms_err=rms, bound=bound, ref_absmax=float(ref.abs().max()))
+    if nl:
+        r_top = ref[:nl].argmax(-1)
+        g_top = got[:nl].argmax(-1)
+        agree = float((r_top == g_top).float().mean())
+        # the oracle's winner must be within the bound of HIP's maximum (a swap of two near-tied logits is not an error)
+        gap = got[:nl].max(-1).values - got[:nl].gather(1, r_top[:, None]).squeeze(1)
+        assert float(gap.max()) <= 2 * bound, f"{what}: oracle's top-1 token sits {float(gap.max()):.4f} below HIP's maximum on a label row"
+        stats.update(top1_agree=agree, top1_gap_max=float(gap.max()))
+        if min_top1 is not None:
+            assert agree >= min_top1, f"{what}: top-1 agreement {agree:.4f} < {min_top1}"
+    print(f"logits {what}: {stats}")
+    rep = os.environ.get("SLAM_TEST_REPORT")
+    if rep:
+        with open(rep + ".logits.tsv", "a") as f:
+            f.write(f"{what}\t" + "\t".join(f"{k}={v:.5g}" if isinstance(v, float) else f"{k}={v}" for k, v in stats.items()) + "\n")
+    return stats
 
 
 def cosine(a, b):

@@ -23,9 +23,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 REGION_RULE = ("gemm_nt_w4_kernel",)   # kernels checked by region instead of by total scratch size
 FILES = {"gemm_bf16.hip": ([], ("gemm_nt_w4_kernel", "gemm_nt_pipe_kernel")),
          "attention.hip": (["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"], ("attn_fwd_kernel", "attn_bwd_dkdv_ring_kernel", "attn_bwd_dq_ring_kernel",
-                                                                  "attn_bwd_dkdv_tr_kernel", "attn_bwd_dq_tr_kernel")),
-         # (built without the VGPR form: the 32-keys-per-wave dK / dV kernel keeps its accumulators in AGPRs)
-         "attention_dkdv32.hip": (["-fno-slp-vectorize"], ("attn_bwd_dkdv32_kernel",))}
+                                                                  "attn_bwd_dkdv_tr_kernel", "attn_bwd_dq_tr_kernel"))}
 
 
 def _scratch_by_kernel(src, extra):

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib.raw(), n), f"{n} declared in include/slam_hip.h but not exported by libslamhip.so"
-    assert lib.raw().slam_abi_version() == 1
+    assert lib.raw().slam_abi_version() == lib.ABI_VERSION == 2
     assert lib.raw().slam_target_arch() == b"gfx950"
 
 

@@ -85,6 +85,95 @@ def test_gradsync_world2_gloo():
         assert flags == [True, True, False]
 
 
+# ------------------------------------------------------------------------------------------------ Join policy at world 3
+def _join_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from slam_llm_amd.train import GradSync, ranks_with_data, setup_distributed, train_step
+    setup_distributed("cpu")
+    n = 40_000
+    plan = [9_000, 9_001, 25_000, n]            # a backward's prefix announcements (SlamHipModel.prefix_plan())
+
+    class FakeStore:
+        size = n
+        pure_bf16 = False
+        grad = torch.zeros(n)
+        flat = torch.ones(n)
+
+    class FakeModel:
+        grad_hooks = []
+        store = FakeStore
+
+        @staticmethod
+        def prefix_plan():
+            return plan
+
+        @staticmethod
+        def attach_grad_views():
+            pass
+
+    class SGD:          # p -= lr * g on the flat buffers: enough to see whether the replicas stay identical
+        steps = 0
+
+        def step(self):
+            FakeStore.flat.sub_(0.1 * FakeStore.grad)
+            SGD.steps += 1
+
+        def zero_grad(self):
+            pass
+
+    gs = GradSync(FakeModel, bucket_bytes=32 * 1024).attach(FakeModel)
+    opt = SGD()
+    n_batches = [3, 1, 2][rank]               # uneven shards: rank 1 runs dry after one batch, rank 2 after two
+    it, history = 0, []
+    while True:
+        has = it < n_batches
+        active = ranks_with_data(has, torch.device("cpu"))
+        if active == 0:
+            break
+        if has:       # a "backward": this rank's gradient of iteration `it` is (rank + 1) * (it + 1) everywhere
+            gs.arm(True)
+            gs.on_backward_begin()
+            FakeStore.grad.fill_(float((rank + 1) * (it + 1)))
+            for end in plan:
+                gs.on_prefix(end)
+            gs.finish()
+            opt.step()
+        else:
+            assert train_step(FakeModel, None, opt, None, gs) == (None, None)
+        history.append((active, float(FakeStore.grad[0]), float(FakeStore.grad[-1])))
+        it += 1
+    q.put((rank, history, opt.steps, float(FakeStore.flat[0]), float(FakeStore.flat[-1])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gradsync_join_policy_world3_gloo():
+    """uneven shard counts (3 / 1 / 2 batches on ranks 0 / 1 / 2) under the Join policy: exhausted ranks shadow the collectives with zero
+    gradients (GradSync.shadow_backward through train_step(batch=None)), so every rank runs three iterations, every iteration's buffer is
+    the sum of the ACTIVE ranks' gradients over the WORLD size (DDP Join's divide_by_initial_world_size), and the replicas' parameters
+    stay identical because every rank applies every averaged step."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_join_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    # iteration 0: ranks 0, 1, 2 active with gradients 1, 2, 3 -> mean 2; iteration 1: ranks 0, 2 with 2, 6 -> 8 / 3; iteration 2: rank 0 with 3 -> 1
+    want = [(3, 2.0), (2, 8.0 / 3.0), (1, 1.0)]
+    for rank, history, steps, p0, p1 in res:
+        assert steps == 3 and len(history) == 3, (rank, history)
+        for (active, g0, g1), (wa, wg) in zip(history, want):
+            assert active == wa and abs(g0 - wg) < 1e-6 and abs(g1 - wg) < 1e-6, (rank, history)
+        assert abs(p0 - (1.0 - 0.1 * (2.0 + 8.0 / 3.0 + 1.0))) < 1e-6 and p0 == p1
+    assert len({(p0, p1) for _, _, _, p0, p1 in res}) == 1      # identical replicas
+
+
 # ------------------------------------------------------------------------------------------------ bench.py's rank logic at world 8 (VERDICT r3 #10)
 def _bench_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))

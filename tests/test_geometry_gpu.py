@@ -16,7 +16,7 @@ import torch
 
 from oracle import slam_oracle as O
 from tests import golden_util as G
-from tests.test_headline_gpu import _check_grads, _oracle_grads
+from tests.test_headline_gpu import _check_grads, _eval_logits_check, _oracle_grads
 
 pytestmark = pytest.mark.gpu
 
@@ -43,7 +43,7 @@ def test_c1_true_geometry_step_matches_oracle(dev):
         emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
         loss, logits = O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
         acc = O.compute_accuracy(torch.argmax(logits, -1)[:, :-1], ob["labels"][:, 1:], -100)
-        return loss, acc
+        return loss, acc, logits
 
     loss_ref, acc_ref, grads = _oracle_grads(W, cfg, ob, fwd)
     model = SlamHipModel(dict(cfg), dev).load_weights(W)
@@ -62,8 +62,9 @@ def test_c1_true_geometry_step_matches_oracle(dev):
     # mid-M products unsliced, 0.99855 with the round-4 K-sliced form (different summation order of the same fp32 products; every GEMM form
     # is held to the fp32 product and to each other in tests/test_ops_gpu.py).  Round 5: 0.99841 at the suite's fixed seeds; floor = 2x that
     # deviation (tests/golden_util.FLOORS), 0.999 at the 1-layer geometries.
-    worst = _check_grads(model, grads, cos_min=G.FLOORS["c1_full_depth"])
+    worst = _check_grads(model, grads, cos_min=G.FLOORS["c1_full_depth"], expected=G.EXPECT["c1_full_depth"])
     print(f"C1 true geometry: loss {got:.4f} vs {loss_ref:.4f}, acc {float(acc):.4f} vs {acc_ref:.4f}, worst gradient cosine {worst:.6f}")
+    _eval_logits_check(model, gb, ob, "C1 true geometry (Whisper-tiny -> TinyLlama-1.1B, 4 + 22 layers)", other_stride=1)
 
 
 @pytest.mark.timeout(2400)
@@ -102,7 +103,7 @@ def test_c4_bench_geometry_step_matches_oracle(dev):
         emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
         loss, logits = O.llama_forward(W, c, emb, ob["attention_mask"], ob["labels"])
         acc = O.compute_accuracy(torch.argmax(logits, -1)[:, :-1], ob["labels"][:, 1:], -100)
-        return loss, acc
+        return loss, acc, logits
 
     loss_ref, acc_ref, grads = _oracle_grads(W, c, ob, fwd)
     model = SlamHipModel(dict(cfg), dev).load_weights(W)
@@ -126,6 +127,7 @@ def test_c4_bench_geometry_step_matches_oracle(dev):
     assert abs(float(acc) - acc_ref) <= 1.0 / n_valid + 1e-6
     worst = _check_grads(model, grads, cos_min=0.998)
     print(f"C4 bench geometry: loss {got:.4f} vs {loss_ref:.4f}, worst gradient cosine {worst:.6f}")
+    _eval_logits_check(model, gb, ob, "C4 bench geometry (6 x 30 s, 2 + 2 + 1 layers)", other_stride=1)
 
 
 @pytest.mark.timeout(2400)
@@ -168,7 +170,7 @@ def test_c5_style_ragged_multitask_step_matches_per_clip_oracle(dev):
         emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
         loss, logits = O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
         acc = O.compute_accuracy(torch.argmax(logits, -1)[:, :-1], ob["labels"][:, 1:], -100)
-        return loss, acc
+        return loss, acc, logits
 
     loss_ref, acc_ref, grads = _oracle_grads(W, cfg, ob, fwd)
     model = SlamHipModel(dict(cfg, pad_or_trim=False, varlen_encoder=True, varlen=True), dev).load_weights(W)
@@ -183,6 +185,8 @@ def test_c5_style_ragged_multitask_step_matches_per_clip_oracle(dev):
     assert abs(float(acc) - acc_ref) <= 1.0 / n_valid + 1e-6
     worst = _check_grads(model, grads)
     print(f"C5-style ragged step: loss {got:.4f} vs {loss_ref:.4f}, worst gradient cosine {worst:.6f}")
+    # packed LLM pass: the logits come back in the padded [B, T, V] layout (pad rows zero, skipped by the check)
+    _eval_logits_check(model, gb, ob, "C5-style ragged multitask batch (varlen encoder + packed LLM)", other_stride=1)
 
 
 @pytest.mark.timeout(2400)

@@ -22,12 +22,33 @@ from tests import golden_util as G
 pytestmark = pytest.mark.gpu
 
 
+LAST_LOGITS = {}
+
+
+def _eval_logits_check(model, gb, ob, what, **kw):
+    """the every-row EVAL forward of the HIP model (the training forward of a labelled batch hands no logits out) against the oracle's
+    logits of the same batch -- SURVEY 8(c) "logits compared on a sampled subset", north_star "loss/logits"."""
+    ref = LAST_LOGITS.pop("ref")
+    was = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            out_eval, _ = model(**{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in gb.items()})
+    finally:
+        model.train(was)
+    assert out_eval.logits is not None, "eval forward returned no logits"
+    return G.check_logits(out_eval.logits, ref, ob["attention_mask"], ob["labels"], what, **kw)
+
+
 def _oracle_grads(W, cfg, ob, fwd):
     names = O.trainable_names(W)
     for n in names:
         W[n].requires_grad_(True)
     torch.set_num_threads(min(64, os.cpu_count()))
-    loss_ref, acc_ref = fwd()
+    res = fwd()
+    loss_ref, acc_ref = res[0], res[1]
+    if len(res) > 2:        # the oracle's logits [B, T, V], kept for G.check_logits (VERDICT r5 missing #1)
+        LAST_LOGITS["ref"] = res[2].detach()
     loss_ref.backward()
     grads = {n: W[n].grad.detach().clone() for n in names}
     for n in names:
@@ -36,8 +57,9 @@ def _oracle_grads(W, cfg, ob, fwd):
     return float(loss_ref.detach()), float(acc_ref), grads
 
 
-def _check_grads(model, grads, cos_min=0.999, norm_tol=3e-2, table=None):
-    """table: a list that receives (name, cosine, relative norm deviation) of every tensor BEFORE the asserts fire"""
+def _check_grads(model, grads, cos_min=0.999, norm_tol=3e-2, table=None, expected=None):
+    """table: a list that receives (name, cosine, relative norm deviation) of every tensor BEFORE the asserts fire;
+    expected: the worst 1 - cosine measured when `cos_min` was set (tests/golden_util.EXPECT): drift alarm outside [0.5, 1.5] x it"""
     worst = 1.0
     gmax = max(float(g.norm()) for g in grads.values())
     if table is not None:
@@ -55,6 +77,8 @@ def _check_grads(model, grads, cos_min=0.999, norm_tol=3e-2, table=None):
         G.floor_check(cs, cos_min, f"grad {n}: cosine {cs}")
         gn, mn = float(grads[n].norm()), float(p.grad.float().norm())
         assert abs(mn - gn) <= norm_tol * gn + 1e-9, f"grad {n}: norm {mn} vs {gn}"
+    if expected is not None:
+        G.drift_check(os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0] + " worst gradient cosine", 1.0 - worst, expected)
     return worst
 
 
@@ -72,12 +96,100 @@ def test_headline_geometry_step_matches_oracle(dev, encoder, B):
 def test_c3_full_depth_step_matches_oracle(dev):
     """VERDICT r4 missing #5: the headline model at FULL depth -- all 32 Whisper-large-v3 layers and all 32 Llama-3-8B layers at true
     widths (the bf16 residual stream at d 4096 through 32 layers has otherwise only met the oracle at C1's widths), B = 2 clips x 30 s,
-    T = 380, raw audio in, LoRA r16 on q, v: loss abs <= 1e-2, accuracy within one token, every gradient cosine >= 0.999 / norm 3 %.
+    T = 380, raw audio in, LoRA r16 on q, v: loss abs <= 1e-2, accuracy within one token; gradients: cosine >= FULL_DEPTH_COS (0.985) / norm within
+    FULL_DEPTH_NORM (8 %) of the FP32 oracle -- NOT the 0.999 / 3 % of the 1-layer cases: see the block comment below and the bf16-emulation
+    check (tests/test_emulation_gpu.py), which shows the fp32 arithmetic of the oracle under this path's bf16 formats deviating as much.
     The fp32 oracle holds 8.6 G parameters (34 GB) on the host: skipped on a box with less than 160 GB of free RAM."""
     import psutil
     if psutil.virtual_memory().available < 160 * 2 ** 30:
         pytest.skip("needs 160 GB of host RAM for the fp32 oracle at full depth")
-    _headline_case(dev, "whisper-large-v3", 2, 32, 32)
+    _headline_case(dev, "whisper-large-v3", 2, 32, 32, keep=FULL_DEPTH_CACHE)
+
+
+FULL_DEPTH_CACHE = {}      # what the full-depth case leaves for the emulation test right behind it (fp32 weights, batch, both gradient sets)
+
+
+def _family_stats(dev_by_name):
+    fam = {}
+    for n, d in dev_by_name.items():
+        key = ("q_proj.lora_A" if "q_proj.lora_A" in n else "q_proj.lora_B" if "q_proj.lora_B" in n else "v_proj.lora_A" if "v_proj.lora_A" in n
+               else "v_proj.lora_B" if "v_proj.lora_B" in n else "projector")
+        fam.setdefault(key, []).append(d)
+    return {k: (float(np.mean(v)), float(np.max(v))) for k, v in fam.items()}
+
+
+@pytest.mark.timeout(3000)
+def test_c3_full_depth_bf16_emulation_explains_the_q_proj_floor(dev):
+    """VERDICT r5 next #1b / ADVICE r5 (medium): the 0.985 floor of the full-depth case, backed by a test instead of prose.
+
+    The oracle's fp32 ARITHMETIC is run again under this path's bf16 number FORMATS (oracle/bf16_emulation.py: a rounding at every tensor
+    the HIP path materialises in bf16, forward and backward; bf16 frozen weights), twice: once as is, once with every contraction summed in
+    another order (what any second correct implementation does).  Measured (CPU, profiles/r06_bf16_emulation_cpu.json; this test re-measures):
+      * emulated vs fp32: q_proj adapters fall to 1 - cos = 7.1e-3 (lora_A, layer 12) while v_proj / projector stay <= 1.7e-4 -- the HIP
+        path's own profile (5.6e-3 / <= 4e-4): the degradation is a property of bf16 formats on THIS input (Whisper's output for 30 s of
+        noise is nearly constant over time -- frame-to-frame cosine 0.998 -- so the keys of a deep random-init LLM share one large common
+        component), not of the kernels;
+      * the two emulations are 9.1e-3 APART from each other on q_proj.lora_A: bf16 roundings flip on 1e-7 differences and the flips
+        cascade through 32 layers, so two correct bf16 implementations are no closer to each other than either is to fp32.  The
+        "HIP vs emulation >= 0.9995" form of the check is therefore unattainable BY THE EMULATION ITSELF; what can be asserted is that the
+        HIP path behaves like one more member of that family:
+          (a) per tensor family (q/v x lora_A/lora_B, projector), HIP-vs-fp32 mean and max deviation <= 1.5x / 2x the larger of the
+              two emulations' (HIP is no noisier than the reference arithmetic in bf16 formats);
+          (b) HIP-vs-emulation <= 1.5x / 2x emulation-vs-reordered-emulation (HIP is as close to the emulation as its own twin is);
+          (c) the emulation reproduces at least half of HIP's worst q_proj deviation (the explanation accounts for the floor).
+      * single sites (CPU run): without the dS rounding 7.2e-3, without the residual-stream rounding 5.0e-3, without the RMSNorm-output
+        rounding 6.8e-3: no single site carries it, and a higher-precision dS operand (round 5's suspicion) buys NOTHING.
+    A depth-dependent defect in the q path (RoPE backward, LoRA-extension dX, Delta) would break (a) and (b)."""
+    import psutil
+    from oracle import bf16_emulation as E
+    if not FULL_DEPTH_CACHE:
+        if psutil.virtual_memory().available < 160 * 2 ** 30:
+            pytest.skip("needs 160 GB of host RAM for the fp32 oracle at full depth")
+        _headline_case(dev, "whisper-large-v3", 2, 32, 32, keep=FULL_DEPTH_CACHE)
+    C = FULL_DEPTH_CACHE
+    W, cfg, ob, enc, g32, ghip = C["W"], C["cfg"], C["ob"], C["enc"], C["grads"], C["hip_grads"]
+    try:
+        for n, t in W.items():          # the frozen matrices take their bf16 values in place (what the HIP model loaded)
+            if not any(m in n for m in O.TRAINABLE_MARKERS) and t.dim() >= 2:
+                t.copy_(E.rb(t))
+        sites = E.ALL_SITES - {"weights"}
+        emb_w = W["llm.base_model.model.model.embed_tokens.weight"]
+
+        def emulated(reorder):
+            def f():
+                proj = E.projector_concat_emulated(W, E.rb(enc), cfg["ds_rate"], sites=sites, reorder=reorder)
+                emb = O.embed_splice(emb_w, ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+                loss, logits = E.llama_forward_emulated(W, cfg, emb, ob["attention_mask"], ob["labels"], sites=sites, reorder=reorder)
+                return loss, torch.zeros(())
+            return f
+        l_em, _, g_em = _oracle_grads(W, cfg, ob, emulated(False))
+        l_re, _, g_re = _oracle_grads(W, cfg, ob, emulated(True))
+    finally:
+        FULL_DEPTH_CACHE.clear()
+    names = [n for n in g32 if not n.endswith("key.bias")]
+    dev_of = lambda a, b: {n: 1.0 - G.cosine(a[n].numpy(), b[n].numpy()) for n in names}  # noqa: E731
+    S = {k: _family_stats(v) for k, v in dict(hip_fp32=dev_of(ghip, g32), emu_fp32=dev_of(g_em, g32), re_fp32=dev_of(g_re, g32),
+                                              hip_emu=dev_of(ghip, g_em), emu_re=dev_of(g_em, g_re)).items()}
+    lines = [f"full depth, B = 2: loss fp32 {C['loss_ref']:.5f} | HIP {C['loss_hip']:.5f} | emulated {l_em:.5f} | emulated, re-ordered sums {l_re:.5f}",
+             "family\tHIP-vs-fp32 mean / max\temulated-vs-fp32\tre-ordered-vs-fp32\tHIP-vs-emulated\temulated-vs-re-ordered"]
+    for fam in sorted(S["hip_fp32"]):
+        lines.append(fam + "\t" + "\t".join(f"{S[k][fam][0]:.2e} / {S[k][fam][1]:.2e}" for k in ("hip_fp32", "emu_fp32", "re_fp32", "hip_emu", "emu_re")))
+    print("\n".join(lines))
+    if os.environ.get("SLAM_TEST_REPORT"):
+        with open(os.environ["SLAM_TEST_REPORT"] + ".emulation.tsv", "a") as f:
+            f.write("\n".join(lines) + "\n")
+    assert abs(l_em - C["loss_ref"]) <= 1e-2 and abs(l_re - C["loss_ref"]) <= 1e-2
+    FLOOR = 2e-4       # below this every family is "clean" (v_proj, projector): ratios of tiny numbers are not compared
+    for fam in S["hip_fp32"]:
+        hm, hx = S["hip_fp32"][fam]
+        em, ex = (max(S["emu_fp32"][fam][i], S["re_fp32"][fam][i]) for i in (0, 1))
+        assert hm <= 1.5 * em + FLOOR and hx <= 2.0 * ex + FLOOR, f"(a) {fam}: HIP-vs-fp32 {hm:.2e} / {hx:.2e} vs emulations {em:.2e} / {ex:.2e}"
+        dm, dx = S["hip_emu"][fam]
+        tm, tx = S["emu_re"][fam]
+        assert dm <= 1.5 * tm + FLOOR and dx <= 2.0 * tx + FLOOR, f"(b) {fam}: HIP-vs-emulated {dm:.2e} / {dx:.2e} vs emulated-vs-re-ordered {tm:.2e} / {tx:.2e}"
+    worst_q_hip = max(S["hip_fp32"]["q_proj.lora_A"][1], S["hip_fp32"]["q_proj.lora_B"][1])
+    worst_q_emu = max(S[k][f][1] for k in ("emu_fp32", "re_fp32") for f in ("q_proj.lora_A", "q_proj.lora_B"))
+    assert worst_q_emu >= 0.5 * worst_q_hip, f"(c) the emulation's worst q_proj deviation {worst_q_emu:.2e} does not account for HIP's {worst_q_hip:.2e}"
 
 
 # Full depth (profiles/r05_c3_full_depth.md, 132 tensors): loss 12.23417 vs 12.23254; every v_proj adapter and the projector >= 0.9996 at
@@ -93,7 +205,7 @@ def test_c3_full_depth_step_matches_oracle(dev):
 FULL_DEPTH_COS, FULL_DEPTH_NORM = 0.985, 8e-2
 
 
-def _headline_case(dev, encoder, B, enc_layers, llm_layers):
+def _headline_case(dev, encoder, B, enc_layers, llm_layers, keep=None):
     from slam_llm_amd import ops
     from slam_llm_amd.model import SlamHipModel, make_config
     PROMPT, ANSWER = 16, 64
@@ -107,14 +219,18 @@ def _headline_case(dev, encoder, B, enc_layers, llm_layers):
     def fwd():
         with torch.no_grad():   # frozen encoder: no graph through the 31 x 20 x 1500 x 1500 attention
             enc = O.whisper_encoder(W, cfg, ob["audio_mel"].permute(0, 2, 1))
+        if keep is not None:
+            keep["enc"] = enc
         proj = O.projector_concat(W, enc, cfg["ds_rate"])
         emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
         loss, logits = O.llama_forward(W, cfg, emb, ob["attention_mask"], ob["labels"])
         acc = O.compute_accuracy(torch.argmax(logits, -1)[:, :-1], ob["labels"][:, 1:], -100)
-        return loss, acc
+        return loss, acc, logits
 
     loss_ref, acc_ref, grads = _oracle_grads(W, cfg, ob, fwd)
     model = SlamHipModel(dict(cfg), dev).load_weights(W)
+    if keep is not None:
+        keep.update(W=W, cfg=dict(cfg), ob=ob, grads=grads, loss_ref=loss_ref)
     del W
     model.train()
     assert ops._GEMM_CFG == 0, "the headline test runs under the AUTO GEMM rule"
@@ -137,13 +253,16 @@ def _headline_case(dev, encoder, B, enc_layers, llm_layers):
         assert any("gemm_nt_w4_kernel" in k for k in used) and any("gemm_nt_persist2_kernel" in k for k in used), sorted(used)
     n_valid = int((ob["labels"][:, 1:] != -100).sum())
     got = float(outputs.loss)
+    if keep is not None:
+        keep.update(loss_hip=got, hip_grads={n: p.grad.float().cpu() for n, p in model.store.params.items()})
     assert abs(got - loss_ref) <= 1e-2, (got, loss_ref)
     assert abs(float(acc) - acc_ref) <= 1.0 / n_valid + 1e-6
     table = []
     try:
         # full depth: 32 layers of bf16 residual stream (each layer's output rounded to 8 mantissa bits before it is added on) under the
         # fp32 oracle; the floor is set from the measured table (profiles/r05_c3_full_depth.md), not from the 1-layer case
-        worst = _check_grads(model, grads, table=table, **(dict(cos_min=FULL_DEPTH_COS, norm_tol=FULL_DEPTH_NORM) if llm_layers > 1 else {}))
+        worst = _check_grads(model, grads, table=table, **(dict(cos_min=FULL_DEPTH_COS, norm_tol=FULL_DEPTH_NORM, expected=G.EXPECT["c3_full_depth"])
+                                                           if llm_layers > 1 else {}))
     finally:
         if os.environ.get("SLAM_TEST_REPORT") and table:
             with open(os.environ["SLAM_TEST_REPORT"] + ".grads.tsv", "a") as f:
@@ -151,6 +270,8 @@ def _headline_case(dev, encoder, B, enc_layers, llm_layers):
                 for n, cs, nr in table:
                     f.write(f"{n}\t{cs:.6f}\t{nr:.5f}\n")
     print(f"{encoder} x {B} ({enc_layers} + {llm_layers} layers): loss {got:.4f} vs {loss_ref:.4f}, acc {float(acc):.4f} vs {acc_ref:.4f}, worst gradient cosine {worst:.6f}")
+    # logits of the every-row eval forward vs the oracle's, every label row + every 5th other valid row x all 128 256 columns
+    _eval_logits_check(model, gb, ob, f"{encoder} x {B}, {enc_layers} + {llm_layers} layers")
     if os.environ.get("SLAM_TEST_REPORT"):      # (tools: append the measured numbers to a file that is committed under profiles/)
         with open(os.environ["SLAM_TEST_REPORT"], "a") as f:
             f.write(f"{encoder} x {B}, {enc_layers} + {llm_layers} layers, T = 380: loss {got:.5f} vs oracle {loss_ref:.5f}; accuracy {float(acc):.4f} vs "
@@ -189,7 +310,7 @@ def test_c4_true_width_step_matches_oracle(dev):
         emb = O.embed_splice(W["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
         loss, logits = O.llama_forward(W, c, emb, ob["attention_mask"], ob["labels"])
         acc = O.compute_accuracy(torch.argmax(logits, -1)[:, :-1], ob["labels"][:, 1:], -100)
-        return loss, acc
+        return loss, acc, logits
 
     loss_ref, acc_ref, grads = _oracle_grads(W, c, ob, fwd)
     model = SlamHipModel(dict(cfg), dev).load_weights(W)
@@ -205,6 +326,7 @@ def test_c4_true_width_step_matches_oracle(dev):
     assert abs(float(acc) - acc_ref) <= 1.0 / n_valid + 1e-6
     worst = _check_grads(model, grads, cos_min=0.998)
     print(f"C4 true widths: loss {got:.4f} vs {loss_ref:.4f}, worst gradient cosine {worst:.6f}")
+    _eval_logits_check(model, gb, ob, "C4 true widths (HuBERT-large -> Q-Former -> Vicuna-7B, 1 + 1 + 1 layers)", other_stride=1)
 
 
 # ------------------------------------------------------------------------------------------------ single kernels at the bench's shapes
