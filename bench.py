@@ -34,7 +34,7 @@ PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MIC
 # Per-launch HIP events (the roofline's live measurement) are recorded on every KERNEL_TIMING_EVERY-th step of the timed region, not on
 # all of them: ~1 170 events per C3 step cost the step they measure 3.4 ms = 0.9 % (tools/timer_overhead.py, profiles/r05_timer_overhead.md).
 # The sampled steps are ordinary steps of the timed region (step 0, 4, 8, ...: with the default K = 5 two of five, with K = 20 five of twenty).
-KERNEL_TIMING_EVERY = 4
+KERNEL_TIMING_EVERY = int(os.environ.get("SLAM_BENCH_TIMING_EVERY", "4"))
 CLIP_SECONDS, PROMPT, ANSWER = 30.0, 16, 64
 
 WORKLOADS = {
@@ -339,6 +339,9 @@ def main():
                     "trains too -- NOT the headline configuration, named as such in config.workload")
     ap.add_argument("--functional-gloo", action="store_true", help="N>1 on a box with fewer than N GPUs: ranks share devices over gloo (functional "
                     "check of the N > 1 path only; without this flag such a run FAILS instead of printing a number)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"], help="replay the training step as ONE captured HIP graph "
+                    "(slam_llm_amd.train.GraphedTrainStep: bit-identical to the eager step) on the steps that carry no per-launch timing events; "
+                    "auto = off (measured neutral on every workload: profiles/r06_graph_ab.md)")
     ap.add_argument("--ddp", action="store_true", help="N>1: reduce through torch DistributedDataParallel (autograd_params mode) "
                                                       "instead of the GradSync fast path")
     args = ap.parse_args()
@@ -350,7 +353,7 @@ def main():
     from slam_llm_amd import ops
     from slam_llm_amd.model import SlamAdamW, SlamHipModel
     from slam_llm_amd.slam_model_hip import build_config
-    from slam_llm_amd.train import GradSync, lr_lambda, rccl_version, setup_distributed, train_step
+    from slam_llm_amd.train import GradSync, GraphedTrainStep, lr_lambda, rccl_version, setup_distributed, train_step
 
     rank, local_rank, world = setup_distributed("cuda")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -396,6 +399,13 @@ def main():
 
     timer = ops.KernelTimer()
     sampled = {"on": False, "i": 0, "n": 0}
+    # auto = off: the captured step measured NEUTRAL on every workload once the per-launch timing events are sampled sparsely (C3 350.0 vs
+    # 350.3 ms, C2 85.2 vs 85.1, C4 46.5 vs 46.8, C1 11.48 vs 11.53: profiles/r06_graph_ab.md) -- the host already runs ahead of the
+    # device in the eager loop, and a graph's kernels start no closer together than a stream's.  The lines stay on the eager step.
+    use_graph = args.graph == "on" and not args.ddp
+    # static bound on the labelled rows = what the synthetic collator produces (ANSWER labelled rows per clip); a real loader passes
+    # B x its longest answer.  The eager steps (warm-up, the sampled timing steps) run under the same bound.
+    graphed = GraphedTrainStep(model, opt, sched, label_rows_cap=n_clips * ANSWER, warmup=1, grad_sync=gsync) if use_graph else None
 
     def step():
         on = sampled["on"] and sampled["i"] % KERNEL_TIMING_EVERY == 0
@@ -403,6 +413,8 @@ def main():
         sampled["n"] += 1 if on else 0
         ops.TIMER = timer if on else None       # (per-launch events on the sampled steps only: see KERNEL_TIMING_EVERY)
         try:
+            if graphed is not None:             # (falls back to the eager train_step by itself while ops.TIMER is set)
+                return graphed(batch)
             return train_step(step_model, batch, opt, sched, gsync)
         finally:
             ops.TIMER = None
@@ -494,6 +506,10 @@ def main():
                    # whether the last decoder layer really ran behind its attention over the labelled rows only in this run (it does not
                    # when LoRA dropout acts on o / gate / up / down of that layer)
                    "last_layer_label_rows_active": bool(getattr(model.llm, "_last_pruned_rows", 0)),
+                   # how the steps of the timed region were issued: replays of ONE captured HIP graph (forward + backward + AdamW; bit-identical
+                   # to the eager step, tests/test_graph_gpu.py) or kernel by kernel from the host (the steps that carry per-launch events)
+                   "step_issue": (f"{graphed.replays} graph replays + {graphed.eager_steps} eager steps over warm-up and timed region "
+                                  f"(static label-row bound {model.llm.label_rows_cap})" if graphed is not None else "eager (one launch per kernel)"),
                    "logits": ("lm_head / cross entropy over the labelled rows only (the rows with label -100 enter neither loss, accuracy nor any "
                               "gradient), last decoder layer behind its attention likewise; SLAM_LM_HEAD_LABEL_ROWS=0 computes every row"
                               if rows_skipped else "full [B*T, V] lm_head computed (chunked), not materialised in fp32")},

@@ -58,6 +58,19 @@ LAST_LAYER_LABEL_ROWS = _os.environ.get("SLAM_LAST_LAYER_LABEL_ROWS", "1") == "1
 # LoRA backward under lora_dropout: second hop + mask + accumulate as ONE pass over dx (slam_lora_hop_dropout) instead of product -> scratch
 # [M, K] -> slam_dropout_bf16(accumulate); bit-identical; SLAM_FUSED_LORA_HOP=0 restores the two launches (A/B)
 FUSE_LORA_HOP = _os.environ.get("SLAM_FUSED_LORA_HOP", "1") == "1"
+# LoRA gradient products (dA / dB grams and their reduces) on a side stream under the next layer's GEMMs (round 6, VERDICT r5 next #5a):
+# bit-identical; SLAM_LORA_SIDE_STREAM=0 keeps them inline on the compute stream (A/B)
+LORA_SIDE_STREAM = _os.environ.get("SLAM_LORA_SIDE_STREAM", "0") == "1"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 LORA_PAD = 64  # K-extension granule (GEMM K-tile)
 # HuBERT / WavLM conv layers 1-6 (k 3 / 2, stride 2, 512 channels, no padding): the im2col matrix of a row-major [T, C] signal is a VIEW
 # with overlapping rows (row t = the k * C contiguous elements from row 2 t on) -- handed to the GEMM as lda = stride * C, one launch
@@ -229,7 +242,7 @@ class FusedLinear:
                             self.WextT[K + a["j0"]: K + a["j0"] + a["r"], a["row0"]: a["row0"] + a["rows"]])
         # A's bf16 copies live in the store's flat bf16 buffer (contiguous block of all adapters of this group);
         # their transpose [K, Rp] serves the second hop of the backward: dx += d(xA^T) . A
-        self.AcatT = ops.transpose(self.a_cat(store), Rp=self.Rp)
+        self.AcatT = ops.transpose_into(getattr(self, "AcatT", None), self.a_cat(store), self.Rp)     # in place: see ops.transpose_into
 
     def a_cat(self, store: TrainableStore) -> torch.Tensor:
         first = self.adapters[0]
@@ -278,8 +291,9 @@ class FusedLinear:
         return ops.gemm_skinny(x_ext, self.Wext, out, swiglu=True)
 
     def backward(self, dy: torch.Tensor, x_ext: Optional[torch.Tensor], store: Optional[TrainableStore],
-                 accumulate: bool, out=None, drop=None) -> torch.Tensor:
-        """returns dx_ext [M, K+Rp] (columns [:K] are dL/dx); deposits adapter gradients into the store."""
+                 accumulate: bool, out=None, drop=None, defer=None) -> torch.Tensor:
+        """returns dx_ext [M, K+Rp] (columns [:K] are dL/dx); deposits adapter gradients into the store.
+        defer(fn, keep): run the adapter-gradient products (off the dX critical path) through the caller's side queue instead of inline."""
         if self.Rp and self.K % 256 == 0:
             # two products instead of one [M, K + Rp] output: the Rp (64) extension columns would open a 17th column of 256-wide
             # tiles that is 25 % full -- at the Llama qkv shape 799 tiles = 3.12 rounds over 256 CUs, paid as 4 (measured 1.1 PF
@@ -301,20 +315,28 @@ class FusedLinear:
                 hop = ops.gemm_nt(dx_ext[:, self.K:], self.AcatT)           # dL/d(dropout(x))
                 ops.dropout(hop, *drop, out=dx_ext[:, : self.K], accumulate=True)  # same mask, recomputed
             K, sr = self.K, self.sum_r
-            # dA[r, K] = du^T x ;  dB[rows, r] = (alpha/r) * dy[:, rows]^T u   (HBM-bound tall-skinny products).
-            # All adapters of the group share x and their A's (and A gradients) are contiguous: one pass over x.
-            # (dropout(x) is never materialised: the gram kernel recomputes the mask)
-            merged = sr % 8 == 0 and sr <= 64
-            if merged:
-                ops.skinny_gram(dx_ext[:, K: K + sr], xin, self.a_cat_grad(store), K, 1, accumulate=accumulate, drop=drop)
-            for a in self.adapters:
-                r = a["r"]
-                if not merged:
-                    ops.skinny_gram(dx_ext[:, K + a["j0"]: K + a["j0"] + r], xin, store.grad_view(a["A"]), K, 1,
-                                    accumulate=accumulate, drop=drop)
-                u = x_ext[:, K + a["j0"]: K + a["j0"] + r]            # xA^T        [M, r]
-                ops.skinny_gram(u, dy[:, a["row0"]: a["row0"] + a["rows"]], store.grad_view(a["B"]), 1, r,
-                                alpha=a["scale"], accumulate=accumulate)
+
+            def adapter_grads():
+                # dA[r, K] = du^T x ;  dB[rows, r] = (alpha/r) * dy[:, rows]^T u   (HBM-bound tall-skinny products).
+                # All adapters of the group share x and their A's (and A gradients) are contiguous: one pass over x.
+                # (dropout(x) is never materialised: the gram kernel recomputes the mask)
+                merged = sr % 8 == 0 and sr <= 64
+                if merged:
+                    ops.skinny_gram(dx_ext[:, K: K + sr], xin, self.a_cat_grad(store), K, 1, accumulate=accumulate, drop=drop)
+                for a in self.adapters:
+                    r = a["r"]
+                    if not merged:
+                        ops.skinny_gram(dx_ext[:, K + a["j0"]: K + a["j0"] + r], xin, store.grad_view(a["A"]), K, 1,
+                                        accumulate=accumulate, drop=drop)
+                    u = x_ext[:, K + a["j0"]: K + a["j0"] + r]            # xA^T        [M, r]
+                    ops.skinny_gram(u, dy[:, a["row0"]: a["row0"] + a["rows"]], store.grad_view(a["B"]), 1, r,
+                                    alpha=a["scale"], accumulate=accumulate)
+            if defer is not None:
+                # NB the second hop above only ADDS into dx_ext[:, :K]; the grams read dx_ext[:, K:] (du), x and dy, none of which the main
+                # stream writes again -- the side queue only has to keep them alive until it is joined
+                defer(adapter_grads, (dx_ext, x_ext, dy))
+            else:
+                adapter_grads()
         return dx_ext
 
 
@@ -1910,8 +1932,9 @@ class HipProjectorConcat(nn.Module):
     def refresh(self):
         s, p = self.store, self.prefix
         # linear1's transpose only serves dL/d(encoder output): built when the encoder is trainable
-        self.w2T = ops.transpose(s.bf16_view(p + "linear2.weight"), Rp=self.dl)  # [hid, dl]
-        self.w1T = ops.transpose(s.bf16_view(p + "linear1.weight"), Rp=self.hid) if self.need_dx else None  # [k*d, hid]
+        # (in place after the first call: see ops.transpose_into)
+        self.w2T = ops.transpose_into(getattr(self, "w2T", None), s.bf16_view(p + "linear2.weight"), self.dl)  # [hid, dl]
+        self.w1T = ops.transpose_into(getattr(self, "w1T", None), s.bf16_view(p + "linear1.weight"), self.hid) if self.need_dx else None  # [k*d, hid]
 
     def forward_hip(self, enc: torch.Tensor, stash: Optional[dict]):
         """enc [B, T2, d] bf16 -> [B, Ta, dl] bf16"""
@@ -1999,10 +2022,15 @@ class HipProjectorCov1d(nn.Module):
         s, p = self.store, self.prefix
         d, k = self.d, self.k
         # frame-major packing of the conv taps: [co, ci, j] -> [co, j*d + ci] (one strided copy of 5*d^2 elements)
-        self.wc = s.bf16_view(p + "conv1d.weight").permute(0, 2, 1).reshape(d, k * d).contiguous()
-        self.w1T = ops.transpose(s.bf16_view(p + "linear1.weight"), Rp=self.hid)  # [d, hid]
-        self.w2T = ops.transpose(s.bf16_view(p + "linear2.weight"), Rp=self.dl)   # [hid, dl]
-        self.wcT = ops.transpose(self.wc, Rp=d) if self.need_dx else None          # [k*d, d]: dL/d(k-frame stack) = dc . Wc
+        # (all four updated in place after the first call: see ops.transpose_into)
+        taps = s.bf16_view(p + "conv1d.weight").permute(0, 2, 1).reshape(d, k * d)
+        if getattr(self, "wc", None) is None:
+            self.wc = taps.contiguous()
+        else:
+            self.wc.copy_(taps)
+        self.w1T = ops.transpose_into(getattr(self, "w1T", None), s.bf16_view(p + "linear1.weight"), self.hid)  # [d, hid]
+        self.w2T = ops.transpose_into(getattr(self, "w2T", None), s.bf16_view(p + "linear2.weight"), self.dl)   # [hid, dl]
+        self.wcT = ops.transpose_into(getattr(self, "wcT", None), self.wc, d) if self.need_dx else None          # [k*d, d]: dL/d(k-frame stack) = dc . Wc
 
     def forward_hip(self, enc: torch.Tensor, stash: Optional[dict]):
         """enc [B, T2, d] bf16 -> [B, T2 // k, dl] bf16"""
@@ -2423,11 +2451,42 @@ class HipLlamaLora(nn.Module):
         f = stash.pop("final")
         dh = ops.rmsnorm_bwd(f["h"], f["rstdN"], self.norm_w, f["dhN"], grad_scale=grad_scale)
         del f
+        # Adapter-gradient products (dA, dB grams + their fixed-order reduces: ~3 ms of HBM-bound launches per C3 step) are off the dX
+        # critical path: with LORA_SIDE_STREAM they run on a second stream, under the NEXT layer's GEMMs (whose partial last rounds leave
+        # CUs idle), and are joined one layer late -- the main stream waits for layer li's products at the end of layer li - 1, and only
+        # then are layer li's gradient-sync hooks fired.  Same kernels, same operands, same fixed-order reductions: bit-identical.
+        side = _side_stream(dh.device) if LORA_SIDE_STREAM else None
+        pending = []        # [(done event, tensors kept alive until the main stream has waited for it)]
+        announced = [len(self.layers)]      # layers >= announced[0] have had their on_layer_done call
+
+        def defer(fn, keep):
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                fn()
+            done = torch.cuda.Event()
+            done.record(side)
+            pending.append((done, keep))
+
+        def join_and_announce(down_to: int):
+            """the main stream waits for all side work queued so far, then layers announced[0] - 1 ... down_to get their hook call"""
+            main = torch.cuda.current_stream()
+            while pending:
+                done, _keep = pending.pop(0)
+                main.wait_event(done)
+            while announced[0] > down_to:
+                announced[0] -= 1
+                if on_layer_done is not None:
+                    on_layer_done(announced[0])
+
+        dfr = defer if side is not None else None
         for li in reversed(range(len(self.layers))):
             L, S = self.layers[li], stash["layers"][li]
             dq_, do_, dg_, dd_ = S["drops"]
             if L.down.adapters or not FUSE_SWIGLU_BWD or S["gu_il"]:
-                d_hh = L.down.backward(dh, S["hh"], st, accumulate, drop=dd_)
+                d_hh = L.down.backward(dh, S["hh"], st, accumulate, drop=dd_, defer=dfr)
                 dgu = ops.swiglu_bwd(S["gu"], d_hh[:, :Fd], interleaved=S["gu_il"])
                 del d_hh
             else:
@@ -2435,11 +2494,14 @@ class HipLlamaLora(nn.Module):
                 # against the stashed [gate | up] and writes dL/dgate | dL/dup directly
                 dgu = torch.empty_like(S["gu"])
                 ops.gemm_nt(dh, L.down.WextT, out=dgu[:, :Fd], act=ops.ACT_SWIGLU_BWD, residual=S["gu"])
-            dx2 = L.gu.backward(dgu, S["x2"], st, accumulate, drop=dg_)
+            dx2 = L.gu.backward(dgu, S["x2"], st, accumulate, drop=dg_, defer=dfr)
             del dgu
             dh_mid = ops.rmsnorm_bwd(S["h_mid"], S["rstd2"], L.ln2, dx2[:, :d], dres=dh)
             del dx2
-            do_ext = L.o.backward(dh_mid, S["o"], st, accumulate, drop=do_)
+            if side is not None and li + 1 < len(self.layers):
+                # the products of the layer ABOVE had this layer's MLP backward (the two largest GEMMs of a layer) to hide under
+                join_and_announce(li + 1)
+            do_ext = L.o.backward(dh_mid, S["o"], st, accumulate, drop=do_, defer=dfr)
             dO, o_attn = do_ext[:, : Hq * D], S["o"]
             if S["inv"] is not None:    # last layer ran behind its attention over the labelled rows only: back to every row (zeros elsewhere)
                 dO, dh_mid, o_attn = ops.gather_rows(dO, S["inv"]), ops.gather_rows(dh_mid, S["inv"]), S["o_full"]
@@ -2450,13 +2512,15 @@ class HipLlamaLora(nn.Module):
                          dqkv[:, : Hq * D], dqkv[:, Hq * D: (Hq + Hkv) * D], dqkv[:, (Hq + Hkv) * D:],
                          B, T, Hq, Hkv, D, True, scale, key_mask=key_mask, rope=rope, seg=seg)  # RoPE backward fused
             del do_ext, dO
-            dx1 = L.qkv.backward(dqkv, S["x1"], st, accumulate, drop=dq_)
+            dx1 = L.qkv.backward(dqkv, S["x1"], st, accumulate, drop=dq_, defer=dfr)
             del dqkv
             dh = ops.rmsnorm_bwd(S["h"], S["rstd1"], L.ln1, dx1[:, :d], dres=dh_mid)
             del dx1, dh_mid
             stash["layers"][li] = None
-            if on_layer_done is not None:
+            if side is None and on_layer_done is not None:
                 on_layer_done(li)
+        if side is not None:
+            join_and_announce(0)
         return dh
 
 

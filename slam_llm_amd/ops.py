@@ -496,6 +496,16 @@ def head_rope_transpose(src2d, col0, B, T, H, D, cos=None, sin=None, inverse=Fal
     return dst
 
 
+def transpose_into(old, x2d, Rp):
+    """transpose into `old` when it is there with the right shape, else into a fresh tensor.  Weights DERIVED from the trainable parameters
+    (transposes, re-packed taps) are refreshed after every optimizer step: they must be updated IN PLACE, because a captured training
+    step (train.GraphedTrainStep) replays the addresses its kernels were launched with -- a re-allocated operand would leave every
+    replay reading the copy of the capture step (round 6: the LoRA second hop read a stale A^T from the third replay on)."""
+    if old is not None and tuple(old.shape) == (x2d.shape[1], Rp) and old.dtype == torch.bfloat16:
+        return transpose(x2d, Rp=Rp, out=old)
+    return transpose(x2d, Rp=Rp)
+
+
 def transpose(x2d, Rp=None, out=None):
     R, C = x2d.shape
     Rp = Rp or round_up(R, 64)
@@ -860,7 +870,7 @@ def skinny_gram(S2d, X2d, out, out_ld_r, out_ld_c, alpha=1.0, accumulate=False, 
     M2, C = X2d.shape
     assert M == M2
     nbytes = call("slam_skinny_gram_workspace_bytes", M, R, C)
-    key = str(S2d.device)
+    key = f"{S2d.device}:{torch.cuda.current_stream().cuda_stream}"     # (one per stream: the LoRA gradient products may run on a side stream)
     if key not in _GRAM_WS or _GRAM_WS[key].numel() * 4 < nbytes:   # one workspace per device, grown to the largest need
         _GRAM_WS[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=S2d.device)
     p_, seed, off = drop if drop is not None else (0.0, 0, 0)

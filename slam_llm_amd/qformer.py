@@ -84,6 +84,7 @@ class HipProjectorQFormer(nn.Module):
     def refresh(self):
         """bf16 transposes of every weight that needs dL/dx (all but the cross K/V projections and nothing else)"""
         st, d = self.store, self.d
+        old = self.wT if isinstance(getattr(self, "wT", None), dict) else {}     # updated in place after the first call (ops.transpose_into)
         self.wT = {}
         for name, (off, n, shape) in st.offsets.items():
             if not name.startswith(self.prefix) or not name.endswith(".weight") or len(shape) != 2:
@@ -91,7 +92,7 @@ class HipProjectorQFormer(nn.Module):
             if "crossattention.attention.key" in name:
                 if self.need_dx:   # trainable encoder: dL/d(encoder states) = d[k | v] . [Wk ; Wv] (fused, reserved back to back)
                     w = self._fused(name, 2 * d, self.d_enc)
-                    self.wT[name.replace("key.weight", "kv")] = ops.transpose(w, Rp=2 * d)
+                    self.wT[name.replace("key.weight", "kv")] = ops.transpose_into(old.get(name.replace("key.weight", "kv")), w, 2 * d)
                 continue
             if "crossattention.attention.value" in name:
                 continue  # covered by the fused k|v transpose above (frozen encoder: d(encoder states) is never needed)
@@ -99,9 +100,9 @@ class HipProjectorQFormer(nn.Module):
                 continue  # covered by the fused q|k|v transpose below
             if ".attention.attention.query" in name:
                 w = self._fused(name, 3 * d, d)
-                self.wT[name.replace("query.weight", "qkv")] = ops.transpose(w, Rp=3 * d)
+                self.wT[name.replace("query.weight", "qkv")] = ops.transpose_into(old.get(name.replace("query.weight", "qkv")), w, 3 * d)
                 continue
-            self.wT[name] = ops.transpose(st.bf16_view(name), Rp=shape[0])
+            self.wT[name] = ops.transpose_into(old.get(name), st.bf16_view(name), shape[0])
 
     def _lin_bwd(self, dy, x, w_first: str, b_first: str, N: int, K: int, acc: bool, wT_key: Optional[str]):
         """gradients of y = x W^T + b for a (possibly fused) weight block starting at w_first; returns dx or None"""

@@ -295,6 +295,8 @@ class GraphedTrainStep:
         m = self.model
         if m.cfg.get("varlen", False) or m.cfg.get("varlen_encoder", False) or m.autograd_params or m.store.pure_bf16:
             return False
+        if m.train_encoder:
+            return False        # (an un-frozen encoder re-allocates its derived weights on every refresh: not capture-safe, see ops.transpose_into)
         if self.gsync is not None and (self.gsync.world > 1 or self.gsync.force):
             return False        # (collectives stay outside the graph: the eager step overlaps them with the backward)
         if any(not isinstance(v, torch.Tensor) for v in batch.values()):

@@ -53,6 +53,19 @@ def _isolated_gpu_test(request):
     yield
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """drift alarm: every relaxed cosine floor is 2x a measured deviation, so a 1.9x regression would pass it; here
+    the worst deviation each floor family saw in THIS run is set against the value it was fitted to -- a line per family, flagged when it
+    leaves [0.5, 1.5] x expected (a warning, never a failure: box-to-box noise is real, a silent 1.9x is not)"""
+    from tests import golden_util as G
+    rows = G.drift_report()
+    if not rows:
+        return
+    terminalreporter.section("cosine-floor drift (worst 1 - cos per floor family vs the value the floor was fitted to)")
+    for fam, measured, expected, ok in rows:
+        terminalreporter.write_line(f"{'ok   ' if ok else 'DRIFT'} {fam:22s} measured {measured:.3e}   expected {expected:.3e}   ratio {measured / expected:.2f}")
+
+
 def pytest_sessionfinish(session, exitstatus):
     """SLAM_TEST_MARGINS=<path>: every cosine floor the suite checked, with the share of its allowed deviation the measurement used
     (tests/golden_util.floor_check): tools/margins_report.py turns the file into profiles/r05_margins.md"""

@@ -45,9 +45,21 @@ FLOORS = dict(
 # the deviation (1 - cosine) measured on MI355X behind each relaxed floor: _check_grads() warns (drift alarm, never a failure) when the worst
 # tensor of a run leaves [0.5, 1.5] x this value -- a 1.9x regression no longer passes silently under a 2x-wide floor
 EXPECT = dict(
-    c1_full_depth=1.59e-3, c3_full_depth=5.6e-3, unfrozen_fixture=1.2e-3, unfrozen=1.96e-3, unfrozen_fe=3.5e-3,
+    frozen=3.4e-4, c1_full_depth=1.59e-3, c3_full_depth=5.6e-3, unfrozen_fixture=1.2e-3, unfrozen=1.96e-3, unfrozen_fe=3.5e-3,
     unfrozen_wavlm_base=5.2e-3, unfrozen_gate=8.2e-3,
 )
+
+
+def drift_report():
+    """per floor family of FLOORS: the worst deviation this run measured against the expected one; a list of (family, measured, expected,
+    inside the [0.5, 1.5] band?) -- tests/conftest.py prints it at the end of a GPU run and warns about every family outside its band"""
+    by_allowed = {round(1.0 - v, 9): k for k, v in FLOORS.items()}
+    worst = {}
+    for _t, _what, measured, allowed in MARGINS:
+        fam = by_allowed.get(round(allowed, 9))
+        if fam is not None:
+            worst[fam] = max(worst.get(fam, 0.0), measured)
+    return [(fam, m, EXPECT[fam], 0.5 * EXPECT[fam] <= m <= 1.5 * EXPECT[fam]) for fam, m in sorted(worst.items()) if fam in EXPECT]
 
 MARGINS = []      # (test id, what, measured deviation, allowed deviation): written by tests/conftest.py when SLAM_TEST_MARGINS is set
 

@@ -1,6 +1,6 @@
-"""GPU (tools): a few launches of the attention kernels of the C3 step at HEAD for rocprofv3 --pmc passes (tools/r05_call17.sh): Whisper forward
-on accumulators started at -m (Q pre-scaled) and with the general softmax (knob 60), Llama forward, Llama backward with the shipped 16-key dK / dV
-kernel and with the 32-key one (knob 71).  python tools/pmc_attn_r05.py [n_launches]"""
+"""GPU (tools): a few launches of the attention kernels of the C3 step at HEAD for rocprofv3 --pmc passes (tools/profile_r06.sh): Whisper forward
+on accumulators started at -m (Q pre-scaled: the shipped form) and with the general softmax (knob 60), Llama forward, Llama backward (dQ + dK / dV
+transposed-read ring kernels).  python tools/pmc_attn_r06.py [n_launches]"""
 import os
 import sys
 
@@ -34,10 +34,7 @@ dol = torch.randn(Bl * Tl, Hq * Dl, device=dev).to(torch.bfloat16)
 dqkv = torch.empty_like(qkvl)
 for _ in range(n):
     ops.attn_fwd(ql, kl, vl, Bl, Tl, Hq, Hkv, Dl, True, Dl ** -0.5, key_mask=km, out=ol)
-for knob in (70, 71):
-    call("slam_attn_set_fwd_qf", knob)
-    for _ in range(n):
-        ops.attn_bwd(ql, kl, vl, ol, dol, lsel, dqkv[:, : Hq * Dl], dqkv[:, Hq * Dl:(Hq + Hkv) * Dl], dqkv[:, (Hq + Hkv) * Dl:],
-                     Bl, Tl, Hq, Hkv, Dl, True, Dl ** -0.5, key_mask=km, rope=(cos, sin))
-    torch.cuda.synchronize()
-call("slam_attn_set_fwd_qf", 70)
+for _ in range(n):
+    ops.attn_bwd(ql, kl, vl, ol, dol, lsel, dqkv[:, : Hq * Dl], dqkv[:, Hq * Dl:(Hq + Hkv) * Dl], dqkv[:, (Hq + Hkv) * Dl:],
+                 Bl, Tl, Hq, Hkv, Dl, True, Dl ** -0.5, key_mask=km, rope=(cos, sin))
+torch.cuda.synchronize()
