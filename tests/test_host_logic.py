@@ -1,4 +1,6 @@
 """CPU: host-side logic of the product (batcher, collators, LR schedule, FLOP model) against the oracle / fixtures."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -360,3 +362,26 @@ def test_conv_stack_pitches_cover_every_valid_window():
             assert P[i - 1] == ss[i] * P[i] and P[i] >= Ts[i] and P[i - 1] >= Ts[i - 1]
             assert ss[i] * (Ts[i] - 1) + ks[i] - 1 <= Ts[i - 1] - 1          # the last valid window ends inside the valid rows
         assert P[-1] - Ts[-1] <= 2                                         # (the padding is a row or two per clip, not a multiple)
+
+
+def test_roctx_phase_ranges_are_a_no_op_unless_enabled():
+    """slam_llm_amd/trace.py (tracing row): without SLAM_ROCTX the phase() context is a shared null context (no library
+    loaded); with SLAM_ROCTX=1 a child interpreter loads the roctx library of this ROCm image and pushes / pops nested ranges."""
+    import subprocess
+    import sys
+    from slam_llm_amd import trace
+    if not trace.ENABLED:
+        assert trace._lib is None and trace.phase("x") is trace.phase("y")
+        with trace.phase("llm_fwd"):
+            pass
+        trace.push("a"); trace.pop(); trace.mark("b")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from slam_llm_amd import trace\n"
+            "assert trace.ENABLED and trace._lib is not None\n"
+            "with trace.phase('outer'):\n"
+            "    with trace.phase('inner'):\n"
+            "        trace.mark('m')\n"
+            "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SLAM_ROCTX="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-400:]
