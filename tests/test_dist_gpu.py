@@ -3,7 +3,7 @@ data-parallel path of src/slam_llm/pipeline/finetune.py:181-184 + utils/train_ut
   * GradSync fast path: after the backward the flat gradient == mean of the two ranks' single-rank gradients,
   * parameters identical across ranks after 3 optimizer steps,
   * gradient accumulation (k = 2) == the reference's all-reduce-every-backward result,
-  * uneven shards (rank 1 runs dry first) end the epoch cleanly on both ranks,
+  * uneven shards (rank 1 runs dry first) end the epoch cleanly on both ranks -- and, under the Join policy, rank 1 shadows the remaining steps,
   * the module wrapped in torch.nn.parallel.DistributedDataParallel (autograd_params mode) gives the same numbers with
     torch.optim.AdamW(model.parameters()), and `.module` / state_dict keys are what checkpoint_handler.py:190-200 walks,
   * the `use_fp16` loop body (autocast + GradScaler, train_utils.py:128-150) around the DDP module == the un-scaled DDP run.
@@ -38,7 +38,7 @@ def _worker(rank, world, port, q):
         import torch.distributed as dist
         from oracle import slam_oracle as O
         from slam_llm_amd.model import SlamAdamW, SlamHipModel
-        from slam_llm_amd.train import GradSync, all_ranks_have_data, setup_distributed, train_step
+        from slam_llm_amd.train import GradSync, all_ranks_have_data, ranks_with_data, setup_distributed, train_step
         r, lr, w = setup_distributed("cuda")
         assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
         dev = torch.device("cuda:0")
@@ -106,6 +106,38 @@ def _worker(rank, world, port, q):
         dist.all_gather(both, flat)
         res["params_equal_across_ranks"] = bool(torch.equal(both[0], both[1]))
         res["params_moved"] = float((flat - SlamHipModel(dict(cfg), dev).load_weights(W).store.flat).abs().max())
+
+        # ---- 3b. the Join policy (round 6; reference: `with Join([model])`, utils/train_utils.py:91): rank 0 has 3 batches, rank 1 only 1;
+        # rank 1 shadows the other two steps (zero gradients through the same collectives, the same optimizer step): both ranks run 3
+        # iterations, the replicas stay bit-identical, and the result equals a single process stepping on (g0 + g1) / 2, g0 / 2, g0 / 2
+        mj = SlamHipModel(dict(cfg), dev).load_weights(W)
+        mj.train()
+        gj = GradSync(mj, bucket_bytes=64 * 1024).attach(mj)
+        oj = SlamAdamW(mj, lr=1e-3)
+        n_mine, it = (3 if rank == 0 else 1), 0
+        while ranks_with_data(it < n_mine, dev) > 0:
+            train_step(mj, batch_for(rank, it) if it < n_mine else None, oj, None, gj)
+            it += 1
+        res["join_iterations"] = it
+        flatj = mj.store.flat.clone()
+        both = [torch.empty_like(flatj) for _ in range(world)]
+        dist.all_gather(both, flatj)
+        res["join_params_equal_across_ranks"] = bool(torch.equal(both[0], both[1]))
+        ms = SlamHipModel(dict(cfg), dev).load_weights(W)       # the single-process statement of the same three updates
+        ms.train()
+        init_flat = ms.store.flat.clone()
+        os_ = SlamAdamW(ms, lr=1e-3)
+        for i in range(3):
+            g = local_grad(ms, [batch_for(0, i)])
+            if i == 0:
+                g = g + local_grad(ms, [batch_for(1, 0)])
+            ms.store.grad.copy_(g / 2)
+            ms.attach_grad_views()
+            os_.step()
+            os_.zero_grad()
+        # (compared as UPDATES: Adam's first steps move every element by ~lr whatever its gradient's size, so an element whose gradient is
+        # ~0 may take the other sign under another summation order of the all-reduce -- the direction of the whole update is the statistic)
+        res["join_vs_single_process"] = 1.0 - _cos(ms.store.flat - init_flat, flatj - init_flat)
 
         # ---- 4. the same through DistributedDataParallel (what the reference's pipeline does) ----------------------------
         m2 = SlamHipModel(dict(cfg), dev, autograd_params=True).load_weights(W)
@@ -213,6 +245,7 @@ def test_two_ranks_real_model_gradsync_and_ddp(dev):
         assert res["accum_cos"] >= 0.9999 and res["accum_maxdiff"] < 2e-2, (rank, res)
         assert res["steps_run"] == 3, (rank, res)
         assert res["params_equal_across_ranks"] and res["params_moved"] > 0, (rank, res)
+        assert res["join_iterations"] == 3 and res["join_params_equal_across_ranks"] and res["join_vs_single_process"] < 1e-3, (rank, res)
         assert res["ddp_has_reference_keys"], (rank, res)
         assert res["ddp_cos"] >= 0.9999 and res["ddp_maxdiff"] < 2e-2, (rank, res)
         assert res["ddp_params_equal_across_ranks"] and res["ddp_losses_finite"] and res["ddp_slamadamw_equal"], (rank, res)

@@ -193,3 +193,40 @@ def test_lora_side_stream_is_bit_identical(dev, graphed):
     if not graphed:
         assert torch.equal(runs[0][1], runs[1][1])
     assert torch.equal(runs[0][2], runs[1][2])
+
+
+@pytest.mark.timeout(600)
+def test_graphed_step_is_bit_identical_at_true_widths(dev):
+    """the capture at the shapes the bench runs (Whisper-large-v3 x 1 -> Llama-3-8B x 1 at true widths, 8 x 30 s clips, raw audio in, T = 380:
+    GPU log-mel, the persistent and the 4-wave GEMM kernels with their registered workspace, chunk-sized lm_head over the label rows, the
+    pruned last layer): 4 steps eager vs 1 eager + 3 replays, lora_dropout 0 -- bit-identical losses and parameters."""
+    from slam_llm_amd.model import SlamAdamW, SlamHipModel, make_config
+    from slam_llm_amd.train import GraphedTrainStep, train_step
+    cfg = make_config("whisper-large-v3", "llama-3-8b", enc_layers=1, llm_layers=1, lora_r=16, lora_alpha=32,
+                      lora_targets=("q_proj", "v_proj"), lora_dropout=0.0)
+    W = O.init_weights(cfg, seed=42)
+    B = 8
+    audio = O.synth_audio(B, 30.0, seed=1234)
+    ob = O.synth_batch(cfg, audio, prompt_len=16, answer_lens=(64,), seed=1236, left_pad=False, pad_to_30s=True)
+    gb = {k: v.to(dev) for k, v in ob.items() if k != "audio_mel"}
+    gb["audio"] = audio.to(dev)
+    runs = []
+    for graphed in (False, True):
+        model = SlamHipModel(dict(cfg), dev).load_weights(W)
+        model.train()
+        model.llm.label_rows_cap = B * 64
+        opt = SlamAdamW(model, lr=1e-3)
+        stepper = GraphedTrainStep(model, opt, None, label_rows_cap=B * 64, warmup=1) if graphed else None
+        losses = []
+        for _ in range(4):
+            b = {k: v.clone() for k, v in gb.items()}
+            loss, _ = stepper(b) if graphed else train_step(model, b, opt)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        if graphed:
+            assert stepper.replays == 3 and stepper.eager_steps == 1
+        runs.append((losses, model.store.flat.clone()))
+        del model, opt, stepper
+        torch.cuda.empty_cache()
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])

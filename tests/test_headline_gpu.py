@@ -136,8 +136,9 @@ def test_c3_full_depth_bf16_emulation_explains_the_q_proj_floor(dev):
         HIP path behaves like one more member of that family:
           (a) per tensor family (q/v x lora_A/lora_B, projector), HIP-vs-fp32 mean and max deviation <= 1.5x / 2x the larger of the
               two emulations' (HIP is no noisier than the reference arithmetic in bf16 formats);
-          (b) HIP-vs-emulation <= 2x emulation-vs-reordered-emulation, mean and max (the twins share their input and their first
-              roundings, HIP shares neither: measured 1.6x on q_proj.lora_A -- the sum of two independent deviations);
+          (b) HIP-vs-emulation <= 2.5x emulation-vs-reordered-emulation, mean and max (the twins share their input and their first
+              roundings, HIP shares neither: measured 1.6x on q_proj.lora_A -- the sum of two independent deviations; the factor leaves
+              room for another host's BLAS drawing closer twins);
           (c) the emulation reproduces at least half of HIP's worst q_proj deviation (the explanation accounts for the floor).
       * single sites (CPU run): without the dS rounding 7.2e-3, without the residual-stream rounding 5.0e-3, without the RMSNorm-output
         rounding 6.8e-3: no single site carries it, and a higher-precision dS operand (round 5's suspicion) buys NOTHING.
@@ -191,7 +192,7 @@ def test_c3_full_depth_bf16_emulation_explains_the_q_proj_floor(dev):
         assert hm <= 1.5 * em + FLOOR and hx <= 2.0 * ex + FLOOR, f"(a) {fam}: HIP-vs-fp32 {hm:.2e} / {hx:.2e} vs emulations {em:.2e} / {ex:.2e}"
         dm, dx = S["hip_emu"][fam]
         tm, tx = S["emu_re"][fam]
-        assert dm <= 2.0 * tm + FLOOR and dx <= 2.0 * tx + FLOOR, f"(b) {fam}: HIP-vs-emulated {dm:.2e} / {dx:.2e} vs emulated-vs-re-ordered {tm:.2e} / {tx:.2e}"
+        assert dm <= 2.5 * tm + FLOOR and dx <= 2.5 * tx + FLOOR, f"(b) {fam}: HIP-vs-emulated {dm:.2e} / {dx:.2e} vs emulated-vs-re-ordered {tm:.2e} / {tx:.2e}"
     worst_q_hip = max(S["hip_fp32"]["q_proj.lora_A"][1], S["hip_fp32"]["q_proj.lora_B"][1])
     worst_q_emu = max(S[k][f][1] for k in ("emu_fp32", "re_fp32") for f in ("q_proj.lora_A", "q_proj.lora_B"))
     assert worst_q_emu >= 0.5 * worst_q_hip, f"(c) the emulation's worst q_proj deviation {worst_q_emu:.2e} does not account for HIP's {worst_q_hip:.2e}"
@@ -499,3 +500,62 @@ def test_attn_heaviest_block_first_order_is_bit_identical_to_id_order(dev, B, T,
         call("slam_attn_set_fwd_qf", 51)
     for a, b_ in zip(*res):
         assert torch.isfinite(a.float()).all() and torch.equal(a, b_)
+
+
+@pytest.mark.timeout(2400)
+def test_headline_width_training_trajectory_tracks_oracle(dev):
+    """the LOOP at true widths ("3 optimizer steps track the reference losses"; so far pinned at fixture widths only): 3 steps of
+    AdamW + LambdaLR on Whisper-large-v3 x 1 -> Llama-3-8B x 1, B = 4 x 30 s clips, T = 380, two alternating batches, against the oracle's
+    `train_steps` (torch.optim.AdamW on fp32 masters, utils/train_utils.py:112-169 + pipeline/finetune.py:247-260): every loss within
+    3e-2, and the UPDATE each trainable tensor received over the three steps (p_after - p_before) agrees with the oracle's in direction
+    (cosine >= 0.965: Adam's sign-like first steps turn a gradient angle a into a / pi sign flips) -- the fused optimizer, the LoRA re-pack of (alpha / r) B and the derived transposes are in that path at d = 4096."""
+    from slam_llm_amd.model import SlamAdamW, SlamHipModel, make_config
+    from slam_llm_amd.train import lr_lambda, train_step
+    cfg = make_config("whisper-large-v3", "llama-3-8b", enc_layers=1, llm_layers=1, lora_r=16, lora_alpha=32,
+                      lora_targets=("q_proj", "v_proj"), lora_dropout=0.0)
+    W = O.init_weights(cfg, seed=42)
+    obs = []
+    for i in range(2):
+        audio = O.synth_audio(4, 30.0, seed=4321 + i)
+        obs.append(O.synth_batch(cfg, audio, prompt_len=16, answer_lens=(64,), seed=77 + i, left_pad=False, pad_to_30s=True))
+    seq = [obs[0], obs[1], obs[0]]
+    model = SlamHipModel(dict(cfg), dev).load_weights(W)
+    model.train()
+    before = {n: p.detach().float().cpu().clone() for n, p in model.store.params.items()}
+    opt = SlamAdamW(model, lr=1e-3, weight_decay=0.0)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: lr_lambda(s + 1, 2, 10))     # (s + 1: a non-zero lr from the first step on)
+    losses = []
+    for ob in seq:
+        loss, _ = train_step(model, {k: v.to(dev) for k, v in ob.items()}, opt, sched)
+        losses.append(float(loss))
+    after = {n: p.detach().float().cpu() for n, p in model.store.params.items()}
+    del model
+    torch.cuda.empty_cache()
+    torch.set_num_threads(min(64, os.cpu_count()))
+    Wt = {k: v.clone() for k, v in W.items()}
+    names = O.trainable_names(Wt)
+    params = [Wt[n].requires_grad_(True) for n in names]
+    ropt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.0)
+    rsched = torch.optim.lr_scheduler.LambdaLR(ropt, lr_lambda=lambda s: lr_lambda(s + 1, 2, 10))
+    ref_losses = []
+    for ob in seq:
+        with torch.no_grad():
+            enc = O.whisper_encoder(Wt, cfg, ob["audio_mel"].permute(0, 2, 1))
+        proj = O.projector_concat(Wt, enc, cfg["ds_rate"])
+        emb = O.embed_splice(Wt["llm.base_model.model.model.embed_tokens.weight"], ob["input_ids"].clone(), ob["modality_mask"].bool(), proj)
+        loss, _ = O.llama_forward(Wt, cfg, emb, ob["attention_mask"], ob["labels"])
+        loss.backward()
+        ropt.step(); rsched.step(); ropt.zero_grad()
+        ref_losses.append(float(loss.detach()))
+    for s, (a, b) in enumerate(zip(losses, ref_losses)):
+        assert abs(a - b) <= 3e-2, (s, losses, ref_losses)
+    worst = 1.0
+    for n in names:
+        du_hip, du_ref = (after[n] - before[n]).numpy(), (Wt[n].detach() - W[n]).numpy()
+        cs = G.cosine(du_ref, du_hip)
+        worst = min(worst, cs)
+        # Adam normalises every element's first steps to ~lr: the update is a SIGN-like field, and two gradients at an angle a disagree in
+        # sign on a fraction a / pi of the elements -- gradient cosines of 0.9999 .. 0.9996 (what the 1-layer geometry measures) give
+        # update cosines of 0.991 .. 0.982; the floor leaves the usual 2x
+        assert cs >= 0.965, f"update of {n}: cosine {cs}"
+    print(f"true-width trajectory: losses {losses} vs oracle {ref_losses}; worst update cosine {worst:.5f}")
