@@ -87,7 +87,8 @@ int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, vo
  * (slam_gemm_set_config(300) = auto plan, 302..316 = forced slices): measured on MI355X the hand-off costs what the idle CUs of the
  * last round would have saved (profiles/r03_gemm_splitk.md). */
 int slam_gemm_set_workspace(void* workspace, int64_t bytes);
-int slam_gemm_set_group_m(int group_m);   /* tuning knob: M-tiles per raster group of the 256x256 kernel (default 8) */
+int slam_gemm_set_group_m(int group_m);   /* tuning knob: M-tiles per raster group of the 256x256 kernels; 0 (default) = the per-shape rule, 1..64 forced */
+int slam_gemm_set_group_m_rule(int short_k_many_cols, int long_k_narrow, int wide_k4096, int other);   /* tools: the per-shape rule's four values (defaults 12, 4, 4, 8) */
 int slam_gemm_set_config(int cfg);   /* also: 100+v / 200+v = the 256x256 kernel of the auto rule for K > 2048 / <= 2048; 300 / 301 / 302..316 = split-K tail auto / off / forced slices; 400 / 401 = cycle stamps off / on (tools) */
 /* tools only (after slam_gemm_set_config(401): production launches never write the stamps): {shader cycles, 100 MHz ticks} at
  * entry and exit of workgroup 0 of the last pipelined-kernel launch (synchronise first); effective shader clock of the launch = d(cycles) / d(ticks) x 100 MHz -- how the DVFS cost of a variant is read */

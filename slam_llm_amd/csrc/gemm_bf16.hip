@@ -1161,13 +1161,34 @@ std::atomic<int> g_gemm_cfg{0};  // 0 = auto
 std::atomic<int> g_gemm_big{12};       // which 256x256 kernel the auto rule uses for K > 2048 (6 | 7 | 12): in the C3 step 12 -> 401.7 ms, 6 -> 408.3 ms
 std::atomic<int> g_gemm_big_shortk{7}; // ... and for K <= 2048
 std::atomic<int> g_gemm_small{1};      // the 128x128 kernel of the auto rule: 1 = two-stage loop, 11 = register-double-buffered pipeline
-std::atomic<int> g_gemm_group_m{8};
+std::atomic<int> g_gemm_group_m{0};    // 0 = per-shape rule (gemm_group_m_for), 1..64 = forced (tools)
 std::atomic<int> g_gemm_probe{0};      // 1: cfg 6 / 12 launch their PROBE instantiation (workgroup 0 stamps g_clk_probe; tools/gemm_epi_probe.py)
 
 }  // namespace
 
-extern "C" int slam_gemm_set_group_m(int group_m) {   // tuning knob (tools): raster group height of the pipelined kernel
-  SLAM_CHECK_ARG(group_m >= 1 && group_m <= 64, "slam_gemm_set_group_m: %d out of range [1,64]", group_m);
+// Raster group height (M-tiles per XCD-local group; a pure renumbering of tiles: results are bit-identical whatever it is).  Round 6
+// (tools/gemm_enc_raster.py on MI355X, profiles/r06_gemm_raster.md): 8 is at or within 0.5 % of the best for most products of the step, but three
+// shape classes have a better value by 2-2.6 %: short-K products with many column tiles (Whisper / HuBERT qkv, fc1: 12), narrow outputs behind a
+// long K (fc2: N = 1280, K = 5120: 4), and wide outputs with K <= 4096 (dX of down_proj, gate|up forward, lm_head: 4).
+std::atomic<int> g_gemm_gm_rule[4] = {{12}, {4}, {4}, {8}};     // the rule's four values (slam_gemm_set_group_m_rule: sweeps)
+static int gemm_group_m_for(int64_t M, int64_t N, int64_t K) {
+  const int forced = g_gemm_group_m;
+  if (forced > 0) return forced;
+  const int64_t tn = (N + 255) / 256;
+  if (K <= 2048 && tn >= 12) return g_gemm_gm_rule[0];
+  if (K >= 4096 && tn <= 6) return g_gemm_gm_rule[1];
+  if (K <= 4096 && tn >= 48) return g_gemm_gm_rule[2];
+  return g_gemm_gm_rule[3];
+}
+extern "C" int slam_gemm_set_group_m_rule(int short_k_many_cols, int long_k_narrow, int wide_k4096, int other) {   // tools: the four values of the rule
+  const int v[4] = {short_k_many_cols, long_k_narrow, wide_k4096, other};
+  for (int i = 0; i < 4; i++) SLAM_CHECK_ARG(v[i] >= 1 && v[i] <= 64, "slam_gemm_set_group_m_rule: value %d out of range [1,64]", v[i]);
+  for (int i = 0; i < 4; i++) g_gemm_gm_rule[i] = v[i];
+  return 0;
+}
+
+extern "C" int slam_gemm_set_group_m(int group_m) {   // tuning knob (tools): raster group height; 0 = the per-shape rule (default)
+  SLAM_CHECK_ARG(group_m >= 0 && group_m <= 64, "slam_gemm_set_group_m: %d out of range [0,64]", group_m);
   g_gemm_group_m = group_m;
   return 0;
 }
@@ -1195,7 +1216,8 @@ extern "C" int slam_gemm_set_workspace(void* workspace, int64_t bytes) {
 // every GEMM tuning knob back to the value it is DEFINED with above (slam_reset_tuning: one place for the defaults)
 void slam_gemm_reset_tuning_() {
   g_gemm_splitk = -1; g_gemm_sk2 = 1; g_gemm_splitk_rmax = 32; g_gemm_splitk_smax = 2; g_gemm_ts = 1;
-  g_gemm_cfg = 0; g_gemm_big = 12; g_gemm_big_shortk = 7; g_gemm_small = 1; g_gemm_group_m = 8; g_gemm_probe = 0;
+  g_gemm_cfg = 0; g_gemm_big = 12; g_gemm_big_shortk = 7; g_gemm_small = 1; g_gemm_group_m = 0; g_gemm_probe = 0;
+  g_gemm_gm_rule[0] = 12; g_gemm_gm_rule[1] = 4; g_gemm_gm_rule[2] = 4; g_gemm_gm_rule[3] = 8;
 }
 
 extern "C" int slam_gemm_set_config(int cfg) {
@@ -1254,7 +1276,7 @@ extern "C" int slam_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int6
   p.act = act; p.alpha = alpha; p.out_f32 = (out_dtype == SLAM_F32); p.accumulate = accumulate;
   p.C2 = nullptr; p.ldc2 = 0;
   int want_two = 0;
-  p.group_m = g_gemm_group_m;
+  p.group_m = gemm_group_m_for(M, N, K);
   hipStream_t s = (hipStream_t)stream;
   int cfg = g_gemm_cfg;
   if ((cfg == 0 || cfg == 3) && N <= 64) {
@@ -1362,6 +1384,6 @@ extern "C" int slam_gemm_swiglu_bf16_nt(const void* A, int64_t lda, const void* 
   p.bias = nullptr; p.res = nullptr; p.ldr = 0; p.res_mod = 0;
   p.act = 4; p.alpha = 1.0f; p.out_f32 = 0; p.accumulate = 0;
   p.C2 = H; p.ldc2 = ldh;
-  p.group_m = g_gemm_group_m;
+  p.group_m = gemm_group_m_for(M, N, K);
   return launch_gemm_w4<256, 256, false>(p, (hipStream_t)stream);
 }

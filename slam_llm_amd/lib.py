@@ -38,6 +38,7 @@ SIGNATURES = {
     "slam_gemm_bf16_nt": [P, I64, P, I64, P, I64, I64, I64, I64, P, P, I64, I64, I32, F, I32, I32, P],
     "slam_gemm_set_config": [I32],
     "slam_gemm_set_group_m": [I32],
+    "slam_gemm_set_group_m_rule": [I32, I32, I32, I32],
     "slam_gemm_set_workspace": [P, I64],
     "slam_gemm_debug_clock": [P],
     "slam_attn_set_fwd_qf": [I32],

@@ -224,6 +224,10 @@ if not ATTN_QS:
     call("slam_attn_set_fwd_qf", 60)
 if not ATTN_HEAVY_FIRST:
     call("slam_attn_set_fwd_qf", 50)
+if os.environ.get("SLAM_GEMM_GROUP_M"):
+    call("slam_gemm_set_group_m", int(os.environ["SLAM_GEMM_GROUP_M"]))
+if os.environ.get("SLAM_GEMM_GROUP_M_RULE"):      # sweeps: "12,4,4,8" = the rule's four values (short-K many columns, long-K narrow, wide K <= 4096, other)
+    call("slam_gemm_set_group_m_rule", *[int(x) for x in os.environ["SLAM_GEMM_GROUP_M_RULE"].split(",")])
 _ENV_DEFAULTS = dict(_GEMM_BIG, sk2=SK2_AUTO, ts=TS_AUTO, splitk=os.environ.get("SLAM_GEMM_SPLITK", "off"))
 
 
@@ -245,7 +249,10 @@ def reset_tuning():
     gemm_set_config(320 + 4)     # split-K tail auto plan: last round <= 32 tiles ...
     gemm_set_config(340 + 2)     # ... into at most 2 slices
     gemm_set_config(400)         # cycle stamps off
-    call("slam_gemm_set_group_m", 8)
+    if os.environ.get("SLAM_GEMM_GROUP_M"):       # A/B: SLAM_GEMM_GROUP_M=8 restores the one-size raster of rounds 1-5 (0 / unset = per-shape rule)
+        call("slam_gemm_set_group_m", int(os.environ["SLAM_GEMM_GROUP_M"]))
+    if os.environ.get("SLAM_GEMM_GROUP_M_RULE"):
+        call("slam_gemm_set_group_m_rule", *[int(x) for x in os.environ["SLAM_GEMM_GROUP_M_RULE"].split(",")])
     call("slam_attn_set_bwd_variant", 0)
     # auto fragments, DMA tiles, XCD-aware numbering, mask-free instantiation, transposing reads, heaviest block first, pre-scaled Q in LSE-less launches
     for knob in (0, 11, 21, 31, 41, 51 if ATTN_HEAVY_FIRST else 50, 61 if ATTN_QS else 60):
