@@ -71,14 +71,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmParams p) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     bid = base + (bid >> 3);
   }
-  constexpr int GM = 8;
-  const int per_group = GM * p.tiles_n;
-  const int group = bid / per_group;
-  const int first_m = group * GM;
-  const int gsz = min(GM, p.tiles_m - first_m);
-  const int within = bid - group * per_group;
-  const int tm = first_m + within % gsz;
-  const int tn = within / gsz;
+  int tm, tn;
+  gemm_tile_of(p, bid, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- per-lane DMA source pointers (row clamp handles the M/N edges) ----
@@ -193,14 +187,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     bid = base + (bid >> 3);
   }
-  const int GM = p.group_m;
-  const int per_group = GM * p.tiles_n;
-  const int group = bid / per_group;
-  const int first_m = group * GM;
-  const int gsz = min(GM, p.tiles_m - first_m);
-  const int within = bid - group * per_group;
-  const int tm = first_m + within % gsz;
-  const int tn = within / gsz;
+  int tm, tn;
+  gemm_tile_of(p, bid, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int srow = lane >> 3;
@@ -365,14 +353,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_persist2_kernel(GemmParam
     const int xcd = vbid & 7, q = nwg >> 3, r = nwg & 7;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int bid = base + (vbid >> 3);
-    const int GM = p.group_m;
-    const int per_group = GM * p.tiles_n;
-    const int group = bid / per_group;
-    const int first_m = group * GM;
-    const int gsz = min(GM, p.tiles_m - first_m);
-    const int within = bid - group * per_group;
-    m0 = (first_m + within % gsz) * BM;
-    n0 = (within / gsz) * BN;
+    int tm, tn;
+    gemm_tile_of(p, bid, tm, tn);
+    m0 = tm * BM;
+    n0 = tn * BN;
   };
   auto stage = [&](int mo, int no, int kt, int s) {
     char* sa = smem + s * STAGE;
@@ -535,14 +519,8 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     bid = base + idx;
   }
-  const int GM = p.group_m;
-  const int per_group = GM * p.tiles_n;
-  const int group = bid / per_group;
-  const int first_m = group * GM;
-  const int gsz = min(GM, p.tiles_m - first_m);
-  const int within = bid - group * per_group;
-  const int tm = first_m + within % gsz;
-  const int tn = within / gsz;
+  int tm, tn;
+  gemm_tile_of(p, bid, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   if (SK && sk_tile >= 0 && p.M - m0 <= 16) {   // a thin tile among the tail tiles is not split: slice 0 computes all of it below
     if (sk_split > 0) return;
@@ -847,13 +825,9 @@ __global__ __launch_bounds__(256) void gemm_sk_reduce_kernel(GemmParams p) {
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     bid = base + idx;
   }
-  const int GM = p.group_m;
-  const int per_group = GM * p.tiles_n;
-  const int group = bid / per_group;
-  const int first_m = group * GM;
-  const int gsz = min(GM, p.tiles_m - first_m);
-  const int within = bid - group * per_group;
-  const int m0 = (first_m + within % gsz) * BM, n0 = (within / gsz) * BN;
+  int tm_, tn_;
+  gemm_tile_of(p, bid, tm_, tn_);
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
   if (p.M - m0 <= 16) return;   // thin tiles are never sliced: slice 0 computed and stored all of it
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, frow = lane & 15, fg = lane >> 4;

@@ -29,6 +29,21 @@ struct GemmParams {
   unsigned* sk_cnt;    // [sk_R] arrival counters, zero between launches
 };
 
+// position in the tile order -> (tile row, tile column): groups of group_m M-tiles x all N-tiles, M fastest; scalar arithmetic (the position is
+// workgroup-uniform).  (Round 6 also tried column BANDS in this order -- every XCD owning ~1 / xc of the columns and ~xc / 8 of the rows, which
+// halves the launch's COMPULSORY fabric traffic xc |A| + (8 / xc) |B| for the wide products -- and measured it 0.65 % SLOWER in the C3 step:
+// with one band all XCDs sweep the same B columns at the same time, and that alignment is worth more than the byte count; profiles/r06_gemm_raster.md.)
+__device__ __forceinline__ void gemm_tile_of(const GemmParams& p, int bid, int& tm, int& tn) {
+  const int GM = p.group_m;
+  const int per_group = GM * p.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GM;
+  const int gsz = min(GM, p.tiles_m - first_m);
+  const int within = bid - group * per_group;
+  tm = first_m + within % gsz;
+  tn = within / gsz;
+}
+
 constexpr int BK = 64;           // bf16 elements per K-tile
 constexpr int ROWB = BK * 2;     // 128 bytes per LDS row
 

@@ -49,6 +49,35 @@ def test_gemm_plain(dev, cfg, M, N, K):
     assert_close(c, ref, atol=2e-2 * math.sqrt(K / 64), rtol=1e-2, what=f"gemm cfg{cfg} {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("cfg", [12, 7, 6, 1])
+@pytest.mark.parametrize("M,N,K", [(11780, 4096, 256), (1300, 7 * 256 + 40, 128), (5 * 256, 5 * 256, 192), (300, 33 * 256, 64)])
+def test_gemm_raster_group_height_is_a_pure_renumbering(dev, cfg, M, N, K):
+    """round 6: the raster group height is chosen per shape class (slam_gemm_set_group_m(0) = the rule of csrc/gemm_bf16.hip:gemm_group_m_for;
+    slam_gemm_set_group_m_rule re-parametrises it).  It only changes WHICH workgroup computes a tile: for group heights 1 / 4 / 8 / 12 / 64 and
+    the rule itself every output element must be written exactly once (NaN-prefilled output) and be bit-identical to the group-8 order of
+    rounds 1-5, on tile grids of 47 x 16, 6 x 8, 5 x 5 and 2 x 33."""
+    ops = _ops()
+    from slam_llm_amd.lib import call
+    a, b = rnd((M, K), dev, seed=11), rnd((N, K), dev, seed=12)
+    ops.gemm_set_config(cfg)
+    try:
+        call("slam_gemm_set_group_m", 8)
+        ref = ops.gemm_nt(a, b)
+        assert_close(ref, a.float() @ b.float().T, atol=2e-2 * math.sqrt(K / 64), rtol=1e-2, what="reference order")
+        for gm in (0, 1, 4, 12, 64):
+            call("slam_gemm_set_group_m", gm)
+            out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+            ops.gemm_nt(a, b, out=out)
+            assert torch.equal(out, ref), f"group_m {gm}: differs from the reference order"
+        call("slam_gemm_set_group_m", 0)
+        call("slam_gemm_set_group_m_rule", 3, 5, 7, 2)
+        out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        ops.gemm_nt(a, b, out=out)
+        assert torch.equal(out, ref)
+    finally:
+        ops.reset_tuning()
+
+
 @pytest.mark.parametrize("M,N,K", [(700, 1280, 1280), (1500, 520, 1280), (260, 3840, 128), (3000, 5120, 1280)])
 def test_gemm_persistent_descriptor_dma_on_strided_views(dev, M, N, K):
     """the auto rule sends K <= 2048 products (the Whisper encoder) to the persistent kernel, whose LDS-DMA uses buffer
