@@ -66,11 +66,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(GemmParams p) {
   // ---- XCD-aware tile remap (bijective for any grid size) ----
   const int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    bid = base + (bid >> 3);
-  }
+  bid = gemm_order_pos(p, nwg, bid & 7, bid >> 3);
   int tm, tn;
   gemm_tile_of(p, bid, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -182,11 +178,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_pipe_kernel(GemmParams p)
 
   const int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    bid = base + (bid >> 3);
-  }
+  bid = gemm_order_pos(p, nwg, bid & 7, bid >> 3);
   int tm, tn;
   gemm_tile_of(p, bid, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -350,9 +342,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_persist2_kernel(GemmParam
   const unsigned voff_b = (unsigned)(wave * 8 + srow) * ldb2 + (unsigned)schunk * 16u;
 
   auto tile_origin = [&](int vbid, int& m0, int& n0) {  // same XCD-aware bijection as the one-tile kernels
-    const int xcd = vbid & 7, q = nwg >> 3, r = nwg & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const int bid = base + (vbid >> 3);
+    const int bid = gemm_order_pos(p, nwg, vbid & 7, vbid >> 3);
     int tm, tn;
     gemm_tile_of(p, bid, tm, tn);
     m0 = tm * BM;
@@ -516,8 +506,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(GemmParams p, unsigned 
       xcd = sk_tile & 7;                // tail tile t is entry sk_main / 8 + t / 8 of XCD (t % 8)'s run
       idx = (p.sk_main >> 3) + (sk_tile >> 3);
     }
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    bid = base + idx;
+    bid = gemm_order_pos(p, nwg, xcd, idx);
   }
   int tm, tn;
   gemm_tile_of(p, bid, tm, tn);
@@ -820,10 +809,8 @@ __global__ __launch_bounds__(256) void gemm_sk_reduce_kernel(GemmParams p) {
   const int nwg = p.tiles_m * p.tiles_n;
   int bid;
   {   // tail tile t -> position in the tile order: entry sk_main / 8 + t / 8 of XCD (t % 8)'s run (as in gemm_nt_w4_kernel)
-    const int q = nwg >> 3, r = nwg & 7;
     const int xcd = t & 7, idx = (p.sk_main >> 3) + (t >> 3);
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    bid = base + idx;
+    bid = gemm_order_pos(p, nwg, xcd, idx);
   }
   int tm_, tn_;
   gemm_tile_of(p, bid, tm_, tn_);

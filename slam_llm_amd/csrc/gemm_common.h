@@ -29,6 +29,16 @@ struct GemmParams {
   unsigned* sk_cnt;    // [sk_R] arrival counters, zero between launches
 };
 
+// (XCD, entry of that XCD) -> position in the tile order.  The hardware deals workgroups to the 8 XCDs round-robin, so XCD x receives entries
+// 0 .. q (- 1) with q = nwg / 8 (the first nwg % 8 XCDs one more); any bijection of those pairs onto [0, nwg) is a valid order.  Shipped: every XCD
+// owns ONE contiguous run.  (Round 6 measured the block-cyclic alternatives in the C3 step -- XCD x owning blocks x, x + 8, ... of one raster group /
+// 256 / 32 / 1 positions: +0.6 % / +0.25 % / +1.2 % / +5.1 % step time; the per-XCD L2 locality of a long contiguous run is what pays.  profiles/r06_gemm_raster.md)
+__device__ __forceinline__ int gemm_order_pos(const GemmParams& p, int nwg, int xcd, int idx) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
 // position in the tile order -> (tile row, tile column): groups of group_m M-tiles x all N-tiles, M fastest; scalar arithmetic (the position is
 // workgroup-uniform).  (Round 6 also tried column BANDS in this order -- every XCD owning ~1 / xc of the columns and ~xc / 8 of the rows, which
 // halves the launch's COMPULSORY fabric traffic xc |A| + (8 / xc) |B| for the wide products -- and measured it 0.65 % SLOWER in the C3 step:

@@ -74,6 +74,7 @@ def test_gemm_raster_group_height_is_a_pure_renumbering(dev, cfg, M, N, K):
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         ops.gemm_nt(a, b, out=out)
         assert torch.equal(out, ref)
+
     finally:
         ops.reset_tuning()
 
