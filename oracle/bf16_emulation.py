@@ -71,18 +71,6 @@ class _RndF(torch.autograd.Function):
         return g
 
 
-class _RndB(torch.autograd.Function):
-    """identity forward, bf16 rounding of the gradient"""
-
-    @staticmethod
-    def forward(ctx, x):
-        return x.clone()
-
-    @staticmethod
-    def backward(ctx, g):
-        return rb(g)
-
-
 class _Emu:
     def __init__(self, sites, reorder):
         self.sites, self.reorder = frozenset(sites), reorder
@@ -95,9 +83,6 @@ class _Emu:
 
     def rf(self, s, t):
         return _RndF.apply(t) if s in self.sites else t
-
-    def rbk(self, s, t):
-        return _RndB.apply(t) if s in self.sites else t
 
     def mm(self, a, b):
         """a @ b; under `reorder` the same fp32 products summed in another order (the contraction cut in two halves that are added

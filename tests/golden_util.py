@@ -74,16 +74,6 @@ def floor_check(cs, floor, what=""):
     assert cs >= floor, f"{what}: cosine {cs} below the floor {floor}"
 
 
-# "Expected" deviations (1 - cosine) behind the relaxed floors: the value measured on MI355X when the floor was set.  floor_check()
-# raises a WARNING (not a failure) when a measured deviation leaves [0.5, 1.5] x its expected value: a drift alarm that fires long
-# before the 2x-wide floor does.  Keys: substrings of the `what` argument.
-EXPECTED = {}
-
-
-def expect(key, deviation):
-    EXPECTED[key] = float(deviation)
-
-
 def drift_check(what, measured, expected, lo=0.5, hi=1.5):
     """warn (never fail) when `measured` leaves [lo, hi] x `expected`; returns True when inside"""
     import warnings
