@@ -1575,24 +1575,25 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_tr_kernel(AttnParams p) {
     }
     const frag_t pb = pack_frag(pm[0], pm[1]);
     const frag_t dsb = pack_frag(ds[0], ds[1]);
-    // dV / dK products, operands AH fragments ahead (wait for fragment df, then request df + AH, then its two products)
+    // dV / dK products, operands AH fragments ahead (wait for fragment df, then request df + AH, then its two products).  The fragments are
+    // requested in fragment ORDER (the LDS returns in order and the waits below count on it): those of the top-up first (KD < AH: the first
+    // products prefetched only KD of them; round 6 -- until then the top-up of fragment PRE was requested BEHIND fragment AH and waited for with a
+    // count that did not cover it, correct only because hipcc happened to sink its two MFMAs below the next fragment's full wait)
     constexpr int PRE = KD < AH ? KD : AH;      // fragments requested above
+    static_for<PRE, AH>([&](auto df) {
+      bd[df].lo = lds_read_tr<SUB>(aT[df]);
+      bd[df].hi = lds_read_tr<SUB + 4 * ROWB>(aT[df]);
+      bq[df].lo = lds_read_tr<0>(aT[df]);
+      bq[df].hi = lds_read_tr<4 * ROWB>(aT[df]);
+    });
     static_for<0, DF>([&](auto df) {
-      if constexpr (df >= PRE && df < AH) {     // (KD < AH: top up to AH fragments in flight)
-        bd[df].lo = lds_read_tr<SUB>(aT[df]);
-        bd[df].hi = lds_read_tr<SUB + 4 * ROWB>(aT[df]);
-        bq[df].lo = lds_read_tr<0>(aT[df]);
-        bq[df].hi = lds_read_tr<4 * ROWB>(aT[df]);
-      }
-      constexpr int inflight = (df < PRE ? PRE : (df < AH ? df + 1 : (DF - df < AH ? DF - df : AH)));   // fragments requested and not yet waited for, incl. df
+      constexpr int inflight = (DF - df < AH ? DF - df : AH);   // fragments df .. df + inflight - 1 are requested and not yet waited for
       lds_wait<4 * (inflight - 1)>(bd[df], bq[df]);
-      if constexpr (df + AH < DF && df + AH >= PRE) {
-        if constexpr (df + AH >= AH) {
-          bd[df + AH].lo = lds_read_tr<SUB>(aT[df + AH]);
-          bd[df + AH].hi = lds_read_tr<SUB + 4 * ROWB>(aT[df + AH]);
-          bq[df + AH].lo = lds_read_tr<0>(aT[df + AH]);
-          bq[df + AH].hi = lds_read_tr<4 * ROWB>(aT[df + AH]);
-        }
+      if constexpr (df + AH < DF) {
+        bd[df + AH].lo = lds_read_tr<SUB>(aT[df + AH]);
+        bd[df + AH].hi = lds_read_tr<SUB + 4 * ROWB>(aT[df + AH]);
+        bq[df + AH].lo = lds_read_tr<0>(aT[df + AH]);
+        bq[df + AH].hi = lds_read_tr<4 * ROWB>(aT[df + AH]);
       }
       dv[df] = mfma16(tr_join(bd[df]), pb, dv[df]);
       dk[df] = mfma16(tr_join(bq[df]), dsb, dk[df]);
