@@ -22,6 +22,10 @@ Weak scaling: per-GPU work is fixed as N grows; no data-path collective except t
 import argparse
 import json
 import os
+# HIP runtime configuration of the product (INTEGRATION.md "Runtime environment"): kernel arguments written straight into device memory instead of a host-visible
+# buffer the command processor reads over the bus.  Measured in-step on MI355X, three interleaved rounds (profiles/r06_runtime_env.md): C4 48.75 -> 46.44 ms, C1 13.02 -> 12.42,
+# C2 86.34 -> 84.96, C3 350.4 -> 348.2.  Set before the HIP runtime is loaded (i.e. before `import torch`); an exported value wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 import socket
 import statistics
 import sys
@@ -486,6 +490,7 @@ def main():
                   f"audio-seconds/sec/node ({wl['title']}: not the headline workload)",
         "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "runtime_env": {k: os.environ.get(k) for k in ("HIP_FORCE_DEV_KERNARG",)},
         "dtype": "bf16", "data": "synthetic (seeded N(0,0.1^2) audio, random token ids, random-init weights at true dims); lora_dropout 0.05 is live with "
                                   "counter-based masks, one per fused projection group: statistically, not bitwise, the reference's torch-RNG dropout "
                                   "(parity tests run at dropout 0)",
