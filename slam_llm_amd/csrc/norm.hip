@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int ROWS_PER_BLOCK = 4;
+constexpr int LN_NARROW_MIN_ROWS = 4096;   // LayerNorm: batches of at least this many rows of d <= 1536 take the two-rows-per-wave kernel
 template <bool CACHE> struct RowUnroll { static constexpr int N = CACHE ? 8 : 1; };
 
 // CACHE: the row (d <= 4096 -> at most 8 16-byte chunks per lane) stays in registers between the passes instead of being
@@ -77,6 +78,89 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
       o[e] = f2bf(t);
     }
     *reinterpret_cast<u16x8_t*>(yr + c * 8) = o;
+  }
+}
+
+// Narrow rows (d <= 1536: Whisper's 1280; at most NCH = 3 16-byte chunks per lane): RPW rows per wave, all their chunks requested before the first reduction.
+// One wave per 2.5 KB row keeps too few bytes in flight per CU (4.7 TB/s on 46500 x 1280); per row the same lane -> chunk map and the same order of
+// additions as layernorm_kernel: bit-identical results.
+template <int NCH, int RPW>
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
+                                                               bf16_t* __restrict__ y, int64_t ldy, int M, int d, float eps, int act,
+                                                               float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= M) return;
+  const int nch = d >> 3;
+  u16x8_t xc[RPW][NCH];
+#pragma unroll
+  for (int r = 0; r < RPW; r++) {
+    const bf16_t* xr = x + (int64_t)min(row0 + r, M - 1) * ldx;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      const int c = lane + i * 64;
+      if (c < nch) xc[r][i] = *reinterpret_cast<const u16x8_t*>(xr + c * 8);
+    }
+  }
+  float mean[RPW], rstd[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; r++) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      if (lane + i * 64 < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) s += bf2f(xc[r][i][e]);
+      }
+    }
+    mean[r] = wave_sum(s) / (float)d;
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; r++) {
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      if (lane + i * 64 < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float t = bf2f(xc[r][i][e]) - mean[r];
+          q += t * t;
+        }
+      }
+    }
+    rstd[r] = rsqrtf(wave_sum(q) / (float)d + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; i++) {
+    const int c = lane + i * 64;
+    if (c >= nch) continue;
+    const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + c * 8);
+    const float4 b1 = *reinterpret_cast<const float4*>(b + c * 8 + 4);
+    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int r = 0; r < RPW; r++) {
+      if (row0 + r >= M) continue;
+      u16x8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float t = (bf2f(xc[r][i][e]) - mean[r]) * rstd[r] * ww[e] + bb[e];
+        if (act == 1) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
+        o[e] = f2bf(t);
+      }
+      *reinterpret_cast<u16x8_t*>(y + (int64_t)(row0 + r) * ldy + c * 8) = o;
+    }
+  }
+  if (lane == 0 && mean_out) {
+#pragma unroll
+    for (int r = 0; r < RPW; r++) {
+      if (row0 + r < M) {
+        mean_out[row0 + r] = mean[r];
+        rstd_out[row0 + r] = rstd[r];
+      }
+    }
   }
 }
 
@@ -329,7 +413,12 @@ extern "C" int slam_layernorm_fwd(const void* x, int64_t ldx, const float* weigh
   SLAM_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0, "slam_layernorm_fwd: bad shape M=%ld d=%ld (d%%8 must be 0)", (long)M, (long)d);
   SLAM_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= d && ldy >= d, "slam_layernorm_fwd: bad leading dims");
   const unsigned grid = (unsigned)cdiv64(M, ROWS_PER_BLOCK);
-  if (d <= 4096)
+  // narrow rows of a large batch: two rows per wave (round 6: 46500 x 1280 in the C3 step 50.2 -> 44.6 us per launch under rocprofv3, 4.74 -> 5.34 TB/s; four rows per
+  // wave: no better than one; bit-identical to the one-row kernel, tests/test_ops_gpu.py::test_layernorm_two_rows_per_wave_is_bit_identical)
+  if (d <= 1536 && M >= LN_NARROW_MIN_ROWS)
+    hipLaunchKernelGGL((layernorm_narrow_kernel<3, 2>), dim3((unsigned)cdiv64(M, ROWS_PER_BLOCK * 2)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       ldx, weight, bias, (bf16_t*)y, ldy, (int)M, (int)d, eps, act, mean_out, rstd_out);
+  else if (d <= 4096)
     hipLaunchKernelGGL(layernorm_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                        ldx, weight, bias, (bf16_t*)y, ldy, (int)M, (int)d, eps, act, mean_out, rstd_out);
   else

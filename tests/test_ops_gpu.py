@@ -578,6 +578,28 @@ def test_layernorm(dev, M, d):
     assert_close(y, ref, atol=1e-2, rtol=1e-2, what="layernorm")
 
 
+@pytest.mark.parametrize("M,d,gelu", [(4101, 1280, False), (4099, 512, True), (8191, 1024, False)])
+def test_layernorm_two_rows_per_wave_is_bit_identical(dev, M, d, gelu):
+    """round 6: batches of >= 4096 rows of d <= 1536 (the Whisper / HuBERT / WavLM encoders) run the two-rows-per-wave kernel; the same rows through the one-row
+    kernel (in pieces of < 4096 rows) give the same bits for y, mean and rstd -- odd row counts and a strided input included -- and both meet torch"""
+    ops = _ops()
+    xs = rnd((M, d + 8), dev, seed=11, std=2.0)
+    x = xs[:, :d]                                    # (row pitch d + 8: not contiguous)
+    w, b = rnd((d,), dev, seed=12, dtype=torch.float32), rnd((d,), dev, seed=13, dtype=torch.float32)
+    y = torch.full((M, d), float("nan"), dtype=torch.bfloat16, device=dev)
+    y, mean, rstd = ops.layernorm(x, w, b, 1e-5, out=y, gelu=gelu, stats=True)
+    ys, ms, rs = [], [], []
+    for r0 in range(0, M, 3000):
+        yy, mm, rr = ops.layernorm(x[r0:r0 + 3000], w, b, 1e-5, gelu=gelu, stats=True)
+        ys.append(yy), ms.append(mm), rs.append(rr)
+    assert torch.equal(y.view(torch.int16), torch.cat(ys).view(torch.int16))
+    assert torch.equal(mean, torch.cat(ms)) and torch.equal(rstd, torch.cat(rs))
+    ref = F.layer_norm(x.float(), (d,), w, b, 1e-5)
+    if gelu:
+        ref = F.gelu(ref)
+    assert_close(y, ref, atol=1e-2, rtol=1e-2, what="layernorm (two rows per wave)")
+
+
 @pytest.mark.parametrize("M,d", [(37, 128), (300, 4096), (16, 4096)])
 def test_rmsnorm_fwd_bwd(dev, M, d):
     ops = _ops()
